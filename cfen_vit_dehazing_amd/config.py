@@ -1,0 +1,123 @@
+"""Network geometry of the CFEN-ViT v3 generator, derived from the reference's `opt` flags.
+
+Reference: models/networks_iid_hlgvit_crs_gd4_cfs_v3.py:104-388 (`dec_ipt.__init__`) reads
+n_feats, hidden_dim_ratio, patch_size, patch_dim, num_heads, loadSize (options/base_options.py:16,96,
+104,110,191-193).  Everything the kernels need (window size, token counts, embedding dims, head
+counts, hidden dims per level) is computed once here so host code and tests agree.
+"""
+from dataclasses import dataclass
+from types import SimpleNamespace
+
+BRANCHES = ("r", "s", "d")
+
+
+@dataclass(frozen=True)
+class VitGeom:
+    """One LViT/GViT instance (reference v3:1062-1135 / 1197-1270)."""
+    name: str
+    kind: str          # "lvit" | "gvit"
+    level: int         # 1..3
+    channels: int      # C of the feature map it runs on
+    patch: int         # 2 (LViT) or 4 (GViT, after 4x avg-pool)
+    seq: int           # tokens per window / per pooled image
+    dim: int           # embedding dim D = C * patch^2
+    heads: int
+    hidden: int        # FFN / mlp_head hidden width
+
+
+@dataclass(frozen=True)
+class NetConfig:
+    n_feats: int = 24
+    hidden_dim_ratio: int = 4
+    patch_size: int = 32      # LViT window edge in feature-map pixels (opt.patch_size)
+    patch_dim: int = 2
+    num_heads: int = 4
+    load_size: int = 256      # edge of the half-resolution feature map xf (opt.loadSize)
+    n_colors: int = 3
+
+    @property
+    def image_size(self):
+        return 2 * self.load_size
+
+    def level_channels(self, level):
+        return self.n_feats << (level - 1)
+
+    def level_size(self, level):
+        return self.load_size >> (level - 1)
+
+    def validate(self):
+        # the reference's nested Crop2x2 (v3:403-428, 493-500, 526-529) yields windows of
+        # loadSize/8 at every level; LViT.img_dim == opt.patch_size must match (v3:1186 fold).
+        if self.load_size != 8 * self.patch_size:
+            raise ValueError("loadSize (%d) must equal 8*patch_size (%d): the reference's fixed "
+                             "crop nesting requires it" % (self.load_size, 8 * self.patch_size))
+        if self.patch_dim != 2:
+            raise ValueError("only patch_dim=2 is supported (reference default)")
+        if self.n_feats % 8 != 0:
+            raise ValueError("n_feats must be a multiple of 8")
+        if (self.load_size // 4) % 16 != 0 and self.load_size // 16 < 1:
+            raise ValueError("loadSize too small")
+
+    def vit_instances(self):
+        """All 24 transformer instances in reference construction order (v3:136-246)."""
+        out = []
+        p = self.patch_dim
+        seq_l = (self.patch_size // p) ** 2
+
+        def lv(name, level):
+            c = self.level_channels(level)
+            d = c * p * p
+            return VitGeom(name, "lvit", level, c, p, seq_l, d, self.num_heads << (level - 1),
+                           d * self.hidden_dim_ratio)
+
+        def gv(name, level):
+            c = self.level_channels(level)
+            gp = 2 * p
+            d = c * gp * gp
+            img = self.level_size(level) // gp          # v3:196-246 img_dim
+            seq = (img // gp) ** 2
+            hidden = d * self.hidden_dim_ratio
+            if name == "globalvit_encoder_02":
+                # v3:200 uses patch_dim (not patch_dim*2) in hidden_dim: reference quirk kept.
+                hidden = c * p * p * self.hidden_dim_ratio
+            return VitGeom(name, "gvit", level, c, gp, seq, d, self.num_heads << (level - 1), hidden)
+
+        out += [lv("localvit_encoder_0%d" % l, l) for l in (1, 2, 3)]
+        for b in BRANCHES:
+            out += [lv("localvit_decoder_0%d%s" % (l, b), l) for l in (3, 2, 1)]
+        out += [gv("globalvit_encoder_0%d" % l, l) for l in (1, 2, 3)]
+        for b in BRANCHES:
+            out += [gv("globalvit_decoder_0%d%s" % (l, b), l) for l in (3, 2, 1)]
+        return out
+
+    def vit(self, name):
+        for g in self.vit_instances():
+            if g.name == name:
+                return g
+        raise KeyError(name)
+
+
+def config_from_opt(opt):
+    """Build a NetConfig from a reference-style `opt` namespace (options/base_options.py)."""
+    for flag in ("no_mlp", "pos_every", "no_pos", "no_norm"):
+        if getattr(opt, flag, False):
+            raise NotImplementedError("--%s is not supported by the HIP path (reference default is off)" % flag)
+    if getattr(opt, "num_layers", 1) != 1:
+        raise NotImplementedError("num_layers != 1 is not supported")
+    if getattr(opt, "dropout_rate", 0) != 0:
+        raise NotImplementedError("dropout_rate != 0 is not supported (inference path)")
+    cfg = NetConfig(n_feats=int(opt.n_feats), hidden_dim_ratio=int(opt.hidden_dim_ratio),
+                    patch_size=int(opt.patch_size), patch_dim=int(getattr(opt, "patch_dim", 2)),
+                    num_heads=int(getattr(opt, "num_heads", 4)), load_size=int(opt.loadSize),
+                    n_colors=int(getattr(opt, "n_colors", 3)))
+    cfg.validate()
+    return cfg
+
+
+def default_opt(**overrides):
+    """The subset of reference flags the hot path reads, with BASELINE.json's values."""
+    o = dict(n_feats=24, hidden_dim_ratio=4, patch_size=32, patch_dim=2, num_heads=4, num_layers=1,
+             num_queries=1, dropout_rate=0, no_mlp=False, pos_every=False, no_pos=False, no_norm=False,
+             loadSize=256, rgb_range=255, n_colors=3, init_type="kaiming", gpu_ids=[])
+    o.update(overrides)
+    return SimpleNamespace(**o)

@@ -1,0 +1,134 @@
+// Shared device helpers for the CFEN-ViT gfx950 kernels.
+//
+// Every contraction in this library (token GEMMs, attention, implicit-GEMM convolutions, the
+// deformable-conv GEMM) is built on ONE wave-level primitive, `Mma<T>`: a 16x16 output tile
+// accumulated in fp32 from 16-byte per-lane operand fragments.
+//
+//   T = _Float16 : v_mfma_f32_16x16x32_f16   one MFMA per 32-deep chunk   (fp16 storage, fp32 accumulate)
+//   T = float    : v_mfma_f32_16x16x4_f32 x4 four MFMAs per 16-deep chunk (exact fp32 fmaf chain)
+//
+// Fragment contract (lane l, r16 = l & 15, h = l >> 4, EPL = 16 / sizeof(T) elements per lane):
+//   A fragment: A[row = r16][k = chunk*KC + h*EPL + j], j = 0..EPL-1   (16 contiguous bytes)
+//   B fragment: B[k = chunk*KC + h*EPL + j][col = r16]                 (16 contiguous bytes, k-major source)
+//   acc[r]    : C[row = 4*h + r][col = r16]
+// For fp32 the four MFMAs use element j of both fragments in step j, i.e. the k order inside a
+// chunk is permuted identically for A and B, which leaves the sum unchanged.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+typedef _Float16 half_t;
+typedef __attribute__((ext_vector_type(8))) _Float16 half8;
+typedef __attribute__((ext_vector_type(4))) _Float16 half4;
+typedef __attribute__((ext_vector_type(4))) float floatx4;
+
+#define CFEN_DEV __device__ __forceinline__
+
+template <typename T> struct Mma;
+
+template <> struct Mma<half_t> {
+  static constexpr int KC = 32;   // k elements covered by one fragment chunk
+  static constexpr int EPL = 8;   // elements per lane per fragment
+  typedef half8 frag;
+  typedef half4 out4;
+  static CFEN_DEV frag zero() { frag z; for (int i = 0; i < 8; ++i) z[i] = (half_t)0; return z; }
+  static CFEN_DEV floatx4 mma(frag a, frag b, floatx4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0);
+  }
+};
+
+template <> struct Mma<float> {
+  static constexpr int KC = 16;
+  static constexpr int EPL = 4;
+  typedef floatx4 frag;
+  typedef floatx4 out4;
+  static CFEN_DEV frag zero() { frag z = {0.f, 0.f, 0.f, 0.f}; return z; }
+  static CFEN_DEV floatx4 mma(frag a, frag b, floatx4 c) {
+    c = __builtin_amdgcn_mfma_f32_16x16x4f32(a[0], b[0], c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_16x16x4f32(a[1], b[1], c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_16x16x4f32(a[2], b[2], c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_16x16x4f32(a[3], b[3], c, 0, 0, 0);
+    return c;
+  }
+};
+
+template <typename T> CFEN_DEV typename Mma<T>::frag load_frag(const T* p) {
+  return *reinterpret_cast<const typename Mma<T>::frag*>(p);
+}
+
+// 4 consecutive elements <-> fp32x4
+template <typename T> CFEN_DEV floatx4 load4(const T* p);
+template <> CFEN_DEV floatx4 load4<float>(const float* p) { return *reinterpret_cast<const floatx4*>(p); }
+template <> CFEN_DEV floatx4 load4<half_t>(const half_t* p) {
+  half4 v = *reinterpret_cast<const half4*>(p);
+  floatx4 r = {(float)v[0], (float)v[1], (float)v[2], (float)v[3]};
+  return r;
+}
+template <typename T> CFEN_DEV void store4(T* p, floatx4 v);
+template <> CFEN_DEV void store4<float>(float* p, floatx4 v) { *reinterpret_cast<floatx4*>(p) = v; }
+template <> CFEN_DEV void store4<half_t>(half_t* p, floatx4 v) {
+  half4 o = {(half_t)v[0], (half_t)v[1], (half_t)v[2], (half_t)v[3]};
+  *reinterpret_cast<half4*>(p) = o;
+}
+
+// one 16-byte vector of T <-> fp32 registers (EPL values)
+template <typename T> struct Vec16;
+template <> struct Vec16<float> {
+  static constexpr int N = 4;
+  static CFEN_DEV void load(const float* p, float* o) {
+    floatx4 v = *reinterpret_cast<const floatx4*>(p);
+    o[0] = v[0]; o[1] = v[1]; o[2] = v[2]; o[3] = v[3];
+  }
+  static CFEN_DEV void store(float* p, const float* o) {
+    floatx4 v = {o[0], o[1], o[2], o[3]};
+    *reinterpret_cast<floatx4*>(p) = v;
+  }
+};
+template <> struct Vec16<half_t> {
+  static constexpr int N = 8;
+  static CFEN_DEV void load(const half_t* p, float* o) {
+    half8 v = *reinterpret_cast<const half8*>(p);
+    for (int i = 0; i < 8; ++i) o[i] = (float)v[i];
+  }
+  static CFEN_DEV void store(half_t* p, const float* o) {
+    half8 v;
+    for (int i = 0; i < 8; ++i) v[i] = (half_t)o[i];
+    *reinterpret_cast<half8*>(p) = v;
+  }
+};
+
+CFEN_DEV float wave_sum(float v) {
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+CFEN_DEV float wave_max(float v) {
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+
+// ---- host side ------------------------------------------------------------------------------
+#define CFEN_OK 0
+#define CFEN_ERR_ARG (-1)
+#define CFEN_ERR_HIP (-2)
+#define CFEN_ERR_STATE (-3)
+
+void cfen_set_error(const char* fmt, ...);
+
+#define CFEN_CHECK_ARG(cond, ...)                 \
+  do {                                            \
+    if (!(cond)) {                                \
+      cfen_set_error(__VA_ARGS__);                \
+      return CFEN_ERR_ARG;                        \
+    }                                             \
+  } while (0)
+
+#define CFEN_CHECK_LAUNCH(what)                                                    \
+  do {                                                                             \
+    hipError_t e__ = hipGetLastError();                                            \
+    if (e__ != hipSuccess) {                                                       \
+      cfen_set_error("%s: launch failed: %s", what, hipGetErrorString(e__));       \
+      return CFEN_ERR_HIP;                                                         \
+    }                                                                              \
+  } while (0)
+
+static inline bool cfen_aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }

@@ -1,0 +1,49 @@
+"""The build's state_dict manifest must equal the reference's dec_ipt(opt).state_dict() listing
+(dumped by tools/gen_golden.py from the imported reference; models/base_model.py:114-131 loads strictly)."""
+import os
+
+import pytest
+import torch
+
+from cfen_vit_dehazing_amd.config import NetConfig
+from cfen_vit_dehazing_amd.manifest import state_manifest, generate_state_dict
+
+CASES = {
+    "tiny_nf24_hdr4": NetConfig(24, 4, patch_size=8, load_size=64),
+    "tiny_nf24_hdr2": NetConfig(24, 2, patch_size=8, load_size=64),
+    "small_nf24_hdr4": NetConfig(24, 4, patch_size=16, load_size=128),
+    "full512_nf24_hdr4": NetConfig(24, 4, patch_size=32, load_size=256),
+    "full512_nf24_hdr2": NetConfig(24, 2, patch_size=32, load_size=256),
+    "full1024_nf24_hdr4": NetConfig(24, 4, patch_size=64, load_size=512),
+}
+
+
+@pytest.mark.parametrize("name", sorted(CASES))
+def test_manifest_matches_reference_listing(name, golden_dir):
+    want = [l.split() for l in open(os.path.join(golden_dir, "state_manifest_%s.txt" % name)) if l.strip()]
+    got = state_manifest(CASES[name])
+    assert len(got) == len(want) == 958
+    for (k, shape, dt), (wk, wshape, wdt) in zip(got, want):
+        assert k == wk
+        assert ("x".join(str(s) for s in shape) or "scalar") == wshape, k
+        assert str(dt).replace("torch.", "") == wdt, k
+
+
+def test_counts_full512():
+    # 479.89 M parameters total, 271.34 M used in forward (hdr=4)
+    cfg = CASES["full512_nf24_hdr4"]
+    tot = sum(int(torch.tensor(s).prod()) if s else 1 for k, s, d in state_manifest(cfg) if d != torch.int64)
+    used = sum(int(torch.tensor(s).prod()) if s else 1 for k, s, d in state_manifest(cfg, with_dead=False) if d != torch.int64)
+    assert abs(tot / 1e6 - 479.89) < 0.02 + 0.01   # + sub/add_mean buffers are parameters with requires_grad False
+    assert abs(used / 1e6 - 271.34) < 0.02
+
+
+def test_generator_is_deterministic_and_initialised():
+    cfg = CASES["tiny_nf24_hdr4"]
+    a = generate_state_dict(cfg, seed=0, with_dead=False)
+    b = generate_state_dict(cfg, seed=0, with_dead=False)
+    c = generate_state_dict(cfg, seed=1, with_dead=False)
+    for k in a:
+        assert torch.equal(a[k], b[k])
+    assert not torch.equal(a["head.0.0.weight"], c["head.0.0.weight"])
+    assert int(a["lgcat_conv_e01.1.initialized"]) == 1

@@ -1,0 +1,277 @@
+#!/usr/bin/env python3
+"""Generate tests/golden/* by importing the REFERENCE (build container only).
+
+Runs /root/reference/models/networks_iid_hlgvit_crs_gd4_cfs_v3.py (imported, never copied) on the
+build's deterministic weights/inputs and stores small vectors:
+
+  state_manifest_<cfg>.txt   key / shape / dtype of dec_ipt(opt).state_dict()
+  net_<cfg>.npz              per-stage float64 sum / abs-sum / 512 sampled values,
+                             output statistics, a centre crop and a strided subsample of xr/xs/xd
+                             (tiny configs: the full outputs)
+  ops_kat.npz                small known-answer vectors for ActNorm init, CFSM2G, bilinear x2 twice,
+                             avgpool twice, one LViT and one GViT module call, tensor2im edge values
+
+The reference never travels to the GPU box; these vectors do.  Usage:
+    PYTHONDONTWRITEBYTECODE=1 python tools/gen_golden.py [--only tiny]
+"""
+import argparse
+import os
+import sys
+
+sys.dont_write_bytecode = True
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+REF = os.environ.get("CFEN_REFERENCE", "/root/reference")
+
+import numpy as np
+import torch
+
+from cfen_vit_dehazing_amd.config import NetConfig, default_opt
+from cfen_vit_dehazing_amd.manifest import generate_state_dict, synthetic_input
+
+GOLD = os.path.join(ROOT, "tests", "golden")
+
+CONFIGS = {
+    # name: (NetConfig, batch, store_full_outputs)
+    "tiny_nf24_hdr4": (NetConfig(24, 4, patch_size=8, load_size=64), 2, True),
+    "tiny_nf24_hdr2": (NetConfig(24, 2, patch_size=8, load_size=64), 1, True),
+    "small_nf24_hdr4": (NetConfig(24, 4, patch_size=16, load_size=128), 1, False),
+    "full512_nf24_hdr4": (NetConfig(24, 4, patch_size=32, load_size=256), 1, False),
+    "full512_nf24_hdr2": (NetConfig(24, 2, patch_size=32, load_size=256), 1, False),
+    "full1024_nf24_hdr4": (NetConfig(24, 4, patch_size=64, load_size=512), 1, False),
+}
+
+STAGE_MODULES = None
+
+
+def import_reference():
+    sys.path.insert(0, REF)
+    from models import networks_iid_hlgvit_crs_gd4_cfs_v3 as v3, common   # noqa
+    return v3, common
+
+
+def opt_for(cfg):
+    return default_opt(n_feats=cfg.n_feats, hidden_dim_ratio=cfg.hidden_dim_ratio, patch_size=cfg.patch_size,
+                       loadSize=cfg.load_size, num_heads=cfg.num_heads, patch_dim=cfg.patch_dim)
+
+
+def stage_names():
+    names = ["head", "ds_conv_e01"]
+    for l in (1, 2, 3):
+        names += ["localvit_encoder_0%d" % l, "globalvit_encoder_0%d" % l, "lgcat_conv_e0%d" % l]
+        if l < 3:
+            names.append("ds_conv_e0%d" % (l + 1))
+    for t in "rsd":
+        for l in (3, 2, 1):
+            names += ["localvit_decoder_0%d%s" % (l, t), "globalvit_decoder_0%d%s" % (l, t),
+                      "lgcat_conv_d0%d%s" % (l, t), "us_conv_d0%d%s" % (l, t)]
+            if l > 1:
+                names.append(("cfsm2g_d0%dd" % l) if t == "d" else ("sk_conv_d0%d%s" % (l, t)))
+        names.append("tail_" + t.upper())
+    return names
+
+
+def sample_idx(name, numel, n=512):
+    import zlib
+    g = torch.Generator()
+    g.manual_seed(zlib.crc32(name.encode()) & 0x7FFFFFFF)
+    return torch.randint(0, numel, (n,), generator=g)
+
+
+class StageRecorder:
+    """Collects the 58 top-level stage outputs of the reference module with forward hooks.
+    LViT modules are called once per window; their joined map is rebuilt from the calls in order
+    of the reference's quadrant recursion (lu, ld, ru, rd nesting, v3:403-486)."""
+
+    def __init__(self, net, cfg, batch):
+        self.cfg, self.B = cfg, batch
+        self.out = {}
+        self.calls = {}
+        for name, mod in net.named_children():
+            if name.startswith("localvit"):
+                mod.register_forward_hook(self._lv_hook(name))
+            elif name.startswith("globalvit") or name.startswith("ds_conv") or name.startswith("us_conv") \
+                    or name.startswith("sk_conv") or name.startswith("cfsm2g") or name in ("head", "tail_R", "tail_S", "tail_D"):
+                tgt = mod[0] if name in ("head", "tail_R", "tail_S", "tail_D") else mod
+                tgt.register_forward_hook(self._hook(name))
+            elif name.startswith("lgcat"):
+                mod.register_forward_hook(self._hook(name + "#pre"))
+
+    def _hook(self, name):
+        def f(m, i, o):
+            self.out[name] = o.detach().clone()
+        return f
+
+    def _lv_hook(self, name):
+        def f(m, i, o):
+            self.calls.setdefault(name, []).append(o.detach().clone())
+        return f
+
+    def finish(self, lgcat_inputs):
+        cfg = self.cfg
+        for name, outs in self.calls.items():
+            level = int(name.split("_0")[1][0])
+            depth = 4 - level                     # crop nesting: 3,2,1 for levels 1,2,3
+            ws = cfg.patch_size
+            size = cfg.level_size(level)
+            C = cfg.level_channels(level)
+            full = torch.zeros(self.B, C, size, size)
+            # call order: nested (lu, ld, ru, rd) == for each quadrant digit q: row = q&1, col = q>>1
+            for idx, o in enumerate(outs):
+                y = x = 0
+                for d in range(depth):
+                    q = (idx // (4 ** (depth - 1 - d))) % 4
+                    half = size >> (d + 1)
+                    y += (q & 1) * half
+                    x += (q >> 1) * half
+                full[:, :, y:y + ws, x:x + ws] = o
+            self.out[name] = full
+        # lgcat stage = relu(actnorm(conv(cat))) + residual, residual = the level input
+        for name in list(self.out):
+            if name.endswith("#pre"):
+                base = name[:-4]
+                self.out[base] = self.out.pop(name) + lgcat_inputs[base]
+        return self.out
+
+
+def run_reference(v3, common, cfg, batch, dtype=torch.float32):
+    opt = opt_for(cfg)
+    torch.manual_seed(0)
+    net = v3.dec_ipt(opt, common.default_conv)
+    sd = generate_state_dict(cfg, seed=0)
+    missing = net.load_state_dict(sd, strict=True)
+    net = net.to(dtype)
+    x = synthetic_input(batch, cfg).to(dtype)
+    rec = StageRecorder(net, cfg, batch)
+    # residual inputs of the lgcat stages: captured through pre-hooks on the LViT's sibling GViT (its input == level input)
+    lg_in = {}
+    for name, mod in net.named_children():
+        if name.startswith("globalvit"):
+            tag = name.replace("globalvit_encoder_0", "lgcat_conv_e0").replace("globalvit_decoder_0", "lgcat_conv_d0")
+            mod.register_forward_pre_hook(lambda m, i, tag=tag: lg_in.__setitem__(tag, i[0].detach().clone()))
+    with torch.no_grad():
+        outs = net(x)
+    stages = rec.finish(lg_in)
+    return net, sd, x, [o.detach() for o in outs], stages
+
+
+def dump_manifest(net, path):
+    with open(path, "w") as f:
+        for k, v in net.state_dict().items():
+            f.write("%s %s %s\n" % (k, "x".join(str(s) for s in v.shape) or "scalar", str(v.dtype).replace("torch.", "")))
+
+
+def gen_net(v3, common, name):
+    cfg, batch, full = CONFIGS[name]
+    print("== %s: reference forward (B=%d, %dx%d)" % (name, batch, cfg.image_size, cfg.image_size), flush=True)
+    net, sd, x, outs, stages = run_reference(v3, common, cfg, batch)
+    dump_manifest(net, os.path.join(GOLD, "state_manifest_%s.txt" % name))
+    data = {"batch": np.int64(batch), "cfg": np.array([cfg.n_feats, cfg.hidden_dim_ratio, cfg.patch_size, cfg.load_size], np.int64)}
+    names = stage_names()
+    assert len(names) == 58 and all(n in stages for n in names), [n for n in names if n not in stages]
+    data["stage_names"] = np.array(names)
+    for n in names:
+        t = stages[n]
+        data["stage_sum/" + n] = np.float64(t.double().sum().item())
+        data["stage_abs/" + n] = np.float64(t.double().abs().sum().item())
+        data["stage_smp/" + n] = t.flatten()[sample_idx(n, t.numel())].numpy()
+        data["stage_shape/" + n] = np.array(t.shape, np.int64)
+    for nm, o in zip(("xr", "xs", "xd"), outs):
+        data["stat/" + nm] = np.array([o.mean().item(), o.std().item(), o.min().item(), o.max().item()], np.float64)
+        if full:
+            data["out/" + nm] = o.numpy()
+        else:
+            n = o.shape[-1]
+            c0 = n // 2 - 32
+            data["crop/" + nm] = o[:, :, c0:c0 + 64, c0:c0 + 64].numpy().copy()
+            data["strided/" + nm] = o[:, :, 3::8, 5::8].numpy().copy()
+    np.savez_compressed(os.path.join(GOLD, "net_%s.npz" % name), **data)
+    for nm, o in zip(("xr", "xs", "xd"), outs):
+        print("   %s mean %.4f std %.4f min %.4f max %.4f" % ((nm,) + tuple(data["stat/" + nm])))
+    # cross-check the oracle right here so a bad fixture/oracle pair is caught at generation time
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import cfen_oracle
+    st = {}
+    with torch.no_grad():
+        o2 = cfen_oracle.forward(sd, x, cfg.num_heads, cfg.patch_size, stages=st)
+    for nm, a, b in zip(("xr", "xs", "xd"), outs, o2):
+        print("   oracle vs reference %s: max-abs %.3e" % (nm, (a - b).abs().max().item()))
+    worst = max((stages[n] - st[n]).abs().max().item() for n in names)
+    print("   worst stage max-abs %.3e" % worst, flush=True)
+
+
+def gen_ops(v3, common):
+    print("== ops_kat", flush=True)
+    sys.path.insert(0, REF)
+    from models.actnorm import ActNorm2d
+    data = {}
+    g = torch.Generator(); g.manual_seed(1234)
+    # ActNorm first-call init (models/actnorm.py:25-37) then apply
+    x = torch.randn(2, 6, 9, 7, generator=g) * 1.7 + 0.3
+    x[:, 2] *= 0.1                                     # variance below the 0.2 floor
+    an = ActNorm2d(6)
+    with torch.no_grad():
+        y = an(x)
+    data["actnorm/x"], data["actnorm/y"] = x.numpy(), y.numpy()
+    data["actnorm/weight"], data["actnorm/bias"] = an.weight.detach().numpy(), an.bias.detach().numpy()
+    # CFSM2G
+    m = v3.CFSM2G(8, 2)
+    for i, p in enumerate(m.parameters()):
+        with torch.no_grad():
+            p.copy_(torch.randn(p.shape, generator=g) * 0.5)
+    xs = [torch.randn(2, 8, 6, 10, generator=g) for _ in range(3)]
+    with torch.no_grad():
+        y = m(xs)
+    for i in range(3):
+        data["cfsm/x%d" % i] = xs[i].numpy()
+    data["cfsm/y"] = y.numpy()
+    for k, v in m.state_dict().items():
+        data["cfsm/sd/" + k] = v.numpy()
+    # bilinear x2 twice, avgpool twice (v3:1274,1323)
+    up = torch.nn.Upsample(scale_factor=2, mode="bilinear")
+    x = torch.randn(1, 3, 5, 4, generator=g)
+    data["up/x"], data["up/y"] = x.numpy(), up(up(x)).numpy()
+    pool = torch.nn.AvgPool2d(2, stride=2)
+    x = torch.randn(1, 3, 8, 12, generator=g)
+    data["pool/x"], data["pool/y"] = x.numpy(), pool(pool(x)).numpy()
+    # one LViT and one GViT module call (small geometry, real code path)
+    lv = v3.LViT(img_dim=8, patch_dim=2, num_channels=12, embedding_dim=48, num_heads=2, num_layers=1, hidden_dim=96,
+                 num_queries=1, dropout_rate=0, mlp=False, pos_every=False, no_pos=False, no_norm=False)
+    gv = v3.GViT(img_dim=8, patch_dim=4, num_channels=6, embedding_dim=96, num_heads=2, num_layers=1, hidden_dim=192,
+                 num_queries=1, dropout_rate=0, mlp=False, pos_every=False, no_pos=False, no_norm=False)
+    for tag, mod, shape in (("lvit", lv, (3, 12, 8, 8)), ("gvit", gv, (2, 6, 32, 32))):
+        with torch.no_grad():
+            for k, p in mod.named_parameters():
+                if p.dim() >= 2:
+                    p.copy_(torch.randn(p.shape, generator=g) / (p.shape[-1] ** 0.5))
+                else:
+                    p.copy_(torch.randn(p.shape, generator=g) * 0.1 + (1.0 if "norm" in k and k.endswith("weight") else 0.0))
+            x = torch.randn(shape, generator=g)
+            y = mod(x)
+        data[tag + "/x"], data[tag + "/y"] = x.numpy(), y.numpy()
+        for k, v in mod.state_dict().items():
+            if "decoder" in k or "query_embed" in k:
+                continue
+            data[tag + "/sd/" + k] = v.numpy()
+    # tensor2im edge values (util/util.py:12-24): truncation toward zero, no clamp, 1-channel tiling
+    from util import util as refutil
+    t = torch.tensor([-1.0, 1.0, 0.0, 0.00392, 0.999, -0.999, 0.5, -0.5, 0.2, 0.99999]).view(1, 2, 5)
+    data["t2i/x"], data["t2i/y"] = t.numpy(), refutil.tensor2im(t)
+    t3 = torch.linspace(-1, 1, 3 * 4 * 4).view(3, 4, 4)
+    data["t2i/x3"], data["t2i/y3"] = t3.numpy(), refutil.tensor2im(t3)
+    np.savez_compressed(os.path.join(GOLD, "ops_kat.npz"), **data)
+
+
+if __name__ == "__main__":
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--only", default="")
+    args = ap.parse_args()
+    os.makedirs(GOLD, exist_ok=True)
+    v3, common = import_reference()
+    torch.set_num_threads(8)
+    if not args.only or args.only == "ops":
+        gen_ops(v3, common)
+    for name in CONFIGS:
+        if args.only and args.only not in name:
+            continue
+        gen_net(v3, common, name)
