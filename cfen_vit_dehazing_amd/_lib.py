@@ -1,0 +1,105 @@
+"""ctypes binding of libcfen_hip.so (C ABI in include/cfen_hip.h).
+
+There is NO fallback: if the library is missing or a call fails, an exception is raised.  The
+product path never routes through PyTorch ops or the CPU oracle.
+"""
+import ctypes
+import os
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "libcfen_hip.so")
+
+CFEN_F32, CFEN_F16 = 0, 1
+c_void_p, c_int, c_float, c_size_t, c_char_p = ctypes.c_void_p, ctypes.c_int, ctypes.c_float, ctypes.c_size_t, ctypes.c_char_p
+
+
+class CfenError(RuntimeError):
+    pass
+
+
+class NetConfigC(ctypes.Structure):
+    _fields_ = [(n, ctypes.c_int32) for n in
+                ("batch", "n_feats", "hidden_dim_ratio", "patch_size", "load_size", "num_heads", "dtype", "reserved")]
+
+
+class ConvArgsC(ctypes.Structure):
+    _fields_ = [(n, ctypes.c_int32) for n in
+                ("kind", "k", "stride", "pad", "reflect", "nsrc", "B", "Hin", "Win", "Cin", "cs_in",
+                 "Cout", "Cout_pad", "Kpad", "cs_out", "act", "out_nchw_f32", "cs_res")] + \
+               [(n, c_void_p) for n in ("src0", "src1", "weight", "scale", "shift", "res0", "res1", "out")]
+
+
+# every symbol include/cfen_hip.h declares: (restype, argtypes)
+_I = c_int
+_P = c_void_p
+SIGNATURES = {
+    "cfen_abi_version": (_I, []),
+    "cfen_last_error": (c_char_p, []),
+    "cfen_net_create": (_I, [ctypes.POINTER(_P), ctypes.POINTER(NetConfigC)]),
+    "cfen_net_destroy": (None, [_P]),
+    "cfen_net_workspace_bytes": (c_size_t, [_P]),
+    "cfen_net_set_param": (_I, [_P, c_char_p, _P, c_size_t]),
+    "cfen_net_missing_params": (_I, [_P, c_char_p, c_size_t]),
+    "cfen_net_forward": (_I, [_P, _P, _P, _P, _P, _P, c_size_t, _P]),
+    "cfen_net_stage": (_I, [_P, c_char_p, ctypes.POINTER(_P)] + [ctypes.POINTER(ctypes.c_int32)] * 4),
+    "cfen_net_flops_per_image": (ctypes.c_double, [_P]),
+    "cfen_gemm_nt": (_I, [_I, _P, _I, _P, _I, _P, _P, _I, _P, _I, _P, _I, _I, _I, _I, _I, _P]),
+    "cfen_layernorm": (_I, [_I, _P, _P, _P, _P, _I, _I, c_float, _P]),
+    "cfen_attention": (_I, [_I, _P, _P, _I, _I, _I, _I, _P]),
+    "cfen_patchify": (_I, [_I, _P, _P] + [_I] * 8 + [_P]),
+    "cfen_unpatchify": (_I, [_I, _P, _P] + [_I] * 7 + [_P]),
+    "cfen_upsample4": (_I, [_I, _P, _P] + [_I] * 6 + [_P]),
+    "cfen_nchw_to_nhwc": (_I, [_I, _P, _P] + [_I] * 5 + [_P]),
+    "cfen_conv2d": (_I, [_I, ctypes.POINTER(ConvArgsC), _P]),
+    "cfen_stats_workspace": (c_size_t, [_I, _I]),
+    "cfen_instnorm_relu": (_I, [_I, _P, _P, _I, _I, _I, _I, c_float, _P]),
+    "cfen_cfsm2g": (_I, [_I, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P]),
+    "cfen_deform_conv_forward": (_I, [_I, _P, _P, _P, _P] + [_I] * 16 + [_P]),
+    "cfen_modulated_deform_conv_forward": (_I, [_I, _P, _P, _P, _P, _P, _P] + [_I] * 16 + [_P]),
+}
+
+_lib = None
+_PENDING = {"cfen_deform_conv_forward", "cfen_modulated_deform_conv_forward"}   # TODO remove once k_dcn.hip lands
+
+
+def load():
+    """Load the shared library once; raise (never fall back) if it is not there."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError("libcfen_hip.so not built: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                          "(hipcc --offload-arch=gfx950) -- there is no CPU/PyTorch fallback for the HIP path")
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        if name in _PENDING and not hasattr(lib, name):
+            continue
+        fn = getattr(lib, name)          # AttributeError if the .so lacks a declared symbol
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def check(rc, what=""):
+    if rc != 0:
+        msg = load().cfen_last_error()
+        raise CfenError("%s failed (%d): %s" % (what or "cfen call", rc, msg.decode() if msg else "?"))
+
+
+def dtype_code(torch_dtype):
+    import torch
+    if torch_dtype == torch.float16:
+        return CFEN_F16
+    if torch_dtype == torch.float32:
+        return CFEN_F32
+    raise TypeError("HIP path supports float16 and float32 storage, got %s" % torch_dtype)
+
+
+def ptr(t):
+    return c_void_p(t.data_ptr()) if t is not None else c_void_p(0)
+
+
+def current_stream():
+    import torch
+    return c_void_p(torch.cuda.current_stream().cuda_stream)

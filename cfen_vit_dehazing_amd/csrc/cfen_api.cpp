@@ -1,0 +1,89 @@
+// extern "C" surface of libcfen_hip.so (declared in include/cfen_hip.h): thin argument adapters over
+// the kernel launchers.  No allocation, no synchronisation, no exceptions.
+#include <stdarg.h>
+#include <stdio.h>
+
+#include "../../include/cfen_hip.h"
+#include "cfen_common.hpp"
+#include "cfen_conv.hpp"
+#include "cfen_internal.hpp"
+
+static thread_local char g_err[512] = "";
+
+void cfen_set_error(const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+}
+
+extern "C" {
+
+int cfen_abi_version(void) { return 1; }
+const char* cfen_last_error(void) { return g_err; }
+
+int cfen_gemm_nt(int dtype, const void* X, int ldx, const void* W, int ldw, const float* bias, const void* R, int ldr, const void* P,
+                 int period, void* Y, int ldy, int M, int N, int K, int relu, void* stream) {
+  return cfen_gemm_impl(dtype, X, ldx, W, ldw, bias, R, ldr, P, period, Y, ldy, M, N, K, relu, (hipStream_t)stream);
+}
+
+int cfen_layernorm(int dtype, const void* X, void* Y, const float* gamma, const float* beta, int M, int D, float eps, void* stream) {
+  CFEN_CHECK_ARG(gamma && beta, "layernorm: gamma/beta required");
+  return cfen_layernorm_impl(dtype, X, Y, gamma, beta, M, D, eps, (hipStream_t)stream);
+}
+
+int cfen_attention(int dtype, const void* qkv, void* out, int nseq, int S, int heads, int dh, void* stream) {
+  return cfen_attention_impl(dtype, qkv, out, nseq, S, heads, dh, (hipStream_t)stream);
+}
+
+int cfen_patchify(int dtype, const void* fmap, void* tokens, int B, int H, int W, int C, int cs, int ws, int p, int pool, void* stream) {
+  return cfen_patchify_impl(dtype, fmap, tokens, B, H, W, C, cs, ws, p, pool, 0, (hipStream_t)stream);
+}
+
+int cfen_unpatchify(int dtype, const void* tokens, void* fmap, int B, int H, int W, int C, int cs, int ws, int p, void* stream) {
+  return cfen_patchify_impl(dtype, fmap, const_cast<void*>(tokens), B, H, W, C, cs, ws, p, 1, 1, (hipStream_t)stream);
+}
+
+int cfen_upsample4(int dtype, const void* small, void* out, int B, int h, int w, int C, int cs_in, int cs_out, void* stream) {
+  return cfen_upsample4_impl(dtype, small, out, B, h, w, C, cs_in, cs_out, (hipStream_t)stream);
+}
+
+int cfen_nchw_to_nhwc(int dtype, const float* in, void* out, int B, int C, int H, int W, int cs, void* stream) {
+  return cfen_nchw_to_nhwc_impl(dtype, in, out, B, C, H, W, cs, (hipStream_t)stream);
+}
+
+int cfen_conv2d(int dtype, const cfen_conv_args* a, void* stream) {
+  CFEN_CHECK_ARG(a != nullptr, "conv2d: null args");
+  ConvDesc d;
+  if (a->kind == 0) {
+    CFEN_CHECK_ARG(a->k >= 1 && a->k <= 7 && a->stride >= 1 && a->stride <= 2 && a->nsrc >= 1 && a->nsrc <= 2 &&
+                   a->k * a->k * a->nsrc <= CFEN_MAX_TAPS, "conv2d: unsupported kernel/stride/nsrc");
+    CFEN_CHECK_ARG(a->nsrc == 1 || a->src1, "conv2d: src1 missing");
+    cfen_desc_conv(&d, a->B, a->Hin, a->Win, a->cs_in, a->Cin, a->k, a->stride, a->pad, a->reflect, a->nsrc);
+  } else if (a->kind == 1) {
+    cfen_desc_convT4(&d, a->B, a->Hin, a->Win, a->cs_in, a->Cin);
+  } else {
+    cfen_set_error("conv2d: unknown kind %d", a->kind);
+    return CFEN_ERR_ARG;
+  }
+  d.src[0] = a->src0; d.src[1] = a->src1;
+  d.weight = a->weight; d.Kpad = a->Kpad;
+  d.scale = a->scale; d.shift = a->shift; d.act = a->act;
+  d.res[0] = a->res0; d.res[1] = a->res1; d.cs_res = a->cs_res;
+  d.out = a->out; d.cs_out = a->cs_out; d.Cout_pad = a->Cout_pad; d.Cout = a->Cout;
+  d.out_nchw_f32 = a->out_nchw_f32;
+  return cfen_conv_impl(dtype, &d, (hipStream_t)stream);
+}
+
+size_t cfen_stats_workspace(int B, int C) { return cfen_stats_workspace_bytes(B, C); }
+
+int cfen_instnorm_relu(int dtype, void* x, float* stats_ws, int B, int HW, int C, int cs, float eps, void* stream) {
+  return cfen_instnorm_relu_impl(dtype, x, stats_ws, B, HW, C, cs, eps, (hipStream_t)stream);
+}
+
+int cfen_cfsm2g(int dtype, const void* x0, const void* x1, const void* x2, void* out, const float* w, float* stats_ws, int B, int HW,
+                int C, int cs, void* stream) {
+  return cfen_cfsm2g_impl(dtype, x0, x1, x2, out, w, stats_ws, B, HW, C, cs, (hipStream_t)stream);
+}
+
+}  // extern "C"

@@ -1,0 +1,79 @@
+// Descriptor of one implicit-GEMM convolution launch (see k_conv.hip) and builders for the layer
+// kinds of the v3 generator.  Host-only plain data; passed to the kernel by value.
+#pragma once
+#include <stdint.h>
+#include <string.h>
+
+#define CFEN_MAX_TAPS 64
+
+struct ConvTap {
+  int8_t dy, dx;   // input offset relative to base*in_stride
+  int8_t src;      // 0/1: which input tensor (1x1 conv over a channel concat reads two)
+  int8_t pad_;
+};
+
+struct ConvDesc {
+  const void* src[2];
+  int Hin, Win, cs_in, Cin;      // Cin = channels consumed per tap (<= cs_in)
+  const void* weight;            // [nphase][Cout_pad][Kpad], k = tap*Cin + c, zero padded
+  int Kpad;
+  int ntaps, nphase;
+  ConvTap taps[CFEN_MAX_TAPS];   // phase p uses taps[p*ntaps .. p*ntaps+ntaps)
+  int in_stride, out_stride;
+  int8_t ph_y[4], ph_x[4];       // output offset of each phase
+  int B, Hb, Wb;                 // base grid (one GEMM column per base pixel per phase)
+  int Hout, Wout;
+  int pad_reflect;
+  const float* scale;            // [Cout_pad] epilogue y = acc*scale + shift
+  const float* shift;
+  int act;                       // 0 none, 1 ReLU, 2 tanh
+  const void* res[2];            // optional residual maps (same geometry as out, channel stride cs_res)
+  int cs_res;
+  void* out;
+  int cs_out, Cout_pad, Cout;
+  int out_nchw_f32;
+};
+
+static inline int cfen_round_up(int v, int m) { return (v + m - 1) / m * m; }
+
+// Conv2d(k, stride, padding=pad) over `nsrc` same-shaped inputs concatenated on channels.
+static inline void cfen_desc_conv(ConvDesc* d, int B, int Hin, int Win, int cs_in, int Cin, int k, int stride, int pad, int reflect,
+                                  int nsrc) {
+  memset(d, 0, sizeof(*d));
+  d->B = B; d->Hin = Hin; d->Win = Win; d->cs_in = cs_in; d->Cin = Cin;
+  d->nphase = 1; d->in_stride = stride; d->out_stride = 1;
+  d->Hout = (Hin + 2 * pad - k) / stride + 1;
+  d->Wout = (Win + 2 * pad - k) / stride + 1;
+  d->Hb = d->Hout; d->Wb = d->Wout;
+  d->pad_reflect = reflect;
+  int n = 0;
+  for (int s = 0; s < nsrc; ++s)
+    for (int ky = 0; ky < k; ++ky)
+      for (int kx = 0; kx < k; ++kx) {
+        d->taps[n].dy = (int8_t)(ky - pad); d->taps[n].dx = (int8_t)(kx - pad); d->taps[n].src = (int8_t)s;
+        ++n;
+      }
+  d->ntaps = n;
+}
+
+// ConvTranspose2d(k=4, stride=2, padding=1): out[2b+p] gathers 2 taps per axis.
+//   p=0: ky=1 (iy=b), ky=3 (iy=b-1);  p=1: ky=0 (iy=b+1), ky=2 (iy=b)        [oy = 2*iy - 1 + ky]
+// Phase index = py*2+px; tap order inside a phase = (ty, tx) with the (ky, kx) listed above; the host
+// packer (packing.py: pack_convT) emits weights in the same order.
+static inline void cfen_desc_convT4(ConvDesc* d, int B, int Hin, int Win, int cs_in, int Cin) {
+  memset(d, 0, sizeof(*d));
+  d->B = B; d->Hin = Hin; d->Win = Win; d->cs_in = cs_in; d->Cin = Cin;
+  d->nphase = 4; d->ntaps = 4; d->in_stride = 1; d->out_stride = 2;
+  d->Hout = 2 * Hin; d->Wout = 2 * Win; d->Hb = Hin; d->Wb = Win;
+  static const int8_t off[2][2] = {{0, -1}, {1, 0}};   // [parity][tap] -> input offset
+  for (int py = 0; py < 2; ++py)
+    for (int px = 0; px < 2; ++px) {
+      int ph = py * 2 + px;
+      d->ph_y[ph] = (int8_t)py; d->ph_x[ph] = (int8_t)px;
+      for (int ty = 0; ty < 2; ++ty)
+        for (int tx = 0; tx < 2; ++tx) {
+          ConvTap* t = &d->taps[ph * 4 + ty * 2 + tx];
+          t->dy = off[py][ty]; t->dx = off[px][tx]; t->src = 0;
+        }
+    }
+}

@@ -1,0 +1,20 @@
+// Internal launcher prototypes shared by cfen_api.cpp and cfen_net.cpp.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stddef.h>
+
+struct ConvDesc;
+
+int cfen_gemm_impl(int dtype, const void* X, int ldx, const void* W, int ldw, const float* bias, const void* R, int ldr, const void* P,
+                   int period, void* Y, int ldy, int M, int N, int K, int relu, hipStream_t s);
+int cfen_attention_impl(int dtype, const void* qkv, void* out, int nseq, int S, int heads, int dh, hipStream_t s);
+int cfen_layernorm_impl(int dtype, const void* X, void* Y, const float* g, const float* b, int M, int D, float eps, hipStream_t s);
+int cfen_patchify_impl(int dtype, const void* fmap, void* tok, int B, int H, int W, int C, int cs, int ws, int p, int pool, int inverse,
+                       hipStream_t s);
+int cfen_upsample4_impl(int dtype, const void* small, void* out, int B, int h, int w, int C, int cs_in, int cs_out, hipStream_t s);
+int cfen_nchw_to_nhwc_impl(int dtype, const float* in, void* out, int B, int C, int H, int W, int cs, hipStream_t s);
+int cfen_conv_impl(int dtype, const ConvDesc* d, hipStream_t s);
+size_t cfen_stats_workspace_bytes(int B, int C);
+int cfen_instnorm_relu_impl(int dtype, void* x, float* part, int B, int HW, int C, int cs, float eps, hipStream_t s);
+int cfen_cfsm2g_impl(int dtype, const void* x0, const void* x1, const void* x2, void* out, const float* w, float* part, int B, int HW,
+                     int C, int cs, hipStream_t s);

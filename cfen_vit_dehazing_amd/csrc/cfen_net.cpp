@@ -1,0 +1,458 @@
+// Host-side launch plan of the v3 generator forward (reference
+// models/networks_iid_hlgvit_crs_gd4_cfs_v3.py:392-1020): a fixed sequence of kernel launches over a
+// caller-provided workspace.  No allocation, no synchronisation: the whole forward can be captured
+// into a hipGraph by the caller.
+//
+// Workspace layout = one NHWC buffer per top-level stage output (so parity tests can read every
+// stage of SURVEY Appendix D after a forward) + token scratch shared by all 24 transformer blocks.
+#include <map>
+#include <string>
+#include <vector>
+
+#include "../../include/cfen_hip.h"
+#include "cfen_common.hpp"
+#include "cfen_conv.hpp"
+#include "cfen_internal.hpp"
+
+namespace {
+
+struct Param {
+  const void* ptr = nullptr;
+  size_t need = 0;
+};
+struct Buf {
+  size_t off = 0;
+  int C = 0, cs = 0, H = 0, W = 0;
+};
+struct Vit {
+  std::string name;
+  bool global;
+  int level, C, p, S, D, heads, hidden;
+  int mapH;   // edge of the map the tokens tile (pooled edge for GViT)
+  int ws;     // window edge on that map
+};
+struct ConvLayer {
+  int kind, k, stride, pad, reflect, nsrc, Cin, Cin_real, Cout, Cout_pad, Kpad, nphase, ntaps, out_edge;
+};
+
+inline int cs_of(int C) { return cfen_round_up(C, 8); }
+
+}  // namespace
+
+struct cfen_net {
+  cfen_net_config cfg;
+  int esz, KC;
+  std::map<std::string, Param> params;
+  std::map<std::string, Buf> bufs;
+  std::map<std::string, ConvLayer> convs;
+  std::vector<Vit> vits;
+  size_t ws_bytes = 0;
+  size_t o_x0 = 0, o_x1 = 0, o_yn = 0, o_qkv = 0, o_att = 0, o_hid = 0, o_small = 0, o_stats = 0;
+  unsigned char* base = nullptr;   // workspace of the current / last forward
+  hipStream_t stream = nullptr;
+
+  size_t alloc(size_t bytes) {
+    size_t off = ws_bytes;
+    ws_bytes += (bytes + 255) / 256 * 256;
+    return off;
+  }
+  void add_map(const std::string& n, int C, int edge) {
+    Buf b;
+    b.C = C; b.cs = cs_of(C); b.H = edge; b.W = edge;
+    b.off = alloc((size_t)cfg.batch * edge * edge * b.cs * esz);
+    bufs[n] = b;
+  }
+  void need(const std::string& n, size_t bytes) { params[n].need = bytes; }
+  void add_conv(const std::string& n, int kind, int k, int stride, int pad, int reflect, int nsrc, int Cin_real, int Cout, int out_edge) {
+    ConvLayer c;
+    const int Cin = cs_of(Cin_real);
+    c.kind = kind; c.k = k; c.stride = stride; c.pad = pad; c.reflect = reflect; c.nsrc = nsrc; c.Cin = Cin; c.Cout = Cout;
+    c.Cin_real = Cin_real; c.out_edge = out_edge;
+    c.Cout_pad = cfen_round_up(Cout, 16);
+    c.nphase = kind == 1 ? 4 : 1;
+    c.ntaps = kind == 1 ? 4 : k * k * nsrc;
+    c.Kpad = cfen_round_up(c.ntaps * Cin, KC);
+    convs[n] = c;
+    need(n + ".w", (size_t)c.nphase * c.Cout_pad * c.Kpad * esz);
+    need(n + ".scale", (size_t)c.Cout_pad * 4);
+    need(n + ".shift", (size_t)c.Cout_pad * 4);
+  }
+  void* at(size_t off) const { return base + off; }
+  void* map_ptr(const std::string& n) const { return base + bufs.at(n).off; }
+  const void* P(const std::string& n) const { return params.at(n).ptr; }
+  const float* Pf(const std::string& n) const { return (const float*)params.at(n).ptr; }
+
+  int build();
+  int run_conv(const std::string& layer, const std::string& in0, const char* in1, const char* res0, const char* res1, int act,
+               const std::string& out, float* nchw_out);
+  int run_vit(const Vit& v, const std::string& in, const std::string& out);
+  int run_level(const char* tag, int l, const std::string& in, const char* extra_res, const std::string& out);
+  int forward(const float* x, float* xr, float* xs, float* xd);
+};
+
+#define TRY(expr)             \
+  do {                        \
+    int rc__ = (expr);        \
+    if (rc__) return rc__;    \
+  } while (0)
+
+int cfen_net::build() {
+  const int nf = cfg.n_feats, N = cfg.load_size, B = cfg.batch;
+  esz = cfg.dtype == CFEN_F16 ? 2 : 4;
+  KC = cfg.dtype == CFEN_F16 ? 32 : 16;
+  CFEN_CHECK_ARG(cfg.dtype == CFEN_F16 || cfg.dtype == CFEN_F32, "net: unknown dtype %d", cfg.dtype);
+  CFEN_CHECK_ARG(B > 0 && nf > 0 && nf % 8 == 0, "net: batch must be > 0 and n_feats a multiple of 8");
+  CFEN_CHECK_ARG(N == 8 * cfg.patch_size, "net: loadSize (%d) must equal 8*patch_size (%d) (reference crop nesting, v3:403-529)", N,
+                 cfg.patch_size);
+  CFEN_CHECK_ARG(cfg.patch_size % 2 == 0 && N % 64 == 0, "net: loadSize must be a multiple of 64 (16-pixel tiles at level 3)");
+  CFEN_CHECK_ARG(cfg.num_heads > 0 && (nf * 4) % cfg.num_heads == 0, "net: embedding dim not divisible by heads");
+  CFEN_CHECK_ARG(4 * nf <= 128, "net: n_feats > 32 unsupported");
+  CFEN_CHECK_ARG(cfg.hidden_dim_ratio > 0, "net: hidden_dim_ratio must be positive");
+
+  // ---- transformer instances (reference v3:136-246) ----
+  static const char* br = "rsd";
+  auto lv = [&](const std::string& name, int l) {
+    Vit v;
+    v.name = name; v.global = false; v.level = l; v.C = nf << (l - 1); v.p = 2;
+    v.ws = cfg.patch_size; v.mapH = N >> (l - 1);
+    v.S = (v.ws / 2) * (v.ws / 2); v.D = v.C * 4; v.heads = cfg.num_heads << (l - 1); v.hidden = v.D * cfg.hidden_dim_ratio;
+    vits.push_back(v);
+  };
+  auto gv = [&](const std::string& name, int l) {
+    Vit v;
+    v.name = name; v.global = true; v.level = l; v.C = nf << (l - 1); v.p = 4;
+    v.mapH = (N >> (l - 1)) / 4; v.ws = v.mapH;
+    v.S = (v.mapH / 4) * (v.mapH / 4); v.D = v.C * 16; v.heads = cfg.num_heads << (l - 1);
+    v.hidden = v.D * cfg.hidden_dim_ratio;
+    if (name == "globalvit_encoder_02") v.hidden = v.C * 4 * cfg.hidden_dim_ratio;   // v3:200 quirk (patch_dim, not patch_dim*2)
+    vits.push_back(v);
+  };
+  for (int l = 1; l <= 3; ++l) lv("localvit_encoder_0" + std::to_string(l), l);
+  for (int b = 0; b < 3; ++b)
+    for (int l = 3; l >= 1; --l) lv("localvit_decoder_0" + std::to_string(l) + br[b], l);
+  for (int l = 1; l <= 3; ++l) gv("globalvit_encoder_0" + std::to_string(l), l);
+  for (int b = 0; b < 3; ++b)
+    for (int l = 3; l >= 1; --l) gv("globalvit_decoder_0" + std::to_string(l) + br[b], l);
+
+  size_t max_md = 0, max_mh = 0, max_small = 0;
+  for (const Vit& v : vits) {
+    CFEN_CHECK_ARG(v.mapH % v.ws == 0 && v.ws % v.p == 0 && v.S >= 1, "net: %s does not tile its map", v.name.c_str());
+    const size_t ntok = (size_t)B * (v.mapH / v.ws) * (v.mapH / v.ws) * v.S;
+    max_md = std::max(max_md, ntok * v.D);
+    max_mh = std::max(max_mh, ntok * v.hidden);
+    if (v.global) max_small = std::max(max_small, (size_t)B * v.mapH * v.mapH * v.C);
+    const std::string& n = v.name;
+    need(n + ".embed.w", (size_t)v.D * v.D * esz); need(n + ".embed.b", (size_t)v.D * 4);
+    need(n + ".pos", (size_t)v.S * v.D * esz);
+    need(n + ".ln1.g", (size_t)v.D * 4); need(n + ".ln1.b", (size_t)v.D * 4);
+    need(n + ".qkv.w", (size_t)3 * v.D * v.D * esz);
+    need(n + ".proj.w", (size_t)v.D * v.D * esz);
+    need(n + ".ln2.g", (size_t)v.D * 4); need(n + ".ln2.b", (size_t)v.D * 4);
+    need(n + ".ffn1.w", (size_t)v.hidden * v.D * esz); need(n + ".ffn1.b", (size_t)v.hidden * 4);
+    need(n + ".ffn2.w", (size_t)v.hidden * v.D * esz); need(n + ".ffn2.b", (size_t)v.D * 4);
+    need(n + ".head1.w", (size_t)v.hidden * v.D * esz); need(n + ".head1.b", (size_t)v.hidden * 4);
+    need(n + ".head2.w", (size_t)v.hidden * v.D * esz); need(n + ".head2.b", (size_t)v.D * 4);
+  }
+
+  // ---- convolution layers ----
+  const int h = nf / 2;
+  add_conv("head.0.0", 0, 5, 1, 2, 0, 1, 3, h, 2 * N);
+  add_conv("head.0.1.body.0", 0, 3, 1, 1, 0, 1, h, h, 2 * N);
+  add_conv("head.0.1.body.2", 0, 3, 1, 1, 0, 1, h, h, 2 * N);
+  add_conv("ds_conv_e01", 0, 3, 2, 1, 0, 1, h, nf, N);
+  add_conv("ds_conv_e02", 0, 3, 2, 1, 0, 1, nf, 2 * nf, N / 2);
+  add_conv("ds_conv_e03", 0, 3, 2, 1, 0, 1, 2 * nf, 4 * nf, N / 4);
+  for (int l = 1; l <= 3; ++l) add_conv("lgcat_conv_e0" + std::to_string(l), 0, 1, 1, 0, 0, 2, nf << (l - 1), nf << (l - 1), N >> (l - 1));
+  for (int b = 0; b < 3; ++b) {
+    const std::string t(1, br[b]);
+    for (int l = 1; l <= 3; ++l)
+      add_conv("lgcat_conv_d0" + std::to_string(l) + t, 0, 1, 1, 0, 0, 2, nf << (l - 1), nf << (l - 1), N >> (l - 1));
+    add_conv("us_conv_d03" + t, 1, 4, 2, 1, 0, 1, 4 * nf, 2 * nf, N / 2);
+    add_conv("us_conv_d02" + t, 1, 4, 2, 1, 0, 1, 2 * nf, nf, N);
+    add_conv("us_conv_d01" + t, 1, 4, 2, 1, 0, 1, nf, h, 2 * N);
+    if (b < 2) {
+      add_conv("sk_conv_d03" + t, 0, 1, 1, 0, 0, 2, 2 * nf, 2 * nf, N / 2);
+      add_conv("sk_conv_d02" + t, 0, 1, 1, 0, 0, 2, nf, nf, N);
+    }
+    const std::string T(1, (char)(br[b] - 32));
+    add_conv("tail_" + T + ".conv3", 0, 3, 1, 1, 0, 1, h, h, 2 * N);
+    add_conv("tail_" + T + ".conv7", 0, 7, 1, 3, 1, 1, h, b == 1 ? 1 : 3, 2 * N);
+  }
+  need("cfsm2g_d03d.w", (size_t)4 * 2 * (2 * nf / 4) * (2 * nf) * 4);
+  need("cfsm2g_d02d.w", (size_t)4 * 2 * (nf / 4) * nf * 4);
+
+  // ---- workspace ----
+  add_map("input", 3, 2 * N);
+  add_map("head.conv5", h, 2 * N);
+  add_map("head.res_mid", h, 2 * N);
+  add_map("head", h, 2 * N);
+  add_map("ds_conv_e01", nf, N);
+  for (int l = 1; l <= 3; ++l) {
+    const std::string L = std::to_string(l);
+    const int C = nf << (l - 1), E = N >> (l - 1);
+    add_map("localvit_encoder_0" + L, C, E);
+    add_map("globalvit_encoder_0" + L, C, E);
+    add_map("lgcat_conv_e0" + L, C, E);
+    if (l < 3) add_map("ds_conv_e0" + std::to_string(l + 1), 2 * C, E / 2);
+  }
+  for (int b = 0; b < 3; ++b) {
+    const std::string t(1, br[b]);
+    for (int l = 3; l >= 1; --l) {
+      const std::string L = std::to_string(l);
+      const int C = nf << (l - 1), E = N >> (l - 1);
+      add_map("localvit_decoder_0" + L + t, C, E);
+      add_map("globalvit_decoder_0" + L + t, C, E);
+      add_map("lgcat_conv_d0" + L + t, C, E);
+      add_map("us_conv_d0" + L + t, C / 2, 2 * E);
+      if (l > 1) add_map(b == 2 ? "cfsm2g_d0" + L + "d" : "sk_conv_d0" + L + t, C / 2, 2 * E);
+    }
+    add_map(std::string("tail_") + (char)(br[b] - 32) + ".mid", h, 2 * N);
+  }
+  o_x0 = alloc(max_md * esz); o_x1 = alloc(max_md * esz); o_yn = alloc(max_md * esz); o_att = alloc(max_md * esz);
+  o_qkv = alloc(3 * max_md * esz);
+  o_hid = alloc(max_mh * esz);
+  o_small = alloc(max_small * esz);
+  o_stats = alloc(cfen_stats_workspace_bytes(B, 128));
+  return CFEN_OK;
+}
+
+int cfen_net::run_conv(const std::string& layer, const std::string& in0, const char* in1, const char* res0, const char* res1, int act,
+                       const std::string& out, float* nchw_out) {
+  const ConvLayer& c = convs.at(layer);
+  const Buf& bi = bufs.at(in0);
+  ConvDesc d;
+  if (c.kind == 0)
+    cfen_desc_conv(&d, cfg.batch, bi.H, bi.W, bi.cs, c.Cin, c.k, c.stride, c.pad, c.reflect, c.nsrc);
+  else
+    cfen_desc_convT4(&d, cfg.batch, bi.H, bi.W, bi.cs, c.Cin);
+  d.src[0] = map_ptr(in0);
+  d.src[1] = in1 ? map_ptr(in1) : nullptr;
+  d.weight = P(layer + ".w"); d.Kpad = c.Kpad;
+  d.scale = Pf(layer + ".scale"); d.shift = Pf(layer + ".shift");
+  d.act = act;
+  d.Cout = c.Cout; d.Cout_pad = c.Cout_pad;
+  if (nchw_out) {
+    d.out = nchw_out; d.out_nchw_f32 = 1; d.cs_out = c.Cout_pad;
+  } else {
+    const Buf& bo = bufs.at(out);
+    CFEN_CHECK_ARG(bo.H == d.Hout && bo.W == d.Wout, "net: %s output geometry mismatch", layer.c_str());
+    d.out = map_ptr(out); d.cs_out = bo.cs; d.cs_res = bo.cs;
+    d.res[0] = res0 ? map_ptr(res0) : nullptr;
+    d.res[1] = res1 ? map_ptr(res1) : nullptr;
+  }
+  return cfen_conv_impl(cfg.dtype, &d, stream);
+}
+
+// One LViT / GViT instance: reference v3:1136-1189 / 1272-1325 (+ TransformerEncoderLayer 1382-1390).
+int cfen_net::run_vit(const Vit& v, const std::string& in, const std::string& out) {
+  const int dt = cfg.dtype, B = cfg.batch;
+  const Buf& bi = bufs.at(in);
+  const Buf& bo = bufs.at(out);
+  const int nwin = (v.mapH / v.ws) * (v.mapH / v.ws);
+  const int M = B * nwin * v.S;
+  const std::string& n = v.name;
+  void *X0 = at(o_x0), *X1 = at(o_x1), *YN = at(o_yn), *QKV = at(o_qkv), *ATT = at(o_att), *HID = at(o_hid);
+  TRY(cfen_patchify_impl(dt, map_ptr(in), X0, B, v.mapH, v.mapH, v.C, bi.cs, v.ws, v.p, v.global ? 4 : 1, 0, stream));
+  // x = linear_encoding(x) + x + pos                                        (v3:1143,1166)
+  TRY(cfen_gemm_impl(dt, X0, v.D, P(n + ".embed.w"), v.D, Pf(n + ".embed.b"), X0, v.D, P(n + ".pos"), v.S, X1, v.D, M, v.D, v.D, 0, stream));
+  // src = src + out_proj(MHA(LN1(src)))                                      (v3:1383-1386)
+  TRY(cfen_layernorm_impl(dt, X1, YN, Pf(n + ".ln1.g"), Pf(n + ".ln1.b"), M, v.D, 1e-5f, stream));
+  TRY(cfen_gemm_impl(dt, YN, v.D, P(n + ".qkv.w"), v.D, nullptr, nullptr, 0, nullptr, 0, QKV, 3 * v.D, M, 3 * v.D, v.D, 0, stream));
+  TRY(cfen_attention_impl(dt, QKV, ATT, B * nwin, v.S, v.heads, v.D / v.heads, stream));
+  TRY(cfen_gemm_impl(dt, ATT, v.D, P(n + ".proj.w"), v.D, nullptr, X1, v.D, nullptr, 0, X1, v.D, M, v.D, v.D, 0, stream));
+  // src = src + linear2(relu(linear1(LN2(src))))                             (v3:1387-1389)
+  TRY(cfen_layernorm_impl(dt, X1, YN, Pf(n + ".ln2.g"), Pf(n + ".ln2.b"), M, v.D, 1e-5f, stream));
+  TRY(cfen_gemm_impl(dt, YN, v.D, P(n + ".ffn1.w"), v.D, Pf(n + ".ffn1.b"), nullptr, 0, nullptr, 0, HID, v.hidden, M, v.hidden, v.D, 1, stream));
+  TRY(cfen_gemm_impl(dt, HID, v.hidden, P(n + ".ffn2.w"), v.hidden, Pf(n + ".ffn2.b"), X1, v.D, nullptr, 0, X1, v.D, M, v.D, v.hidden, 0, stream));
+  // x = mlp_head(x) + x                                                      (v3:1173)
+  TRY(cfen_gemm_impl(dt, X1, v.D, P(n + ".head1.w"), v.D, Pf(n + ".head1.b"), nullptr, 0, nullptr, 0, HID, v.hidden, M, v.hidden, v.D, 1, stream));
+  TRY(cfen_gemm_impl(dt, HID, v.hidden, P(n + ".head2.w"), v.hidden, Pf(n + ".head2.b"), X1, v.D, nullptr, 0, X0, v.D, M, v.D, v.hidden, 0, stream));
+  if (!v.global) return cfen_patchify_impl(dt, map_ptr(out), X0, B, v.mapH, v.mapH, v.C, bo.cs, v.ws, v.p, 1, 1, stream);
+  void* SM = at(o_small);
+  TRY(cfen_patchify_impl(dt, SM, X0, B, v.mapH, v.mapH, v.C, v.C, v.ws, v.p, 1, 1, stream));
+  return cfen_upsample4_impl(dt, SM, map_ptr(out), B, v.mapH, v.mapH, v.C, v.C, bo.cs, stream);
+}
+
+// LViT || GViT -> 1x1 fuse conv over their concat -> ActNorm -> ReLU -> + level input   (v3:403-488 ...)
+int cfen_net::run_level(const char* tag, int l, const std::string& in, const char* extra_res, const std::string& out) {
+  const std::string L = std::to_string(l);
+  const bool enc = tag[0] == 'e';
+  const std::string ln = enc ? "localvit_encoder_0" + L : "localvit_decoder_0" + L + tag;
+  const std::string gn = enc ? "globalvit_encoder_0" + L : "globalvit_decoder_0" + L + tag;
+  const Vit *lvp = nullptr, *gvp = nullptr;
+  for (const Vit& v : vits) {
+    if (v.name == ln) lvp = &v;
+    if (v.name == gn) gvp = &v;
+  }
+  TRY(run_vit(*lvp, in, ln));
+  TRY(run_vit(*gvp, in, gn));
+  return run_conv(out, ln, gn.c_str(), in.c_str(), extra_res, 1, out, nullptr);
+}
+
+int cfen_net::forward(const float* x, float* xr, float* xs, float* xd) {
+  const int dt = cfg.dtype, B = cfg.batch, N = cfg.load_size;
+  float* stats = (float*)at(o_stats);
+  const Buf& bin = bufs.at("input");
+  TRY(cfen_nchw_to_nhwc_impl(dt, x, map_ptr("input"), B, 3, 2 * N, 2 * N, bin.cs, stream));
+  // head: conv5x5 + ResBlock                                                   (v3:123-127,395)
+  TRY(run_conv("head.0.0", "input", nullptr, nullptr, nullptr, 0, "head.conv5", nullptr));
+  TRY(run_conv("head.0.1.body.0", "head.conv5", nullptr, nullptr, nullptr, 1, "head.res_mid", nullptr));
+  TRY(run_conv("head.0.1.body.2", "head.res_mid", nullptr, "head.conv5", nullptr, 0, "head", nullptr));
+  auto down = [&](const std::string& layer, const std::string& in) -> int {   // conv s2 -> IN -> ReLU (v3:292-298)
+    TRY(run_conv(layer, in, nullptr, nullptr, nullptr, 0, layer, nullptr));
+    const Buf& b = bufs.at(layer);
+    return cfen_instnorm_relu_impl(dt, map_ptr(layer), stats, B, b.H * b.W, b.C, b.cs, 1e-5f, stream);
+  };
+  TRY(down("ds_conv_e01", "head"));
+  TRY(run_level("e", 1, "ds_conv_e01", nullptr, "lgcat_conv_e01"));
+  TRY(down("ds_conv_e02", "lgcat_conv_e01"));
+  TRY(run_level("e", 2, "ds_conv_e02", nullptr, "lgcat_conv_e02"));
+  TRY(down("ds_conv_e03", "lgcat_conv_e02"));
+  TRY(run_level("e", 3, "ds_conv_e03", nullptr, "lgcat_conv_e03"));
+
+  float* outs[3] = {xr, xs, xd};
+  static const char* br = "rsd";
+  for (int b = 0; b < 3; ++b) {   // R, S, then D: D's skip inputs are R's and S's upsampled maps (v3:885,920)
+    const std::string t(1, br[b]);
+    const std::string T(1, (char)(br[b] - 32));
+    TRY(run_level(t.c_str(), 3, "lgcat_conv_e03", nullptr, "lgcat_conv_d03" + t));
+    {  // ConvT -> InstanceNorm -> ReLU (v3:301-302)
+      const std::string u = "us_conv_d03" + t;
+      TRY(run_conv(u, "lgcat_conv_d03" + t, nullptr, nullptr, nullptr, 0, u, nullptr));
+      const Buf& bu = bufs.at(u);
+      TRY(cfen_instnorm_relu_impl(dt, map_ptr(u), stats, B, bu.H * bu.W, bu.C, bu.cs, 1e-5f, stream));
+    }
+    std::string in2, in1;
+    if (b == 2) {
+      in2 = "cfsm2g_d03d";
+      const Buf& bu = bufs.at(in2);
+      TRY(cfen_cfsm2g_impl(dt, map_ptr("us_conv_d03d"), map_ptr("us_conv_d03r"), map_ptr("us_conv_d03s"), map_ptr(in2),
+                           Pf("cfsm2g_d03d.w"), stats, B, bu.H * bu.W, bu.C, bu.cs, stream));
+    } else {
+      in2 = "sk_conv_d03" + t;
+      TRY(run_conv(in2, "us_conv_d03" + t, "lgcat_conv_e02", nullptr, nullptr, 1, in2, nullptr));
+    }
+    TRY(run_level(t.c_str(), 2, in2, nullptr, "lgcat_conv_d02" + t));
+    TRY(run_conv("us_conv_d02" + t, "lgcat_conv_d02" + t, nullptr, nullptr, nullptr, 1, "us_conv_d02" + t, nullptr));
+    if (b == 2) {
+      in1 = "cfsm2g_d02d";
+      const Buf& bu = bufs.at(in1);
+      TRY(cfen_cfsm2g_impl(dt, map_ptr("us_conv_d02d"), map_ptr("us_conv_d02r"), map_ptr("us_conv_d02s"), map_ptr(in1),
+                           Pf("cfsm2g_d02d.w"), stats, B, bu.H * bu.W, bu.C, bu.cs, stream));
+    } else {
+      in1 = "sk_conv_d02" + t;
+      TRY(run_conv(in1, "us_conv_d02" + t, "lgcat_conv_e01", nullptr, nullptr, 1, in1, nullptr));
+    }
+    // `xr = us_conv_d01r(r_d_01 + xf)` (v3:696,852,1008): the extra `+ xf` rides along as a second
+    // residual of the fuse conv, so stage lgcat_conv_d01* holds (reference stage + xf).
+    TRY(run_level(t.c_str(), 1, in1, "ds_conv_e01", "lgcat_conv_d01" + t));
+    TRY(run_conv("us_conv_d01" + t, "lgcat_conv_d01" + t, nullptr, nullptr, nullptr, 1, "us_conv_d01" + t, nullptr));
+    TRY(run_conv("tail_" + T + ".conv3", "us_conv_d01" + t, nullptr, nullptr, nullptr, 1, "tail_" + T + ".mid", nullptr));
+    TRY(run_conv("tail_" + T + ".conv7", "tail_" + T + ".mid", nullptr, nullptr, nullptr, 2, "", outs[b]));
+  }
+  return CFEN_OK;
+}
+
+extern "C" {
+
+int cfen_net_create(cfen_net** out, const cfen_net_config* cfg) {
+  CFEN_CHECK_ARG(out && cfg, "net_create: null argument");
+  cfen_net* n = new (std::nothrow) cfen_net();
+  CFEN_CHECK_ARG(n != nullptr, "net_create: out of host memory");
+  n->cfg = *cfg;
+  int rc = n->build();
+  if (rc) {
+    delete n;
+    return rc;
+  }
+  *out = n;
+  return CFEN_OK;
+}
+
+void cfen_net_destroy(cfen_net* net) { delete net; }
+
+size_t cfen_net_workspace_bytes(const cfen_net* net) { return net ? net->ws_bytes : 0; }
+
+int cfen_net_set_param(cfen_net* net, const char* name, const void* dev_ptr, size_t nbytes) {
+  CFEN_CHECK_ARG(net && name && dev_ptr, "set_param: null argument");
+  auto it = net->params.find(name);
+  CFEN_CHECK_ARG(it != net->params.end(), "set_param: unknown parameter '%s'", name);
+  CFEN_CHECK_ARG(it->second.need == nbytes, "set_param: '%s' needs %zu bytes, got %zu", name, it->second.need, nbytes);
+  CFEN_CHECK_ARG(cfen_aligned16(dev_ptr), "set_param: '%s' must be 16-byte aligned", name);
+  it->second.ptr = dev_ptr;
+  return CFEN_OK;
+}
+
+int cfen_net_missing_params(const cfen_net* net, char* buf, size_t buflen) {
+  int count = 0;
+  size_t pos = 0;
+  if (buf && buflen) buf[0] = 0;
+  if (!net) return 0;
+  for (const auto& kv : net->params)
+    if (!kv.second.ptr) {
+      ++count;
+      if (buf && pos + kv.first.size() + 2 < buflen) {
+        memcpy(buf + pos, kv.first.c_str(), kv.first.size());
+        pos += kv.first.size();
+        buf[pos++] = ';';
+        buf[pos] = 0;
+      }
+    }
+  return count;
+}
+
+int cfen_net_forward(cfen_net* net, const float* x, float* xr, float* xs, float* xd, void* workspace, size_t workspace_bytes,
+                     void* stream) {
+  CFEN_CHECK_ARG(net && x && xr && xs && xd && workspace, "net_forward: null argument");
+  if (workspace_bytes < net->ws_bytes) {
+    cfen_set_error("net_forward: workspace has %zu bytes, %zu needed", workspace_bytes, net->ws_bytes);
+    return CFEN_ERR_STATE;
+  }
+  CFEN_CHECK_ARG((reinterpret_cast<uintptr_t>(workspace) & 255) == 0, "net_forward: workspace must be 256-byte aligned");
+  for (const auto& kv : net->params)
+    if (!kv.second.ptr) {
+      cfen_set_error("net_forward: parameter '%s' was never set", kv.first.c_str());
+      return CFEN_ERR_STATE;
+    }
+  net->base = (unsigned char*)workspace;
+  net->stream = (hipStream_t)stream;
+  return net->forward(x, xr, xs, xd);
+}
+
+int cfen_net_stage(const cfen_net* net, const char* name, const void** ptr, int32_t* C, int32_t* cs, int32_t* H, int32_t* W) {
+  CFEN_CHECK_ARG(net && name && ptr, "net_stage: null argument");
+  auto it = net->bufs.find(name);
+  CFEN_CHECK_ARG(it != net->bufs.end(), "net_stage: unknown stage '%s'", name);
+  if (!net->base) {
+    cfen_set_error("net_stage: no forward has run yet");
+    return CFEN_ERR_STATE;
+  }
+  *ptr = net->base + it->second.off;
+  if (C) *C = it->second.C;
+  if (cs) *cs = it->second.cs;
+  if (H) *H = it->second.H;
+  if (W) *W = it->second.W;
+  return CFEN_OK;
+}
+
+double cfen_net_flops_per_image(const cfen_net* net) {
+  if (!net) return 0.0;
+  const int B = net->cfg.batch;
+  double f = 0.0;
+  for (const Vit& v : net->vits) {   // 2T(5D^2 + 4DH) + 4 T S D
+    const double T = (double)(v.mapH / v.ws) * (v.mapH / v.ws) * v.S;
+    f += 2.0 * T * (5.0 * v.D * v.D + 4.0 * (double)v.D * v.hidden) + 4.0 * T * v.S * v.D;
+  }
+  for (const auto& kv : net->convs) {
+    const ConvLayer& c = kv.second;
+    const double e = (double)c.out_edge;
+    if (c.kind == 1)
+      f += 2.0 * c.Cin_real * c.Cout * 16.0 * (e / 2.0) * (e / 2.0);   // 2*Cin*Cout*16*Hin*Win
+    else
+      f += 2.0 * c.Cout * (double)c.Cin_real * c.nsrc * c.k * c.k * e * e;
+  }
+  (void)B;
+  return f;
+}
+
+}  // extern "C"

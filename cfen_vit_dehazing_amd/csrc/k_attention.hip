@@ -1,0 +1,258 @@
+// Multi-head self-attention (bias-free nn.MultiheadAttention, reference v3:1364,1383-1386) and LayerNorm
+// (v3:1370-1371) for LViT windows and GViT pooled maps.
+//
+// Attention.  One workgroup = (sequence, head, group of 64 queries); each of its 4 waves owns 16
+// queries.  Scores are computed TRANSPOSED, S^T = K Q^T, so that after the MFMA every lane holds
+// scores of ONE query (column = lane & 15) for 4 keys per tile:
+//   * the softmax row reduction is in-lane plus two xor-shuffles (lanes l, l^16, l^32, l^48),
+//   * the probabilities are already laid out as the B operand of O^T = V^T P^T -- no LDS round trip.
+// Keys stream through LDS in super-blocks (K row-major, V transposed) with an online softmax, so any
+// sequence length works (S = 256 windows, S = 1024 windows of the 1024^2 config, S = 1..256 pooled
+// maps) and head_dim 24 is zero-padded to the MFMA K of 32 (fp16) / 2x16 (fp32).
+#include "cfen_common.hpp"
+
+namespace {
+
+template <typename T> struct PV;
+template <> struct PV<half_t> {
+  // o[d][q] += sum over 32 keys; p0/p1 = probabilities of key tiles 0/1 for query (lane & 15)
+  static CFEN_DEV floatx4 run(const unsigned char* vt, int h, floatx4 p0, floatx4 p1, floatx4 o) {
+    half4 lo = *reinterpret_cast<const half4*>(vt + 8 * h);
+    half4 hi = *reinterpret_cast<const half4*>(vt + 32 + 8 * h);
+    half8 a = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+    half8 b = {(half_t)p0[0], (half_t)p0[1], (half_t)p0[2], (half_t)p0[3],
+               (half_t)p1[0], (half_t)p1[1], (half_t)p1[2], (half_t)p1[3]};
+    return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, o, 0, 0, 0);
+  }
+};
+template <> struct PV<float> {
+  static CFEN_DEV floatx4 run(const unsigned char* vt, int h, floatx4 p0, floatx4 p1, floatx4 o) {
+    floatx4 a0 = *reinterpret_cast<const floatx4*>(vt + 16 * h);
+    floatx4 a1 = *reinterpret_cast<const floatx4*>(vt + 64 + 16 * h);
+    o = Mma<float>::mma(a0, p0, o);
+    return Mma<float>::mma(a1, p1, o);
+  }
+};
+
+template <typename T, int NDT>
+__global__ __launch_bounds__(256) void k_attention(const T* __restrict__ QKV, T* __restrict__ O, int S, int D, int heads,
+                                                   int dh, int skb, int nqg, float scale_log2) {
+  constexpr int KC = Mma<T>::KC, EPL = Mma<T>::EPL;
+  constexpr int NCQ = (NDT * 16 + KC - 1) / KC;    // K chunks covering the (padded) head dim
+  constexpr int DHPK = NCQ * KC;
+  constexpr int SZ = (int)sizeof(T);
+  typedef typename Mma<T>::frag frag;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int krow = DHPK * SZ + 16;
+  const int vrow = skb * SZ + 16;
+  unsigned char* Kl = smem;
+  unsigned char* Vl = smem + (size_t)skb * krow;
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r16 = lane & 15, h = lane >> 4;
+  const int qg = blockIdx.x % nqg;
+  const int sh = blockIdx.x / nqg;
+  const int head = sh % heads, seq = sh / heads;
+  const int ld = 3 * D;
+  const T* Qp = QKV + (size_t)seq * S * ld + head * dh;
+  const T* Kp = Qp + D;
+  const T* Vp = Qp + 2 * D;
+  const int q0 = (qg * 4 + wave) * 16;
+  const bool active = q0 < S;
+
+  frag qf[NCQ];
+  {
+    const int qrow = min(q0 + r16, S - 1);
+#pragma unroll
+    for (int c = 0; c < NCQ; ++c) {
+      int d = c * KC + h * EPL;
+      qf[c] = (d < dh) ? load_frag<T>(Qp + (size_t)qrow * ld + d) : Mma<T>::zero();
+    }
+  }
+  floatx4 o[NDT];
+#pragma unroll
+  for (int i = 0; i < NDT; ++i) o[i] = floatx4{0.f, 0.f, 0.f, 0.f};
+  float m_run = -1e30f, l_run = 0.f;
+
+  constexpr int NVK = DHPK / EPL;        // 16-byte vectors per staged K row
+  constexpr int NVV = NDT * 16 / EPL;    // 16-byte vectors per V row (padded head dim)
+  for (int ks = 0; ks < S; ks += skb) {
+    if (ks) __syncthreads();
+    for (int idx = tid; idx < skb * NVK; idx += 256) {
+      int kr = idx / NVK, v = idx - kr * NVK;
+      int key = ks + kr, d = v * EPL;
+      frag val = (key < S && d < dh) ? load_frag<T>(Kp + (size_t)key * ld + d) : Mma<T>::zero();
+      *reinterpret_cast<frag*>(Kl + kr * krow + v * 16) = val;
+    }
+    for (int idx = tid; idx < skb * NVV; idx += 256) {
+      int kr = idx / NVV, v = idx - kr * NVV;
+      int key = ks + kr, d = v * EPL;
+      frag val = (key < S && d < dh) ? load_frag<T>(Vp + (size_t)key * ld + d) : Mma<T>::zero();
+#pragma unroll
+      for (int e = 0; e < EPL; ++e) *reinterpret_cast<T*>(Vl + (d + e) * vrow + kr * SZ) = val[e];
+    }
+    __syncthreads();
+    if (!active) continue;
+    const int kend = min(skb, S - ks);
+    for (int kb = 0; kb < kend; kb += 32) {
+      floatx4 st[2];
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {
+        st[t] = floatx4{0.f, 0.f, 0.f, 0.f};
+        const unsigned char* kp = Kl + (kb + 16 * t + r16) * krow + h * 16;
+#pragma unroll
+        for (int c = 0; c < NCQ; ++c) st[t] = Mma<T>::mma(*reinterpret_cast<const frag*>(kp + c * 64), qf[c], st[t]);
+      }
+      float mx = -1e30f;
+#pragma unroll
+      for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          int key = ks + kb + 16 * t + 4 * h + r;
+          float s = (key < S) ? st[t][r] * scale_log2 : -1e30f;
+          st[t][r] = s;
+          mx = fmaxf(mx, s);
+        }
+      mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+      mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+      const float m_new = fmaxf(m_run, mx);
+      const float alpha = exp2f(m_run - m_new);
+      float rs = 0.f;
+#pragma unroll
+      for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          float p = exp2f(st[t][r] - m_new);
+          st[t][r] = p;
+          rs += p;
+        }
+      rs += __shfl_xor(rs, 16, 64);
+      rs += __shfl_xor(rs, 32, 64);
+      l_run = l_run * alpha + rs;
+      m_run = m_new;
+#pragma unroll
+      for (int i = 0; i < NDT; ++i) {
+        o[i] *= alpha;
+        o[i] = PV<T>::run(Vl + (i * 16 + r16) * vrow + kb * SZ, h, st[0], st[1], o[i]);
+      }
+    }
+  }
+  if (active && q0 + r16 < S) {
+    const float inv = 1.f / l_run;
+    T* op = O + ((size_t)seq * S + q0 + r16) * D + head * dh;
+#pragma unroll
+    for (int i = 0; i < NDT; ++i) {
+      int d = i * 16 + 4 * h;
+      if (d < dh) store4<T>(op + d, o[i] * inv);
+    }
+  }
+}
+
+template <typename T, int NDT>
+int launch_attn(const void* qkv, void* out, int nseq, int S, int heads, int dh, hipStream_t s) {
+  constexpr int KC = Mma<T>::KC;
+  constexpr int NCQ = (NDT * 16 + KC - 1) / KC;
+  const int SZ = (int)sizeof(T);
+  const int sp = (S + 31) / 32 * 32;
+  const int perkey = NCQ * KC * SZ + 16 + NDT * 16 * SZ;
+  int skb = ((60 * 1024 - NDT * 16 * 16) / perkey) / 32 * 32;
+  if (skb < 32) skb = 32;
+  if (skb > sp) skb = sp;
+  const size_t smem = (size_t)skb * (NCQ * KC * SZ + 16) + (size_t)NDT * 16 * (skb * SZ + 16);
+  const int nqg = (S + 63) / 64;
+  const long long blocks = (long long)nseq * heads * nqg;
+  CFEN_CHECK_ARG(blocks > 0 && blocks < (1ll << 31), "attention: bad grid");
+  const float scale_log2 = 1.4426950408889634f / sqrtf((float)dh);
+  hipLaunchKernelGGL((k_attention<T, NDT>), dim3((unsigned)blocks), dim3(256), smem, s, (const T*)qkv, (T*)out, S,
+                     heads * dh, heads, dh, skb, nqg, scale_log2);
+  CFEN_CHECK_LAUNCH("attention");
+  return CFEN_OK;
+}
+
+template <typename T>
+int dispatch_attn(const void* qkv, void* out, int nseq, int S, int heads, int dh, hipStream_t s) {
+  CFEN_CHECK_ARG(nseq > 0 && S > 0 && heads > 0 && dh > 0, "attention: empty problem");
+  CFEN_CHECK_ARG(dh % Mma<T>::EPL == 0, "attention: head_dim %d must be a multiple of %d", dh, Mma<T>::EPL);
+  CFEN_CHECK_ARG(cfen_aligned16(qkv) && cfen_aligned16(out), "attention: pointers must be 16-byte aligned");
+  if (dh <= 32) return launch_attn<T, 2>(qkv, out, nseq, S, heads, dh, s);
+  if (dh <= 96) return launch_attn<T, 6>(qkv, out, nseq, S, heads, dh, s);
+  if (dh <= 128) return launch_attn<T, 8>(qkv, out, nseq, S, heads, dh, s);
+  cfen_set_error("attention: head_dim %d > 128 unsupported", dh);
+  return CFEN_ERR_ARG;
+}
+
+// ---------------------------------------------------------------------------------------------
+// LayerNorm over the last dim, one wave per token row, statistics in fp32 (two passes over registers).
+template <typename T, int MAXV>
+__global__ __launch_bounds__(256) void k_layernorm(const T* __restrict__ X, T* __restrict__ Y, const float* __restrict__ g,
+                                                   const float* __restrict__ b, int M, int D, float eps) {
+  constexpr int EPL = Vec16<T>::N;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int row = blockIdx.x * 4 + wave;
+  if (row >= M) return;
+  const int nvec = D / EPL;
+  const T* x = X + (size_t)row * D;
+  float v[MAXV][EPL];
+  float sum = 0.f;
+#pragma unroll
+  for (int i = 0; i < MAXV; ++i) {
+    int idx = lane + i * 64;
+    if (idx < nvec) {
+      Vec16<T>::load(x + idx * EPL, v[i]);
+#pragma unroll
+      for (int e = 0; e < EPL; ++e) sum += v[i][e];
+    }
+  }
+  const float mean = wave_sum(sum) / (float)D;
+  float sq = 0.f;
+#pragma unroll
+  for (int i = 0; i < MAXV; ++i) {
+    int idx = lane + i * 64;
+    if (idx < nvec) {
+#pragma unroll
+      for (int e = 0; e < EPL; ++e) {
+        float d = v[i][e] - mean;
+        sq += d * d;
+      }
+    }
+  }
+  const float rstd = rsqrtf(wave_sum(sq) / (float)D + eps);
+  T* y = Y + (size_t)row * D;
+#pragma unroll
+  for (int i = 0; i < MAXV; ++i) {
+    int idx = lane + i * 64;
+    if (idx < nvec) {
+      float o[EPL];
+#pragma unroll
+      for (int e = 0; e < EPL; ++e) o[e] = (v[i][e] - mean) * rstd * g[idx * EPL + e] + b[idx * EPL + e];
+      Vec16<T>::store(y + idx * EPL, o);
+    }
+  }
+}
+
+template <typename T, int MAXV>
+int launch_ln(const void* X, void* Y, const float* g, const float* b, int M, int D, float eps, hipStream_t s) {
+  CFEN_CHECK_ARG(M > 0 && D > 0, "layernorm: empty problem");
+  CFEN_CHECK_ARG(D % Vec16<T>::N == 0 && D <= 64 * MAXV * Vec16<T>::N, "layernorm: D=%d unsupported (multiple of %d, <= %d)", D,
+                 Vec16<T>::N, 64 * MAXV * Vec16<T>::N);
+  CFEN_CHECK_ARG(cfen_aligned16(X) && cfen_aligned16(Y), "layernorm: pointers must be 16-byte aligned");
+  hipLaunchKernelGGL((k_layernorm<T, MAXV>), dim3((M + 3) / 4), dim3(256), 0, s, (const T*)X, (T*)Y, g, b, M, D, eps);
+  CFEN_CHECK_LAUNCH("layernorm");
+  return CFEN_OK;
+}
+
+}  // namespace
+
+int cfen_attention_impl(int dtype, const void* qkv, void* out, int nseq, int S, int heads, int dh, hipStream_t s) {
+  if (dtype == 1) return dispatch_attn<half_t>(qkv, out, nseq, S, heads, dh, s);
+  if (dtype == 0) return dispatch_attn<float>(qkv, out, nseq, S, heads, dh, s);
+  cfen_set_error("attention: unknown dtype %d", dtype);
+  return CFEN_ERR_ARG;
+}
+
+int cfen_layernorm_impl(int dtype, const void* X, void* Y, const float* g, const float* b, int M, int D, float eps,
+                        hipStream_t s) {
+  if (dtype == 1) return launch_ln<half_t, 4>(X, Y, g, b, M, D, eps, s);
+  if (dtype == 0) return launch_ln<float, 8>(X, Y, g, b, M, D, eps, s);
+  cfen_set_error("layernorm: unknown dtype %d", dtype);
+  return CFEN_ERR_ARG;
+}

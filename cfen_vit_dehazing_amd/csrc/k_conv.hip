@@ -1,0 +1,383 @@
+// Implicit-GEMM convolution on MFMA for the CNN encoder/decoder (NHWC, no im2col buffer in HBM).
+//
+// One kernel covers every convolution of the v3 generator:
+//   head 5x5 (v3:123-127, common.py:11-14), ResBlock / tail 3x3 (common.py:41-62, v3:351), tail 7x7 behind
+//   ReflectionPad2d(3) (v3:354-355), stride-2 3x3 down-convs (v3:292-298), 1x1 fuse convs over a channel
+//   concat of two maps (v3:255-284, 329-338: the cat is never materialised, each source is a "tap"), and
+//   ConvTranspose2d(k4,s2,p1) (v3:301-322) as four output-parity phases of 2x2 taps.
+// The epilogue applies a per-channel affine (conv bias and ActNorm2d y=(x+b)*exp(w) folded together,
+// models/actnorm.py:39-42), ReLU/tanh, up to two residual adds, and writes NHWC T or NCHW fp32.
+//
+// GEMM view: out^T[n][pixel] = sum_k W[n][k] * patch[pixel][k], k = tap*Cin + c.  Weights are the MFMA A
+// operand, gathered input pixels the B operand (one 16-byte channel vector per lane), so a lane ends up
+// with 4 consecutive output channels of one pixel (vector NHWC store) and, for NCHW, 16 consecutive
+// pixels per channel across lanes.
+#include "cfen_common.hpp"
+#include "cfen_conv.hpp"
+
+namespace {
+
+template <typename T, int TN, int TM>
+__global__ __launch_bounds__(256) void k_conv(ConvDesc d) {
+  constexpr int KC = Mma<T>::KC, EPL = Mma<T>::EPL;
+  typedef typename Mma<T>::frag frag;
+  __shared__ int taps_l[CFEN_MAX_TAPS];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r16 = lane & 15, h = lane >> 4;
+  const int phase = blockIdx.y;
+  if (tid < d.ntaps) {
+    ConvTap t = d.taps[phase * d.ntaps + tid];
+    taps_l[tid] = ((int)(unsigned char)t.src << 16) | ((int)(unsigned char)t.dy << 8) | (int)(unsigned char)t.dx;
+  }
+  __syncthreads();
+  const long long total = (long long)d.B * d.Hb * d.Wb;
+  const long long q_wave = ((long long)blockIdx.x * 4 + wave) * (TM * 16);
+  if (q_wave >= total) return;
+
+  int pb[TM], py[TM], px[TM];
+  bool pv[TM];
+#pragma unroll
+  for (int j = 0; j < TM; ++j) {
+    long long q = q_wave + j * 16 + r16;
+    pv[j] = q < total;
+    if (!pv[j]) q = total - 1;
+    px[j] = (int)(q % d.Wb);
+    py[j] = (int)((q / d.Wb) % d.Hb);
+    pb[j] = (int)(q / ((long long)d.Wb * d.Hb));
+  }
+  floatx4 acc[TN][TM];
+#pragma unroll
+  for (int i = 0; i < TN; ++i)
+#pragma unroll
+    for (int j = 0; j < TM; ++j) acc[i][j] = floatx4{0.f, 0.f, 0.f, 0.f};
+
+  const T* wbase = (const T*)d.weight + ((size_t)phase * d.Cout_pad + r16) * d.Kpad + h * EPL;
+  int t = (h * EPL) / d.Cin;
+  int c = h * EPL - t * d.Cin;
+  const int nch = d.Kpad / KC;
+  for (int kc = 0; kc < nch; ++kc) {
+    frag bf[TM];
+    if (t < d.ntaps) {
+      const int tp = taps_l[t];
+      const int dy = (int)(signed char)((tp >> 8) & 0xff), dx = (int)(signed char)(tp & 0xff);
+      const T* sp = (const T*)d.src[(tp >> 16) & 1];
+#pragma unroll
+      for (int j = 0; j < TM; ++j) {
+        int iy = py[j] * d.in_stride + dy, ix = px[j] * d.in_stride + dx;
+        bool ok = true;
+        if (d.pad_reflect) {
+          iy = iy < 0 ? -iy : (iy >= d.Hin ? 2 * d.Hin - 2 - iy : iy);
+          ix = ix < 0 ? -ix : (ix >= d.Win ? 2 * d.Win - 2 - ix : ix);
+        } else {
+          ok = (iy >= 0) & (iy < d.Hin) & (ix >= 0) & (ix < d.Win);
+        }
+        bf[j] = ok ? load_frag<T>(sp + (((size_t)pb[j] * d.Hin + iy) * d.Win + ix) * d.cs_in + c) : Mma<T>::zero();
+      }
+    } else {
+#pragma unroll
+      for (int j = 0; j < TM; ++j) bf[j] = Mma<T>::zero();
+    }
+    frag af[TN];
+#pragma unroll
+    for (int i = 0; i < TN; ++i) af[i] = load_frag<T>(wbase + (size_t)i * 16 * d.Kpad + kc * KC);
+#pragma unroll
+    for (int i = 0; i < TN; ++i)
+#pragma unroll
+      for (int j = 0; j < TM; ++j) acc[i][j] = Mma<T>::mma(af[i], bf[j], acc[i][j]);
+    c += KC;
+    while (c >= d.Cin) {
+      c -= d.Cin;
+      ++t;
+    }
+  }
+
+  const int oy_off = d.ph_y[phase], ox_off = d.ph_x[phase];
+#pragma unroll
+  for (int j = 0; j < TM; ++j) {
+    if (!pv[j]) continue;
+    const int oy = py[j] * d.out_stride + oy_off, ox = px[j] * d.out_stride + ox_off;
+    const size_t opix = ((size_t)pb[j] * d.Hout + oy) * d.Wout + ox;
+#pragma unroll
+    for (int i = 0; i < TN; ++i) {
+      const int n = i * 16 + 4 * h;
+      floatx4 v = acc[i][j] * *reinterpret_cast<const floatx4*>(d.scale + n) + *reinterpret_cast<const floatx4*>(d.shift + n);
+      if (d.act == 1) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f);
+      } else if (d.act == 2) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] = tanhf(v[r]);
+      }
+      if (d.out_nchw_f32) {
+        float* o = (float*)d.out;
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          if (n + r < d.Cout) o[(((size_t)pb[j] * d.Cout + n + r) * d.Hout + oy) * d.Wout + ox] = v[r];
+      } else if (n < d.cs_out) {
+        if (d.res[0]) v += load4<T>((const T*)d.res[0] + opix * d.cs_res + n);
+        if (d.res[1]) v += load4<T>((const T*)d.res[1] + opix * d.cs_res + n);
+        store4<T>((T*)d.out + opix * d.cs_out + n, v);
+      }
+    }
+  }
+}
+
+template <typename T, int TN, int TM>
+int launch_conv_t(const ConvDesc& d, hipStream_t s) {
+  const long long total = (long long)d.B * d.Hb * d.Wb;
+  const long long per_block = 4 * TM * 16;
+  dim3 grid((unsigned)((total + per_block - 1) / per_block), d.nphase);
+  hipLaunchKernelGGL((k_conv<T, TN, TM>), grid, dim3(256), 0, s, d);
+  CFEN_CHECK_LAUNCH("conv");
+  return CFEN_OK;
+}
+
+template <typename T>
+int launch_conv(const ConvDesc& d, hipStream_t s) {
+  constexpr int KC = Mma<T>::KC, EPL = Mma<T>::EPL;
+  CFEN_CHECK_ARG(d.B > 0 && d.Hb > 0 && d.Wb > 0, "conv: empty problem");
+  CFEN_CHECK_ARG(d.Wb % 16 == 0, "conv: output width (%d) must be a multiple of 16", d.Wb);
+  CFEN_CHECK_ARG(d.Cin % EPL == 0 && d.cs_in % EPL == 0 && d.Cin <= d.cs_in, "conv: Cin=%d cs_in=%d must be multiples of %d", d.Cin,
+                 d.cs_in, EPL);
+  CFEN_CHECK_ARG(d.ntaps > 0 && d.nphase > 0 && d.ntaps * d.nphase <= CFEN_MAX_TAPS, "conv: too many taps");
+  CFEN_CHECK_ARG(d.Kpad % KC == 0 && d.Kpad >= d.ntaps * d.Cin, "conv: Kpad=%d must be a multiple of %d and >= taps*Cin", d.Kpad, KC);
+  CFEN_CHECK_ARG(d.Cout_pad % 16 == 0 && d.Cout_pad >= d.Cout && d.Cout > 0, "conv: bad Cout/Cout_pad");
+  CFEN_CHECK_ARG(d.out_nchw_f32 || (d.cs_out % 4 == 0 && d.cs_out <= d.Cout_pad), "conv: cs_out=%d must be a multiple of 4 and <= Cout_pad",
+                 d.cs_out);
+  CFEN_CHECK_ARG(!(d.out_nchw_f32 && (d.res[0] || d.res[1])), "conv: residuals unsupported with NCHW output");
+  CFEN_CHECK_ARG(cfen_aligned16(d.src[0]) && cfen_aligned16(d.src[1]) && cfen_aligned16(d.weight) && cfen_aligned16(d.out) &&
+                 cfen_aligned16(d.scale) && cfen_aligned16(d.shift) && cfen_aligned16(d.res[0]) && cfen_aligned16(d.res[1]),
+                 "conv: pointers must be 16-byte aligned");
+  CFEN_CHECK_ARG(d.src[0] && d.weight && d.out && d.scale && d.shift, "conv: null pointer");
+  if (d.pad_reflect) {
+    int maxd = 0;
+    for (int i = 0; i < d.ntaps * d.nphase; ++i) {
+      maxd = max(maxd, abs((int)d.taps[i].dy));
+      maxd = max(maxd, abs((int)d.taps[i].dx));
+    }
+    CFEN_CHECK_ARG(maxd < d.Hin && maxd < d.Win, "conv: reflection pad larger than the image");
+  }
+  switch (d.Cout_pad / 16) {
+    case 1: return launch_conv_t<T, 1, 4>(d, s);
+    case 2: return launch_conv_t<T, 2, 4>(d, s);
+    case 3: return launch_conv_t<T, 3, 4>(d, s);
+    case 4: return launch_conv_t<T, 4, 2>(d, s);
+    case 6: return launch_conv_t<T, 6, 2>(d, s);
+    case 8: return launch_conv_t<T, 8, 1>(d, s);
+    default:
+      cfen_set_error("conv: Cout_pad=%d unsupported (16,32,48,64,96,128)", d.Cout_pad);
+      return CFEN_ERR_ARG;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Per-(image, channel) statistics of x0 (+x1 +x2): sum, sum of squares, max -- partial results per
+// pixel chunk, finished by the consumer.  Serves InstanceNorm2d (v3:292-302) and CFSM2G's global
+// average / max pools (v3:1503-1505).
+constexpr int ST_CHUNKS = 64;
+
+template <typename T>
+__global__ __launch_bounds__(256) void k_chan_stats(const T* __restrict__ x0, const T* __restrict__ x1, const T* __restrict__ x2,
+                                                    float* __restrict__ part, int HW, int C, int cs) {
+  constexpr int EPL = Vec16<T>::N;
+  __shared__ float red[3][256][EPL + 1];
+  const int b = blockIdx.y, chunk = blockIdx.x, tid = threadIdx.x;
+  const int cv = C / EPL;                       // channel vectors
+  const int lanes_per_cv = 256 / cv;            // threads sharing one channel vector
+  const int my_cv = tid % cv, my_p = tid / cv;
+  const int per = (HW + ST_CHUNKS - 1) / ST_CHUNKS;
+  const int p0 = chunk * per, p1 = min(HW, p0 + per);
+  float s[EPL], q[EPL], m[EPL];
+#pragma unroll
+  for (int e = 0; e < EPL; ++e) { s[e] = 0.f; q[e] = 0.f; m[e] = -3.0e38f; }
+  if (my_p < lanes_per_cv) {
+    for (int p = p0 + my_p; p < p1; p += lanes_per_cv) {
+      size_t off = ((size_t)b * HW + p) * cs + my_cv * EPL;
+      float v[EPL];
+      Vec16<T>::load(x0 + off, v);
+      if (x1) {
+        float u[EPL];
+        Vec16<T>::load(x1 + off, u);
+#pragma unroll
+        for (int e = 0; e < EPL; ++e) v[e] += u[e];
+        Vec16<T>::load(x2 + off, u);
+#pragma unroll
+        for (int e = 0; e < EPL; ++e) v[e] += u[e];
+      }
+#pragma unroll
+      for (int e = 0; e < EPL; ++e) { s[e] += v[e]; q[e] += v[e] * v[e]; m[e] = fmaxf(m[e], v[e]); }
+    }
+  }
+#pragma unroll
+  for (int e = 0; e < EPL; ++e) { red[0][tid][e] = s[e]; red[1][tid][e] = q[e]; red[2][tid][e] = m[e]; }
+  __syncthreads();
+  if (tid < C) {
+    const int vcol = tid / EPL, e = tid % EPL;
+    float ss = 0.f, qq = 0.f, mm = -3.0e38f;
+    for (int k = 0; k < lanes_per_cv; ++k) {
+      int src = k * cv + vcol;
+      ss += red[0][src][e]; qq += red[1][src][e]; mm = fmaxf(mm, red[2][src][e]);
+    }
+    float* o = part + (((size_t)b * ST_CHUNKS + chunk) * 3) * C;
+    o[tid] = ss; o[C + tid] = qq; o[2 * C + tid] = mm;
+  }
+}
+
+// InstanceNorm2d(affine=False, eps) + ReLU, in place (biased variance).
+template <typename T>
+__global__ __launch_bounds__(256) void k_instnorm_relu(T* __restrict__ x, const float* __restrict__ part, int HW, int C, int cs, float eps,
+                                                       long long nvec_per_img) {
+  constexpr int EPL = Vec16<T>::N;
+  __shared__ float mean_l[256], rstd_l[256];
+  const int b = blockIdx.y, tid = threadIdx.x;
+  if (tid < C) {
+    double s = 0.0, q = 0.0;
+    for (int k = 0; k < ST_CHUNKS; ++k) {
+      const float* o = part + (((size_t)b * ST_CHUNKS + k) * 3) * C;
+      s += (double)o[tid]; q += (double)o[C + tid];
+    }
+    double mean = s / HW;
+    double var = q / HW - mean * mean;
+    if (var < 0.0) var = 0.0;
+    mean_l[tid] = (float)mean;
+    rstd_l[tid] = (float)(1.0 / sqrt(var + (double)eps));
+  }
+  __syncthreads();
+  const int cv = C / EPL;
+  for (long long idx = (long long)blockIdx.x * 256 + tid; idx < nvec_per_img; idx += (long long)gridDim.x * 256) {
+    int v = (int)(idx % cv);
+    long long p = idx / cv;
+    T* ptr = x + ((size_t)b * HW + p) * cs + v * EPL;
+    float val[EPL];
+    Vec16<T>::load(ptr, val);
+#pragma unroll
+    for (int e = 0; e < EPL; ++e) val[e] = fmaxf((val[e] - mean_l[v * EPL + e]) * rstd_l[v * EPL + e], 0.f);
+    Vec16<T>::store(ptr, val);
+  }
+}
+
+// CFSM2G (v3:1481-1517): gates from the pooled statistics (four C -> C/4 -> C MLPs, recomputed by
+// every block: ~10 kFLOP), then out = x0 + x1*g1 + x2*g2.
+template <typename T>
+__global__ __launch_bounds__(256) void k_cfsm_apply(const T* __restrict__ x0, const T* __restrict__ x1, const T* __restrict__ x2,
+                                                    T* __restrict__ out, const float* __restrict__ part, const float* __restrict__ w,
+                                                    int HW, int C, int cs, long long nvec_per_img) {
+  constexpr int EPL = Vec16<T>::N;
+  __shared__ float avg_l[128], max_l[128], hid[4][32], g_l[2][128];
+  const int b = blockIdx.y, tid = threadIdx.x;
+  const int bk = C / 4;
+  if (tid < C) {
+    double s = 0.0;
+    float m = -3.0e38f;
+    for (int k = 0; k < ST_CHUNKS; ++k) {
+      const float* o = part + (((size_t)b * ST_CHUNKS + k) * 3) * C;
+      s += (double)o[tid];
+      m = fmaxf(m, o[2 * C + tid]);
+    }
+    avg_l[tid] = (float)(s / HW);
+    max_l[tid] = m;
+  }
+  __syncthreads();
+  // weights: [avg1, avg2, max1, max2] each {W0 (bk x C), W2 (C x bk)}
+  const int per = 2 * bk * C;
+  if (tid < 4 * bk) {
+    int f = tid / bk, j = tid % bk;
+    const float* W0 = w + f * per;
+    const float* in = (f < 2) ? avg_l : max_l;
+    float a = 0.f;
+    for (int c = 0; c < C; ++c) a += W0[j * C + c] * in[c];
+    hid[f][j] = fmaxf(a, 0.f);
+  }
+  __syncthreads();
+  if (tid < 2 * C) {
+    int gsel = tid / C, c = tid % C;
+    const float* Wa = w + gsel * per + bk * C;          // fc_avg_cf{1,2}.2
+    const float* Wm = w + (2 + gsel) * per + bk * C;    // fc_max_cf{1,2}.2
+    float a = 0.f;
+    for (int j = 0; j < bk; ++j) a += Wa[c * bk + j] * hid[gsel][j] + Wm[c * bk + j] * hid[2 + gsel][j];
+    g_l[gsel][c] = 1.f / (1.f + expf(-a));
+  }
+  __syncthreads();
+  const int cv = C / EPL;
+  for (long long idx = (long long)blockIdx.x * 256 + tid; idx < nvec_per_img; idx += (long long)gridDim.x * 256) {
+    int v = (int)(idx % cv);
+    long long p = idx / cv;
+    size_t off = ((size_t)b * HW + p) * cs + v * EPL;
+    float a0[EPL], a1[EPL], a2[EPL];
+    Vec16<T>::load(x0 + off, a0);
+    Vec16<T>::load(x1 + off, a1);
+    Vec16<T>::load(x2 + off, a2);
+#pragma unroll
+    for (int e = 0; e < EPL; ++e) a0[e] = a0[e] + a1[e] * g_l[0][v * EPL + e] + a2[e] * g_l[1][v * EPL + e];
+    Vec16<T>::store(out + off, a0);
+  }
+}
+
+template <typename T>
+int run_stats(const void* x0, const void* x1, const void* x2, float* part, int B, int HW, int C, int cs, hipStream_t s) {
+  constexpr int EPL = Vec16<T>::N;
+  CFEN_CHECK_ARG(B > 0 && HW > 0 && C > 0, "chan_stats: empty problem");
+  CFEN_CHECK_ARG(C % EPL == 0 && cs % EPL == 0 && C <= cs && C <= 128, "chan_stats: C=%d cs=%d unsupported", C, cs);
+  CFEN_CHECK_ARG((x1 == nullptr) == (x2 == nullptr), "chan_stats: x1 and x2 go together");
+  CFEN_CHECK_ARG(cfen_aligned16(x0) && cfen_aligned16(x1) && cfen_aligned16(x2) && part, "chan_stats: bad pointers");
+  hipLaunchKernelGGL(k_chan_stats<T>, dim3(ST_CHUNKS, B), dim3(256), 0, s, (const T*)x0, (const T*)x1, (const T*)x2, part, HW, C, cs);
+  CFEN_CHECK_LAUNCH("chan_stats");
+  return CFEN_OK;
+}
+
+inline unsigned grid_img(long long nvec) {
+  long long g = (nvec + 255) / 256;
+  return (unsigned)(g < 1 ? 1 : (g > 2048 ? 2048 : g));
+}
+
+}  // namespace
+
+size_t cfen_stats_workspace_bytes(int B, int C) { return (size_t)B * ST_CHUNKS * 3 * C * sizeof(float); }
+
+int cfen_conv_impl(int dtype, const ConvDesc* d, hipStream_t s) {
+  if (dtype == 1) return launch_conv<half_t>(*d, s);
+  if (dtype == 0) return launch_conv<float>(*d, s);
+  cfen_set_error("conv: unknown dtype %d", dtype);
+  return CFEN_ERR_ARG;
+}
+
+int cfen_instnorm_relu_impl(int dtype, void* x, float* part, int B, int HW, int C, int cs, float eps, hipStream_t s) {
+  int rc = dtype == 1 ? run_stats<half_t>(x, nullptr, nullptr, part, B, HW, C, cs, s)
+                      : dtype == 0 ? run_stats<float>(x, nullptr, nullptr, part, B, HW, C, cs, s) : CFEN_ERR_ARG;
+  if (rc) {
+    if (dtype != 0 && dtype != 1) cfen_set_error("instnorm: unknown dtype %d", dtype);
+    return rc;
+  }
+  if (dtype == 1) {
+    long long nvec = (long long)HW * (C / 8);
+    hipLaunchKernelGGL(k_instnorm_relu<half_t>, dim3(grid_img(nvec), B), dim3(256), 0, s, (half_t*)x, part, HW, C, cs, eps, nvec);
+  } else {
+    long long nvec = (long long)HW * (C / 4);
+    hipLaunchKernelGGL(k_instnorm_relu<float>, dim3(grid_img(nvec), B), dim3(256), 0, s, (float*)x, part, HW, C, cs, eps, nvec);
+  }
+  CFEN_CHECK_LAUNCH("instnorm");
+  return CFEN_OK;
+}
+
+int cfen_cfsm2g_impl(int dtype, const void* x0, const void* x1, const void* x2, void* out, const float* w, float* part, int B, int HW,
+                     int C, int cs, hipStream_t s) {
+  CFEN_CHECK_ARG(C % 4 == 0 && C <= 128 && C / 4 <= 32, "cfsm2g: C=%d unsupported", C);
+  CFEN_CHECK_ARG(x1 && x2 && w && out, "cfsm2g: null pointer");
+  int rc = dtype == 1 ? run_stats<half_t>(x0, x1, x2, part, B, HW, C, cs, s)
+                      : dtype == 0 ? run_stats<float>(x0, x1, x2, part, B, HW, C, cs, s) : CFEN_ERR_ARG;
+  if (rc) {
+    if (dtype != 0 && dtype != 1) cfen_set_error("cfsm2g: unknown dtype %d", dtype);
+    return rc;
+  }
+  CFEN_CHECK_ARG(cfen_aligned16(out), "cfsm2g: output must be 16-byte aligned");
+  if (dtype == 1) {
+    long long nvec = (long long)HW * (C / 8);
+    hipLaunchKernelGGL(k_cfsm_apply<half_t>, dim3(grid_img(nvec), B), dim3(256), 0, s, (const half_t*)x0, (const half_t*)x1,
+                       (const half_t*)x2, (half_t*)out, part, w, HW, C, cs, nvec);
+  } else {
+    long long nvec = (long long)HW * (C / 4);
+    hipLaunchKernelGGL(k_cfsm_apply<float>, dim3(grid_img(nvec), B), dim3(256), 0, s, (const float*)x0, (const float*)x1,
+                       (const float*)x2, (float*)out, part, w, HW, C, cs, nvec);
+  }
+  CFEN_CHECK_LAUNCH("cfsm2g");
+  return CFEN_OK;
+}

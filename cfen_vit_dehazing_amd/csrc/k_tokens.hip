@@ -1,0 +1,247 @@
+// Data-movement kernels between NHWC feature maps and token matrices.
+//
+// Feature maps live in HBM as NHWC with a channel stride `cs` >= C (12-channel maps are stored with
+// cs = 16 so every pixel is a whole number of 16-byte vectors).  Token rows use the feature order
+// (i, j, c) -- the four (LViT) or sixteen (GViT) pixels of a patch laid end to end -- instead of the
+// reference's F.unfold order (c, i, j) (v3:1140); the host permutes every D-sized weight axis once at
+// load time (packing.py), so a token row is p*p contiguous C-vectors of the map: pure 16-byte copies.
+//
+//   patchify   : Crop2x2 nesting (v3:403-428) + F.unfold (v3:1140), optionally fused with GViT's
+//                avgpool2(avgpool2(x)) (v3:1274) as one 4x4 mean
+//   unpatchify : F.fold (v3:1186) + Join2x2 (v3:1046-1056)
+//   upsample4  : GViT's upsam(upsam(x)) (v3:1323): two successive bilinear x2, align_corners=False
+//   nchw_to_nhwc: network input (B,3,H,W) fp32 -> NHWC T, channels zero-padded to `cs`
+#include "cfen_common.hpp"
+
+namespace {
+
+struct TokGeom {
+  int B, H, W;     // (pooled) map size the tokens tile
+  int C, cs;       // channels / channel stride of the map in HBM
+  int ws, p;       // window edge (pooled pixels), patch edge
+  int pool;        // 1 or 4: map in HBM is pool x larger than (H, W)
+};
+
+template <typename T>
+__global__ __launch_bounds__(256) void k_patchify(const T* __restrict__ fmap, T* __restrict__ tok, TokGeom g, long long nvec) {
+  constexpr int EPL = Vec16<T>::N;
+  const int cv = g.C / EPL;               // vectors per pixel
+  const int D = g.p * g.p * g.C;
+  const int tw = g.ws / g.p;              // tokens per window row
+  const int S = tw * tw;
+  const int nwx = g.W / g.ws, nwy = g.H / g.ws;
+  for (long long idx = (long long)blockIdx.x * 256 + threadIdx.x; idx < nvec; idx += (long long)gridDim.x * 256) {
+    int v = (int)(idx % (D / EPL));
+    long long m = idx / (D / EPL);
+    int c = (v % cv) * EPL;
+    int ij = v / cv;
+    int i = ij / g.p, j = ij % g.p;
+    int t = (int)(m % S);
+    long long wi = m / S;
+    int wx = (int)(wi % nwx);
+    int wy = (int)((wi / nwx) % nwy);
+    int b = (int)(wi / ((long long)nwx * nwy));
+    int y = wy * g.ws + (t / tw) * g.p + i;
+    int x = wx * g.ws + (t % tw) * g.p + j;
+    float o[EPL];
+    if (g.pool == 1) {
+      Vec16<T>::load(fmap + (((size_t)b * g.H + y) * g.W + x) * g.cs + c, o);
+    } else {
+      const int HW = g.W * g.pool;
+#pragma unroll
+      for (int e = 0; e < EPL; ++e) o[e] = 0.f;
+      for (int dy = 0; dy < g.pool; ++dy)
+        for (int dx = 0; dx < g.pool; ++dx) {
+          float t8[EPL];
+          Vec16<T>::load(fmap + (((size_t)b * g.H * g.pool + y * g.pool + dy) * HW + x * g.pool + dx) * g.cs + c, t8);
+#pragma unroll
+          for (int e = 0; e < EPL; ++e) o[e] += t8[e];
+        }
+      const float inv = 1.f / (float)(g.pool * g.pool);
+#pragma unroll
+      for (int e = 0; e < EPL; ++e) o[e] *= inv;
+    }
+    Vec16<T>::store(tok + m * D + v * EPL, o);
+  }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void k_unpatchify(const T* __restrict__ tok, T* __restrict__ fmap, TokGeom g, long long nvec) {
+  constexpr int EPL = Vec16<T>::N;
+  const int cv = g.C / EPL;
+  const int D = g.p * g.p * g.C;
+  const int tw = g.ws / g.p;
+  const int S = tw * tw;
+  const int nwx = g.W / g.ws, nwy = g.H / g.ws;
+  for (long long idx = (long long)blockIdx.x * 256 + threadIdx.x; idx < nvec; idx += (long long)gridDim.x * 256) {
+    int v = (int)(idx % (D / EPL));
+    long long m = idx / (D / EPL);
+    int c = (v % cv) * EPL;
+    int ij = v / cv;
+    int i = ij / g.p, j = ij % g.p;
+    int t = (int)(m % S);
+    long long wi = m / S;
+    int wx = (int)(wi % nwx);
+    int wy = (int)((wi / nwx) % nwy);
+    int b = (int)(wi / ((long long)nwx * nwy));
+    int y = wy * g.ws + (t / tw) * g.p + i;
+    int x = wx * g.ws + (t % tw) * g.p + j;
+    typedef typename Mma<T>::frag vec;
+    *reinterpret_cast<vec*>(fmap + (((size_t)b * g.H + y) * g.W + x) * g.cs + c) =
+        *reinterpret_cast<const vec*>(tok + m * D + v * EPL);
+  }
+}
+
+// source index/weight of one bilinear x2 step (align_corners=False): src = max((dst+0.5)/2-0.5, 0)
+CFEN_DEV void up2_src(int dst, int n, int& i0, int& i1, float& w1) {
+  float s = fmaxf(((float)dst + 0.5f) * 0.5f - 0.5f, 0.f);
+  i0 = (int)s;
+  i1 = min(i0 + 1, n - 1);
+  w1 = s - (float)i0;
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void k_upsample4(const T* __restrict__ small, T* __restrict__ out, int B, int h, int w, int C,
+                                                   int cs_in, int cs_out, long long nvec) {
+  constexpr int EPL = Vec16<T>::N;
+  const int cv = C / EPL;
+  const int H = 4 * h, W = 4 * w;
+  for (long long idx = (long long)blockIdx.x * 256 + threadIdx.x; idx < nvec; idx += (long long)gridDim.x * 256) {
+    int c = (int)(idx % cv) * EPL;
+    long long pix = idx / cv;
+    int x = (int)(pix % W);
+    int y = (int)((pix / W) % H);
+    int b = (int)(pix / ((long long)W * H));
+    // second (outer) x2 step reads the 2h x 2w intermediate; first step reads the h x w map
+    int ya[2], xa[2];
+    float wyo, wxo;
+    up2_src(y, 2 * h, ya[0], ya[1], wyo);
+    up2_src(x, 2 * w, xa[0], xa[1], wxo);
+    float acc[EPL];
+#pragma unroll
+    for (int e = 0; e < EPL; ++e) acc[e] = 0.f;
+#pragma unroll
+    for (int a = 0; a < 2; ++a) {
+      int y0, y1;
+      float wy1;
+      up2_src(ya[a], h, y0, y1, wy1);
+      const float wa = a ? wyo : 1.f - wyo;
+#pragma unroll
+      for (int bb = 0; bb < 2; ++bb) {
+        int x0, x1;
+        float wx1;
+        up2_src(xa[bb], w, x0, x1, wx1);
+        const float wb = bb ? wxo : 1.f - wxo;
+        float p00[EPL], p01[EPL], p10[EPL], p11[EPL];
+        const T* base = small + (size_t)b * h * w * cs_in + c;
+        Vec16<T>::load(base + ((size_t)y0 * w + x0) * cs_in, p00);
+        Vec16<T>::load(base + ((size_t)y0 * w + x1) * cs_in, p01);
+        Vec16<T>::load(base + ((size_t)y1 * w + x0) * cs_in, p10);
+        Vec16<T>::load(base + ((size_t)y1 * w + x1) * cs_in, p11);
+#pragma unroll
+        for (int e = 0; e < EPL; ++e) {
+          float top = p00[e] * (1.f - wx1) + p01[e] * wx1;
+          float bot = p10[e] * (1.f - wx1) + p11[e] * wx1;
+          acc[e] += wa * wb * (top * (1.f - wy1) + bot * wy1);
+        }
+      }
+    }
+    Vec16<T>::store(out + (((size_t)b * H + y) * W + x) * cs_out + c, acc);
+  }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void k_nchw_to_nhwc(const float* __restrict__ in, T* __restrict__ out, int B, int C, int H, int W,
+                                                      int cs, long long npix) {
+  constexpr int EPL = Vec16<T>::N;
+  for (long long pix = (long long)blockIdx.x * 256 + threadIdx.x; pix < npix; pix += (long long)gridDim.x * 256) {
+    long long b = pix / ((long long)H * W), r = pix % ((long long)H * W);
+    for (int c0 = 0; c0 < cs; c0 += EPL) {
+      float o[EPL];
+#pragma unroll
+      for (int e = 0; e < EPL; ++e) o[e] = (c0 + e < C) ? in[(b * C + c0 + e) * (long long)H * W + r] : 0.f;
+      Vec16<T>::store(out + pix * cs + c0, o);
+    }
+  }
+}
+
+inline unsigned grid_for(long long n) {
+  long long g = (n + 255) / 256;
+  return (unsigned)(g < 1 ? 1 : (g > 16384 ? 16384 : g));
+}
+
+template <typename T>
+int check_geom(const TokGeom& g, const char* what) {
+  constexpr int EPL = Vec16<T>::N;
+  CFEN_CHECK_ARG(g.B > 0 && g.H > 0 && g.W > 0 && g.C > 0, "%s: empty problem", what);
+  CFEN_CHECK_ARG(g.C % EPL == 0 && g.cs % EPL == 0 && g.cs >= g.C, "%s: C=%d cs=%d must be multiples of %d", what, g.C, g.cs, EPL);
+  CFEN_CHECK_ARG(g.ws > 0 && g.p > 0 && g.ws % g.p == 0 && g.H % g.ws == 0 && g.W % g.ws == 0,
+                 "%s: window %d / patch %d do not tile the %dx%d map", what, g.ws, g.p, g.H, g.W);
+  CFEN_CHECK_ARG(g.pool == 1 || g.pool == 4, "%s: pool must be 1 or 4", what);
+  return CFEN_OK;
+}
+
+template <typename T>
+int run_patchify(const void* fmap, void* tok, TokGeom g, int inverse, hipStream_t s) {
+  int rc = check_geom<T>(g, inverse ? "unpatchify" : "patchify");
+  if (rc) return rc;
+  CFEN_CHECK_ARG(cfen_aligned16(fmap) && cfen_aligned16(tok), "patchify: pointers must be 16-byte aligned");
+  CFEN_CHECK_ARG(!(inverse && g.pool != 1), "unpatchify: pool must be 1");
+  const long long nvec = (long long)g.B * g.H * g.W * g.C / Vec16<T>::N;
+  if (inverse)
+    hipLaunchKernelGGL(k_unpatchify<T>, dim3(grid_for(nvec)), dim3(256), 0, s, (const T*)tok, (T*)fmap, g, nvec);
+  else
+    hipLaunchKernelGGL(k_patchify<T>, dim3(grid_for(nvec)), dim3(256), 0, s, (const T*)fmap, (T*)tok, g, nvec);
+  CFEN_CHECK_LAUNCH("patchify");
+  return CFEN_OK;
+}
+
+}  // namespace
+
+int cfen_patchify_impl(int dtype, const void* fmap, void* tok, int B, int H, int W, int C, int cs, int ws, int p, int pool,
+                       int inverse, hipStream_t s) {
+  TokGeom g{B, H, W, C, cs, ws, p, pool};
+  if (dtype == 1) return run_patchify<half_t>(fmap, tok, g, inverse, s);
+  if (dtype == 0) return run_patchify<float>(fmap, tok, g, inverse, s);
+  cfen_set_error("patchify: unknown dtype %d", dtype);
+  return CFEN_ERR_ARG;
+}
+
+int cfen_upsample4_impl(int dtype, const void* small, void* out, int B, int h, int w, int C, int cs_in, int cs_out, hipStream_t s) {
+  CFEN_CHECK_ARG(B > 0 && h > 0 && w > 0 && C > 0, "upsample4: empty problem");
+  CFEN_CHECK_ARG(cfen_aligned16(small) && cfen_aligned16(out), "upsample4: pointers must be 16-byte aligned");
+  if (dtype == 1) {
+    CFEN_CHECK_ARG(C % 8 == 0 && cs_in % 8 == 0 && cs_out % 8 == 0, "upsample4: channels must be multiples of 8");
+    long long nvec = (long long)B * 16 * h * w * (C / 8);
+    hipLaunchKernelGGL(k_upsample4<half_t>, dim3(grid_for(nvec)), dim3(256), 0, s, (const half_t*)small, (half_t*)out, B, h, w, C, cs_in,
+                       cs_out, nvec);
+  } else if (dtype == 0) {
+    CFEN_CHECK_ARG(C % 4 == 0 && cs_in % 4 == 0 && cs_out % 4 == 0, "upsample4: channels must be multiples of 4");
+    long long nvec = (long long)B * 16 * h * w * (C / 4);
+    hipLaunchKernelGGL(k_upsample4<float>, dim3(grid_for(nvec)), dim3(256), 0, s, (const float*)small, (float*)out, B, h, w, C, cs_in,
+                       cs_out, nvec);
+  } else {
+    cfen_set_error("upsample4: unknown dtype %d", dtype);
+    return CFEN_ERR_ARG;
+  }
+  CFEN_CHECK_LAUNCH("upsample4");
+  return CFEN_OK;
+}
+
+int cfen_nchw_to_nhwc_impl(int dtype, const float* in, void* out, int B, int C, int H, int W, int cs, hipStream_t s) {
+  CFEN_CHECK_ARG(B > 0 && C > 0 && H > 0 && W > 0 && cs >= C, "nchw_to_nhwc: bad shape");
+  CFEN_CHECK_ARG(cfen_aligned16(out), "nchw_to_nhwc: output must be 16-byte aligned");
+  long long npix = (long long)B * H * W;
+  if (dtype == 1) {
+    CFEN_CHECK_ARG(cs % 8 == 0, "nchw_to_nhwc: cs must be a multiple of 8");
+    hipLaunchKernelGGL(k_nchw_to_nhwc<half_t>, dim3(grid_for(npix)), dim3(256), 0, s, in, (half_t*)out, B, C, H, W, cs, npix);
+  } else if (dtype == 0) {
+    CFEN_CHECK_ARG(cs % 4 == 0, "nchw_to_nhwc: cs must be a multiple of 4");
+    hipLaunchKernelGGL(k_nchw_to_nhwc<float>, dim3(grid_for(npix)), dim3(256), 0, s, in, (float*)out, B, C, H, W, cs, npix);
+  } else {
+    cfen_set_error("nchw_to_nhwc: unknown dtype %d", dtype);
+    return CFEN_ERR_ARG;
+  }
+  CFEN_CHECK_LAUNCH("nchw_to_nhwc");
+  return CFEN_OK;
+}

@@ -1,0 +1,217 @@
+"""`dec_ipt` -- the v3 generator as an nn.Module whose forward is the HIP launch plan.
+
+Drop-in for the module `define_G(opt, conv)` returns in the reference
+(models/networks_iid_hlgvit_crs_gd4_cfs_v3.py:93-100, class dec_ipt v3:103-1023):
+  * same 958-key state_dict (strict load of real `<epoch>_net_G.pth` files works, including the
+    208.6 M never-used `decoder.*` / `query_embed` parameters, which are kept on the host side only);
+  * `net(x)` with x (B,3,H,W) float32 in [-1,1] returns [xr (B,3,H,W), xs (B,1,H,W), xd (B,3,H,W)] float32.
+The arithmetic runs entirely in libcfen_hip.so (csrc/cfen_net.cpp); this class owns parameters,
+packed device copies, the workspace and one C `cfen_net` per batch size.
+"""
+import ctypes
+
+import torch
+from torch import nn
+
+from . import _lib
+from ._lib import CfenError, NetConfigC, check, ptr, current_stream
+from .config import NetConfig, config_from_opt
+from .manifest import state_manifest, _is_dead
+from .packing import pack_state_dict
+
+_DTYPES = {"fp16": torch.float16, "half": torch.float16, "fp32": torch.float32, "single": torch.float32,
+           torch.float16: torch.float16, torch.float32: torch.float32}
+
+
+class _Node(nn.Module):
+    """Anonymous container so dotted reference keys map onto a real module tree."""
+
+
+def _build_tree(root, manifest, materialize_dead):
+    for key, shape, dt in manifest:
+        parts = key.split(".")
+        mod = root
+        for p in parts[:-1]:
+            if not hasattr(mod, p):
+                mod.add_module(p, _Node())
+            mod = getattr(mod, p)
+        if dt == torch.int64:
+            if key.endswith("position_ids"):
+                mod.register_buffer(parts[-1], torch.arange(shape[1]).expand(1, -1).clone())
+            else:
+                mod.register_buffer(parts[-1], torch.tensor(0))            # ActNorm `initialized` (models/actnorm.py:16)
+        else:
+            dead = _is_dead(key)
+            t = torch.zeros(shape) if (materialize_dead or not dead) else torch.zeros(shape)
+            mod.register_parameter(parts[-1], nn.Parameter(t, requires_grad=False))
+
+
+class dec_ipt(nn.Module):
+    def __init__(self, opt, conv=None, compute_dtype="fp16"):
+        super().__init__()
+        self.opt = opt
+        self.cfg = config_from_opt(opt) if not isinstance(opt, NetConfig) else opt
+        self.scale_idx = 0
+        self.compute_dtype = _DTYPES[compute_dtype]
+        _build_tree(self, state_manifest(self.cfg), True)
+        self._packed = None          # {name: device tensor}
+        self._nets = {}              # batch -> (handle, workspace tensor)
+        self._last = None
+
+    # ---- parameter management ---------------------------------------------------------------
+    def load_state_dict(self, state_dict, strict=True, **kw):
+        r = super().load_state_dict(state_dict, strict=strict, **kw)
+        self.invalidate()
+        return r
+
+    def invalidate(self):
+        """Call after mutating parameters in place; packed copies are rebuilt at the next forward."""
+        self._packed = None
+        self._free_nets()
+
+    def _free_nets(self):
+        lib = _lib.load() if self._nets else None
+        for h, _ in self._nets.values():
+            lib.cfen_net_destroy(h)
+        self._nets = {}
+        self._last = None
+
+    def __del__(self):
+        try:
+            self._free_nets()
+        except Exception:
+            pass
+
+    def set_compute_dtype(self, dtype):
+        self.compute_dtype = _DTYPES[dtype]
+        self.invalidate()
+
+    def _live_state(self, device):
+        sd = {}
+        for k, v in self.state_dict().items():
+            if not _is_dead(k):
+                sd[k] = v.detach().to(device)
+        return sd
+
+    def _ensure_packed(self, device):
+        if self._packed is None:
+            packed = pack_state_dict(self._live_state(device), self.cfg, self.compute_dtype)
+            self._packed = {k: v.to(device).contiguous() for k, v in packed.items()}
+        return self._packed
+
+    def _net_for(self, batch, device):
+        if batch in self._nets:
+            return self._nets[batch]
+        lib = _lib.load()
+        packed = self._ensure_packed(device)
+        c = self.cfg
+        cc = NetConfigC(batch=batch, n_feats=c.n_feats, hidden_dim_ratio=c.hidden_dim_ratio, patch_size=c.patch_size,
+                        load_size=c.load_size, num_heads=c.num_heads, dtype=_lib.dtype_code(self.compute_dtype), reserved=0)
+        h = ctypes.c_void_p()
+        check(lib.cfen_net_create(ctypes.byref(h), ctypes.byref(cc)), "cfen_net_create")
+        for name, t in packed.items():
+            check(lib.cfen_net_set_param(h, name.encode(), ptr(t), t.numel() * t.element_size()), "cfen_net_set_param(%s)" % name)
+        buf = ctypes.create_string_buffer(4096)
+        if lib.cfen_net_missing_params(h, buf, 4096):
+            raise CfenError("packed parameters missing: " + buf.value.decode())
+        ws = torch.empty(lib.cfen_net_workspace_bytes(h), dtype=torch.uint8, device=device)
+        self._nets[batch] = (h, ws)
+        return self._nets[batch]
+
+    # ---- forward ----------------------------------------------------------------------------
+    def forward(self, x):
+        if not x.is_cuda:
+            raise CfenError("the HIP generator needs a CUDA(HIP) tensor; there is no CPU fallback (got %s)" % x.device)
+        n = self.cfg.image_size
+        if x.dim() != 4 or x.shape[1] != self.cfg.n_colors or x.shape[2] != n or x.shape[3] != n:
+            raise RuntimeError("input must be (B,%d,%d,%d) for --loadSize %d --patch_size %d (image size is baked into the "
+                               "network, reference v3:1186); got %s" % (self.cfg.n_colors, n, n, self.cfg.load_size,
+                                                                       self.cfg.patch_size, tuple(x.shape)))
+        x = x.contiguous().float()
+        B = x.shape[0]
+        h, ws = self._net_for(B, x.device)
+        xr = torch.empty(B, 3, n, n, dtype=torch.float32, device=x.device)
+        xs = torch.empty(B, 1, n, n, dtype=torch.float32, device=x.device)
+        xd = torch.empty(B, 3, n, n, dtype=torch.float32, device=x.device)
+        check(_lib.load().cfen_net_forward(h, ptr(x), ptr(xr), ptr(xs), ptr(xd), ptr(ws), ws.numel(), current_stream()), "cfen_net_forward")
+        self._last = B
+        return [xr, xs, xd]
+
+    def set_scale(self, scale_idx):
+        self.scale_idx = scale_idx
+
+    # ---- introspection (parity tests, roofline) -----------------------------------------------
+    def stage(self, name):
+        """NCHW float32 copy of a top-level stage output of the last forward (SURVEY Appendix D names)."""
+        if self._last is None:
+            raise CfenError("no forward has run")
+        h, ws = self._nets[self._last]
+        p = ctypes.c_void_p()
+        C, cs, H, W = (ctypes.c_int32() for _ in range(4))
+        check(_lib.load().cfen_net_stage(h, name.encode(), ctypes.byref(p), ctypes.byref(C), ctypes.byref(cs), ctypes.byref(H),
+                                         ctypes.byref(W)), "cfen_net_stage")
+        esz = 2 if self.compute_dtype == torch.float16 else 4
+        off = p.value - ws.data_ptr()
+        n = self._last * H.value * W.value * cs.value
+        flat = ws[off:off + n * esz].view(self.compute_dtype)
+        return flat.view(self._last, H.value, W.value, cs.value)[..., :C.value].permute(0, 3, 1, 2).float().contiguous()
+
+    def flops_per_image(self):
+        if not self._nets:
+            raise CfenError("no net instantiated yet")
+        h, _ = next(iter(self._nets.values()))
+        return float(_lib.load().cfen_net_flops_per_image(h))
+
+
+def init_weights(net, init_type="kaiming", gain=0.02, seed=None):
+    """Counterpart of init_weights (v3:49-74) + nn defaults for what it leaves alone.  Conv/Linear
+    weights: `init_type`; their biases 0; LayerNorm 1/0; MHA in_proj kaiming_uniform(a=sqrt(5)) (v3:1377);
+    embeddings N(0,1).  ActNorm stays uninitialised (`initialized` = 0) exactly like the reference."""
+    import math
+    g = torch.Generator()
+    if seed is not None:
+        g.manual_seed(seed)
+    with torch.no_grad():
+        for k, p in net.named_parameters():
+            leaf = k.rsplit(".", 1)[-1]
+            if k.startswith(("sub_mean", "add_mean")):
+                continue
+            if p.dim() >= 2:
+                fan_in = p[0].numel()
+                if ".pe.weight" in k or "query_embed" in k:
+                    p.copy_(torch.randn(p.shape, generator=g))
+                elif "in_proj_weight" in k:
+                    b = 1.0 / math.sqrt(fan_in)
+                    p.copy_((torch.rand(p.shape, generator=g) * 2 - 1) * b)
+                elif init_type == "kaiming":
+                    p.copy_(torch.randn(p.shape, generator=g) * math.sqrt(2.0 / fan_in))
+                elif init_type == "normal":
+                    p.copy_(torch.randn(p.shape, generator=g) * gain)
+                elif init_type == "xavier":
+                    fan_out = p.shape[0] * (p[0][0].numel() if p.dim() > 2 else 1)
+                    p.copy_(torch.randn(p.shape, generator=g) * gain * math.sqrt(2.0 / (fan_in + fan_out)))
+                elif init_type == "orthogonal":
+                    nn.init.orthogonal_(p, gain=gain)
+                else:
+                    raise NotImplementedError("initialization method [%s] is not implemented" % init_type)
+            elif ".norm" in k:
+                p.fill_(1.0 if leaf == "weight" else 0.0)
+            elif leaf == "bias":
+                p.zero_()
+    print("initialize network with %s" % init_type)
+    if hasattr(net, "invalidate"):
+        net.invalidate()
+
+
+def define_G(opt, conv=None, compute_dtype=None):
+    """Counterpart of define_G/init_net (v3:93-100, 77-83): build, move to GPU, initialise.  Multi-GPU
+    is one process per GPU (parallel.py), not nn.DataParallel, so gpu_ids[0] is the only device used."""
+    if compute_dtype is None:
+        compute_dtype = {"single": "fp32", "half": "fp16"}.get(getattr(opt, "precision", "half"), "fp16")
+    net = dec_ipt(opt, conv, compute_dtype=compute_dtype)
+    gpu_ids = getattr(opt, "gpu_ids", [])
+    if len(gpu_ids) > 0:
+        assert torch.cuda.is_available()
+        net.to(gpu_ids[0])
+    init_weights(net, getattr(opt, "init_type", "kaiming"))
+    return net

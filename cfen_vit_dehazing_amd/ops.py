@@ -1,0 +1,146 @@
+"""Python handles on the individual HIP operators of libcfen_hip.so (tensors in, tensors out).
+
+Used by the parity tests and by anyone who wants one fused block instead of the whole generator.
+Every function launches on torch's current CUDA(=HIP) stream and raises CfenError on failure; there
+is no PyTorch fallback.
+"""
+import ctypes
+
+import torch
+
+from . import _lib
+from ._lib import ptr, check, dtype_code, current_stream, ConvArgsC
+from .packing import round_up
+
+
+def _cuda(*ts):
+    for t in ts:
+        if t is not None and (not t.is_cuda or not t.is_contiguous()):
+            raise ValueError("HIP operators need contiguous CUDA tensors")
+
+
+def gemm_nt(x, w, bias=None, residual=None, pos=None, relu=False, out=None):
+    """act(x @ w.T + bias) + residual + pos[row % len(pos)]   (x: [M,K], w: [N,K])"""
+    _cuda(x, w, bias, residual, pos, out)
+    M, K = x.shape
+    N = w.shape[0]
+    if out is None:
+        out = torch.empty(M, N, dtype=x.dtype, device=x.device)
+    lib = _lib.load()
+    check(lib.cfen_gemm_nt(dtype_code(x.dtype), ptr(x), K, ptr(w), K, ptr(bias), ptr(residual), N, ptr(pos),
+                           pos.shape[0] if pos is not None else 0, ptr(out), N, M, N, K, int(relu), current_stream()), "gemm_nt")
+    return out
+
+
+def layernorm(x, gamma, beta, eps=1e-5):
+    _cuda(x, gamma, beta)
+    out = torch.empty_like(x)
+    check(_lib.load().cfen_layernorm(dtype_code(x.dtype), ptr(x), ptr(out), ptr(gamma), ptr(beta), x.shape[0], x.shape[1], eps,
+                                     current_stream()), "layernorm")
+    return out
+
+
+def attention(qkv, nseq, S, heads):
+    """qkv: [nseq*S, 3*D] -> [nseq*S, D]"""
+    _cuda(qkv)
+    D = qkv.shape[1] // 3
+    out = torch.empty(qkv.shape[0], D, dtype=qkv.dtype, device=qkv.device)
+    check(_lib.load().cfen_attention(dtype_code(qkv.dtype), ptr(qkv), ptr(out), nseq, S, heads, D // heads, current_stream()), "attention")
+    return out
+
+
+def patchify(fmap, C, ws, p, pool=1):
+    """fmap: NHWC [B,Hf,Wf,cs] -> tokens [B*nwin*S, p*p*C] in (i,j,c) feature order."""
+    _cuda(fmap)
+    B, Hf, Wf, cs = fmap.shape
+    H, W = Hf // pool, Wf // pool
+    tok = torch.empty(B * H * W // (p * p), p * p * C, dtype=fmap.dtype, device=fmap.device)
+    check(_lib.load().cfen_patchify(dtype_code(fmap.dtype), ptr(fmap), ptr(tok), B, H, W, C, cs, ws, p, pool, current_stream()), "patchify")
+    return tok
+
+
+def unpatchify(tok, B, H, W, C, cs, ws, p):
+    _cuda(tok)
+    fmap = torch.zeros(B, H, W, cs, dtype=tok.dtype, device=tok.device)
+    check(_lib.load().cfen_unpatchify(dtype_code(tok.dtype), ptr(tok), ptr(fmap), B, H, W, C, cs, ws, p, current_stream()), "unpatchify")
+    return fmap
+
+
+def upsample4(small, cs_out=None):
+    _cuda(small)
+    B, h, w, cs_in = small.shape
+    cs_out = cs_out or cs_in
+    out = torch.zeros(B, 4 * h, 4 * w, cs_out, dtype=small.dtype, device=small.device)
+    check(_lib.load().cfen_upsample4(dtype_code(small.dtype), ptr(small), ptr(out), B, h, w, cs_in, cs_in, cs_out, current_stream()), "upsample4")
+    return out
+
+
+def nchw_to_nhwc(x, cs, dtype):
+    _cuda(x)
+    B, C, H, W = x.shape
+    out = torch.empty(B, H, W, cs, dtype=dtype, device=x.device)
+    check(_lib.load().cfen_nchw_to_nhwc(dtype_code(dtype), ptr(x), ptr(out), B, C, H, W, cs, current_stream()), "nchw_to_nhwc")
+    return out
+
+
+def conv2d(src0, weight, scale, shift, cin, cout, k=3, stride=1, pad=1, reflect=False, src1=None, transpose=False, act=0,
+           res0=None, res1=None, cs_out=None, nchw_f32=False):
+    """src*: NHWC [B,H,W,cs]; weight/scale/shift packed by packing.pack_conv*_weight / affine."""
+    _cuda(src0, src1, weight, scale, shift, res0, res1)
+    B, Hin, Win, cs_in = src0.shape
+    cout_pad = round_up(cout, 16)
+    if transpose:
+        Hout, Wout = 2 * Hin, 2 * Win
+    else:
+        Hout, Wout = (Hin + 2 * pad - k) // stride + 1, (Win + 2 * pad - k) // stride + 1
+    if nchw_f32:
+        out = torch.empty(B, cout, Hout, Wout, dtype=torch.float32, device=src0.device)
+        cs_out = cout_pad
+    else:
+        cs_out = cs_out or round_up(cout, 8)
+        out = torch.zeros(B, Hout, Wout, cs_out, dtype=src0.dtype, device=src0.device)
+    a = ConvArgsC(kind=1 if transpose else 0, k=k, stride=stride, pad=pad, reflect=int(reflect), nsrc=2 if src1 is not None else 1,
+                  B=B, Hin=Hin, Win=Win, Cin=cin, cs_in=cs_in, Cout=cout, Cout_pad=cout_pad, Kpad=weight.shape[-1], cs_out=cs_out,
+                  act=act, out_nchw_f32=int(nchw_f32), cs_res=cs_out,
+                  src0=src0.data_ptr(), src1=src1.data_ptr() if src1 is not None else None, weight=weight.data_ptr(),
+                  scale=scale.data_ptr(), shift=shift.data_ptr(), res0=res0.data_ptr() if res0 is not None else None,
+                  res1=res1.data_ptr() if res1 is not None else None, out=out.data_ptr())
+    check(_lib.load().cfen_conv2d(dtype_code(src0.dtype), ctypes.byref(a), current_stream()), "conv2d")
+    return out
+
+
+def _stats_ws(B, device):
+    n = _lib.load().cfen_stats_workspace(B, 128)
+    return torch.empty(n // 4, dtype=torch.float32, device=device)
+
+
+def instnorm_relu_(x, C, eps=1e-5):
+    """in place on NHWC [B,H,W,cs]"""
+    _cuda(x)
+    B, H, W, cs = x.shape
+    ws = _stats_ws(B, x.device)
+    check(_lib.load().cfen_instnorm_relu(dtype_code(x.dtype), ptr(x), ptr(ws), B, H * W, C, cs, eps, current_stream()), "instnorm_relu")
+    return x
+
+
+def cfsm2g(x0, x1, x2, w, C):
+    _cuda(x0, x1, x2, w)
+    B, H, W, cs = x0.shape
+    out = torch.zeros_like(x0)
+    ws = _stats_ws(B, x0.device)
+    check(_lib.load().cfen_cfsm2g(dtype_code(x0.dtype), ptr(x0), ptr(x1), ptr(x2), ptr(out), ptr(w), ptr(ws), B, H * W, C, cs,
+                                  current_stream()), "cfsm2g")
+    return out
+
+
+def to_nhwc(x, cs=None, dtype=None):
+    """NCHW torch tensor -> zero-padded NHWC (test helper; plain torch, not on the product path)."""
+    B, C, H, W = x.shape
+    cs = cs or round_up(C, 8)
+    out = torch.zeros(B, H, W, cs, dtype=dtype or x.dtype, device=x.device)
+    out[..., :C] = x.permute(0, 2, 3, 1)
+    return out
+
+
+def from_nhwc(x, C):
+    return x[..., :C].permute(0, 3, 1, 2).contiguous()

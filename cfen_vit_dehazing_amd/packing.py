@@ -1,0 +1,173 @@
+"""One-time repack of a reference-keyed state_dict into the layouts the HIP kernels read.
+
+Input: the 958-key state_dict of `dec_ipt` (reference models/networks_iid_hlgvit_crs_gd4_cfs_v3.py:104-388,
+saved by models/base_model.py:89-101).  Output: {packed name: tensor} with the names/sizes
+csrc/cfen_net.cpp expects.  The never-called `decoder.*`, `query_embed`, `sub_mean`, `add_mean`
+tensors (208.6 M parameters) are dropped here.
+
+Layout choices:
+  * token features are ordered (i, j, c) instead of F.unfold's (c, i, j) (v3:1140): every weight axis
+    that lives in the D-sized residual stream is permuted with `token_perm`, so patchify/unpatchify
+    are contiguous 16-byte copies of NHWC pixels;
+  * conv weights are [phase][Cout_pad][K], K = tap*Cin + c zero-padded to the MFMA chunk, channels
+    padded to the map's channel stride; ConvTranspose2d(4,2,1) is split into its 4 output-parity phases;
+  * conv bias and ActNorm2d (models/actnorm.py:39-42, y = (x + b) * exp(w)) fold into one fp32
+    per-channel (scale, shift) pair.
+"""
+import torch
+
+from .config import NetConfig, BRANCHES
+
+
+def round_up(v, m):
+    return (v + m - 1) // m * m
+
+
+def cs_of(c):
+    return round_up(c, 8)
+
+
+def token_perm(C, p):
+    """perm[f_new] = f_ref with f_new = (i*p + j)*C + c and f_ref = c*p*p + i*p + j."""
+    return torch.arange(C * p * p).view(C, p * p).t().reshape(-1)
+
+
+def pack_vit(sd, g, dtype):
+    n = g.name
+    perm = token_perm(g.channels, g.patch)
+    e = n + ".encoder.layers.0"
+    f32 = torch.float32
+    out = {
+        n + ".embed.w": sd[n + ".linear_encoding.weight"][perm][:, perm].to(dtype),
+        n + ".embed.b": sd[n + ".linear_encoding.bias"][perm].to(f32),
+        n + ".pos": sd[n + ".position_encoding.pe.weight"][:g.seq][:, perm].to(dtype),
+        n + ".ln1.g": sd[e + ".norm1.weight"][perm].to(f32), n + ".ln1.b": sd[e + ".norm1.bias"][perm].to(f32),
+        n + ".qkv.w": sd[e + ".self_attn.in_proj_weight"][:, perm].to(dtype),
+        n + ".proj.w": sd[e + ".self_attn.out_proj.weight"][perm].to(dtype),
+        n + ".ln2.g": sd[e + ".norm2.weight"][perm].to(f32), n + ".ln2.b": sd[e + ".norm2.bias"][perm].to(f32),
+        n + ".ffn1.w": sd[e + ".linear1.weight"][:, perm].to(dtype), n + ".ffn1.b": sd[e + ".linear1.bias"].to(f32),
+        n + ".ffn2.w": sd[e + ".linear2.weight"][perm].to(dtype), n + ".ffn2.b": sd[e + ".linear2.bias"][perm].to(f32),
+        n + ".head1.w": sd[n + ".mlp_head.0.weight"][:, perm].to(dtype), n + ".head1.b": sd[n + ".mlp_head.0.bias"].to(f32),
+        n + ".head2.w": sd[n + ".mlp_head.3.weight"][perm].to(dtype), n + ".head2.b": sd[n + ".mlp_head.3.bias"][perm].to(f32),
+    }
+    return out
+
+
+def pack_conv_weight(w, cin_pad, kc, dtype):
+    """Conv2d weight (Cout, Cin_total, k, k) with Cin_total = nsrc*Cin -> [1][Cout_pad][Kpad]; taps are
+    (src, ky, kx) so a 1x1 conv over a concat keeps its natural channel order."""
+    cout, cin_total, k, _ = w.shape
+    if k == 1:
+        nsrc_cin = cin_total                                   # concat sources are unpadded (C % 8 == 0)
+        flat = w.reshape(cout, nsrc_cin)
+    else:
+        wp = torch.zeros(cout, k, k, cin_pad, dtype=w.dtype, device=w.device)
+        wp[..., :cin_total] = w.permute(0, 2, 3, 1)
+        flat = wp.reshape(cout, k * k * cin_pad)
+    cout_pad, kpad = round_up(cout, 16), round_up(flat.shape[1], kc)
+    out = torch.zeros(1, cout_pad, kpad, dtype=dtype, device=w.device)
+    out[0, :cout, :flat.shape[1]] = flat.to(dtype)
+    return out
+
+
+_KY = ((1, 3), (0, 2))    # [output parity][tap] -> kernel index; input offsets (0,-1),(+1,0): csrc/cfen_conv.hpp
+
+
+def pack_convT_weight(w, cin_pad, kc, dtype):
+    """ConvTranspose2d weight (Cin, Cout, 4, 4) -> [4 phases][Cout_pad][Kpad], K = (ty*2+tx)*Cin + ci."""
+    cin, cout = w.shape[0], w.shape[1]
+    cout_pad, kpad = round_up(cout, 16), round_up(4 * cin_pad, kc)
+    out = torch.zeros(4, cout_pad, kpad, dtype=dtype, device=w.device)
+    for py in range(2):
+        for px in range(2):
+            for ty in range(2):
+                for tx in range(2):
+                    t = ty * 2 + tx
+                    out[py * 2 + px, :cout, t * cin_pad:t * cin_pad + cin] = w[:, :, _KY[py][ty], _KY[px][tx]].t().to(dtype)
+    return out
+
+
+def affine(bias, an_w=None, an_b=None, cout_pad=None):
+    """(scale, shift) so that y = acc*scale + shift == ActNorm(conv + bias)."""
+    bias = bias.float()
+    if an_w is None:
+        scale, shift = torch.ones_like(bias), bias
+    else:
+        scale = torch.exp(an_w.float())
+        shift = (bias + an_b.float()) * scale
+    s = torch.zeros(cout_pad, dtype=torch.float32, device=bias.device)
+    t = torch.zeros(cout_pad, dtype=torch.float32, device=bias.device)
+    s[:bias.numel()], t[:bias.numel()] = scale, shift
+    return s, t
+
+
+def _check_actnorm(sd, prefix):
+    if int(sd[prefix + ".initialized"]) != 1:
+        raise NotImplementedError(
+            "ActNorm2d '%s' is not initialised (models/actnorm.py:25-37 would fill it from the first batch); "
+            "load a checkpoint or call init_actnorm_from_data() first" % prefix)
+
+
+def pack_state_dict(sd, cfg: NetConfig, dtype=torch.float16):
+    """reference state_dict (tensors on any one device) -> packed tensors on the same device."""
+    kc = 32 if dtype == torch.float16 else 16
+    nf, h = cfg.n_feats, cfg.n_feats // 2
+    out = {}
+    for g in cfg.vit_instances():
+        out.update(pack_vit(sd, g, dtype))
+
+    def conv(name, key, cin, an=None):
+        w = sd[key + ".weight"]
+        cp = round_up(w.shape[0], 16)
+        out[name + ".w"] = pack_conv_weight(w, cs_of(cin), kc, dtype)
+        if an:
+            _check_actnorm(sd, an)
+            s, t = affine(sd[key + ".bias"], sd[an + ".weight"], sd[an + ".bias"], cp)
+        else:
+            s, t = affine(sd[key + ".bias"], cout_pad=cp)
+        out[name + ".scale"], out[name + ".shift"] = s, t
+
+    def convT(name, key, cin, an=None):
+        w = sd[key + ".weight"]
+        cp = round_up(w.shape[1], 16)
+        out[name + ".w"] = pack_convT_weight(w, cs_of(cin), kc, dtype)
+        if an:
+            _check_actnorm(sd, an)
+            s, t = affine(sd[key + ".bias"], sd[an + ".weight"], sd[an + ".bias"], cp)
+        else:
+            s, t = affine(sd[key + ".bias"], cout_pad=cp)
+        out[name + ".scale"], out[name + ".shift"] = s, t
+
+    conv("head.0.0", "head.0.0", 3)
+    conv("head.0.1.body.0", "head.0.1.body.0", h)
+    conv("head.0.1.body.2", "head.0.1.body.2", h)
+    conv("ds_conv_e01", "ds_conv_e01.0", h)
+    conv("ds_conv_e02", "ds_conv_e02.0", nf)
+    conv("ds_conv_e03", "ds_conv_e03.0", 2 * nf)
+    for l in (1, 2, 3):
+        n = "lgcat_conv_e0%d" % l
+        conv(n, n + ".0", nf << (l - 1), an=n + ".1")
+    for b in BRANCHES:
+        for l in (1, 2, 3):
+            n = "lgcat_conv_d0%d%s" % (l, b)
+            conv(n, n + ".0", nf << (l - 1), an=n + ".1")
+        convT("us_conv_d03" + b, "us_conv_d03%s.0" % b, 4 * nf)
+        convT("us_conv_d02" + b, "us_conv_d02%s.0" % b, 2 * nf, an="us_conv_d02%s.1" % b)
+        convT("us_conv_d01" + b, "us_conv_d01%s.0" % b, nf, an="us_conv_d01%s.1" % b)
+        if b != "d":
+            conv("sk_conv_d03" + b, "sk_conv_d03%s.0" % b, 2 * nf, an="sk_conv_d03%s.1" % b)
+            conv("sk_conv_d02" + b, "sk_conv_d02%s.0" % b, nf, an="sk_conv_d02%s.1" % b)
+        T = "tail_" + b.upper()
+        if b == "s":
+            conv(T + ".conv3", T + ".0.1", h)
+            conv(T + ".conv7", T + ".0.4", h)
+        else:
+            conv(T + ".conv3", T + ".0.1", h, an=T + ".0.2")
+            conv(T + ".conv7", T + ".0.5", h)
+    for n in ("cfsm2g_d03d", "cfsm2g_d02d"):
+        parts = []
+        for fc in ("fc_avg_cf1", "fc_avg_cf2", "fc_max_cf1", "fc_max_cf2"):
+            parts.append(sd["%s.0.%s.0.weight" % (n, fc)].float().reshape(-1))
+            parts.append(sd["%s.0.%s.2.weight" % (n, fc)].float().reshape(-1))
+        out[n + ".w"] = torch.cat(parts)
+    return {k: v.contiguous() for k, v in out.items()}

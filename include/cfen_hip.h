@@ -1,0 +1,130 @@
+/* cfen_hip.h -- C ABI of the MI355X-native CFEN-ViT dehazing inference path (libcfen_hip.so).
+ *
+ * Drop-in boundary for the generator forward of phoenixtreesky7/CFEN-ViT-Dehazing
+ *   models/networks_iid_hlgvit_crs_gd4_cfs_v3.py:392-1020   dec_ipt.forward
+ * called by the reference at models/model_iid_dehazing.py:143 (`self.netG(self.real_B)`), plus the
+ * standalone deformable-convolution operator of dcn/src/deform_conv_cuda.cpp.
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer on the current HIP device unless stated otherwise;
+ *   - `dtype` selects storage + MFMA input type: CFEN_F32 (exact fp32 MFMA) or CFEN_F16 (fp16 storage,
+ *     fp32 accumulate); biases / norm parameters / affine tables are always fp32;
+ *   - feature maps are NHWC with an explicit channel stride `cs`; token matrices are row-major;
+ *   - all functions are asynchronous on `stream` (a hipStream_t passed as void*), allocate nothing,
+ *     return 0 on success or a negative CFEN_ERR_* code; cfen_last_error() gives the message.
+ *   - no exceptions cross this boundary.
+ */
+#ifndef CFEN_HIP_H
+#define CFEN_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define CFEN_F32 0
+#define CFEN_F16 1
+
+#define CFEN_OK 0
+#define CFEN_ERR_ARG (-1)   /* invalid argument / unsupported shape      */
+#define CFEN_ERR_HIP (-2)   /* HIP runtime reported an error             */
+#define CFEN_ERR_STATE (-3) /* missing parameter, workspace too small... */
+
+int cfen_abi_version(void);
+const char* cfen_last_error(void);
+
+/* ---- whole generator: replaces define_G (v3:93-100) + dec_ipt.forward (v3:392-1020) ------------- */
+typedef struct cfen_net cfen_net;
+
+typedef struct cfen_net_config {
+  int32_t batch;            /* images per forward on this GPU                                   */
+  int32_t n_feats;          /* options/base_options.py:110                                     */
+  int32_t hidden_dim_ratio; /* options/base_options.py:104                                     */
+  int32_t patch_size;       /* LViT window edge in feature-map pixels, base_options.py:96      */
+  int32_t load_size;        /* edge of the half-resolution map xf, base_options.py:16          */
+  int32_t num_heads;        /* base_options.py:192                                             */
+  int32_t dtype;            /* CFEN_F32 | CFEN_F16                                             */
+  int32_t reserved;
+} cfen_net_config;
+
+int cfen_net_create(cfen_net** out, const cfen_net_config* cfg);
+void cfen_net_destroy(cfen_net* net);
+/* bytes of device scratch the caller must pass to cfen_net_forward (256-byte aligned) */
+size_t cfen_net_workspace_bytes(const cfen_net* net);
+/* register one packed parameter (layout: cfen_vit_dehazing_amd/packing.py); the pointer must stay
+ * valid for the life of the net.  `nbytes` is checked against what the layer needs.               */
+int cfen_net_set_param(cfen_net* net, const char* name, const void* dev_ptr, size_t nbytes);
+/* names still missing, written as a ';'-separated list into buf; returns the count                */
+int cfen_net_missing_params(const cfen_net* net, char* buf, size_t buflen);
+/* x: (B,3,H,W) fp32 NCHW in [-1,1];  xr: (B,3,H,W), xs: (B,1,H,W), xd: (B,3,H,W) fp32 NCHW        */
+int cfen_net_forward(cfen_net* net, const float* x, float* xr, float* xs, float* xd, void* workspace, size_t workspace_bytes,
+                     void* stream);
+/* device pointer + geometry of a named top-level stage output (SURVEY Appendix D names) inside the
+ * workspace of the LAST forward; NHWC, element type = net dtype.                                  */
+int cfen_net_stage(const cfen_net* net, const char* name, const void** ptr, int32_t* C, int32_t* cs, int32_t* H, int32_t* W);
+/* 2*MAC count of one forward per image (SURVEY 8d closed form), for roofline reporting             */
+double cfen_net_flops_per_image(const cfen_net* net);
+
+/* ---- individual operators (unit-tested against the oracle; also what cfen_net_forward launches) -- */
+
+/* Y[m][n] = act(sum_k X[m][k] W[n][k] + bias[n]) + R[m][n] + P[m % period][n]      (nn.Linear family) */
+int cfen_gemm_nt(int dtype, const void* X, int ldx, const void* W, int ldw, const float* bias, const void* R, int ldr, const void* P,
+                 int period, void* Y, int ldy, int M, int N, int K, int relu, void* stream);
+/* LayerNorm over the last dim (eps as given), gamma/beta fp32                       (v3:1370-1371) */
+int cfen_layernorm(int dtype, const void* X, void* Y, const float* gamma, const float* beta, int M, int D, float eps, void* stream);
+/* softmax(QK^T/sqrt(dh))V per (sequence, head); QKV is [nseq*S][3*heads*dh], out [nseq*S][heads*dh]  (v3:1364) */
+int cfen_attention(int dtype, const void* qkv, void* out, int nseq, int S, int heads, int dh, void* stream);
+/* window partition + unfold (+ optional 4x4 mean pool) / fold + window join          (v3:1025-1056,1140,1186,1274) */
+int cfen_patchify(int dtype, const void* fmap, void* tokens, int B, int H, int W, int C, int cs, int ws, int p, int pool, void* stream);
+int cfen_unpatchify(int dtype, const void* tokens, void* fmap, int B, int H, int W, int C, int cs, int ws, int p, void* stream);
+/* two successive bilinear x2 upsamples, align_corners=False                           (v3:1323) */
+int cfen_upsample4(int dtype, const void* small, void* out, int B, int h, int w, int C, int cs_in, int cs_out, void* stream);
+int cfen_nchw_to_nhwc(int dtype, const float* in, void* out, int B, int C, int H, int W, int cs, void* stream);
+
+/* Conv2d / ConvTranspose2d(4,2,1) as implicit GEMM with fused affine + activation + residuals.
+ * kind 0: Conv2d(k, stride, pad) over nsrc (1|2) channel-concatenated inputs; kind 1: ConvTranspose2d k4 s2 p1.
+ * weight: packed [nphase][Cout_pad][Kpad] (packing.py); scale/shift: [Cout_pad] fp32.                */
+typedef struct cfen_conv_args {
+  int32_t kind, k, stride, pad, reflect, nsrc;
+  int32_t B, Hin, Win, Cin, cs_in;
+  int32_t Cout, Cout_pad, Kpad, cs_out;
+  int32_t act;            /* 0 none, 1 ReLU, 2 tanh */
+  int32_t out_nchw_f32;   /* write (B,Cout,H,W) fp32 instead of NHWC */
+  int32_t cs_res;
+  const void* src0;
+  const void* src1;
+  const void* weight;
+  const float* scale;
+  const float* shift;
+  const void* res0;
+  const void* res1;
+  void* out;
+} cfen_conv_args;
+int cfen_conv2d(int dtype, const cfen_conv_args* a, void* stream);
+
+size_t cfen_stats_workspace(int B, int C);
+/* InstanceNorm2d(affine=False) + ReLU in place                                        (v3:292-302) */
+int cfen_instnorm_relu(int dtype, void* x, float* stats_ws, int B, int HW, int C, int cs, float eps, void* stream);
+/* CFSM2G: out = x0 + x1*g1 + x2*g2, gates from global avg/max pools of x0+x1+x2          (v3:1481-1517)
+ * w: fp32 [avg_cf1, avg_cf2, max_cf1, max_cf2] x {W0 (C/4 x C), W2 (C x C/4)}                      */
+int cfen_cfsm2g(int dtype, const void* x0, const void* x1, const void* x2, void* out, const float* w, float* stats_ws, int B, int HW,
+                int C, int cs, void* stream);
+
+/* ---- deformable convolution (replaces the pybind module of dcn/src/deform_conv_cuda.cpp:681-695) ---- */
+/* deform_conv_forward_cuda (dcn/src/deform_conv_cuda.cpp:151-156): NCHW tensors; note the reference
+ * passes W before H for kernel/stride/pad/dilation here.  `columns`/`ones` buffers are not needed.  */
+int cfen_deform_conv_forward(int dtype, const void* input, const void* weight, const void* offset, void* output, int B, int Cin, int H,
+                             int W, int Cout, int kW, int kH, int dW, int dH, int padW, int padH, int dilationW, int dilationH, int group,
+                             int deformable_group, int im2col_step, void* stream);
+/* modulated_deform_conv_cuda_forward (dcn/src/deform_conv_cuda.cpp:486-492): h before w; bias may be NULL */
+int cfen_modulated_deform_conv_forward(int dtype, const void* input, const void* weight, const void* bias, const void* offset,
+                                       const void* mask, void* output, int B, int Cin, int H, int W, int Cout, int kernel_h, int kernel_w,
+                                       int stride_h, int stride_w, int pad_h, int pad_w, int dilation_h, int dilation_w, int group,
+                                       int deformable_group, int with_bias, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CFEN_HIP_H */

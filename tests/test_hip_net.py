@@ -1,0 +1,131 @@
+"""GPU parity of the whole generator forward (C ABI cfen_net_forward) against
+  (1) golden vectors produced by the imported reference (tests/golden/net_*.npz), and
+  (2) the CPU oracle run here on the same seeded weights / inputs.
+
+Tolerances (BASELINE.json north_star): fp32 path <= 1e-3 max-abs on the outputs (we hold 2e-4 on every
+stage); fp16 path: PSNR / SSIM of the outputs against a reference target move by <= 0.01 dB / 1e-4
+relative to the fp32 reference outputs."""
+import numpy as np
+import pytest
+import torch
+
+import cfen_oracle
+from cfen_vit_dehazing_amd.config import NetConfig
+from cfen_vit_dehazing_amd.hipnet import dec_ipt
+from cfen_vit_dehazing_amd.manifest import generate_state_dict, synthetic_input
+from helpers import load_net_fixture, check_outputs, check_stages
+
+pytestmark = pytest.mark.gpu
+
+
+def make_net(cfg, dtype, seed=0):
+    net = dec_ipt(cfg, compute_dtype=dtype)
+    net.load_state_dict(generate_state_dict(cfg, seed=seed), strict=True)
+    return net.to("cuda:0")
+
+
+def gpu_stages(net, z):
+    st = {}
+    xf = net.stage("ds_conv_e01")
+    for n in [str(s) for s in z["stage_names"]]:
+        if n.startswith("tail_"):
+            continue
+        t = net.stage(n)
+        if n.startswith("lgcat_conv_d01"):
+            t = t - xf                      # the plan folds `+ xf` (v3:696,852,1008) into this stage's epilogue
+        st[n] = t
+    return st
+
+
+@pytest.mark.parametrize("name", ["tiny_nf24_hdr4", "tiny_nf24_hdr2", "small_nf24_hdr4"])
+def test_fp32_matches_reference_vectors_all_stages(name):
+    cfg, batch, z = load_net_fixture(name)
+    net = make_net(cfg, "fp32")
+    x = synthetic_input(batch, cfg).to("cuda:0")
+    outs = net(x)
+    st = gpu_stages(net, z)
+    for nm, o in zip(("tail_R", "tail_S", "tail_D"), outs):
+        st[nm] = o
+    worst = check_stages(z, st, 2e-4, rel_sum=2e-4)
+    wo = check_outputs(z, outs, 1e-4)
+    print("%s fp32: worst stage sample diff %.2e, outputs %.2e" % (name, worst, wo))
+
+
+def test_fp32_full512_matches_reference_vectors():
+    cfg, batch, z = load_net_fixture("full512_nf24_hdr4")
+    net = make_net(cfg, "fp32")
+    outs = net(synthetic_input(batch, cfg).to("cuda:0"))
+    st = gpu_stages(net, z)
+    for nm, o in zip(("tail_R", "tail_S", "tail_D"), outs):
+        st[nm] = o
+    check_stages(z, st, 3e-4, rel_sum=2e-4)
+    wo = check_outputs(z, outs, 1e-4)
+    assert wo <= 1e-3                               # the north_star bar
+    print("full512 fp32 outputs max-abs vs reference %.2e" % wo)
+
+
+def test_fp32_hdr2_and_1024_configs():
+    for name in ("full512_nf24_hdr2", "full1024_nf24_hdr4"):
+        cfg, batch, z = load_net_fixture(name)
+        net = make_net(cfg, "fp32")
+        outs = net(synthetic_input(batch, cfg).to("cuda:0"))
+        check_outputs(z, outs, 2e-4)
+        del net
+        torch.cuda.empty_cache()
+
+
+def _psnr_ssim_delta(ref_outs, got_outs, target):
+    res = []
+    for r, g in zip(ref_outs, got_outs):
+        t = target[:, :r.shape[1]]
+        res.append((abs(cfen_oracle.psnr(r, t) - cfen_oracle.psnr(g, t)), abs(cfen_oracle.ssim(r, t) - cfen_oracle.ssim(g, t)),
+                    cfen_oracle.psnr(r, g), float((r - g).abs().max())))
+    return res
+
+
+@pytest.mark.parametrize("name", ["tiny_nf24_hdr4", "small_nf24_hdr4"])
+def test_fp16_psnr_ssim_against_oracle(name):
+    cfg, batch, z = load_net_fixture(name)
+    sd = generate_state_dict(cfg, seed=0, with_dead=False)
+    x = synthetic_input(batch, cfg)
+    with torch.no_grad():
+        ref = cfen_oracle.forward(sd, x, cfg.num_heads, cfg.patch_size)
+    net = make_net(cfg, "fp16")
+    got = [o.cpu() for o in net(x.to("cuda:0"))]
+    # "ground truth" stand-in: the (clean) input itself; what matters is that both outputs score the same
+    for dp, ds, p, mx in _psnr_ssim_delta(ref, got, x):
+        print("%s fp16: dPSNR %.4f dB, dSSIM %.2e, PSNR(fp16 vs ref) %.1f dB, max-abs %.2e" % (name, dp, ds, p, mx))
+        assert dp <= 0.01 and ds <= 1e-4
+        assert p >= 50.0 and mx <= 3e-2
+
+
+def test_fp16_full512_against_reference_vectors():
+    cfg, batch, z = load_net_fixture("full512_nf24_hdr4")
+    net = make_net(cfg, "fp16")
+    outs = net(synthetic_input(batch, cfg).to("cuda:0"))
+    worst = check_outputs(z, outs, 3e-2)
+    print("full512 fp16 outputs max-abs vs reference %.2e" % worst)
+    for nm, o in zip(("xr", "xs", "xd"), outs):
+        stat = z["stat/" + nm]
+        assert abs(float(o.mean()) - stat[0]) < 2e-3 and abs(float(o.std()) - stat[1]) < 2e-3
+
+
+def test_batch_invariance_and_determinism():
+    cfg = NetConfig(24, 4, patch_size=8, load_size=64)
+    net = make_net(cfg, "fp32")
+    x = synthetic_input(3, cfg).to("cuda:0")
+    a = [o.clone() for o in net(x)]
+    b = [o.clone() for o in net(x)]
+    one = net(x[2:3])
+    for u, v, w in zip(a, b, one):
+        assert torch.equal(u, v)                                  # bitwise reproducible
+        assert float((u[2:3] - w).abs().max()) <= 1e-5            # sharding the batch does not change results
+
+
+def test_wrong_input_size_raises():
+    cfg = NetConfig(24, 4, patch_size=8, load_size=64)
+    net = make_net(cfg, "fp32")
+    with pytest.raises(RuntimeError):
+        net(torch.zeros(1, 3, 64, 64, device="cuda:0"))
+    with pytest.raises(Exception):
+        net(torch.zeros(1, 3, 128, 128))                          # CPU tensor: no fallback

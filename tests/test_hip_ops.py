@@ -1,0 +1,250 @@
+"""GPU parity of every HIP operator (called through the C ABI) against the CPU oracle / float64 math.
+
+Tolerances: CFEN_F32 runs exact-fp32 MFMA -> 2e-5 * scale; CFEN_F16 stores fp16 and accumulates fp32 ->
+inputs are rounded to fp16 first and the result may differ by fp16 output rounding (2^-10 relative)."""
+import math
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+import cfen_oracle
+from cfen_vit_dehazing_amd import ops, packing
+
+pytestmark = pytest.mark.gpu
+DTYPES = [torch.float32, torch.float16]
+
+
+def dev():
+    return torch.device("cuda:0")
+
+
+def tol(dtype, scale=1.0):
+    return (3e-5 if dtype == torch.float32 else 3e-3) * scale
+
+
+def rnd(shape, seed, dtype, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return (torch.randn(shape, generator=g) * scale).to(dtype)
+
+
+def close(got, want, atol, what=""):
+    d = float((got.double().cpu() - want.double().cpu()).abs().max())
+    assert d <= atol, "%s max-abs %.3e > %.1e" % (what, d, atol)
+    return d
+
+
+# ---------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_gemm_exact_integers_asymmetric(dtype):
+    # exact in both dtypes: catches any transposed / permuted fragment mapping
+    M, N, K = 37, 48, 64
+    x = (torch.arange(M * K).view(M, K) % 7 - 3).to(dtype)
+    w = ((torch.arange(N * K).view(N, K) * 5) % 11 - 5).to(dtype)
+    y = ops.gemm_nt(x.to(dev()), w.to(dev()))
+    assert torch.equal(y.float().cpu(), x.float() @ w.float().t())
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("M,N,K", [(16, 96, 96), (100, 288, 96), (300, 128, 192), (128, 384, 1536), (257, 96, 384), (2048, 768, 192)])
+def test_gemm_epilogues(dtype, M, N, K):
+    x, w = rnd((M, K), 1, dtype), rnd((N, K), 2, dtype, 1 / math.sqrt(K))
+    bias = rnd((N,), 3, torch.float32)
+    res = rnd((M, N), 4, dtype)
+    S = 16
+    pos = rnd((S, N), 5, dtype)
+    ref = x.double() @ w.double().t()
+    d = dev()
+    close(ops.gemm_nt(x.to(d), w.to(d)), ref, tol(dtype, 4), "plain")
+    want = torch.relu(ref + bias.double()) + res.double() + pos.double()[torch.arange(M) % S]
+    got = ops.gemm_nt(x.to(d), w.to(d), bias=bias.to(d), residual=res.to(d), pos=pos.to(d), relu=True)
+    close(got, want, tol(dtype, 8), "bias+relu+res+pos")
+    # in-place residual (Y aliases R), as the transformer block uses it
+    r = res.to(d).clone()
+    ops.gemm_nt(x.to(d), w.to(d), residual=r, out=r)
+    close(r, ref + res.double(), tol(dtype, 8), "in-place residual")
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("M,D", [(5, 96), (64, 192), (33, 384), (16, 1536), (7, 2048)])
+def test_layernorm(dtype, M, D):
+    x = rnd((M, D), 1, dtype, 2.0) + 0.5
+    g, b = 1 + 0.1 * rnd((D,), 2, torch.float32), 0.1 * rnd((D,), 3, torch.float32)
+    want = cfen_oracle.layer_norm(x.double(), g.double(), b.double())
+    close(ops.layernorm(x.to(dev()), g.to(dev()), b.to(dev())), want, tol(dtype, 4))
+
+
+def attn_ref(qkv, nseq, S, heads):
+    D = qkv.shape[1] // 3
+    dh = D // heads
+    q, k, v = qkv.double().view(nseq, S, 3, heads, dh).permute(2, 0, 3, 1, 4)
+    a = torch.softmax(q @ k.transpose(-1, -2) / math.sqrt(dh), -1) @ v
+    return a.transpose(1, 2).reshape(nseq * S, D)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("nseq,S,heads,dh", [(3, 256, 4, 24), (2, 16, 4, 24), (2, 4, 8, 24), (2, 1, 16, 24), (2, 64, 2, 96),
+                                              (1, 256, 4, 96), (3, 100, 2, 32), (1, 1024, 2, 24), (2, 80, 1, 128)])
+def test_attention(dtype, nseq, S, heads, dh):
+    qkv = rnd((nseq * S, 3 * heads * dh), 7, dtype, 1.5)
+    got = ops.attention(qkv.to(dev()), nseq, S, heads)
+    close(got, attn_ref(qkv, nseq, S, heads), tol(dtype, 3))
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_attention_spiky_scores(dtype):
+    # one key dominates late in the sequence: exercises the online-softmax rescale
+    nseq, S, heads, dh = 1, 256, 1, 24
+    qkv = rnd((S, 3 * dh), 11, torch.float32, 0.5)
+    qkv[200, dh:2 * dh] = qkv[3, :dh] * 25           # key 200 aligned with query 3
+    qkv = qkv.to(dtype)
+    close(ops.attention(qkv.to(dev()), nseq, S, heads), attn_ref(qkv, nseq, S, heads), tol(dtype, 3))
+
+
+# ---------------------------------------------------------------------------------------------------
+def perm_tokens(tok_ref, C, p):
+    return tok_ref[..., packing.token_perm(C, p)]
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_patchify_roundtrip_lvit(dtype):
+    B, C, H, ws = 2, 24, 64, 16
+    x = rnd((B, C, H, H), 1, dtype)
+    want = perm_tokens(cfen_oracle.unfold_tokens(cfen_oracle.window_partition(x.float(), ws), 2), C, 2).reshape(-1, 4 * C)
+    xn = ops.to_nhwc(x).to(dev())
+    tok = ops.patchify(xn, C, ws, 2)
+    assert torch.equal(tok.float().cpu(), want)
+    back = ops.unpatchify(tok, B, H, H, C, xn.shape[-1], ws, 2)
+    assert torch.equal(back.cpu(), xn.cpu())
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_patchify_pooled_gvit_and_padded_stride(dtype):
+    B, C, H = 2, 24, 64
+    x = rnd((B, C, H, H), 2, dtype)
+    pooled = cfen_oracle.avgpool2(cfen_oracle.avgpool2(x.double()))
+    want = perm_tokens(cfen_oracle.unfold_tokens(pooled, 4), C, 4).reshape(-1, 16 * C)
+    xn = ops.to_nhwc(x, cs=32).to(dev())                       # channel stride larger than C
+    tok = ops.patchify(xn, C, H // 4, 4, pool=4)
+    close(tok, want, tol(dtype))
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_upsample4(dtype):
+    B, C, h, w = 2, 8, 5, 7
+    x = rnd((B, C, h, w), 3, dtype)
+    want = cfen_oracle.upsample2_bilinear(cfen_oracle.upsample2_bilinear(x.double()))
+    got = ops.from_nhwc(ops.upsample4(ops.to_nhwc(x).to(dev())), C)
+    close(got, want, tol(dtype))
+
+
+def test_nchw_to_nhwc():
+    x = rnd((2, 3, 16, 32), 4, torch.float32)
+    for dtype in DTYPES:
+        got = ops.nchw_to_nhwc(x.to(dev()), 8, dtype)
+        want = ops.to_nhwc(x, cs=8).to(dtype)
+        assert torch.equal(got.cpu(), want)
+
+
+# ---------------------------------------------------------------------------------------------------
+def run_conv(dtype, x, w, b, k, stride, pad, reflect=False, an=None, act=0, res=None, nchw=False, x2=None):
+    kc = 32 if dtype == torch.float16 else 16
+    d = dev()
+    cout = w.shape[0]
+    cin = x.shape[1]
+    wp = packing.pack_conv_weight(w, packing.cs_of(cin), kc, dtype)[0]
+    s, t = packing.affine(b, an[0] if an else None, an[1] if an else None, packing.round_up(cout, 16))
+    xn = ops.to_nhwc(x.to(dtype)).to(d)
+    x2n = ops.to_nhwc(x2.to(dtype)).to(d) if x2 is not None else None
+    resn = ops.to_nhwc(res.to(dtype)).to(d) if res is not None else None
+    out = ops.conv2d(xn, wp.to(d), s.to(d), t.to(d), packing.cs_of(cin), cout, k=k, stride=stride, pad=pad, reflect=reflect,
+                     src1=x2n, act=act, res0=resn, nchw_f32=nchw)
+    return out if nchw else ops.from_nhwc(out, cout)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("cin,cout,k,stride,pad,size", [(3, 12, 5, 1, 2, 32), (12, 12, 3, 1, 1, 32), (12, 24, 3, 2, 1, 64),
+                                                       (24, 48, 3, 2, 1, 32), (48, 96, 3, 2, 1, 32)])
+def test_conv_plain(dtype, cin, cout, k, stride, pad, size):
+    x = rnd((2, cin, size, size), 1, dtype)
+    w = rnd((cout, cin, k, k), 2, dtype, 1 / math.sqrt(cin * k * k))
+    b = rnd((cout,), 3, torch.float32, 0.1)
+    want = F.conv2d(x.double(), w.double(), b.double(), stride=stride, padding=pad)
+    close(run_conv(dtype, x, w, b, k, stride, pad), want, tol(dtype, 4))
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_conv_identity_kernel_is_exact(dtype):
+    # asymmetric known answer: a one-hot 3x3 kernel shifts the image (zero padding at the border)
+    x = rnd((1, 8, 16, 16), 1, dtype)
+    w = torch.zeros(8, 8, 3, 3)
+    for c in range(8):
+        w[c, (c + 1) % 8, 0, 2] = 1.0                 # out[c](y,x) = in[c+1](y-1, x+1)
+    got = run_conv(dtype, x, w.to(dtype), torch.zeros(8), 3, 1, 1)
+    want = F.conv2d(x.float(), w, padding=1)
+    assert torch.equal(got.float().cpu(), want)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_conv_reflect7_tanh_nchw(dtype):
+    x = rnd((2, 12, 32, 32), 1, dtype)
+    for cout in (3, 1):
+        w = rnd((cout, 12, 7, 7), 2, dtype, 0.3 / math.sqrt(12 * 49))
+        b = rnd((cout,), 3, torch.float32, 0.1)
+        want = torch.tanh(F.conv2d(F.pad(x.double(), (3, 3, 3, 3), mode="reflect"), w.double(), b.double()))
+        got = run_conv(dtype, x, w, b, 7, 1, 3, reflect=True, act=2, nchw=True)
+        assert got.dtype == torch.float32 and got.shape == want.shape
+        close(got, want, tol(dtype, 2))
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("C", [24, 48, 96])
+def test_conv_1x1_concat_actnorm_relu_residual(dtype, C):
+    a, b2 = rnd((2, C, 16, 16), 1, dtype), rnd((2, C, 16, 16), 2, dtype)
+    w = rnd((C, 2 * C, 1, 1), 3, dtype, 1 / math.sqrt(2 * C))
+    bias, anw, anb = rnd((C,), 4, torch.float32, 0.1), rnd((C,), 5, torch.float32, 0.2), rnd((C,), 6, torch.float32, 0.2)
+    res = rnd((2, C, 16, 16), 7, dtype)
+    y = F.conv2d(torch.cat((a, b2), 1).double(), w.double(), bias.double())
+    want = torch.relu((y + anb.double().view(1, -1, 1, 1)) * torch.exp(anw.double()).view(1, -1, 1, 1)) + res.double()
+    got = run_conv(dtype, a, w, bias, 1, 1, 0, an=(anw, anb), act=1, res=res, x2=b2)
+    close(got, want, tol(dtype, 6))
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("cin,cout", [(96, 48), (48, 24), (24, 12)])
+def test_conv_transpose(dtype, cin, cout):
+    kc = 32 if dtype == torch.float16 else 16
+    d = dev()
+    x = rnd((2, cin, 16, 16), 1, dtype)
+    w = rnd((cin, cout, 4, 4), 2, dtype, 1 / math.sqrt(cin * 4))
+    b = rnd((cout,), 3, torch.float32, 0.1)
+    want = torch.relu(F.conv_transpose2d(x.double(), w.double(), b.double(), stride=2, padding=1))
+    wp = packing.pack_convT_weight(w, packing.cs_of(cin), kc, dtype)
+    s, t = packing.affine(b, cout_pad=packing.round_up(cout, 16))
+    out = ops.conv2d(ops.to_nhwc(x).to(d), wp.to(d), s.to(d), t.to(d), packing.cs_of(cin), cout, transpose=True, act=1)
+    close(ops.from_nhwc(out, cout), want, tol(dtype, 4))
+    if packing.cs_of(cout) != cout:     # padded channels must be written as zeros
+        assert float(out[..., cout:].abs().max()) == 0.0
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_instnorm_relu(dtype):
+    for C, size in ((24, 32), (96, 16), (48, 8)):
+        x = rnd((2, C, size, size), 1, dtype, 2.0) + 0.7
+        want = torch.relu(cfen_oracle.instance_norm(x.double()))
+        xn = ops.to_nhwc(x).to(dev())
+        close(ops.from_nhwc(ops.instnorm_relu_(xn, C), C), want, tol(dtype, 2))
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_cfsm2g_against_reference_vectors(dtype, golden_dir):
+    kat = np.load(golden_dir + "/ops_kat.npz")
+    sd = {"c." + k[len("cfsm/sd/"):]: torch.from_numpy(kat[k]) for k in kat.files if k.startswith("cfsm/sd/")}
+    xs = [torch.from_numpy(kat["cfsm/x%d" % i]) for i in range(3)]
+    w = torch.cat([sd["c.%s.%d.weight" % (fc, i)].reshape(-1) for fc in ("fc_avg_cf1", "fc_avg_cf2", "fc_max_cf1", "fc_max_cf2")
+                   for i in (0, 2)])
+    d = dev()
+    xn = [ops.to_nhwc(x.to(dtype)).to(d) for x in xs]
+    got = ops.from_nhwc(ops.cfsm2g(xn[0], xn[1], xn[2], w.to(d), 8), 8)
+    close(got, torch.from_numpy(kat["cfsm/y"]), tol(dtype, 4))
