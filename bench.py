@@ -1,0 +1,181 @@
+#!/usr/bin/env python3
+"""Headline benchmark: images/sec of the CFEN-ViT v3 generator forward at 512x512, n_feats=24
+(BASELINE.json configs[1]: batch 8 per GPU, hidden_dim_ratio 4, fp16 storage / fp32 accumulate).
+
+    python bench.py --gpus 1 --steps 20 --warmup 5
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+A step = one forward of one batch of synthetic hazy tensors already resident in HBM, through
+libcfen_hip.so (replayed from a hipGraph).  With N > 1 every rank runs its own 8 images (weak scaling,
+weights replicated) and the per-rank output slab is all-gathered with RCCL; the gather of step i
+overlaps the forward of step i+1 on a side stream and the last one is waited for inside the timed region.
+Rank 0 prints ONE JSON line.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import torch
+
+MFMA_PEAK_TFLOPS = {"fp16": 2500.0, "fp32": 157.3}     # /opt/skills/guides/MI355X_MICROARCH.md chip table (dense)
+
+
+def cpu_baseline(cfg, seconds=20.0):
+    """The CPU oracle (a port of the reference forward, pinned to it by tests/golden) timed on the
+    host cores on a bounded sample: batch-1 forwards at the benchmark's image size for ~`seconds`."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import cfen_oracle
+    from cfen_vit_dehazing_amd.manifest import generate_state_dict, synthetic_input
+    sd = generate_state_dict(cfg, seed=0, with_dead=False)
+    x = synthetic_input(1, cfg)
+    with torch.no_grad():
+        cfen_oracle.forward(sd, x, cfg.num_heads, cfg.patch_size)          # warm-up
+        times = []
+        t_end = time.time() + seconds
+        while time.time() < t_end and len(times) < 30:
+            t0 = time.time()
+            cfen_oracle.forward(sd, x, cfg.num_heads, cfg.patch_size)
+            times.append(time.time() - t0)
+    times.sort()
+    med = times[len(times) // 2]
+    return {"value": round(1.0 / med, 4), "unit": "images/sec", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": "%d batch-1 fp32 forwards of the CPU oracle at %dx%d (median)" % (len(times), cfg.image_size, cfg.image_size)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=30)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--batch", type=int, default=8, help="images per GPU")
+    ap.add_argument("--dtype", default="fp16", choices=["fp16", "fp32"])
+    ap.add_argument("--hidden-dim-ratio", type=int, default=4)
+    ap.add_argument("--load-size", type=int, default=256, help="256 -> 512x512 images")
+    ap.add_argument("--no-graph", action="store_true", help="launch eagerly instead of replaying a hipGraph")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=20.0)
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("--gpus %d needs torch.distributed.run with --nproc-per-node %d" % (args.gpus, args.gpus))
+        raise SystemExit("WORLD_SIZE=%d does not match --gpus %d" % (world, args.gpus))
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+
+    from cfen_vit_dehazing_amd.config import NetConfig
+    from cfen_vit_dehazing_amd.hipnet import dec_ipt
+    from cfen_vit_dehazing_amd.manifest import generate_state_dict, synthetic_input
+    from cfen_vit_dehazing_amd.parallel import OutputGatherer
+
+    cfg = NetConfig(24, args.hidden_dim_ratio, patch_size=args.load_size // 8, load_size=args.load_size)
+    B, n = args.batch, cfg.image_size
+    net = dec_ipt(cfg, compute_dtype=args.dtype)
+    net.load_state_dict(generate_state_dict(cfg, seed=0), strict=True)
+    net.to(dev)
+    x = synthetic_input(B, cfg, seed0=rank * B).to(dev)
+    slabs = [torch.empty(7 * B * n * n, dtype=torch.float32, device=dev) for _ in range(2)]
+    gather = OutputGatherer(world, slabs[0].numel(), dev) if world > 1 else None
+
+    net(x, out=slabs[0])                       # packs weights, builds the plan
+    torch.cuda.synchronize()
+    graphs = None
+    if not args.no_graph:
+        graphs = []
+        side = torch.cuda.Stream()
+        with torch.cuda.stream(side):
+            for s in slabs:
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g, stream=side):
+                    net(x, out=s)
+                graphs.append(g)
+        torch.cuda.synchronize()
+
+    def step(i):
+        s = slabs[i & 1]
+        if gather is not None:
+            gather.before_write(i & 1)         # the gather of step i-2 must have consumed this slab
+        if graphs is not None:
+            graphs[i & 1].replay()
+        else:
+            net(x, out=s)
+        if gather is not None:
+            gather.launch(s, i & 1)            # async all-gather on the communication stream
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for i in range(args.warmup):
+        step(i)
+    if gather is not None:
+        gather.wait_all()
+    barrier()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        step(i)
+    if gather is not None:
+        gather.wait_all()
+    barrier()
+    dt = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+
+    ms_step = dt / args.steps * 1e3
+    ips = world * B * args.steps / dt
+
+    result = None
+    if rank == 0:
+        flops_img = net.flops_per_image()
+        # per-kernel-class timing with HIP events on the launch stream (3 profiled forwards, median of sums)
+        profs = [net.profile(x) for _ in range(3)]
+        classes = {}
+        for name in net.KERNEL_CLASSES:
+            runs = sorted(p[name][0] for p in profs)
+            classes[name] = {"ms": round(runs[1], 4), "launches": profs[0][name][2], "gflop": round(profs[0][name][1] / 1e9, 2)}
+        dom = max((c for c in classes if classes[c]["gflop"] > 0), key=lambda c: classes[c]["ms"])
+        ach = classes[dom]["gflop"] / classes[dom]["ms"]            # GFLOP / ms == TFLOP/s
+        peak = MFMA_PEAK_TFLOPS[args.dtype]
+        for c in classes.values():
+            c["tflops"] = round(c["gflop"] / c["ms"], 2) if c["ms"] > 0 and c["gflop"] > 0 else None
+        whole = ips / world * flops_img / 1e12
+        result = {
+            "metric": "images/sec @512x512 n_feats=24", "value": round(ips, 2), "unit": "images/sec", "n_gpus": world,
+            "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_step, 3), "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "f16" if args.dtype == "fp16" else "f32", "data": "synthetic",
+            "config": {"workload": "batch=%d/GPU %dx%d n_feats=24 hidden_dim_ratio=%d %s, weights random-init (seeded generator)"
+                                   % (B, n, n, args.hidden_dim_ratio, args.dtype),
+                       "global_batch": world * B, "parallelism": "dp%d" % world, "graph": graphs is not None,
+                       "gflop_per_image": round(flops_img / 1e9, 2)},
+            "roofline": {"bound": "mfma", "kernel": dom, "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s",
+                         "frac": round(ach / peak, 5), "traffic": None,
+                         "whole_forward_tflops": round(whole, 2), "whole_forward_frac": round(whole / peak, 5)},
+            "kernel_classes": classes,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            result["cpu_baseline"] = cpu_baseline(cfg, args.cpu_seconds)
+        print(json.dumps(result), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -41,6 +41,8 @@ SIGNATURES = {
     "cfen_net_set_param": (_I, [_P, c_char_p, _P, c_size_t]),
     "cfen_net_missing_params": (_I, [_P, c_char_p, c_size_t]),
     "cfen_net_forward": (_I, [_P, _P, _P, _P, _P, _P, c_size_t, _P]),
+    "cfen_net_profile": (_I, [_P, _P, _P, _P, _P, _P, c_size_t, _P, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_double),
+                              ctypes.POINTER(ctypes.c_int32), _I]),
     "cfen_net_stage": (_I, [_P, c_char_p, ctypes.POINTER(_P)] + [ctypes.POINTER(ctypes.c_int32)] * 4),
     "cfen_net_flops_per_image": (ctypes.c_double, [_P]),
     "cfen_gemm_nt": (_I, [_I, _P, _I, _P, _I, _P, _P, _I, _P, _I, _P, _I, _I, _I, _I, _I, _P]),

@@ -50,6 +50,19 @@ struct cfen_net {
   size_t o_x0 = 0, o_x1 = 0, o_yn = 0, o_qkv = 0, o_att = 0, o_hid = 0, o_small = 0, o_stats = 0;
   unsigned char* base = nullptr;   // workspace of the current / last forward
   hipStream_t stream = nullptr;
+  // optional per-launch timing (cfen_net_profile): one event pair per launch, tagged with a class
+  bool profiling = false;
+  struct Rec { int cls; double flops; hipEvent_t a, b; };
+  std::vector<Rec> recs;
+  int prof_begin(int cls, double flops) {
+    if (!profiling) return -1;
+    Rec r; r.cls = cls; r.flops = flops;
+    if (hipEventCreate(&r.a) != hipSuccess || hipEventCreate(&r.b) != hipSuccess) return -1;
+    (void)hipEventRecord(r.a, stream);
+    recs.push_back(r);
+    return (int)recs.size() - 1;
+  }
+  void prof_end(int id) { if (id >= 0) (void)hipEventRecord(recs[id].b, stream); }
 
   size_t alloc(size_t bytes) {
     size_t off = ws_bytes;
@@ -95,6 +108,17 @@ struct cfen_net {
     int rc__ = (expr);        \
     if (rc__) return rc__;    \
   } while (0)
+
+// launch `expr`, attributing its time to kernel class `cls` when profiling
+#define TRYP(cls, flops, expr)            \
+  do {                                    \
+    int id__ = prof_begin(cls, flops);    \
+    int rc__ = (expr);                    \
+    prof_end(id__);                       \
+    if (rc__) return rc__;                \
+  } while (0)
+
+enum { K_GEMM = 0, K_ATTN = 1, K_LNORM = 2, K_TOKEN = 3, K_CONV = 4, K_NORM = 5, K_NCLASS = 6 };
 
 int cfen_net::build() {
   const int nf = cfg.n_feats, N = cfg.load_size, B = cfg.batch;
@@ -240,7 +264,11 @@ int cfen_net::run_conv(const std::string& layer, const std::string& in0, const c
     d.res[0] = res0 ? map_ptr(res0) : nullptr;
     d.res[1] = res1 ? map_ptr(res1) : nullptr;
   }
-  return cfen_conv_impl(cfg.dtype, &d, stream);
+  const double e = (double)c.out_edge;
+  const double fl = cfg.batch * (c.kind == 1 ? 2.0 * c.Cin_real * c.Cout * 16.0 * (e / 2) * (e / 2)
+                                             : 2.0 * c.Cout * (double)c.Cin_real * c.nsrc * c.k * c.k * e * e);
+  TRYP(K_CONV, fl, cfen_conv_impl(cfg.dtype, &d, stream));
+  return CFEN_OK;
 }
 
 // One LViT / GViT instance: reference v3:1136-1189 / 1272-1325 (+ TransformerEncoderLayer 1382-1390).
@@ -252,25 +280,37 @@ int cfen_net::run_vit(const Vit& v, const std::string& in, const std::string& ou
   const int M = B * nwin * v.S;
   const std::string& n = v.name;
   void *X0 = at(o_x0), *X1 = at(o_x1), *YN = at(o_yn), *QKV = at(o_qkv), *ATT = at(o_att), *HID = at(o_hid);
-  TRY(cfen_patchify_impl(dt, map_ptr(in), X0, B, v.mapH, v.mapH, v.C, bi.cs, v.ws, v.p, v.global ? 4 : 1, 0, stream));
+  const double Md = (double)M, D = v.D, Hd = v.hidden;
+  TRYP(K_TOKEN, 0, cfen_patchify_impl(dt, map_ptr(in), X0, B, v.mapH, v.mapH, v.C, bi.cs, v.ws, v.p, v.global ? 4 : 1, 0, stream));
   // x = linear_encoding(x) + x + pos                                        (v3:1143,1166)
-  TRY(cfen_gemm_impl(dt, X0, v.D, P(n + ".embed.w"), v.D, Pf(n + ".embed.b"), X0, v.D, P(n + ".pos"), v.S, X1, v.D, M, v.D, v.D, 0, stream));
+  TRYP(K_GEMM, 2 * Md * D * D,
+       cfen_gemm_impl(dt, X0, v.D, P(n + ".embed.w"), v.D, Pf(n + ".embed.b"), X0, v.D, P(n + ".pos"), v.S, X1, v.D, M, v.D, v.D, 0, stream));
   // src = src + out_proj(MHA(LN1(src)))                                      (v3:1383-1386)
-  TRY(cfen_layernorm_impl(dt, X1, YN, Pf(n + ".ln1.g"), Pf(n + ".ln1.b"), M, v.D, 1e-5f, stream));
-  TRY(cfen_gemm_impl(dt, YN, v.D, P(n + ".qkv.w"), v.D, nullptr, nullptr, 0, nullptr, 0, QKV, 3 * v.D, M, 3 * v.D, v.D, 0, stream));
-  TRY(cfen_attention_impl(dt, QKV, ATT, B * nwin, v.S, v.heads, v.D / v.heads, stream));
-  TRY(cfen_gemm_impl(dt, ATT, v.D, P(n + ".proj.w"), v.D, nullptr, X1, v.D, nullptr, 0, X1, v.D, M, v.D, v.D, 0, stream));
+  TRYP(K_LNORM, 0, cfen_layernorm_impl(dt, X1, YN, Pf(n + ".ln1.g"), Pf(n + ".ln1.b"), M, v.D, 1e-5f, stream));
+  TRYP(K_GEMM, 6 * Md * D * D,
+       cfen_gemm_impl(dt, YN, v.D, P(n + ".qkv.w"), v.D, nullptr, nullptr, 0, nullptr, 0, QKV, 3 * v.D, M, 3 * v.D, v.D, 0, stream));
+  TRYP(K_ATTN, 4 * Md * v.S * D, cfen_attention_impl(dt, QKV, ATT, B * nwin, v.S, v.heads, v.D / v.heads, stream));
+  TRYP(K_GEMM, 2 * Md * D * D,
+       cfen_gemm_impl(dt, ATT, v.D, P(n + ".proj.w"), v.D, nullptr, X1, v.D, nullptr, 0, X1, v.D, M, v.D, v.D, 0, stream));
   // src = src + linear2(relu(linear1(LN2(src))))                             (v3:1387-1389)
-  TRY(cfen_layernorm_impl(dt, X1, YN, Pf(n + ".ln2.g"), Pf(n + ".ln2.b"), M, v.D, 1e-5f, stream));
-  TRY(cfen_gemm_impl(dt, YN, v.D, P(n + ".ffn1.w"), v.D, Pf(n + ".ffn1.b"), nullptr, 0, nullptr, 0, HID, v.hidden, M, v.hidden, v.D, 1, stream));
-  TRY(cfen_gemm_impl(dt, HID, v.hidden, P(n + ".ffn2.w"), v.hidden, Pf(n + ".ffn2.b"), X1, v.D, nullptr, 0, X1, v.D, M, v.D, v.hidden, 0, stream));
+  TRYP(K_LNORM, 0, cfen_layernorm_impl(dt, X1, YN, Pf(n + ".ln2.g"), Pf(n + ".ln2.b"), M, v.D, 1e-5f, stream));
+  TRYP(K_GEMM, 2 * Md * D * Hd,
+       cfen_gemm_impl(dt, YN, v.D, P(n + ".ffn1.w"), v.D, Pf(n + ".ffn1.b"), nullptr, 0, nullptr, 0, HID, v.hidden, M, v.hidden, v.D, 1, stream));
+  TRYP(K_GEMM, 2 * Md * D * Hd,
+       cfen_gemm_impl(dt, HID, v.hidden, P(n + ".ffn2.w"), v.hidden, Pf(n + ".ffn2.b"), X1, v.D, nullptr, 0, X1, v.D, M, v.D, v.hidden, 0, stream));
   // x = mlp_head(x) + x                                                      (v3:1173)
-  TRY(cfen_gemm_impl(dt, X1, v.D, P(n + ".head1.w"), v.D, Pf(n + ".head1.b"), nullptr, 0, nullptr, 0, HID, v.hidden, M, v.hidden, v.D, 1, stream));
-  TRY(cfen_gemm_impl(dt, HID, v.hidden, P(n + ".head2.w"), v.hidden, Pf(n + ".head2.b"), X1, v.D, nullptr, 0, X0, v.D, M, v.D, v.hidden, 0, stream));
-  if (!v.global) return cfen_patchify_impl(dt, map_ptr(out), X0, B, v.mapH, v.mapH, v.C, bo.cs, v.ws, v.p, 1, 1, stream);
+  TRYP(K_GEMM, 2 * Md * D * Hd,
+       cfen_gemm_impl(dt, X1, v.D, P(n + ".head1.w"), v.D, Pf(n + ".head1.b"), nullptr, 0, nullptr, 0, HID, v.hidden, M, v.hidden, v.D, 1, stream));
+  TRYP(K_GEMM, 2 * Md * D * Hd,
+       cfen_gemm_impl(dt, HID, v.hidden, P(n + ".head2.w"), v.hidden, Pf(n + ".head2.b"), X1, v.D, nullptr, 0, X0, v.D, M, v.D, v.hidden, 0, stream));
+  if (!v.global) {
+    TRYP(K_TOKEN, 0, cfen_patchify_impl(dt, map_ptr(out), X0, B, v.mapH, v.mapH, v.C, bo.cs, v.ws, v.p, 1, 1, stream));
+    return CFEN_OK;
+  }
   void* SM = at(o_small);
-  TRY(cfen_patchify_impl(dt, SM, X0, B, v.mapH, v.mapH, v.C, v.C, v.ws, v.p, 1, 1, stream));
-  return cfen_upsample4_impl(dt, SM, map_ptr(out), B, v.mapH, v.mapH, v.C, v.C, bo.cs, stream);
+  TRYP(K_TOKEN, 0, cfen_patchify_impl(dt, SM, X0, B, v.mapH, v.mapH, v.C, v.C, v.ws, v.p, 1, 1, stream));
+  TRYP(K_TOKEN, 0, cfen_upsample4_impl(dt, SM, map_ptr(out), B, v.mapH, v.mapH, v.C, v.C, bo.cs, stream));
+  return CFEN_OK;
 }
 
 // LViT || GViT -> 1x1 fuse conv over their concat -> ActNorm -> ReLU -> + level input   (v3:403-488 ...)
@@ -293,7 +333,7 @@ int cfen_net::forward(const float* x, float* xr, float* xs, float* xd) {
   const int dt = cfg.dtype, B = cfg.batch, N = cfg.load_size;
   float* stats = (float*)at(o_stats);
   const Buf& bin = bufs.at("input");
-  TRY(cfen_nchw_to_nhwc_impl(dt, x, map_ptr("input"), B, 3, 2 * N, 2 * N, bin.cs, stream));
+  TRYP(K_TOKEN, 0, cfen_nchw_to_nhwc_impl(dt, x, map_ptr("input"), B, 3, 2 * N, 2 * N, bin.cs, stream));
   // head: conv5x5 + ResBlock                                                   (v3:123-127,395)
   TRY(run_conv("head.0.0", "input", nullptr, nullptr, nullptr, 0, "head.conv5", nullptr));
   TRY(run_conv("head.0.1.body.0", "head.conv5", nullptr, nullptr, nullptr, 1, "head.res_mid", nullptr));
@@ -301,7 +341,8 @@ int cfen_net::forward(const float* x, float* xr, float* xs, float* xd) {
   auto down = [&](const std::string& layer, const std::string& in) -> int {   // conv s2 -> IN -> ReLU (v3:292-298)
     TRY(run_conv(layer, in, nullptr, nullptr, nullptr, 0, layer, nullptr));
     const Buf& b = bufs.at(layer);
-    return cfen_instnorm_relu_impl(dt, map_ptr(layer), stats, B, b.H * b.W, b.C, b.cs, 1e-5f, stream);
+    TRYP(K_NORM, 0, cfen_instnorm_relu_impl(dt, map_ptr(layer), stats, B, b.H * b.W, b.C, b.cs, 1e-5f, stream));
+    return CFEN_OK;
   };
   TRY(down("ds_conv_e01", "head"));
   TRY(run_level("e", 1, "ds_conv_e01", nullptr, "lgcat_conv_e01"));
@@ -320,14 +361,14 @@ int cfen_net::forward(const float* x, float* xr, float* xs, float* xd) {
       const std::string u = "us_conv_d03" + t;
       TRY(run_conv(u, "lgcat_conv_d03" + t, nullptr, nullptr, nullptr, 0, u, nullptr));
       const Buf& bu = bufs.at(u);
-      TRY(cfen_instnorm_relu_impl(dt, map_ptr(u), stats, B, bu.H * bu.W, bu.C, bu.cs, 1e-5f, stream));
+      TRYP(K_NORM, 0, cfen_instnorm_relu_impl(dt, map_ptr(u), stats, B, bu.H * bu.W, bu.C, bu.cs, 1e-5f, stream));
     }
     std::string in2, in1;
     if (b == 2) {
       in2 = "cfsm2g_d03d";
       const Buf& bu = bufs.at(in2);
-      TRY(cfen_cfsm2g_impl(dt, map_ptr("us_conv_d03d"), map_ptr("us_conv_d03r"), map_ptr("us_conv_d03s"), map_ptr(in2),
-                           Pf("cfsm2g_d03d.w"), stats, B, bu.H * bu.W, bu.C, bu.cs, stream));
+      TRYP(K_NORM, 0, cfen_cfsm2g_impl(dt, map_ptr("us_conv_d03d"), map_ptr("us_conv_d03r"), map_ptr("us_conv_d03s"), map_ptr(in2),
+                                       Pf("cfsm2g_d03d.w"), stats, B, bu.H * bu.W, bu.C, bu.cs, stream));
     } else {
       in2 = "sk_conv_d03" + t;
       TRY(run_conv(in2, "us_conv_d03" + t, "lgcat_conv_e02", nullptr, nullptr, 1, in2, nullptr));
@@ -337,8 +378,8 @@ int cfen_net::forward(const float* x, float* xr, float* xs, float* xd) {
     if (b == 2) {
       in1 = "cfsm2g_d02d";
       const Buf& bu = bufs.at(in1);
-      TRY(cfen_cfsm2g_impl(dt, map_ptr("us_conv_d02d"), map_ptr("us_conv_d02r"), map_ptr("us_conv_d02s"), map_ptr(in1),
-                           Pf("cfsm2g_d02d.w"), stats, B, bu.H * bu.W, bu.C, bu.cs, stream));
+      TRYP(K_NORM, 0, cfen_cfsm2g_impl(dt, map_ptr("us_conv_d02d"), map_ptr("us_conv_d02r"), map_ptr("us_conv_d02s"), map_ptr(in1),
+                                       Pf("cfsm2g_d02d.w"), stats, B, bu.H * bu.W, bu.C, bu.cs, stream));
     } else {
       in1 = "sk_conv_d02" + t;
       TRY(run_conv(in1, "us_conv_d02" + t, "lgcat_conv_e01", nullptr, nullptr, 1, in1, nullptr));
@@ -417,6 +458,30 @@ int cfen_net_forward(cfen_net* net, const float* x, float* xr, float* xs, float*
   net->base = (unsigned char*)workspace;
   net->stream = (hipStream_t)stream;
   return net->forward(x, xr, xs, xd);
+}
+
+int cfen_net_profile(cfen_net* net, const float* x, float* xr, float* xs, float* xd, void* workspace, size_t workspace_bytes, void* stream,
+                     double* ms_per_class, double* flops_per_class, int32_t* launches_per_class, int nclass) {
+  CFEN_CHECK_ARG(net && ms_per_class && flops_per_class && launches_per_class && nclass >= K_NCLASS, "net_profile: bad arguments");
+  net->profiling = true;
+  net->recs.clear();
+  int rc = cfen_net_forward(net, x, xr, xs, xd, workspace, workspace_bytes, stream);
+  net->profiling = false;
+  for (int i = 0; i < nclass; ++i) { ms_per_class[i] = 0; flops_per_class[i] = 0; launches_per_class[i] = 0; }
+  if (rc == CFEN_OK && hipStreamSynchronize((hipStream_t)stream) != hipSuccess) {
+    cfen_set_error("net_profile: stream synchronize failed");
+    rc = CFEN_ERR_HIP;
+  }
+  for (auto& r : net->recs) {
+    float ms = 0.f;
+    if (rc == CFEN_OK && hipEventElapsedTime(&ms, r.a, r.b) == hipSuccess) {
+      ms_per_class[r.cls] += ms; flops_per_class[r.cls] += r.flops; launches_per_class[r.cls] += 1;
+    }
+    (void)hipEventDestroy(r.a);
+    (void)hipEventDestroy(r.b);
+  }
+  net->recs.clear();
+  return rc;
 }
 
 int cfen_net_stage(const cfen_net* net, const char* name, const void** ptr, int32_t* C, int32_t* cs, int32_t* H, int32_t* W) {

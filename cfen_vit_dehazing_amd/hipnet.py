@@ -119,7 +119,20 @@ class dec_ipt(nn.Module):
         return self._nets[batch]
 
     # ---- forward ----------------------------------------------------------------------------
-    def forward(self, x):
+    KERNEL_CLASSES = ("gemm", "attention", "layernorm", "tokens", "conv", "norm")
+
+    def forward(self, x, out=None):
+        """`out`: optional flat float32 CUDA buffer of 7*B*H*W elements that receives [xr | xs | xd]
+        back to back (one slab for the data-parallel all-gather); the returned tensors are views of it."""
+        return self._run(x, out, None)
+
+    def profile(self, x):
+        """One forward with HIP events around every launch: {class: (ms, algorithmic flops, launches)}."""
+        prof = {}
+        self._run(x, None, prof)
+        return prof
+
+    def _run(self, x, out, prof):
         if not x.is_cuda:
             raise CfenError("the HIP generator needs a CUDA(HIP) tensor; there is no CPU fallback (got %s)" % x.device)
         n = self.cfg.image_size
@@ -130,10 +143,23 @@ class dec_ipt(nn.Module):
         x = x.contiguous().float()
         B = x.shape[0]
         h, ws = self._net_for(B, x.device)
-        xr = torch.empty(B, 3, n, n, dtype=torch.float32, device=x.device)
-        xs = torch.empty(B, 1, n, n, dtype=torch.float32, device=x.device)
-        xd = torch.empty(B, 3, n, n, dtype=torch.float32, device=x.device)
-        check(_lib.load().cfen_net_forward(h, ptr(x), ptr(xr), ptr(xs), ptr(xd), ptr(ws), ws.numel(), current_stream()), "cfen_net_forward")
+        if out is None:
+            out = torch.empty(7 * B * n * n, dtype=torch.float32, device=x.device)
+        elif out.dtype != torch.float32 or out.numel() != 7 * B * n * n or not out.is_contiguous() or out.device != x.device:
+            raise ValueError("out must be a contiguous float32 buffer of 7*B*H*W elements on the input's device")
+        px = B * n * n
+        flat = out.view(-1)
+        xr, xs, xd = flat[:3 * px].view(B, 3, n, n), flat[3 * px:4 * px].view(B, 1, n, n), flat[4 * px:].view(B, 3, n, n)
+        lib = _lib.load()
+        if prof is None:
+            check(lib.cfen_net_forward(h, ptr(x), ptr(xr), ptr(xs), ptr(xd), ptr(ws), ws.numel(), current_stream()), "cfen_net_forward")
+        else:
+            nc = len(self.KERNEL_CLASSES)
+            ms, fl, cnt = (ctypes.c_double * nc)(), (ctypes.c_double * nc)(), (ctypes.c_int32 * nc)()
+            check(lib.cfen_net_profile(h, ptr(x), ptr(xr), ptr(xs), ptr(xd), ptr(ws), ws.numel(), current_stream(), ms, fl, cnt, nc),
+                  "cfen_net_profile")
+            for i, name in enumerate(self.KERNEL_CLASSES):
+                prof[name] = (ms[i], fl[i], cnt[i])
         self._last = B
         return [xr, xs, xd]
 

@@ -1,0 +1,64 @@
+"""Data-parallel sharding of image batches: one process per GPU, weights replicated, no exchange inside
+the forward, ONE all-gather of the per-rank output slab (RCCL over xGMI; `nccl` backend == RCCL on ROCm).
+
+The reference's only parallelism is single-process nn.DataParallel (scatter batch / gather outputs,
+models/networks_iid_hlgvit_crs_gd4_cfs_v3.py:77-83); every op of the forward is per-sample once ActNorm
+is initialised, so sharding dim 0 is exact.  Instead of a gather to one master GPU the
+slab [xr | xs | xd] of each rank is all-gathered, and the collective of batch i runs on a side stream
+underneath the forward of batch i+1.
+"""
+import torch
+import torch.distributed as dist
+
+
+def shard_range(total, world, rank):
+    """Contiguous [lo, hi) slice of a global batch for `rank` (sizes differ by at most one)."""
+    base, rem = divmod(total, world)
+    lo = rank * base + min(rank, rem)
+    return lo, lo + base + (1 if rank < rem else 0)
+
+
+def split_slab(slab, batch, n):
+    """flat [xr | xs | xd] slab of one rank -> views (B,3,n,n), (B,1,n,n), (B,3,n,n)."""
+    px = batch * n * n
+    return slab[:3 * px].view(batch, 3, n, n), slab[3 * px:4 * px].view(batch, 1, n, n), slab[4 * px:7 * px].view(batch, 3, n, n)
+
+
+def merge_gathered(gathered, world, batch, n):
+    """all-gathered buffer (world slabs back to back) -> global-batch tensors in rank order."""
+    per = 7 * batch * n * n
+    parts = [split_slab(gathered[r * per:(r + 1) * per], batch, n) for r in range(world)]
+    return [torch.cat([p[i] for p in parts], 0) for i in range(3)]
+
+
+class OutputGatherer:
+    """Double-buffered asynchronous all-gather of equally sized per-rank slabs."""
+
+    def __init__(self, world, numel, device, dtype=torch.float32):
+        self.world, self.numel = world, numel
+        self.cuda = torch.device(device).type == "cuda"
+        self.bufs = [torch.empty(world * numel, dtype=dtype, device=device) for _ in range(2)]
+        self.stream = torch.cuda.Stream(device) if self.cuda else None
+        self.events = [None, None]
+
+    def before_write(self, slot):
+        """Call before the compute stream overwrites the slab last handed to launch(slot)."""
+        if self.cuda and self.events[slot] is not None:
+            torch.cuda.current_stream().wait_event(self.events[slot])
+
+    def launch(self, slab, slot):
+        if not self.cuda:
+            dist.all_gather_into_tensor(self.bufs[slot], slab)
+            return self.bufs[slot]
+        self.stream.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(self.stream):
+            work = dist.all_gather_into_tensor(self.bufs[slot], slab, async_op=True)
+            work.wait()                                   # side stream now orders after the collective
+            ev = torch.cuda.Event()
+            ev.record(self.stream)
+        self.events[slot] = ev
+        return self.bufs[slot]
+
+    def wait_all(self):
+        if self.cuda:
+            torch.cuda.current_stream().wait_stream(self.stream)

@@ -61,6 +61,13 @@ int cfen_net_missing_params(const cfen_net* net, char* buf, size_t buflen);
 /* x: (B,3,H,W) fp32 NCHW in [-1,1];  xr: (B,3,H,W), xs: (B,1,H,W), xd: (B,3,H,W) fp32 NCHW        */
 int cfen_net_forward(cfen_net* net, const float* x, float* xr, float* xs, float* xd, void* workspace, size_t workspace_bytes,
                      void* stream);
+/* one forward with a HIP event pair around every kernel launch on `stream` (synchronises the stream at
+ * the end -- not graph-capturable).  Classes: 0 token GEMMs, 1 attention, 2 LayerNorm, 3 patchify /
+ * unpatchify / upsample / layout, 4 convolutions, 5 InstanceNorm / CFSM2G.  Per class: summed kernel
+ * milliseconds, algorithmic FLOPs (2*MAC) of those launches, number of launches.                  */
+#define CFEN_NUM_KERNEL_CLASSES 6
+int cfen_net_profile(cfen_net* net, const float* x, float* xr, float* xs, float* xd, void* workspace, size_t workspace_bytes,
+                     void* stream, double* ms_per_class, double* flops_per_class, int32_t* launches_per_class, int nclass);
 /* device pointer + geometry of a named top-level stage output (SURVEY Appendix D names) inside the
  * workspace of the LAST forward; NHWC, element type = net dtype.                                  */
 int cfen_net_stage(const cfen_net* net, const char* name, const void** ptr, int32_t* C, int32_t* cs, int32_t* H, int32_t* W);
