@@ -61,7 +61,6 @@ SIGNATURES = {
 }
 
 _lib = None
-_PENDING = {"cfen_deform_conv_forward", "cfen_modulated_deform_conv_forward"}   # TODO remove once k_dcn.hip lands
 
 
 def load():
@@ -74,8 +73,6 @@ def load():
                           "(hipcc --offload-arch=gfx950) -- there is no CPU/PyTorch fallback for the HIP path")
     lib = ctypes.CDLL(LIB_PATH)
     for name, (res, args) in SIGNATURES.items():
-        if name in _PENDING and not hasattr(lib, name):
-            continue
         fn = getattr(lib, name)          # AttributeError if the .so lacks a declared symbol
         fn.restype = res
         fn.argtypes = args

@@ -1,0 +1,222 @@
+"""Deformable convolution operator with the reference's Python API, backed by the HIP kernel.
+
+Mirrors dcn/deform_conv.py of the reference (functions :15-154, modules :161-329) for the FORWARD
+direction: same call signatures, argument meaning, error behaviour (ValueError for non-4D input and
+too-small outputs, AssertionError when im2col_step does not divide the batch, NotImplementedError for
+CPU tensors).  The pybind module `deform_conv_cuda` (dcn/src/deform_conv_cuda.cpp:681-695) is replaced
+by two C-ABI entry points of libcfen_hip.so; the `columns` / `ones` scratch tensors of the reference
+do not exist because the column matrix is never materialised (csrc/k_dcn.hip).
+Backward is out of scope for the inference path and raises NotImplementedError.
+"""
+import logging
+import math
+
+import torch
+import torch.nn as nn
+from torch.autograd import Function
+from torch.nn.modules.utils import _pair
+
+from .. import _lib
+from .._lib import check, ptr, dtype_code, current_stream
+
+logger = logging.getLogger('base')
+
+
+def _contig(*ts):
+    return [t.contiguous() if t is not None else None for t in ts]
+
+
+class DeformConvFunction(Function):
+    @staticmethod
+    def forward(ctx, input, offset, weight, stride=1, padding=0, dilation=1, groups=1, deformable_groups=1, im2col_step=64):
+        if input is not None and input.dim() != 4:
+            raise ValueError("Expected 4D tensor as input, got {}D tensor instead.".format(input.dim()))
+        stride, padding, dilation = _pair(stride), _pair(padding), _pair(dilation)
+        output = input.new_empty(DeformConvFunction._output_size(input, weight, padding, dilation, stride))
+        if not input.is_cuda:
+            raise NotImplementedError
+        cur_im2col_step = min(im2col_step, input.shape[0])
+        assert (input.shape[0] % cur_im2col_step) == 0, 'im2col step must divide batchsize'
+        if offset.shape[1] != deformable_groups * 2 * weight.size(2) * weight.size(3):
+            raise RuntimeError("invalid number of channels of offset")
+        if tuple(offset.shape[2:]) != tuple(output.shape[2:]):
+            raise RuntimeError("invalid spatial size of offset, expected height: %d width: %d, but got height: %d width: %d"
+                               % (output.shape[2], output.shape[3], offset.shape[2], offset.shape[3]))
+        if input.size(1) != weight.size(1) * groups:
+            raise RuntimeError("invalid number of input planes, expected: %d, but got: %d" % (weight.size(1) * groups, input.size(1)))
+        input, offset, weight = _contig(input, offset.to(input.dtype), weight.to(input.dtype))
+        B, C, H, W = input.shape
+        # note the reference passes W before H here (deform_conv.py:41-46)
+        check(_lib.load().cfen_deform_conv_forward(
+            dtype_code(input.dtype), ptr(input), ptr(weight), ptr(offset), ptr(output), B, C, H, W, weight.size(0),
+            weight.size(3), weight.size(2), stride[1], stride[0], padding[1], padding[0], dilation[1], dilation[0],
+            groups, deformable_groups, cur_im2col_step, current_stream()), "deform_conv_forward")
+        return output
+
+    @staticmethod
+    def backward(ctx, grad_output):
+        raise NotImplementedError("deform_conv backward is outside the inference hot path (SURVEY 8f)")
+
+    @staticmethod
+    def _output_size(input, weight, padding, dilation, stride):
+        channels = weight.size(0)
+        output_size = (input.size(0), channels)
+        for d in range(input.dim() - 2):
+            in_size = input.size(d + 2)
+            pad = padding[d]
+            kernel = dilation[d] * (weight.size(d + 2) - 1) + 1
+            stride_ = stride[d]
+            output_size += ((in_size + (2 * pad) - kernel) // stride_ + 1, )
+        if not all(map(lambda s: s > 0, output_size)):
+            raise ValueError("convolution input is too small (output would be {})".format('x'.join(map(str, output_size))))
+        return output_size
+
+
+class ModulatedDeformConvFunction(Function):
+    @staticmethod
+    def forward(ctx, input, offset, mask, weight, bias=None, stride=1, padding=0, dilation=1, groups=1, deformable_groups=1):
+        with_bias = bias is not None
+        if not input.is_cuda:
+            raise NotImplementedError
+        n, channels_out = input.size(0), weight.size(0)
+        height, width = input.shape[2:4]
+        kernel_h, kernel_w = weight.shape[2:4]
+        height_out = (height + 2 * padding - (dilation * (kernel_h - 1) + 1)) // stride + 1
+        width_out = (width + 2 * padding - (dilation * (kernel_w - 1) + 1)) // stride + 1
+        output = input.new_empty((n, channels_out, height_out, width_out))
+        if input.size(1) != weight.size(1) * groups:
+            raise RuntimeError("Input shape and kernel channels wont match: (%d vs %d)." % (input.size(1), weight.size(1) * groups))
+        input, offset, mask, weight, bias = _contig(input, offset.to(input.dtype), mask.to(input.dtype), weight.to(input.dtype),
+                                                    bias.to(input.dtype) if with_bias else None)
+        # scalar stride / padding / dilation, h before w (deform_conv.py:117-119)
+        check(_lib.load().cfen_modulated_deform_conv_forward(
+            dtype_code(input.dtype), ptr(input), ptr(weight), ptr(bias), ptr(offset), ptr(mask), ptr(output), n, input.size(1),
+            height, width, channels_out, kernel_h, kernel_w, stride, stride, padding, padding, dilation, dilation, groups,
+            deformable_groups, int(with_bias), current_stream()), "modulated_deform_conv_forward")
+        return output
+
+    @staticmethod
+    def backward(ctx, grad_output):
+        raise NotImplementedError("modulated_deform_conv backward is outside the inference hot path (SURVEY 8f)")
+
+
+deform_conv = DeformConvFunction.apply
+modulated_deform_conv = ModulatedDeformConvFunction.apply
+
+
+class DeformConv(nn.Module):
+    def __init__(self, in_channels, out_channels, kernel_size, stride=1, padding=0, dilation=1, groups=1, deformable_groups=1,
+                 bias=False):
+        super(DeformConv, self).__init__()
+        assert not bias
+        assert in_channels % groups == 0, 'in_channels {} cannot be divisible by groups {}'.format(in_channels, groups)
+        assert out_channels % groups == 0, 'out_channels {} cannot be divisible by groups {}'.format(out_channels, groups)
+        self.in_channels = in_channels
+        self.out_channels = out_channels
+        self.kernel_size = _pair(kernel_size)
+        self.stride = _pair(stride)
+        self.padding = _pair(padding)
+        self.dilation = _pair(dilation)
+        self.groups = groups
+        self.deformable_groups = deformable_groups
+        self.weight = nn.Parameter(torch.Tensor(out_channels, in_channels // self.groups, *self.kernel_size))
+        self.reset_parameters()
+
+    def reset_parameters(self):
+        n = self.in_channels
+        for k in self.kernel_size:
+            n *= k
+        stdv = 1. / math.sqrt(n)
+        self.weight.data.uniform_(-stdv, stdv)
+
+    def forward(self, x, offset):
+        return deform_conv(x, offset, self.weight, self.stride, self.padding, self.dilation, self.groups, self.deformable_groups)
+
+
+class DeformConvPack(DeformConv):
+    def __init__(self, *args, **kwargs):
+        super(DeformConvPack, self).__init__(*args, **kwargs)
+        self.conv_offset = nn.Conv2d(self.in_channels, self.deformable_groups * 2 * self.kernel_size[0] * self.kernel_size[1],
+                                     kernel_size=self.kernel_size, stride=_pair(self.stride), padding=_pair(self.padding), bias=True)
+        self.init_offset()
+
+    def init_offset(self):
+        self.conv_offset.weight.data.zero_()
+        self.conv_offset.bias.data.zero_()
+
+    def forward(self, x):
+        offset = self.conv_offset(x)
+        return deform_conv(x, offset, self.weight, self.stride, self.padding, self.dilation, self.groups, self.deformable_groups)
+
+
+class ModulatedDeformConv(nn.Module):
+    def __init__(self, in_channels, out_channels, kernel_size, stride=1, padding=0, dilation=1, groups=1, deformable_groups=1,
+                 bias=True):
+        super(ModulatedDeformConv, self).__init__()
+        self.in_channels = in_channels
+        self.out_channels = out_channels
+        self.kernel_size = _pair(kernel_size)
+        self.stride = stride
+        self.padding = padding
+        self.dilation = dilation
+        self.groups = groups
+        self.deformable_groups = deformable_groups
+        self.with_bias = bias
+        self.weight = nn.Parameter(torch.Tensor(out_channels, in_channels // groups, *self.kernel_size))
+        if bias:
+            self.bias = nn.Parameter(torch.Tensor(out_channels))
+        else:
+            self.register_parameter('bias', None)
+        self.reset_parameters()
+
+    def reset_parameters(self):
+        n = self.in_channels
+        for k in self.kernel_size:
+            n *= k
+        stdv = 1. / math.sqrt(n)
+        self.weight.data.uniform_(-stdv, stdv)
+        if self.bias is not None:
+            self.bias.data.zero_()
+
+    def forward(self, x, offset, mask):
+        return modulated_deform_conv(x, offset, mask, self.weight, self.bias, self.stride, self.padding, self.dilation, self.groups,
+                                     self.deformable_groups)
+
+
+class ModulatedDeformConvPack(ModulatedDeformConv):
+    _offset_in_channels = None
+
+    def __init__(self, *args, extra_offset_mask=False, **kwargs):
+        super(ModulatedDeformConvPack, self).__init__(*args, **kwargs)
+        self.extra_offset_mask = extra_offset_mask
+        self.conv_offset_mask = nn.Conv2d(self._offset_in_channels or self.in_channels,
+                                          self.deformable_groups * 3 * self.kernel_size[0] * self.kernel_size[1],
+                                          kernel_size=self.kernel_size, stride=_pair(self.stride), padding=_pair(self.padding), bias=True)
+        self.init_offset()
+
+    def init_offset(self):
+        self.conv_offset_mask.weight.data.zero_()
+        self.conv_offset_mask.bias.data.zero_()
+
+    def forward(self, x):
+        if self.extra_offset_mask:
+            out = self.conv_offset_mask(x[1])      # x = [input, features]
+            x = x[0]
+        else:
+            out = self.conv_offset_mask(x)
+        o1, o2, mask = torch.chunk(out, 3, dim=1)
+        offset = torch.cat((o1, o2), dim=1)
+        mask = torch.sigmoid(mask)
+        offset_mean = torch.mean(torch.abs(offset))
+        if offset_mean > 100:
+            logger.warning('Offset mean is {}, larger than 100.'.format(offset_mean))
+        return modulated_deform_conv(x, offset, mask, self.weight, self.bias, self.stride, self.padding, self.dilation, self.groups,
+                                     self.deformable_groups)
+
+
+class ModulatedDeformConvPack2(ModulatedDeformConvPack):
+    """Same as ModulatedDeformConvPack with an offset branch fed by `offset_in_channel` features."""
+
+    def __init__(self, *args, extra_offset_mask=False, offset_in_channel=32, **kwargs):
+        self._offset_in_channels = offset_in_channel
+        super(ModulatedDeformConvPack2, self).__init__(*args, extra_offset_mask=extra_offset_mask, **kwargs)

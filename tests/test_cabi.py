@@ -1,0 +1,55 @@
+"""The C-ABI library loads and exports every symbol include/cfen_hip.h declares (no compute calls: runs
+without a GPU), and the ctypes signature table covers exactly that set."""
+import ctypes
+import os
+import re
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def declared_symbols():
+    text = open(os.path.join(ROOT, "include", "cfen_hip.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(cfen_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_header_symbols_are_exported_and_bound():
+    from cfen_vit_dehazing_amd import _lib
+    if not os.path.exists(_lib.LIB_PATH):
+        import __graft_entry__
+        __graft_entry__.build()
+    syms = declared_symbols()
+    assert len(syms) >= 20
+    lib = ctypes.CDLL(_lib.LIB_PATH)
+    for s in syms:
+        assert hasattr(lib, s), "libcfen_hip.so does not export %s" % s
+    assert sorted(_lib.SIGNATURES) == syms
+    assert _lib.load().cfen_abi_version() == 1
+
+
+def test_argument_errors_do_not_need_a_gpu():
+    from cfen_vit_dehazing_amd import _lib
+    lib = _lib.load()
+    cfg = _lib.NetConfigC(batch=1, n_feats=24, hidden_dim_ratio=4, patch_size=32, load_size=250, num_heads=4, dtype=1, reserved=0)
+    h = ctypes.c_void_p()
+    assert lib.cfen_net_create(ctypes.byref(h), ctypes.byref(cfg)) == -1          # loadSize != 8*patch_size
+    assert b"loadSize" in lib.cfen_last_error()
+    cfg.load_size = 256
+    assert lib.cfen_net_create(ctypes.byref(h), ctypes.byref(cfg)) == 0
+    assert lib.cfen_net_workspace_bytes(h) > 0
+    assert abs(lib.cfen_net_flops_per_image(h) / 1e9 - 120.85) < 0.01           # SURVEY 8d closed form
+    assert lib.cfen_net_set_param(h, b"no.such.param", ctypes.c_void_p(16), 4) == -1
+    buf = ctypes.create_string_buffer(1 << 16)
+    assert lib.cfen_net_missing_params(h, buf, 1 << 16) == 521
+    lib.cfen_net_destroy(h)
+    for hdr, gf in ((2, 85.07),):
+        cfg.hidden_dim_ratio = hdr
+        assert lib.cfen_net_create(ctypes.byref(h), ctypes.byref(cfg)) == 0
+        assert abs(lib.cfen_net_flops_per_image(h) / 1e9 - gf) < 0.01
+        lib.cfen_net_destroy(h)
+    cfg.hidden_dim_ratio, cfg.patch_size, cfg.load_size = 4, 64, 512
+    assert lib.cfen_net_create(ctypes.byref(h), ctypes.byref(cfg)) == 0
+    assert abs(lib.cfen_net_flops_per_image(h) / 1e9 - 624.21) < 0.01
+    lib.cfen_net_destroy(h)

@@ -1,0 +1,73 @@
+"""GPU parity of the HIP deformable-conv operator (through the reference-shaped Python API and the C ABI)
+against the C oracle, on the feature-map shapes of the v3 generator and the edge cases
+the reference's Python layer guards."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+import dcn_oracle
+from cfen_vit_dehazing_amd import dcn
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def rnd(shape, seed, scale=1.0):
+    return torch.randn(shape, generator=torch.Generator().manual_seed(seed)) * scale
+
+
+def tol(dtype):
+    return 2e-4 if dtype == torch.float32 else 2e-2
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.float16])
+@pytest.mark.parametrize("B,C,H,Cout,k,stride,pad,dil,groups,dg", [
+    (2, 24, 32, 24, 3, 1, 1, 1, 1, 1), (1, 48, 16, 48, 3, 1, 1, 1, 1, 8), (1, 96, 16, 96, 3, 1, 1, 1, 1, 8),
+    (2, 8, 13, 6, 3, 2, 1, 1, 1, 2), (1, 8, 12, 12, 5, 1, 2, 1, 2, 1), (1, 6, 10, 160, 3, 1, 2, 2, 1, 3), (3, 3, 9, 5, 1, 1, 0, 1, 1, 1)])
+def test_deform_conv_v1_and_v2(dtype, B, C, H, Cout, k, stride, pad, dil, groups, dg):
+    x, w = rnd((B, C, H, H + 3), 1), rnd((Cout, C // groups, k, k), 2, (C // groups * k * k) ** -0.5)
+    Ho = (H + 2 * pad - (dil * (k - 1) + 1)) // stride + 1
+    Wo = (H + 3 + 2 * pad - (dil * (k - 1) + 1)) // stride + 1
+    off = rnd((B, dg * 2 * k * k, Ho, Wo), 3, 2.0)
+    mask = torch.sigmoid(rnd((B, dg * k * k, Ho, Wo), 4))
+    bias = rnd((Cout,), 5)
+    xq, wq, oq, mq, bq = (t.to(dtype) for t in (x, w, off, mask, bias))
+    want1 = dcn_oracle.deform_conv(xq.float(), oq.float(), wq.float(), stride, pad, dil, groups, dg)
+    got1 = dcn.deform_conv(xq.to(DEV), oq.to(DEV), wq.to(DEV), stride, pad, dil, groups, dg)
+    assert got1.dtype == dtype and got1.shape == want1.shape
+    assert float((got1.float().cpu() - want1).abs().max()) <= tol(dtype)
+    want2 = dcn_oracle.deform_conv(xq.float(), oq.float(), wq.float(), stride, pad, dil, groups, dg, mask=mq.float(), bias=bq.float())
+    got2 = dcn.modulated_deform_conv(xq.to(DEV), oq.to(DEV), mq.to(DEV), wq.to(DEV), bq.to(DEV), stride, pad, dil, groups, dg)
+    assert float((got2.float().cpu() - want2).abs().max()) <= tol(dtype)
+
+
+def test_pack_modules_at_init_are_plain_convs():
+    # DeformConvPack zero-initialises conv_offset (deform_conv.py:211-213) => plain conv
+    torch.manual_seed(0)
+    m = dcn.DeformConvPack(24, 24, 3, stride=1, padding=1, deformable_groups=8).to(DEV)
+    x = rnd((2, 24, 32, 32), 1).to(DEV)
+    want = F.conv2d(x.cpu(), m.weight.detach().cpu(), padding=1)
+    assert float((m(x).cpu() - want).abs().max()) <= 2e-4
+    m2 = dcn.ModulatedDeformConvPack(24, 12, 3, stride=1, padding=1, deformable_groups=2, bias=True).to(DEV)
+    with torch.no_grad():
+        m2.bias.copy_(rnd((12,), 2))
+    want2 = 0.5 * F.conv2d(x.cpu(), m2.weight.detach().cpu(), padding=1) + m2.bias.detach().cpu().view(1, -1, 1, 1)   # sigmoid(0) = 0.5
+    assert float((m2(x).cpu() - want2).abs().max()) <= 2e-4
+    m3 = dcn.ModulatedDeformConvPack2(24, 12, 3, stride=1, padding=1, extra_offset_mask=True, offset_in_channel=8).to(DEV)
+    feat = rnd((2, 8, 32, 32), 3).to(DEV)
+    assert m3([x, feat]).shape == (2, 12, 32, 32)
+
+
+def test_error_behaviour_matches_reference():
+    x = torch.zeros(2, 4, 8, 8, device=DEV)
+    w = torch.zeros(4, 4, 3, 3, device=DEV)
+    with pytest.raises(ValueError):
+        dcn.deform_conv(torch.zeros(4, 8, 8, device=DEV), torch.zeros(1, device=DEV), w)            # not 4-D (deform_conv.py:19-21)
+    with pytest.raises(ValueError):
+        dcn.deform_conv(torch.zeros(1, 4, 2, 2, device=DEV), torch.zeros(1, 18, 1, 1, device=DEV), w)  # output too small (:91-93)
+    with pytest.raises(AssertionError):
+        dcn.deform_conv(torch.zeros(3, 4, 8, 8, device=DEV), torch.zeros(3, 18, 8, 8, device=DEV), w, 1, 1, 1, 1, 1, 2)  # step !| batch (:40)
+    with pytest.raises(NotImplementedError):
+        dcn.deform_conv(x.cpu(), torch.zeros(2, 18, 8, 8), w.cpu(), 1, 1)                           # CPU tensors (:36-37)
+    with pytest.raises(RuntimeError):
+        dcn.deform_conv(x, torch.zeros(2, 16, 8, 8, device=DEV), w, 1, 1)                            # offset channels (.cpp:129-130)
