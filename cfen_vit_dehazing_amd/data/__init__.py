@@ -1,0 +1,114 @@
+"""Folder dataset + loader of the inference harness: data/__init__.py:10-60, data/dec_vit_data.py:11-120,
+data/base_dataset.py:20-47, data/image_folder.py:37-47 of the reference (test-time subset: `dataroot/hazy/*`).
+torchvision is not a dependency: ToTensor + Normalize(0.5, 0.5) are written out (HWC uint8 -> CHW float in
+[-1, 1]); images are fed at native size because the reference default --resize_or_crop 'resize' matches no
+transform branch (base_dataset.py:20-47)."""
+import os
+import random
+
+import numpy as np
+import torch
+import torch.utils.data
+from PIL import Image
+
+IMG_EXTENSIONS = ['.jpg', '.JPG', '.jpeg', '.JPEG', '.png', '.PNG', '.ppm', '.PPM', '.bmp', '.BMP']
+
+
+def is_image_file(filename):
+    return any(filename.endswith(extension) for extension in IMG_EXTENSIONS)
+
+
+def make_dataset(dir):
+    images = []
+    assert os.path.isdir(dir), '%s is not a valid directory' % dir
+    for root, _, fnames in sorted(os.walk(dir)):
+        for fname in fnames:
+            if is_image_file(fname):
+                images.append(os.path.join(root, fname))
+    return list(set(images))
+
+
+def to_normalized_tensor(img):
+    """transforms.ToTensor() + Normalize((.5,.5,.5),(.5,.5,.5)) (base_dataset.py:44-46)."""
+    a = np.asarray(img, dtype=np.uint8)
+    t = torch.from_numpy(a.copy()).permute(2, 0, 1).float().div(255.0)
+    return (t - 0.5) / 0.5
+
+
+def get_transform(opt):
+    mode = opt.resize_or_crop
+    if mode in ('resize', 'none'):
+        return to_normalized_tensor
+    if mode in ('resize_only', 'scale_width'):
+        def f(img):
+            w, h = img.size
+            s = opt.loadSize / min(w, h)
+            return to_normalized_tensor(img.resize((max(1, round(w * s)), max(1, round(h * s))), Image.BICUBIC))
+        return f
+    raise NotImplementedError("--resize_or_crop %s uses random crops (training only)" % mode)
+
+
+class DECVITDATA(torch.utils.data.Dataset):
+    def initialize(self, opt):
+        self.opt = opt
+        self.root = opt.dataroot
+        self.dir_B = os.path.join(opt.dataroot, 'hazy')
+        self.B_paths = sorted(make_dataset(self.dir_B))
+        self.B_size = len(self.B_paths)
+        self.transform = get_transform(opt)
+
+    def __getitem__(self, index):
+        if self.opt.sb:
+            B_path = self.B_paths[index % self.B_size]
+        else:                                   # the reference samples randomly unless --sb (dec_vit_data.py:51-58)
+            B_path = self.B_paths[random.randint(0, self.B_size - 1)]
+        B = self.transform(Image.open(B_path).convert('RGB'))
+        if self.opt.output_nc == 1 and self.opt.which_direction != 'BtoA' or self.opt.input_nc == 1 and self.opt.which_direction == 'BtoA':
+            B = (B[0, ...] * 0.299 + B[1, ...] * 0.587 + B[2, ...] * 0.114).unsqueeze(0)
+        return {'B': B, 'B_paths': B_path}
+
+    def __len__(self):
+        return self.B_size
+
+    def name(self):
+        return 'DEC_ViT'
+
+
+def CreateDataset(opt):
+    if opt.dataset_mode == 'dec_vit':
+        dataset = DECVITDATA()
+    else:
+        raise ValueError("Dataset [%s] not recognized." % opt.dataset_mode)
+    print("dataset [%s] was created" % (dataset.name()))
+    dataset.initialize(opt)
+    return dataset
+
+
+class CustomDatasetDataLoader():
+    def name(self):
+        return 'CustomDatasetDataLoader'
+
+    def initialize(self, opt):
+        self.opt = opt
+        self.dataset = CreateDataset(opt)
+        self.dataloader = torch.utils.data.DataLoader(self.dataset, batch_size=opt.batchSize, shuffle=not opt.sb,
+                                                      num_workers=int(opt.nThreads))
+
+    def load_data(self):
+        return self
+
+    def __len__(self):
+        return min(len(self.dataset), self.opt.max_dataset_size)
+
+    def __iter__(self):
+        for i, data in enumerate(self.dataloader):
+            if i * self.opt.batchSize >= self.opt.max_dataset_size:
+                break
+            yield data
+
+
+def CreateDataLoader(opt):
+    data_loader = CustomDatasetDataLoader()
+    print(data_loader.name())
+    data_loader.initialize(opt)
+    return data_loader

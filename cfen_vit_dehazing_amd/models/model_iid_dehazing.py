@@ -1,0 +1,26 @@
+"""DECHLGVIT of the reference (models/model_iid_dehazing.py:14-156), inference subset.  `netG` is the
+HIP-backed generator; `forward` is `[fake_R, fake_S, fake_A] = netG(real_B)` (model_iid_dehazing.py:140-143)."""
+from .base_model import BaseModel
+
+
+class DECHLGVIT(BaseModel):
+    def name(self):
+        return 'DECHLGVIT'
+
+    def initialize(self, opt):
+        BaseModel.initialize(self, opt)
+        if self.isTrain:
+            raise NotImplementedError("training is outside the MI355X inference path")
+        self.visual_names = ['fake_A', 'real_B', 'fake_R', 'fake_S']
+        self.model_names = ['G']
+        if opt.model_G == 'iid_hlgvit_crs_gd4_cfs_v3':
+            from . import networks_iid_hlgvit_crs_gd4_cfs_v3
+            self.netG = networks_iid_hlgvit_crs_gd4_cfs_v3.define_G(opt, None)
+        # any other --model_G leaves netG undefined, as the reference's if/elif chain does (-> AttributeError)
+
+    def set_input(self, input):
+        self.real_B = input['B'].to(self.device)            # hazy image, H2D copy
+        self.image_paths = input['B_paths']
+
+    def forward(self):
+        [self.fake_R, self.fake_S, self.fake_A] = self.netG(self.real_B)

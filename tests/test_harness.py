@@ -1,0 +1,123 @@
+"""Host-side mirror of the reference's inference harness (options / data / BaseModel / save_images):
+behaviour pinned by vectors captured from the reference (tensor2im) and by its documented conventions."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+from PIL import Image
+
+from cfen_vit_dehazing_amd.config import NetConfig
+from cfen_vit_dehazing_amd.hipnet import dec_ipt
+from cfen_vit_dehazing_amd.manifest import generate_state_dict, state_manifest
+from cfen_vit_dehazing_amd.options.test_options import TestOptions
+from cfen_vit_dehazing_amd.util import util
+from cfen_vit_dehazing_amd.util.visualizer import save_images
+from cfen_vit_dehazing_amd import data as cdata
+from cfen_vit_dehazing_amd.models import create_model
+
+
+def parse(tmp_path, extra=()):
+    argv = ['--dataroot', str(tmp_path / 'data'), '--checkpoints_dir', str(tmp_path / 'ckpt'), '--results_dir', str(tmp_path / 'res'),
+            '--name', 'iid_hlgvit_crs_gd4_cfs_v3_unit', '--n_feats', '24', '--hidden_dim_ratio', '4', '--sb', '--out_all'] + list(extra)
+    return TestOptions().parse(argv)
+
+
+def test_tensor2im_matches_reference_vectors(golden_dir):
+    kat = np.load(golden_dir + "/ops_kat.npz")
+    assert np.array_equal(util.tensor2im(torch.from_numpy(kat["t2i/x"])), kat["t2i/y"])      # truncation, 1-channel tiling
+    assert np.array_equal(util.tensor2im(torch.from_numpy(kat["t2i/x3"])), kat["t2i/y3"])
+
+
+def test_options_defaults_and_readme_command(tmp_path):
+    opt = parse(tmp_path, ['--which_epoch', '32', '--some_training_flag', '7'])
+    assert (opt.n_feats, opt.hidden_dim_ratio, opt.patch_size, opt.loadSize, opt.patch_dim, opt.num_heads) == (24, 4, 32, 256, 2, 4)
+    assert opt.model == 'dec_vit' and opt.model_G == 'iid_hlgvit_crs_gd4_cfs_v3' and opt.dataset_mode == 'dec_vit'
+    assert opt.gpu_ids == [0] and opt.isTrain is False and opt.which_epoch == '32' and opt.batchSize == 1
+    assert os.path.exists(tmp_path / 'ckpt' / opt.name / 'opt.txt')                           # base_options.py:241-248
+    d = TestOptions().parse(['--dataroot', 'x', '--checkpoints_dir', str(tmp_path / 'c2')])
+    assert (d.n_feats, d.hidden_dim_ratio, d.how_many, d.which_epoch, d.phase) == (32, 6, 924, 'latest', 'test')
+
+
+def test_dataset_reads_hazy_folder_in_order(tmp_path):
+    hazy = tmp_path / 'data' / 'hazy'
+    hazy.mkdir(parents=True)
+    rs = np.random.RandomState(0)
+    imgs = {}
+    for nm in ('b_0002.png', 'a_0001.png', 'c.jpg.txt'):
+        if nm.endswith('.txt'):
+            (hazy / nm).write_text('not an image')
+            continue
+        a = rs.randint(0, 256, (16, 24, 3), dtype=np.uint8)
+        Image.fromarray(a).save(hazy / nm)
+        imgs[nm] = a
+    opt = parse(tmp_path, ['--batchSize', '2'])
+    loader = cdata.CreateDataLoader(opt).load_data()
+    batches = list(loader)
+    assert len(loader) == 2 and len(batches) == 1
+    b = batches[0]
+    assert [os.path.basename(p) for p in b['B_paths']] == ['a_0001.png', 'b_0002.png']            # sorted (dec_vit_data.py:32)
+    want = torch.from_numpy(imgs['a_0001.png']).permute(2, 0, 1).float() / 255 * 2 - 1
+    assert b['B'].shape == (2, 3, 16, 24) and torch.allclose(b['B'][0], want, atol=1e-6)
+    with pytest.raises(ValueError):
+        opt.dataset_mode = 'vit'
+        cdata.CreateDataset(opt)
+
+
+def test_save_images_naming(tmp_path):
+    from collections import OrderedDict
+    vis = OrderedDict(fake_A=torch.zeros(2, 3, 4, 4), fake_S=torch.ones(2, 1, 4, 4) * 0.5)
+    save_images(str(tmp_path), vis, ['/x/y/img_0001.png', 'C:\\d\\img_0002.jpg'])
+    assert sorted(os.listdir(tmp_path)) == ['img_0001_fake_A.png', 'img_0001_fake_S.png', 'img_0002_fake_A.png', 'img_0002_fake_S.png']
+    a = np.asarray(Image.open(tmp_path / 'img_0001_fake_A.png'))
+    assert a.shape == (4, 4, 3) and int(a[0, 0, 0]) == 127                                       # (0+1)/2*255 = 127.5 -> 127
+    s = np.asarray(Image.open(tmp_path / 'img_0002_fake_S.png'))
+    assert s.shape == (4, 4, 3) and int(s[0, 0, 0]) == 191
+
+
+def test_module_state_dict_is_reference_compatible(tmp_path):
+    cfg = NetConfig(8, 2, patch_size=8, load_size=64)              # small n_feats: same key structure, 30x fewer bytes
+    net = dec_ipt(cfg)
+    keys = [k for k, _, _ in state_manifest(cfg)]
+    assert list(net.state_dict().keys()) == keys                   # same keys, same order as dec_ipt(opt).state_dict()
+    sd = generate_state_dict(cfg)
+    net.load_state_dict(sd, strict=True)
+    for k, v in net.state_dict().items():
+        assert torch.equal(v, sd[k]), k
+    bad = dict(sd)
+    bad.pop('head.0.0.weight')
+    with pytest.raises(RuntimeError):
+        net.load_state_dict(bad, strict=True)                      # strict, like base_model.py:131
+    bad = dict(sd)
+    bad['head.0.0.weight'] = torch.zeros(4, 3, 3, 3)
+    with pytest.raises(RuntimeError):
+        net.load_state_dict(bad)
+
+
+def test_create_model_errors_and_checkpoint_roundtrip(tmp_path):
+    opt = parse(tmp_path, ['--loadSize', '64', '--patch_size', '8', '--gpu_ids', '-1'])
+    opt.n_feats, opt.hidden_dim_ratio = 8, 2                       # keep the checkpoint files small
+    opt.model = 'vit'
+    with pytest.raises(NotImplementedError):
+        create_model(opt)                                          # models/__init__.py:26
+    opt.model = 'dec_vit'
+    model = create_model(opt)
+    assert model.name() == 'DECHLGVIT' and model.model_names == ['G'] and model.visual_names == ['fake_A', 'real_B', 'fake_R', 'fake_S']
+    assert str(model.device) == 'cpu' and model.save_dir == os.path.join(opt.checkpoints_dir, opt.name)
+    with pytest.raises(FileNotFoundError):
+        model.setup(opt)                                           # no checkpoint yet
+    sd = generate_state_dict(NetConfig(8, 2, patch_size=8, load_size=64), seed=3)
+    torch.save(sd, os.path.join(model.save_dir, 'latest_net_G.pth'))
+    model.setup(opt)
+    assert torch.equal(model.netG.state_dict()['tail_S.0.4.weight'], sd['tail_S.0.4.weight'])
+    model.save_networks('7')
+    again = torch.load(os.path.join(model.save_dir, '7_net_G.pth'))
+    assert list(again.keys()) == list(sd.keys()) and torch.equal(again['head.0.0.bias'], sd['head.0.0.bias'])
+    # CPU tensors are refused loudly: there is no fallback path
+    model.set_input({'B': torch.zeros(1, 3, 128, 128), 'B_paths': ['x.png']})
+    with pytest.raises(Exception):
+        model.test(opt)
+    opt.model_G = 'iid_cnn_crs'
+    m2 = create_model(opt)
+    assert not hasattr(m2, 'netG')                                 # reference: silently undefined -> AttributeError later
