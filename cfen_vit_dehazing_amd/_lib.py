@@ -29,6 +29,12 @@ class ConvArgsC(ctypes.Structure):
                [(n, c_void_p) for n in ("src0", "src1", "weight", "scale", "shift", "res0", "res1", "out")]
 
 
+class MlpArgsC(ctypes.Structure):
+    _fields_ = [(n, c_void_p) for n in ("x", "y", "fmap", "ln_gamma", "ln_beta", "w1a", "b1a", "w2a", "b2a", "w1b", "b1b", "w2b", "b2b")] + \
+               [("M", ctypes.c_int64), ("D", ctypes.c_int32), ("H", ctypes.c_int32), ("eps", c_float)] + \
+               [(n, ctypes.c_int32) for n in ("mapH", "mapW", "C", "cs", "ws", "p")]
+
+
 # every symbol include/cfen_hip.h declares: (restype, argtypes)
 _I = c_int
 _P = c_void_p
@@ -48,6 +54,7 @@ SIGNATURES = {
     "cfen_gemm_nt": (_I, [_I, _P, _I, _P, _I, _P, _P, _I, _P, _I, _P, _I, _I, _I, _I, _I, _P]),
     "cfen_layernorm": (_I, [_I, _P, _P, _P, _P, _I, _I, c_float, _P]),
     "cfen_attention": (_I, [_I, _P, _P, _I, _I, _I, _I, _P]),
+    "cfen_mlp_block": (_I, [_I, ctypes.POINTER(MlpArgsC), _P]),
     "cfen_patchify": (_I, [_I, _P, _P] + [_I] * 8 + [_P]),
     "cfen_unpatchify": (_I, [_I, _P, _P] + [_I] * 7 + [_P]),
     "cfen_upsample4": (_I, [_I, _P, _P] + [_I] * 6 + [_P]),

@@ -6,7 +6,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libcfen_hip.so")
-SOURCES = ["k_gemm.hip", "k_attention.hip", "k_tokens.hip", "k_conv.hip", "k_dcn.hip", "cfen_api.cpp", "cfen_net.cpp"]
+SOURCES = ["k_gemm.hip", "k_attention.hip", "k_tokens.hip", "k_conv.hip", "k_mlp.hip", "k_dcn.hip", "cfen_api.cpp", "cfen_net.cpp"]
 
 
 def _newer(a, b):

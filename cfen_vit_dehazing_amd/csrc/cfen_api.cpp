@@ -7,6 +7,7 @@
 #include "cfen_common.hpp"
 #include "cfen_conv.hpp"
 #include "cfen_internal.hpp"
+#include "cfen_mlp.hpp"
 
 static thread_local char g_err[512] = "";
 
@@ -34,6 +35,17 @@ int cfen_layernorm(int dtype, const void* X, void* Y, const float* gamma, const 
 
 int cfen_attention(int dtype, const void* qkv, void* out, int nseq, int S, int heads, int dh, void* stream) {
   return cfen_attention_impl(dtype, qkv, out, nseq, S, heads, dh, (hipStream_t)stream);
+}
+
+int cfen_mlp_block(int dtype, const cfen_mlp_args* a, void* stream) {
+  CFEN_CHECK_ARG(a != nullptr, "mlp_block: null args");
+  MlpArgs m{};
+  m.X = a->x; m.Y = a->y; m.fmap = a->fmap; m.ln_g = a->ln_gamma; m.ln_b = a->ln_beta;
+  m.W1a = a->w1a; m.b1a = a->b1a; m.W2a = a->w2a; m.b2a = a->b2a;
+  m.W1b = a->w1b; m.b1b = a->b1b; m.W2b = a->w2b; m.b2b = a->b2b;
+  m.M = a->M; m.D = a->D; m.H = a->H; m.eps = a->eps;
+  m.mapH = a->mapH; m.mapW = a->mapW; m.C = a->C; m.cs = a->cs; m.ws = a->ws; m.p = a->p;
+  return cfen_mlp_impl(dtype, &m, (hipStream_t)stream);
 }
 
 int cfen_patchify(int dtype, const void* fmap, void* tokens, int B, int H, int W, int C, int cs, int ws, int p, int pool, void* stream) {

@@ -1,0 +1,20 @@
+// Arguments of the fused token-MLP kernel (k_mlp.hip).
+#pragma once
+#include <hip/hip_runtime.h>
+
+struct MlpArgs {
+  const void* X;        // [M][D] tokens in
+  void* Y;              // [M][D] tokens out (may alias X), or null when fmap is set
+  void* fmap;           // optional: fold the result into an NHWC map (unpatchify fused)
+  const float* ln_g;    // LayerNorm before stage a (null = none)
+  const float* ln_b;
+  const void* W1a; const float* b1a; const void* W2a; const float* b2a;   // stage a: y1 = x + W2a relu(W1a LN(x) + b1a) + b2a
+  const void* W1b; const float* b1b; const void* W2b; const float* b2b;   // stage b (optional): y2 = y1 + W2b relu(W1b y1 + b1b) + b2b
+  long long M;
+  int D, H;
+  float eps;
+  int mapH, mapW, C, cs, ws, p;   // fold geometry when fmap != null
+};
+
+bool cfen_mlp_supported(int D, int H, int dtype);
+int cfen_mlp_impl(int dtype, const MlpArgs* a, hipStream_t s);

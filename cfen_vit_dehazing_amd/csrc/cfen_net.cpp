@@ -13,6 +13,7 @@
 #include "cfen_common.hpp"
 #include "cfen_conv.hpp"
 #include "cfen_internal.hpp"
+#include "cfen_mlp.hpp"
 
 namespace {
 
@@ -30,6 +31,7 @@ struct Vit {
   int level, C, p, S, D, heads, hidden;
   int mapH;   // edge of the map the tokens tile (pooled edge for GViT)
   int ws;     // window edge on that map
+  bool fused_mlp;   // LN2+FFN+mlp_head+fold run as one k_mlp launch
 };
 struct ConvLayer {
   int kind, k, stride, pad, reflect, nsrc, Cin, Cin_real, Cout, Cout_pad, Kpad, nphase, ntaps, out_edge;
@@ -118,7 +120,7 @@ struct cfen_net {
     if (rc__) return rc__;                \
   } while (0)
 
-enum { K_GEMM = 0, K_ATTN = 1, K_LNORM = 2, K_TOKEN = 3, K_CONV = 4, K_NORM = 5, K_NCLASS = 6 };
+enum { K_GEMM = 0, K_ATTN = 1, K_LNORM = 2, K_TOKEN = 3, K_CONV = 4, K_NORM = 5, K_MLP = 6, K_NCLASS = 7 };
 
 int cfen_net::build() {
   const int nf = cfg.n_feats, N = cfg.load_size, B = cfg.batch;
@@ -159,7 +161,8 @@ int cfen_net::build() {
     for (int l = 3; l >= 1; --l) gv("globalvit_decoder_0" + std::to_string(l) + br[b], l);
 
   size_t max_md = 0, max_mh = 0, max_small = 0;
-  for (const Vit& v : vits) {
+  for (Vit& v : vits) {
+    v.fused_mlp = cfen_mlp_supported(v.D, v.hidden, cfg.dtype);
     CFEN_CHECK_ARG(v.mapH % v.ws == 0 && v.ws % v.p == 0 && v.S >= 1, "net: %s does not tile its map", v.name.c_str());
     const size_t ntok = (size_t)B * (v.mapH / v.ws) * (v.mapH / v.ws) * v.S;
     max_md = std::max(max_md, ntok * v.D);
@@ -172,10 +175,11 @@ int cfen_net::build() {
     need(n + ".qkv.w", (size_t)3 * v.D * v.D * esz);
     need(n + ".proj.w", (size_t)v.D * v.D * esz);
     need(n + ".ln2.g", (size_t)v.D * 4); need(n + ".ln2.b", (size_t)v.D * 4);
-    need(n + ".ffn1.w", (size_t)v.hidden * v.D * esz); need(n + ".ffn1.b", (size_t)v.hidden * 4);
-    need(n + ".ffn2.w", (size_t)v.hidden * v.D * esz); need(n + ".ffn2.b", (size_t)v.D * 4);
-    need(n + ".head1.w", (size_t)v.hidden * v.D * esz); need(n + ".head1.b", (size_t)v.hidden * 4);
-    need(n + ".head2.w", (size_t)v.hidden * v.D * esz); need(n + ".head2.b", (size_t)v.D * 4);
+    const char* wn = v.fused_mlp ? ".wk" : ".w";
+    need(n + ".ffn1" + wn, (size_t)v.hidden * v.D * esz); need(n + ".ffn1.b", (size_t)v.hidden * 4);
+    need(n + ".ffn2" + wn, (size_t)v.hidden * v.D * esz); need(n + ".ffn2.b", (size_t)v.D * 4);
+    need(n + ".head1" + wn, (size_t)v.hidden * v.D * esz); need(n + ".head1.b", (size_t)v.hidden * 4);
+    need(n + ".head2" + wn, (size_t)v.hidden * v.D * esz); need(n + ".head2.b", (size_t)v.D * 4);
   }
 
   // ---- convolution layers ----
@@ -292,24 +296,32 @@ int cfen_net::run_vit(const Vit& v, const std::string& in, const std::string& ou
   TRYP(K_ATTN, 4 * Md * v.S * D, cfen_attention_impl(dt, QKV, ATT, B * nwin, v.S, v.heads, v.D / v.heads, stream));
   TRYP(K_GEMM, 2 * Md * D * D,
        cfen_gemm_impl(dt, ATT, v.D, P(n + ".proj.w"), v.D, nullptr, X1, v.D, nullptr, 0, X1, v.D, M, v.D, v.D, 0, stream));
-  // src = src + linear2(relu(linear1(LN2(src))))                             (v3:1387-1389)
-  TRYP(K_LNORM, 0, cfen_layernorm_impl(dt, X1, YN, Pf(n + ".ln2.g"), Pf(n + ".ln2.b"), M, v.D, 1e-5f, stream));
-  TRYP(K_GEMM, 2 * Md * D * Hd,
-       cfen_gemm_impl(dt, YN, v.D, P(n + ".ffn1.w"), v.D, Pf(n + ".ffn1.b"), nullptr, 0, nullptr, 0, HID, v.hidden, M, v.hidden, v.D, 1, stream));
-  TRYP(K_GEMM, 2 * Md * D * Hd,
-       cfen_gemm_impl(dt, HID, v.hidden, P(n + ".ffn2.w"), v.hidden, Pf(n + ".ffn2.b"), X1, v.D, nullptr, 0, X1, v.D, M, v.D, v.hidden, 0, stream));
-  // x = mlp_head(x) + x                                                      (v3:1173)
-  TRYP(K_GEMM, 2 * Md * D * Hd,
-       cfen_gemm_impl(dt, X1, v.D, P(n + ".head1.w"), v.D, Pf(n + ".head1.b"), nullptr, 0, nullptr, 0, HID, v.hidden, M, v.hidden, v.D, 1, stream));
-  TRYP(K_GEMM, 2 * Md * D * Hd,
-       cfen_gemm_impl(dt, HID, v.hidden, P(n + ".head2.w"), v.hidden, Pf(n + ".head2.b"), X1, v.D, nullptr, 0, X0, v.D, M, v.D, v.hidden, 0, stream));
-  if (!v.global) {
-    TRYP(K_TOKEN, 0, cfen_patchify_impl(dt, map_ptr(out), X0, B, v.mapH, v.mapH, v.C, bo.cs, v.ws, v.p, 1, 1, stream));
-    return CFEN_OK;
+  void* SM = v.global ? at(o_small) : nullptr;
+  if (v.fused_mlp) {
+    // LN2 + FFN + residual + mlp_head + residual + fold, hidden activations never leave registers (k_mlp.hip)
+    MlpArgs m{};
+    m.X = X1; m.Y = nullptr; m.fmap = v.global ? SM : map_ptr(out);
+    m.ln_g = Pf(n + ".ln2.g"); m.ln_b = Pf(n + ".ln2.b");
+    m.W1a = P(n + ".ffn1.wk"); m.b1a = Pf(n + ".ffn1.b"); m.W2a = P(n + ".ffn2.wk"); m.b2a = Pf(n + ".ffn2.b");
+    m.W1b = P(n + ".head1.wk"); m.b1b = Pf(n + ".head1.b"); m.W2b = P(n + ".head2.wk"); m.b2b = Pf(n + ".head2.b");
+    m.M = M; m.D = v.D; m.H = v.hidden; m.eps = 1e-5f;
+    m.mapH = v.mapH; m.mapW = v.mapH; m.C = v.C; m.cs = v.global ? v.C : bo.cs; m.ws = v.ws; m.p = v.p;
+    TRYP(K_MLP, 8 * Md * D * Hd, cfen_mlp_impl(dt, &m, stream));
+  } else {
+    // src = src + linear2(relu(linear1(LN2(src))))                             (v3:1387-1389)
+    TRYP(K_LNORM, 0, cfen_layernorm_impl(dt, X1, YN, Pf(n + ".ln2.g"), Pf(n + ".ln2.b"), M, v.D, 1e-5f, stream));
+    TRYP(K_GEMM, 2 * Md * D * Hd,
+         cfen_gemm_impl(dt, YN, v.D, P(n + ".ffn1.w"), v.D, Pf(n + ".ffn1.b"), nullptr, 0, nullptr, 0, HID, v.hidden, M, v.hidden, v.D, 1, stream));
+    TRYP(K_GEMM, 2 * Md * D * Hd,
+         cfen_gemm_impl(dt, HID, v.hidden, P(n + ".ffn2.w"), v.hidden, Pf(n + ".ffn2.b"), X1, v.D, nullptr, 0, X1, v.D, M, v.D, v.hidden, 0, stream));
+    // x = mlp_head(x) + x                                                      (v3:1173)
+    TRYP(K_GEMM, 2 * Md * D * Hd,
+         cfen_gemm_impl(dt, X1, v.D, P(n + ".head1.w"), v.D, Pf(n + ".head1.b"), nullptr, 0, nullptr, 0, HID, v.hidden, M, v.hidden, v.D, 1, stream));
+    TRYP(K_GEMM, 2 * Md * D * Hd,
+         cfen_gemm_impl(dt, HID, v.hidden, P(n + ".head2.w"), v.hidden, Pf(n + ".head2.b"), X1, v.D, nullptr, 0, X0, v.D, M, v.D, v.hidden, 0, stream));
+    TRYP(K_TOKEN, 0, cfen_patchify_impl(dt, v.global ? SM : map_ptr(out), X0, B, v.mapH, v.mapH, v.C, v.global ? v.C : bo.cs, v.ws, v.p, 1, 1, stream));
   }
-  void* SM = at(o_small);
-  TRYP(K_TOKEN, 0, cfen_patchify_impl(dt, SM, X0, B, v.mapH, v.mapH, v.C, v.C, v.ws, v.p, 1, 1, stream));
-  TRYP(K_TOKEN, 0, cfen_upsample4_impl(dt, SM, map_ptr(out), B, v.mapH, v.mapH, v.C, v.C, bo.cs, stream));
+  if (v.global) TRYP(K_TOKEN, 0, cfen_upsample4_impl(dt, SM, map_ptr(out), B, v.mapH, v.mapH, v.C, v.C, bo.cs, stream));
   return CFEN_OK;
 }
 

@@ -1,0 +1,271 @@
+// Fused token MLP block:   y1 = x  + W2 relu(W1 LN(x) + b1) + b2      (encoder FFN,  v3:1387-1389)
+//                           y2 = y1 + Wh2 relu(Wh1 y1 + bh1) + bh2     (mlp_head,     v3:1173)
+//                           fold(y2) -> NHWC feature map                (v3:1176,1186 + Join2x2 v3:1046-1056)
+// for LViT / GViT instances with D in {96, 192, 384}.
+//
+// Each wave owns TM*16 tokens for the whole chain; tokens never leave its registers:
+//   * the residual stream lives as fp32 MFMA accumulators acc[n-tile][m-tile] (rows = features, cols = tokens),
+//     D/16 * TM = 24 tiles for every supported D (TM = 4 / 2 / 1);
+//   * LayerNorm reduces over features = over a lane's registers + two xor-shuffles (lanes l^16, l^32);
+//   * an accumulator tile pair IS the B operand of the next GEMM (k-slot (h,j) of a 32-deep chunk <- rows
+//     4h+j of tile a, j<4, and of tile b, j>=4), so LN(x) feeds FFN1 and relu(FFN1) feeds FFN2 with no LDS
+//     or HBM round trip; the hidden activation (M x 4D, the largest tensor of the block) is never stored.
+//     The matching permutation of the weights' k axis is applied once on the host (packing.kperm32).
+//   * weights stream through LDS in hidden-dim chunks shared by the workgroup's 4 waves, with the next
+//     chunk's global loads in flight during the MFMAs (register prefetch, two barriers per chunk).
+// HBM traffic per instance: read x once, write y2 once (+ weights from L2).
+#include "cfen_common.hpp"
+#include "cfen_mlp.hpp"
+
+namespace {
+
+template <typename T> struct Pack;
+template <> struct Pack<half_t> {
+  static constexpr int NPC = 2;   // accumulator n-tiles per K chunk
+  static CFEN_DEV half8 make(const floatx4* t) {   // t[0], t[1]: tiles a, b of the same token tile
+    half8 f = {(half_t)t[0][0], (half_t)t[0][1], (half_t)t[0][2], (half_t)t[0][3],
+               (half_t)t[1][0], (half_t)t[1][1], (half_t)t[1][2], (half_t)t[1][3]};
+    return f;
+  }
+};
+template <> struct Pack<float> {
+  static constexpr int NPC = 1;
+  static CFEN_DEV floatx4 make(const floatx4* t) { return t[0]; }
+};
+
+template <typename T, int ND, int TM>
+__global__ __launch_bounds__(256) void k_mlp(MlpArgs a) {
+  constexpr int KC = Mma<T>::KC, EPL = Mma<T>::EPL, SZ = (int)sizeof(T);
+  constexpr int NPC = Pack<T>::NPC;
+  constexpr int D = ND * 16;
+  constexpr int NCH = ND / NPC;                   // K chunks over D
+  constexpr int W1ROW = D * SZ + 16;              // LDS row of the W1 slice (KC rows)
+  constexpr int W2ROW = KC * SZ + 16;             // LDS row of the W2 slice (D rows)
+  constexpr int W1BYTES = KC * W1ROW;
+  constexpr int P1 = KC * (D * SZ / 16);          // 16-byte pieces of the W1 slice
+  constexpr int P2 = D * (KC * SZ / 16);          // ... of the W2 slice
+  constexpr int NPF = (P1 + P2) / 256;            // prefetch pieces per thread
+  static_assert((P1 + P2) % 256 == 0, "slice pieces must split evenly over 256 threads");
+  typedef typename Mma<T>::frag frag;
+  __shared__ __attribute__((aligned(16))) unsigned char lds[W1BYTES + D * W2ROW];
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r16 = lane & 15, h = lane >> 4;
+  const long long tok0 = ((long long)blockIdx.x * 4 + wave) * (TM * 16);
+
+  // ---- load x^T into accumulator layout: acc[i][j][r] = x[token j*16+r16][feature i*16+4h+r] ----
+  floatx4 acc[ND][TM];
+  const T* X = (const T*)a.X;
+#pragma unroll
+  for (int j = 0; j < TM; ++j) {
+    long long t = tok0 + j * 16 + r16;
+    if (t >= a.M) t = a.M - 1;
+    const T* xp = X + t * D + 4 * h;
+#pragma unroll
+    for (int i = 0; i < ND; ++i) acc[i][j] = load4<T>(xp + i * 16);
+  }
+
+  frag xb[NCH][TM];
+#pragma unroll 1
+  for (int stage = 0; stage < 2; ++stage) {
+    const T* W1 = (const T*)(stage ? a.W1b : a.W1a);
+    const T* W2 = (const T*)(stage ? a.W2b : a.W2a);
+    const float* b1 = stage ? a.b1b : a.b1a;
+    const float* b2 = stage ? a.b2b : a.b2a;
+    if (!W1) break;
+    // ---- B fragments of the stage input (LayerNorm first for the FFN stage) ----
+    if (stage == 0 && a.ln_g) {
+#pragma unroll
+      for (int j = 0; j < TM; ++j) {
+        float s = 0.f;
+#pragma unroll
+        for (int i = 0; i < ND; ++i) s += acc[i][j][0] + acc[i][j][1] + acc[i][j][2] + acc[i][j][3];
+        s += __shfl_xor(s, 16, 64);
+        s += __shfl_xor(s, 32, 64);
+        const float mean = s * (1.f / D);
+        float q = 0.f;
+#pragma unroll
+        for (int i = 0; i < ND; ++i)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            float d = acc[i][j][r] - mean;
+            q += d * d;
+          }
+        q += __shfl_xor(q, 16, 64);
+        q += __shfl_xor(q, 32, 64);
+        const float rstd = rsqrtf(q * (1.f / D) + a.eps);
+#pragma unroll
+        for (int c = 0; c < NCH; ++c) {
+          floatx4 t[NPC];
+#pragma unroll
+          for (int u = 0; u < NPC; ++u) {
+            const int i = c * NPC + u;
+            const floatx4 g = *reinterpret_cast<const floatx4*>(a.ln_g + i * 16 + 4 * h);
+            const floatx4 b = *reinterpret_cast<const floatx4*>(a.ln_b + i * 16 + 4 * h);
+            t[u] = (acc[i][j] - mean) * rstd * g + b;
+          }
+          xb[c][j] = Pack<T>::make(t);
+        }
+      }
+    } else {
+#pragma unroll
+      for (int j = 0; j < TM; ++j)
+#pragma unroll
+        for (int c = 0; c < NCH; ++c) xb[c][j] = Pack<T>::make(&acc[c * NPC][j]);
+    }
+    // residual + output bias: acc <- x + b2, FFN2 accumulates on top
+#pragma unroll
+    for (int i = 0; i < ND; ++i) {
+      const floatx4 bb = *reinterpret_cast<const floatx4*>(b2 + i * 16 + 4 * h);
+#pragma unroll
+      for (int j = 0; j < TM; ++j) acc[i][j] += bb;
+    }
+
+    // ---- hidden-dim chunk loop ----
+    const int nhc = a.H / KC;
+    frag pf[NPF];
+    auto prefetch = [&](int hc) {
+#pragma unroll
+      for (int u = 0; u < NPF; ++u) {
+        const int id = tid + u * 256;
+        if (id < P1) {   // W1 slice: rows hc*KC.., D elements each
+          const int row = id / (D * SZ / 16), pc = id % (D * SZ / 16);
+          pf[u] = load_frag<T>(W1 + (size_t)(hc * KC + row) * D + pc * EPL);
+        } else {         // W2 slice: D rows, KC elements at column hc*KC
+          const int id2 = id - P1;
+          const int row = id2 / (KC * SZ / 16), pc = id2 % (KC * SZ / 16);
+          pf[u] = load_frag<T>(W2 + (size_t)row * a.H + hc * KC + pc * EPL);
+        }
+      }
+    };
+    auto commit = [&]() {
+#pragma unroll
+      for (int u = 0; u < NPF; ++u) {
+        const int id = tid + u * 256;
+        if (id < P1) {
+          const int row = id / (D * SZ / 16), pc = id % (D * SZ / 16);
+          *reinterpret_cast<frag*>(lds + row * W1ROW + pc * 16) = pf[u];
+        } else {
+          const int id2 = id - P1;
+          const int row = id2 / (KC * SZ / 16), pc = id2 % (KC * SZ / 16);
+          *reinterpret_cast<frag*>(lds + W1BYTES + row * W2ROW + pc * 16) = pf[u];
+        }
+      }
+    };
+    prefetch(0);
+#pragma unroll 1
+    for (int hc = 0; hc < nhc; ++hc) {
+      __syncthreads();               // every wave is done with the previous slice
+      commit();
+      __syncthreads();
+      if (hc + 1 < nhc) prefetch(hc + 1);
+      // FFN1 slice: hidden[KC units][tokens] = W1 slice . LN(x)^T + b1
+      floatx4 hacc[NPC][TM];
+#pragma unroll
+      for (int u = 0; u < NPC; ++u) {
+        const floatx4 bb = *reinterpret_cast<const floatx4*>(b1 + hc * KC + u * 16 + 4 * h);
+#pragma unroll
+        for (int j = 0; j < TM; ++j) hacc[u][j] = bb;
+#pragma unroll
+        for (int c = 0; c < NCH; ++c) {
+          const frag af = *reinterpret_cast<const frag*>(lds + (u * 16 + r16) * W1ROW + c * 64 + h * 16);
+#pragma unroll
+          for (int j = 0; j < TM; ++j) hacc[u][j] = Mma<T>::mma(af, xb[c][j], hacc[u][j]);
+        }
+      }
+      frag hb[TM];
+#pragma unroll
+      for (int j = 0; j < TM; ++j) {
+        floatx4 t[NPC];
+#pragma unroll
+        for (int u = 0; u < NPC; ++u)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) t[u][r] = fmaxf(hacc[u][j][r], 0.f);
+        hb[j] = Pack<T>::make(t);
+      }
+      // FFN2 slice: y += W2[:, slice] . relu(hidden)
+#pragma unroll
+      for (int i = 0; i < ND; ++i) {
+        const frag af = *reinterpret_cast<const frag*>(lds + W1BYTES + (i * 16 + r16) * W2ROW + h * 16);
+#pragma unroll
+        for (int j = 0; j < TM; ++j) acc[i][j] = Mma<T>::mma(af, hb[j], acc[i][j]);
+      }
+    }
+    __syncthreads();
+  }
+
+  // ---- epilogue: token-major store, or fold + window join into the NHWC map ----
+#pragma unroll
+  for (int j = 0; j < TM; ++j) {
+    const long long t = tok0 + j * 16 + r16;
+    if (t >= a.M) continue;
+    if (!a.fmap) {
+      T* yp = (T*)a.Y + t * D + 4 * h;
+#pragma unroll
+      for (int i = 0; i < ND; ++i) store4<T>(yp + i * 16, acc[i][j]);
+    } else {
+      // token -> (image, window, ty, tx); feature f = (pi*p + pj)*C + c  (token_perm order)
+      const int tw = a.ws / a.p, S = tw * tw;
+      const int nwx = a.mapW / a.ws, nwy = a.mapH / a.ws;
+      const int tt = (int)(t % S);
+      const long long wi = t / S;
+      const int wx = (int)(wi % nwx), wy = (int)((wi / nwx) % nwy);
+      const long long b = wi / ((long long)nwx * nwy);
+      const int y0 = wy * a.ws + (tt / tw) * a.p, x0 = wx * a.ws + (tt % tw) * a.p;
+#pragma unroll
+      for (int i = 0; i < ND; ++i) {
+        const int f = i * 16 + 4 * h;
+        const int ij = f / a.C, c = f - ij * a.C;
+        const int pi = ij / a.p, pj = ij - pi * a.p;
+        T* dst = (T*)a.fmap + ((b * a.mapH + y0 + pi) * a.mapW + x0 + pj) * a.cs + c;
+        store4<T>(dst, acc[i][j]);
+      }
+    }
+  }
+}
+
+template <typename T, int ND, int TM>
+int launch_mlp_t(const MlpArgs& a, hipStream_t s) {
+  const long long per = 4 * TM * 16;
+  const long long blocks = (a.M + per - 1) / per;
+  CFEN_CHECK_ARG(blocks > 0 && blocks < (1ll << 31), "mlp: bad grid");
+  hipLaunchKernelGGL((k_mlp<T, ND, TM>), dim3((unsigned)blocks), dim3(256), 0, s, a);
+  CFEN_CHECK_LAUNCH("mlp");
+  return CFEN_OK;
+}
+
+template <typename T>
+int launch_mlp(const MlpArgs& a, hipStream_t s) {
+  constexpr int KC = Mma<T>::KC;
+  CFEN_CHECK_ARG(a.M > 0 && a.H > 0 && a.H % KC == 0, "mlp: hidden dim %d must be a positive multiple of %d", a.H, KC);
+  CFEN_CHECK_ARG(a.X && a.W1a && a.W2a && a.b1a && a.b2a, "mlp: null pointer");
+  CFEN_CHECK_ARG((a.W1b == nullptr) == (a.W2b == nullptr) && (!a.W1b || (a.b1b && a.b2b)), "mlp: incomplete second stage");
+  CFEN_CHECK_ARG((a.ln_g == nullptr) == (a.ln_b == nullptr), "mlp: LayerNorm needs gamma and beta");
+  CFEN_CHECK_ARG(a.Y || a.fmap, "mlp: no output");
+  if (a.fmap) {
+    CFEN_CHECK_ARG(a.C > 0 && a.C % 4 == 0 && a.cs >= a.C && a.cs % 4 == 0 && a.p > 0 && a.ws % a.p == 0 && a.mapH % a.ws == 0 &&
+                   a.mapW % a.ws == 0 && a.p * a.p * a.C == a.D, "mlp: bad fold geometry");
+    CFEN_CHECK_ARG(a.M % ((long long)(a.ws / a.p) * (a.ws / a.p)) == 0, "mlp: token count does not tile the map");
+  }
+  CFEN_CHECK_ARG(cfen_aligned16(a.X) && cfen_aligned16(a.Y) && cfen_aligned16(a.fmap) && cfen_aligned16(a.W1a) && cfen_aligned16(a.W2a) &&
+                 cfen_aligned16(a.W1b) && cfen_aligned16(a.W2b) && cfen_aligned16(a.b1a) && cfen_aligned16(a.b2a) && cfen_aligned16(a.b1b) &&
+                 cfen_aligned16(a.b2b) && cfen_aligned16(a.ln_g) && cfen_aligned16(a.ln_b), "mlp: pointers must be 16-byte aligned");
+  switch (a.D) {
+    case 96: return launch_mlp_t<T, 6, 4>(a, s);
+    case 192: return launch_mlp_t<T, 12, 2>(a, s);
+    case 384: return launch_mlp_t<T, 24, 1>(a, s);
+    default:
+      cfen_set_error("mlp: fused kernel supports D in {96,192,384}, got %d", a.D);
+      return CFEN_ERR_ARG;
+  }
+}
+
+}  // namespace
+
+bool cfen_mlp_supported(int D, int H, int dtype) { return (D == 96 || D == 192 || D == 384) && H % (dtype == 1 ? 32 : 16) == 0; }
+
+int cfen_mlp_impl(int dtype, const MlpArgs* a, hipStream_t s) {
+  if (dtype == 1) return launch_mlp<half_t>(*a, s);
+  if (dtype == 0) return launch_mlp<float>(*a, s);
+  cfen_set_error("mlp: unknown dtype %d", dtype);
+  return CFEN_ERR_ARG;
+}

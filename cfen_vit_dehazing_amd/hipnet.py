@@ -119,7 +119,7 @@ class dec_ipt(nn.Module):
         return self._nets[batch]
 
     # ---- forward ----------------------------------------------------------------------------
-    KERNEL_CLASSES = ("gemm", "attention", "layernorm", "tokens", "conv", "norm")
+    KERNEL_CLASSES = ("gemm", "attention", "layernorm", "tokens", "conv", "norm", "mlp")
 
     def forward(self, x, out=None):
         """`out`: optional flat float32 CUDA buffer of 7*B*H*W elements that receives [xr | xs | xd]

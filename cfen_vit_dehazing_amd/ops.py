@@ -9,7 +9,7 @@ import ctypes
 import torch
 
 from . import _lib
-from ._lib import ptr, check, dtype_code, current_stream, ConvArgsC
+from ._lib import ptr, check, dtype_code, current_stream, ConvArgsC, MlpArgsC
 from .packing import round_up
 
 
@@ -46,6 +46,31 @@ def attention(qkv, nseq, S, heads):
     D = qkv.shape[1] // 3
     out = torch.empty(qkv.shape[0], D, dtype=qkv.dtype, device=qkv.device)
     check(_lib.load().cfen_attention(dtype_code(qkv.dtype), ptr(qkv), ptr(out), nseq, S, heads, D // heads, current_stream()), "attention")
+    return out
+
+
+def mlp_block(x, w1a, b1a, w2a, b2a, ln=None, second=None, fold=None):
+    """Fused y1 = x + W2a relu(W1a LN(x)+b1a) + b2a [; y2 = y1 + W2b relu(W1b y1 + b1b) + b2b].
+    Weights must already carry packing.kperm32 on their k axis for fp16.  fold = (B, H, W, C, cs, ws, p) writes
+    the result into a fresh NHWC map instead of a token matrix."""
+    _cuda(x, w1a, b1a, w2a, b2a)
+    M, D = x.shape
+    a = MlpArgsC(x=x.data_ptr(), w1a=w1a.data_ptr(), b1a=b1a.data_ptr(), w2a=w2a.data_ptr(), b2a=b2a.data_ptr(), M=M, D=D,
+                 H=w1a.shape[0], eps=1e-5)
+    if ln is not None:
+        _cuda(*ln)
+        a.ln_gamma, a.ln_beta = ln[0].data_ptr(), ln[1].data_ptr()
+    if second is not None:
+        _cuda(*second)
+        a.w1b, a.b1b, a.w2b, a.b2b = (t.data_ptr() for t in second)
+    if fold is None:
+        out = torch.empty_like(x)
+        a.y = out.data_ptr()
+    else:
+        B, H, W, C, cs, ws, p = fold
+        out = torch.zeros(B, H, W, cs, dtype=x.dtype, device=x.device)
+        a.fmap, a.mapH, a.mapW, a.C, a.cs, a.ws, a.p = out.data_ptr(), H, W, C, cs, ws, p
+    check(_lib.load().cfen_mlp_block(dtype_code(x.dtype), ctypes.byref(a), current_stream()), "mlp_block")
     return out
 
 

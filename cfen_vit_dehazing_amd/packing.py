@@ -32,6 +32,23 @@ def token_perm(C, p):
     return torch.arange(C * p * p).view(C, p * p).t().reshape(-1)
 
 
+def kperm32(n):
+    """k-axis permutation that lets an MFMA accumulator tile pair feed the next MFMA as its B operand
+    (csrc/k_mlp.hip): inside every group of 32, slot 8h+j holds index 4h+j (j<4) or 16+4h+(j-4) (j>=4)."""
+    assert n % 32 == 0
+    slot = torch.arange(32)
+    hh, jj = slot // 8, slot % 8
+    old = torch.where(jj < 4, 4 * hh + jj, 16 + 4 * hh + (jj - 4))
+    return (torch.arange(0, n, 32).view(-1, 1) + old.view(1, -1)).reshape(-1)
+
+
+FUSED_MLP_DIMS = (96, 192, 384)
+
+
+def mlp_is_fused(g, dtype):
+    return g.dim in FUSED_MLP_DIMS and g.hidden % (32 if dtype == torch.float16 else 16) == 0
+
+
 def pack_vit(sd, g, dtype):
     n = g.name
     perm = token_perm(g.channels, g.patch)
@@ -50,6 +67,13 @@ def pack_vit(sd, g, dtype):
         n + ".head1.w": sd[n + ".mlp_head.0.weight"][:, perm].to(dtype), n + ".head1.b": sd[n + ".mlp_head.0.bias"].to(f32),
         n + ".head2.w": sd[n + ".mlp_head.3.weight"][perm].to(dtype), n + ".head2.b": sd[n + ".mlp_head.3.bias"][perm].to(f32),
     }
+    if mlp_is_fused(g, dtype):
+        # the fused MLP kernel replaces the four separate GEMMs: same matrices, k axis re-slotted (fp16 only)
+        for a, b in (("ffn1", "ffn2"), ("head1", "head2")):
+            w1, w2 = out.pop(n + "." + a + ".w"), out.pop(n + "." + b + ".w")
+            if dtype == torch.float16:
+                w1, w2 = w1[:, kperm32(g.dim)], w2[:, kperm32(g.hidden)]
+            out[n + "." + a + ".wk"], out[n + "." + b + ".wk"] = w1.contiguous(), w2.contiguous()
     return out
 
 

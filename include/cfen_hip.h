@@ -63,9 +63,9 @@ int cfen_net_forward(cfen_net* net, const float* x, float* xr, float* xs, float*
                      void* stream);
 /* one forward with a HIP event pair around every kernel launch on `stream` (synchronises the stream at
  * the end -- not graph-capturable).  Classes: 0 token GEMMs, 1 attention, 2 LayerNorm, 3 patchify /
- * unpatchify / upsample / layout, 4 convolutions, 5 InstanceNorm / CFSM2G.  Per class: summed kernel
+ * unpatchify / upsample / layout, 4 convolutions, 5 InstanceNorm / CFSM2G, 6 fused token MLP.  Per class: summed kernel
  * milliseconds, algorithmic FLOPs (2*MAC) of those launches, number of launches.                  */
-#define CFEN_NUM_KERNEL_CLASSES 6
+#define CFEN_NUM_KERNEL_CLASSES 7
 int cfen_net_profile(cfen_net* net, const float* x, float* xr, float* xs, float* xd, void* workspace, size_t workspace_bytes,
                      void* stream, double* ms_per_class, double* flops_per_class, int32_t* launches_per_class, int nclass);
 /* device pointer + geometry of a named top-level stage output (SURVEY Appendix D names) inside the
@@ -83,6 +83,22 @@ int cfen_gemm_nt(int dtype, const void* X, int ldx, const void* W, int ldw, cons
 int cfen_layernorm(int dtype, const void* X, void* Y, const float* gamma, const float* beta, int M, int D, float eps, void* stream);
 /* softmax(QK^T/sqrt(dh))V per (sequence, head); QKV is [nseq*S][3*heads*dh], out [nseq*S][heads*dh]  (v3:1364) */
 int cfen_attention(int dtype, const void* qkv, void* out, int nseq, int S, int heads, int dh, void* stream);
+/* Fused token MLP block (D in {96,192,384}):
+ *   y1 = x + W2a relu(W1a LN(x) + b1a) + b2a  (LN skipped when ln_gamma is NULL);  y2 = y1 + W2b relu(W1b y1 + b1b) + b2b
+ *   (second stage skipped when W1b is NULL).  Output: token-major `y` and/or folded into the NHWC map `fmap`
+ *   (F.fold + Join2x2: map H x W, channels C with stride cs, window ws, patch p).  Weights [H][D] / [D][H] with
+ *   the k axis in packing.kperm32 order for CFEN_F16 (natural order for CFEN_F32).   (v3:1387-1389, 1173, 1186) */
+typedef struct cfen_mlp_args {
+  const void* x; void* y; void* fmap;
+  const float* ln_gamma; const float* ln_beta;
+  const void* w1a; const float* b1a; const void* w2a; const float* b2a;
+  const void* w1b; const float* b1b; const void* w2b; const float* b2b;
+  int64_t M;
+  int32_t D, H;
+  float eps;
+  int32_t mapH, mapW, C, cs, ws, p;
+} cfen_mlp_args;
+int cfen_mlp_block(int dtype, const cfen_mlp_args* a, void* stream);
 /* window partition + unfold (+ optional 4x4 mean pool) / fold + window join          (v3:1025-1056,1140,1186,1274) */
 int cfen_patchify(int dtype, const void* fmap, void* tokens, int B, int H, int W, int C, int cs, int ws, int p, int pool, void* stream);
 int cfen_unpatchify(int dtype, const void* tokens, void* fmap, int B, int H, int W, int C, int cs, int ws, int p, void* stream);

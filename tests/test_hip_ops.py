@@ -248,3 +248,50 @@ def test_cfsm2g_against_reference_vectors(dtype, golden_dir):
     xn = [ops.to_nhwc(x.to(dtype)).to(d) for x in xs]
     got = ops.from_nhwc(ops.cfsm2g(xn[0], xn[1], xn[2], w.to(d), 8), 8)
     close(got, torch.from_numpy(kat["cfsm/y"]), tol(dtype, 4))
+
+
+# ---------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("D,H,M", [(96, 384, 300), (96, 192, 64), (192, 768, 200), (384, 1536, 130), (384, 768, 64)])
+def test_fused_mlp_block(dtype, D, H, M):
+    x = rnd((M, D), 1, dtype)
+    g, b = 1 + 0.1 * rnd((D,), 2, torch.float32), 0.1 * rnd((D,), 3, torch.float32)
+    w1a, w2a = rnd((H, D), 4, dtype, D ** -0.5), rnd((D, H), 5, dtype, 0.5 * H ** -0.5)
+    w1b, w2b = rnd((H, D), 6, dtype, D ** -0.5), rnd((D, H), 7, dtype, 0.5 * H ** -0.5)
+    b1a, b2a, b1b, b2b = (0.1 * rnd((n,), 8 + i, torch.float32) for i, n in enumerate((H, D, H, D)))
+    xd = x.double()
+    y1 = xd + torch.relu(cfen_oracle.layer_norm(xd, g.double(), b.double()) @ w1a.double().t() + b1a.double()) @ w2a.double().t() + b2a.double()
+    y2 = y1 + torch.relu(y1 @ w1b.double().t() + b1b.double()) @ w2b.double().t() + b2b.double()
+    d = dev()
+    if dtype == torch.float16:
+        kd, kh = packing.kperm32(D), packing.kperm32(H)
+        p = lambda w1, w2: (w1[:, kd].contiguous().to(d), w2[:, kh].contiguous().to(d))
+    else:
+        p = lambda w1, w2: (w1.to(d), w2.to(d))
+    wa, wb = p(w1a, w2a), p(w1b, w2b)
+    one = ops.mlp_block(x.to(d), wa[0], b1a.to(d), wa[1], b2a.to(d), ln=(g.to(d), b.to(d)))
+    close(one, y1, tol(dtype, 6), "stage a")
+    two = ops.mlp_block(x.to(d), wa[0], b1a.to(d), wa[1], b2a.to(d), ln=(g.to(d), b.to(d)), second=(wb[0], b1b.to(d), wb[1], b2b.to(d)))
+    close(two, y2, tol(dtype, 10), "both stages")
+    nol = ops.mlp_block(x.to(d), wa[0], b1a.to(d), wa[1], b2a.to(d))
+    close(nol, xd + torch.relu(xd @ w1a.double().t() + b1a.double()) @ w2a.double().t() + b2a.double(), tol(dtype, 6), "no LN")
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_fused_mlp_fold_epilogue(dtype):
+    # D = 96 = 2*2*24: 8x8 windows of 2x2 patches on a 16x32 map, padded channel stride
+    B, C, Hm, Wm, ws, pp, cs = 2, 24, 16, 32, 8, 2, 32
+    D, H = 96, 192
+    M = B * Hm * Wm // 4
+    x = rnd((M, D), 1, dtype)
+    w1, w2 = rnd((H, D), 2, dtype, D ** -0.5), rnd((D, H), 3, dtype, H ** -0.5)
+    b1, b2 = 0.1 * rnd((H,), 4, torch.float32), 0.1 * rnd((D,), 5, torch.float32)
+    d = dev()
+    if dtype == torch.float16:
+        w1p, w2p = w1[:, packing.kperm32(D)].contiguous(), w2[:, packing.kperm32(H)].contiguous()
+    else:
+        w1p, w2p = w1, w2
+    tok = ops.mlp_block(x.to(d), w1p.to(d), b1.to(d), w2p.to(d), b2.to(d))
+    fm = ops.mlp_block(x.to(d), w1p.to(d), b1.to(d), w2p.to(d), b2.to(d), fold=(B, Hm, Wm, C, cs, ws, pp))
+    want = ops.unpatchify(tok, B, Hm, Wm, C, cs, ws, pp)
+    assert torch.equal(fm, want)
