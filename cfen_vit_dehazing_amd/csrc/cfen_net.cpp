@@ -162,7 +162,7 @@ int cfen_net::build() {
 
   size_t max_md = 0, max_mh = 0, max_small = 0;
   for (Vit& v : vits) {
-    v.fused_mlp = cfen_mlp_supported(v.D, v.hidden, cfg.dtype);
+    v.fused_mlp = !v.global && cfen_mlp_supported(v.D, v.hidden, cfg.dtype);
     CFEN_CHECK_ARG(v.mapH % v.ws == 0 && v.ws % v.p == 0 && v.S >= 1, "net: %s does not tile its map", v.name.c_str());
     const size_t ntok = (size_t)B * (v.mapH / v.ws) * (v.mapH / v.ws) * v.S;
     max_md = std::max(max_md, ntok * v.D);

@@ -23,7 +23,7 @@ template <typename T> struct GemmArgs {
 
 constexpr int G_BN = 96, G_BM = 128, G_ROWS = G_BN + G_BM;
 constexpr int G_BKB = 128;             // bytes of K per row per stage
-constexpr int G_ROWB = G_BKB + 16;     // padded LDS row
+constexpr int G_ROWB = G_BKB + 16;     // padded LDS row (a 32-byte pad would be conflict-free but overflows 64 KB of static LDS)
 constexpr int G_PIECES = G_BKB / 16;   // 16-byte pieces per row
 constexpr int G_LOADS = G_ROWS * G_PIECES / 256;   // 7 pieces per thread
 
@@ -127,6 +127,57 @@ __global__ __launch_bounds__(256) void k_gemm_nt(GemmArgs<T> a) {
   }
 }
 
+// Small-M variant (GViT: 128..2048 tokens per batch against weight matrices of up to 6144 x 1536): the
+// problem is weight-bandwidth bound, so the grid is cut for parallelism instead of reuse -- one workgroup
+// per 16 output features x 64 tokens, its 4 waves split K and reduce through LDS; operands go straight
+// from global memory into MFMA fragments (32 contiguous bytes per lane per step), no staging, no barrier
+// in the loop.  Same epilogue as k_gemm_nt.
+template <typename T>
+__global__ __launch_bounds__(256) void k_gemm_skinny(GemmArgs<T> a) {
+  constexpr int EPL = Mma<T>::EPL, KS = 2 * Mma<T>::KC;
+  typedef typename Mma<T>::frag frag;
+  __shared__ floatx4 red[4][4][64];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r16 = lane & 15, h = lane >> 4;
+  const int n0 = blockIdx.x * 16, m0 = blockIdx.y * 64;
+  const T* wp = a.W + (size_t)min(n0 + r16, a.N - 1) * a.ldw + h * 2 * EPL;
+  const T* xp[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) xp[j] = a.X + (size_t)min(m0 + j * 16 + r16, a.M - 1) * a.ldx + h * 2 * EPL;
+  floatx4 acc[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) acc[j] = floatx4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll 2
+  for (int k0 = wave * KS; k0 < a.K; k0 += 4 * KS) {
+    const frag a0 = load_frag<T>(wp + k0), a1 = load_frag<T>(wp + k0 + EPL);
+    frag b0[4], b1[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      b0[j] = load_frag<T>(xp[j] + k0);
+      b1[j] = load_frag<T>(xp[j] + k0 + EPL);
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      acc[j] = Mma<T>::mma(a0, b0[j], acc[j]);
+      acc[j] = Mma<T>::mma(a1, b1[j], acc[j]);
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < 4; ++j) red[wave][j][lane] = acc[j];
+  __syncthreads();
+  const int j = wave;                       // wave w finishes token tile w
+  floatx4 v = red[0][j][lane] + red[1][j][lane] + red[2][j][lane] + red[3][j][lane];
+  const int m = m0 + j * 16 + r16, n = n0 + 4 * h;
+  if (m >= a.M || n >= a.N) return;
+  if (a.bias) v += *reinterpret_cast<const floatx4*>(a.bias + n);
+  if (a.relu) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f);
+  }
+  if (a.R) v += load4<T>(a.R + (size_t)m * a.ldr + n);
+  if (a.P) v += load4<T>(a.P + (size_t)(m % a.period) * a.N + n);
+  store4<T>(a.Y + (size_t)m * a.ldy + n, v);
+}
+
 template <typename T>
 int launch_gemm(const void* X, int ldx, const void* W, int ldw, const float* bias, const void* R, int ldr,
                 const void* P, int period, void* Y, int ldy, int M, int N, int K, int relu, hipStream_t s) {
@@ -139,6 +190,11 @@ int launch_gemm(const void* X, int ldx, const void* W, int ldw, const float* bia
                  cfen_aligned16(bias), "gemm: pointers must be 16-byte aligned");
   CFEN_CHECK_ARG(!P || period > 0, "gemm: position table needs a period");
   GemmArgs<T> a{(const T*)X, (const T*)W, bias, (const T*)R, (const T*)P, (T*)Y, M, N, K, ldx, ldw, ldr, ldy, period, relu};
+  if (M <= 2048 && K % (2 * Mma<T>::KC) == 0) {
+    hipLaunchKernelGGL(k_gemm_skinny<T>, dim3((N + 15) / 16, (M + 63) / 64), dim3(256), 0, s, a);
+    CFEN_CHECK_LAUNCH("gemm");
+    return CFEN_OK;
+  }
   dim3 grid((N + G_BN - 1) / G_BN, (M + G_BM - 1) / G_BM);
   CFEN_CHECK_ARG(grid.y <= 65535, "gemm: M too large for one launch");
   hipLaunchKernelGGL(k_gemm_nt<T>, grid, dim3(256), 0, s, a);

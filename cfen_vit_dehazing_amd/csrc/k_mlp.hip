@@ -1,11 +1,11 @@
 // Fused token MLP block:   y1 = x  + W2 relu(W1 LN(x) + b1) + b2      (encoder FFN,  v3:1387-1389)
 //                           y2 = y1 + Wh2 relu(Wh1 y1 + bh1) + bh2     (mlp_head,     v3:1173)
 //                           fold(y2) -> NHWC feature map                (v3:1176,1186 + Join2x2 v3:1046-1056)
-// for LViT / GViT instances with D in {96, 192, 384}.
+// for LViT instances with D in {96, 192} (levels 1 and 2).
 //
 // Each wave owns TM*16 tokens for the whole chain; tokens never leave its registers:
 //   * the residual stream lives as fp32 MFMA accumulators acc[n-tile][m-tile] (rows = features, cols = tokens),
-//     D/16 * TM = 24 tiles for every supported D (TM = 4 / 2 / 1);
+//     D/16 * TM = 24 tiles for every supported D (TM = 4 / 2);
 //   * LayerNorm reduces over features = over a lane's registers + two xor-shuffles (lanes l^16, l^32);
 //   * an accumulator tile pair IS the B operand of the next GEMM (k-slot (h,j) of a 32-deep chunk <- rows
 //     4h+j of tile a, j<4, and of tile b, j>=4), so LN(x) feeds FFN1 and relu(FFN1) feeds FFN2 with no LDS
@@ -33,24 +33,28 @@ template <> struct Pack<float> {
   static CFEN_DEV floatx4 make(const floatx4* t) { return t[0]; }
 };
 
-template <typename T, int ND, int TM>
-__global__ __launch_bounds__(256) void k_mlp(MlpArgs a) {
+// ND = D/16 n-tiles, TM = token tiles per wave, NW = waves per workgroup, HCH = hidden units per LDS stage
+template <typename T, int ND, int TM, int NW, int HCH>
+__global__ __launch_bounds__(NW * 64) void k_mlp(MlpArgs a) {
   constexpr int KC = Mma<T>::KC, EPL = Mma<T>::EPL, SZ = (int)sizeof(T);
   constexpr int NPC = Pack<T>::NPC;
+  constexpr int NT = NW * 64;
   constexpr int D = ND * 16;
   constexpr int NCH = ND / NPC;                   // K chunks over D
-  constexpr int W1ROW = D * SZ + 16;              // LDS row of the W1 slice (KC rows)
-  constexpr int W2ROW = KC * SZ + 16;             // LDS row of the W2 slice (D rows)
-  constexpr int W1BYTES = KC * W1ROW;
-  constexpr int P1 = KC * (D * SZ / 16);          // 16-byte pieces of the W1 slice
-  constexpr int P2 = D * (KC * SZ / 16);          // ... of the W2 slice
-  constexpr int NPF = (P1 + P2) / 256;            // prefetch pieces per thread
-  static_assert((P1 + P2) % 256 == 0, "slice pieces must split evenly over 256 threads");
+  constexpr int NSUB = HCH / KC;                  // MFMA K chunks per LDS stage
+  constexpr int W1ROW = D * SZ + 16;              // LDS row of the W1 slice (HCH rows)
+  constexpr int W2ROW = HCH * SZ + 16;            // LDS row of the W2 slice (D rows)
+  constexpr int W1BYTES = HCH * W1ROW;
+  constexpr int STAGE = W1BYTES + D * W2ROW;
+  constexpr int P1 = HCH * (D * SZ / 16);         // 16-byte pieces of the W1 slice
+  constexpr int P2 = D * (HCH * SZ / 16);         // ... of the W2 slice
+  constexpr int NPF = (P1 + P2) / NT;             // prefetch pieces per thread
+  static_assert((P1 + P2) % NT == 0 && HCH % KC == 0, "slice pieces must split evenly over the workgroup");
   typedef typename Mma<T>::frag frag;
-  __shared__ __attribute__((aligned(16))) unsigned char lds[W1BYTES + D * W2ROW];
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds[];   // 2 stages
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r16 = lane & 15, h = lane >> 4;
-  const long long tok0 = ((long long)blockIdx.x * 4 + wave) * (TM * 16);
+  const long long tok0 = ((long long)blockIdx.x * NW + wave) * (TM * 16);
 
   // ---- load x^T into accumulator layout: acc[i][j][r] = x[token j*16+r16][feature i*16+4h+r] ----
   floatx4 acc[ND][TM];
@@ -110,7 +114,12 @@ __global__ __launch_bounds__(256) void k_mlp(MlpArgs a) {
 #pragma unroll
       for (int j = 0; j < TM; ++j)
 #pragma unroll
-        for (int c = 0; c < NCH; ++c) xb[c][j] = Pack<T>::make(&acc[c * NPC][j]);
+        for (int c = 0; c < NCH; ++c) {
+          floatx4 t[NPC];
+#pragma unroll
+          for (int u = 0; u < NPC; ++u) t[u] = acc[c * NPC + u][j];
+          xb[c][j] = Pack<T>::make(t);
+        }
     }
     // residual + output bias: acc <- x + b2, FFN2 accumulates on top
 #pragma unroll
@@ -120,77 +129,82 @@ __global__ __launch_bounds__(256) void k_mlp(MlpArgs a) {
       for (int j = 0; j < TM; ++j) acc[i][j] += bb;
     }
 
-    // ---- hidden-dim chunk loop ----
-    const int nhc = a.H / KC;
+    // ---- hidden-dim stage loop: double-buffered LDS, next stage's loads in flight during the MFMAs ----
+    const int nhc = a.H / HCH;
     frag pf[NPF];
     auto prefetch = [&](int hc) {
 #pragma unroll
       for (int u = 0; u < NPF; ++u) {
-        const int id = tid + u * 256;
-        if (id < P1) {   // W1 slice: rows hc*KC.., D elements each
+        const int id = tid + u * NT;
+        if (id < P1) {   // W1 slice: rows hc*HCH.., D elements each
           const int row = id / (D * SZ / 16), pc = id % (D * SZ / 16);
-          pf[u] = load_frag<T>(W1 + (size_t)(hc * KC + row) * D + pc * EPL);
-        } else {         // W2 slice: D rows, KC elements at column hc*KC
+          pf[u] = load_frag<T>(W1 + (size_t)(hc * HCH + row) * D + pc * EPL);
+        } else {         // W2 slice: D rows, HCH elements at column hc*HCH
           const int id2 = id - P1;
-          const int row = id2 / (KC * SZ / 16), pc = id2 % (KC * SZ / 16);
-          pf[u] = load_frag<T>(W2 + (size_t)row * a.H + hc * KC + pc * EPL);
+          const int row = id2 / (HCH * SZ / 16), pc = id2 % (HCH * SZ / 16);
+          pf[u] = load_frag<T>(W2 + (size_t)row * a.H + hc * HCH + pc * EPL);
         }
       }
     };
-    auto commit = [&]() {
+    auto commit = [&](unsigned char* buf) {
 #pragma unroll
       for (int u = 0; u < NPF; ++u) {
-        const int id = tid + u * 256;
+        const int id = tid + u * NT;
         if (id < P1) {
           const int row = id / (D * SZ / 16), pc = id % (D * SZ / 16);
-          *reinterpret_cast<frag*>(lds + row * W1ROW + pc * 16) = pf[u];
+          *reinterpret_cast<frag*>(buf + row * W1ROW + pc * 16) = pf[u];
         } else {
           const int id2 = id - P1;
-          const int row = id2 / (KC * SZ / 16), pc = id2 % (KC * SZ / 16);
-          *reinterpret_cast<frag*>(lds + W1BYTES + row * W2ROW + pc * 16) = pf[u];
+          const int row = id2 / (HCH * SZ / 16), pc = id2 % (HCH * SZ / 16);
+          *reinterpret_cast<frag*>(buf + W1BYTES + row * W2ROW + pc * 16) = pf[u];
         }
       }
     };
     prefetch(0);
+    __syncthreads();                 // previous MLP stage is done with both buffers
+    commit(lds);
+    __syncthreads();
 #pragma unroll 1
     for (int hc = 0; hc < nhc; ++hc) {
-      __syncthreads();               // every wave is done with the previous slice
-      commit();
-      __syncthreads();
+      const unsigned char* buf = lds + (hc & 1) * STAGE;
       if (hc + 1 < nhc) prefetch(hc + 1);
-      // FFN1 slice: hidden[KC units][tokens] = W1 slice . LN(x)^T + b1
-      floatx4 hacc[NPC][TM];
 #pragma unroll
-      for (int u = 0; u < NPC; ++u) {
-        const floatx4 bb = *reinterpret_cast<const floatx4*>(b1 + hc * KC + u * 16 + 4 * h);
+      for (int sub = 0; sub < NSUB; ++sub) {
+        // FFN1 slice: hidden[KC units][tokens] = W1 slice . LN(x)^T + b1
+        floatx4 hacc[NPC][TM];
 #pragma unroll
-        for (int j = 0; j < TM; ++j) hacc[u][j] = bb;
+        for (int u = 0; u < NPC; ++u) {
+          const floatx4 bb = *reinterpret_cast<const floatx4*>(b1 + hc * HCH + sub * KC + u * 16 + 4 * h);
 #pragma unroll
-        for (int c = 0; c < NCH; ++c) {
-          const frag af = *reinterpret_cast<const frag*>(lds + (u * 16 + r16) * W1ROW + c * 64 + h * 16);
+          for (int j = 0; j < TM; ++j) hacc[u][j] = bb;
 #pragma unroll
-          for (int j = 0; j < TM; ++j) hacc[u][j] = Mma<T>::mma(af, xb[c][j], hacc[u][j]);
+          for (int c = 0; c < NCH; ++c) {
+            const frag af = *reinterpret_cast<const frag*>(buf + (sub * KC + u * 16 + r16) * W1ROW + c * 64 + h * 16);
+#pragma unroll
+            for (int j = 0; j < TM; ++j) hacc[u][j] = Mma<T>::mma(af, xb[c][j], hacc[u][j]);
+          }
+        }
+        frag hb[TM];
+#pragma unroll
+        for (int j = 0; j < TM; ++j) {
+          floatx4 t[NPC];
+#pragma unroll
+          for (int u = 0; u < NPC; ++u)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) t[u][r] = fmaxf(hacc[u][j][r], 0.f);
+          hb[j] = Pack<T>::make(t);
+        }
+        // FFN2 slice: y += W2[:, slice] . relu(hidden)
+#pragma unroll
+        for (int i = 0; i < ND; ++i) {
+          const frag af = *reinterpret_cast<const frag*>(buf + W1BYTES + (i * 16 + r16) * W2ROW + sub * 64 + h * 16);
+#pragma unroll
+          for (int j = 0; j < TM; ++j) acc[i][j] = Mma<T>::mma(af, hb[j], acc[i][j]);
         }
       }
-      frag hb[TM];
-#pragma unroll
-      for (int j = 0; j < TM; ++j) {
-        floatx4 t[NPC];
-#pragma unroll
-        for (int u = 0; u < NPC; ++u)
-#pragma unroll
-          for (int r = 0; r < 4; ++r) t[u][r] = fmaxf(hacc[u][j][r], 0.f);
-        hb[j] = Pack<T>::make(t);
-      }
-      // FFN2 slice: y += W2[:, slice] . relu(hidden)
-#pragma unroll
-      for (int i = 0; i < ND; ++i) {
-        const frag af = *reinterpret_cast<const frag*>(lds + W1BYTES + (i * 16 + r16) * W2ROW + h * 16);
-#pragma unroll
-        for (int j = 0; j < TM; ++j) acc[i][j] = Mma<T>::mma(af, hb[j], acc[i][j]);
-      }
+      if (hc + 1 < nhc) commit(lds + ((hc + 1) & 1) * STAGE);
+      __syncthreads();
     }
-    __syncthreads();
   }
 
   // ---- epilogue: token-major store, or fold + window join into the NHWC map ----
@@ -223,12 +237,23 @@ __global__ __launch_bounds__(256) void k_mlp(MlpArgs a) {
   }
 }
 
-template <typename T, int ND, int TM>
+template <typename T, int ND, int TM, int NW, int HCH>
 int launch_mlp_t(const MlpArgs& a, hipStream_t s) {
-  const long long per = 4 * TM * 16;
+  constexpr int SZ = (int)sizeof(T), D = ND * 16;
+  constexpr size_t smem = 2 * (size_t)(HCH * (D * SZ + 16) + D * (HCH * SZ + 16));
+  CFEN_CHECK_ARG(a.H % HCH == 0, "mlp: hidden dim %d must be a multiple of %d", a.H, HCH);
+  const long long per = (long long)NW * TM * 16;
   const long long blocks = (a.M + per - 1) / per;
   CFEN_CHECK_ARG(blocks > 0 && blocks < (1ll << 31), "mlp: bad grid");
-  hipLaunchKernelGGL((k_mlp<T, ND, TM>), dim3((unsigned)blocks), dim3(256), 0, s, a);
+  static bool attr_set = false;
+  if (!attr_set) {
+    if (hipFuncSetAttribute((const void*)k_mlp<T, ND, TM, NW, HCH>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) != hipSuccess) {
+      cfen_set_error("mlp: cannot reserve %zu bytes of LDS", smem);
+      return CFEN_ERR_HIP;
+    }
+    attr_set = true;
+  }
+  hipLaunchKernelGGL((k_mlp<T, ND, TM, NW, HCH>), dim3((unsigned)blocks), dim3(NW * 64), smem, s, a);
   CFEN_CHECK_LAUNCH("mlp");
   return CFEN_OK;
 }
@@ -236,7 +261,7 @@ int launch_mlp_t(const MlpArgs& a, hipStream_t s) {
 template <typename T>
 int launch_mlp(const MlpArgs& a, hipStream_t s) {
   constexpr int KC = Mma<T>::KC;
-  CFEN_CHECK_ARG(a.M > 0 && a.H > 0 && a.H % KC == 0, "mlp: hidden dim %d must be a positive multiple of %d", a.H, KC);
+  CFEN_CHECK_ARG(a.M > 0 && a.H > 0 && a.H % (2 * KC) == 0, "mlp: hidden dim %d must be a positive multiple of %d", a.H, 2 * KC);
   CFEN_CHECK_ARG(a.X && a.W1a && a.W2a && a.b1a && a.b2a, "mlp: null pointer");
   CFEN_CHECK_ARG((a.W1b == nullptr) == (a.W2b == nullptr) && (!a.W1b || (a.b1b && a.b2b)), "mlp: incomplete second stage");
   CFEN_CHECK_ARG((a.ln_g == nullptr) == (a.ln_b == nullptr), "mlp: LayerNorm needs gamma and beta");
@@ -250,18 +275,19 @@ int launch_mlp(const MlpArgs& a, hipStream_t s) {
                  cfen_aligned16(a.W1b) && cfen_aligned16(a.W2b) && cfen_aligned16(a.b1a) && cfen_aligned16(a.b2a) && cfen_aligned16(a.b1b) &&
                  cfen_aligned16(a.b2b) && cfen_aligned16(a.ln_g) && cfen_aligned16(a.ln_b), "mlp: pointers must be 16-byte aligned");
   switch (a.D) {
-    case 96: return launch_mlp_t<T, 6, 4>(a, s);
-    case 192: return launch_mlp_t<T, 12, 2>(a, s);
-    case 384: return launch_mlp_t<T, 24, 1>(a, s);
+    case 96: return launch_mlp_t<T, 6, 4, 4, 2 * KC>(a, s);      // 256 tokens / WG, 24 KB stages
+    case 192: return launch_mlp_t<T, 12, 2, 4, KC>(a, s);        // 128 tokens / WG, 24 KB stages
     default:
-      cfen_set_error("mlp: fused kernel supports D in {96,192,384}, got %d", a.D);
+      cfen_set_error("mlp: fused kernel supports D in {96,192}, got %d", a.D);
       return CFEN_ERR_ARG;
   }
 }
 
 }  // namespace
 
-bool cfen_mlp_supported(int D, int H, int dtype) { return (D == 96 || D == 192 || D == 384) && H % (dtype == 1 ? 32 : 16) == 0; }
+// D = 384 (LViT level 3, 8192 tokens per batch of 8) does not fill the chip with 128-token workgroups and its
+// 4.7 MB of weights per instance exceed what one CU can stream per token tile: the tiled GEMM path is faster there.
+bool cfen_mlp_supported(int D, int H, int dtype) { return (D == 96 || D == 192) && H % (dtype == 1 ? 64 : 32) == 0; }
 
 int cfen_mlp_impl(int dtype, const MlpArgs* a, hipStream_t s) {
   if (dtype == 1) return launch_mlp<half_t>(*a, s);

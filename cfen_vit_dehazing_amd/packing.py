@@ -42,11 +42,12 @@ def kperm32(n):
     return (torch.arange(0, n, 32).view(-1, 1) + old.view(1, -1)).reshape(-1)
 
 
-FUSED_MLP_DIMS = (96, 192, 384)
+FUSED_MLP_DIMS = (96, 192)
 
 
 def mlp_is_fused(g, dtype):
-    return g.dim in FUSED_MLP_DIMS and g.hidden % (32 if dtype == torch.float16 else 16) == 0
+    # LViT only: GViT has too few tokens per image to fill the chip with 128-token workgroups
+    return g.kind == "lvit" and g.dim in FUSED_MLP_DIMS and g.hidden % (64 if dtype == torch.float16 else 32) == 0
 
 
 def pack_vit(sd, g, dtype):

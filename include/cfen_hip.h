@@ -83,7 +83,7 @@ int cfen_gemm_nt(int dtype, const void* X, int ldx, const void* W, int ldw, cons
 int cfen_layernorm(int dtype, const void* X, void* Y, const float* gamma, const float* beta, int M, int D, float eps, void* stream);
 /* softmax(QK^T/sqrt(dh))V per (sequence, head); QKV is [nseq*S][3*heads*dh], out [nseq*S][heads*dh]  (v3:1364) */
 int cfen_attention(int dtype, const void* qkv, void* out, int nseq, int S, int heads, int dh, void* stream);
-/* Fused token MLP block (D in {96,192,384}):
+/* Fused token MLP block (D in {96,192}; H a multiple of 64 (fp16) / 32 (fp32)):
  *   y1 = x + W2a relu(W1a LN(x) + b1a) + b2a  (LN skipped when ln_gamma is NULL);  y2 = y1 + W2b relu(W1b y1 + b1b) + b2b
  *   (second stage skipped when W1b is NULL).  Output: token-major `y` and/or folded into the NHWC map `fmap`
  *   (F.fold + Join2x2: map H x W, channels C with stride cs, window ws, patch p).  Weights [H][D] / [D][H] with

@@ -252,7 +252,7 @@ def test_cfsm2g_against_reference_vectors(dtype, golden_dir):
 
 # ---------------------------------------------------------------------------------------------------
 @pytest.mark.parametrize("dtype", DTYPES)
-@pytest.mark.parametrize("D,H,M", [(96, 384, 300), (96, 192, 64), (192, 768, 200), (384, 1536, 130), (384, 768, 64)])
+@pytest.mark.parametrize("D,H,M", [(96, 384, 300), (96, 192, 64), (192, 768, 200), (192, 384, 130), (96, 128, 1000)])
 def test_fused_mlp_block(dtype, D, H, M):
     x = rnd((M, D), 1, dtype)
     g, b = 1 + 0.1 * rnd((D,), 2, torch.float32), 0.1 * rnd((D,), 3, torch.float32)
