@@ -49,9 +49,39 @@ struct cfen_net {
   std::map<std::string, ConvLayer> convs;
   std::vector<Vit> vits;
   size_t ws_bytes = 0;
-  size_t o_x0 = 0, o_x1 = 0, o_yn = 0, o_qkv = 0, o_att = 0, o_hid = 0, o_small = 0, o_stats = 0;
+  // Token scratch, one set per concurrently running transformer block (LViT / GViT of branch A / B)
+  struct Scratch { size_t x0, x1, yn, qkv, att, hid, small; };
+  Scratch scr_set[4];
+  size_t o_stats_set[2] = {0, 0};
+  int scr = 0, st = 0;             // scratch / stats set of the lane being enqueued
   unsigned char* base = nullptr;   // workspace of the current / last forward
-  hipStream_t stream = nullptr;
+  hipStream_t stream = nullptr;    // stream of the lane being enqueued
+  // fork/join over internal side streams (captured into the caller's hipGraph like any other work):
+  //   GViT runs beside LViT of the same level, the S decoder beside the R decoder.
+  bool parallel = true;
+  hipStream_t side[3] = {nullptr, nullptr, nullptr};
+  std::vector<hipEvent_t> evs;
+  size_t ev_next = 0;
+  struct Lane { hipStream_t s; int scr, st; };
+  void use(const Lane& l) { stream = l.s; scr = l.scr; st = l.st; }
+  int order(hipStream_t before, hipStream_t after) {   // work enqueued on `after` from now on waits for `before`'s work so far
+    if (before == after) return CFEN_OK;
+    if (ev_next == evs.size()) {
+      hipEvent_t e;
+      if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) { cfen_set_error("net: cannot create event"); return CFEN_ERR_HIP; }
+      evs.push_back(e);
+    }
+    hipEvent_t e = evs[ev_next++];
+    if (hipEventRecord(e, before) != hipSuccess || hipStreamWaitEvent(after, e, 0) != hipSuccess) {
+      cfen_set_error("net: stream fork/join failed");
+      return CFEN_ERR_HIP;
+    }
+    return CFEN_OK;
+  }
+  ~cfen_net() {
+    for (hipEvent_t e : evs) (void)hipEventDestroy(e);
+    for (hipStream_t q : side) if (q) (void)hipStreamDestroy(q);
+  }
   // optional per-launch timing (cfen_net_profile): one event pair per launch, tagged with a class
   bool profiling = false;
   struct Rec { int cls; double flops; hipEvent_t a, b; };
@@ -101,7 +131,8 @@ struct cfen_net {
   int run_conv(const std::string& layer, const std::string& in0, const char* in1, const char* res0, const char* res1, int act,
                const std::string& out, float* nchw_out);
   int run_vit(const Vit& v, const std::string& in, const std::string& out);
-  int run_level(const char* tag, int l, const std::string& in, const char* extra_res, const std::string& out);
+  int run_level(const char* tag, int l, const std::string& in, const char* extra_res, const std::string& out, const Lane& lm, const Lane& ls);
+  int run_branch(int b, const Lane& lm, const Lane& ls, float* out);
   int forward(const float* x, float* xr, float* xs, float* xd);
 };
 
@@ -160,13 +191,13 @@ int cfen_net::build() {
   for (int b = 0; b < 3; ++b)
     for (int l = 3; l >= 1; --l) gv("globalvit_decoder_0" + std::to_string(l) + br[b], l);
 
-  size_t max_md = 0, max_mh = 0, max_small = 0;
+  size_t max_md_l = 0, max_mh_l = 0, max_md_g = 0, max_mh_g = 0, max_small = 0;
   for (Vit& v : vits) {
     v.fused_mlp = !v.global && cfen_mlp_supported(v.D, v.hidden, cfg.dtype);
     CFEN_CHECK_ARG(v.mapH % v.ws == 0 && v.ws % v.p == 0 && v.S >= 1, "net: %s does not tile its map", v.name.c_str());
     const size_t ntok = (size_t)B * (v.mapH / v.ws) * (v.mapH / v.ws) * v.S;
-    max_md = std::max(max_md, ntok * v.D);
-    max_mh = std::max(max_mh, ntok * v.hidden);
+    (v.global ? max_md_g : max_md_l) = std::max(v.global ? max_md_g : max_md_l, ntok * v.D);
+    (v.global ? max_mh_g : max_mh_l) = std::max(v.global ? max_mh_g : max_mh_l, ntok * v.hidden);
     if (v.global) max_small = std::max(max_small, (size_t)B * v.mapH * v.mapH * v.C);
     const std::string& n = v.name;
     need(n + ".embed.w", (size_t)v.D * v.D * esz); need(n + ".embed.b", (size_t)v.D * 4);
@@ -236,11 +267,17 @@ int cfen_net::build() {
     }
     add_map(std::string("tail_") + (char)(br[b] - 32) + ".mid", h, 2 * N);
   }
-  o_x0 = alloc(max_md * esz); o_x1 = alloc(max_md * esz); o_yn = alloc(max_md * esz); o_att = alloc(max_md * esz);
-  o_qkv = alloc(3 * max_md * esz);
-  o_hid = alloc(max_mh * esz);
-  o_small = alloc(max_small * esz);
-  o_stats = alloc(cfen_stats_workspace_bytes(B, 128));
+  for (int k = 0; k < 4; ++k) {
+    const bool g = k & 1;             // odd sets serve GViT lanes: far fewer tokens
+    const size_t md = g ? max_md_g : max_md_l, mh = g ? max_mh_g : max_mh_l;
+    Scratch& q = scr_set[k];
+    q.x0 = alloc(md * esz); q.x1 = alloc(md * esz); q.yn = alloc(md * esz); q.att = alloc(md * esz);
+    q.qkv = alloc(3 * md * esz);
+    q.hid = alloc(mh * esz);
+    q.small = alloc(g ? max_small * esz : 256);
+  }
+  for (int k = 0; k < 2; ++k) o_stats_set[k] = alloc(cfen_stats_workspace_bytes(B, 128));
+  parallel = (cfg.reserved & 1) == 0;
   return CFEN_OK;
 }
 
@@ -283,7 +320,9 @@ int cfen_net::run_vit(const Vit& v, const std::string& in, const std::string& ou
   const int nwin = (v.mapH / v.ws) * (v.mapH / v.ws);
   const int M = B * nwin * v.S;
   const std::string& n = v.name;
-  void *X0 = at(o_x0), *X1 = at(o_x1), *YN = at(o_yn), *QKV = at(o_qkv), *ATT = at(o_att), *HID = at(o_hid);
+  const Scratch& q = scr_set[scr];
+  CFEN_CHECK_ARG(v.global == (bool)(scr & 1), "net: %s enqueued on the wrong scratch set", n.c_str());
+  void *X0 = at(q.x0), *X1 = at(q.x1), *YN = at(q.yn), *QKV = at(q.qkv), *ATT = at(q.att), *HID = at(q.hid);
   const double Md = (double)M, D = v.D, Hd = v.hidden;
   TRYP(K_TOKEN, 0, cfen_patchify_impl(dt, map_ptr(in), X0, B, v.mapH, v.mapH, v.C, bi.cs, v.ws, v.p, v.global ? 4 : 1, 0, stream));
   // x = linear_encoding(x) + x + pos                                        (v3:1143,1166)
@@ -296,7 +335,7 @@ int cfen_net::run_vit(const Vit& v, const std::string& in, const std::string& ou
   TRYP(K_ATTN, 4 * Md * v.S * D, cfen_attention_impl(dt, QKV, ATT, B * nwin, v.S, v.heads, v.D / v.heads, stream));
   TRYP(K_GEMM, 2 * Md * D * D,
        cfen_gemm_impl(dt, ATT, v.D, P(n + ".proj.w"), v.D, nullptr, X1, v.D, nullptr, 0, X1, v.D, M, v.D, v.D, 0, stream));
-  void* SM = v.global ? at(o_small) : nullptr;
+  void* SM = v.global ? at(q.small) : nullptr;
   if (v.fused_mlp) {
     // LN2 + FFN + residual + mlp_head + residual + fold, hidden activations never leave registers (k_mlp.hip)
     MlpArgs m{};
@@ -326,7 +365,10 @@ int cfen_net::run_vit(const Vit& v, const std::string& in, const std::string& ou
 }
 
 // LViT || GViT -> 1x1 fuse conv over their concat -> ActNorm -> ReLU -> + level input   (v3:403-488 ...)
-int cfen_net::run_level(const char* tag, int l, const std::string& in, const char* extra_res, const std::string& out) {
+// GViT (few tokens, huge weights: latency / weight-bandwidth bound) is enqueued on the lane's side stream
+// and overlaps LViT (many tokens, MFMA bound) of the same level.
+int cfen_net::run_level(const char* tag, int l, const std::string& in, const char* extra_res, const std::string& out, const Lane& lm,
+                        const Lane& ls) {
   const std::string L = std::to_string(l);
   const bool enc = tag[0] == 'e';
   const std::string ln = enc ? "localvit_encoder_0" + L : "localvit_decoder_0" + L + tag;
@@ -336,14 +378,75 @@ int cfen_net::run_level(const char* tag, int l, const std::string& in, const cha
     if (v.name == ln) lvp = &v;
     if (v.name == gn) gvp = &v;
   }
-  TRY(run_vit(*lvp, in, ln));
+  TRY(order(lm.s, ls.s));
+  use(ls);
   TRY(run_vit(*gvp, in, gn));
+  use(lm);
+  TRY(run_vit(*lvp, in, ln));
+  TRY(order(ls.s, lm.s));
   return run_conv(out, ln, gn.c_str(), in.c_str(), extra_res, 1, out, nullptr);
+}
+
+// One decoder (R, S or D): v3:546-697 / 706-853 / 862-1009.
+int cfen_net::run_branch(int b, const Lane& lm, const Lane& ls, float* outp) {
+  const int dt = cfg.dtype, B = cfg.batch;
+  static const char* br = "rsd";
+  const std::string t(1, br[b]);
+  const std::string T(1, (char)(br[b] - 32));
+  use(lm);
+  float* stats = (float*)at(o_stats_set[lm.st]);
+  TRY(run_level(t.c_str(), 3, "lgcat_conv_e03", nullptr, "lgcat_conv_d03" + t, lm, ls));
+  {  // ConvT -> InstanceNorm -> ReLU (v3:301-302)
+    const std::string u = "us_conv_d03" + t;
+    TRY(run_conv(u, "lgcat_conv_d03" + t, nullptr, nullptr, nullptr, 0, u, nullptr));
+    const Buf& bu = bufs.at(u);
+    TRYP(K_NORM, 0, cfen_instnorm_relu_impl(dt, map_ptr(u), stats, B, bu.H * bu.W, bu.C, bu.cs, 1e-5f, stream));
+  }
+  std::string in2, in1;
+  if (b == 2) {   // D's skip inputs are R's and S's upsampled maps (v3:885,920)
+    in2 = "cfsm2g_d03d";
+    const Buf& bu = bufs.at(in2);
+    TRYP(K_NORM, 0, cfen_cfsm2g_impl(dt, map_ptr("us_conv_d03d"), map_ptr("us_conv_d03r"), map_ptr("us_conv_d03s"), map_ptr(in2),
+                                     Pf("cfsm2g_d03d.w"), stats, B, bu.H * bu.W, bu.C, bu.cs, stream));
+  } else {
+    in2 = "sk_conv_d03" + t;
+    TRY(run_conv(in2, "us_conv_d03" + t, "lgcat_conv_e02", nullptr, nullptr, 1, in2, nullptr));
+  }
+  TRY(run_level(t.c_str(), 2, in2, nullptr, "lgcat_conv_d02" + t, lm, ls));
+  TRY(run_conv("us_conv_d02" + t, "lgcat_conv_d02" + t, nullptr, nullptr, nullptr, 1, "us_conv_d02" + t, nullptr));
+  if (b == 2) {
+    in1 = "cfsm2g_d02d";
+    const Buf& bu = bufs.at(in1);
+    TRYP(K_NORM, 0, cfen_cfsm2g_impl(dt, map_ptr("us_conv_d02d"), map_ptr("us_conv_d02r"), map_ptr("us_conv_d02s"), map_ptr(in1),
+                                     Pf("cfsm2g_d02d.w"), stats, B, bu.H * bu.W, bu.C, bu.cs, stream));
+  } else {
+    in1 = "sk_conv_d02" + t;
+    TRY(run_conv(in1, "us_conv_d02" + t, "lgcat_conv_e01", nullptr, nullptr, 1, in1, nullptr));
+  }
+  // `xr = us_conv_d01r(r_d_01 + xf)` (v3:696,852,1008): the extra `+ xf` rides along as a second
+  // residual of the fuse conv, so stage lgcat_conv_d01* holds (reference stage + xf).
+  TRY(run_level(t.c_str(), 1, in1, "ds_conv_e01", "lgcat_conv_d01" + t, lm, ls));
+  TRY(run_conv("us_conv_d01" + t, "lgcat_conv_d01" + t, nullptr, nullptr, nullptr, 1, "us_conv_d01" + t, nullptr));
+  TRY(run_conv("tail_" + T + ".conv3", "us_conv_d01" + t, nullptr, nullptr, nullptr, 1, "tail_" + T + ".mid", nullptr));
+  TRY(run_conv("tail_" + T + ".conv7", "tail_" + T + ".mid", nullptr, nullptr, nullptr, 2, "", outp));
+  return CFEN_OK;
 }
 
 int cfen_net::forward(const float* x, float* xr, float* xs, float* xd) {
   const int dt = cfg.dtype, B = cfg.batch, N = cfg.load_size;
-  float* stats = (float*)at(o_stats);
+  const hipStream_t s0 = stream;
+  const bool par = parallel && !profiling;
+  if (par && !side[0]) {
+    for (int k = 0; k < 3; ++k)
+      if (hipStreamCreateWithFlags(&side[k], hipStreamNonBlocking) != hipSuccess) {
+        cfen_set_error("net: cannot create side stream");
+        return CFEN_ERR_HIP;
+      }
+  }
+  ev_next = 0;
+  const Lane A{s0, 0, 0}, Ag{par ? side[0] : s0, 1, 0}, Bm{par ? side[1] : s0, 2, 1}, Bg{par ? side[2] : s0, 3, 1};
+  use(A);
+  float* stats = (float*)at(o_stats_set[0]);
   const Buf& bin = bufs.at("input");
   TRYP(K_TOKEN, 0, cfen_nchw_to_nhwc_impl(dt, x, map_ptr("input"), B, 3, 2 * N, 2 * N, bin.cs, stream));
   // head: conv5x5 + ResBlock                                                   (v3:123-127,395)
@@ -357,52 +460,19 @@ int cfen_net::forward(const float* x, float* xr, float* xs, float* xd) {
     return CFEN_OK;
   };
   TRY(down("ds_conv_e01", "head"));
-  TRY(run_level("e", 1, "ds_conv_e01", nullptr, "lgcat_conv_e01"));
+  TRY(run_level("e", 1, "ds_conv_e01", nullptr, "lgcat_conv_e01", A, Ag));
   TRY(down("ds_conv_e02", "lgcat_conv_e01"));
-  TRY(run_level("e", 2, "ds_conv_e02", nullptr, "lgcat_conv_e02"));
+  TRY(run_level("e", 2, "ds_conv_e02", nullptr, "lgcat_conv_e02", A, Ag));
   TRY(down("ds_conv_e03", "lgcat_conv_e02"));
-  TRY(run_level("e", 3, "ds_conv_e03", nullptr, "lgcat_conv_e03"));
+  TRY(run_level("e", 3, "ds_conv_e03", nullptr, "lgcat_conv_e03", A, Ag));
 
-  float* outs[3] = {xr, xs, xd};
-  static const char* br = "rsd";
-  for (int b = 0; b < 3; ++b) {   // R, S, then D: D's skip inputs are R's and S's upsampled maps (v3:885,920)
-    const std::string t(1, br[b]);
-    const std::string T(1, (char)(br[b] - 32));
-    TRY(run_level(t.c_str(), 3, "lgcat_conv_e03", nullptr, "lgcat_conv_d03" + t));
-    {  // ConvT -> InstanceNorm -> ReLU (v3:301-302)
-      const std::string u = "us_conv_d03" + t;
-      TRY(run_conv(u, "lgcat_conv_d03" + t, nullptr, nullptr, nullptr, 0, u, nullptr));
-      const Buf& bu = bufs.at(u);
-      TRYP(K_NORM, 0, cfen_instnorm_relu_impl(dt, map_ptr(u), stats, B, bu.H * bu.W, bu.C, bu.cs, 1e-5f, stream));
-    }
-    std::string in2, in1;
-    if (b == 2) {
-      in2 = "cfsm2g_d03d";
-      const Buf& bu = bufs.at(in2);
-      TRYP(K_NORM, 0, cfen_cfsm2g_impl(dt, map_ptr("us_conv_d03d"), map_ptr("us_conv_d03r"), map_ptr("us_conv_d03s"), map_ptr(in2),
-                                       Pf("cfsm2g_d03d.w"), stats, B, bu.H * bu.W, bu.C, bu.cs, stream));
-    } else {
-      in2 = "sk_conv_d03" + t;
-      TRY(run_conv(in2, "us_conv_d03" + t, "lgcat_conv_e02", nullptr, nullptr, 1, in2, nullptr));
-    }
-    TRY(run_level(t.c_str(), 2, in2, nullptr, "lgcat_conv_d02" + t));
-    TRY(run_conv("us_conv_d02" + t, "lgcat_conv_d02" + t, nullptr, nullptr, nullptr, 1, "us_conv_d02" + t, nullptr));
-    if (b == 2) {
-      in1 = "cfsm2g_d02d";
-      const Buf& bu = bufs.at(in1);
-      TRYP(K_NORM, 0, cfen_cfsm2g_impl(dt, map_ptr("us_conv_d02d"), map_ptr("us_conv_d02r"), map_ptr("us_conv_d02s"), map_ptr(in1),
-                                       Pf("cfsm2g_d02d.w"), stats, B, bu.H * bu.W, bu.C, bu.cs, stream));
-    } else {
-      in1 = "sk_conv_d02" + t;
-      TRY(run_conv(in1, "us_conv_d02" + t, "lgcat_conv_e01", nullptr, nullptr, 1, in1, nullptr));
-    }
-    // `xr = us_conv_d01r(r_d_01 + xf)` (v3:696,852,1008): the extra `+ xf` rides along as a second
-    // residual of the fuse conv, so stage lgcat_conv_d01* holds (reference stage + xf).
-    TRY(run_level(t.c_str(), 1, in1, "ds_conv_e01", "lgcat_conv_d01" + t));
-    TRY(run_conv("us_conv_d01" + t, "lgcat_conv_d01" + t, nullptr, nullptr, nullptr, 1, "us_conv_d01" + t, nullptr));
-    TRY(run_conv("tail_" + T + ".conv3", "us_conv_d01" + t, nullptr, nullptr, nullptr, 1, "tail_" + T + ".mid", nullptr));
-    TRY(run_conv("tail_" + T + ".conv7", "tail_" + T + ".mid", nullptr, nullptr, nullptr, 2, "", outs[b]));
-  }
+  // R on lanes (A, Ag), S beside it on (Bm, Bg); D needs both (CFSM2G) and follows on (A, Ag).
+  TRY(order(s0, Bm.s));
+  TRY(run_branch(0, A, Ag, xr));
+  TRY(run_branch(1, Bm, Bg, xs));
+  TRY(order(Bm.s, s0));
+  TRY(run_branch(2, A, Ag, xd));
+  use(A);
   return CFEN_OK;
 }
 
