@@ -95,14 +95,7 @@ def main():
     torch.cuda.synchronize()
     graphs = None
     if not args.no_graph:
-        graphs = []
-        side = torch.cuda.Stream()
-        with torch.cuda.stream(side):
-            for s in slabs:
-                g = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(g, stream=side):
-                    net(x, out=s)
-                graphs.append(g)
+        graphs = [net.capture(x, out=s)[0] for s in slabs]     # native hipGraph per output slab
         torch.cuda.synchronize()
 
     def step(i):
@@ -110,7 +103,7 @@ def main():
         if gather is not None:
             gather.before_write(i & 1)         # the gather of step i-2 must have consumed this slab
         if graphs is not None:
-            graphs[i & 1].replay()
+            net.replay(graphs[i & 1])
         else:
             net(x, out=s)
         if gather is not None:

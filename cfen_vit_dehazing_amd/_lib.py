@@ -47,6 +47,8 @@ SIGNATURES = {
     "cfen_net_set_param": (_I, [_P, c_char_p, _P, c_size_t]),
     "cfen_net_missing_params": (_I, [_P, c_char_p, c_size_t]),
     "cfen_net_forward": (_I, [_P, _P, _P, _P, _P, _P, c_size_t, _P]),
+    "cfen_net_graph_capture": (_I, [_P, _P, _P, _P, _P, _P, c_size_t, ctypes.POINTER(ctypes.c_int32)]),
+    "cfen_net_graph_launch": (_I, [_P, ctypes.c_int32, _P]),
     "cfen_net_profile": (_I, [_P, _P, _P, _P, _P, _P, c_size_t, _P, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_double),
                               ctypes.POINTER(ctypes.c_int32), _I]),
     "cfen_net_stage": (_I, [_P, c_char_p, ctypes.POINTER(_P)] + [ctypes.POINTER(ctypes.c_int32)] * 4),

@@ -7,6 +7,9 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libcfen_hip.so")
 SOURCES = ["k_gemm.hip", "k_attention.hip", "k_tokens.hip", "k_conv.hip", "k_mlp.hip", "k_dcn.hip", "cfen_api.cpp", "cfen_net.cpp"]
+# per-file codegen flags.  k_attention: the softmax is VALU bound -- drop fmaxf's NaN canonicalisation (no NaNs can
+# occur: masked scores are -1e30, not -inf) and let MFMA results land in VGPRs instead of AGPR + v_accvgpr_read.
+EXTRA_FLAGS = {"k_attention.hip": ["-fno-honor-nans", "-mllvm", "-amdgpu-mfma-vgpr-form=1"]}
 
 
 def _newer(a, b):
@@ -19,6 +22,7 @@ def build(force=False, verbose=False):
     os.makedirs(objdir, exist_ok=True)
     headers = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".hpp")]
     headers.append(os.path.join(os.path.dirname(HERE), "include", "cfen_hip.h"))
+    headers.append(os.path.abspath(__file__))          # flags live here
     objs = []
     procs = []
     for src in SOURCES:
@@ -29,7 +33,7 @@ def build(force=False, verbose=False):
         objs.append(obj)
         if force or _newer(path, obj) or any(_newer(h, obj) for h in headers):
             cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-x", "hip", "-c", path, "-o", obj,
-                   "-Wall", "-Wno-unused-function"]
+                   "-Wall", "-Wno-unused-function"] + EXTRA_FLAGS.get(src, [])
             if verbose:
                 print(" ".join(cmd), flush=True)
             procs.append((src, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)))

@@ -18,6 +18,15 @@ void cfen_set_error(const char* fmt, ...) {
   va_end(ap);
 }
 
+CfenGraphRecorder*& cfen_recorder() {
+  static thread_local CfenGraphRecorder* rec = nullptr;
+  return rec;
+}
+hipError_t& cfen_last_launch() {
+  static thread_local hipError_t e = hipSuccess;
+  return e;
+}
+
 extern "C" {
 
 int cfen_abi_version(void) { return 1; }

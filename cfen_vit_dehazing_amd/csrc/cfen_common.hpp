@@ -16,6 +16,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <string.h>
 
 typedef _Float16 half_t;
 typedef __attribute__((ext_vector_type(8))) _Float16 half8;
@@ -122,9 +123,57 @@ void cfen_set_error(const char* fmt, ...);
     }                                             \
   } while (0)
 
+// ---- kernel launch: eager on a stream, or recorded as a node of an explicitly built hipGraph -------------
+// The multi-stream plan (GViT beside LViT, S decoder beside R decoder) is turned into a graph by ADDING KERNEL
+// NODES WITH EXPLICIT DEPENDENCIES, not by stream capture: hipStreamEndCapture of ROCm 7.2 recurses without bound
+// on repeated fork/join between the same streams.  While a recorder is installed, "streams" are only lane ids.
+#include <map>
+#include <tuple>
+#include <utility>
+#include <vector>
+
+struct CfenGraphRecorder {
+  hipGraph_t graph = nullptr;
+  std::map<hipStream_t, std::vector<hipGraphNode_t>> tail;   // nodes the next launch on a lane must follow
+  size_t nodes = 0;
+};
+CfenGraphRecorder*& cfen_recorder();      // thread-local, null = launch eagerly
+hipError_t& cfen_last_launch();           // thread-local status of the latest CFEN_LAUNCH
+
+template <typename... KArgs, size_t... I>
+static inline hipError_t cfen_add_node(void (*kernel)(KArgs...), dim3 grid, dim3 block, size_t smem, hipStream_t lane,
+                                       std::tuple<KArgs...>& packed, std::index_sequence<I...>) {
+  CfenGraphRecorder* rec = cfen_recorder();
+  void* params[] = {(void*)&std::get<I>(packed)...};
+  hipKernelNodeParams p;
+  memset(&p, 0, sizeof(p));
+  p.func = (void*)kernel; p.gridDim = grid; p.blockDim = block; p.sharedMemBytes = (unsigned)smem; p.kernelParams = params;
+  std::vector<hipGraphNode_t>& deps = rec->tail[lane];
+  hipGraphNode_t node;
+  hipError_t e = hipGraphAddKernelNode(&node, rec->graph, deps.empty() ? nullptr : deps.data(), deps.size(), &p);
+  if (e == hipSuccess) {
+    deps.assign(1, node);
+    ++rec->nodes;
+  }
+  return e;
+}
+
+template <typename... KArgs, typename... Args>
+static inline hipError_t cfen_launch(void (*kernel)(KArgs...), dim3 grid, dim3 block, size_t smem, hipStream_t s, Args&&... args) {
+  if (!cfen_recorder()) {
+    hipLaunchKernelGGL(kernel, grid, block, smem, s, std::forward<Args>(args)...);
+    return hipGetLastError();
+  }
+  std::tuple<KArgs...> packed(std::forward<Args>(args)...);
+  return cfen_add_node(kernel, grid, block, smem, s, packed, std::index_sequence_for<KArgs...>{});
+}
+
+#define CFEN_LAUNCH(kernel, grid, block, smem, stream, ...) \
+  cfen_last_launch() = cfen_launch(kernel, grid, block, smem, stream, __VA_ARGS__)
+
 #define CFEN_CHECK_LAUNCH(what)                                                    \
   do {                                                                             \
-    hipError_t e__ = hipGetLastError();                                            \
+    hipError_t e__ = cfen_last_launch();                                           \
     if (e__ != hipSuccess) {                                                       \
       cfen_set_error("%s: launch failed: %s", what, hipGetErrorString(e__));       \
       return CFEN_ERR_HIP;                                                         \

@@ -5,6 +5,7 @@
 //
 // Workspace layout = one NHWC buffer per top-level stage output (so parity tests can read every
 // stage of SURVEY Appendix D after a forward) + token scratch shared by all 24 transformer blocks.
+#include <algorithm>
 #include <map>
 #include <string>
 #include <vector>
@@ -59,13 +60,25 @@ struct cfen_net {
   // fork/join over internal side streams (captured into the caller's hipGraph like any other work):
   //   GViT runs beside LViT of the same level, the S decoder beside the R decoder.
   bool parallel = true;
-  hipStream_t side[3] = {nullptr, nullptr, nullptr};
+  // every fork uses a stream that has not been forked before in this forward: re-forking a stream that
+  // already joined makes hipStreamEndCapture (ROCm 7.2) recurse without bound
+  static constexpr int NSIDE = 16;
+  hipStream_t side[NSIDE] = {};
+  int side_next = 0;
+  hipStream_t fresh_side() { return side[side_next++ % NSIDE]; }
   std::vector<hipEvent_t> evs;
   size_t ev_next = 0;
   struct Lane { hipStream_t s; int scr, st; };
   void use(const Lane& l) { stream = l.s; scr = l.scr; st = l.st; }
+  std::vector<hipGraphExec_t> execs;   // instantiated launch plans (cfen_net_graph_capture)
   int order(hipStream_t before, hipStream_t after) {   // work enqueued on `after` from now on waits for `before`'s work so far
     if (before == after) return CFEN_OK;
+    if (CfenGraphRecorder* rec = cfen_recorder()) {     // building a graph: lanes are dependency lists, not streams
+      std::vector<hipGraphNode_t>& a = rec->tail[after];
+      for (hipGraphNode_t n : rec->tail[before])
+        if (std::find(a.begin(), a.end(), n) == a.end()) a.push_back(n);
+      return CFEN_OK;
+    }
     if (ev_next == evs.size()) {
       hipEvent_t e;
       if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) { cfen_set_error("net: cannot create event"); return CFEN_ERR_HIP; }
@@ -79,6 +92,7 @@ struct cfen_net {
     return CFEN_OK;
   }
   ~cfen_net() {
+    for (hipGraphExec_t g : execs) if (g) (void)hipGraphExecDestroy(g);
     for (hipEvent_t e : evs) (void)hipEventDestroy(e);
     for (hipStream_t q : side) if (q) (void)hipStreamDestroy(q);
   }
@@ -378,12 +392,14 @@ int cfen_net::run_level(const char* tag, int l, const std::string& in, const cha
     if (v.name == ln) lvp = &v;
     if (v.name == gn) gvp = &v;
   }
-  TRY(order(lm.s, ls.s));
-  use(ls);
+  Lane lg = ls;
+  if (ls.s != lm.s) lg.s = fresh_side();
+  TRY(order(lm.s, lg.s));
+  use(lg);
   TRY(run_vit(*gvp, in, gn));
   use(lm);
   TRY(run_vit(*lvp, in, ln));
-  TRY(order(ls.s, lm.s));
+  TRY(order(lg.s, lm.s));
   return run_conv(out, ln, gn.c_str(), in.c_str(), extra_res, 1, out, nullptr);
 }
 
@@ -437,14 +453,16 @@ int cfen_net::forward(const float* x, float* xr, float* xs, float* xd) {
   const hipStream_t s0 = stream;
   const bool par = parallel && !profiling;
   if (par && !side[0]) {
-    for (int k = 0; k < 3; ++k)
+    for (int k = 0; k < NSIDE; ++k)
       if (hipStreamCreateWithFlags(&side[k], hipStreamNonBlocking) != hipSuccess) {
         cfen_set_error("net: cannot create side stream");
         return CFEN_ERR_HIP;
       }
   }
   ev_next = 0;
-  const Lane A{s0, 0, 0}, Ag{par ? side[0] : s0, 1, 0}, Bm{par ? side[1] : s0, 2, 1}, Bg{par ? side[2] : s0, 3, 1};
+  side_next = 0;
+  // lanes: main / its GViT companion, and the same pair for the S decoder; companion streams are drawn fresh per fork
+  const Lane A{s0, 0, 0}, Ag{par ? side[NSIDE - 1] : s0, 1, 0}, Bm{par ? fresh_side() : s0, 2, 1}, Bg{par ? side[NSIDE - 1] : s0, 3, 1};
   use(A);
   float* stats = (float*)at(o_stats_set[0]);
   const Buf& bin = bufs.at("input");
@@ -540,6 +558,52 @@ int cfen_net_forward(cfen_net* net, const float* x, float* xr, float* xs, float*
   net->base = (unsigned char*)workspace;
   net->stream = (hipStream_t)stream;
   return net->forward(x, xr, xs, xd);
+}
+
+// Build the launch plan as an explicit hipGraph (kernel nodes + dependency edges; lanes that run on side
+// streams in eager mode become parallel branches) and instantiate it.  Pointers are baked into the nodes.
+int cfen_net_graph_capture(cfen_net* net, const float* x, float* xr, float* xs, float* xd, void* workspace, size_t workspace_bytes,
+                           int32_t* graph_id) {
+  CFEN_CHECK_ARG(net && x && xr && xs && xd && workspace && graph_id, "graph_capture: null argument");
+  if (workspace_bytes < net->ws_bytes) {
+    cfen_set_error("graph_capture: workspace has %zu bytes, %zu needed", workspace_bytes, net->ws_bytes);
+    return CFEN_ERR_STATE;
+  }
+  CFEN_CHECK_ARG((reinterpret_cast<uintptr_t>(workspace) & 255) == 0, "graph_capture: workspace must be 256-byte aligned");
+  for (const auto& kv : net->params)
+    if (!kv.second.ptr) {
+      cfen_set_error("graph_capture: parameter '%s' was never set", kv.first.c_str());
+      return CFEN_ERR_STATE;
+    }
+  CfenGraphRecorder rec;
+  if (hipGraphCreate(&rec.graph, 0) != hipSuccess) {
+    cfen_set_error("graph_capture: hipGraphCreate failed");
+    return CFEN_ERR_HIP;
+  }
+  net->base = (unsigned char*)workspace;
+  net->stream = (hipStream_t)(uintptr_t)16;          // lane key of the main lane; nothing is launched on it
+  cfen_recorder() = &rec;
+  int rc = net->forward(x, xr, xs, xd);
+  cfen_recorder() = nullptr;
+  hipGraphExec_t exec = nullptr;
+  if (rc == CFEN_OK && hipGraphInstantiate(&exec, rec.graph, nullptr, nullptr, 0) != hipSuccess) {
+    cfen_set_error("graph_capture: hipGraphInstantiate failed (%zu nodes)", rec.nodes);
+    rc = CFEN_ERR_HIP;
+  }
+  (void)hipGraphDestroy(rec.graph);
+  if (rc) return rc;
+  net->execs.push_back(exec);
+  *graph_id = (int32_t)net->execs.size() - 1;
+  return CFEN_OK;
+}
+
+int cfen_net_graph_launch(cfen_net* net, int32_t graph_id, void* stream) {
+  CFEN_CHECK_ARG(net && graph_id >= 0 && (size_t)graph_id < net->execs.size(), "graph_launch: bad graph id");
+  if (hipGraphLaunch(net->execs[graph_id], (hipStream_t)stream) != hipSuccess) {
+    cfen_set_error("graph_launch: hipGraphLaunch failed");
+    return CFEN_ERR_HIP;
+  }
+  return CFEN_OK;
 }
 
 int cfen_net_profile(cfen_net* net, const float* x, float* xr, float* xs, float* xd, void* workspace, size_t workspace_bytes, void* stream,

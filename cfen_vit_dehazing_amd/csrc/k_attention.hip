@@ -147,6 +147,138 @@ __global__ __launch_bounds__(256) void k_attention(const T* __restrict__ QKV, T*
   }
 }
 
+// Window fast path (S = 64 or 256 keys: every LViT window and the larger GViT maps of the 512x512 configs).
+// One workgroup = one (sequence, head): K and V^T are staged ONCE, each wave walks its query tiles with an
+// exact two-pass softmax over all S keys held in registers (no online rescaling, branch-free unrolled loops
+// so the K-fragment LDS reads of a query tile are all in flight together).  The row sum comes out of the PV
+// MFMA itself when the head dim has a padding row (dh = 24 -> row 24 of V^T is all ones).
+template <typename T, int NDT, int NKT, bool ONES>
+__global__ __launch_bounds__(256) void k_attention_win(const T* __restrict__ QKV, T* __restrict__ O, int D, int heads, int dh,
+                                                       float scale_log2) {
+  constexpr int KC = Mma<T>::KC, EPL = Mma<T>::EPL, SZ = (int)sizeof(T);
+  constexpr int NCQ = (NDT * 16 + KC - 1) / KC;
+  constexpr int DHPK = NCQ * KC;
+  constexpr int S = NKT * 16;
+  constexpr int KROW = DHPK * SZ + 32;              // stride = 32 (mod 64) bytes: conflict-free ds_read_b128
+  constexpr int VROW = S * SZ + 16;
+  typedef typename Mma<T>::frag frag;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  unsigned char* Kl = smem;
+  unsigned char* Vl = smem + S * KROW;
+  constexpr bool ones_row = ONES;                   // a free V^T row (dh < NDT*16) carries the softmax denominator
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r16 = lane & 15, h = lane >> 4;
+  const int head = blockIdx.x % heads, seq = blockIdx.x / heads;
+  const int ld = 3 * D;
+  const T* Qp = QKV + (size_t)seq * S * ld + head * dh;
+  const T* Kp = Qp + D;
+  const T* Vp = Qp + 2 * D;
+
+  constexpr int NVK = DHPK / EPL, NVV = NDT * 16 / EPL;
+  for (int idx = tid; idx < S * NVK; idx += 256) {
+    int kr = idx / NVK, v = idx - kr * NVK, d = v * EPL;
+    frag val = (d < dh) ? load_frag<T>(Kp + (size_t)kr * ld + d) : Mma<T>::zero();
+    *reinterpret_cast<frag*>(Kl + kr * KROW + v * 16) = val;
+  }
+  for (int idx = tid; idx < S * NVV; idx += 256) {
+    int kr = idx / NVV, v = idx - kr * NVV, d = v * EPL;
+    frag val = (d < dh) ? load_frag<T>(Vp + (size_t)kr * ld + d) : Mma<T>::zero();
+    if (ones_row && d == dh / EPL * EPL) val[dh % EPL] = (T)1.0f;
+#pragma unroll
+    for (int e = 0; e < EPL; ++e) *reinterpret_cast<T*>(Vl + (d + e) * VROW + kr * SZ) = val[e];
+  }
+  __syncthreads();
+
+  const float c = scale_log2;
+#pragma unroll 1
+  for (int qt = wave; qt < NKT; qt += 4) {
+    const int q0 = qt * 16;
+    frag qf[NCQ];
+#pragma unroll
+    for (int cc = 0; cc < NCQ; ++cc) {
+      int d = cc * KC + h * EPL;
+      qf[cc] = (d < dh) ? load_frag<T>(Qp + (size_t)(q0 + r16) * ld + d) : Mma<T>::zero();
+    }
+    floatx4 st[NKT];
+#pragma unroll
+    for (int t = 0; t < NKT; ++t) {
+      floatx4 a = floatx4{0.f, 0.f, 0.f, 0.f};
+      const unsigned char* kp = Kl + (t * 16 + r16) * KROW + h * 16;
+#pragma unroll
+      for (int cc = 0; cc < NCQ; ++cc) a = Mma<T>::mma(*reinterpret_cast<const frag*>(kp + cc * 64), qf[cc], a);
+      st[t] = a;
+    }
+    float mx = -1e30f;
+#pragma unroll
+    for (int t = 0; t < NKT; ++t) mx = fmaxf(fmaxf(mx, fmaxf(st[t][0], st[t][1])), fmaxf(st[t][2], st[t][3]));
+    mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    const float mc = -mx * c;
+    float rs = 0.f;
+#pragma unroll
+    for (int t = 0; t < NKT; ++t)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        float p = __builtin_amdgcn_exp2f(fmaf(st[t][r], c, mc));
+        st[t][r] = p;
+        if (!ones_row) rs += p;
+      }
+    floatx4 o[NDT];
+#pragma unroll
+    for (int i = 0; i < NDT; ++i) o[i] = floatx4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int kb = 0; kb < NKT / 2; ++kb)
+#pragma unroll
+      for (int i = 0; i < NDT; ++i) o[i] = PV<T>::run(Vl + (i * 16 + r16) * VROW + kb * 32 * SZ, h, st[2 * kb], st[2 * kb + 1], o[i]);
+    float l;
+    if (ones_row) {   // denominator = row `dh` of O^T: tile dh/16, lane group (dh%16)/4, register dh%4
+      float cand = 0.f;
+#pragma unroll
+      for (int i = 0; i < NDT; ++i)
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          if (i * 16 + r == dh - ((dh % 16) / 4) * 4) cand = o[i][r];
+      l = __shfl(cand, r16 + 16 * ((dh % 16) / 4), 64);
+    } else {
+      rs += __shfl_xor(rs, 16, 64);
+      rs += __shfl_xor(rs, 32, 64);
+      l = rs;
+    }
+    const float inv = 1.f / l;
+    T* op = O + ((size_t)seq * S + q0 + r16) * D + head * dh;
+#pragma unroll
+    for (int i = 0; i < NDT; ++i) {
+      int d = i * 16 + 4 * h;
+      if (d < dh) store4<T>(op + d, o[i] * inv);
+    }
+  }
+}
+
+template <typename T, int NDT, int NKT>
+int launch_attn_win(const void* qkv, void* out, int nseq, int heads, int dh, size_t smem, hipStream_t s) {
+  const float scale_log2 = 1.4426950408889634f / sqrtf((float)dh);
+  if (dh < NDT * 16)
+    CFEN_LAUNCH((k_attention_win<T, NDT, NKT, true>), dim3((unsigned)(nseq * heads)), dim3(256), smem, s, (const T*)qkv, (T*)out,
+                       heads * dh, heads, dh, scale_log2);
+  else
+    CFEN_LAUNCH((k_attention_win<T, NDT, NKT, false>), dim3((unsigned)(nseq * heads)), dim3(256), smem, s, (const T*)qkv, (T*)out,
+                       heads * dh, heads, dh, scale_log2);
+  CFEN_CHECK_LAUNCH("attention");
+  return CFEN_OK;
+}
+
+template <typename T, int NDT>
+bool try_attn_win(const void* qkv, void* out, int nseq, int S, int heads, int dh, hipStream_t s, int* rc) {
+  constexpr int KC = Mma<T>::KC;
+  constexpr int NCQ = (NDT * 16 + KC - 1) / KC;
+  const int SZ = (int)sizeof(T);
+  if (S != 256 && S != 64) return false;
+  const size_t smem = (size_t)S * (NCQ * KC * SZ + 32) + (size_t)NDT * 16 * (S * SZ + 16);
+  if (smem > 64 * 1024) return false;   // larger dynamic-LDS kernel nodes crash hipGraph instantiation on ROCm 7.2
+  *rc = S == 256 ? launch_attn_win<T, NDT, 16>(qkv, out, nseq, heads, dh, smem, s) : launch_attn_win<T, NDT, 4>(qkv, out, nseq, heads, dh, smem, s);
+  return true;
+}
+
 template <typename T, int NDT>
 int launch_attn(const void* qkv, void* out, int nseq, int S, int heads, int dh, hipStream_t s) {
   constexpr int KC = Mma<T>::KC;
@@ -162,7 +294,7 @@ int launch_attn(const void* qkv, void* out, int nseq, int S, int heads, int dh, 
   const long long blocks = (long long)nseq * heads * nqg;
   CFEN_CHECK_ARG(blocks > 0 && blocks < (1ll << 31), "attention: bad grid");
   const float scale_log2 = 1.4426950408889634f / sqrtf((float)dh);
-  hipLaunchKernelGGL((k_attention<T, NDT>), dim3((unsigned)blocks), dim3(256), smem, s, (const T*)qkv, (T*)out, S,
+  CFEN_LAUNCH((k_attention<T, NDT>), dim3((unsigned)blocks), dim3(256), smem, s, (const T*)qkv, (T*)out, S,
                      heads * dh, heads, dh, skb, nqg, scale_log2);
   CFEN_CHECK_LAUNCH("attention");
   return CFEN_OK;
@@ -173,40 +305,48 @@ int dispatch_attn(const void* qkv, void* out, int nseq, int S, int heads, int dh
   CFEN_CHECK_ARG(nseq > 0 && S > 0 && heads > 0 && dh > 0, "attention: empty problem");
   CFEN_CHECK_ARG(dh % Mma<T>::EPL == 0, "attention: head_dim %d must be a multiple of %d", dh, Mma<T>::EPL);
   CFEN_CHECK_ARG(cfen_aligned16(qkv) && cfen_aligned16(out), "attention: pointers must be 16-byte aligned");
-  if (dh <= 32) return launch_attn<T, 2>(qkv, out, nseq, S, heads, dh, s);
-  if (dh <= 96) return launch_attn<T, 6>(qkv, out, nseq, S, heads, dh, s);
-  if (dh <= 128) return launch_attn<T, 8>(qkv, out, nseq, S, heads, dh, s);
+  CFEN_CHECK_ARG((long long)nseq * heads < (1ll << 31), "attention: bad grid");
+  int rc = CFEN_OK;
+  if (dh <= 32) return try_attn_win<T, 2>(qkv, out, nseq, S, heads, dh, s, &rc) ? rc : launch_attn<T, 2>(qkv, out, nseq, S, heads, dh, s);
+  if (dh <= 96) return try_attn_win<T, 6>(qkv, out, nseq, S, heads, dh, s, &rc) ? rc : launch_attn<T, 6>(qkv, out, nseq, S, heads, dh, s);
+  if (dh <= 128) return try_attn_win<T, 8>(qkv, out, nseq, S, heads, dh, s, &rc) ? rc : launch_attn<T, 8>(qkv, out, nseq, S, heads, dh, s);
   cfen_set_error("attention: head_dim %d > 128 unsupported", dh);
   return CFEN_ERR_ARG;
 }
 
 // ---------------------------------------------------------------------------------------------
-// LayerNorm over the last dim, one wave per token row, statistics in fp32 (two passes over registers).
-template <typename T, int MAXV>
+// LayerNorm over the last dim, statistics in fp32 (two passes over registers).  A row is handled by a
+// group of G = 16, 32 or 64 lanes (G >= D / (16-byte vector)), so a wave normalises 4 / 2 / 1 rows and all
+// lanes carry data even for the 192-byte rows of LViT level 1.
+template <typename T, int MAXV, int G>
 __global__ __launch_bounds__(256) void k_layernorm(const T* __restrict__ X, T* __restrict__ Y, const float* __restrict__ g,
                                                    const float* __restrict__ b, int M, int D, float eps) {
   constexpr int EPL = Vec16<T>::N;
+  constexpr int RPW = 64 / G;                        // rows per wave
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int row = blockIdx.x * 4 + wave;
-  if (row >= M) return;
+  const int sub = lane / G, gl = lane % G;
+  const long long row = ((long long)blockIdx.x * 4 + wave) * RPW + sub;
+  const bool live = row < M;
   const int nvec = D / EPL;
-  const T* x = X + (size_t)row * D;
+  const T* x = X + (live ? row : 0) * D;
   float v[MAXV][EPL];
   float sum = 0.f;
 #pragma unroll
   for (int i = 0; i < MAXV; ++i) {
-    int idx = lane + i * 64;
+    int idx = gl + i * G;
     if (idx < nvec) {
       Vec16<T>::load(x + idx * EPL, v[i]);
 #pragma unroll
       for (int e = 0; e < EPL; ++e) sum += v[i][e];
     }
   }
-  const float mean = wave_sum(sum) / (float)D;
+#pragma unroll
+  for (int o = G / 2; o > 0; o >>= 1) sum += __shfl_xor(sum, o, 64);
+  const float mean = sum / (float)D;
   float sq = 0.f;
 #pragma unroll
   for (int i = 0; i < MAXV; ++i) {
-    int idx = lane + i * 64;
+    int idx = gl + i * G;
     if (idx < nvec) {
 #pragma unroll
       for (int e = 0; e < EPL; ++e) {
@@ -215,11 +355,14 @@ __global__ __launch_bounds__(256) void k_layernorm(const T* __restrict__ X, T* _
       }
     }
   }
-  const float rstd = rsqrtf(wave_sum(sq) / (float)D + eps);
-  T* y = Y + (size_t)row * D;
+#pragma unroll
+  for (int o = G / 2; o > 0; o >>= 1) sq += __shfl_xor(sq, o, 64);
+  const float rstd = rsqrtf(sq / (float)D + eps);
+  if (!live) return;
+  T* y = Y + row * D;
 #pragma unroll
   for (int i = 0; i < MAXV; ++i) {
-    int idx = lane + i * 64;
+    int idx = gl + i * G;
     if (idx < nvec) {
       float o[EPL];
 #pragma unroll
@@ -231,11 +374,18 @@ __global__ __launch_bounds__(256) void k_layernorm(const T* __restrict__ X, T* _
 
 template <typename T, int MAXV>
 int launch_ln(const void* X, void* Y, const float* g, const float* b, int M, int D, float eps, hipStream_t s) {
+  constexpr int EPL = Vec16<T>::N;
   CFEN_CHECK_ARG(M > 0 && D > 0, "layernorm: empty problem");
-  CFEN_CHECK_ARG(D % Vec16<T>::N == 0 && D <= 64 * MAXV * Vec16<T>::N, "layernorm: D=%d unsupported (multiple of %d, <= %d)", D,
-                 Vec16<T>::N, 64 * MAXV * Vec16<T>::N);
+  CFEN_CHECK_ARG(D % EPL == 0 && D <= 64 * MAXV * EPL, "layernorm: D=%d unsupported (multiple of %d, <= %d)", D, EPL, 64 * MAXV * EPL);
   CFEN_CHECK_ARG(cfen_aligned16(X) && cfen_aligned16(Y), "layernorm: pointers must be 16-byte aligned");
-  hipLaunchKernelGGL((k_layernorm<T, MAXV>), dim3((M + 3) / 4), dim3(256), 0, s, (const T*)X, (T*)Y, g, b, M, D, eps);
+  const int nvec = D / EPL;
+  if (nvec <= 16) {
+    CFEN_LAUNCH((k_layernorm<T, 1, 16>), dim3((M + 15) / 16), dim3(256), 0, s, (const T*)X, (T*)Y, g, b, M, D, eps);
+  } else if (nvec <= 32) {
+    CFEN_LAUNCH((k_layernorm<T, 1, 32>), dim3((M + 7) / 8), dim3(256), 0, s, (const T*)X, (T*)Y, g, b, M, D, eps);
+  } else {
+    CFEN_LAUNCH((k_layernorm<T, MAXV, 64>), dim3((M + 3) / 4), dim3(256), 0, s, (const T*)X, (T*)Y, g, b, M, D, eps);
+  }
   CFEN_CHECK_LAUNCH("layernorm");
   return CFEN_OK;
 }

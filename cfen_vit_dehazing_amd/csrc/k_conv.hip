@@ -126,7 +126,7 @@ int launch_conv_t(const ConvDesc& d, hipStream_t s) {
   const long long total = (long long)d.B * d.Hb * d.Wb;
   const long long per_block = 4 * TM * 16;
   dim3 grid((unsigned)((total + per_block - 1) / per_block), d.nphase);
-  hipLaunchKernelGGL((k_conv<T, TN, TM>), grid, dim3(256), 0, s, d);
+  CFEN_LAUNCH((k_conv<T, TN, TM>), grid, dim3(256), 0, s, d);
   CFEN_CHECK_LAUNCH("conv");
   return CFEN_OK;
 }
@@ -319,7 +319,7 @@ int run_stats(const void* x0, const void* x1, const void* x2, float* part, int B
   CFEN_CHECK_ARG(C % EPL == 0 && cs % EPL == 0 && C <= cs && C <= 128, "chan_stats: C=%d cs=%d unsupported", C, cs);
   CFEN_CHECK_ARG((x1 == nullptr) == (x2 == nullptr), "chan_stats: x1 and x2 go together");
   CFEN_CHECK_ARG(cfen_aligned16(x0) && cfen_aligned16(x1) && cfen_aligned16(x2) && part, "chan_stats: bad pointers");
-  hipLaunchKernelGGL(k_chan_stats<T>, dim3(ST_CHUNKS, B), dim3(256), 0, s, (const T*)x0, (const T*)x1, (const T*)x2, part, HW, C, cs);
+  CFEN_LAUNCH(k_chan_stats<T>, dim3(ST_CHUNKS, B), dim3(256), 0, s, (const T*)x0, (const T*)x1, (const T*)x2, part, HW, C, cs);
   CFEN_CHECK_LAUNCH("chan_stats");
   return CFEN_OK;
 }
@@ -349,10 +349,10 @@ int cfen_instnorm_relu_impl(int dtype, void* x, float* part, int B, int HW, int 
   }
   if (dtype == 1) {
     long long nvec = (long long)HW * (C / 8);
-    hipLaunchKernelGGL(k_instnorm_relu<half_t>, dim3(grid_img(nvec), B), dim3(256), 0, s, (half_t*)x, part, HW, C, cs, eps, nvec);
+    CFEN_LAUNCH(k_instnorm_relu<half_t>, dim3(grid_img(nvec), B), dim3(256), 0, s, (half_t*)x, part, HW, C, cs, eps, nvec);
   } else {
     long long nvec = (long long)HW * (C / 4);
-    hipLaunchKernelGGL(k_instnorm_relu<float>, dim3(grid_img(nvec), B), dim3(256), 0, s, (float*)x, part, HW, C, cs, eps, nvec);
+    CFEN_LAUNCH(k_instnorm_relu<float>, dim3(grid_img(nvec), B), dim3(256), 0, s, (float*)x, part, HW, C, cs, eps, nvec);
   }
   CFEN_CHECK_LAUNCH("instnorm");
   return CFEN_OK;
@@ -371,11 +371,11 @@ int cfen_cfsm2g_impl(int dtype, const void* x0, const void* x1, const void* x2, 
   CFEN_CHECK_ARG(cfen_aligned16(out), "cfsm2g: output must be 16-byte aligned");
   if (dtype == 1) {
     long long nvec = (long long)HW * (C / 8);
-    hipLaunchKernelGGL(k_cfsm_apply<half_t>, dim3(grid_img(nvec), B), dim3(256), 0, s, (const half_t*)x0, (const half_t*)x1,
+    CFEN_LAUNCH(k_cfsm_apply<half_t>, dim3(grid_img(nvec), B), dim3(256), 0, s, (const half_t*)x0, (const half_t*)x1,
                        (const half_t*)x2, (half_t*)out, part, w, HW, C, cs, nvec);
   } else {
     long long nvec = (long long)HW * (C / 4);
-    hipLaunchKernelGGL(k_cfsm_apply<float>, dim3(grid_img(nvec), B), dim3(256), 0, s, (const float*)x0, (const float*)x1,
+    CFEN_LAUNCH(k_cfsm_apply<float>, dim3(grid_img(nvec), B), dim3(256), 0, s, (const float*)x0, (const float*)x1,
                        (const float*)x2, (float*)out, part, w, HW, C, cs, nvec);
   }
   CFEN_CHECK_LAUNCH("cfsm2g");

@@ -148,9 +148,9 @@ int launch_dcn(int dtype, const DcnArgs& a, hipStream_t s) {
   dim3 grid((unsigned)((HWo + D_PIX - 1) / D_PIX), a.B, a.group * ncb);
   CFEN_CHECK_ARG(grid.y <= 65535 && grid.z <= 65535, "deform_conv: batch / groups too large for one launch");
   if (dtype == 1)
-    hipLaunchKernelGGL(k_dcn<half_t>, grid, dim3(256), 0, s, a);
+    CFEN_LAUNCH(k_dcn<half_t>, grid, dim3(256), 0, s, a);
   else if (dtype == 0)
-    hipLaunchKernelGGL(k_dcn<float>, grid, dim3(256), 0, s, a);
+    CFEN_LAUNCH(k_dcn<float>, grid, dim3(256), 0, s, a);
   else {
     cfen_set_error("deform_conv: dtype %d unsupported (fp32, fp16; the reference's fp64 dispatch is not provided)", dtype);
     return CFEN_ERR_ARG;

@@ -191,13 +191,13 @@ int launch_gemm(const void* X, int ldx, const void* W, int ldw, const float* bia
   CFEN_CHECK_ARG(!P || period > 0, "gemm: position table needs a period");
   GemmArgs<T> a{(const T*)X, (const T*)W, bias, (const T*)R, (const T*)P, (T*)Y, M, N, K, ldx, ldw, ldr, ldy, period, relu};
   if (M <= 2048 && K % (2 * Mma<T>::KC) == 0) {
-    hipLaunchKernelGGL(k_gemm_skinny<T>, dim3((N + 15) / 16, (M + 63) / 64), dim3(256), 0, s, a);
+    CFEN_LAUNCH(k_gemm_skinny<T>, dim3((N + 15) / 16, (M + 63) / 64), dim3(256), 0, s, a);
     CFEN_CHECK_LAUNCH("gemm");
     return CFEN_OK;
   }
   dim3 grid((N + G_BN - 1) / G_BN, (M + G_BM - 1) / G_BM);
   CFEN_CHECK_ARG(grid.y <= 65535, "gemm: M too large for one launch");
-  hipLaunchKernelGGL(k_gemm_nt<T>, grid, dim3(256), 0, s, a);
+  CFEN_LAUNCH(k_gemm_nt<T>, grid, dim3(256), 0, s, a);
   CFEN_CHECK_LAUNCH("gemm");
   return CFEN_OK;
 }

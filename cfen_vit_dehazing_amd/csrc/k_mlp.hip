@@ -253,7 +253,7 @@ int launch_mlp_t(const MlpArgs& a, hipStream_t s) {
     }
     attr_set = true;
   }
-  hipLaunchKernelGGL((k_mlp<T, ND, TM, NW, HCH>), dim3((unsigned)blocks), dim3(NW * 64), smem, s, a);
+  CFEN_LAUNCH((k_mlp<T, ND, TM, NW, HCH>), dim3((unsigned)blocks), dim3(NW * 64), smem, s, a);
   CFEN_CHECK_LAUNCH("mlp");
   return CFEN_OK;
 }

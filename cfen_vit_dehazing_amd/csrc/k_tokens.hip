@@ -189,9 +189,9 @@ int run_patchify(const void* fmap, void* tok, TokGeom g, int inverse, hipStream_
   CFEN_CHECK_ARG(!(inverse && g.pool != 1), "unpatchify: pool must be 1");
   const long long nvec = (long long)g.B * g.H * g.W * g.C / Vec16<T>::N;
   if (inverse)
-    hipLaunchKernelGGL(k_unpatchify<T>, dim3(grid_for(nvec)), dim3(256), 0, s, (const T*)tok, (T*)fmap, g, nvec);
+    CFEN_LAUNCH(k_unpatchify<T>, dim3(grid_for(nvec)), dim3(256), 0, s, (const T*)tok, (T*)fmap, g, nvec);
   else
-    hipLaunchKernelGGL(k_patchify<T>, dim3(grid_for(nvec)), dim3(256), 0, s, (const T*)fmap, (T*)tok, g, nvec);
+    CFEN_LAUNCH(k_patchify<T>, dim3(grid_for(nvec)), dim3(256), 0, s, (const T*)fmap, (T*)tok, g, nvec);
   CFEN_CHECK_LAUNCH("patchify");
   return CFEN_OK;
 }
@@ -213,12 +213,12 @@ int cfen_upsample4_impl(int dtype, const void* small, void* out, int B, int h, i
   if (dtype == 1) {
     CFEN_CHECK_ARG(C % 8 == 0 && cs_in % 8 == 0 && cs_out % 8 == 0, "upsample4: channels must be multiples of 8");
     long long nvec = (long long)B * 16 * h * w * (C / 8);
-    hipLaunchKernelGGL(k_upsample4<half_t>, dim3(grid_for(nvec)), dim3(256), 0, s, (const half_t*)small, (half_t*)out, B, h, w, C, cs_in,
+    CFEN_LAUNCH(k_upsample4<half_t>, dim3(grid_for(nvec)), dim3(256), 0, s, (const half_t*)small, (half_t*)out, B, h, w, C, cs_in,
                        cs_out, nvec);
   } else if (dtype == 0) {
     CFEN_CHECK_ARG(C % 4 == 0 && cs_in % 4 == 0 && cs_out % 4 == 0, "upsample4: channels must be multiples of 4");
     long long nvec = (long long)B * 16 * h * w * (C / 4);
-    hipLaunchKernelGGL(k_upsample4<float>, dim3(grid_for(nvec)), dim3(256), 0, s, (const float*)small, (float*)out, B, h, w, C, cs_in,
+    CFEN_LAUNCH(k_upsample4<float>, dim3(grid_for(nvec)), dim3(256), 0, s, (const float*)small, (float*)out, B, h, w, C, cs_in,
                        cs_out, nvec);
   } else {
     cfen_set_error("upsample4: unknown dtype %d", dtype);
@@ -234,10 +234,10 @@ int cfen_nchw_to_nhwc_impl(int dtype, const float* in, void* out, int B, int C, 
   long long npix = (long long)B * H * W;
   if (dtype == 1) {
     CFEN_CHECK_ARG(cs % 8 == 0, "nchw_to_nhwc: cs must be a multiple of 8");
-    hipLaunchKernelGGL(k_nchw_to_nhwc<half_t>, dim3(grid_for(npix)), dim3(256), 0, s, in, (half_t*)out, B, C, H, W, cs, npix);
+    CFEN_LAUNCH(k_nchw_to_nhwc<half_t>, dim3(grid_for(npix)), dim3(256), 0, s, in, (half_t*)out, B, C, H, W, cs, npix);
   } else if (dtype == 0) {
     CFEN_CHECK_ARG(cs % 4 == 0, "nchw_to_nhwc: cs must be a multiple of 4");
-    hipLaunchKernelGGL(k_nchw_to_nhwc<float>, dim3(grid_for(npix)), dim3(256), 0, s, in, (float*)out, B, C, H, W, cs, npix);
+    CFEN_LAUNCH(k_nchw_to_nhwc<float>, dim3(grid_for(npix)), dim3(256), 0, s, in, (float*)out, B, C, H, W, cs, npix);
   } else {
     cfen_set_error("nchw_to_nhwc: unknown dtype %d", dtype);
     return CFEN_ERR_ARG;

@@ -9,6 +9,7 @@ The arithmetic runs entirely in libcfen_hip.so (csrc/cfen_net.cpp); this class o
 packed device copies, the workspace and one C `cfen_net` per batch size.
 """
 import ctypes
+import os
 
 import torch
 from torch import nn
@@ -106,7 +107,8 @@ class dec_ipt(nn.Module):
         packed = self._ensure_packed(device)
         c = self.cfg
         cc = NetConfigC(batch=batch, n_feats=c.n_feats, hidden_dim_ratio=c.hidden_dim_ratio, patch_size=c.patch_size,
-                        load_size=c.load_size, num_heads=c.num_heads, dtype=_lib.dtype_code(self.compute_dtype), reserved=0)
+                        load_size=c.load_size, num_heads=c.num_heads, dtype=_lib.dtype_code(self.compute_dtype),
+                        reserved=1 if os.environ.get("CFEN_SERIAL") else 0)     # bit 0: single-stream launch plan
         h = ctypes.c_void_p()
         check(lib.cfen_net_create(ctypes.byref(h), ctypes.byref(cc)), "cfen_net_create")
         for name, t in packed.items():
@@ -126,13 +128,26 @@ class dec_ipt(nn.Module):
         back to back (one slab for the data-parallel all-gather); the returned tensors are views of it."""
         return self._run(x, out, None)
 
+    def capture(self, x, out=None):
+        """Build + instantiate the launch plan as a hipGraph for these exact tensors (native kernel nodes with
+        explicit dependencies, csrc/cfen_net.cpp; not torch's stream capture).  Returns (graph id, [xr, xs, xd]);
+        `x` and the outputs must stay alive and in place while the graph is replayed."""
+        res = {}
+        outs = self._run(x, out, res, capture=True)
+        self._graph_keep = getattr(self, "_graph_keep", []) + [(x, outs)]
+        return res["gid"], outs
+
+    def replay(self, gid, batch=None):
+        h, _ = self._nets[batch if batch is not None else self._last]
+        check(_lib.load().cfen_net_graph_launch(h, gid, current_stream()), "cfen_net_graph_launch")
+
     def profile(self, x):
         """One forward with HIP events around every launch: {class: (ms, algorithmic flops, launches)}."""
         prof = {}
         self._run(x, None, prof)
         return prof
 
-    def _run(self, x, out, prof):
+    def _run(self, x, out, prof, capture=False):
         if not x.is_cuda:
             raise CfenError("the HIP generator needs a CUDA(HIP) tensor; there is no CPU fallback (got %s)" % x.device)
         n = self.cfg.image_size
@@ -140,6 +155,8 @@ class dec_ipt(nn.Module):
             raise RuntimeError("input must be (B,%d,%d,%d) for --loadSize %d --patch_size %d (image size is baked into the "
                                "network, reference v3:1186); got %s" % (self.cfg.n_colors, n, n, self.cfg.load_size,
                                                                        self.cfg.patch_size, tuple(x.shape)))
+        if capture and (not x.is_contiguous() or x.dtype != torch.float32):
+            raise ValueError("capture() needs a contiguous float32 input (its address is baked into the graph)")
         x = x.contiguous().float()
         B = x.shape[0]
         h, ws = self._net_for(B, x.device)
@@ -151,7 +168,12 @@ class dec_ipt(nn.Module):
         flat = out.view(-1)
         xr, xs, xd = flat[:3 * px].view(B, 3, n, n), flat[3 * px:4 * px].view(B, 1, n, n), flat[4 * px:].view(B, 3, n, n)
         lib = _lib.load()
-        if prof is None:
+        if capture:
+            gid = ctypes.c_int32()
+            check(lib.cfen_net_graph_capture(h, ptr(x), ptr(xr), ptr(xs), ptr(xd), ptr(ws), ws.numel(), ctypes.byref(gid)),
+                  "cfen_net_graph_capture")
+            prof["gid"] = gid.value
+        elif prof is None:
             check(lib.cfen_net_forward(h, ptr(x), ptr(xr), ptr(xs), ptr(xd), ptr(ws), ws.numel(), current_stream()), "cfen_net_forward")
         else:
             nc = len(self.KERNEL_CLASSES)

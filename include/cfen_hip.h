@@ -61,6 +61,12 @@ int cfen_net_missing_params(const cfen_net* net, char* buf, size_t buflen);
 /* x: (B,3,H,W) fp32 NCHW in [-1,1];  xr: (B,3,H,W), xs: (B,1,H,W), xd: (B,3,H,W) fp32 NCHW        */
 int cfen_net_forward(cfen_net* net, const float* x, float* xr, float* xs, float* xd, void* workspace, size_t workspace_bytes,
                      void* stream);
+/* The same launch plan as an explicit hipGraph: kernel nodes with dependency edges (the branches that eager mode
+ * runs on internal side streams -- GViT beside LViT, S decoder beside R decoder -- become parallel graph branches).
+ * All pointers are baked in; replay with cfen_net_graph_launch on any stream.  Returns an id in *graph_id.     */
+int cfen_net_graph_capture(cfen_net* net, const float* x, float* xr, float* xs, float* xd, void* workspace, size_t workspace_bytes,
+                           int32_t* graph_id);
+int cfen_net_graph_launch(cfen_net* net, int32_t graph_id, void* stream);
 /* one forward with a HIP event pair around every kernel launch on `stream` (synchronises the stream at
  * the end -- not graph-capturable).  Classes: 0 token GEMMs, 1 attention, 2 LayerNorm, 3 patchify /
  * unpatchify / upsample / layout, 4 convolutions, 5 InstanceNorm / CFSM2G, 6 fused token MLP.  Per class: summed kernel
