@@ -7,7 +7,7 @@ import ctypes
 import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "libcfen_hip.so")
+LIB_PATH = os.environ.get("CFEN_HIP_LIB") or os.path.join(HERE, "libcfen_hip.so")   # override: A/B builds of the same ABI
 
 CFEN_F32, CFEN_F16 = 0, 1
 c_void_p, c_int, c_float, c_size_t, c_char_p = ctypes.c_void_p, ctypes.c_int, ctypes.c_float, ctypes.c_size_t, ctypes.c_char_p

@@ -98,12 +98,45 @@ template <> struct Vec16<half_t> {
   }
 };
 
-CFEN_DEV float wave_sum(float v) {
-  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+// Cross-lane reductions stay in the VALU (DPP row operations + v_permlane16_swap / v_permlane32_swap) instead of
+// ds_bpermute (__shfl*): no LDS-pipe round trip, and every lane of a group ends with the bitwise identical total.
+// Sum / max over the 4 lanes {l, l^16, l^32, l^48} (the lanes that hold one MFMA column):
+CFEN_DEV float col_sum(float v) {
+  auto q = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+  const float a = __uint_as_float(q[0]) + __uint_as_float(q[1]);
+  auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(a), __float_as_uint(a), false, false);
+  return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
+CFEN_DEV float col_max(float v) {
+  auto q = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+  const float a = fmaxf(__uint_as_float(q[0]), __uint_as_float(q[1]));
+  auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(a), __float_as_uint(a), false, false);
+  return fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
+}
+
+// Reductions inside a 16-lane row with DPP (quad_perm xor1 / xor2, row_half_mirror, row_mirror): pure VALU.
+// Every lane of the row ends with the bitwise identical total.
+template <int CTRL> CFEN_DEV float dpp_mov(float v) {
+  return __uint_as_float(__builtin_amdgcn_update_dpp(0u, __float_as_uint(v), CTRL, 0xf, 0xf, false));
+}
+CFEN_DEV float row16_sum(float v) {
+  v += dpp_mov<0xB1>(v);
+  v += dpp_mov<0x4E>(v);
+  v += dpp_mov<0x141>(v);
+  v += dpp_mov<0x140>(v);
   return v;
 }
-CFEN_DEV float wave_max(float v) {
-  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+// Sum over a group of G = 16, 32 or 64 consecutive lanes (group-aligned).
+template <int G> CFEN_DEV float group_sum(float v) {
+  v = row16_sum(v);
+  if (G >= 32) {
+    auto q = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    v = __uint_as_float(q[0]) + __uint_as_float(q[1]);
+  }
+  if (G >= 64) {
+    auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    v = __uint_as_float(r[0]) + __uint_as_float(r[1]);
+  }
   return v;
 }
 

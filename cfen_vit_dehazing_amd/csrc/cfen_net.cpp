@@ -5,6 +5,7 @@
 //
 // Workspace layout = one NHWC buffer per top-level stage output (so parity tests can read every
 // stage of SURVEY Appendix D after a forward) + token scratch shared by all 24 transformer blocks.
+#include <stdlib.h>
 #include <algorithm>
 #include <map>
 #include <string>

@@ -9,6 +9,7 @@
 // Keys stream through LDS in super-blocks (K row-major, V transposed) with an online softmax, so any
 // sequence length works (S = 256 windows, S = 1024 windows of the 1024^2 config, S = 1..256 pooled
 // maps) and head_dim 24 is zero-padded to the MFMA K of 32 (fp16) / 2x16 (fp32).
+#include <stdlib.h>
 #include "cfen_common.hpp"
 
 namespace {
@@ -31,6 +32,30 @@ template <> struct PV<float> {
     floatx4 a1 = *reinterpret_cast<const floatx4*>(vt + 64 + 16 * h);
     o = Mma<float>::mma(a0, p0, o);
     return Mma<float>::mma(a1, p1, o);
+  }
+};
+
+// V^T staging: a thread takes one 16-byte vector of V for TWO consecutive keys and writes (d, key pair) entries.
+// For fp16 the two keys pack into one 32-bit LDS word: half as many ds_write instructions as a 16-bit scatter.
+template <typename T> struct VtStore;
+template <> struct VtStore<half_t> {
+  static CFEN_DEV void put(unsigned char* vl, int vrow, int d, int key, half8 a, half8 b) {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      typedef __attribute__((ext_vector_type(2))) _Float16 half2_t;
+      half2_t pr = {a[e], b[e]};
+      *reinterpret_cast<half2_t*>(vl + (d + e) * vrow + key * 2) = pr;
+    }
+  }
+};
+template <> struct VtStore<float> {
+  static CFEN_DEV void put(unsigned char* vl, int vrow, int d, int key, floatx4 a, floatx4 b) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      typedef __attribute__((ext_vector_type(2))) float float2_t;
+      float2_t pr = {a[e], b[e]};
+      *reinterpret_cast<float2_t*>(vl + (d + e) * vrow + key * 4) = pr;
+    }
   }
 };
 
@@ -83,12 +108,12 @@ __global__ __launch_bounds__(256) void k_attention(const T* __restrict__ QKV, T*
       frag val = (key < S && d < dh) ? load_frag<T>(Kp + (size_t)key * ld + d) : Mma<T>::zero();
       *reinterpret_cast<frag*>(Kl + kr * krow + v * 16) = val;
     }
-    for (int idx = tid; idx < skb * NVV; idx += 256) {
-      int kr = idx / NVV, v = idx - kr * NVV;
-      int key = ks + kr, d = v * EPL;
-      frag val = (key < S && d < dh) ? load_frag<T>(Vp + (size_t)key * ld + d) : Mma<T>::zero();
-#pragma unroll
-      for (int e = 0; e < EPL; ++e) *reinterpret_cast<T*>(Vl + (d + e) * vrow + kr * SZ) = val[e];
+    for (int idx = tid; idx < (skb / 2) * NVV; idx += 256) {
+      int kp = idx / NVV, v = idx - kp * NVV;
+      int key = ks + 2 * kp, d = v * EPL;
+      frag v0 = (key < S && d < dh) ? load_frag<T>(Vp + (size_t)key * ld + d) : Mma<T>::zero();
+      frag v1 = (key + 1 < S && d < dh) ? load_frag<T>(Vp + (size_t)(key + 1) * ld + d) : Mma<T>::zero();
+      VtStore<T>::put(Vl, vrow, d, 2 * kp, v0, v1);
     }
     __syncthreads();
     if (!active) continue;
@@ -112,8 +137,7 @@ __global__ __launch_bounds__(256) void k_attention(const T* __restrict__ QKV, T*
           st[t][r] = s;
           mx = fmaxf(mx, s);
         }
-      mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
-      mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+      mx = col_max(mx);
       const float m_new = fmaxf(m_run, mx);
       const float alpha = exp2f(m_run - m_new);
       float rs = 0.f;
@@ -125,8 +149,7 @@ __global__ __launch_bounds__(256) void k_attention(const T* __restrict__ QKV, T*
           st[t][r] = p;
           rs += p;
         }
-      rs += __shfl_xor(rs, 16, 64);
-      rs += __shfl_xor(rs, 32, 64);
+      rs = col_sum(rs);
       l_run = l_run * alpha + rs;
       m_run = m_new;
 #pragma unroll
@@ -180,12 +203,15 @@ __global__ __launch_bounds__(256) void k_attention_win(const T* __restrict__ QKV
     frag val = (d < dh) ? load_frag<T>(Kp + (size_t)kr * ld + d) : Mma<T>::zero();
     *reinterpret_cast<frag*>(Kl + kr * KROW + v * 16) = val;
   }
-  for (int idx = tid; idx < S * NVV; idx += 256) {
-    int kr = idx / NVV, v = idx - kr * NVV, d = v * EPL;
-    frag val = (d < dh) ? load_frag<T>(Vp + (size_t)kr * ld + d) : Mma<T>::zero();
-    if (ones_row && d == dh / EPL * EPL) val[dh % EPL] = (T)1.0f;
-#pragma unroll
-    for (int e = 0; e < EPL; ++e) *reinterpret_cast<T*>(Vl + (d + e) * VROW + kr * SZ) = val[e];
+  for (int idx = tid; idx < (S / 2) * NVV; idx += 256) {
+    int kp = idx / NVV, v = idx - kp * NVV, d = v * EPL;
+    frag v0 = (d < dh) ? load_frag<T>(Vp + (size_t)(2 * kp) * ld + d) : Mma<T>::zero();
+    frag v1 = (d < dh) ? load_frag<T>(Vp + (size_t)(2 * kp + 1) * ld + d) : Mma<T>::zero();
+    if (ones_row && d == dh / EPL * EPL) {
+      v0[dh % EPL] = (T)1.0f;
+      v1[dh % EPL] = (T)1.0f;
+    }
+    VtStore<T>::put(Vl, VROW, d, 2 * kp, v0, v1);
   }
   __syncthreads();
 
@@ -211,8 +237,7 @@ __global__ __launch_bounds__(256) void k_attention_win(const T* __restrict__ QKV
     float mx = -1e30f;
 #pragma unroll
     for (int t = 0; t < NKT; ++t) mx = fmaxf(fmaxf(mx, fmaxf(st[t][0], st[t][1])), fmaxf(st[t][2], st[t][3]));
-    mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
-    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    mx = col_max(mx);
     const float mc = -mx * c;
     float rs = 0.f;
 #pragma unroll
@@ -238,11 +263,9 @@ __global__ __launch_bounds__(256) void k_attention_win(const T* __restrict__ QKV
 #pragma unroll
         for (int r = 0; r < 4; ++r)
           if (i * 16 + r == dh - ((dh % 16) / 4) * 4) cand = o[i][r];
-      l = __shfl(cand, r16 + 16 * ((dh % 16) / 4), 64);
+      l = col_sum(h == (dh % 16) / 4 ? cand : 0.f);   // broadcast from the lane group that owns row `dh`
     } else {
-      rs += __shfl_xor(rs, 16, 64);
-      rs += __shfl_xor(rs, 32, 64);
-      l = rs;
+      l = col_sum(rs);
     }
     const float inv = 1.f / l;
     T* op = O + ((size_t)seq * S + q0 + r16) * D + head * dh;
@@ -340,8 +363,7 @@ __global__ __launch_bounds__(256) void k_layernorm(const T* __restrict__ X, T* _
       for (int e = 0; e < EPL; ++e) sum += v[i][e];
     }
   }
-#pragma unroll
-  for (int o = G / 2; o > 0; o >>= 1) sum += __shfl_xor(sum, o, 64);
+  sum = group_sum<G>(sum);
   const float mean = sum / (float)D;
   float sq = 0.f;
 #pragma unroll
@@ -355,8 +377,7 @@ __global__ __launch_bounds__(256) void k_layernorm(const T* __restrict__ X, T* _
       }
     }
   }
-#pragma unroll
-  for (int o = G / 2; o > 0; o >>= 1) sq += __shfl_xor(sq, o, 64);
+  sq = group_sum<G>(sq);
   const float rstd = rsqrtf(sq / (float)D + eps);
   if (!live) return;
   T* y = Y + row * D;

@@ -14,6 +14,7 @@
 //   * weights stream through LDS in hidden-dim chunks shared by the workgroup's 4 waves, with the next
 //     chunk's global loads in flight during the MFMAs (register prefetch, two barriers per chunk).
 // HBM traffic per instance: read x once, write y2 once (+ weights from L2).
+#include <stdlib.h>
 #include "cfen_common.hpp"
 #include "cfen_mlp.hpp"
 
@@ -83,8 +84,7 @@ __global__ __launch_bounds__(NW * 64) void k_mlp(MlpArgs a) {
         float s = 0.f;
 #pragma unroll
         for (int i = 0; i < ND; ++i) s += acc[i][j][0] + acc[i][j][1] + acc[i][j][2] + acc[i][j][3];
-        s += __shfl_xor(s, 16, 64);
-        s += __shfl_xor(s, 32, 64);
+        s = col_sum(s);
         const float mean = s * (1.f / D);
         float q = 0.f;
 #pragma unroll
@@ -94,8 +94,7 @@ __global__ __launch_bounds__(NW * 64) void k_mlp(MlpArgs a) {
             float d = acc[i][j][r] - mean;
             q += d * d;
           }
-        q += __shfl_xor(q, 16, 64);
-        q += __shfl_xor(q, 32, 64);
+        q = col_sum(q);
         const float rstd = rsqrtf(q * (1.f / D) + a.eps);
 #pragma unroll
         for (int c = 0; c < NCH; ++c) {
