@@ -48,6 +48,19 @@ def cpu_baseline(cfg, seconds=20.0):
             "sample": "%d batch-1 fp32 forwards of the CPU oracle at %dx%d (median)" % (len(times), cfg.image_size, cfg.image_size)}
 
 
+def pmc_traffic(kernel_class):
+    """HBM bytes per launch of a kernel class from the latest committed rocprofv3 PMC summary (tools/pmc_summary.py:
+    FETCH_SIZE and WRITE_SIZE passes of this same command, fetch doubled as the gfx950 guide prescribes); None if absent."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic.json")))
+    if not files:
+        return None
+    try:
+        return json.load(open(files[-1]))["classes"][kernel_class]["hbm_bytes_per_launch"]
+    except (KeyError, ValueError, OSError):
+        return None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -158,7 +171,7 @@ def main():
                        "global_batch": world * B, "parallelism": "dp%d" % world, "graph": graphs is not None,
                        "gflop_per_image": round(flops_img / 1e9, 2)},
             "roofline": {"bound": "mfma", "kernel": dom, "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s",
-                         "frac": round(ach / peak, 5), "traffic": None,
+                         "frac": round(ach / peak, 5), "traffic": pmc_traffic(dom),
                          "whole_forward_tflops": round(whole, 2), "whole_forward_frac": round(whole / peak, 5)},
             "kernel_classes": classes,
         }

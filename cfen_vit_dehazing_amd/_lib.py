@@ -51,6 +51,8 @@ SIGNATURES = {
     "cfen_net_graph_launch": (_I, [_P, ctypes.c_int32, _P]),
     "cfen_net_profile": (_I, [_P, _P, _P, _P, _P, _P, c_size_t, _P, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_double),
                               ctypes.POINTER(ctypes.c_int32), _I]),
+    "cfen_net_profile_entry": (_I, [_P, _I, ctypes.POINTER(c_char_p), ctypes.POINTER(ctypes.c_int32), ctypes.POINTER(ctypes.c_double),
+                                    ctypes.POINTER(ctypes.c_double)]),
     "cfen_net_stage": (_I, [_P, c_char_p, ctypes.POINTER(_P)] + [ctypes.POINTER(ctypes.c_int32)] * 4),
     "cfen_net_flops_per_image": (ctypes.c_double, [_P]),
     "cfen_gemm_nt": (_I, [_I, _P, _I, _P, _I, _P, _P, _I, _P, _I, _P, _I, _I, _I, _I, _I, _P]),

@@ -99,11 +99,12 @@ struct cfen_net {
   }
   // optional per-launch timing (cfen_net_profile): one event pair per launch, tagged with a class
   bool profiling = false;
-  struct Rec { int cls; double flops; hipEvent_t a, b; };
-  std::vector<Rec> recs;
+  struct Rec { int cls; double flops; hipEvent_t a, b; std::string label; double ms; };
+  std::vector<Rec> recs, last_profile;   // last_profile: per-launch detail of the latest cfen_net_profile
+  std::string label;                     // what the launches being enqueued belong to (layer / block step)
   int prof_begin(int cls, double flops) {
     if (!profiling) return -1;
-    Rec r; r.cls = cls; r.flops = flops;
+    Rec r; r.cls = cls; r.flops = flops; r.label = label; r.ms = 0;
     if (hipEventCreate(&r.a) != hipSuccess || hipEventCreate(&r.b) != hipSuccess) return -1;
     (void)hipEventRecord(r.a, stream);
     recs.push_back(r);
@@ -323,6 +324,7 @@ int cfen_net::run_conv(const std::string& layer, const std::string& in0, const c
   const double e = (double)c.out_edge;
   const double fl = cfg.batch * (c.kind == 1 ? 2.0 * c.Cin_real * c.Cout * 16.0 * (e / 2) * (e / 2)
                                              : 2.0 * c.Cout * (double)c.Cin_real * c.nsrc * c.k * c.k * e * e);
+  label = layer;
   TRYP(K_CONV, fl, cfen_conv_impl(cfg.dtype, &d, stream));
   return CFEN_OK;
 }
@@ -339,15 +341,22 @@ int cfen_net::run_vit(const Vit& v, const std::string& in, const std::string& ou
   CFEN_CHECK_ARG(v.global == (bool)(scr & 1), "net: %s enqueued on the wrong scratch set", n.c_str());
   void *X0 = at(q.x0), *X1 = at(q.x1), *YN = at(q.yn), *QKV = at(q.qkv), *ATT = at(q.att), *HID = at(q.hid);
   const double Md = (double)M, D = v.D, Hd = v.hidden;
+  auto step = [&](const char* what) { if (profiling) label = n + ":" + what; };
+  step("patchify");
   TRYP(K_TOKEN, 0, cfen_patchify_impl(dt, map_ptr(in), X0, B, v.mapH, v.mapH, v.C, bi.cs, v.ws, v.p, v.global ? 4 : 1, 0, stream));
   // x = linear_encoding(x) + x + pos                                        (v3:1143,1166)
+  step("embed");
   TRYP(K_GEMM, 2 * Md * D * D,
        cfen_gemm_impl(dt, X0, v.D, P(n + ".embed.w"), v.D, Pf(n + ".embed.b"), X0, v.D, P(n + ".pos"), v.S, X1, v.D, M, v.D, v.D, 0, stream));
   // src = src + out_proj(MHA(LN1(src)))                                      (v3:1383-1386)
+  step("ln1");
   TRYP(K_LNORM, 0, cfen_layernorm_impl(dt, X1, YN, Pf(n + ".ln1.g"), Pf(n + ".ln1.b"), M, v.D, 1e-5f, stream));
+  step("qkv");
   TRYP(K_GEMM, 6 * Md * D * D,
        cfen_gemm_impl(dt, YN, v.D, P(n + ".qkv.w"), v.D, nullptr, nullptr, 0, nullptr, 0, QKV, 3 * v.D, M, 3 * v.D, v.D, 0, stream));
+  step("attention");
   TRYP(K_ATTN, 4 * Md * v.S * D, cfen_attention_impl(dt, QKV, ATT, B * nwin, v.S, v.heads, v.D / v.heads, stream));
+  step("proj");
   TRYP(K_GEMM, 2 * Md * D * D,
        cfen_gemm_impl(dt, ATT, v.D, P(n + ".proj.w"), v.D, nullptr, X1, v.D, nullptr, 0, X1, v.D, M, v.D, v.D, 0, stream));
   void* SM = v.global ? at(q.small) : nullptr;
@@ -360,21 +369,29 @@ int cfen_net::run_vit(const Vit& v, const std::string& in, const std::string& ou
     m.W1b = P(n + ".head1.wk"); m.b1b = Pf(n + ".head1.b"); m.W2b = P(n + ".head2.wk"); m.b2b = Pf(n + ".head2.b");
     m.M = M; m.D = v.D; m.H = v.hidden; m.eps = 1e-5f;
     m.mapH = v.mapH; m.mapW = v.mapH; m.C = v.C; m.cs = v.global ? v.C : bo.cs; m.ws = v.ws; m.p = v.p;
+    step("mlp_fused");
     TRYP(K_MLP, 8 * Md * D * Hd, cfen_mlp_impl(dt, &m, stream));
   } else {
     // src = src + linear2(relu(linear1(LN2(src))))                             (v3:1387-1389)
+    step("ln2");
     TRYP(K_LNORM, 0, cfen_layernorm_impl(dt, X1, YN, Pf(n + ".ln2.g"), Pf(n + ".ln2.b"), M, v.D, 1e-5f, stream));
+    step("ffn1");
     TRYP(K_GEMM, 2 * Md * D * Hd,
          cfen_gemm_impl(dt, YN, v.D, P(n + ".ffn1.w"), v.D, Pf(n + ".ffn1.b"), nullptr, 0, nullptr, 0, HID, v.hidden, M, v.hidden, v.D, 1, stream));
+    step("ffn2");
     TRYP(K_GEMM, 2 * Md * D * Hd,
          cfen_gemm_impl(dt, HID, v.hidden, P(n + ".ffn2.w"), v.hidden, Pf(n + ".ffn2.b"), X1, v.D, nullptr, 0, X1, v.D, M, v.D, v.hidden, 0, stream));
     // x = mlp_head(x) + x                                                      (v3:1173)
+    step("head1");
     TRYP(K_GEMM, 2 * Md * D * Hd,
          cfen_gemm_impl(dt, X1, v.D, P(n + ".head1.w"), v.D, Pf(n + ".head1.b"), nullptr, 0, nullptr, 0, HID, v.hidden, M, v.hidden, v.D, 1, stream));
+    step("head2");
     TRYP(K_GEMM, 2 * Md * D * Hd,
          cfen_gemm_impl(dt, HID, v.hidden, P(n + ".head2.w"), v.hidden, Pf(n + ".head2.b"), X1, v.D, nullptr, 0, X0, v.D, M, v.D, v.hidden, 0, stream));
+    step("fold");
     TRYP(K_TOKEN, 0, cfen_patchify_impl(dt, v.global ? SM : map_ptr(out), X0, B, v.mapH, v.mapH, v.C, v.global ? v.C : bo.cs, v.ws, v.p, 1, 1, stream));
   }
+  step("upsample4");
   if (v.global) TRYP(K_TOKEN, 0, cfen_upsample4_impl(dt, SM, map_ptr(out), B, v.mapH, v.mapH, v.C, v.C, bo.cs, stream));
   return CFEN_OK;
 }
@@ -417,12 +434,14 @@ int cfen_net::run_branch(int b, const Lane& lm, const Lane& ls, float* outp) {
     const std::string u = "us_conv_d03" + t;
     TRY(run_conv(u, "lgcat_conv_d03" + t, nullptr, nullptr, nullptr, 0, u, nullptr));
     const Buf& bu = bufs.at(u);
+    label = u + ":instnorm";
     TRYP(K_NORM, 0, cfen_instnorm_relu_impl(dt, map_ptr(u), stats, B, bu.H * bu.W, bu.C, bu.cs, 1e-5f, stream));
   }
   std::string in2, in1;
   if (b == 2) {   // D's skip inputs are R's and S's upsampled maps (v3:885,920)
     in2 = "cfsm2g_d03d";
     const Buf& bu = bufs.at(in2);
+    label = in2;
     TRYP(K_NORM, 0, cfen_cfsm2g_impl(dt, map_ptr("us_conv_d03d"), map_ptr("us_conv_d03r"), map_ptr("us_conv_d03s"), map_ptr(in2),
                                      Pf("cfsm2g_d03d.w"), stats, B, bu.H * bu.W, bu.C, bu.cs, stream));
   } else {
@@ -434,6 +453,7 @@ int cfen_net::run_branch(int b, const Lane& lm, const Lane& ls, float* outp) {
   if (b == 2) {
     in1 = "cfsm2g_d02d";
     const Buf& bu = bufs.at(in1);
+    label = in1;
     TRYP(K_NORM, 0, cfen_cfsm2g_impl(dt, map_ptr("us_conv_d02d"), map_ptr("us_conv_d02r"), map_ptr("us_conv_d02s"), map_ptr(in1),
                                      Pf("cfsm2g_d02d.w"), stats, B, bu.H * bu.W, bu.C, bu.cs, stream));
   } else {
@@ -467,6 +487,7 @@ int cfen_net::forward(const float* x, float* xr, float* xs, float* xd) {
   use(A);
   float* stats = (float*)at(o_stats_set[0]);
   const Buf& bin = bufs.at("input");
+  label = "input:nchw_to_nhwc";
   TRYP(K_TOKEN, 0, cfen_nchw_to_nhwc_impl(dt, x, map_ptr("input"), B, 3, 2 * N, 2 * N, bin.cs, stream));
   // head: conv5x5 + ResBlock                                                   (v3:123-127,395)
   TRY(run_conv("head.0.0", "input", nullptr, nullptr, nullptr, 0, "head.conv5", nullptr));
@@ -475,6 +496,7 @@ int cfen_net::forward(const float* x, float* xr, float* xs, float* xd) {
   auto down = [&](const std::string& layer, const std::string& in) -> int {   // conv s2 -> IN -> ReLU (v3:292-298)
     TRY(run_conv(layer, in, nullptr, nullptr, nullptr, 0, layer, nullptr));
     const Buf& b = bufs.at(layer);
+    label = layer + ":instnorm";
     TRYP(K_NORM, 0, cfen_instnorm_relu_impl(dt, map_ptr(layer), stats, B, b.H * b.W, b.C, b.cs, 1e-5f, stream));
     return CFEN_OK;
   };
@@ -619,16 +641,30 @@ int cfen_net_profile(cfen_net* net, const float* x, float* xr, float* xs, float*
     cfen_set_error("net_profile: stream synchronize failed");
     rc = CFEN_ERR_HIP;
   }
+  net->last_profile.clear();
   for (auto& r : net->recs) {
     float ms = 0.f;
     if (rc == CFEN_OK && hipEventElapsedTime(&ms, r.a, r.b) == hipSuccess) {
       ms_per_class[r.cls] += ms; flops_per_class[r.cls] += r.flops; launches_per_class[r.cls] += 1;
+      r.ms = ms;
+      net->last_profile.push_back(r);
     }
     (void)hipEventDestroy(r.a);
     (void)hipEventDestroy(r.b);
   }
   net->recs.clear();
   return rc;
+}
+
+int cfen_net_profile_entry(const cfen_net* net, int index, const char** label, int32_t* kernel_class, double* flops, double* ms) {
+  CFEN_CHECK_ARG(net && index >= 0, "net_profile_entry: bad arguments");
+  if ((size_t)index >= net->last_profile.size()) return CFEN_ERR_STATE;   // past the end (not an error message: callers iterate until this)
+  const cfen_net::Rec& r = net->last_profile[(size_t)index];
+  if (label) *label = r.label.c_str();
+  if (kernel_class) *kernel_class = r.cls;
+  if (flops) *flops = r.flops;
+  if (ms) *ms = r.ms;
+  return CFEN_OK;
 }
 
 int cfen_net_stage(const cfen_net* net, const char* name, const void** ptr, int32_t* C, int32_t* cs, int32_t* H, int32_t* W) {

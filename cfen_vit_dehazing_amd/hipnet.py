@@ -9,6 +9,7 @@ The arithmetic runs entirely in libcfen_hip.so (csrc/cfen_net.cpp); this class o
 packed device copies, the workspace and one C `cfen_net` per batch size.
 """
 import ctypes
+from ctypes import c_char_p as c_char_p_
 import os
 
 import torch
@@ -182,6 +183,12 @@ class dec_ipt(nn.Module):
                   "cfen_net_profile")
             for i, name in enumerate(self.KERNEL_CLASSES):
                 prof[name] = (ms[i], fl[i], cnt[i])
+            detail, i = [], 0
+            lab, cls, f, t = c_char_p_(), ctypes.c_int32(), ctypes.c_double(), ctypes.c_double()
+            while lib.cfen_net_profile_entry(h, i, ctypes.byref(lab), ctypes.byref(cls), ctypes.byref(f), ctypes.byref(t)) == 0:
+                detail.append((lab.value.decode(), self.KERNEL_CLASSES[cls.value], f.value, t.value))
+                i += 1
+            prof["launches"] = detail
         self._last = B
         return [xr, xs, xd]
 

@@ -74,6 +74,10 @@ int cfen_net_graph_launch(cfen_net* net, int32_t graph_id, void* stream);
 #define CFEN_NUM_KERNEL_CLASSES 7
 int cfen_net_profile(cfen_net* net, const float* x, float* xr, float* xs, float* xd, void* workspace, size_t workspace_bytes,
                      void* stream, double* ms_per_class, double* flops_per_class, int32_t* launches_per_class, int nclass);
+/* per-launch detail of the latest cfen_net_profile: entry `index` (launch order) -> layer / block-step label (owned by
+ * the net, valid until the next profile), kernel class, algorithmic FLOPs, milliseconds.  Returns CFEN_ERR_STATE past
+ * the last entry.                                                                                   */
+int cfen_net_profile_entry(const cfen_net* net, int index, const char** label, int32_t* kernel_class, double* flops, double* ms);
 /* device pointer + geometry of a named top-level stage output (SURVEY Appendix D names) inside the
  * workspace of the LAST forward; NHWC, element type = net dtype.                                  */
 int cfen_net_stage(const cfen_net* net, const char* name, const void** ptr, int32_t* C, int32_t* cs, int32_t* H, int32_t* W);
