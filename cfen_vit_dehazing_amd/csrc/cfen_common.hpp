@@ -140,6 +140,12 @@ template <int G> CFEN_DEV float group_sum(float v) {
   return v;
 }
 
+// Workgroups are dealt round-robin to the 8 XCDs, each with its own L2.  Launch a 1-D grid of cfen_grid8(n) blocks and
+// map the hardware block id to a logical one so that every XCD works on ONE contiguous range of logical blocks:
+// neighbours that share cache lines (conv halo rows, the heads of one attention window) then share an L2.
+CFEN_DEV unsigned xcd_chunked_block(unsigned bid, unsigned nblocks8) { return (bid & 7u) * (nblocks8 >> 3) + (bid >> 3); }
+static inline unsigned cfen_grid8(long long n) { return (unsigned)((n + 7) / 8 * 8); }
+
 // ---- host side ------------------------------------------------------------------------------
 #define CFEN_OK 0
 #define CFEN_ERR_ARG (-1)

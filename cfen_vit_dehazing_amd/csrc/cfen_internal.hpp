@@ -14,6 +14,10 @@ int cfen_patchify_impl(int dtype, const void* fmap, void* tok, int B, int H, int
 int cfen_upsample4_impl(int dtype, const void* small, void* out, int B, int h, int w, int C, int cs_in, int cs_out, hipStream_t s);
 int cfen_nchw_to_nhwc_impl(int dtype, const float* in, void* out, int B, int C, int H, int W, int cs, hipStream_t s);
 int cfen_conv_impl(int dtype, const ConvDesc* d, hipStream_t s);
+// LDS-tiled stride-1 path (k_conv_tile.hip); weights in the "rows" layout, d->Kpad == cfen_conv_tile_kpad
+bool cfen_conv_tile_supported(int dtype, int kind, int k, int stride, int pad, int nsrc, int cs_in, int Cout_pad, int H, int W);
+int cfen_conv_tile_kpad(int dtype, int k, int cs_in);
+int cfen_conv_tile_impl(int dtype, const ConvDesc* d, int k, hipStream_t s);
 size_t cfen_stats_workspace_bytes(int B, int C);
 int cfen_instnorm_relu_impl(int dtype, void* x, float* part, int B, int HW, int C, int cs, float eps, hipStream_t s);
 int cfen_cfsm2g_impl(int dtype, const void* x0, const void* x1, const void* x2, void* out, const float* w, float* part, int B, int HW,

@@ -37,6 +37,7 @@ struct Vit {
 };
 struct ConvLayer {
   int kind, k, stride, pad, reflect, nsrc, Cin, Cin_real, Cout, Cout_pad, Kpad, nphase, ntaps, out_edge;
+  bool tile;   // LDS-tiled kernel, weights "<layer>.wr" in the rows layout
 };
 
 inline int cs_of(int C) { return cfen_round_up(C, 8); }
@@ -133,8 +134,10 @@ struct cfen_net {
     c.nphase = kind == 1 ? 4 : 1;
     c.ntaps = kind == 1 ? 4 : k * k * nsrc;
     c.Kpad = cfen_round_up(c.ntaps * Cin, KC);
+    c.tile = cfen_conv_tile_supported(cfg.dtype, kind, k, stride, pad, nsrc, Cin, c.Cout_pad, out_edge, out_edge);
+    if (c.tile) c.Kpad = cfen_conv_tile_kpad(cfg.dtype, k, Cin);
     convs[n] = c;
-    need(n + ".w", (size_t)c.nphase * c.Cout_pad * c.Kpad * esz);
+    need(n + (c.tile ? ".wr" : ".w"), (size_t)c.nphase * c.Cout_pad * c.Kpad * esz);
     need(n + ".scale", (size_t)c.Cout_pad * 4);
     need(n + ".shift", (size_t)c.Cout_pad * 4);
   }
@@ -308,7 +311,7 @@ int cfen_net::run_conv(const std::string& layer, const std::string& in0, const c
     cfen_desc_convT4(&d, cfg.batch, bi.H, bi.W, bi.cs, c.Cin);
   d.src[0] = map_ptr(in0);
   d.src[1] = in1 ? map_ptr(in1) : nullptr;
-  d.weight = P(layer + ".w"); d.Kpad = c.Kpad;
+  d.weight = P(layer + (c.tile ? ".wr" : ".w")); d.Kpad = c.Kpad;
   d.scale = Pf(layer + ".scale"); d.shift = Pf(layer + ".shift");
   d.act = act;
   d.Cout = c.Cout; d.Cout_pad = c.Cout_pad;
@@ -325,7 +328,10 @@ int cfen_net::run_conv(const std::string& layer, const std::string& in0, const c
   const double fl = cfg.batch * (c.kind == 1 ? 2.0 * c.Cin_real * c.Cout * 16.0 * (e / 2) * (e / 2)
                                              : 2.0 * c.Cout * (double)c.Cin_real * c.nsrc * c.k * c.k * e * e);
   label = layer;
-  TRYP(K_CONV, fl, cfen_conv_impl(cfg.dtype, &d, stream));
+  if (c.tile)
+    TRYP(K_CONV, fl, cfen_conv_tile_impl(cfg.dtype, &d, c.k, stream));
+  else
+    TRYP(K_CONV, fl, cfen_conv_impl(cfg.dtype, &d, stream));
   return CFEN_OK;
 }
 

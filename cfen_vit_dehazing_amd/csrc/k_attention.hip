@@ -177,7 +177,7 @@ __global__ __launch_bounds__(256) void k_attention(const T* __restrict__ QKV, T*
 // MFMA itself when the head dim has a padding row (dh = 24 -> row 24 of V^T is all ones).
 template <typename T, int NDT, int NKT, bool ONES>
 __global__ __launch_bounds__(256) void k_attention_win(const T* __restrict__ QKV, T* __restrict__ O, int D, int heads, int dh,
-                                                       float scale_log2) {
+                                                       float scale_log2, int nblk) {
   constexpr int KC = Mma<T>::KC, EPL = Mma<T>::EPL, SZ = (int)sizeof(T);
   constexpr int NCQ = (NDT * 16 + KC - 1) / KC;
   constexpr int DHPK = NCQ * KC;
@@ -191,7 +191,9 @@ __global__ __launch_bounds__(256) void k_attention_win(const T* __restrict__ QKV
   constexpr bool ones_row = ONES;                   // a free V^T row (dh < NDT*16) carries the softmax denominator
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r16 = lane & 15, h = lane >> 4;
-  const int head = blockIdx.x % heads, seq = blockIdx.x / heads;
+  const int blk = (int)xcd_chunked_block(blockIdx.x, gridDim.x);   // all heads of a window on one XCD: they share qkv lines
+  if (blk >= nblk) return;
+  const int head = blk % heads, seq = blk / heads;
   const int ld = 3 * D;
   const T* Qp = QKV + (size_t)seq * S * ld + head * dh;
   const T* Kp = Qp + D;
@@ -281,11 +283,11 @@ template <typename T, int NDT, int NKT>
 int launch_attn_win(const void* qkv, void* out, int nseq, int heads, int dh, size_t smem, hipStream_t s) {
   const float scale_log2 = 1.4426950408889634f / sqrtf((float)dh);
   if (dh < NDT * 16)
-    CFEN_LAUNCH((k_attention_win<T, NDT, NKT, true>), dim3((unsigned)(nseq * heads)), dim3(256), smem, s, (const T*)qkv, (T*)out,
-                       heads * dh, heads, dh, scale_log2);
+    CFEN_LAUNCH((k_attention_win<T, NDT, NKT, true>), dim3(cfen_grid8((long long)nseq * heads)), dim3(256), smem, s, (const T*)qkv, (T*)out,
+                       heads * dh, heads, dh, scale_log2, nseq * heads);
   else
-    CFEN_LAUNCH((k_attention_win<T, NDT, NKT, false>), dim3((unsigned)(nseq * heads)), dim3(256), smem, s, (const T*)qkv, (T*)out,
-                       heads * dh, heads, dh, scale_log2);
+    CFEN_LAUNCH((k_attention_win<T, NDT, NKT, false>), dim3(cfen_grid8((long long)nseq * heads)), dim3(256), smem, s, (const T*)qkv, (T*)out,
+                       heads * dh, heads, dh, scale_log2, nseq * heads);
   CFEN_CHECK_LAUNCH("attention");
   return CFEN_OK;
 }

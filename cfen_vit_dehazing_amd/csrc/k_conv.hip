@@ -30,7 +30,7 @@ __global__ __launch_bounds__(256) void k_conv(ConvDesc d) {
   }
   __syncthreads();
   const long long total = (long long)d.B * d.Hb * d.Wb;
-  const long long q_wave = ((long long)blockIdx.x * 4 + wave) * (TM * 16);
+  const long long q_wave = ((long long)xcd_chunked_block(blockIdx.x, gridDim.x) * 4 + wave) * (TM * 16);
   if (q_wave >= total) return;
 
   int pb[TM], py[TM], px[TM];
@@ -125,7 +125,7 @@ template <typename T, int TN, int TM>
 int launch_conv_t(const ConvDesc& d, hipStream_t s) {
   const long long total = (long long)d.B * d.Hb * d.Wb;
   const long long per_block = 4 * TM * 16;
-  dim3 grid((unsigned)((total + per_block - 1) / per_block), d.nphase);
+  dim3 grid(cfen_grid8((total + per_block - 1) / per_block), d.nphase);   // padded blocks exit on q_wave >= total
   CFEN_LAUNCH((k_conv<T, TN, TM>), grid, dim3(256), 0, s, d);
   CFEN_CHECK_LAUNCH("conv");
   return CFEN_OK;

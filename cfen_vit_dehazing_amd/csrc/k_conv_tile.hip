@@ -1,0 +1,177 @@
+// LDS-tiled stride-1 convolution for the full-resolution CNN layers (12 channels at 2N x 2N: head 5x5 + ResBlock 3x3,
+// v3:123-127 / common.py:41-62; tail 3x3 + 7x7 behind ReflectionPad2d(3), v3:351-355).  These layers are HBM bound
+// (2 * map bytes), but the gather kernel (k_conv.hip) spends its time on per-tap address arithmetic and L1/L2 re-reads.
+//
+// One workgroup = 64 x R output pixels; its (R+KS-1) x (64+KS-1) input halo is staged ONCE in LDS (zero or reflect
+// padding resolved while staging).  A wave owns a 16-pixel-wide column strip of R rows:
+//   * NHWC pixels are PIXB = 16/32/64 bytes, so the 64 bytes an MFMA chunk consumes per column are TPC = 64/PIXB
+//     horizontally adjacent taps: the B fragment is one ds_read_b128 at  row*RB + (x + c*TPC)*PIXB + 16*h  -- no per-tap
+//     address math, no select;
+//   * the same input-row fragment serves every (output row r, dy = iy - r) pair, so it is read once and fed to up to KS
+//     MFMAs whose weights (all KS*NCR fragments of the layer) sit in registers.
+// Weight layout "rows": [Cout_pad=16][KS][NCR*TPC taps][CSI], i.e. the tap-major layout of a KS x (NCR*TPC) kernel whose
+// extra columns are zero (packing.pack_conv_weight_rows).
+#include "cfen_common.hpp"
+#include "cfen_conv.hpp"
+
+namespace {
+
+template <typename T, int PIXB, int KS, int R>
+__global__ __launch_bounds__(256) void k_conv_tile(ConvDesc d, int nblk) {
+  constexpr int SZ = (int)sizeof(T), EPL = Mma<T>::EPL, KC = Mma<T>::KC;
+  constexpr int CSI = PIXB / SZ;              // channel stride of the input map
+  constexpr int TPC = 64 / PIXB;              // taps per 64-byte chunk
+  constexpr int NCR = (KS + TPC - 1) / TPC;   // chunks per kernel row
+  constexpr int PAD = KS / 2;
+  constexpr int ROWS = R + KS - 1;
+  constexpr int WT = 64 + NCR * TPC;          // staged columns: 64 + KS - 1 real, the rest zero (they meet zero weights)
+  constexpr int RB = WT * PIXB;
+  constexpr int PPP = PIXB / 16;              // 16-byte pieces per pixel
+  constexpr int NPIECE = ROWS * WT * PPP;
+  constexpr int NIT = (NPIECE + 255) / 256;
+  constexpr int KPAD = KS * NCR * KC;
+  typedef typename Mma<T>::frag frag;
+  static_assert(KC * SZ == 64, "one MFMA chunk is 64 bytes of K per column");
+  __shared__ __attribute__((aligned(16))) unsigned char lds[ROWS * RB];
+
+  const int blk = (int)xcd_chunked_block(blockIdx.x, gridDim.x);
+  if (blk >= nblk) return;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r16 = lane & 15, h = lane >> 4;
+  const int tiles_x = d.Win / 64, tiles_y = d.Hin / R;
+  const int tx = blk % tiles_x, ty = (blk / tiles_x) % tiles_y, b = blk / (tiles_x * tiles_y);
+  const int x0 = tx * 64, y0 = ty * R;
+  const unsigned char* src = (const unsigned char*)d.src[0] + (size_t)b * d.Hin * d.Win * PIXB;
+
+  // ---- stage the halo tile (all loads in flight before the first LDS store) ----
+  frag stg[NIT];
+#pragma unroll
+  for (int i = 0; i < NIT; ++i) {
+    const int idx = tid + i * 256;
+    const int piece = idx % PPP, col = (idx / PPP) % WT, row = idx / (PPP * WT);
+    int gy = y0 - PAD + row, gx = x0 - PAD + col;
+    bool ok = idx < NPIECE && col < 64 + KS - 1;
+    if (d.pad_reflect) {
+      gy = gy < 0 ? -gy : (gy >= d.Hin ? 2 * d.Hin - 2 - gy : gy);
+      gx = gx < 0 ? -gx : (gx >= d.Win ? 2 * d.Win - 2 - gx : gx);
+    } else {
+      ok = ok && gy >= 0 && gy < d.Hin && gx >= 0 && gx < d.Win;
+    }
+    stg[i] = ok ? *reinterpret_cast<const frag*>(src + ((size_t)gy * d.Win + gx) * PIXB + piece * 16) : Mma<T>::zero();
+  }
+  // ---- the layer's weights: lane (r16 = output feature, h) keeps its 16 bytes of every chunk ----
+  frag wf[KS][NCR];
+  {
+    const T* wp = (const T*)d.weight + (size_t)r16 * KPAD + h * EPL;
+#pragma unroll
+    for (int dy = 0; dy < KS; ++dy)
+#pragma unroll
+      for (int c = 0; c < NCR; ++c) wf[dy][c] = load_frag<T>(wp + (dy * NCR + c) * KC);
+  }
+#pragma unroll
+  for (int i = 0; i < NIT; ++i) {
+    const int idx = tid + i * 256;
+    if (idx < NPIECE) *reinterpret_cast<frag*>(&lds[idx * 16]) = stg[i];   // piece order == LDS order
+  }
+  __syncthreads();
+
+  floatx4 acc[R];
+#pragma unroll
+  for (int r = 0; r < R; ++r) acc[r] = floatx4{0.f, 0.f, 0.f, 0.f};
+  const unsigned char* lp = lds + (wave * 16 + r16) * PIXB + h * 16;
+#pragma unroll
+  for (int iy = 0; iy < ROWS; ++iy) {
+#pragma unroll
+    for (int c = 0; c < NCR; ++c) {
+      const frag bf = *reinterpret_cast<const frag*>(lp + iy * RB + c * TPC * PIXB);
+#pragma unroll
+      for (int r = 0; r < R; ++r) {
+        const int dy = iy - r;
+        if (dy >= 0 && dy < KS) acc[r] = Mma<T>::mma(wf[dy][c], bf, acc[r]);
+      }
+    }
+  }
+
+  // ---- epilogue: lane owns output features 4h..4h+3 of pixel (y0 + r, x0 + 16*wave + r16) ----
+  const int n = 4 * h, ox = x0 + wave * 16 + r16;
+  const floatx4 sc = *reinterpret_cast<const floatx4*>(d.scale + n), sh = *reinterpret_cast<const floatx4*>(d.shift + n);
+#pragma unroll
+  for (int r = 0; r < R; ++r) {
+    const int oy = y0 + r;
+    floatx4 v = acc[r] * sc + sh;
+    if (d.act == 1) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
+    } else if (d.act == 2) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) v[e] = tanhf(v[e]);
+    }
+    if (d.out_nchw_f32) {
+      float* o = (float*)d.out;
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+        if (n + e < d.Cout) o[(((size_t)b * d.Cout + n + e) * d.Hin + oy) * d.Win + ox] = v[e];
+    } else if (n < d.cs_out) {
+      const size_t opix = ((size_t)b * d.Hin + oy) * d.Win + ox;
+      if (d.res[0]) v += load4<T>((const T*)d.res[0] + opix * d.cs_res + n);
+      if (d.res[1]) v += load4<T>((const T*)d.res[1] + opix * d.cs_res + n);
+      store4<T>((T*)d.out + opix * d.cs_out + n, v);
+    }
+  }
+}
+
+constexpr int TILE_R = 8;
+
+template <typename T, int PIXB, int KS>
+int launch_tile(const ConvDesc& d, hipStream_t s) {
+  const long long nblk = (long long)d.B * (d.Hin / TILE_R) * (d.Win / 64);
+  CFEN_LAUNCH((k_conv_tile<T, PIXB, KS, TILE_R>), dim3(cfen_grid8(nblk)), dim3(256), 0, s, d, (int)nblk);
+  CFEN_CHECK_LAUNCH("conv (tile)");
+  return CFEN_OK;
+}
+
+template <typename T>
+int launch_conv_tile(const ConvDesc& d, int k, hipStream_t s) {
+  const int pixb = d.cs_in * (int)sizeof(T);
+  CFEN_CHECK_ARG(cfen_aligned16(d.src[0]) && cfen_aligned16(d.weight) && cfen_aligned16(d.out) && cfen_aligned16(d.scale) &&
+                 cfen_aligned16(d.shift) && cfen_aligned16(d.res[0]) && cfen_aligned16(d.res[1]), "conv: pointers must be 16-byte aligned");
+  CFEN_CHECK_ARG(d.src[0] && d.weight && d.out && d.scale && d.shift, "conv: null pointer");
+  CFEN_CHECK_ARG(!(d.out_nchw_f32 && (d.res[0] || d.res[1])), "conv: residuals unsupported with NCHW output");
+  CFEN_CHECK_ARG(d.out_nchw_f32 || (d.cs_out % 4 == 0 && d.cs_out <= 16), "conv: cs_out=%d must be a multiple of 4 and <= 16", d.cs_out);
+  CFEN_CHECK_ARG(!d.pad_reflect || (k / 2 < d.Hin && k / 2 < d.Win), "conv: reflection pad larger than the image");
+  if constexpr (sizeof(T) == 2) {
+    if (pixb == 16 && k == 5) return launch_tile<T, 16, 5>(d, s);
+    if (pixb == 32 && k == 3) return launch_tile<T, 32, 3>(d, s);
+    if (pixb == 32 && k == 7) return launch_tile<T, 32, 7>(d, s);
+  } else {
+    if (pixb == 32 && k == 5) return launch_tile<T, 32, 5>(d, s);
+    if (pixb == 64 && k == 3) return launch_tile<T, 64, 3>(d, s);
+    if (pixb == 64 && k == 7) return launch_tile<T, 64, 7>(d, s);
+  }
+  cfen_set_error("conv (rows layout): kernel %dx%d over %d-byte pixels has no tiled instantiation", k, k, pixb);
+  return CFEN_ERR_ARG;
+}
+
+}  // namespace
+
+// geometry the tiled kernel covers (mirrored by packing.conv_uses_rows_layout)
+bool cfen_conv_tile_supported(int dtype, int kind, int k, int stride, int pad, int nsrc, int cs_in, int Cout_pad, int H, int W) {
+  const int pixb = cs_in * (dtype == 1 ? 2 : 4);
+  if (kind != 0 || stride != 1 || nsrc != 1 || pad != k / 2 || Cout_pad != 16 || H % TILE_R || W % 64) return false;
+  if (dtype == 1) return (pixb == 16 && k == 5) || (pixb == 32 && (k == 3 || k == 7));
+  return (pixb == 32 && k == 5) || (pixb == 64 && (k == 3 || k == 7));
+}
+
+int cfen_conv_tile_kpad(int dtype, int k, int cs_in) {
+  const int pixb = cs_in * (dtype == 1 ? 2 : 4), tpc = 64 / pixb, ncr = (k + tpc - 1) / tpc;
+  return k * ncr * (dtype == 1 ? 32 : 16);
+}
+
+int cfen_conv_tile_impl(int dtype, const ConvDesc* d, int k, hipStream_t s) {
+  CFEN_CHECK_ARG(cfen_conv_tile_supported(dtype, 0, k, d->in_stride, k / 2, 1, d->cs_in, d->Cout_pad, d->Hin, d->Win) && d->nphase == 1 &&
+                 d->Hout == d->Hin && d->Wout == d->Win,
+                 "conv (rows layout): unsupported geometry k=%d cs_in=%d Cout_pad=%d %dx%d", k, d->cs_in, d->Cout_pad, d->Hin, d->Win);
+  CFEN_CHECK_ARG(d->Kpad == cfen_conv_tile_kpad(dtype, k, d->cs_in), "conv (rows layout): Kpad=%d, expected %d", d->Kpad,
+                 cfen_conv_tile_kpad(dtype, k, d->cs_in));
+  if (dtype == 1) return launch_conv_tile<half_t>(*d, k, s);
+  return launch_conv_tile<float>(*d, k, s);
+}

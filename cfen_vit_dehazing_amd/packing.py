@@ -95,6 +95,28 @@ def pack_conv_weight(w, cin_pad, kc, dtype):
     return out
 
 
+def conv_uses_rows_layout(dtype, k, stride, pad, nsrc, cs_in, cout, H, W):
+    """mirror of cfen_conv_tile_supported (csrc/k_conv_tile.hip): which Conv2d layers run on the LDS-tiled kernel"""
+    pixb = cs_in * (2 if dtype == torch.float16 else 4)
+    if stride != 1 or nsrc != 1 or pad != k // 2 or round_up(cout, 16) != 16 or H % 8 or W % 64:
+        return False
+    if dtype == torch.float16:
+        return (pixb == 16 and k == 5) or (pixb == 32 and k in (3, 7))
+    return (pixb == 32 and k == 5) or (pixb == 64 and k in (3, 7))
+
+
+def pack_conv_weight_rows(w, cin_pad, dtype):
+    """Conv2d weight (Cout<=16, Cin, k, k) -> [1][16][k*KSP*cin_pad]: tap-major, every kernel row padded with zero
+    taps to a whole number of 64-byte chunks (KSP taps)."""
+    cout, cin, k, _ = w.shape
+    pixb = cin_pad * (2 if dtype == torch.float16 else 4)
+    tpc = 64 // pixb
+    ksp = (k + tpc - 1) // tpc * tpc
+    wp = torch.zeros(16, k, ksp, cin_pad, dtype=dtype, device=w.device)
+    wp[:cout, :, :k, :cin] = w.permute(0, 2, 3, 1).to(dtype)
+    return wp.reshape(1, 16, k * ksp * cin_pad)
+
+
 _KY = ((1, 3), (0, 2))    # [output parity][tap] -> kernel index; input offsets (0,-1),(+1,0): csrc/cfen_conv.hpp
 
 
@@ -141,10 +163,16 @@ def pack_state_dict(sd, cfg: NetConfig, dtype=torch.float16):
     for g in cfg.vit_instances():
         out.update(pack_vit(sd, g, dtype))
 
-    def conv(name, key, cin, an=None):
+    full = 2 * cfg.load_size
+
+    def conv(name, key, cin, an=None, rows=None):
+        # rows = (stride, pad) of a full-resolution layer that may run on the LDS-tiled kernel
         w = sd[key + ".weight"]
         cp = round_up(w.shape[0], 16)
-        out[name + ".w"] = pack_conv_weight(w, cs_of(cin), kc, dtype)
+        if rows and conv_uses_rows_layout(dtype, w.shape[2], rows[0], rows[1], 1, cs_of(cin), w.shape[0], full, full):
+            out[name + ".wr"] = pack_conv_weight_rows(w, cs_of(cin), dtype)
+        else:
+            out[name + ".w"] = pack_conv_weight(w, cs_of(cin), kc, dtype)
         if an:
             _check_actnorm(sd, an)
             s, t = affine(sd[key + ".bias"], sd[an + ".weight"], sd[an + ".bias"], cp)
@@ -163,9 +191,9 @@ def pack_state_dict(sd, cfg: NetConfig, dtype=torch.float16):
             s, t = affine(sd[key + ".bias"], cout_pad=cp)
         out[name + ".scale"], out[name + ".shift"] = s, t
 
-    conv("head.0.0", "head.0.0", 3)
-    conv("head.0.1.body.0", "head.0.1.body.0", h)
-    conv("head.0.1.body.2", "head.0.1.body.2", h)
+    conv("head.0.0", "head.0.0", 3, rows=(1, 2))
+    conv("head.0.1.body.0", "head.0.1.body.0", h, rows=(1, 1))
+    conv("head.0.1.body.2", "head.0.1.body.2", h, rows=(1, 1))
     conv("ds_conv_e01", "ds_conv_e01.0", h)
     conv("ds_conv_e02", "ds_conv_e02.0", nf)
     conv("ds_conv_e03", "ds_conv_e03.0", 2 * nf)
@@ -184,11 +212,11 @@ def pack_state_dict(sd, cfg: NetConfig, dtype=torch.float16):
             conv("sk_conv_d02" + b, "sk_conv_d02%s.0" % b, nf, an="sk_conv_d02%s.1" % b)
         T = "tail_" + b.upper()
         if b == "s":
-            conv(T + ".conv3", T + ".0.1", h)
-            conv(T + ".conv7", T + ".0.4", h)
+            conv(T + ".conv3", T + ".0.1", h, rows=(1, 1))
+            conv(T + ".conv7", T + ".0.4", h, rows=(1, 3))
         else:
-            conv(T + ".conv3", T + ".0.1", h, an=T + ".0.2")
-            conv(T + ".conv7", T + ".0.5", h)
+            conv(T + ".conv3", T + ".0.1", h, an=T + ".0.2", rows=(1, 1))
+            conv(T + ".conv7", T + ".0.5", h, rows=(1, 3))
     for n in ("cfsm2g_d03d", "cfsm2g_d02d"):
         parts = []
         for fc in ("fc_avg_cf1", "fc_avg_cf2", "fc_max_cf1", "fc_max_cf2"):

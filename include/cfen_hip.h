@@ -118,7 +118,10 @@ int cfen_nchw_to_nhwc(int dtype, const float* in, void* out, int B, int C, int H
 
 /* Conv2d / ConvTranspose2d(4,2,1) as implicit GEMM with fused affine + activation + residuals.
  * kind 0: Conv2d(k, stride, pad) over nsrc (1|2) channel-concatenated inputs; kind 1: ConvTranspose2d k4 s2 p1.
- * weight: packed [nphase][Cout_pad][Kpad] (packing.py); scale/shift: [Cout_pad] fp32.                */
+ * weight: packed [nphase][Cout_pad][Kpad] (packing.py); scale/shift: [Cout_pad] fp32.
+ * wlayout 0: k = tap*Cin + c (any geometry).  wlayout 1 ("rows", LDS-tiled kernel): stride 1, pad k/2, one source,
+ * Cout <= 16, H % 8 == 0, W % 64 == 0, pixel stride 16/32/64 bytes; each kernel row is padded with zero taps to a
+ * multiple of 64 bytes: k = (ky*KSP + kx)*cs_in + c, KSP = ceil(k*cs_in*esz/64)*64/(cs_in*esz), Kpad = k*KSP*cs_in. */
 typedef struct cfen_conv_args {
   int32_t kind, k, stride, pad, reflect, nsrc;
   int32_t B, Hin, Win, Cin, cs_in;
@@ -126,6 +129,7 @@ typedef struct cfen_conv_args {
   int32_t act;            /* 0 none, 1 ReLU, 2 tanh */
   int32_t out_nchw_f32;   /* write (B,Cout,H,W) fp32 instead of NHWC */
   int32_t cs_res;
+  int32_t wlayout;        /* 0 tap-major, 1 rows (see above) */
   const void* src0;
   const void* src1;
   const void* weight;

@@ -186,6 +186,66 @@ def test_conv_identity_kernel_is_exact(dtype):
     assert torch.equal(got.float().cpu(), want)
 
 
+def run_conv_rows(dtype, x, w, b, k, reflect=False, an=None, act=0, res=None, nchw=False):
+    """the LDS-tiled kernel behind wlayout=1 (k_conv_tile.hip)"""
+    d = dev()
+    cout, cin = w.shape[0], x.shape[1]
+    cs = packing.cs_of(cin)
+    assert packing.conv_uses_rows_layout(dtype, k, 1, k // 2, 1, cs, cout, x.shape[2], x.shape[3])
+    wp = packing.pack_conv_weight_rows(w, cs, dtype)[0]
+    s, t = packing.affine(b, an[0] if an else None, an[1] if an else None, 16)
+    xn = ops.to_nhwc(x.to(dtype)).to(d)
+    resn = ops.to_nhwc(res.to(dtype)).to(d) if res is not None else None
+    out = ops.conv2d(xn, wp.to(d), s.to(d), t.to(d), cs, cout, k=k, stride=1, pad=k // 2, reflect=reflect, act=act, res0=resn,
+                     nchw_f32=nchw, rows_layout=True)
+    return out if nchw else ops.from_nhwc(out, cout)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("cin,cout,k,H,W", [(3, 12, 5, 16, 64), (12, 12, 3, 8, 128), (12, 12, 3, 40, 64), (12, 3, 7, 24, 192)])
+def test_conv_rows_layout_matches_torch(dtype, cin, cout, k, H, W):
+    x = rnd((2, cin, H, W), 1, dtype)
+    w = rnd((cout, cin, k, k), 2, dtype, 1 / math.sqrt(cin * k * k))
+    b = rnd((cout,), 3, torch.float32, 0.1)
+    res = rnd((2, cout, H, W), 4, dtype)
+    want = torch.relu(F.conv2d(x.double(), w.double(), b.double(), padding=k // 2)) + res.double()
+    close(run_conv_rows(dtype, x, w, b, k, act=1, res=res), want, tol(dtype, 4))
+    # and bitwise-comparable with the gather kernel on the same operands (same MFMA chunking is not guaranteed: tolerance)
+    close(run_conv_rows(dtype, x, w, b, k), run_conv(dtype, x, w, b, k, 1, k // 2).double(), tol(dtype, 4))
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_conv_rows_layout_shift_kernel_is_exact(dtype):
+    # one-hot taps at the kernel corners: out[c](y,x) = in[c'](y+dy, x+dx) with zero padding, across tile borders
+    x = rnd((1, 12, 16, 128), 1, dtype)
+    for k in (3, 7):
+        w = torch.zeros(12, 12, k, k)
+        for c in range(12):
+            w[c, (c + 5) % 12, (0 if c % 2 else k - 1), (k - 1 if c % 3 else 0)] = 1.0
+        got = run_conv_rows(dtype, x, w.to(dtype), torch.zeros(12), k)
+        assert torch.equal(got.float().cpu(), F.conv2d(x.float(), w, padding=k // 2))
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_conv_rows_layout_reflect7_tanh_nchw(dtype):
+    x = rnd((2, 12, 16, 64), 1, dtype)
+    for cout in (3, 1):
+        w = rnd((cout, 12, 7, 7), 2, dtype, 0.3 / math.sqrt(12 * 49))
+        b = rnd((cout,), 3, torch.float32, 0.1)
+        want = torch.tanh(F.conv2d(F.pad(x.double(), (3, 3, 3, 3), mode="reflect"), w.double(), b.double()))
+        got = run_conv_rows(dtype, x, w, b, 7, reflect=True, act=2, nchw=True)
+        assert got.dtype == torch.float32 and got.shape == want.shape
+        close(got, want, tol(dtype, 2))
+
+
+def test_conv_rows_layout_rejects_unsupported_geometry():
+    x = rnd((1, 12, 12, 64), 1, torch.float16)          # H not a multiple of 8
+    wp = packing.pack_conv_weight_rows(rnd((12, 12, 3, 3), 2, torch.float16), 16, torch.float16)[0]
+    s, t = packing.affine(torch.zeros(12), cout_pad=16)
+    with pytest.raises(Exception, match="rows layout"):
+        ops.conv2d(ops.to_nhwc(x).to(dev()), wp.to(dev()), s.to(dev()), t.to(dev()), 16, 12, k=3, rows_layout=True)
+
+
 @pytest.mark.parametrize("dtype", DTYPES)
 def test_conv_reflect7_tanh_nchw(dtype):
     x = rnd((2, 12, 32, 32), 1, dtype)
