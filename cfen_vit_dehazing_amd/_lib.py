@@ -41,6 +41,7 @@ _P = c_void_p
 SIGNATURES = {
     "cfen_abi_version": (_I, []),
     "cfen_last_error": (c_char_p, []),
+    "cfen_tune": (_I, [c_char_p, _I]),
     "cfen_net_create": (_I, [ctypes.POINTER(_P), ctypes.POINTER(NetConfigC)]),
     "cfen_net_destroy": (None, [_P]),
     "cfen_net_workspace_bytes": (c_size_t, [_P]),

@@ -73,6 +73,17 @@ int cfen_nchw_to_nhwc(int dtype, const float* in, void* out, int B, int C, int H
   return cfen_nchw_to_nhwc_impl(dtype, in, out, B, C, H, W, cs, (hipStream_t)stream);
 }
 
+int cfen_tune(const char* key, int value) {
+  CFEN_CHECK_ARG(key != nullptr, "tune: null key");
+  if (!strcmp(key, "gemm.kernel")) {
+    CFEN_CHECK_ARG(value >= -1 && value <= 2, "tune: gemm.kernel must be -1 .. 2");
+    cfen_tune_gemm_kernel() = value;
+    return CFEN_OK;
+  }
+  cfen_set_error("tune: unknown key '%s'", key);
+  return CFEN_ERR_ARG;
+}
+
 int cfen_conv2d(int dtype, const cfen_conv_args* a, void* stream) {
   CFEN_CHECK_ARG(a != nullptr, "conv2d: null args");
   ConvDesc d;

@@ -22,3 +22,4 @@ size_t cfen_stats_workspace_bytes(int B, int C);
 int cfen_instnorm_relu_impl(int dtype, void* x, float* part, int B, int HW, int C, int cs, float eps, hipStream_t s);
 int cfen_cfsm2g_impl(int dtype, const void* x0, const void* x1, const void* x2, void* out, const float* w, float* part, int B, int HW,
                      int C, int cs, hipStream_t s);
+int& cfen_tune_gemm_kernel();   // -1 auto, 0 tiled, 1 skinny (cfen_tune "gemm.kernel")

@@ -13,6 +13,7 @@
 // K is staged through LDS in 128-byte row slices (+16 B pad against bank conflicts), double
 // buffered with register prefetch: one barrier per K step.
 #include "cfen_common.hpp"
+#include "cfen_internal.hpp"
 
 namespace {
 
@@ -20,6 +21,55 @@ template <typename T> struct GemmArgs {
   const T* X; const T* W; const float* bias; const T* R; const T* P; T* Y;
   int M, N, K, ldx, ldw, ldr, ldy, period, relu;
 };
+
+// Epilogue of the 3 x 4 tile block of one wave: the lane owns Y[m + 16 j][n + 16 i .. +3].  All residual / position
+// loads are issued before the first store (R may alias Y element for element -- in-place residual -- so the compiler
+// must not be left to order them: it would wait for every load separately), bias is read once.
+template <typename T>
+CFEN_DEV void gemm_epilogue(const GemmArgs<T>& a, floatx4 (&acc)[3][4], int n, int m) {
+  typedef typename Mma<T>::out4 out4;
+  floatx4 bias[3];
+  bool nok[3];
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {
+    nok[i] = n + 16 * i < a.N;
+    bias[i] = (a.bias && nok[i]) ? *reinterpret_cast<const floatx4*>(a.bias + n + 16 * i) : floatx4{0.f, 0.f, 0.f, 0.f};
+  }
+  out4 rv[3][4], pv[3][4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int mj = m + 16 * j;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+      const bool ok = nok[i] && mj < a.M;
+      if (a.R && ok) rv[i][j] = *reinterpret_cast<const out4*>(a.R + (size_t)mj * a.ldr + n + 16 * i);
+      if (a.P && ok) pv[i][j] = *reinterpret_cast<const out4*>(a.P + (size_t)(mj % a.period) * a.N + n + 16 * i);
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int mj = m + 16 * j;
+    if (mj >= a.M) continue;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+      if (!nok[i]) continue;
+      floatx4 v = acc[i][j] + bias[i];
+      if (a.relu) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f);
+      }
+      if (a.R) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] += (float)rv[i][j][r];
+      }
+      if (a.P) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] += (float)pv[i][j][r];
+      }
+      store4<T>(a.Y + (size_t)mj * a.ldy + n + 16 * i, v);
+    }
+  }
+}
 
 constexpr int G_BN = 96, G_BM = 128, G_ROWS = G_BN + G_BM;
 constexpr int G_BKB = 128;             // bytes of K per row per stage
@@ -102,29 +152,92 @@ __global__ __launch_bounds__(256) void k_gemm_nt(GemmArgs<T> a) {
     __syncthreads();
   }
 
-  // epilogue: lane owns Y[m][n..n+3], m = tile col, n = tile row block 4h
+  gemm_epilogue<T>(a, acc, n0 + wn * 48 + 4 * h, m0 + wm * 64 + r16);
+}
+
+// Same 128 x 96 block tile, staged by LDS-DMA (global_load_lds_dwordx4: no VGPR round trip, no ds_write_b128 -- the
+// 13-cycle wide LDS store of the register-staged kernel above costs as much LDS-path time per K step as all its
+// fragment reads).  One wave-instruction lands 1 KiB = 8 rows x 128 B lane-linearly, so the image cannot be padded;
+// bank conflicts are avoided by XOR-swizzling the 16-byte piece index with (row & 7) on the SOURCE address and on
+// the fragment read address.  Two LDS stages; the DMA of stage k+1 stays in flight across the barriers of stage k
+// (counted vmcnt, raw s_barrier).  Needs K * sizeof(T) % 128 == 0.
+// one global_load_lds_dwordx4: this lane's 16 bytes at `g` land at (wave-uniform) `l` + 16 * lane
+CFEN_DEV void dma16(const void* g, unsigned char* l) {
+  __builtin_amdgcn_global_load_lds(g, (__attribute__((address_space(3))) void*)l, 16, 0, 0);
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void k_gemm_dma(GemmArgs<T> a) {
+  constexpr int EPL = Mma<T>::EPL;
+  constexpr int BK = G_BKB / (int)sizeof(T);
+  constexpr int NCH = BK / Mma<T>::KC;   // 2
+  constexpr int STAGE = G_ROWS * G_BKB;  // 28 KiB
+  typedef typename Mma<T>::frag frag;
+  __shared__ __attribute__((aligned(1024))) unsigned char lds[2 * STAGE];
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int r16 = lane & 15, h = lane >> 4;
+  const int n0 = blockIdx.x * G_BN, m0 = blockIdx.y * G_BM;
+  const int wn = wave & 1, wm = wave >> 1;
+
+  // DMA assignment: instruction i of wave w fills rows i*32 + w*8 .. +8; lane -> (row, 16-byte slot)
+  const T* gptr[G_LOADS];
 #pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    const int m = m0 + wm * 64 + j * 16 + r16;
-    if (m >= a.M) continue;
-#pragma unroll
-    for (int i = 0; i < 3; ++i) {
-      const int n = n0 + wn * 48 + i * 16 + 4 * h;
-      if (n >= a.N) continue;
-      floatx4 v = acc[i][j];
-      if (a.bias) {
-        floatx4 b = *reinterpret_cast<const floatx4*>(a.bias + n);
-        v += b;
-      }
-      if (a.relu) {
-#pragma unroll
-        for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f);
-      }
-      if (a.R) v += load4<T>(a.R + (size_t)m * a.ldr + n);
-      if (a.P) v += load4<T>(a.P + (size_t)(m % a.period) * a.N + n);
-      store4<T>(a.Y + (size_t)m * a.ldy + n, v);
-    }
+  for (int i = 0; i < G_LOADS; ++i) {
+    const int row = i * 32 + wave * 8 + (lane >> 3), slot = lane & 7;
+    const int piece = slot ^ (row & 7);
+    const T* base = row < G_BN ? a.W + (size_t)min(n0 + row, a.N - 1) * a.ldw : a.X + (size_t)min(m0 + row - G_BN, a.M - 1) * a.ldx;
+    gptr[i] = base + piece * EPL;
   }
+#define CFEN_GEMM_DMA_ISSUE(kt_, buf_)                                                                              \
+  _Pragma("unroll") for (int i_ = 0; i_ < G_LOADS; ++i_)                                                              \
+      dma16(gptr[i_] + (kt_) * BK, lds + (buf_) * STAGE + (i_ * 256 + wave * 64) * 16)
+
+  floatx4 acc[3][4];
+#pragma unroll
+  for (int i = 0; i < 3; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = floatx4{0.f, 0.f, 0.f, 0.f};
+
+  // fragment read offsets: row r, chunk c, quarter h -> r*128 + (((c*4 + h) ^ (r & 7)) << 4)
+  int aoff[3], boff[4];
+#pragma unroll
+  for (int i = 0; i < 3; ++i) aoff[i] = (wn * 48 + i * 16 + r16) * G_BKB;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) boff[j] = (G_BN + wm * 64 + j * 16 + r16) * G_BKB;
+  const int sw = r16 & 7;   // every fragment row of this lane has (row & 7) == (r16 & 7): all tile offsets are multiples of 16
+
+  const int nk = a.K / BK;
+  CFEN_GEMM_DMA_ISSUE(0, 0);
+  for (int kt = 0; kt < nk; ++kt) {
+    const int buf = kt & 1;
+    if (kt + 1 < nk) {
+      CFEN_GEMM_DMA_ISSUE(kt + 1, buf ^ 1);
+      asm volatile("s_waitcnt vmcnt(7)" ::: "memory");   // stage kt landed, stage kt+1 (7 DMAs) may stay in flight
+    } else {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    __builtin_amdgcn_s_barrier();
+    const unsigned char* st = lds + buf * STAGE;
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+      const int po = ((c * 4 + h) ^ sw) << 4;
+      frag af[3], bf[4];
+#pragma unroll
+      for (int i = 0; i < 3; ++i) af[i] = *reinterpret_cast<const frag*>(st + aoff[i] + po);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) bf[j] = *reinterpret_cast<const frag*>(st + boff[j] + po);
+#pragma unroll
+      for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = Mma<T>::mma(af[i], bf[j], acc[i][j]);
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();   // every wave is done reading `buf` before the next iteration's DMA refills it
+  }
+
+  gemm_epilogue<T>(a, acc, n0 + wn * 48 + 4 * h, m0 + wm * 64 + r16);
+#undef CFEN_GEMM_DMA_ISSUE
 }
 
 // Small-M variant (GViT: 128..2048 tokens per batch against weight matrices of up to 6144 x 1536): the
@@ -190,19 +303,34 @@ int launch_gemm(const void* X, int ldx, const void* W, int ldw, const float* bia
                  cfen_aligned16(bias), "gemm: pointers must be 16-byte aligned");
   CFEN_CHECK_ARG(!P || period > 0, "gemm: position table needs a period");
   GemmArgs<T> a{(const T*)X, (const T*)W, bias, (const T*)R, (const T*)P, (T*)Y, M, N, K, ldx, ldw, ldr, ldy, period, relu};
-  if (M <= 2048 && K % (2 * Mma<T>::KC) == 0) {
+  const int forced = cfen_tune_gemm_kernel();
+  const bool k128 = (K * (int)sizeof(T)) % G_BKB == 0;
+  CFEN_CHECK_ARG((forced != 1 && forced != 2) || k128, "gemm: k_gemm_skinny / k_gemm_dma need K * sizeof(T) %% 128 == 0");
+  // the tiled kernels need enough 128 x 96 tiles to occupy the chip; below that (GViT: <= 2048 tokens against square or
+  // K-heavy weights) the skinny kernel's 16 x 64 tiles with in-workgroup split-K win (tools/bench_gemm.py)
+  const long long tiles = (long long)((N + G_BN - 1) / G_BN) * ((M + G_BM - 1) / G_BM);
+  const bool want_skinny = k128 && (tiles <= 32 || (tiles <= 64 && K * (int)sizeof(T) <= 1024));
+  if (forced == 1 || (forced < 0 && want_skinny)) {
     CFEN_LAUNCH(k_gemm_skinny<T>, dim3((N + 15) / 16, (M + 63) / 64), dim3(256), 0, s, a);
     CFEN_CHECK_LAUNCH("gemm");
     return CFEN_OK;
   }
   dim3 grid((N + G_BN - 1) / G_BN, (M + G_BM - 1) / G_BM);
   CFEN_CHECK_ARG(grid.y <= 65535, "gemm: M too large for one launch");
-  CFEN_LAUNCH(k_gemm_nt<T>, grid, dim3(256), 0, s, a);
+  if (forced == 2 || (forced < 0 && k128))
+    CFEN_LAUNCH(k_gemm_dma<T>, grid, dim3(256), 0, s, a);
+  else
+    CFEN_LAUNCH(k_gemm_nt<T>, grid, dim3(256), 0, s, a);
   CFEN_CHECK_LAUNCH("gemm");
   return CFEN_OK;
 }
 
 }  // namespace
+
+int& cfen_tune_gemm_kernel() {
+  static int v = -1;
+  return v;
+}
 
 int cfen_gemm_impl(int dtype, const void* X, int ldx, const void* W, int ldw, const float* bias, const void* R, int ldr,
                    const void* P, int period, void* Y, int ldy, int M, int N, int K, int relu, hipStream_t s) {

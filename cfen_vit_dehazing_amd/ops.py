@@ -19,6 +19,11 @@ def _cuda(*ts):
             raise ValueError("HIP operators need contiguous CUDA tensors")
 
 
+def tune(key, value):
+    """process-wide kernel-variant knob (cfen_tune); for benchmarks"""
+    check(_lib.load().cfen_tune(key.encode(), int(value)), "tune")
+
+
 def gemm_nt(x, w, bias=None, residual=None, pos=None, relu=False, out=None):
     """act(x @ w.T + bias) + residual + pos[row % len(pos)]   (x: [M,K], w: [N,K])"""
     _cuda(x, w, bias, residual, pos, out)

@@ -1,0 +1,41 @@
+#!/usr/bin/env python3
+"""Time every token-GEMM shape of the generator (batch B, 512x512, n_feats 24) on both GEMM kernels."""
+import sys, os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from cfen_vit_dehazing_amd import ops
+
+B = int(sys.argv[1]) if len(sys.argv) > 1 else 8
+d = "cuda:0"
+
+def timeit(f, n=30):
+    for _ in range(3): f()
+    torch.cuda.synchronize()
+    s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    s.record()
+    for _ in range(n): f()
+    e.record(); torch.cuda.synchronize()
+    return s.elapsed_time(e) / n * 1e3
+
+shapes = []
+for lvl, (T, D, G_T, G_D) in enumerate(((16384, 96, 256, 384), (4096, 192, 64, 768), (1024, 384, 16, 1536)), 1):
+    for kind, t, dd in (("L", T, D), ("G", G_T, G_D)):
+        M = B * t
+        shapes += [("%s%d embed/proj" % (kind, lvl), M, dd, dd), ("%s%d qkv" % (kind, lvl), M, 3 * dd, dd)]
+        if kind == "G" or dd == 384:
+            shapes += [("%s%d ffn1" % (kind, lvl), M, 4 * dd, dd), ("%s%d ffn2" % (kind, lvl), M, dd, 4 * dd)]
+print("%-16s %7s %6s %6s | %9s %9s %9s | best" % ("shape", "M", "N", "K", "tiled us", "skinny us", "dma us"))
+for name, M, N, K in shapes:
+    x = torch.randn(M, K, device=d).half(); w = (torch.randn(N, K, device=d) * 0.05).half(); b = torch.zeros(N, device=d)
+    r = torch.randn(M, N, device=d).half(); out = torch.empty(M, N, device=d).half()
+    res = []
+    for v in (0, 1, 2):
+        ops.tune("gemm.kernel", v)
+        try:
+            res.append(timeit(lambda: ops.gemm_nt(x, w, bias=b, residual=r, out=out)))
+        except Exception:
+            res.append(float("inf"))
+    ops.tune("gemm.kernel", -1)
+    auto = timeit(lambda: ops.gemm_nt(x, w, bias=b, residual=r, out=out))
+    fl = 2.0 * M * N * K
+    print("%-16s %7d %6d %6d | %9.1f %9.1f %9.1f | %s %.0f TF (auto %.1f us)" % (name, M, N, K, res[0], res[1], res[2], ("tiled", "skinny", "dma")[res.index(min(res))], fl / min(res) / 1e6, auto))
