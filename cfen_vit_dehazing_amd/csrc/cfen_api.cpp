@@ -104,6 +104,7 @@ int cfen_conv2d(int dtype, const cfen_conv_args* a, void* stream) {
   d.res[0] = a->res0; d.res[1] = a->res1; d.cs_res = a->cs_res;
   d.out = a->out; d.cs_out = a->cs_out; d.Cout_pad = a->Cout_pad; d.Cout = a->Cout;
   d.out_nchw_f32 = a->out_nchw_f32;
+  if (a->wlayout == 1 && a->kind == 1) return cfen_convT_tile_impl(dtype, &d, (hipStream_t)stream);
   if (a->wlayout == 1) {
     CFEN_CHECK_ARG(a->kind == 0 && a->nsrc == 1 && a->stride == 1 && a->pad == a->k / 2, "conv2d: rows layout needs a stride-1 same-size Conv2d");
     return cfen_conv_tile_impl(dtype, &d, a->k, (hipStream_t)stream);

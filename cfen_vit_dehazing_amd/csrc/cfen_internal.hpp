@@ -18,6 +18,9 @@ int cfen_conv_impl(int dtype, const ConvDesc* d, hipStream_t s);
 bool cfen_conv_tile_supported(int dtype, int kind, int k, int stride, int pad, int nsrc, int cs_in, int Cout_pad, int H, int W);
 int cfen_conv_tile_kpad(int dtype, int k, int cs_in);
 int cfen_conv_tile_impl(int dtype, const ConvDesc* d, int k, hipStream_t s);
+bool cfen_convT_tile_supported(int dtype, int cs_in, int Cout_pad, int Hin, int Win);
+int cfen_convT_tile_kpad(int dtype, int cs_in);
+int cfen_convT_tile_impl(int dtype, const ConvDesc* d, hipStream_t s);
 size_t cfen_stats_workspace_bytes(int B, int C);
 int cfen_instnorm_relu_impl(int dtype, void* x, float* part, int B, int HW, int C, int cs, float eps, hipStream_t s);
 int cfen_cfsm2g_impl(int dtype, const void* x0, const void* x1, const void* x2, void* out, const float* w, float* part, int B, int HW,

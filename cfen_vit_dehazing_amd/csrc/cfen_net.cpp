@@ -134,8 +134,13 @@ struct cfen_net {
     c.nphase = kind == 1 ? 4 : 1;
     c.ntaps = kind == 1 ? 4 : k * k * nsrc;
     c.Kpad = cfen_round_up(c.ntaps * Cin, KC);
-    c.tile = cfen_conv_tile_supported(cfg.dtype, kind, k, stride, pad, nsrc, Cin, c.Cout_pad, out_edge, out_edge);
-    if (c.tile) c.Kpad = cfen_conv_tile_kpad(cfg.dtype, k, Cin);
+    if (kind == 1) {
+      c.tile = cfen_convT_tile_supported(cfg.dtype, Cin, c.Cout_pad, out_edge / 2, out_edge / 2);
+      if (c.tile) c.Kpad = cfen_convT_tile_kpad(cfg.dtype, Cin);
+    } else {
+      c.tile = cfen_conv_tile_supported(cfg.dtype, kind, k, stride, pad, nsrc, Cin, c.Cout_pad, out_edge, out_edge);
+      if (c.tile) c.Kpad = cfen_conv_tile_kpad(cfg.dtype, k, Cin);
+    }
     convs[n] = c;
     need(n + (c.tile ? ".wr" : ".w"), (size_t)c.nphase * c.Cout_pad * c.Kpad * esz);
     need(n + ".scale", (size_t)c.Cout_pad * 4);
@@ -328,7 +333,9 @@ int cfen_net::run_conv(const std::string& layer, const std::string& in0, const c
   const double fl = cfg.batch * (c.kind == 1 ? 2.0 * c.Cin_real * c.Cout * 16.0 * (e / 2) * (e / 2)
                                              : 2.0 * c.Cout * (double)c.Cin_real * c.nsrc * c.k * c.k * e * e);
   label = layer;
-  if (c.tile)
+  if (c.tile && c.kind == 1)
+    TRYP(K_CONV, fl, cfen_convT_tile_impl(cfg.dtype, &d, stream));
+  else if (c.tile)
     TRYP(K_CONV, fl, cfen_conv_tile_impl(cfg.dtype, &d, c.k, stream));
   else
     TRYP(K_CONV, fl, cfen_conv_impl(cfg.dtype, &d, stream));

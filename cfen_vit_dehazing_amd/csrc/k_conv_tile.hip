@@ -175,3 +175,166 @@ int cfen_conv_tile_impl(int dtype, const ConvDesc* d, int k, hipStream_t s) {
   if (dtype == 1) return launch_conv_tile<half_t>(*d, k, s);
   return launch_conv_tile<float>(*d, k, s);
 }
+
+// ---------------------------------------------------------------------------------------------------------------
+// ConvTranspose2d(k4, s2, p1) (v3:301-322) on an LDS-staged input tile.  Output pixel (2y+py, 2x+px) gathers a 2x2
+// input neighbourhood (cfen_conv.hpp: cfen_desc_convT4), so the four parity phases of one base tile read the SAME
+// (RY+2) x (16*NX+2) input halo: it is staged once (channels zero-padded to a whole number of 64-byte chunks, CPT per
+// pixel) and each of the 4 waves computes one phase of the whole tile with its phase's weights in registers.  An
+// input-row fragment feeds both output rows that use it (taps ty = 0 and 1).  16-byte pieces are XOR-swizzled inside a
+// pixel so that the 16 lanes of a ds_read_b128 group hit distinct bank positions.
+// Weight layout "rows": [4 phases][Cout_pad][4 taps][PIXB / sizeof(T)] (packing.pack_convT_weight_rows).
+namespace {
+
+template <int PIXB> CFEN_DEV int convt_swz(int col) {
+  if (PIXB == 128) return (col >> 1) & 7;        // 8 pieces per pixel: 3-bit flip
+  return (4 - ((col >> 2) & 3)) & 3;             // 64 / 192 bytes per pixel: flip inside each 64-byte chunk
+}
+
+template <typename T, int PIXB, int TN, int NX, int RY>
+__global__ __launch_bounds__(256) void k_convT_tile(ConvDesc d, int nblk) {
+  constexpr int SZ = (int)sizeof(T), EPL = Mma<T>::EPL, KC = Mma<T>::KC;
+  constexpr int CPT = PIXB / 64;                 // chunks per tap
+  constexpr int TW = 16 * NX;                    // base pixels per tile row
+  constexpr int WT = TW + 2, ROWS = RY + 2;
+  constexpr int RB = WT * PIXB;
+  constexpr int PPP = PIXB / 16;
+  constexpr int NPIECE = ROWS * WT * PPP;
+  constexpr int NIT = (NPIECE + 255) / 256;
+  constexpr int KPAD = 4 * CPT * KC;
+  typedef typename Mma<T>::frag frag;
+  __shared__ __attribute__((aligned(16))) unsigned char lds[ROWS * RB];
+
+  const int blk = (int)xcd_chunked_block(blockIdx.x, gridDim.x);
+  if (blk >= nblk) return;
+  const int tid = threadIdx.x, lane = tid & 63, phase = tid >> 6, r16 = lane & 15, h = lane >> 4;
+  const int py = phase >> 1, px = phase & 1;
+  const int tiles_x = d.Win / TW, tiles_y = d.Hin / RY;
+  const int tx = blk % tiles_x, ty = (blk / tiles_x) % tiles_y, b = blk / (tiles_x * tiles_y);
+  const int x0 = tx * TW, y0 = ty * RY;
+  const int src_pixb = d.cs_in * SZ, src_pieces = src_pixb / 16;
+  const unsigned char* src = (const unsigned char*)d.src[0] + (size_t)b * d.Hin * d.Win * src_pixb;
+
+  frag stg[NIT];
+#pragma unroll
+  for (int i = 0; i < NIT; ++i) {
+    const int idx = tid + i * 256;
+    const int piece = idx % PPP, col = (idx / PPP) % WT, row = idx / (PPP * WT);
+    const int gy = y0 - 1 + row, gx = x0 - 1 + col;
+    const bool ok = idx < NPIECE && piece < src_pieces && gy >= 0 && gy < d.Hin && gx >= 0 && gx < d.Win;
+    stg[i] = ok ? *reinterpret_cast<const frag*>(src + ((size_t)gy * d.Win + gx) * src_pixb + piece * 16) : Mma<T>::zero();
+  }
+  // this wave's phase: weights of its 4 taps
+  frag wf[4][CPT][TN];
+  {
+    const T* wp = (const T*)d.weight + ((size_t)phase * d.Cout_pad + r16) * KPAD + h * EPL;
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+      for (int c = 0; c < CPT; ++c)
+#pragma unroll
+        for (int i = 0; i < TN; ++i) wf[t][c][i] = load_frag<T>(wp + (size_t)i * 16 * KPAD + (t * CPT + c) * KC);
+  }
+#pragma unroll
+  for (int i = 0; i < NIT; ++i) {
+    const int idx = tid + i * 256;
+    const int piece = idx % PPP, col = (idx / PPP) % WT, row = idx / (PPP * WT);
+    if (idx < NPIECE) *reinterpret_cast<frag*>(&lds[row * RB + col * PIXB + ((piece ^ convt_swz<PIXB>(col)) << 4)]) = stg[i];
+  }
+  __syncthreads();
+
+  floatx4 acc[RY][NX][TN];
+#pragma unroll
+  for (int r = 0; r < RY; ++r)
+#pragma unroll
+    for (int xq = 0; xq < NX; ++xq)
+#pragma unroll
+      for (int i = 0; i < TN; ++i) acc[r][xq][i] = floatx4{0.f, 0.f, 0.f, 0.f};
+
+  // Parity p reads input offsets {0, -1} (p = 0) or {+1, 0} (p = 1) for taps 0, 1 (cfen_conv.hpp), i.e. tap t of output
+  // base row r reads halo row r - t + 1 + p.  Output rows r = q (tap 0) and r = q + 1 (tap 1) share halo row q + 1 + p:
+  // loop over q with compile-time accumulator indices; the phase only moves the LDS address.
+  const unsigned char* lp = lds + (1 + py) * RB;
+#pragma unroll
+  for (int q = -1; q < RY; ++q) {
+#pragma unroll
+    for (int txx = 0; txx < 2; ++txx) {
+#pragma unroll
+      for (int xq = 0; xq < NX; ++xq) {
+        const int col = xq * 16 + r16 + px + 1 - txx;
+        const unsigned char* pp = lp + q * RB + col * PIXB;
+        const int sw = convt_swz<PIXB>(col);
+#pragma unroll
+        for (int c = 0; c < CPT; ++c) {
+          const frag bf = *reinterpret_cast<const frag*>(pp + (((c * 4 + h) ^ sw) << 4));
+          if (q >= 0) {
+#pragma unroll
+            for (int i = 0; i < TN; ++i) acc[q][xq][i] = Mma<T>::mma(wf[txx][c][i], bf, acc[q][xq][i]);
+          }
+          if (q + 1 < RY) {
+#pragma unroll
+            for (int i = 0; i < TN; ++i) acc[q + 1][xq][i] = Mma<T>::mma(wf[2 + txx][c][i], bf, acc[q + 1][xq][i]);
+          }
+        }
+      }
+    }
+  }
+
+  const int Hout = 2 * d.Hin, Wout = 2 * d.Win;
+#pragma unroll
+  for (int i = 0; i < TN; ++i) {
+    const int n = i * 16 + 4 * h;
+    if (n >= d.cs_out) continue;
+    const floatx4 sc = *reinterpret_cast<const floatx4*>(d.scale + n), sh = *reinterpret_cast<const floatx4*>(d.shift + n);
+#pragma unroll
+    for (int r = 0; r < RY; ++r)
+#pragma unroll
+      for (int xq = 0; xq < NX; ++xq) {
+        const int oy = 2 * (y0 + r) + py, ox = 2 * (x0 + xq * 16 + r16) + px;
+        floatx4 v = acc[r][xq][i] * sc + sh;
+        if (d.act == 1) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
+        }
+        store4<T>((T*)d.out + (((size_t)b * Hout + oy) * Wout + ox) * d.cs_out + n, v);
+      }
+  }
+}
+
+template <typename T, int PIXB, int TN, int NX, int RY>
+int launch_convT_tile(const ConvDesc& d, hipStream_t s) {
+  const long long nblk = (long long)d.B * (d.Hin / RY) * (d.Win / (16 * NX));
+  CFEN_LAUNCH((k_convT_tile<T, PIXB, TN, NX, RY>), dim3(cfen_grid8(nblk)), dim3(256), 0, s, d, (int)nblk);
+  CFEN_CHECK_LAUNCH("convT (tile)");
+  return CFEN_OK;
+}
+
+constexpr int CT_RY = 4;
+
+}  // namespace
+
+static int convt_pixb(int dtype, int cin) { return (cin * (dtype == 1 ? 2 : 4) + 63) / 64 * 64; }
+
+// geometry the tiled ConvTranspose kernel covers (mirrored by packing.convT_uses_rows_layout)
+bool cfen_convT_tile_supported(int dtype, int cs_in, int Cout_pad, int Hin, int Win) {
+  const int pixb = convt_pixb(dtype, cs_in);
+  if (dtype != 1 || Hin % CT_RY || Win % 32) return false;       // fp32 keeps the gather kernel
+  return (pixb == 64 && Cout_pad == 16) || (pixb == 128 && Cout_pad == 32) || (pixb == 192 && Cout_pad == 48);
+}
+
+int cfen_convT_tile_kpad(int dtype, int cs_in) { return 4 * convt_pixb(dtype, cs_in) / (dtype == 1 ? 2 : 4); }
+
+int cfen_convT_tile_impl(int dtype, const ConvDesc* d, hipStream_t s) {
+  CFEN_CHECK_ARG(d->nphase == 4 && cfen_convT_tile_supported(dtype, d->cs_in, d->Cout_pad, d->Hin, d->Win),
+                 "convT (rows layout): unsupported geometry cs_in=%d Cout_pad=%d %dx%d dtype=%d", d->cs_in, d->Cout_pad, d->Hin, d->Win, dtype);
+  CFEN_CHECK_ARG(d->Kpad == cfen_convT_tile_kpad(dtype, d->cs_in), "convT (rows layout): Kpad=%d, expected %d", d->Kpad,
+                 cfen_convT_tile_kpad(dtype, d->cs_in));
+  CFEN_CHECK_ARG(cfen_aligned16(d->src[0]) && cfen_aligned16(d->weight) && cfen_aligned16(d->out) && cfen_aligned16(d->scale) &&
+                 cfen_aligned16(d->shift) && d->src[0] && d->weight && d->out && d->scale && d->shift, "convT: null or misaligned pointer");
+  CFEN_CHECK_ARG(!d->res[0] && !d->res[1] && !d->out_nchw_f32 && d->cs_out % 4 == 0 && d->cs_out <= d->Cout_pad && d->act != 2,
+                 "convT (rows layout): residuals / NCHW output / tanh unsupported");
+  const int pixb = convt_pixb(dtype, d->cs_in);
+  if (pixb == 64) return launch_convT_tile<half_t, 64, 1, 2, CT_RY>(*d, s);
+  if (pixb == 128) return launch_convT_tile<half_t, 128, 2, 2, CT_RY>(*d, s);
+  return launch_convT_tile<half_t, 192, 3, 1, CT_RY>(*d, s);
+}

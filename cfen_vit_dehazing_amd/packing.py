@@ -134,6 +134,29 @@ def pack_convT_weight(w, cin_pad, kc, dtype):
     return out
 
 
+def convT_uses_rows_layout(dtype, cin_pad, cout, Hin, Win):
+    """mirror of cfen_convT_tile_supported (csrc/k_conv_tile.hip)"""
+    if dtype != torch.float16 or Hin % 4 or Win % 32:
+        return False
+    pixb = (cin_pad * 2 + 63) // 64 * 64
+    return (pixb, round_up(cout, 16)) in ((64, 16), (128, 32), (192, 48))
+
+
+def pack_convT_weight_rows(w, cin_pad, dtype):
+    """ConvTranspose2d weight (Cin, Cout, 4, 4) -> [4 phases][Cout_pad][4 taps * CP]: as pack_convT_weight with every
+    tap's channels zero-padded to a whole number of 64-byte chunks (CP elements)."""
+    cin, cout = w.shape[0], w.shape[1]
+    esz = 2 if dtype == torch.float16 else 4
+    cp = (cin_pad * esz + 63) // 64 * 64 // esz
+    out = torch.zeros(4, round_up(cout, 16), 4, cp, dtype=dtype, device=w.device)
+    for py in range(2):
+        for px in range(2):
+            for ty in range(2):
+                for tx in range(2):
+                    out[py * 2 + px, :cout, ty * 2 + tx, :cin] = w[:, :, _KY[py][ty], _KY[px][tx]].t().to(dtype)
+    return out.reshape(4, out.shape[1], 4 * cp)
+
+
 def affine(bias, an_w=None, an_b=None, cout_pad=None):
     """(scale, shift) so that y = acc*scale + shift == ActNorm(conv + bias)."""
     bias = bias.float()
@@ -180,10 +203,13 @@ def pack_state_dict(sd, cfg: NetConfig, dtype=torch.float16):
             s, t = affine(sd[key + ".bias"], cout_pad=cp)
         out[name + ".scale"], out[name + ".shift"] = s, t
 
-    def convT(name, key, cin, an=None):
+    def convT(name, key, cin, an=None, edge=None):
         w = sd[key + ".weight"]
         cp = round_up(w.shape[1], 16)
-        out[name + ".w"] = pack_convT_weight(w, cs_of(cin), kc, dtype)
+        if convT_uses_rows_layout(dtype, cs_of(cin), w.shape[1], edge, edge):
+            out[name + ".wr"] = pack_convT_weight_rows(w, cs_of(cin), dtype)
+        else:
+            out[name + ".w"] = pack_convT_weight(w, cs_of(cin), kc, dtype)
         if an:
             _check_actnorm(sd, an)
             s, t = affine(sd[key + ".bias"], sd[an + ".weight"], sd[an + ".bias"], cp)
@@ -204,9 +230,9 @@ def pack_state_dict(sd, cfg: NetConfig, dtype=torch.float16):
         for l in (1, 2, 3):
             n = "lgcat_conv_d0%d%s" % (l, b)
             conv(n, n + ".0", nf << (l - 1), an=n + ".1")
-        convT("us_conv_d03" + b, "us_conv_d03%s.0" % b, 4 * nf)
-        convT("us_conv_d02" + b, "us_conv_d02%s.0" % b, 2 * nf, an="us_conv_d02%s.1" % b)
-        convT("us_conv_d01" + b, "us_conv_d01%s.0" % b, nf, an="us_conv_d01%s.1" % b)
+        convT("us_conv_d03" + b, "us_conv_d03%s.0" % b, 4 * nf, edge=full // 8)
+        convT("us_conv_d02" + b, "us_conv_d02%s.0" % b, 2 * nf, an="us_conv_d02%s.1" % b, edge=full // 4)
+        convT("us_conv_d01" + b, "us_conv_d01%s.0" % b, nf, an="us_conv_d01%s.1" % b, edge=full // 2)
         if b != "d":
             conv("sk_conv_d03" + b, "sk_conv_d03%s.0" % b, 2 * nf, an="sk_conv_d03%s.1" % b)
             conv("sk_conv_d02" + b, "sk_conv_d02%s.0" % b, nf, an="sk_conv_d02%s.1" % b)

@@ -125,7 +125,9 @@ int cfen_nchw_to_nhwc(int dtype, const float* in, void* out, int B, int C, int H
  * weight: packed [nphase][Cout_pad][Kpad] (packing.py); scale/shift: [Cout_pad] fp32.
  * wlayout 0: k = tap*Cin + c (any geometry).  wlayout 1 ("rows", LDS-tiled kernel): stride 1, pad k/2, one source,
  * Cout <= 16, H % 8 == 0, W % 64 == 0, pixel stride 16/32/64 bytes; each kernel row is padded with zero taps to a
- * multiple of 64 bytes: k = (ky*KSP + kx)*cs_in + c, KSP = ceil(k*cs_in*esz/64)*64/(cs_in*esz), Kpad = k*KSP*cs_in. */
+ * multiple of 64 bytes: k = (ky*KSP + kx)*cs_in + c, KSP = ceil(k*cs_in*esz/64)*64/(cs_in*esz), Kpad = k*KSP*cs_in.
+ * wlayout 1 with kind 1 (fp16, Hin % 4 == 0, Win % 32 == 0, (cs_in, Cout_pad) in {(24,16),(48,32),(96,48)}): every tap's
+ * channels zero-padded to a multiple of 64 bytes: [4 phases][Cout_pad][4 taps][CP], CP = ceil(cs_in*esz/64)*64/esz.        */
 typedef struct cfen_conv_args {
   int32_t kind, k, stride, pad, reflect, nsrc;
   int32_t B, Hin, Win, Cin, cs_in;

@@ -288,6 +288,43 @@ def test_conv_transpose(dtype, cin, cout):
         assert float(out[..., cout:].abs().max()) == 0.0
 
 
+@pytest.mark.parametrize("cin,cout,H,W", [(96, 48, 8, 32), (48, 24, 12, 64), (24, 12, 16, 96)])
+def test_conv_transpose_rows_layout(cin, cout, H, W):
+    """LDS-tiled ConvTranspose2d (k_convT_tile, fp16 only): vs torch, vs the gather kernel, and padded channels zero"""
+    dtype, d = torch.float16, dev()
+    assert packing.convT_uses_rows_layout(dtype, packing.cs_of(cin), cout, H, W)
+    x = rnd((2, cin, H, W), 1, dtype)
+    w = rnd((cin, cout, 4, 4), 2, dtype, 1 / math.sqrt(cin * 4))
+    b = rnd((cout,), 3, torch.float32, 0.1)
+    anw, anb = rnd((cout,), 4, torch.float32, 0.2), rnd((cout,), 5, torch.float32, 0.2)
+    y = F.conv_transpose2d(x.double(), w.double(), b.double(), stride=2, padding=1)
+    want = torch.relu((y + anb.double().view(1, -1, 1, 1)) * torch.exp(anw.double()).view(1, -1, 1, 1))
+    s, t = packing.affine(b, anw, anb, packing.round_up(cout, 16))
+    xn = ops.to_nhwc(x).to(d)
+    out = ops.conv2d(xn, packing.pack_convT_weight_rows(w, packing.cs_of(cin), dtype).to(d), s.to(d), t.to(d), packing.cs_of(cin), cout,
+                     transpose=True, act=1, rows_layout=True)
+    close(ops.from_nhwc(out, cout), want, tol(dtype, 4))
+    ref = ops.conv2d(xn, packing.pack_convT_weight(w, packing.cs_of(cin), 32, dtype).to(d), s.to(d), t.to(d), packing.cs_of(cin), cout,
+                     transpose=True, act=1)
+    close(ops.from_nhwc(out, cout), ops.from_nhwc(ref, cout).double(), tol(dtype, 4))
+    if packing.cs_of(cout) != cout:
+        assert float(out[..., cout:].abs().max()) == 0.0
+
+
+def test_conv_transpose_rows_layout_one_hot_is_exact():
+    # each output parity picks exactly one kernel tap per input pixel: a one-hot weight makes the output a (shifted) copy
+    dtype, d = torch.float16, dev()
+    x = rnd((1, 24, 8, 64), 1, dtype)
+    w = torch.zeros(24, 12, 4, 4)
+    for co in range(12):
+        w[(2 * co + 1) % 24, co, co % 4, (co // 4 + 1) % 4] = 1.0
+    want = F.conv_transpose2d(x.float(), w, stride=2, padding=1)
+    s, t = packing.affine(torch.zeros(12), cout_pad=16)
+    out = ops.conv2d(ops.to_nhwc(x).to(d), packing.pack_convT_weight_rows(w.to(dtype), 24, dtype).to(d), s.to(d), t.to(d), 24, 12,
+                     transpose=True, rows_layout=True)
+    assert torch.equal(ops.from_nhwc(out, 12).float().cpu(), want)
+
+
 @pytest.mark.parametrize("dtype", DTYPES)
 def test_instnorm_relu(dtype):
     for C, size in ((24, 32), (96, 16), (48, 8)):
