@@ -156,12 +156,16 @@ int launch_conv(const ConvDesc& d, hipStream_t s) {
     }
     CFEN_CHECK_ARG(maxd < d.Hin && maxd < d.Win, "conv: reflection pad larger than the image");
   }
+  // Wave tile = (Cout_pad / 16) x TM MFMA tiles.  The gather loop is a chain of dependent global loads, so what hides its
+  // latency is the number of waves in flight: shrink TM until the launch has a few thousand waves (tools/profile_launches.py).
+  const long long px = (long long)d.B * d.Hb * d.Wb * d.nphase;
+  const int shrink = px >= (1 << 20) ? 0 : px >= (1 << 18) ? 1 : 2;   // halve TM once / twice for small maps
   switch (d.Cout_pad / 16) {
-    case 1: return launch_conv_t<T, 1, 4>(d, s);
-    case 2: return launch_conv_t<T, 2, 4>(d, s);
-    case 3: return launch_conv_t<T, 3, 4>(d, s);
-    case 4: return launch_conv_t<T, 4, 2>(d, s);
-    case 6: return launch_conv_t<T, 6, 2>(d, s);
+    case 1: return launch_conv_t<T, 1, 2>(d, s);
+    case 2: return shrink >= 2 ? launch_conv_t<T, 2, 1>(d, s) : launch_conv_t<T, 2, 2>(d, s);
+    case 3: return shrink >= 2 ? launch_conv_t<T, 3, 1>(d, s) : shrink == 1 ? launch_conv_t<T, 3, 2>(d, s) : launch_conv_t<T, 3, 4>(d, s);
+    case 4: return shrink >= 1 ? launch_conv_t<T, 4, 1>(d, s) : launch_conv_t<T, 4, 2>(d, s);
+    case 6: return shrink >= 1 ? launch_conv_t<T, 6, 1>(d, s) : launch_conv_t<T, 6, 2>(d, s);
     case 8: return launch_conv_t<T, 8, 1>(d, s);
     default:
       cfen_set_error("conv: Cout_pad=%d unsupported (16,32,48,64,96,128)", d.Cout_pad);
