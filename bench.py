@@ -61,6 +61,16 @@ def pmc_traffic(kernel_class):
         return None
 
 
+def apply_tuning():
+    """CFEN_TUNE="key=value,..." -> cfen_tune (kernel-variant experiments; unset = shipped defaults)"""
+    spec = os.environ.get("CFEN_TUNE", "")
+    if spec:
+        from cfen_vit_dehazing_amd import ops
+        for kv in spec.split(","):
+            k, v = kv.split("=")
+            ops.tune(k.strip(), int(v))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -74,6 +84,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=20.0)
     args = ap.parse_args()
+    apply_tuning()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))

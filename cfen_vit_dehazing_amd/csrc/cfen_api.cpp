@@ -76,8 +76,13 @@ int cfen_nchw_to_nhwc(int dtype, const float* in, void* out, int B, int C, int H
 int cfen_tune(const char* key, int value) {
   CFEN_CHECK_ARG(key != nullptr, "tune: null key");
   if (!strcmp(key, "gemm.kernel")) {
-    CFEN_CHECK_ARG(value >= -1 && value <= 2, "tune: gemm.kernel must be -1 .. 2");
+    CFEN_CHECK_ARG(value >= -1 && value <= 5, "tune: gemm.kernel must be -1 .. 5");
     cfen_tune_gemm_kernel() = value;
+    return CFEN_OK;
+  }
+  if (!strcmp(key, "gemm.large") || !strcmp(key, "gemm.small")) {
+    CFEN_CHECK_ARG(value >= 2 && value <= 5, "tune: %s must be 2 .. 5", key);
+    (key[5] == 'l' ? cfen_tune_gemm_large() : cfen_tune_gemm_small()) = value;
     return CFEN_OK;
   }
   cfen_set_error("tune: unknown key '%s'", key);

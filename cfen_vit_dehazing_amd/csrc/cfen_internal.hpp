@@ -26,3 +26,5 @@ int cfen_instnorm_relu_impl(int dtype, void* x, float* part, int B, int HW, int 
 int cfen_cfsm2g_impl(int dtype, const void* x0, const void* x1, const void* x2, void* out, const float* w, float* part, int B, int HW,
                      int C, int cs, hipStream_t s);
 int& cfen_tune_gemm_kernel();   // -1 auto, 0 tiled, 1 skinny (cfen_tune "gemm.kernel")
+int& cfen_tune_gemm_large();    // k_gemm_dma tile id (2..5) for problems with >= 1024 tiles of 96 x 64 ("gemm.large")
+int& cfen_tune_gemm_small();    // ... and for smaller ones ("gemm.small")

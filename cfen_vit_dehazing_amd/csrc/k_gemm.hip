@@ -25,8 +25,8 @@ template <typename T> struct GemmArgs {
 // Epilogue of the 3 x 4 tile block of one wave: the lane owns Y[m + 16 j][n + 16 i .. +3].  All residual / position
 // loads are issued before the first store (R may alias Y element for element -- in-place residual -- so the compiler
 // must not be left to order them: it would wait for every load separately), bias is read once.
-template <typename T>
-CFEN_DEV void gemm_epilogue(const GemmArgs<T>& a, floatx4 (&acc)[3][4], int n, int m) {
+template <typename T, int TM>
+CFEN_DEV void gemm_epilogue(const GemmArgs<T>& a, floatx4 (&acc)[3][TM], int n, int m) {
   typedef typename Mma<T>::out4 out4;
   floatx4 bias[3];
   bool nok[3];
@@ -35,9 +35,9 @@ CFEN_DEV void gemm_epilogue(const GemmArgs<T>& a, floatx4 (&acc)[3][4], int n, i
     nok[i] = n + 16 * i < a.N;
     bias[i] = (a.bias && nok[i]) ? *reinterpret_cast<const floatx4*>(a.bias + n + 16 * i) : floatx4{0.f, 0.f, 0.f, 0.f};
   }
-  out4 rv[3][4], pv[3][4];
+  out4 rv[3][TM], pv[3][TM];
 #pragma unroll
-  for (int j = 0; j < 4; ++j) {
+  for (int j = 0; j < TM; ++j) {
     const int mj = m + 16 * j;
 #pragma unroll
     for (int i = 0; i < 3; ++i) {
@@ -47,7 +47,7 @@ CFEN_DEV void gemm_epilogue(const GemmArgs<T>& a, floatx4 (&acc)[3][4], int n, i
     }
   }
 #pragma unroll
-  for (int j = 0; j < 4; ++j) {
+  for (int j = 0; j < TM; ++j) {
     const int mj = m + 16 * j;
     if (mj >= a.M) continue;
 #pragma unroll
@@ -166,45 +166,46 @@ CFEN_DEV void dma16(const void* g, unsigned char* l) {
   __builtin_amdgcn_global_load_lds(g, (__attribute__((address_space(3))) void*)l, 16, 0, 0);
 }
 
-template <typename T>
+template <typename T, int TM>   // block tile = 96 features x 32*TM tokens; a wave owns 3 x TM MFMA tiles
 __global__ __launch_bounds__(256) void k_gemm_dma(GemmArgs<T> a) {
   constexpr int EPL = Mma<T>::EPL;
   constexpr int BK = G_BKB / (int)sizeof(T);
   constexpr int NCH = BK / Mma<T>::KC;   // 2
-  constexpr int STAGE = G_ROWS * G_BKB;  // 28 KiB
+  constexpr int BM = 32 * TM, ROWS = G_BN + BM, LOADS = ROWS / 32;
+  constexpr int STAGE = ROWS * G_BKB;    // 28 KiB at TM = 4
   typedef typename Mma<T>::frag frag;
   __shared__ __attribute__((aligned(1024))) unsigned char lds[2 * STAGE];
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int r16 = lane & 15, h = lane >> 4;
-  const int n0 = blockIdx.x * G_BN, m0 = blockIdx.y * G_BM;
+  const int n0 = blockIdx.x * G_BN, m0 = blockIdx.y * BM;
   const int wn = wave & 1, wm = wave >> 1;
 
   // DMA assignment: instruction i of wave w fills rows i*32 + w*8 .. +8; lane -> (row, 16-byte slot)
-  const T* gptr[G_LOADS];
+  const T* gptr[LOADS];
 #pragma unroll
-  for (int i = 0; i < G_LOADS; ++i) {
+  for (int i = 0; i < LOADS; ++i) {
     const int row = i * 32 + wave * 8 + (lane >> 3), slot = lane & 7;
     const int piece = slot ^ (row & 7);
     const T* base = row < G_BN ? a.W + (size_t)min(n0 + row, a.N - 1) * a.ldw : a.X + (size_t)min(m0 + row - G_BN, a.M - 1) * a.ldx;
     gptr[i] = base + piece * EPL;
   }
 #define CFEN_GEMM_DMA_ISSUE(kt_, buf_)                                                                              \
-  _Pragma("unroll") for (int i_ = 0; i_ < G_LOADS; ++i_)                                                              \
+  _Pragma("unroll") for (int i_ = 0; i_ < LOADS; ++i_)                                                              \
       dma16(gptr[i_] + (kt_) * BK, lds + (buf_) * STAGE + (i_ * 256 + wave * 64) * 16)
 
-  floatx4 acc[3][4];
+  floatx4 acc[3][TM];
 #pragma unroll
   for (int i = 0; i < 3; ++i)
 #pragma unroll
-    for (int j = 0; j < 4; ++j) acc[i][j] = floatx4{0.f, 0.f, 0.f, 0.f};
+    for (int j = 0; j < TM; ++j) acc[i][j] = floatx4{0.f, 0.f, 0.f, 0.f};
 
   // fragment read offsets: row r, chunk c, quarter h -> r*128 + (((c*4 + h) ^ (r & 7)) << 4)
-  int aoff[3], boff[4];
+  int aoff[3], boff[TM];
 #pragma unroll
   for (int i = 0; i < 3; ++i) aoff[i] = (wn * 48 + i * 16 + r16) * G_BKB;
 #pragma unroll
-  for (int j = 0; j < 4; ++j) boff[j] = (G_BN + wm * 64 + j * 16 + r16) * G_BKB;
+  for (int j = 0; j < TM; ++j) boff[j] = (G_BN + wm * 16 * TM + j * 16 + r16) * G_BKB;
   const int sw = r16 & 7;   // every fragment row of this lane has (row & 7) == (r16 & 7): all tile offsets are multiples of 16
 
   const int nk = a.K / BK;
@@ -213,7 +214,11 @@ __global__ __launch_bounds__(256) void k_gemm_dma(GemmArgs<T> a) {
     const int buf = kt & 1;
     if (kt + 1 < nk) {
       CFEN_GEMM_DMA_ISSUE(kt + 1, buf ^ 1);
-      asm volatile("s_waitcnt vmcnt(7)" ::: "memory");   // stage kt landed, stage kt+1 (7 DMAs) may stay in flight
+      // stage kt landed; the LOADS DMAs of stage kt+1 may stay in flight
+      if (LOADS == 7) asm volatile("s_waitcnt vmcnt(7)" ::: "memory");
+      else if (LOADS == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+      else if (LOADS == 5) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
     } else {
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
@@ -222,21 +227,21 @@ __global__ __launch_bounds__(256) void k_gemm_dma(GemmArgs<T> a) {
 #pragma unroll
     for (int c = 0; c < NCH; ++c) {
       const int po = ((c * 4 + h) ^ sw) << 4;
-      frag af[3], bf[4];
+      frag af[3], bf[TM];
 #pragma unroll
       for (int i = 0; i < 3; ++i) af[i] = *reinterpret_cast<const frag*>(st + aoff[i] + po);
 #pragma unroll
-      for (int j = 0; j < 4; ++j) bf[j] = *reinterpret_cast<const frag*>(st + boff[j] + po);
+      for (int j = 0; j < TM; ++j) bf[j] = *reinterpret_cast<const frag*>(st + boff[j] + po);
 #pragma unroll
       for (int i = 0; i < 3; ++i)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = Mma<T>::mma(af[i], bf[j], acc[i][j]);
+        for (int j = 0; j < TM; ++j) acc[i][j] = Mma<T>::mma(af[i], bf[j], acc[i][j]);
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();   // every wave is done reading `buf` before the next iteration's DMA refills it
   }
 
-  gemm_epilogue<T>(a, acc, n0 + wn * 48 + 4 * h, m0 + wm * 64 + r16);
+  gemm_epilogue<T, TM>(a, acc, n0 + wn * 48 + 4 * h, m0 + wm * 16 * TM + r16);
 #undef CFEN_GEMM_DMA_ISSUE
 }
 
@@ -305,28 +310,39 @@ int launch_gemm(const void* X, int ldx, const void* W, int ldw, const float* bia
   GemmArgs<T> a{(const T*)X, (const T*)W, bias, (const T*)R, (const T*)P, (T*)Y, M, N, K, ldx, ldw, ldr, ldy, period, relu};
   const int forced = cfen_tune_gemm_kernel();
   const bool k128 = (K * (int)sizeof(T)) % G_BKB == 0;
-  CFEN_CHECK_ARG((forced != 1 && forced != 2) || k128, "gemm: k_gemm_skinny / k_gemm_dma need K * sizeof(T) %% 128 == 0");
-  // the tiled kernels need enough 128 x 96 tiles to occupy the chip; below that (GViT: <= 2048 tokens against square or
-  // K-heavy weights) the skinny kernel's 16 x 64 tiles with in-workgroup split-K win (tools/bench_gemm.py)
-  const long long tiles = (long long)((N + G_BN - 1) / G_BN) * ((M + G_BM - 1) / G_BM);
-  const bool want_skinny = k128 && (tiles <= 32 || (tiles <= 64 && K * (int)sizeof(T) <= 1024));
-  if (forced == 1 || (forced < 0 && want_skinny)) {
-    CFEN_LAUNCH(k_gemm_skinny<T>, dim3((N + 15) / 16, (M + 63) / 64), dim3(256), 0, s, a);
-    CFEN_CHECK_LAUNCH("gemm");
-    return CFEN_OK;
+  CFEN_CHECK_ARG(forced <= 0 || k128, "gemm: k_gemm_skinny / k_gemm_dma need K * sizeof(T) %% 128 == 0");
+  // Kernel choice from measured kernel times on MI355X (tools/bench_gemm.py under rocprofv3 --kernel-trace, batch 8):
+  //   K not a multiple of 128 bytes (LViT level 1, K = 96)      -> register-staged k_gemm_nt (zero-fills the K tail)
+  //   <= 128 tokens against <= 2048 features (GViT-3 square/K-heavy) -> k_gemm_skinny (in-workgroup split-K)
+  //   otherwise k_gemm_dma with the SMALLEST token tile that still leaves >= 1024 tiles: 96 x 64 (4 workgroups per CU)
+  //   for the LViT-sized problems, 96 x 32 (5 per CU) for GViT -- occupancy hides the DMA latency better than reuse.
+  const long long tiles64 = (long long)((N + G_BN - 1) / G_BN) * ((M + 63) / 64);
+  int kern = forced;
+  if (kern < 0) kern = !k128 ? 0 : (M <= 128 && N <= 2048) ? 1 : tiles64 >= 1024 ? cfen_tune_gemm_large() : cfen_tune_gemm_small();
+  const unsigned gx = (unsigned)((N + G_BN - 1) / G_BN);
+  CFEN_CHECK_ARG((M + 31) / 32 <= 65535, "gemm: M too large for one launch");
+  switch (kern) {
+    case 0: CFEN_LAUNCH(k_gemm_nt<T>, dim3(gx, (M + G_BM - 1) / G_BM), dim3(256), 0, s, a); break;
+    case 1: CFEN_LAUNCH(k_gemm_skinny<T>, dim3((N + 15) / 16, (M + 63) / 64), dim3(256), 0, s, a); break;
+    case 2: CFEN_LAUNCH((k_gemm_dma<T, 4>), dim3(gx, (M + 127) / 128), dim3(256), 0, s, a); break;
+    case 3: CFEN_LAUNCH((k_gemm_dma<T, 3>), dim3(gx, (M + 95) / 96), dim3(256), 0, s, a); break;
+    case 4: CFEN_LAUNCH((k_gemm_dma<T, 2>), dim3(gx, (M + 63) / 64), dim3(256), 0, s, a); break;
+    default: CFEN_LAUNCH((k_gemm_dma<T, 1>), dim3(gx, (M + 31) / 32), dim3(256), 0, s, a); break;
   }
-  dim3 grid((N + G_BN - 1) / G_BN, (M + G_BM - 1) / G_BM);
-  CFEN_CHECK_ARG(grid.y <= 65535, "gemm: M too large for one launch");
-  if (forced == 2 || (forced < 0 && k128))
-    CFEN_LAUNCH(k_gemm_dma<T>, grid, dim3(256), 0, s, a);
-  else
-    CFEN_LAUNCH(k_gemm_nt<T>, grid, dim3(256), 0, s, a);
   CFEN_CHECK_LAUNCH("gemm");
   return CFEN_OK;
 }
 
 }  // namespace
 
+int& cfen_tune_gemm_large() {
+  static int v = 4;
+  return v;
+}
+int& cfen_tune_gemm_small() {
+  static int v = 5;
+  return v;
+}
 int& cfen_tune_gemm_kernel() {
   static int v = -1;
   return v;

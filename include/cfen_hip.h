@@ -35,8 +35,9 @@ extern "C" {
 int cfen_abi_version(void);
 const char* cfen_last_error(void);
 /* Process-wide tuning knobs for benchmarking kernel variants (tools/bench_gemm.py); the defaults are what ships.
- *   "gemm.kernel": -1 choose by shape (default), 0 register-staged k_gemm_nt, 1 k_gemm_skinny, 2 LDS-DMA k_gemm_dma
- *                  (1 and 2 need K * element size to be a multiple of 128 bytes) */
+ *   "gemm.kernel": -1 choose by shape (default), 0 register-staged k_gemm_nt, 1 k_gemm_skinny, 2..5 LDS-DMA k_gemm_dma with a
+ *                  96 x 128 / 96 / 64 / 32 (features x tokens) tile (1..5 need K * element size to be a multiple of 128 bytes)
+ *   "gemm.large" / "gemm.small": the k_gemm_dma tile (2..5) the shape rule uses for problems with >= / < 1024 tiles of 96 x 64 */
 int cfen_tune(const char* key, int value);
 
 /* ---- whole generator: replaces define_G (v3:93-100) + dec_ipt.forward (v3:392-1020) ------------- */

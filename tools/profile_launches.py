@@ -8,6 +8,9 @@ from cfen_vit_dehazing_amd.config import NetConfig
 from cfen_vit_dehazing_amd.hipnet import dec_ipt
 from cfen_vit_dehazing_amd.manifest import generate_state_dict, synthetic_input
 
+from cfen_vit_dehazing_amd import ops
+for kv in filter(None, os.environ.get("CFEN_TUNE", "").split(",")):
+    ops.tune(kv.split("=")[0], int(kv.split("=")[1]))
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 8
 dt = sys.argv[2] if len(sys.argv) > 2 else "fp16"
 cfg = NetConfig(24, 4, patch_size=32, load_size=256)
