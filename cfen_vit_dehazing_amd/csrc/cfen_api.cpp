@@ -76,12 +76,12 @@ int cfen_nchw_to_nhwc(int dtype, const float* in, void* out, int B, int C, int H
 int cfen_tune(const char* key, int value) {
   CFEN_CHECK_ARG(key != nullptr, "tune: null key");
   if (!strcmp(key, "gemm.kernel")) {
-    CFEN_CHECK_ARG(value >= -1 && value <= 5, "tune: gemm.kernel must be -1 .. 5");
+    CFEN_CHECK_ARG(value >= -1 && value <= 25, "tune: gemm.kernel must be -1 .. 25");
     cfen_tune_gemm_kernel() = value;
     return CFEN_OK;
   }
   if (!strcmp(key, "gemm.large") || !strcmp(key, "gemm.small")) {
-    CFEN_CHECK_ARG(value >= 2 && value <= 5, "tune: %s must be 2 .. 5", key);
+    CFEN_CHECK_ARG(value % 10 >= 2 && value % 10 <= 5 && value >= 2 && value <= 25, "tune: %s must be tile 2 .. 5 (+10 / +20 for 3 / 4 LDS stages)", key);
     (key[5] == 'l' ? cfen_tune_gemm_large() : cfen_tune_gemm_small()) = value;
     return CFEN_OK;
   }

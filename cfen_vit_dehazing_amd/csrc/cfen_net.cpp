@@ -54,8 +54,8 @@ struct cfen_net {
   size_t ws_bytes = 0;
   // Token scratch, one set per concurrently running transformer block (LViT / GViT of branch A / B)
   struct Scratch { size_t x0, x1, yn, qkv, att, hid, small; };
-  Scratch scr_set[4];
-  size_t o_stats_set[2] = {0, 0};
+  Scratch scr_set[6];
+  size_t o_stats_set[3] = {0, 0, 0};
   int scr = 0, st = 0;             // scratch / stats set of the lane being enqueued
   unsigned char* base = nullptr;   // workspace of the current / last forward
   hipStream_t stream = nullptr;    // stream of the lane being enqueued
@@ -156,7 +156,7 @@ struct cfen_net {
                const std::string& out, float* nchw_out);
   int run_vit(const Vit& v, const std::string& in, const std::string& out);
   int run_level(const char* tag, int l, const std::string& in, const char* extra_res, const std::string& out, const Lane& lm, const Lane& ls);
-  int run_branch(int b, const Lane& lm, const Lane& ls, float* out);
+  int run_branch(int b, int stage, const Lane& lm, const Lane& ls, float* out);
   int forward(const float* x, float* xr, float* xs, float* xd);
 };
 
@@ -291,7 +291,7 @@ int cfen_net::build() {
     }
     add_map(std::string("tail_") + (char)(br[b] - 32) + ".mid", h, 2 * N);
   }
-  for (int k = 0; k < 4; ++k) {
+  for (int k = 0; k < 6; ++k) {
     const bool g = k & 1;             // odd sets serve GViT lanes: far fewer tokens
     const size_t md = g ? max_md_g : max_md_l, mh = g ? max_mh_g : max_mh_l;
     Scratch& q = scr_set[k];
@@ -300,7 +300,7 @@ int cfen_net::build() {
     q.hid = alloc(mh * esz);
     q.small = alloc(g ? max_small * esz : 256);
   }
-  for (int k = 0; k < 2; ++k) o_stats_set[k] = alloc(cfen_stats_workspace_bytes(B, 128));
+  for (int k = 0; k < 3; ++k) o_stats_set[k] = alloc(cfen_stats_workspace_bytes(B, 128));
   parallel = (cfg.reserved & 1) == 0;
   return CFEN_OK;
 }
@@ -434,52 +434,49 @@ int cfen_net::run_level(const char* tag, int l, const std::string& in, const cha
   return run_conv(out, ln, gn.c_str(), in.c_str(), extra_res, 1, out, nullptr);
 }
 
-// One decoder (R, S or D): v3:546-697 / 706-853 / 862-1009.
-int cfen_net::run_branch(int b, const Lane& lm, const Lane& ls, float* outp) {
+// One decoder (R, S or D): v3:546-697 / 706-853 / 862-1009, cut at the two points where D consumes R's and S's upsampled
+// maps (CFSM2G, v3:885,920) so that the three decoders can be pipelined one level apart:
+//   stage 3: level-3 block -> ConvT -> InstanceNorm -> ReLU            (produces us_conv_d03*)
+//   stage 2: skip fuse (sk_conv / CFSM2G) -> level-2 block -> ConvT    (produces us_conv_d02*)
+//   stage 1: skip fuse -> level-1 block -> ConvT -> tail
+int cfen_net::run_branch(int b, int stage, const Lane& lm, const Lane& ls, float* outp) {
   const int dt = cfg.dtype, B = cfg.batch;
   static const char* br = "rsd";
   const std::string t(1, br[b]);
   const std::string T(1, (char)(br[b] - 32));
   use(lm);
   float* stats = (float*)at(o_stats_set[lm.st]);
-  TRY(run_level(t.c_str(), 3, "lgcat_conv_e03", nullptr, "lgcat_conv_d03" + t, lm, ls));
-  {  // ConvT -> InstanceNorm -> ReLU (v3:301-302)
-    const std::string u = "us_conv_d03" + t;
+  if (stage == 3) {
+    TRY(run_level(t.c_str(), 3, "lgcat_conv_e03", nullptr, "lgcat_conv_d03" + t, lm, ls));
+    const std::string u = "us_conv_d03" + t;   // ConvT -> InstanceNorm -> ReLU (v3:301-302)
     TRY(run_conv(u, "lgcat_conv_d03" + t, nullptr, nullptr, nullptr, 0, u, nullptr));
     const Buf& bu = bufs.at(u);
     label = u + ":instnorm";
     TRYP(K_NORM, 0, cfen_instnorm_relu_impl(dt, map_ptr(u), stats, B, bu.H * bu.W, bu.C, bu.cs, 1e-5f, stream));
+    return CFEN_OK;
   }
-  std::string in2, in1;
-  if (b == 2) {   // D's skip inputs are R's and S's upsampled maps (v3:885,920)
-    in2 = "cfsm2g_d03d";
-    const Buf& bu = bufs.at(in2);
-    label = in2;
-    TRYP(K_NORM, 0, cfen_cfsm2g_impl(dt, map_ptr("us_conv_d03d"), map_ptr("us_conv_d03r"), map_ptr("us_conv_d03s"), map_ptr(in2),
-                                     Pf("cfsm2g_d03d.w"), stats, B, bu.H * bu.W, bu.C, bu.cs, stream));
+  const std::string L = std::to_string(stage), Lup = std::to_string(stage + 1);
+  std::string in;
+  if (b == 2) {   // D's skip inputs are R's and S's upsampled maps
+    in = "cfsm2g_d0" + Lup + "d";
+    const Buf& bu = bufs.at(in);
+    label = in;
+    TRYP(K_NORM, 0, cfen_cfsm2g_impl(dt, map_ptr("us_conv_d0" + Lup + "d"), map_ptr("us_conv_d0" + Lup + "r"), map_ptr("us_conv_d0" + Lup + "s"),
+                                     map_ptr(in), Pf(in + ".w"), stats, B, bu.H * bu.W, bu.C, bu.cs, stream));
   } else {
-    in2 = "sk_conv_d03" + t;
-    TRY(run_conv(in2, "us_conv_d03" + t, "lgcat_conv_e02", nullptr, nullptr, 1, in2, nullptr));
+    in = "sk_conv_d0" + Lup + t;
+    TRY(run_conv(in, "us_conv_d0" + Lup + t, stage == 2 ? "lgcat_conv_e02" : "lgcat_conv_e01", nullptr, nullptr, 1, in, nullptr));
   }
-  TRY(run_level(t.c_str(), 2, in2, nullptr, "lgcat_conv_d02" + t, lm, ls));
-  TRY(run_conv("us_conv_d02" + t, "lgcat_conv_d02" + t, nullptr, nullptr, nullptr, 1, "us_conv_d02" + t, nullptr));
-  if (b == 2) {
-    in1 = "cfsm2g_d02d";
-    const Buf& bu = bufs.at(in1);
-    label = in1;
-    TRYP(K_NORM, 0, cfen_cfsm2g_impl(dt, map_ptr("us_conv_d02d"), map_ptr("us_conv_d02r"), map_ptr("us_conv_d02s"), map_ptr(in1),
-                                     Pf("cfsm2g_d02d.w"), stats, B, bu.H * bu.W, bu.C, bu.cs, stream));
-  } else {
-    in1 = "sk_conv_d02" + t;
-    TRY(run_conv(in1, "us_conv_d02" + t, "lgcat_conv_e01", nullptr, nullptr, 1, in1, nullptr));
+  if (stage == 2) {
+    TRY(run_level(t.c_str(), 2, in, nullptr, "lgcat_conv_d02" + t, lm, ls));
+    return run_conv("us_conv_d02" + t, "lgcat_conv_d02" + t, nullptr, nullptr, nullptr, 1, "us_conv_d02" + t, nullptr);
   }
   // `xr = us_conv_d01r(r_d_01 + xf)` (v3:696,852,1008): the extra `+ xf` rides along as a second
   // residual of the fuse conv, so stage lgcat_conv_d01* holds (reference stage + xf).
-  TRY(run_level(t.c_str(), 1, in1, "ds_conv_e01", "lgcat_conv_d01" + t, lm, ls));
+  TRY(run_level(t.c_str(), 1, in, "ds_conv_e01", "lgcat_conv_d01" + t, lm, ls));
   TRY(run_conv("us_conv_d01" + t, "lgcat_conv_d01" + t, nullptr, nullptr, nullptr, 1, "us_conv_d01" + t, nullptr));
   TRY(run_conv("tail_" + T + ".conv3", "us_conv_d01" + t, nullptr, nullptr, nullptr, 1, "tail_" + T + ".mid", nullptr));
-  TRY(run_conv("tail_" + T + ".conv7", "tail_" + T + ".mid", nullptr, nullptr, nullptr, 2, "", outp));
-  return CFEN_OK;
+  return run_conv("tail_" + T + ".conv7", "tail_" + T + ".mid", nullptr, nullptr, nullptr, 2, "", outp);
 }
 
 int cfen_net::forward(const float* x, float* xr, float* xs, float* xd) {
@@ -495,8 +492,9 @@ int cfen_net::forward(const float* x, float* xr, float* xs, float* xd) {
   }
   ev_next = 0;
   side_next = 0;
-  // lanes: main / its GViT companion, and the same pair for the S decoder; companion streams are drawn fresh per fork
-  const Lane A{s0, 0, 0}, Ag{par ? side[NSIDE - 1] : s0, 1, 0}, Bm{par ? fresh_side() : s0, 2, 1}, Bg{par ? side[NSIDE - 1] : s0, 3, 1};
+  // lanes: a main lane and its GViT companion per decoder; companion streams are drawn fresh per fork
+  const Lane A{s0, 0, 0}, Ag{par ? side[NSIDE - 1] : s0, 1, 0}, Bm{par ? fresh_side() : s0, 2, 1}, Bg{par ? side[NSIDE - 1] : s0, 3, 1},
+      Dm{par ? fresh_side() : s0, 4, 2}, Dg{par ? side[NSIDE - 1] : s0, 5, 2};
   use(A);
   float* stats = (float*)at(o_stats_set[0]);
   const Buf& bin = bufs.at("input");
@@ -520,12 +518,21 @@ int cfen_net::forward(const float* x, float* xr, float* xs, float* xd) {
   TRY(down("ds_conv_e03", "lgcat_conv_e02"));
   TRY(run_level("e", 3, "ds_conv_e03", nullptr, "lgcat_conv_e03", A, Ag));
 
-  // R on lanes (A, Ag), S beside it on (Bm, Bg); D needs both (CFSM2G) and follows on (A, Ag).
+  // The three decoders run side by side on their own lanes, D one CFSM2G hand-off behind R and S.
+  const Lane* lm[3] = {&A, &Bm, &Dm};
+  const Lane* lg[3] = {&Ag, &Bg, &Dg};
+  float* outs[3] = {xr, xs, xd};
   TRY(order(s0, Bm.s));
-  TRY(run_branch(0, A, Ag, xr));
-  TRY(run_branch(1, Bm, Bg, xs));
+  TRY(order(s0, Dm.s));
+  for (int stage = 3; stage >= 1; --stage) {
+    for (int b = 0; b < 3; ++b) TRY(run_branch(b, stage, *lm[b], *lg[b], outs[b]));
+    if (stage > 1) {   // D's next CFSM2G reads us_conv_d0{stage}{r,s}
+      TRY(order(A.s, Dm.s));
+      TRY(order(Bm.s, Dm.s));
+    }
+  }
   TRY(order(Bm.s, s0));
-  TRY(run_branch(2, A, Ag, xd));
+  TRY(order(Dm.s, s0));
   use(A);
   return CFEN_OK;
 }

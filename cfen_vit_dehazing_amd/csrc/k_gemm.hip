@@ -17,9 +17,40 @@
 
 namespace {
 
+// XCD-aware block -> tile map.  Blocks are dealt round-robin to the 8 XCDs (own L2 each); XCD x = block & 7 works on one
+// cell of a pn x pm partition of the tile grid (pn * pm == 8), so a weight tile is fetched from HBM by pm XCDs and a token
+// tile by pn XCDs instead of by all 8.  The host picks the partition that minimises  W bytes * pm + X bytes * pn.
+struct TileMap {
+  int gn, gm;   // tile grid (feature tiles x token tiles)
+  int pn, pm;   // XCD partition
+  int cn, cm;   // cell size in tiles: ceil(gn / pn) x ceil(gm / pm); the launch has 8 * cn * cm blocks
+};
+CFEN_DEV bool tile_of_block(const TileMap& t, unsigned bid, int& tn, int& tm) {
+  const int x = (int)(bid & 7u), l = (int)(bid >> 3);
+  const int ln = l % t.cn, lm = l / t.cn;   // feature tile fastest: neighbours in time share the token tile
+  tn = (x % t.pn) * t.cn + ln;
+  tm = (x / t.pn) * t.cm + lm;
+  return tn < t.gn && tm < t.gm;
+}
+static TileMap make_tile_map(int gn, int gm, double w_bytes, double x_bytes) {
+  TileMap best{gn, gm, 1, 8, gn, (gm + 7) / 8};
+  double best_cost = -1.0;
+  for (int pn = 1; pn <= 8; pn *= 2) {
+    const int pm = 8 / pn, cn = (gn + pn - 1) / pn, cm = (gm + pm - 1) / pm;
+    const double waste = 8.0 * cn * cm / ((double)gn * gm);
+    const double cost = (w_bytes * pm + x_bytes * pn) * waste * waste;   // padded cells are idle XCD slots: penalise twice
+    if (best_cost < 0 || cost < best_cost) {
+      best_cost = cost;
+      best = TileMap{gn, gm, pn, pm, cn, cm};
+    }
+  }
+  return best;
+}
+
 template <typename T> struct GemmArgs {
   const T* X; const T* W; const float* bias; const T* R; const T* P; T* Y;
   int M, N, K, ldx, ldw, ldr, ldy, period, relu;
+  TileMap map;
 };
 
 // Epilogue of the 3 x 4 tile block of one wave: the lane owns Y[m + 16 j][n + 16 i .. +3].  All residual / position
@@ -87,7 +118,9 @@ __global__ __launch_bounds__(256) void k_gemm_nt(GemmArgs<T> a) {
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int r16 = lane & 15, h = lane >> 4;
-  const int n0 = blockIdx.x * G_BN, m0 = blockIdx.y * G_BM;
+  int tn, tm;
+  if (!tile_of_block(a.map, blockIdx.x, tn, tm)) return;
+  const int n0 = tn * G_BN, m0 = tm * G_BM;
   const int wn = wave & 1, wm = wave >> 1;
 
   // per-thread staging assignment
@@ -166,7 +199,8 @@ CFEN_DEV void dma16(const void* g, unsigned char* l) {
   __builtin_amdgcn_global_load_lds(g, (__attribute__((address_space(3))) void*)l, 16, 0, 0);
 }
 
-template <typename T, int TM>   // block tile = 96 features x 32*TM tokens; a wave owns 3 x TM MFMA tiles
+// NS LDS stages form a ring: NS - 1 K-steps of DMA are in flight while one is consumed, one barrier per K-step.
+template <typename T, int TM, int NS>   // block tile = 96 features x 32*TM tokens; a wave owns 3 x TM MFMA tiles
 __global__ __launch_bounds__(256) void k_gemm_dma(GemmArgs<T> a) {
   constexpr int EPL = Mma<T>::EPL;
   constexpr int BK = G_BKB / (int)sizeof(T);
@@ -174,11 +208,14 @@ __global__ __launch_bounds__(256) void k_gemm_dma(GemmArgs<T> a) {
   constexpr int BM = 32 * TM, ROWS = G_BN + BM, LOADS = ROWS / 32;
   constexpr int STAGE = ROWS * G_BKB;    // 28 KiB at TM = 4
   typedef typename Mma<T>::frag frag;
-  __shared__ __attribute__((aligned(1024))) unsigned char lds[2 * STAGE];
+  static_assert(NS * STAGE <= 65536, "static LDS");
+  __shared__ __attribute__((aligned(1024))) unsigned char lds[NS * STAGE];
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int r16 = lane & 15, h = lane >> 4;
-  const int n0 = blockIdx.x * G_BN, m0 = blockIdx.y * BM;
+  int tn, tm;
+  if (!tile_of_block(a.map, blockIdx.x, tn, tm)) return;
+  const int n0 = tn * G_BN, m0 = tm * BM;
   const int wn = wave & 1, wm = wave >> 1;
 
   // DMA assignment: instruction i of wave w fills rows i*32 + w*8 .. +8; lane -> (row, 16-byte slot)
@@ -209,20 +246,18 @@ __global__ __launch_bounds__(256) void k_gemm_dma(GemmArgs<T> a) {
   const int sw = r16 & 7;   // every fragment row of this lane has (row & 7) == (r16 & 7): all tile offsets are multiples of 16
 
   const int nk = a.K / BK;
-  CFEN_GEMM_DMA_ISSUE(0, 0);
+#pragma unroll
+  for (int st = 0; st < NS - 1; ++st)
+    if (st < nk) CFEN_GEMM_DMA_ISSUE(st, st);
+  int buf = 0, fill = NS - 1;   // ring slots: `buf` is consumed at this step, `fill` receives K-step kt + NS - 1
   for (int kt = 0; kt < nk; ++kt) {
-    const int buf = kt & 1;
-    if (kt + 1 < nk) {
-      CFEN_GEMM_DMA_ISSUE(kt + 1, buf ^ 1);
-      // stage kt landed; the LOADS DMAs of stage kt+1 may stay in flight
-      if (LOADS == 7) asm volatile("s_waitcnt vmcnt(7)" ::: "memory");
-      else if (LOADS == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-      else if (LOADS == 5) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
-      else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-    } else {
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    }
-    __builtin_amdgcn_s_barrier();
+    // K-step kt must have landed; the younger K-steps (at most NS - 2 groups of LOADS DMAs) may stay in flight
+    const int younger = min(NS - 2, nk - 1 - kt);
+    if (younger >= 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * LOADS) : "memory");
+    else if (younger == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LOADS) : "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();   // K-step kt visible to all waves; all waves are done with the slot consumed at kt - 1
+    if (kt + NS - 1 < nk) CFEN_GEMM_DMA_ISSUE(kt + NS - 1, fill);
     const unsigned char* st = lds + buf * STAGE;
 #pragma unroll
     for (int c = 0; c < NCH; ++c) {
@@ -237,8 +272,9 @@ __global__ __launch_bounds__(256) void k_gemm_dma(GemmArgs<T> a) {
 #pragma unroll
         for (int j = 0; j < TM; ++j) acc[i][j] = Mma<T>::mma(af[i], bf[j], acc[i][j]);
     }
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();   // every wave is done reading `buf` before the next iteration's DMA refills it
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // this wave's reads of `buf` are complete before it reaches the next barrier
+    fill = buf;
+    buf = buf + 1 == NS ? 0 : buf + 1;
   }
 
   gemm_epilogue<T, TM>(a, acc, n0 + wn * 48 + 4 * h, m0 + wm * 16 * TM + r16);
@@ -256,7 +292,9 @@ __global__ __launch_bounds__(256) void k_gemm_skinny(GemmArgs<T> a) {
   typedef typename Mma<T>::frag frag;
   __shared__ floatx4 red[4][4][64];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r16 = lane & 15, h = lane >> 4;
-  const int n0 = blockIdx.x * 16, m0 = blockIdx.y * 64;
+  int tn, tm;
+  if (!tile_of_block(a.map, blockIdx.x, tn, tm)) return;
+  const int n0 = tn * 16, m0 = tm * 64;
   const T* wp = a.W + (size_t)min(n0 + r16, a.N - 1) * a.ldw + h * 2 * EPL;
   const T* xp[4];
 #pragma unroll
@@ -317,17 +355,29 @@ int launch_gemm(const void* X, int ldx, const void* W, int ldw, const float* bia
   //   otherwise k_gemm_dma with the SMALLEST token tile that still leaves >= 1024 tiles: 96 x 64 (4 workgroups per CU)
   //   for the LViT-sized problems, 96 x 32 (5 per CU) for GViT -- occupancy hides the DMA latency better than reuse.
   const long long tiles64 = (long long)((N + G_BN - 1) / G_BN) * ((M + 63) / 64);
-  int kern = forced;
-  if (kern < 0) kern = !k128 ? 0 : (M <= 128 && N <= 2048) ? 1 : tiles64 >= 1024 ? cfen_tune_gemm_large() : cfen_tune_gemm_small();
-  const unsigned gx = (unsigned)((N + G_BN - 1) / G_BN);
-  CFEN_CHECK_ARG((M + 31) / 32 <= 65535, "gemm: M too large for one launch");
-  switch (kern) {
-    case 0: CFEN_LAUNCH(k_gemm_nt<T>, dim3(gx, (M + G_BM - 1) / G_BM), dim3(256), 0, s, a); break;
-    case 1: CFEN_LAUNCH(k_gemm_skinny<T>, dim3((N + 15) / 16, (M + 63) / 64), dim3(256), 0, s, a); break;
-    case 2: CFEN_LAUNCH((k_gemm_dma<T, 4>), dim3(gx, (M + 127) / 128), dim3(256), 0, s, a); break;
-    case 3: CFEN_LAUNCH((k_gemm_dma<T, 3>), dim3(gx, (M + 95) / 96), dim3(256), 0, s, a); break;
-    case 4: CFEN_LAUNCH((k_gemm_dma<T, 2>), dim3(gx, (M + 63) / 64), dim3(256), 0, s, a); break;
-    default: CFEN_LAUNCH((k_gemm_dma<T, 1>), dim3(gx, (M + 31) / 32), dim3(256), 0, s, a); break;
+  int kern = forced < 0 ? -1 : forced % 10, stages = forced < 0 ? 2 : 2 + forced / 10;
+  if (kern < 0) {
+    const int pick = tiles64 >= 1024 ? cfen_tune_gemm_large() : cfen_tune_gemm_small();
+    stages = 2 + pick / 10;
+  }
+  if (kern < 0) kern = !k128 ? 0 : (M <= 128 && N <= 2048) ? 1 : (tiles64 >= 1024 ? cfen_tune_gemm_large() : cfen_tune_gemm_small()) % 10;
+  if (kern < 2) stages = 2;
+  const int bn = kern == 1 ? 16 : G_BN, bm = kern == 0 || kern == 2 ? 128 : kern == 3 ? 96 : kern == 4 || kern == 1 ? 64 : 32;
+  a.map = make_tile_map((N + bn - 1) / bn, (M + bm - 1) / bm, (double)N * K * sizeof(T), (double)M * K * sizeof(T));
+  const long long blocks = 8LL * a.map.cn * a.map.cm;
+  CFEN_CHECK_ARG(blocks < (1LL << 31), "gemm: problem too large for one launch");
+  const dim3 grid((unsigned)blocks);
+  switch (kern + 10 * (stages - 2)) {
+    case 0: case 10: case 20: CFEN_LAUNCH(k_gemm_nt<T>, grid, dim3(256), 0, s, a); break;
+    case 1: case 11: case 21: CFEN_LAUNCH(k_gemm_skinny<T>, grid, dim3(256), 0, s, a); break;
+    case 2: case 12: case 22: CFEN_LAUNCH((k_gemm_dma<T, 4, 2>), grid, dim3(256), 0, s, a); break;
+    case 3: CFEN_LAUNCH((k_gemm_dma<T, 3, 2>), grid, dim3(256), 0, s, a); break;
+    case 13: case 23: CFEN_LAUNCH((k_gemm_dma<T, 3, 2>), grid, dim3(256), 0, s, a); break;
+    case 4: CFEN_LAUNCH((k_gemm_dma<T, 2, 2>), grid, dim3(256), 0, s, a); break;
+    case 14: case 24: CFEN_LAUNCH((k_gemm_dma<T, 2, 3>), grid, dim3(256), 0, s, a); break;
+    case 5: CFEN_LAUNCH((k_gemm_dma<T, 1, 2>), grid, dim3(256), 0, s, a); break;
+    case 15: CFEN_LAUNCH((k_gemm_dma<T, 1, 3>), grid, dim3(256), 0, s, a); break;
+    default: CFEN_LAUNCH((k_gemm_dma<T, 1, 4>), grid, dim3(256), 0, s, a); break;
   }
   CFEN_CHECK_LAUNCH("gemm");
   return CFEN_OK;

@@ -24,12 +24,14 @@ for lvl, (T, D, G_T, G_D) in enumerate(((16384, 96, 256, 384), (4096, 192, 64, 7
         shapes += [("%s%d embed/proj" % (kind, lvl), M, dd, dd), ("%s%d qkv" % (kind, lvl), M, 3 * dd, dd)]
         if kind == "G" or dd == 384:
             shapes += [("%s%d ffn1" % (kind, lvl), M, 4 * dd, dd), ("%s%d ffn2" % (kind, lvl), M, dd, 4 * dd)]
-print("%-16s %7s %6s %6s | %9s %9s %9s %9s %9s %9s | best" % ("shape", "M", "N", "K", "tiled us", "skinny us", "dma128", "dma96", "dma64", "dma32"))
+VARIANTS = (0, 1, 4, 14, 5, 15, 25)
+NAMES = ("tiled", "skinny", "dma64", "dma64x3", "dma32", "dma32x3", "dma32x4")
+print("%-16s %7s %6s %6s | " % ("shape", "M", "N", "K") + " ".join("%9s" % n for n in NAMES) + " | best")
 for name, M, N, K in shapes:
     x = torch.randn(M, K, device=d).half(); w = (torch.randn(N, K, device=d) * 0.05).half(); b = torch.zeros(N, device=d)
     r = None; out = torch.empty(M, N, device=d).half()
     res = []
-    for v in (0, 1, 2, 3, 4, 5):
+    for v in VARIANTS:
         ops.tune("gemm.kernel", v)
         try:
             res.append(timeit(lambda: ops.gemm_nt(x, w, bias=b, residual=r, out=out)))
@@ -38,4 +40,4 @@ for name, M, N, K in shapes:
     ops.tune("gemm.kernel", -1)
     auto = timeit(lambda: ops.gemm_nt(x, w, bias=b, residual=r, out=out))
     fl = 2.0 * M * N * K
-    print("%-16s %7d %6d %6d | %9.1f %9.1f %9.1f %9.1f %9.1f %9.1f | %s %.0f TF (auto %.1f us)" % (name, M, N, K, res[0], res[1], res[2], res[3], res[4], res[5], ("tiled", "skinny", "dma128", "dma96", "dma64", "dma32")[res.index(min(res))], fl / min(res) / 1e6, auto))
+    print("%-16s %7d %6d %6d | " % (name, M, N, K) + " ".join("%9.1f" % r for r in res) + " | %s %.0f TF (auto %.1f us)" % (NAMES[res.index(min(res))], fl / min(res) / 1e6, auto))
