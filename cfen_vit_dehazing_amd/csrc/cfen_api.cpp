@@ -73,6 +73,14 @@ int cfen_nchw_to_nhwc(int dtype, const float* in, void* out, int B, int C, int H
   return cfen_nchw_to_nhwc_impl(dtype, in, out, B, C, H, W, cs, (hipStream_t)stream);
 }
 
+int cfen_embed_gather(int dtype, const void* fmap, int B, int H, int W, int C, int cs, int ws, int p, const void* weight, int ldw,
+                      const float* bias, const void* pos, int period, void* Y, int ldy, void* stream) {
+  CFEN_CHECK_ARG(B > 0 && ws > 0 && p > 0 && ws % p == 0 && H > 0 && W > 0 && H % ws == 0 && W % ws == 0, "embed_gather: bad geometry");
+  CfenTokGather tg{fmap, B, H, W, C, cs, ws, p};
+  const int tw = ws / p;
+  return cfen_embed_gather_impl(dtype, &tg, weight, ldw, bias, pos, period, Y, ldy, B * (H / ws) * (W / ws) * tw * tw, (hipStream_t)stream);
+}
+
 int cfen_tune(const char* key, int value) {
   CFEN_CHECK_ARG(key != nullptr, "tune: null key");
   if (!strcmp(key, "gemm.kernel")) {
@@ -83,6 +91,22 @@ int cfen_tune(const char* key, int value) {
   if (!strcmp(key, "gemm.large") || !strcmp(key, "gemm.small")) {
     CFEN_CHECK_ARG(value % 10 >= 2 && value % 10 <= 5 && value >= 2 && value <= 25, "tune: %s must be tile 2 .. 5 (+10 / +20 for 3 / 4 LDS stages)", key);
     (key[5] == 'l' ? cfen_tune_gemm_large() : cfen_tune_gemm_small()) = value;
+    return CFEN_OK;
+  }
+  if (!strcmp(key, "gemm.wtiled_experiment")) {
+    cfen_tune_gemm_wtiled_experiment() = value;
+    return CFEN_OK;
+  }
+  if (!strcmp(key, "net.skip_classes")) {
+    cfen_tune_skip_classes() = value;
+    return CFEN_OK;
+  }
+  if (!strcmp(key, "mlp.small_tiles")) {
+    cfen_tune_mlp_small_tiles() = value != 0;
+    return CFEN_OK;
+  }
+  if (!strcmp(key, "net.embed_gather")) {
+    cfen_tune_embed_gather() = value != 0;
     return CFEN_OK;
   }
   cfen_set_error("tune: unknown key '%s'", key);

@@ -7,6 +7,11 @@ struct ConvDesc;
 
 int cfen_gemm_impl(int dtype, const void* X, int ldx, const void* W, int ldw, const float* bias, const void* R, int ldr, const void* P,
                    int period, void* Y, int ldy, int M, int N, int K, int relu, hipStream_t s);
+// Y = tok W^T + bias + tok + P[m % period]  with tok = the patch tokens of an NHWC map, gathered by the GEMM's loader
+// (window partition + unfold + linear_encoding + residual + position add in one launch; v3:1025-1056,1140-1143,1166)
+struct CfenTokGather { const void* map; int B, H, W, C, cs, ws, p; };
+int cfen_embed_gather_impl(int dtype, const CfenTokGather* tg, const void* W, int ldw, const float* bias, const void* P, int period,
+                           void* Y, int ldy, int M, hipStream_t s);
 int cfen_attention_impl(int dtype, const void* qkv, void* out, int nseq, int S, int heads, int dh, hipStream_t s);
 int cfen_layernorm_impl(int dtype, const void* X, void* Y, const float* g, const float* b, int M, int D, float eps, hipStream_t s);
 int cfen_patchify_impl(int dtype, const void* fmap, void* tok, int B, int H, int W, int C, int cs, int ws, int p, int pool, int inverse,
@@ -28,3 +33,7 @@ int cfen_cfsm2g_impl(int dtype, const void* x0, const void* x1, const void* x2, 
 int& cfen_tune_gemm_kernel();   // -1 auto, 0 tiled, 1 skinny (cfen_tune "gemm.kernel")
 int& cfen_tune_gemm_large();    // k_gemm_dma tile id (2..5) for problems with >= 1024 tiles of 96 x 64 ("gemm.large")
 int& cfen_tune_gemm_small();    // ... and for smaller ones ("gemm.small")
+int& cfen_tune_embed_gather();  // 1 (default): LViT embedding gathers its tokens from the map; 0: separate k_patchify ("net.embed_gather")
+int& cfen_tune_gemm_wtiled_experiment();
+int& cfen_tune_mlp_small_tiles();   // 1: fused MLP with half-size token tiles per wave (more waves in flight) ("mlp.small_tiles")
+int& cfen_tune_skip_classes();    // bit mask of kernel classes NOT launched by the net (marginal-cost timing; outputs invalid) ("net.skip_classes")

@@ -17,6 +17,15 @@
 #include "cfen_internal.hpp"
 #include "cfen_mlp.hpp"
 
+int& cfen_tune_skip_classes() {
+  static int v = 0;
+  return v;
+}
+int& cfen_tune_embed_gather() {
+  static int v = 1;
+  return v;
+}
+
 namespace {
 
 struct Param {
@@ -57,6 +66,7 @@ struct cfen_net {
   Scratch scr_set[6];
   size_t o_stats_set[3] = {0, 0, 0};
   int scr = 0, st = 0;             // scratch / stats set of the lane being enqueued
+  int blk_kind = 0;                // 0 CNN, 1 GViT block, 2 LViT block (selects bits 8.. / 16.. of "net.skip_classes")
   unsigned char* base = nullptr;   // workspace of the current / last forward
   hipStream_t stream = nullptr;    // stream of the lane being enqueued
   // fork/join over internal side streams (captured into the caller's hipGraph like any other work):
@@ -169,6 +179,7 @@ struct cfen_net {
 // launch `expr`, attributing its time to kernel class `cls` when profiling
 #define TRYP(cls, flops, expr)            \
   do {                                    \
+    if (cfen_tune_skip_classes() & ((1 << (cls)) | (1 << ((cls) + 8 * blk_kind)))) break; /* what-if timing: outputs are garbage */ \
     int id__ = prof_begin(cls, flops);    \
     int rc__ = (expr);                    \
     prof_end(id__);                       \
@@ -351,16 +362,26 @@ int cfen_net::run_vit(const Vit& v, const std::string& in, const std::string& ou
   const int M = B * nwin * v.S;
   const std::string& n = v.name;
   const Scratch& q = scr_set[scr];
+  blk_kind = v.global ? 1 : 2;
+  struct Reset { int& k; ~Reset() { k = 0; } } reset_{blk_kind};
   CFEN_CHECK_ARG(v.global == (bool)(scr & 1), "net: %s enqueued on the wrong scratch set", n.c_str());
   void *X0 = at(q.x0), *X1 = at(q.x1), *YN = at(q.yn), *QKV = at(q.qkv), *ATT = at(q.att), *HID = at(q.hid);
   const double Md = (double)M, D = v.D, Hd = v.hidden;
   auto step = [&](const char* what) { if (profiling) label = n + ":" + what; };
-  step("patchify");
-  TRYP(K_TOKEN, 0, cfen_patchify_impl(dt, map_ptr(in), X0, B, v.mapH, v.mapH, v.C, bi.cs, v.ws, v.p, v.global ? 4 : 1, 0, stream));
-  // x = linear_encoding(x) + x + pos                                        (v3:1143,1166)
-  step("embed");
-  TRYP(K_GEMM, 2 * Md * D * D,
-       cfen_gemm_impl(dt, X0, v.D, P(n + ".embed.w"), v.D, Pf(n + ".embed.b"), X0, v.D, P(n + ".pos"), v.S, X1, v.D, M, v.D, v.D, 0, stream));
+  if (v.global || !cfen_tune_embed_gather()) {
+    step("patchify");
+    TRYP(K_TOKEN, 0, cfen_patchify_impl(dt, map_ptr(in), X0, B, v.mapH, v.mapH, v.C, bi.cs, v.ws, v.p, v.global ? 4 : 1, 0, stream));
+    // x = linear_encoding(x) + x + pos                                      (v3:1143,1166)
+    step("embed");
+    TRYP(K_GEMM, 2 * Md * D * D,
+         cfen_gemm_impl(dt, X0, v.D, P(n + ".embed.w"), v.D, Pf(n + ".embed.b"), X0, v.D, P(n + ".pos"), v.S, X1, v.D, M, v.D, v.D, 0, stream));
+  } else {
+    // LViT: the window / patch gather rides on the embedding GEMM's loader, no token buffer is written
+    step("embed");
+    CfenTokGather tg{map_ptr(in), B, v.mapH, v.mapH, v.C, bi.cs, v.ws, v.p};
+    TRYP(K_GEMM, 2 * Md * D * D,
+         cfen_embed_gather_impl(dt, &tg, P(n + ".embed.w"), v.D, Pf(n + ".embed.b"), P(n + ".pos"), v.S, X1, v.D, M, stream));
+  }
   // src = src + out_proj(MHA(LN1(src)))                                      (v3:1383-1386)
   step("ln1");
   TRYP(K_LNORM, 0, cfen_layernorm_impl(dt, X1, YN, Pf(n + ".ln1.g"), Pf(n + ".ln1.b"), M, v.D, 1e-5f, stream));

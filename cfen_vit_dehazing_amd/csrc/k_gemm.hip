@@ -51,7 +51,27 @@ template <typename T> struct GemmArgs {
   const T* X; const T* W; const float* bias; const T* R; const T* P; T* Y;
   int M, N, K, ldx, ldw, ldr, ldy, period, relu;
   TileMap map;
+  // optional token gather (LViT embedding, v3:1140-1143,1166): X -- and R, which is the same tokens -- are not a
+  // token-major matrix but windows of patches read straight from the NHWC map (what k_patchify would have written):
+  // token m = (image, window, patch), k = (i, j, c) -> pixel (y + i, x + j), channel c.
+  const T* gmap;
+  int gH, gW, gcs, gC, gws, gp;
+  int wtiled;   // W is stored [N / 96][K / BK][96][BK]: one K-step of a 96-feature tile is one contiguous 12 KiB block
 };
+
+// pointer to channel 0 of the top-left pixel of token m's patch
+template <typename T> CFEN_DEV const T* gather_pix(const GemmArgs<T>& a, int m) {
+  const int tw = a.gws / a.gp, S = tw * tw, nwx = a.gW / a.gws, nwy = a.gH / a.gws;
+  const int t = m % S, wi = m / S;
+  const int wx = wi % nwx, wy = (wi / nwx) % nwy, b = wi / (nwx * nwy);
+  const int y = wy * a.gws + (t / tw) * a.gp, x = wx * a.gws + (t % tw) * a.gp;
+  return a.gmap + (((size_t)b * a.gH + y) * a.gW + x) * a.gcs;
+}
+// element offset of feature k = (i, j, c) from that pixel
+template <typename T> CFEN_DEV int gather_off(const GemmArgs<T>& a, int k) {
+  const int ij = k / a.gC, c = k - ij * a.gC;
+  return ((ij / a.gp) * a.gW + (ij % a.gp)) * a.gcs + c;
+}
 
 // Epilogue of the 3 x 4 tile block of one wave: the lane owns Y[m + 16 j][n + 16 i .. +3].  All residual / position
 // loads are issued before the first store (R may alias Y element for element -- in-place residual -- so the compiler
@@ -73,7 +93,8 @@ CFEN_DEV void gemm_epilogue(const GemmArgs<T>& a, floatx4 (&acc)[3][TM], int n, 
 #pragma unroll
     for (int i = 0; i < 3; ++i) {
       const bool ok = nok[i] && mj < a.M;
-      if (a.R && ok) rv[i][j] = *reinterpret_cast<const out4*>(a.R + (size_t)mj * a.ldr + n + 16 * i);
+      if (a.gmap && ok) rv[i][j] = *reinterpret_cast<const out4*>(gather_pix(a, mj) + gather_off(a, n + 16 * i));
+      else if (a.R && ok) rv[i][j] = *reinterpret_cast<const out4*>(a.R + (size_t)mj * a.ldr + n + 16 * i);
       if (a.P && ok) pv[i][j] = *reinterpret_cast<const out4*>(a.P + (size_t)(mj % a.period) * a.N + n + 16 * i);
     }
   }
@@ -89,7 +110,7 @@ CFEN_DEV void gemm_epilogue(const GemmArgs<T>& a, floatx4 (&acc)[3][TM], int n, 
 #pragma unroll
         for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f);
       }
-      if (a.R) {
+      if (a.R || a.gmap) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) v[r] += (float)rv[i][j][r];
       }
@@ -135,7 +156,7 @@ __global__ __launch_bounds__(256) void k_gemm_nt(GemmArgs<T> a) {
       gptr[i] = a.W + (size_t)n * a.ldw;
     } else {
       int m = min(m0 + row - G_BN, a.M - 1);
-      gptr[i] = a.X + (size_t)m * a.ldx;
+      gptr[i] = a.gmap ? gather_pix(a, m) : a.X + (size_t)m * a.ldx;
     }
     koff[i] = pc * EPL;
     loff[i] = row * G_ROWB + pc * 16;
@@ -153,7 +174,8 @@ __global__ __launch_bounds__(256) void k_gemm_nt(GemmArgs<T> a) {
 #pragma unroll
     for (int i = 0; i < G_LOADS; ++i) {
       int k = kt * BK + koff[i];
-      stage[i] = (k < a.K) ? load_frag<T>(gptr[i] + k) : Mma<T>::zero();
+      const bool xrow = (tid + i * 256) / G_PIECES >= G_BN;
+      stage[i] = (k < a.K) ? load_frag<T>(gptr[i] + ((a.gmap && xrow) ? gather_off(a, k) : k)) : Mma<T>::zero();
     }
   };
   auto lstore = [&](int buf) {
@@ -220,17 +242,23 @@ __global__ __launch_bounds__(256) void k_gemm_dma(GemmArgs<T> a) {
 
   // DMA assignment: instruction i of wave w fills rows i*32 + w*8 .. +8; lane -> (row, 16-byte slot)
   const T* gptr[LOADS];
+  int gpc[LOADS];
 #pragma unroll
   for (int i = 0; i < LOADS; ++i) {
     const int row = i * 32 + wave * 8 + (lane >> 3), slot = lane & 7;
     const int piece = slot ^ (row & 7);
-    const T* base = row < G_BN ? a.W + (size_t)min(n0 + row, a.N - 1) * a.ldw : a.X + (size_t)min(m0 + row - G_BN, a.M - 1) * a.ldx;
-    gptr[i] = base + piece * EPL;
+    const bool gx = a.gmap && row >= G_BN;   // gathered token row: gptr = patch origin, the piece offset is added per K-step
+    const T* base = row < G_BN ? (a.wtiled ? a.W + ((size_t)tn * (a.K / BK) * G_BN + row) * BK : a.W + (size_t)min(n0 + row, a.N - 1) * a.ldw)
+                               : gx ? gather_pix(a, min(m0 + row - G_BN, a.M - 1)) : a.X + (size_t)min(m0 + row - G_BN, a.M - 1) * a.ldx;
+    gptr[i] = gx ? base : base + piece * EPL;
+    gpc[i] = gx ? piece * EPL : -1;
   }
 #define CFEN_GEMM_DMA_ISSUE(kt_, buf_)                                                                              \
   _Pragma("unroll") for (int i_ = 0; i_ < LOADS; ++i_)                                                              \
-      dma16(gptr[i_] + (kt_) * BK, lds + (buf_) * STAGE + (i_ * 256 + wave * 64) * 16)
+      dma16(gptr[i_] + ((i_ >= 3 && gpc[i_] >= 0) ? gather_off(a, (kt_) * BK + gpc[i_]) : (kt_) * (i_ < 3 ? wstep : BK)),  \
+            lds + (buf_) * STAGE + (i_ * 256 + wave * 64) * 16)
 
+  const int wstep = a.wtiled ? G_BN * BK : BK;   // elements between consecutive K-steps of a weight row
   floatx4 acc[3][TM];
 #pragma unroll
   for (int i = 0; i < 3; ++i)
@@ -336,8 +364,16 @@ __global__ __launch_bounds__(256) void k_gemm_skinny(GemmArgs<T> a) {
 
 template <typename T>
 int launch_gemm(const void* X, int ldx, const void* W, int ldw, const float* bias, const void* R, int ldr,
-                const void* P, int period, void* Y, int ldy, int M, int N, int K, int relu, hipStream_t s) {
+                const void* P, int period, void* Y, int ldy, int M, int N, int K, int relu, hipStream_t s, const CfenTokGather* tg) {
   constexpr int EPL = Mma<T>::EPL;
+  if (tg) {   // X and R are the patch tokens of an NHWC map
+    CFEN_CHECK_ARG(tg->map && cfen_aligned16(tg->map) && tg->C % EPL == 0 && tg->cs % EPL == 0 && tg->cs >= tg->C && tg->p > 0 &&
+                   tg->ws % tg->p == 0 && tg->H % tg->ws == 0 && tg->W % tg->ws == 0, "gemm (gather): bad token geometry");
+    CFEN_CHECK_ARG(K == tg->p * tg->p * tg->C && N == K && !R, "gemm (gather): needs N == K == p*p*C and no separate residual");
+    const int tw = tg->ws / tg->p;
+    CFEN_CHECK_ARG(M == tg->B * (tg->H / tg->ws) * (tg->W / tg->ws) * tw * tw, "gemm (gather): M does not match the map");
+    X = tg->map; ldx = K;   // placeholders for the generic checks below
+  }
   CFEN_CHECK_ARG(M > 0 && N > 0 && K > 0, "gemm: empty problem M=%d N=%d K=%d", M, N, K);
   CFEN_CHECK_ARG(N % 4 == 0 && K % EPL == 0, "gemm: N (%d) must be a multiple of 4 and K (%d) of %d", N, K, EPL);
   CFEN_CHECK_ARG(ldx % EPL == 0 && ldw % EPL == 0 && ldy % 4 == 0 && (!R || ldr % 4 == 0), "gemm: misaligned leading dimension");
@@ -346,21 +382,30 @@ int launch_gemm(const void* X, int ldx, const void* W, int ldw, const float* bia
                  cfen_aligned16(bias), "gemm: pointers must be 16-byte aligned");
   CFEN_CHECK_ARG(!P || period > 0, "gemm: position table needs a period");
   GemmArgs<T> a{(const T*)X, (const T*)W, bias, (const T*)R, (const T*)P, (T*)Y, M, N, K, ldx, ldw, ldr, ldy, period, relu};
+  if (tg) {
+    a.gmap = (const T*)tg->map; a.gH = tg->H; a.gW = tg->W; a.gcs = tg->cs; a.gC = tg->C; a.gws = tg->ws; a.gp = tg->p;
+  }
+  a.wtiled = cfen_tune_gemm_wtiled_experiment() && N % G_BN == 0;
   const int forced = cfen_tune_gemm_kernel();
   const bool k128 = (K * (int)sizeof(T)) % G_BKB == 0;
   CFEN_CHECK_ARG(forced <= 0 || k128, "gemm: k_gemm_skinny / k_gemm_dma need K * sizeof(T) %% 128 == 0");
-  // Kernel choice from measured kernel times on MI355X (tools/bench_gemm.py under rocprofv3 --kernel-trace, batch 8):
-  //   K not a multiple of 128 bytes (LViT level 1, K = 96)      -> register-staged k_gemm_nt (zero-fills the K tail)
-  //   <= 128 tokens against <= 2048 features (GViT-3 square/K-heavy) -> k_gemm_skinny (in-workgroup split-K)
-  //   otherwise k_gemm_dma with the SMALLEST token tile that still leaves >= 1024 tiles: 96 x 64 (4 workgroups per CU)
-  //   for the LViT-sized problems, 96 x 32 (5 per CU) for GViT -- occupancy hides the DMA latency better than reuse.
+  // Kernel choice from kernel times measured with COLD caches (tools/bench_gemm_cold.py: in the network the 540 MB of
+  // weights stream from HBM, a warm-cache microbenchmark picks the wrong variants), MI355X, batch 8:
+  //   K not a multiple of 128 bytes (LViT level 1, K = 96)           -> register-staged k_gemm_nt (zero-fills the K tail)
+  //   <= 128 tokens against <= 2048 features (GViT-3 square / K-heavy) -> k_gemm_skinny (in-workgroup split-K)
+  //   >= 1024 tiles of 96 x 64 (LViT)                                 -> k_gemm_dma 96 x 64, 2 stages: occupancy (4 WG/CU) wins
+  //   few tiles (GViT: weight streaming, <= 2 workgroups per CU anyway) -> k_gemm_dma 96 x 32 with a 4-stage ring: what
+  //     bounds these is HBM latency x bytes in flight, and LDS is free to spend on it
+  //   in between                                                      -> k_gemm_dma 96 x 32, 2 stages
   const long long tiles64 = (long long)((N + G_BN - 1) / G_BN) * ((M + 63) / 64);
+  const long long tiles32 = (long long)((N + G_BN - 1) / G_BN) * ((M + 31) / 32);
   int kern = forced < 0 ? -1 : forced % 10, stages = forced < 0 ? 2 : 2 + forced / 10;
   if (kern < 0) {
-    const int pick = tiles64 >= 1024 ? cfen_tune_gemm_large() : cfen_tune_gemm_small();
+    const int pick = !k128 ? 0 : (M <= 128 && N <= 2048 && !tg) ? 1 : tiles64 >= 1024 ? cfen_tune_gemm_large() : tiles32 <= 512 ? cfen_tune_gemm_small() : 5;
+    kern = pick % 10;
     stages = 2 + pick / 10;
   }
-  if (kern < 0) kern = !k128 ? 0 : (M <= 128 && N <= 2048) ? 1 : (tiles64 >= 1024 ? cfen_tune_gemm_large() : cfen_tune_gemm_small()) % 10;
+  CFEN_CHECK_ARG(!(tg && kern == 1), "gemm (gather): k_gemm_skinny does not gather");
   if (kern < 2) stages = 2;
   const int bn = kern == 1 ? 16 : G_BN, bm = kern == 0 || kern == 2 ? 128 : kern == 3 ? 96 : kern == 4 || kern == 1 ? 64 : 32;
   a.map = make_tile_map((N + bn - 1) / bn, (M + bm - 1) / bm, (double)N * K * sizeof(T), (double)M * K * sizeof(T));
@@ -385,6 +430,10 @@ int launch_gemm(const void* X, int ldx, const void* W, int ldw, const float* bia
 
 }  // namespace
 
+int& cfen_tune_gemm_wtiled_experiment() {
+  static int v = 0;
+  return v;
+}
 int& cfen_tune_gemm_large() {
   static int v = 4;
   return v;
@@ -400,8 +449,18 @@ int& cfen_tune_gemm_kernel() {
 
 int cfen_gemm_impl(int dtype, const void* X, int ldx, const void* W, int ldw, const float* bias, const void* R, int ldr,
                    const void* P, int period, void* Y, int ldy, int M, int N, int K, int relu, hipStream_t s) {
-  if (dtype == 1) return launch_gemm<half_t>(X, ldx, W, ldw, bias, R, ldr, P, period, Y, ldy, M, N, K, relu, s);
-  if (dtype == 0) return launch_gemm<float>(X, ldx, W, ldw, bias, R, ldr, P, period, Y, ldy, M, N, K, relu, s);
+  if (dtype == 1) return launch_gemm<half_t>(X, ldx, W, ldw, bias, R, ldr, P, period, Y, ldy, M, N, K, relu, s, nullptr);
+  if (dtype == 0) return launch_gemm<float>(X, ldx, W, ldw, bias, R, ldr, P, period, Y, ldy, M, N, K, relu, s, nullptr);
   cfen_set_error("gemm: unknown dtype %d", dtype);
+  return CFEN_ERR_ARG;
+}
+
+int cfen_embed_gather_impl(int dtype, const CfenTokGather* tg, const void* W, int ldw, const float* bias, const void* P, int period,
+                           void* Y, int ldy, int M, hipStream_t s) {
+  CFEN_CHECK_ARG(tg != nullptr, "embed_gather: null geometry");
+  const int D = tg->p * tg->p * tg->C;
+  if (dtype == 1) return launch_gemm<half_t>(nullptr, 0, W, ldw, bias, nullptr, 0, P, period, Y, ldy, M, D, D, 0, s, tg);
+  if (dtype == 0) return launch_gemm<float>(nullptr, 0, W, ldw, bias, nullptr, 0, P, period, Y, ldy, M, D, D, 0, s, tg);
+  cfen_set_error("embed_gather: unknown dtype %d", dtype);
   return CFEN_ERR_ARG;
 }

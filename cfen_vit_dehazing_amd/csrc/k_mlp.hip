@@ -17,6 +17,7 @@
 #include <stdlib.h>
 #include "cfen_common.hpp"
 #include "cfen_mlp.hpp"
+#include "cfen_internal.hpp"
 
 namespace {
 
@@ -35,8 +36,9 @@ template <> struct Pack<float> {
 };
 
 // ND = D/16 n-tiles, TM = token tiles per wave, NW = waves per workgroup, HCH = hidden units per LDS stage
-template <typename T, int ND, int TM, int NW, int HCH>
-__global__ __launch_bounds__(NW * 64) void k_mlp(MlpArgs a) {
+// WPE = waves per SIMD the register allocation must leave room for
+template <typename T, int ND, int TM, int NW, int HCH, int WPE>
+__global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) void k_mlp(MlpArgs a) {
   constexpr int KC = Mma<T>::KC, EPL = Mma<T>::EPL, SZ = (int)sizeof(T);
   constexpr int NPC = Pack<T>::NPC;
   constexpr int NT = NW * 64;
@@ -236,7 +238,7 @@ __global__ __launch_bounds__(NW * 64) void k_mlp(MlpArgs a) {
   }
 }
 
-template <typename T, int ND, int TM, int NW, int HCH>
+template <typename T, int ND, int TM, int NW, int HCH, int WPE>
 int launch_mlp_t(const MlpArgs& a, hipStream_t s) {
   constexpr int SZ = (int)sizeof(T), D = ND * 16;
   constexpr size_t smem = 2 * (size_t)(HCH * (D * SZ + 16) + D * (HCH * SZ + 16));
@@ -246,13 +248,13 @@ int launch_mlp_t(const MlpArgs& a, hipStream_t s) {
   CFEN_CHECK_ARG(blocks > 0 && blocks < (1ll << 31), "mlp: bad grid");
   static bool attr_set = false;
   if (!attr_set) {
-    if (hipFuncSetAttribute((const void*)k_mlp<T, ND, TM, NW, HCH>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) != hipSuccess) {
+    if (hipFuncSetAttribute((const void*)k_mlp<T, ND, TM, NW, HCH, WPE>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) != hipSuccess) {
       cfen_set_error("mlp: cannot reserve %zu bytes of LDS", smem);
       return CFEN_ERR_HIP;
     }
     attr_set = true;
   }
-  CFEN_LAUNCH((k_mlp<T, ND, TM, NW, HCH>), dim3((unsigned)blocks), dim3(NW * 64), smem, s, a);
+  CFEN_LAUNCH((k_mlp<T, ND, TM, NW, HCH, WPE>), dim3((unsigned)blocks), dim3(NW * 64), smem, s, a);
   CFEN_CHECK_LAUNCH("mlp");
   return CFEN_OK;
 }
@@ -273,9 +275,12 @@ int launch_mlp(const MlpArgs& a, hipStream_t s) {
   CFEN_CHECK_ARG(cfen_aligned16(a.X) && cfen_aligned16(a.Y) && cfen_aligned16(a.fmap) && cfen_aligned16(a.W1a) && cfen_aligned16(a.W2a) &&
                  cfen_aligned16(a.W1b) && cfen_aligned16(a.W2b) && cfen_aligned16(a.b1a) && cfen_aligned16(a.b2a) && cfen_aligned16(a.b1b) &&
                  cfen_aligned16(a.b2b) && cfen_aligned16(a.ln_g) && cfen_aligned16(a.ln_b), "mlp: pointers must be 16-byte aligned");
+  const int small = cfen_tune_mlp_small_tiles();
   switch (a.D) {
-    case 96: return launch_mlp_t<T, 6, 4, 4, 2 * KC>(a, s);      // 256 tokens / WG, 24 KB stages
-    case 192: return launch_mlp_t<T, 12, 2, 4, KC>(a, s);        // 128 tokens / WG, 24 KB stages
+    case 96: return small ? launch_mlp_t<T, 6, 2, 4, 2 * KC, 2>(a, s)     // 128 tokens / WG, 2 waves per SIMD
+                          : launch_mlp_t<T, 6, 4, 4, 2 * KC, 1>(a, s);    // 256 tokens / WG, 24 KB stages
+    case 192: return small ? launch_mlp_t<T, 12, 1, 4, KC, 2>(a, s)       // 64 tokens / WG, 2 waves per SIMD
+                           : launch_mlp_t<T, 12, 2, 4, KC, 1>(a, s);      // 128 tokens / WG, 24 KB stages
     default:
       cfen_set_error("mlp: fused kernel supports D in {96,192}, got %d", a.D);
       return CFEN_ERR_ARG;
@@ -286,6 +291,11 @@ int launch_mlp(const MlpArgs& a, hipStream_t s) {
 
 // D = 384 (LViT level 3, 8192 tokens per batch of 8) does not fill the chip with 128-token workgroups and its
 // 4.7 MB of weights per instance exceed what one CU can stream per token tile: the tiled GEMM path is faster there.
+int& cfen_tune_mlp_small_tiles() {
+  static int v = 1;
+  return v;
+}
+
 bool cfen_mlp_supported(int D, int H, int dtype) { return (D == 96 || D == 192) && H % (dtype == 1 ? 64 : 32) == 0; }
 
 int cfen_mlp_impl(int dtype, const MlpArgs* a, hipStream_t s) {

@@ -89,6 +89,17 @@ def patchify(fmap, C, ws, p, pool=1):
     return tok
 
 
+def embed_gather(fmap, C, ws, p, w, bias, pos):
+    """tokens = patchify(fmap) gathered inside the GEMM:  tok @ w.T + bias + tok + pos[row % len(pos)]  -> [M, p*p*C]"""
+    _cuda(fmap, w, bias, pos)
+    B, H, W, cs = fmap.shape
+    D = p * p * C
+    out = torch.empty(B * H * W // (p * p), D, dtype=fmap.dtype, device=fmap.device)
+    check(_lib.load().cfen_embed_gather(dtype_code(fmap.dtype), ptr(fmap), B, H, W, C, cs, ws, p, ptr(w), w.shape[1], ptr(bias), ptr(pos),
+                                        pos.shape[0] if pos is not None else 0, ptr(out), D, current_stream()), "embed_gather")
+    return out
+
+
 def unpatchify(tok, B, H, W, C, cs, ws, p):
     _cuda(tok)
     fmap = torch.zeros(B, H, W, cs, dtype=tok.dtype, device=tok.device)

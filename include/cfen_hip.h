@@ -37,6 +37,8 @@ const char* cfen_last_error(void);
 /* Process-wide tuning knobs for benchmarking kernel variants (tools/bench_gemm.py); the defaults are what ships.
  *   "gemm.kernel": -1 choose by shape (default), 0 register-staged k_gemm_nt, 1 k_gemm_skinny, 2..5 LDS-DMA k_gemm_dma with a
  *                  96 x 128 / 96 / 64 / 32 (features x tokens) tile (1..5 need K * element size to be a multiple of 128 bytes)
+ *   "net.embed_gather": 1 (default) the LViT embedding GEMM gathers its patch tokens from the map, 0 separate patchify launch
+ *                  (read when a forward is enqueued or a graph is built)
  *   "gemm.large" / "gemm.small": the k_gemm_dma tile (2..5) the shape rule uses for problems with >= / < 1024 tiles of 96 x 64 */
 int cfen_tune(const char* key, int value);
 
@@ -94,6 +96,11 @@ double cfen_net_flops_per_image(const cfen_net* net);
 /* Y[m][n] = act(sum_k X[m][k] W[n][k] + bias[n]) + R[m][n] + P[m % period][n]      (nn.Linear family) */
 int cfen_gemm_nt(int dtype, const void* X, int ldx, const void* W, int ldw, const float* bias, const void* R, int ldr, const void* P,
                  int period, void* Y, int ldy, int M, int N, int K, int relu, void* stream);
+/* LViT token embedding without a token buffer: tok = patchify(fmap) (window partition + unfold, as cfen_patchify with pool 1)
+ * is gathered by the GEMM's loader;  Y[m][n] = sum_k tok[m][k] W[n][k] + bias[n] + tok[m][n] + pos[m % period][n],
+ * D = p*p*C, W is [D][D] (ldw), Y is [M][D] (ldy).                                        (v3:1140-1143, 1166) */
+int cfen_embed_gather(int dtype, const void* fmap, int B, int H, int W, int C, int cs, int ws, int p, const void* weight, int ldw,
+                      const float* bias, const void* pos, int period, void* Y, int ldy, void* stream);
 /* LayerNorm over the last dim (eps as given), gamma/beta fp32                       (v3:1370-1371) */
 int cfen_layernorm(int dtype, const void* X, void* Y, const float* gamma, const float* beta, int M, int D, float eps, void* stream);
 /* softmax(QK^T/sqrt(dh))V per (sequence, head); QKV is [nseq*S][3*heads*dh], out [nseq*S][heads*dh]  (v3:1364) */

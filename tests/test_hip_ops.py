@@ -147,6 +147,26 @@ def test_nchw_to_nhwc():
         assert torch.equal(got.cpu(), want)
 
 
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("C,H,W,ws", [(24, 64, 32, 32), (48, 32, 32, 16), (96, 16, 48, 16)])
+def test_embed_gather_equals_patchify_then_gemm(dtype, C, H, W, ws):
+    """LViT embedding with the patch gather inside the GEMM loader (k_gemm_nt for K = 96, k_gemm_dma otherwise)"""
+    d = dev()
+    B, p, D = 3, 2, 4 * C
+    S = (ws // p) ** 2
+    fmap = ops.to_nhwc(rnd((B, C, H, W), 1, dtype)).to(d)
+    w = rnd((D, D), 2, dtype, 1 / math.sqrt(D)).to(d)
+    b = rnd((D,), 3, torch.float32, 0.1).to(d)
+    pos = rnd((S, D), 4, dtype).to(d)
+    tok = ops.patchify(fmap, C, ws, p)
+    want = ops.gemm_nt(tok, w, bias=b, residual=tok, pos=pos)
+    got = ops.embed_gather(fmap, C, ws, p, w, b, pos)
+    assert got.shape == want.shape
+    assert torch.equal(got, want)          # same kernels, same operand values, same accumulation order
+    ref = tok.double().cpu() @ w.double().cpu().t() + b.double().cpu() + tok.double().cpu() + pos.double().cpu().repeat(tok.shape[0] // S, 1)
+    close(got, ref, tol(dtype, 4))
+
+
 # ---------------------------------------------------------------------------------------------------
 def run_conv(dtype, x, w, b, k, stride, pad, reflect=False, an=None, act=0, res=None, nchw=False, x2=None):
     kc = 32 if dtype == torch.float16 else 16
