@@ -93,10 +93,6 @@ int cfen_tune(const char* key, int value) {
     (key[5] == 'l' ? cfen_tune_gemm_large() : cfen_tune_gemm_small()) = value;
     return CFEN_OK;
   }
-  if (!strcmp(key, "gemm.wtiled_experiment")) {
-    cfen_tune_gemm_wtiled_experiment() = value;
-    return CFEN_OK;
-  }
   if (!strcmp(key, "net.skip_classes")) {
     cfen_tune_skip_classes() = value;
     return CFEN_OK;

@@ -146,6 +146,13 @@ template <int G> CFEN_DEV float group_sum(float v) {
 CFEN_DEV unsigned xcd_chunked_block(unsigned bid, unsigned nblocks8) { return (bid & 7u) * (nblocks8 >> 3) + (bid >> 3); }
 static inline unsigned cfen_grid8(long long n) { return (unsigned)((n + 7) / 8 * 8); }
 
+// Grouped launches: up to CFEN_MAX_GROUPS independent problems of identical geometry (the R, S and D decoders run the
+// same layer on different maps with different weights) go out as ONE launch, blockIdx.z selecting the problem: three
+// times the workgroups per launch for the latency-bound small kernels, a third of the launches.
+constexpr int CFEN_MAX_GROUPS = 3;
+template <class A> struct Grouped { A g[CFEN_MAX_GROUPS]; };
+template <class P> struct PtrG { P* p[CFEN_MAX_GROUPS]; };
+
 // ---- host side ------------------------------------------------------------------------------
 #define CFEN_OK 0
 #define CFEN_ERR_ARG (-1)

@@ -12,6 +12,17 @@ int cfen_gemm_impl(int dtype, const void* X, int ldx, const void* W, int ldw, co
 struct CfenTokGather { const void* map; int B, H, W, C, cs, ws, p; };
 int cfen_embed_gather_impl(int dtype, const CfenTokGather* tg, const void* W, int ldw, const float* bias, const void* P, int period,
                            void* Y, int ldy, int M, hipStream_t s);
+// grouped launches (cfen_common.hpp: CFEN_MAX_GROUPS problems of identical geometry, one launch)
+struct CfenGemmPtrs { const void* X; const void* W; const float* bias; const void* R; const void* P; void* Y; const void* gmap; };
+int cfen_gemm_impl_g(int dtype, int ng, const CfenGemmPtrs* gp, int ldx, int ldw, int ldr, int period, int ldy, int M, int N, int K, int relu,
+                     const CfenTokGather* tg, hipStream_t s);   // tg: geometry only, the maps are gp[g].gmap
+int cfen_patchify_impl_g(int dtype, int ng, const void* const* fmap, void* const* tok, int B, int H, int W, int C, int cs, int ws, int p, int pool,
+                         int inverse, hipStream_t s);
+int cfen_upsample4_impl_g(int dtype, int ng, const void* const* small, void* const* out, int B, int h, int w, int C, int cs_in, int cs_out,
+                          hipStream_t s);
+int cfen_attention_impl_g(int dtype, int ng, const void* const* qkv, void* const* out, int nseq, int S, int heads, int dh, hipStream_t s);
+int cfen_layernorm_impl_g(int dtype, int ng, const void* const* X, void* const* Y, const float* const* g, const float* const* b, int M, int D,
+                          float eps, hipStream_t s);
 int cfen_attention_impl(int dtype, const void* qkv, void* out, int nseq, int S, int heads, int dh, hipStream_t s);
 int cfen_layernorm_impl(int dtype, const void* X, void* Y, const float* g, const float* b, int M, int D, float eps, hipStream_t s);
 int cfen_patchify_impl(int dtype, const void* fmap, void* tok, int B, int H, int W, int C, int cs, int ws, int p, int pool, int inverse,
@@ -26,6 +37,9 @@ int cfen_conv_tile_impl(int dtype, const ConvDesc* d, int k, hipStream_t s);
 bool cfen_convT_tile_supported(int dtype, int cs_in, int Cout_pad, int Hin, int Win);
 int cfen_convT_tile_kpad(int dtype, int cs_in);
 int cfen_convT_tile_impl(int dtype, const ConvDesc* d, hipStream_t s);
+int cfen_conv_impl_g(int dtype, int ng, const ConvDesc* d, hipStream_t s);
+int cfen_conv_tile_impl_g(int dtype, int ng, const ConvDesc* d, int k, hipStream_t s);
+int cfen_convT_tile_impl_g(int dtype, int ng, const ConvDesc* d, hipStream_t s);
 size_t cfen_stats_workspace_bytes(int B, int C);
 int cfen_instnorm_relu_impl(int dtype, void* x, float* part, int B, int HW, int C, int cs, float eps, hipStream_t s);
 int cfen_cfsm2g_impl(int dtype, const void* x0, const void* x1, const void* x2, void* out, const float* w, float* part, int B, int HW,
@@ -34,6 +48,5 @@ int& cfen_tune_gemm_kernel();   // -1 auto, 0 tiled, 1 skinny (cfen_tune "gemm.k
 int& cfen_tune_gemm_large();    // k_gemm_dma tile id (2..5) for problems with >= 1024 tiles of 96 x 64 ("gemm.large")
 int& cfen_tune_gemm_small();    // ... and for smaller ones ("gemm.small")
 int& cfen_tune_embed_gather();  // 1 (default): LViT embedding gathers its tokens from the map; 0: separate k_patchify ("net.embed_gather")
-int& cfen_tune_gemm_wtiled_experiment();
 int& cfen_tune_mlp_small_tiles();   // 1: fused MLP with half-size token tiles per wave (more waves in flight) ("mlp.small_tiles")
 int& cfen_tune_skip_classes();    // bit mask of kernel classes NOT launched by the net (marginal-cost timing; outputs invalid) ("net.skip_classes")

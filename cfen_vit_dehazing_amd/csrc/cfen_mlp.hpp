@@ -18,3 +18,4 @@ struct MlpArgs {
 
 bool cfen_mlp_supported(int D, int H, int dtype);
 int cfen_mlp_impl(int dtype, const MlpArgs* a, hipStream_t s);
+int cfen_mlp_impl_g(int dtype, int ng, const MlpArgs* a, hipStream_t s);   // ng problems of the same shape, one launch

@@ -65,7 +65,6 @@ struct cfen_net {
   struct Scratch { size_t x0, x1, yn, qkv, att, hid, small; };
   Scratch scr_set[6];
   size_t o_stats_set[3] = {0, 0, 0};
-  int scr = 0, st = 0;             // scratch / stats set of the lane being enqueued
   int blk_kind = 0;                // 0 CNN, 1 GViT block, 2 LViT block (selects bits 8.. / 16.. of "net.skip_classes")
   unsigned char* base = nullptr;   // workspace of the current / last forward
   hipStream_t stream = nullptr;    // stream of the lane being enqueued
@@ -80,8 +79,6 @@ struct cfen_net {
   hipStream_t fresh_side() { return side[side_next++ % NSIDE]; }
   std::vector<hipEvent_t> evs;
   size_t ev_next = 0;
-  struct Lane { hipStream_t s; int scr, st; };
-  void use(const Lane& l) { stream = l.s; scr = l.scr; st = l.st; }
   std::vector<hipGraphExec_t> execs;   // instantiated launch plans (cfen_net_graph_capture)
   int order(hipStream_t before, hipStream_t after) {   // work enqueued on `after` from now on waits for `before`'s work so far
     if (before == after) return CFEN_OK;
@@ -162,11 +159,19 @@ struct cfen_net {
   const float* Pf(const std::string& n) const { return (const float*)params.at(n).ptr; }
 
   int build();
+  // one convolution of up to CFEN_MAX_GROUPS same-shaped layers (the R / S / D copies of a decoder layer) as ONE launch
+  struct ConvCall { std::string layer, in0, in1, res0, res1, out; float* nchw_out = nullptr; };   // "" = absent
+  int run_conv_g(int ng, const ConvCall* c, int act);
   int run_conv(const std::string& layer, const std::string& in0, const char* in1, const char* res0, const char* res1, int act,
-               const std::string& out, float* nchw_out);
-  int run_vit(const Vit& v, const std::string& in, const std::string& out);
-  int run_level(const char* tag, int l, const std::string& in, const char* extra_res, const std::string& out, const Lane& lm, const Lane& ls);
-  int run_branch(int b, int stage, const Lane& lm, const Lane& ls, float* out);
+               const std::string& out, float* nchw_out) {
+    ConvCall c{layer, in0, in1 ? in1 : "", res0 ? res0 : "", res1 ? res1 : "", out, nchw_out};
+    return run_conv_g(1, &c, act);
+  }
+  struct VitCall { const Vit* v; std::string in, out; };
+  int run_vit_g(int ng, const VitCall* c, int scr0);   // group member g uses scratch set scr0 + 2 g
+  int run_level_g(int ng, const char* tags, int l, const std::string* in, const char* extra_res, const std::string* out, hipStream_t sm,
+                  hipStream_t sg);
+  int run_decoder(float* const* outs, hipStream_t sm, hipStream_t sg);
   int forward(const float* x, float* xr, float* xs, float* xd);
 };
 
@@ -289,6 +294,7 @@ int cfen_net::build() {
     add_map("lgcat_conv_e0" + L, C, E);
     if (l < 3) add_map("ds_conv_e0" + std::to_string(l + 1), 2 * C, E / 2);
   }
+  for (int b = 0; b < 3; ++b) add_map(std::string("us_conv_d03") + br[b], 2 * nf, N / 2);   // back to back: one InstanceNorm over 3B images
   for (int b = 0; b < 3; ++b) {
     const std::string t(1, br[b]);
     for (int l = 3; l >= 1; --l) {
@@ -297,7 +303,7 @@ int cfen_net::build() {
       add_map("localvit_decoder_0" + L + t, C, E);
       add_map("globalvit_decoder_0" + L + t, C, E);
       add_map("lgcat_conv_d0" + L + t, C, E);
-      add_map("us_conv_d0" + L + t, C / 2, 2 * E);
+      if (l < 3) add_map("us_conv_d0" + L + t, C / 2, 2 * E);
       if (l > 1) add_map(b == 2 ? "cfsm2g_d0" + L + "d" : "sk_conv_d0" + L + t, C / 2, 2 * E);
     }
     add_map(std::string("tail_") + (char)(br[b] - 32) + ".mid", h, 2 * N);
@@ -311,193 +317,248 @@ int cfen_net::build() {
     q.hid = alloc(mh * esz);
     q.small = alloc(g ? max_small * esz : 256);
   }
-  for (int k = 0; k < 3; ++k) o_stats_set[k] = alloc(cfen_stats_workspace_bytes(B, 128));
+  for (int k = 0; k < 3; ++k) o_stats_set[k] = alloc(cfen_stats_workspace_bytes(3 * B, 128));   // [0] also serves the 3B-image InstanceNorm
   parallel = (cfg.reserved & 1) == 0;
   return CFEN_OK;
 }
 
-int cfen_net::run_conv(const std::string& layer, const std::string& in0, const char* in1, const char* res0, const char* res1, int act,
-                       const std::string& out, float* nchw_out) {
-  const ConvLayer& c = convs.at(layer);
-  const Buf& bi = bufs.at(in0);
-  ConvDesc d;
-  if (c.kind == 0)
-    cfen_desc_conv(&d, cfg.batch, bi.H, bi.W, bi.cs, c.Cin, c.k, c.stride, c.pad, c.reflect, c.nsrc);
-  else
-    cfen_desc_convT4(&d, cfg.batch, bi.H, bi.W, bi.cs, c.Cin);
-  d.src[0] = map_ptr(in0);
-  d.src[1] = in1 ? map_ptr(in1) : nullptr;
-  d.weight = P(layer + (c.tile ? ".wr" : ".w")); d.Kpad = c.Kpad;
-  d.scale = Pf(layer + ".scale"); d.shift = Pf(layer + ".shift");
-  d.act = act;
-  d.Cout = c.Cout; d.Cout_pad = c.Cout_pad;
-  if (nchw_out) {
-    d.out = nchw_out; d.out_nchw_f32 = 1; d.cs_out = c.Cout_pad;
-  } else {
-    const Buf& bo = bufs.at(out);
-    CFEN_CHECK_ARG(bo.H == d.Hout && bo.W == d.Wout, "net: %s output geometry mismatch", layer.c_str());
-    d.out = map_ptr(out); d.cs_out = bo.cs; d.cs_res = bo.cs;
-    d.res[0] = res0 ? map_ptr(res0) : nullptr;
-    d.res[1] = res1 ? map_ptr(res1) : nullptr;
+int cfen_net::run_conv_g(int ng, const ConvCall* cc, int act) {
+  ConvDesc d[CFEN_MAX_GROUPS];
+  const ConvLayer& c0 = convs.at(cc[0].layer);
+  double fl = 0.0;
+  for (int g = 0; g < ng; ++g) {
+    const ConvCall& q = cc[g];
+    const ConvLayer& c = convs.at(q.layer);
+    CFEN_CHECK_ARG(c.kind == c0.kind && c.k == c0.k && c.tile == c0.tile && c.Cout_pad == c0.Cout_pad && c.Kpad == c0.Kpad,
+                   "net: %s and %s cannot share a launch", cc[0].layer.c_str(), q.layer.c_str());
+    const Buf& bi = bufs.at(q.in0);
+    if (c.kind == 0)
+      cfen_desc_conv(&d[g], cfg.batch, bi.H, bi.W, bi.cs, c.Cin, c.k, c.stride, c.pad, c.reflect, c.nsrc);
+    else
+      cfen_desc_convT4(&d[g], cfg.batch, bi.H, bi.W, bi.cs, c.Cin);
+    d[g].src[0] = map_ptr(q.in0);
+    d[g].src[1] = q.in1.empty() ? nullptr : map_ptr(q.in1);
+    d[g].weight = P(q.layer + (c.tile ? ".wr" : ".w")); d[g].Kpad = c.Kpad;
+    d[g].scale = Pf(q.layer + ".scale"); d[g].shift = Pf(q.layer + ".shift");
+    d[g].act = act;
+    d[g].Cout = c.Cout; d[g].Cout_pad = c.Cout_pad;
+    if (q.nchw_out) {
+      d[g].out = q.nchw_out; d[g].out_nchw_f32 = 1; d[g].cs_out = c.Cout_pad;
+    } else {
+      const Buf& bo = bufs.at(q.out);
+      CFEN_CHECK_ARG(bo.H == d[g].Hout && bo.W == d[g].Wout, "net: %s output geometry mismatch", q.layer.c_str());
+      d[g].out = map_ptr(q.out); d[g].cs_out = bo.cs; d[g].cs_res = bo.cs;
+      d[g].res[0] = q.res0.empty() ? nullptr : map_ptr(q.res0);
+      d[g].res[1] = q.res1.empty() ? nullptr : map_ptr(q.res1);
+    }
+    const double e = (double)c.out_edge;
+    fl += cfg.batch * (c.kind == 1 ? 2.0 * c.Cin_real * c.Cout * 16.0 * (e / 2) * (e / 2)
+                                   : 2.0 * c.Cout * (double)c.Cin_real * c.nsrc * c.k * c.k * e * e);
   }
-  const double e = (double)c.out_edge;
-  const double fl = cfg.batch * (c.kind == 1 ? 2.0 * c.Cin_real * c.Cout * 16.0 * (e / 2) * (e / 2)
-                                             : 2.0 * c.Cout * (double)c.Cin_real * c.nsrc * c.k * c.k * e * e);
-  label = layer;
-  if (c.tile && c.kind == 1)
-    TRYP(K_CONV, fl, cfen_convT_tile_impl(cfg.dtype, &d, stream));
-  else if (c.tile)
-    TRYP(K_CONV, fl, cfen_conv_tile_impl(cfg.dtype, &d, c.k, stream));
+  label = cc[0].layer + (ng > 1 ? " (x" + std::to_string(ng) + ")" : "");
+  if (c0.tile && c0.kind == 1)
+    TRYP(K_CONV, fl, cfen_convT_tile_impl_g(cfg.dtype, ng, d, stream));
+  else if (c0.tile)
+    TRYP(K_CONV, fl, cfen_conv_tile_impl_g(cfg.dtype, ng, d, c0.k, stream));
   else
-    TRYP(K_CONV, fl, cfen_conv_impl(cfg.dtype, &d, stream));
+    TRYP(K_CONV, fl, cfen_conv_impl_g(cfg.dtype, ng, d, stream));
   return CFEN_OK;
 }
 
 // One LViT / GViT instance: reference v3:1136-1189 / 1272-1325 (+ TransformerEncoderLayer 1382-1390).
-int cfen_net::run_vit(const Vit& v, const std::string& in, const std::string& out) {
+int cfen_net::run_vit_g(int ng, const VitCall* vc, int scr0) {
   const int dt = cfg.dtype, B = cfg.batch;
-  const Buf& bi = bufs.at(in);
-  const Buf& bo = bufs.at(out);
+  const Vit& v = *vc[0].v;
+  const Buf& bi = bufs.at(vc[0].in);
+  const Buf& bo = bufs.at(vc[0].out);
   const int nwin = (v.mapH / v.ws) * (v.mapH / v.ws);
   const int M = B * nwin * v.S;
-  const std::string& n = v.name;
-  const Scratch& q = scr_set[scr];
   blk_kind = v.global ? 1 : 2;
   struct Reset { int& k; ~Reset() { k = 0; } } reset_{blk_kind};
-  CFEN_CHECK_ARG(v.global == (bool)(scr & 1), "net: %s enqueued on the wrong scratch set", n.c_str());
-  void *X0 = at(q.x0), *X1 = at(q.x1), *YN = at(q.yn), *QKV = at(q.qkv), *ATT = at(q.att), *HID = at(q.hid);
-  const double Md = (double)M, D = v.D, Hd = v.hidden;
-  auto step = [&](const char* what) { if (profiling) label = n + ":" + what; };
+  CFEN_CHECK_ARG(v.global == (bool)(scr0 & 1) && scr0 + 2 * (ng - 1) < 6, "net: %s enqueued on the wrong scratch set", v.name.c_str());
+  // per-member operands: scratch set scr0 + 2g, parameters by instance name
+  void *X0[3], *X1[3], *YN[3], *QKV[3], *ATT[3], *HID[3], *SM[3], *OUT[3];
+  const void *IN[3], *cX0[3], *cX1[3], *cYN[3], *cQKV[3], *cSM[3];
+  std::string nm[3];
+  for (int g = 0; g < ng; ++g) {
+    const Vit& w = *vc[g].v;
+    CFEN_CHECK_ARG(w.global == v.global && w.D == v.D && w.hidden == v.hidden && w.S == v.S && w.mapH == v.mapH && w.heads == v.heads &&
+                   w.fused_mlp == v.fused_mlp && bufs.at(vc[g].in).cs == bi.cs && bufs.at(vc[g].out).cs == bo.cs,
+                   "net: %s and %s cannot share launches", v.name.c_str(), w.name.c_str());
+    const Scratch& q = scr_set[scr0 + 2 * g];
+    X0[g] = at(q.x0); X1[g] = at(q.x1); YN[g] = at(q.yn); QKV[g] = at(q.qkv); ATT[g] = at(q.att); HID[g] = at(q.hid);
+    SM[g] = v.global ? at(q.small) : nullptr;
+    IN[g] = map_ptr(vc[g].in); OUT[g] = map_ptr(vc[g].out);
+    cX0[g] = X0[g]; cX1[g] = X1[g]; cYN[g] = YN[g]; cQKV[g] = QKV[g]; cSM[g] = SM[g];
+    nm[g] = w.name;
+  }
+  const double Md = (double)M * ng, D = v.D, Hd = v.hidden;
+  auto step = [&](const char* what) { if (profiling) label = nm[0] + (ng > 1 ? " (x" + std::to_string(ng) + ")" : "") + ":" + what; };
+  // Y = act(X W^T + bias) + R + P for every member; operand arrays are indexed by member
+  auto gemm = [&](const void* const* X, const char* wname, const char* bname, void* const* R, const char* pname, void* const* Y, int N, int K,
+                  int relu, const CfenTokGather* tg) -> int {
+    CfenGemmPtrs gp[3];
+    for (int g = 0; g < ng; ++g)
+      gp[g] = CfenGemmPtrs{tg ? nullptr : X[g], P(nm[g] + wname), bname ? Pf(nm[g] + bname) : nullptr, R ? R[g] : nullptr,
+                           pname ? P(nm[g] + pname) : nullptr, Y[g], tg ? IN[g] : nullptr};
+    return cfen_gemm_impl_g(dt, ng, gp, K, K, N, v.S, N, M, N, K, relu, tg, stream);
+  };
   if (v.global || !cfen_tune_embed_gather()) {
     step("patchify");
-    TRYP(K_TOKEN, 0, cfen_patchify_impl(dt, map_ptr(in), X0, B, v.mapH, v.mapH, v.C, bi.cs, v.ws, v.p, v.global ? 4 : 1, 0, stream));
+    TRYP(K_TOKEN, 0, cfen_patchify_impl_g(dt, ng, IN, X0, B, v.mapH, v.mapH, v.C, bi.cs, v.ws, v.p, v.global ? 4 : 1, 0, stream));
     // x = linear_encoding(x) + x + pos                                      (v3:1143,1166)
     step("embed");
-    TRYP(K_GEMM, 2 * Md * D * D,
-         cfen_gemm_impl(dt, X0, v.D, P(n + ".embed.w"), v.D, Pf(n + ".embed.b"), X0, v.D, P(n + ".pos"), v.S, X1, v.D, M, v.D, v.D, 0, stream));
+    TRYP(K_GEMM, 2 * Md * D * D, gemm(cX0, ".embed.w", ".embed.b", X0, ".pos", X1, v.D, v.D, 0, nullptr));
   } else {
     // LViT: the window / patch gather rides on the embedding GEMM's loader, no token buffer is written
     step("embed");
-    CfenTokGather tg{map_ptr(in), B, v.mapH, v.mapH, v.C, bi.cs, v.ws, v.p};
-    TRYP(K_GEMM, 2 * Md * D * D,
-         cfen_embed_gather_impl(dt, &tg, P(n + ".embed.w"), v.D, Pf(n + ".embed.b"), P(n + ".pos"), v.S, X1, v.D, M, stream));
+    CfenTokGather tg{nullptr, B, v.mapH, v.mapH, v.C, bi.cs, v.ws, v.p};
+    TRYP(K_GEMM, 2 * Md * D * D, gemm(nullptr, ".embed.w", ".embed.b", nullptr, ".pos", X1, v.D, v.D, 0, &tg));
   }
+  const float* lg[3];
+  const float* lb[3];
   // src = src + out_proj(MHA(LN1(src)))                                      (v3:1383-1386)
   step("ln1");
-  TRYP(K_LNORM, 0, cfen_layernorm_impl(dt, X1, YN, Pf(n + ".ln1.g"), Pf(n + ".ln1.b"), M, v.D, 1e-5f, stream));
+  for (int g = 0; g < ng; ++g) { lg[g] = Pf(nm[g] + ".ln1.g"); lb[g] = Pf(nm[g] + ".ln1.b"); }
+  TRYP(K_LNORM, 0, cfen_layernorm_impl_g(dt, ng, cX1, YN, lg, lb, M, v.D, 1e-5f, stream));
   step("qkv");
-  TRYP(K_GEMM, 6 * Md * D * D,
-       cfen_gemm_impl(dt, YN, v.D, P(n + ".qkv.w"), v.D, nullptr, nullptr, 0, nullptr, 0, QKV, 3 * v.D, M, 3 * v.D, v.D, 0, stream));
+  TRYP(K_GEMM, 6 * Md * D * D, gemm(cYN, ".qkv.w", nullptr, nullptr, nullptr, QKV, 3 * v.D, v.D, 0, nullptr));
   step("attention");
-  TRYP(K_ATTN, 4 * Md * v.S * D, cfen_attention_impl(dt, QKV, ATT, B * nwin, v.S, v.heads, v.D / v.heads, stream));
+  TRYP(K_ATTN, 4 * Md * v.S * D, cfen_attention_impl_g(dt, ng, cQKV, ATT, B * nwin, v.S, v.heads, v.D / v.heads, stream));
   step("proj");
-  TRYP(K_GEMM, 2 * Md * D * D,
-       cfen_gemm_impl(dt, ATT, v.D, P(n + ".proj.w"), v.D, nullptr, X1, v.D, nullptr, 0, X1, v.D, M, v.D, v.D, 0, stream));
-  void* SM = v.global ? at(q.small) : nullptr;
+  const void* cATT[3] = {ATT[0], ATT[1], ATT[2]};
+  TRYP(K_GEMM, 2 * Md * D * D, gemm(cATT, ".proj.w", nullptr, X1, nullptr, X1, v.D, v.D, 0, nullptr));
   if (v.fused_mlp) {
     // LN2 + FFN + residual + mlp_head + residual + fold, hidden activations never leave registers (k_mlp.hip)
-    MlpArgs m{};
-    m.X = X1; m.Y = nullptr; m.fmap = v.global ? SM : map_ptr(out);
-    m.ln_g = Pf(n + ".ln2.g"); m.ln_b = Pf(n + ".ln2.b");
-    m.W1a = P(n + ".ffn1.wk"); m.b1a = Pf(n + ".ffn1.b"); m.W2a = P(n + ".ffn2.wk"); m.b2a = Pf(n + ".ffn2.b");
-    m.W1b = P(n + ".head1.wk"); m.b1b = Pf(n + ".head1.b"); m.W2b = P(n + ".head2.wk"); m.b2b = Pf(n + ".head2.b");
-    m.M = M; m.D = v.D; m.H = v.hidden; m.eps = 1e-5f;
-    m.mapH = v.mapH; m.mapW = v.mapH; m.C = v.C; m.cs = v.global ? v.C : bo.cs; m.ws = v.ws; m.p = v.p;
+    MlpArgs m[3];
+    for (int g = 0; g < ng; ++g) {
+      const std::string& n = nm[g];
+      m[g] = MlpArgs{};
+      m[g].X = X1[g]; m[g].Y = nullptr; m[g].fmap = v.global ? SM[g] : OUT[g];
+      m[g].ln_g = Pf(n + ".ln2.g"); m[g].ln_b = Pf(n + ".ln2.b");
+      m[g].W1a = P(n + ".ffn1.wk"); m[g].b1a = Pf(n + ".ffn1.b"); m[g].W2a = P(n + ".ffn2.wk"); m[g].b2a = Pf(n + ".ffn2.b");
+      m[g].W1b = P(n + ".head1.wk"); m[g].b1b = Pf(n + ".head1.b"); m[g].W2b = P(n + ".head2.wk"); m[g].b2b = Pf(n + ".head2.b");
+      m[g].M = M; m[g].D = v.D; m[g].H = v.hidden; m[g].eps = 1e-5f;
+      m[g].mapH = v.mapH; m[g].mapW = v.mapH; m[g].C = v.C; m[g].cs = v.global ? v.C : bo.cs; m[g].ws = v.ws; m[g].p = v.p;
+    }
     step("mlp_fused");
-    TRYP(K_MLP, 8 * Md * D * Hd, cfen_mlp_impl(dt, &m, stream));
+    TRYP(K_MLP, 8 * Md * D * Hd, cfen_mlp_impl_g(dt, ng, m, stream));
   } else {
     // src = src + linear2(relu(linear1(LN2(src))))                             (v3:1387-1389)
     step("ln2");
-    TRYP(K_LNORM, 0, cfen_layernorm_impl(dt, X1, YN, Pf(n + ".ln2.g"), Pf(n + ".ln2.b"), M, v.D, 1e-5f, stream));
+    for (int g = 0; g < ng; ++g) { lg[g] = Pf(nm[g] + ".ln2.g"); lb[g] = Pf(nm[g] + ".ln2.b"); }
+    TRYP(K_LNORM, 0, cfen_layernorm_impl_g(dt, ng, cX1, YN, lg, lb, M, v.D, 1e-5f, stream));
+    const void* cHID[3] = {HID[0], HID[1], HID[2]};
     step("ffn1");
-    TRYP(K_GEMM, 2 * Md * D * Hd,
-         cfen_gemm_impl(dt, YN, v.D, P(n + ".ffn1.w"), v.D, Pf(n + ".ffn1.b"), nullptr, 0, nullptr, 0, HID, v.hidden, M, v.hidden, v.D, 1, stream));
+    TRYP(K_GEMM, 2 * Md * D * Hd, gemm(cYN, ".ffn1.w", ".ffn1.b", nullptr, nullptr, HID, v.hidden, v.D, 1, nullptr));
     step("ffn2");
-    TRYP(K_GEMM, 2 * Md * D * Hd,
-         cfen_gemm_impl(dt, HID, v.hidden, P(n + ".ffn2.w"), v.hidden, Pf(n + ".ffn2.b"), X1, v.D, nullptr, 0, X1, v.D, M, v.D, v.hidden, 0, stream));
+    TRYP(K_GEMM, 2 * Md * D * Hd, gemm(cHID, ".ffn2.w", ".ffn2.b", X1, nullptr, X1, v.D, v.hidden, 0, nullptr));
     // x = mlp_head(x) + x                                                      (v3:1173)
     step("head1");
-    TRYP(K_GEMM, 2 * Md * D * Hd,
-         cfen_gemm_impl(dt, X1, v.D, P(n + ".head1.w"), v.D, Pf(n + ".head1.b"), nullptr, 0, nullptr, 0, HID, v.hidden, M, v.hidden, v.D, 1, stream));
+    TRYP(K_GEMM, 2 * Md * D * Hd, gemm(cX1, ".head1.w", ".head1.b", nullptr, nullptr, HID, v.hidden, v.D, 1, nullptr));
     step("head2");
-    TRYP(K_GEMM, 2 * Md * D * Hd,
-         cfen_gemm_impl(dt, HID, v.hidden, P(n + ".head2.w"), v.hidden, Pf(n + ".head2.b"), X1, v.D, nullptr, 0, X0, v.D, M, v.D, v.hidden, 0, stream));
+    TRYP(K_GEMM, 2 * Md * D * Hd, gemm(cHID, ".head2.w", ".head2.b", X1, nullptr, X0, v.D, v.hidden, 0, nullptr));
     step("fold");
-    TRYP(K_TOKEN, 0, cfen_patchify_impl(dt, v.global ? SM : map_ptr(out), X0, B, v.mapH, v.mapH, v.C, v.global ? v.C : bo.cs, v.ws, v.p, 1, 1, stream));
+    const void* dst[3];
+    for (int g = 0; g < ng; ++g) dst[g] = v.global ? SM[g] : OUT[g];
+    TRYP(K_TOKEN, 0, cfen_patchify_impl_g(dt, ng, dst, X0, B, v.mapH, v.mapH, v.C, v.global ? v.C : bo.cs, v.ws, v.p, 1, 1, stream));
   }
   step("upsample4");
-  if (v.global) TRYP(K_TOKEN, 0, cfen_upsample4_impl(dt, SM, map_ptr(out), B, v.mapH, v.mapH, v.C, v.C, bo.cs, stream));
+  if (v.global) TRYP(K_TOKEN, 0, cfen_upsample4_impl_g(dt, ng, cSM, OUT, B, v.mapH, v.mapH, v.C, v.C, bo.cs, stream));
   return CFEN_OK;
 }
 
 // LViT || GViT -> 1x1 fuse conv over their concat -> ActNorm -> ReLU -> + level input   (v3:403-488 ...)
-// GViT (few tokens, huge weights: latency / weight-bandwidth bound) is enqueued on the lane's side stream
-// and overlaps LViT (many tokens, MFMA bound) of the same level.
-int cfen_net::run_level(const char* tag, int l, const std::string& in, const char* extra_res, const std::string& out, const Lane& lm,
-                        const Lane& ls) {
+// for `ng` same-level blocks at once (tags "e" = the encoder block, "rsd" = the three decoders).  GViT (few tokens, huge
+// weights: latency / weight-bandwidth bound) is enqueued on the side stream `sg` and overlaps LViT (many tokens).
+int cfen_net::run_level_g(int ng, const char* tags, int l, const std::string* in, const char* extra_res, const std::string* out,
+                          hipStream_t sm, hipStream_t sg) {
   const std::string L = std::to_string(l);
-  const bool enc = tag[0] == 'e';
-  const std::string ln = enc ? "localvit_encoder_0" + L : "localvit_decoder_0" + L + tag;
-  const std::string gn = enc ? "globalvit_encoder_0" + L : "globalvit_decoder_0" + L + tag;
-  const Vit *lvp = nullptr, *gvp = nullptr;
-  for (const Vit& v : vits) {
-    if (v.name == ln) lvp = &v;
-    if (v.name == gn) gvp = &v;
+  VitCall lv[3], gv[3];
+  ConvCall fuse[3];
+  for (int g = 0; g < ng; ++g) {
+    const bool enc = tags[g] == 'e';
+    const std::string ln = enc ? "localvit_encoder_0" + L : "localvit_decoder_0" + L + tags[g];
+    const std::string gn = enc ? "globalvit_encoder_0" + L : "globalvit_decoder_0" + L + tags[g];
+    lv[g] = VitCall{nullptr, in[g], ln};
+    gv[g] = VitCall{nullptr, in[g], gn};
+    for (const Vit& v : vits) {
+      if (v.name == ln) lv[g].v = &v;
+      if (v.name == gn) gv[g].v = &v;
+    }
+    fuse[g] = ConvCall{out[g], ln, gn, in[g], extra_res ? extra_res : "", out[g], nullptr};
   }
-  Lane lg = ls;
-  if (ls.s != lm.s) lg.s = fresh_side();
-  TRY(order(lm.s, lg.s));
-  use(lg);
-  TRY(run_vit(*gvp, in, gn));
-  use(lm);
-  TRY(run_vit(*lvp, in, ln));
-  TRY(order(lg.s, lm.s));
-  return run_conv(out, ln, gn.c_str(), in.c_str(), extra_res, 1, out, nullptr);
+  // globalvit_encoder_02 has its own hidden size (v3:200), so blocks of one level share launches only within the decoders
+  hipStream_t lane_g = sg == sm ? sm : fresh_side();
+  TRY(order(sm, lane_g));
+  stream = lane_g;
+  TRY(run_vit_g(ng, gv, 1));
+  stream = sm;
+  TRY(run_vit_g(ng, lv, 0));
+  TRY(order(lane_g, sm));
+  return run_conv_g(ng, fuse, 1);
 }
 
-// One decoder (R, S or D): v3:546-697 / 706-853 / 862-1009, cut at the two points where D consumes R's and S's upsampled
-// maps (CFSM2G, v3:885,920) so that the three decoders can be pipelined one level apart:
-//   stage 3: level-3 block -> ConvT -> InstanceNorm -> ReLU            (produces us_conv_d03*)
-//   stage 2: skip fuse (sk_conv / CFSM2G) -> level-2 block -> ConvT    (produces us_conv_d02*)
-//   stage 1: skip fuse -> level-1 block -> ConvT -> tail
-int cfen_net::run_branch(int b, int stage, const Lane& lm, const Lane& ls, float* outp) {
+// The three decoders (v3:546-697 / 706-853 / 862-1009) in lockstep: each layer of R, S and D is one grouped launch.
+// D consumes R's and S's upsampled maps through CFSM2G (v3:885,920), which the lockstep order provides for free.
+int cfen_net::run_decoder(float* const* outs, hipStream_t sm, hipStream_t sg) {
   const int dt = cfg.dtype, B = cfg.batch;
-  static const char* br = "rsd";
-  const std::string t(1, br[b]);
-  const std::string T(1, (char)(br[b] - 32));
-  use(lm);
-  float* stats = (float*)at(o_stats_set[lm.st]);
-  if (stage == 3) {
-    TRY(run_level(t.c_str(), 3, "lgcat_conv_e03", nullptr, "lgcat_conv_d03" + t, lm, ls));
-    const std::string u = "us_conv_d03" + t;   // ConvT -> InstanceNorm -> ReLU (v3:301-302)
-    TRY(run_conv(u, "lgcat_conv_d03" + t, nullptr, nullptr, nullptr, 0, u, nullptr));
-    const Buf& bu = bufs.at(u);
-    label = u + ":instnorm";
-    TRYP(K_NORM, 0, cfen_instnorm_relu_impl(dt, map_ptr(u), stats, B, bu.H * bu.W, bu.C, bu.cs, 1e-5f, stream));
-    return CFEN_OK;
+  static const char* tags = "rsd";
+  auto names = [](const std::string& base, std::string* o) { for (int g = 0; g < 3; ++g) o[g] = base + tags[g]; };
+  stream = sm;
+  std::string in[3], out[3], up[3];
+  // ---- level 3: block -> ConvT -> InstanceNorm -> ReLU (v3:301-302) ----
+  for (int g = 0; g < 3; ++g) in[g] = "lgcat_conv_e03";
+  names("lgcat_conv_d03", out);
+  TRY(run_level_g(3, tags, 3, in, nullptr, out, sm, sg));
+  names("us_conv_d03", up);
+  {
+    ConvCall c[3];
+    for (int g = 0; g < 3; ++g) c[g] = ConvCall{up[g], out[g], "", "", "", up[g], nullptr};
+    TRY(run_conv_g(3, c, 0));
+    // the three maps are allocated back to back: one InstanceNorm over 3B "images"
+    const Buf& bu = bufs.at(up[0]);
+    const size_t bytes = (size_t)B * bu.H * bu.W * bu.cs * esz;
+    CFEN_CHECK_ARG(bufs.at(up[1]).off == bu.off + bytes && bufs.at(up[2]).off == bu.off + 2 * bytes, "net: us_conv_d03 maps are not contiguous");
+    label = "us_conv_d03 (x3):instnorm";
+    TRYP(K_NORM, 0, cfen_instnorm_relu_impl(dt, map_ptr(up[0]), (float*)at(o_stats_set[0]), 3 * B, bu.H * bu.W, bu.C, bu.cs, 1e-5f, stream));
   }
-  const std::string L = std::to_string(stage), Lup = std::to_string(stage + 1);
-  std::string in;
-  if (b == 2) {   // D's skip inputs are R's and S's upsampled maps
-    in = "cfsm2g_d0" + Lup + "d";
-    const Buf& bu = bufs.at(in);
-    label = in;
-    TRYP(K_NORM, 0, cfen_cfsm2g_impl(dt, map_ptr("us_conv_d0" + Lup + "d"), map_ptr("us_conv_d0" + Lup + "r"), map_ptr("us_conv_d0" + Lup + "s"),
-                                     map_ptr(in), Pf(in + ".w"), stats, B, bu.H * bu.W, bu.C, bu.cs, stream));
-  } else {
-    in = "sk_conv_d0" + Lup + t;
-    TRY(run_conv(in, "us_conv_d0" + Lup + t, stage == 2 ? "lgcat_conv_e02" : "lgcat_conv_e01", nullptr, nullptr, 1, in, nullptr));
+  for (int l = 2; l >= 1; --l) {
+    const std::string L = std::to_string(l), Lup = std::to_string(l + 1);
+    // ---- skip fuse: D through CFSM2G over (D, R, S) upsampled maps, R and S through a 1x1 conv with the encoder skip ----
+    const std::string cf = "cfsm2g_d0" + Lup + "d";
+    {
+      const Buf& bu = bufs.at(cf);
+      label = cf;
+      TRYP(K_NORM, 0, cfen_cfsm2g_impl(dt, map_ptr("us_conv_d0" + Lup + "d"), map_ptr("us_conv_d0" + Lup + "r"), map_ptr("us_conv_d0" + Lup + "s"),
+                                       map_ptr(cf), Pf(cf + ".w"), (float*)at(o_stats_set[1]), B, bu.H * bu.W, bu.C, bu.cs, stream));
+      ConvCall c[2];
+      for (int g = 0; g < 2; ++g) {
+        const std::string sk = "sk_conv_d0" + Lup + tags[g];
+        c[g] = ConvCall{sk, "us_conv_d0" + Lup + tags[g], l == 2 ? "lgcat_conv_e02" : "lgcat_conv_e01", "", "", sk, nullptr};
+        in[g] = sk;
+      }
+      TRY(run_conv_g(2, c, 1));
+      in[2] = cf;
+    }
+    names("lgcat_conv_d0" + L, out);
+    // `xr = us_conv_d01r(r_d_01 + xf)` (v3:696,852,1008): the extra `+ xf` rides along as a second residual of the
+    // level-1 fuse conv, so stage lgcat_conv_d01* holds (reference stage + xf).
+    TRY(run_level_g(3, tags, l, in, l == 1 ? "ds_conv_e01" : nullptr, out, sm, sg));
+    names("us_conv_d0" + L, up);
+    ConvCall c[3];
+    for (int g = 0; g < 3; ++g) c[g] = ConvCall{up[g], out[g], "", "", "", up[g], nullptr};
+    TRY(run_conv_g(3, c, 1));
   }
-  if (stage == 2) {
-    TRY(run_level(t.c_str(), 2, in, nullptr, "lgcat_conv_d02" + t, lm, ls));
-    return run_conv("us_conv_d02" + t, "lgcat_conv_d02" + t, nullptr, nullptr, nullptr, 1, "us_conv_d02" + t, nullptr);
+  // ---- tails: conv3 (+ActNorm for R, D) + ReLU, reflect-pad conv7 + tanh, fp32 NCHW out (v3:348-383) ----
+  ConvCall c3[3], c7[3];
+  for (int g = 0; g < 3; ++g) {
+    const std::string T = std::string("tail_") + (char)(tags[g] - 32);
+    c3[g] = ConvCall{T + ".conv3", up[g], "", "", "", T + ".mid", nullptr};
+    c7[g] = ConvCall{T + ".conv7", T + ".mid", "", "", "", "", outs[g]};
   }
-  // `xr = us_conv_d01r(r_d_01 + xf)` (v3:696,852,1008): the extra `+ xf` rides along as a second
-  // residual of the fuse conv, so stage lgcat_conv_d01* holds (reference stage + xf).
-  TRY(run_level(t.c_str(), 1, in, "ds_conv_e01", "lgcat_conv_d01" + t, lm, ls));
-  TRY(run_conv("us_conv_d01" + t, "lgcat_conv_d01" + t, nullptr, nullptr, nullptr, 1, "us_conv_d01" + t, nullptr));
-  TRY(run_conv("tail_" + T + ".conv3", "us_conv_d01" + t, nullptr, nullptr, nullptr, 1, "tail_" + T + ".mid", nullptr));
-  return run_conv("tail_" + T + ".conv7", "tail_" + T + ".mid", nullptr, nullptr, nullptr, 2, "", outp);
+  TRY(run_conv_g(3, c3, 1));
+  return run_conv_g(3, c7, 2);
 }
 
 int cfen_net::forward(const float* x, float* xr, float* xs, float* xd) {
@@ -513,10 +574,9 @@ int cfen_net::forward(const float* x, float* xr, float* xs, float* xd) {
   }
   ev_next = 0;
   side_next = 0;
-  // lanes: a main lane and its GViT companion per decoder; companion streams are drawn fresh per fork
-  const Lane A{s0, 0, 0}, Ag{par ? side[NSIDE - 1] : s0, 1, 0}, Bm{par ? fresh_side() : s0, 2, 1}, Bg{par ? side[NSIDE - 1] : s0, 3, 1},
-      Dm{par ? fresh_side() : s0, 4, 2}, Dg{par ? side[NSIDE - 1] : s0, 5, 2};
-  use(A);
+  // two lanes: the caller's stream (CNN + LViT) and a side stream per level for GViT (drawn fresh per fork)
+  const hipStream_t sg = par ? side[NSIDE - 1] : s0;   // only a marker "!= s0": run_level_g draws the real stream
+  stream = s0;
   float* stats = (float*)at(o_stats_set[0]);
   const Buf& bin = bufs.at("input");
   label = "input:nchw_to_nhwc";
@@ -532,29 +592,16 @@ int cfen_net::forward(const float* x, float* xr, float* xs, float* xd) {
     TRYP(K_NORM, 0, cfen_instnorm_relu_impl(dt, map_ptr(layer), stats, B, b.H * b.W, b.C, b.cs, 1e-5f, stream));
     return CFEN_OK;
   };
-  TRY(down("ds_conv_e01", "head"));
-  TRY(run_level("e", 1, "ds_conv_e01", nullptr, "lgcat_conv_e01", A, Ag));
-  TRY(down("ds_conv_e02", "lgcat_conv_e01"));
-  TRY(run_level("e", 2, "ds_conv_e02", nullptr, "lgcat_conv_e02", A, Ag));
-  TRY(down("ds_conv_e03", "lgcat_conv_e02"));
-  TRY(run_level("e", 3, "ds_conv_e03", nullptr, "lgcat_conv_e03", A, Ag));
-
-  // The three decoders run side by side on their own lanes, D one CFSM2G hand-off behind R and S.
-  const Lane* lm[3] = {&A, &Bm, &Dm};
-  const Lane* lg[3] = {&Ag, &Bg, &Dg};
-  float* outs[3] = {xr, xs, xd};
-  TRY(order(s0, Bm.s));
-  TRY(order(s0, Dm.s));
-  for (int stage = 3; stage >= 1; --stage) {
-    for (int b = 0; b < 3; ++b) TRY(run_branch(b, stage, *lm[b], *lg[b], outs[b]));
-    if (stage > 1) {   // D's next CFSM2G reads us_conv_d0{stage}{r,s}
-      TRY(order(A.s, Dm.s));
-      TRY(order(Bm.s, Dm.s));
-    }
+  std::string in = "head";
+  for (int l = 1; l <= 3; ++l) {
+    const std::string L = std::to_string(l), ds = "ds_conv_e0" + L, out = "lgcat_conv_e0" + L;
+    TRY(down(ds, in));
+    TRY(run_level_g(1, "e", l, &ds, nullptr, &out, s0, sg));
+    in = out;
   }
-  TRY(order(Bm.s, s0));
-  TRY(order(Dm.s, s0));
-  use(A);
+  float* outs[3] = {xr, xs, xd};
+  TRY(run_decoder(outs, s0, sg));
+  stream = s0;
   return CFEN_OK;
 }
 

@@ -60,8 +60,10 @@ template <> struct VtStore<float> {
 };
 
 template <typename T, int NDT>
-__global__ __launch_bounds__(256) void k_attention(const T* __restrict__ QKV, T* __restrict__ O, int S, int D, int heads,
+__global__ __launch_bounds__(256) void k_attention(PtrG<const T> QKVg, PtrG<T> Og, int S, int D, int heads,
                                                    int dh, int skb, int nqg, float scale_log2) {
+  const T* __restrict__ QKV = QKVg.p[blockIdx.z];
+  T* __restrict__ O = Og.p[blockIdx.z];
   constexpr int KC = Mma<T>::KC, EPL = Mma<T>::EPL;
   constexpr int NCQ = (NDT * 16 + KC - 1) / KC;    // K chunks covering the (padded) head dim
   constexpr int DHPK = NCQ * KC;
@@ -176,8 +178,10 @@ __global__ __launch_bounds__(256) void k_attention(const T* __restrict__ QKV, T*
 // so the K-fragment LDS reads of a query tile are all in flight together).  The row sum comes out of the PV
 // MFMA itself when the head dim has a padding row (dh = 24 -> row 24 of V^T is all ones).
 template <typename T, int NDT, int NKT, bool ONES>
-__global__ __launch_bounds__(256) void k_attention_win(const T* __restrict__ QKV, T* __restrict__ O, int D, int heads, int dh,
+__global__ __launch_bounds__(256) void k_attention_win(PtrG<const T> QKVg, PtrG<T> Og, int D, int heads, int dh,
                                                        float scale_log2, int nblk) {
+  const T* __restrict__ QKV = QKVg.p[blockIdx.z];
+  T* __restrict__ O = Og.p[blockIdx.z];
   constexpr int KC = Mma<T>::KC, EPL = Mma<T>::EPL, SZ = (int)sizeof(T);
   constexpr int NCQ = (NDT * 16 + KC - 1) / KC;
   constexpr int DHPK = NCQ * KC;
@@ -280,32 +284,35 @@ __global__ __launch_bounds__(256) void k_attention_win(const T* __restrict__ QKV
 }
 
 template <typename T, int NDT, int NKT>
-int launch_attn_win(const void* qkv, void* out, int nseq, int heads, int dh, size_t smem, hipStream_t s) {
+int launch_attn_win(int ng, const void* const* qkv, void* const* out, int nseq, int heads, int dh, size_t smem, hipStream_t s) {
   const float scale_log2 = 1.4426950408889634f / sqrtf((float)dh);
+  PtrG<const T> qg{};
+  PtrG<T> og{};
+  for (int g = 0; g < ng; ++g) { qg.p[g] = (const T*)qkv[g]; og.p[g] = (T*)out[g]; }
   if (dh < NDT * 16)
-    CFEN_LAUNCH((k_attention_win<T, NDT, NKT, true>), dim3(cfen_grid8((long long)nseq * heads)), dim3(256), smem, s, (const T*)qkv, (T*)out,
+    CFEN_LAUNCH((k_attention_win<T, NDT, NKT, true>), dim3(cfen_grid8((long long)nseq * heads), 1, ng), dim3(256), smem, s, qg, og,
                        heads * dh, heads, dh, scale_log2, nseq * heads);
   else
-    CFEN_LAUNCH((k_attention_win<T, NDT, NKT, false>), dim3(cfen_grid8((long long)nseq * heads)), dim3(256), smem, s, (const T*)qkv, (T*)out,
+    CFEN_LAUNCH((k_attention_win<T, NDT, NKT, false>), dim3(cfen_grid8((long long)nseq * heads), 1, ng), dim3(256), smem, s, qg, og,
                        heads * dh, heads, dh, scale_log2, nseq * heads);
   CFEN_CHECK_LAUNCH("attention");
   return CFEN_OK;
 }
 
 template <typename T, int NDT>
-bool try_attn_win(const void* qkv, void* out, int nseq, int S, int heads, int dh, hipStream_t s, int* rc) {
+bool try_attn_win(int ng, const void* const* qkv, void* const* out, int nseq, int S, int heads, int dh, hipStream_t s, int* rc) {
   constexpr int KC = Mma<T>::KC;
   constexpr int NCQ = (NDT * 16 + KC - 1) / KC;
   const int SZ = (int)sizeof(T);
   if (S != 256 && S != 64) return false;
   const size_t smem = (size_t)S * (NCQ * KC * SZ + 32) + (size_t)NDT * 16 * (S * SZ + 16);
   if (smem > 64 * 1024) return false;   // larger dynamic-LDS kernel nodes crash hipGraph instantiation on ROCm 7.2
-  *rc = S == 256 ? launch_attn_win<T, NDT, 16>(qkv, out, nseq, heads, dh, smem, s) : launch_attn_win<T, NDT, 4>(qkv, out, nseq, heads, dh, smem, s);
+  *rc = S == 256 ? launch_attn_win<T, NDT, 16>(ng, qkv, out, nseq, heads, dh, smem, s) : launch_attn_win<T, NDT, 4>(ng, qkv, out, nseq, heads, dh, smem, s);
   return true;
 }
 
 template <typename T, int NDT>
-int launch_attn(const void* qkv, void* out, int nseq, int S, int heads, int dh, hipStream_t s) {
+int launch_attn(int ng, const void* const* qkv, void* const* out, int nseq, int S, int heads, int dh, hipStream_t s) {
   constexpr int KC = Mma<T>::KC;
   constexpr int NCQ = (NDT * 16 + KC - 1) / KC;
   const int SZ = (int)sizeof(T);
@@ -319,22 +326,27 @@ int launch_attn(const void* qkv, void* out, int nseq, int S, int heads, int dh, 
   const long long blocks = (long long)nseq * heads * nqg;
   CFEN_CHECK_ARG(blocks > 0 && blocks < (1ll << 31), "attention: bad grid");
   const float scale_log2 = 1.4426950408889634f / sqrtf((float)dh);
-  CFEN_LAUNCH((k_attention<T, NDT>), dim3((unsigned)blocks), dim3(256), smem, s, (const T*)qkv, (T*)out, S,
+  PtrG<const T> qg{};
+  PtrG<T> og{};
+  for (int g = 0; g < ng; ++g) { qg.p[g] = (const T*)qkv[g]; og.p[g] = (T*)out[g]; }
+  CFEN_LAUNCH((k_attention<T, NDT>), dim3((unsigned)blocks, 1, ng), dim3(256), smem, s, qg, og, S,
                      heads * dh, heads, dh, skb, nqg, scale_log2);
   CFEN_CHECK_LAUNCH("attention");
   return CFEN_OK;
 }
 
 template <typename T>
-int dispatch_attn(const void* qkv, void* out, int nseq, int S, int heads, int dh, hipStream_t s) {
+int dispatch_attn(int ng, const void* const* qkv, void* const* out, int nseq, int S, int heads, int dh, hipStream_t s) {
   CFEN_CHECK_ARG(nseq > 0 && S > 0 && heads > 0 && dh > 0, "attention: empty problem");
   CFEN_CHECK_ARG(dh % Mma<T>::EPL == 0, "attention: head_dim %d must be a multiple of %d", dh, Mma<T>::EPL);
-  CFEN_CHECK_ARG(cfen_aligned16(qkv) && cfen_aligned16(out), "attention: pointers must be 16-byte aligned");
+  CFEN_CHECK_ARG(ng >= 1 && ng <= CFEN_MAX_GROUPS, "attention: 1..%d problems per launch", CFEN_MAX_GROUPS);
+  for (int g = 0; g < ng; ++g)
+    CFEN_CHECK_ARG(qkv[g] && out[g] && cfen_aligned16(qkv[g]) && cfen_aligned16(out[g]), "attention: pointers must be non-null and 16-byte aligned");
   CFEN_CHECK_ARG((long long)nseq * heads < (1ll << 31), "attention: bad grid");
   int rc = CFEN_OK;
-  if (dh <= 32) return try_attn_win<T, 2>(qkv, out, nseq, S, heads, dh, s, &rc) ? rc : launch_attn<T, 2>(qkv, out, nseq, S, heads, dh, s);
-  if (dh <= 96) return try_attn_win<T, 6>(qkv, out, nseq, S, heads, dh, s, &rc) ? rc : launch_attn<T, 6>(qkv, out, nseq, S, heads, dh, s);
-  if (dh <= 128) return try_attn_win<T, 8>(qkv, out, nseq, S, heads, dh, s, &rc) ? rc : launch_attn<T, 8>(qkv, out, nseq, S, heads, dh, s);
+  if (dh <= 32) return try_attn_win<T, 2>(ng, qkv, out, nseq, S, heads, dh, s, &rc) ? rc : launch_attn<T, 2>(ng, qkv, out, nseq, S, heads, dh, s);
+  if (dh <= 96) return try_attn_win<T, 6>(ng, qkv, out, nseq, S, heads, dh, s, &rc) ? rc : launch_attn<T, 6>(ng, qkv, out, nseq, S, heads, dh, s);
+  if (dh <= 128) return try_attn_win<T, 8>(ng, qkv, out, nseq, S, heads, dh, s, &rc) ? rc : launch_attn<T, 8>(ng, qkv, out, nseq, S, heads, dh, s);
   cfen_set_error("attention: head_dim %d > 128 unsupported", dh);
   return CFEN_ERR_ARG;
 }
@@ -344,8 +356,11 @@ int dispatch_attn(const void* qkv, void* out, int nseq, int S, int heads, int dh
 // group of G = 16, 32 or 64 lanes (G >= D / (16-byte vector)), so a wave normalises 4 / 2 / 1 rows and all
 // lanes carry data even for the 192-byte rows of LViT level 1.
 template <typename T, int MAXV, int G>
-__global__ __launch_bounds__(256) void k_layernorm(const T* __restrict__ X, T* __restrict__ Y, const float* __restrict__ g,
-                                                   const float* __restrict__ b, int M, int D, float eps) {
+__global__ __launch_bounds__(256) void k_layernorm(PtrG<const T> Xg, PtrG<T> Yg, PtrG<const float> gg, PtrG<const float> bg, int M, int D, float eps) {
+  const T* __restrict__ X = Xg.p[blockIdx.z];
+  T* __restrict__ Y = Yg.p[blockIdx.z];
+  const float* __restrict__ g = gg.p[blockIdx.z];
+  const float* __restrict__ b = bg.p[blockIdx.z];
   constexpr int EPL = Vec16<T>::N;
   constexpr int RPW = 64 / G;                        // rows per wave
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -396,18 +411,25 @@ __global__ __launch_bounds__(256) void k_layernorm(const T* __restrict__ X, T* _
 }
 
 template <typename T, int MAXV>
-int launch_ln(const void* X, void* Y, const float* g, const float* b, int M, int D, float eps, hipStream_t s) {
+int launch_ln(int ng, const void* const* X, void* const* Y, const float* const* g, const float* const* b, int M, int D, float eps, hipStream_t s) {
   constexpr int EPL = Vec16<T>::N;
   CFEN_CHECK_ARG(M > 0 && D > 0, "layernorm: empty problem");
   CFEN_CHECK_ARG(D % EPL == 0 && D <= 64 * MAXV * EPL, "layernorm: D=%d unsupported (multiple of %d, <= %d)", D, EPL, 64 * MAXV * EPL);
-  CFEN_CHECK_ARG(cfen_aligned16(X) && cfen_aligned16(Y), "layernorm: pointers must be 16-byte aligned");
+  CFEN_CHECK_ARG(ng >= 1 && ng <= CFEN_MAX_GROUPS, "layernorm: 1..%d problems per launch", CFEN_MAX_GROUPS);
+  PtrG<const T> xg{};
+  PtrG<T> yg{};
+  PtrG<const float> gg{}, bg{};
+  for (int k = 0; k < ng; ++k) {
+    CFEN_CHECK_ARG(X[k] && Y[k] && g[k] && b[k] && cfen_aligned16(X[k]) && cfen_aligned16(Y[k]), "layernorm: pointers must be non-null and 16-byte aligned");
+    xg.p[k] = (const T*)X[k]; yg.p[k] = (T*)Y[k]; gg.p[k] = g[k]; bg.p[k] = b[k];
+  }
   const int nvec = D / EPL;
   if (nvec <= 16) {
-    CFEN_LAUNCH((k_layernorm<T, 1, 16>), dim3((M + 15) / 16), dim3(256), 0, s, (const T*)X, (T*)Y, g, b, M, D, eps);
+    CFEN_LAUNCH((k_layernorm<T, 1, 16>), dim3((M + 15) / 16, 1, ng), dim3(256), 0, s, xg, yg, gg, bg, M, D, eps);
   } else if (nvec <= 32) {
-    CFEN_LAUNCH((k_layernorm<T, 1, 32>), dim3((M + 7) / 8), dim3(256), 0, s, (const T*)X, (T*)Y, g, b, M, D, eps);
+    CFEN_LAUNCH((k_layernorm<T, 1, 32>), dim3((M + 7) / 8, 1, ng), dim3(256), 0, s, xg, yg, gg, bg, M, D, eps);
   } else {
-    CFEN_LAUNCH((k_layernorm<T, MAXV, 64>), dim3((M + 3) / 4), dim3(256), 0, s, (const T*)X, (T*)Y, g, b, M, D, eps);
+    CFEN_LAUNCH((k_layernorm<T, MAXV, 64>), dim3((M + 3) / 4, 1, ng), dim3(256), 0, s, xg, yg, gg, bg, M, D, eps);
   }
   CFEN_CHECK_LAUNCH("layernorm");
   return CFEN_OK;
@@ -415,17 +437,23 @@ int launch_ln(const void* X, void* Y, const float* g, const float* b, int M, int
 
 }  // namespace
 
-int cfen_attention_impl(int dtype, const void* qkv, void* out, int nseq, int S, int heads, int dh, hipStream_t s) {
-  if (dtype == 1) return dispatch_attn<half_t>(qkv, out, nseq, S, heads, dh, s);
-  if (dtype == 0) return dispatch_attn<float>(qkv, out, nseq, S, heads, dh, s);
+int cfen_attention_impl_g(int dtype, int ng, const void* const* qkv, void* const* out, int nseq, int S, int heads, int dh, hipStream_t s) {
+  if (dtype == 1) return dispatch_attn<half_t>(ng, qkv, out, nseq, S, heads, dh, s);
+  if (dtype == 0) return dispatch_attn<float>(ng, qkv, out, nseq, S, heads, dh, s);
   cfen_set_error("attention: unknown dtype %d", dtype);
   return CFEN_ERR_ARG;
 }
+int cfen_attention_impl(int dtype, const void* qkv, void* out, int nseq, int S, int heads, int dh, hipStream_t s) {
+  return cfen_attention_impl_g(dtype, 1, &qkv, &out, nseq, S, heads, dh, s);
+}
 
-int cfen_layernorm_impl(int dtype, const void* X, void* Y, const float* g, const float* b, int M, int D, float eps,
-                        hipStream_t s) {
-  if (dtype == 1) return launch_ln<half_t, 4>(X, Y, g, b, M, D, eps, s);
-  if (dtype == 0) return launch_ln<float, 8>(X, Y, g, b, M, D, eps, s);
+int cfen_layernorm_impl_g(int dtype, int ng, const void* const* X, void* const* Y, const float* const* g, const float* const* b, int M, int D,
+                          float eps, hipStream_t s) {
+  if (dtype == 1) return launch_ln<half_t, 4>(ng, X, Y, g, b, M, D, eps, s);
+  if (dtype == 0) return launch_ln<float, 8>(ng, X, Y, g, b, M, D, eps, s);
   cfen_set_error("layernorm: unknown dtype %d", dtype);
   return CFEN_ERR_ARG;
+}
+int cfen_layernorm_impl(int dtype, const void* X, void* Y, const float* g, const float* b, int M, int D, float eps, hipStream_t s) {
+  return cfen_layernorm_impl_g(dtype, 1, &X, &Y, &g, &b, M, D, eps, s);
 }

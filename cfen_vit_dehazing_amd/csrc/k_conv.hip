@@ -18,7 +18,8 @@
 namespace {
 
 template <typename T, int TN, int TM>
-__global__ __launch_bounds__(256) void k_conv(ConvDesc d) {
+__global__ __launch_bounds__(256) void k_conv(Grouped<ConvDesc> dg) {
+  const ConvDesc& d = dg.g[blockIdx.z];
   constexpr int KC = Mma<T>::KC, EPL = Mma<T>::EPL;
   typedef typename Mma<T>::frag frag;
   __shared__ int taps_l[CFEN_MAX_TAPS];
@@ -122,17 +123,20 @@ __global__ __launch_bounds__(256) void k_conv(ConvDesc d) {
 }
 
 template <typename T, int TN, int TM>
-int launch_conv_t(const ConvDesc& d, hipStream_t s) {
+int launch_conv_t(int ng, const ConvDesc* dp, hipStream_t s) {
+  const ConvDesc& d = dp[0];
+  Grouped<ConvDesc> dg;
+  for (int g = 0; g < CFEN_MAX_GROUPS; ++g) dg.g[g] = dp[g < ng ? g : 0];
   const long long total = (long long)d.B * d.Hb * d.Wb;
   const long long per_block = 4 * TM * 16;
-  dim3 grid(cfen_grid8((total + per_block - 1) / per_block), d.nphase);   // padded blocks exit on q_wave >= total
-  CFEN_LAUNCH((k_conv<T, TN, TM>), grid, dim3(256), 0, s, d);
+  dim3 grid(cfen_grid8((total + per_block - 1) / per_block), d.nphase, ng);   // padded blocks exit on q_wave >= total
+  CFEN_LAUNCH((k_conv<T, TN, TM>), grid, dim3(256), 0, s, dg);
   CFEN_CHECK_LAUNCH("conv");
   return CFEN_OK;
 }
 
 template <typename T>
-int launch_conv(const ConvDesc& d, hipStream_t s) {
+int check_conv(const ConvDesc& d) {
   constexpr int KC = Mma<T>::KC, EPL = Mma<T>::EPL;
   CFEN_CHECK_ARG(d.B > 0 && d.Hb > 0 && d.Wb > 0, "conv: empty problem");
   CFEN_CHECK_ARG(d.Wb % 16 == 0, "conv: output width (%d) must be a multiple of 16", d.Wb);
@@ -156,17 +160,31 @@ int launch_conv(const ConvDesc& d, hipStream_t s) {
     }
     CFEN_CHECK_ARG(maxd < d.Hin && maxd < d.Win, "conv: reflection pad larger than the image");
   }
+  return CFEN_OK;
+}
+
+template <typename T>
+int launch_conv(int ng, const ConvDesc* dp, hipStream_t s) {
+  CFEN_CHECK_ARG(ng >= 1 && ng <= CFEN_MAX_GROUPS && dp, "conv: 1..%d problems per launch", CFEN_MAX_GROUPS);
+  for (int g = 0; g < ng; ++g) {
+    int rc = check_conv<T>(dp[g]);
+    if (rc) return rc;
+    CFEN_CHECK_ARG(dp[g].B == dp[0].B && dp[g].Hb == dp[0].Hb && dp[g].Wb == dp[0].Wb && dp[g].Cout_pad == dp[0].Cout_pad &&
+                   dp[g].Kpad == dp[0].Kpad && dp[g].nphase == dp[0].nphase && dp[g].ntaps == dp[0].ntaps,
+                   "conv: grouped problems must have the same geometry");
+  }
+  const ConvDesc& d = dp[0];
   // Wave tile = (Cout_pad / 16) x TM MFMA tiles.  The gather loop is a chain of dependent global loads, so what hides its
   // latency is the number of waves in flight: shrink TM until the launch has a few thousand waves (tools/profile_launches.py).
-  const long long px = (long long)d.B * d.Hb * d.Wb * d.nphase;
+  const long long px = (long long)ng * d.B * d.Hb * d.Wb * d.nphase;
   const int shrink = px >= (1 << 20) ? 0 : px >= (1 << 18) ? 1 : 2;   // halve TM once / twice for small maps
   switch (d.Cout_pad / 16) {
-    case 1: return launch_conv_t<T, 1, 2>(d, s);
-    case 2: return shrink >= 2 ? launch_conv_t<T, 2, 1>(d, s) : launch_conv_t<T, 2, 2>(d, s);
-    case 3: return shrink >= 2 ? launch_conv_t<T, 3, 1>(d, s) : shrink == 1 ? launch_conv_t<T, 3, 2>(d, s) : launch_conv_t<T, 3, 4>(d, s);
-    case 4: return shrink >= 1 ? launch_conv_t<T, 4, 1>(d, s) : launch_conv_t<T, 4, 2>(d, s);
-    case 6: return shrink >= 1 ? launch_conv_t<T, 6, 1>(d, s) : launch_conv_t<T, 6, 2>(d, s);
-    case 8: return launch_conv_t<T, 8, 1>(d, s);
+    case 1: return launch_conv_t<T, 1, 2>(ng, dp, s);
+    case 2: return shrink >= 2 ? launch_conv_t<T, 2, 1>(ng, dp, s) : launch_conv_t<T, 2, 2>(ng, dp, s);
+    case 3: return shrink >= 2 ? launch_conv_t<T, 3, 1>(ng, dp, s) : shrink == 1 ? launch_conv_t<T, 3, 2>(ng, dp, s) : launch_conv_t<T, 3, 4>(ng, dp, s);
+    case 4: return shrink >= 1 ? launch_conv_t<T, 4, 1>(ng, dp, s) : launch_conv_t<T, 4, 2>(ng, dp, s);
+    case 6: return shrink >= 1 ? launch_conv_t<T, 6, 1>(ng, dp, s) : launch_conv_t<T, 6, 2>(ng, dp, s);
+    case 8: return launch_conv_t<T, 8, 1>(ng, dp, s);
     default:
       cfen_set_error("conv: Cout_pad=%d unsupported (16,32,48,64,96,128)", d.Cout_pad);
       return CFEN_ERR_ARG;
@@ -337,12 +355,13 @@ inline unsigned grid_img(long long nvec) {
 
 size_t cfen_stats_workspace_bytes(int B, int C) { return (size_t)B * ST_CHUNKS * 3 * C * sizeof(float); }
 
-int cfen_conv_impl(int dtype, const ConvDesc* d, hipStream_t s) {
-  if (dtype == 1) return launch_conv<half_t>(*d, s);
-  if (dtype == 0) return launch_conv<float>(*d, s);
+int cfen_conv_impl_g(int dtype, int ng, const ConvDesc* d, hipStream_t s) {
+  if (dtype == 1) return launch_conv<half_t>(ng, d, s);
+  if (dtype == 0) return launch_conv<float>(ng, d, s);
   cfen_set_error("conv: unknown dtype %d", dtype);
   return CFEN_ERR_ARG;
 }
+int cfen_conv_impl(int dtype, const ConvDesc* d, hipStream_t s) { return cfen_conv_impl_g(dtype, 1, d, s); }
 
 int cfen_instnorm_relu_impl(int dtype, void* x, float* part, int B, int HW, int C, int cs, float eps, hipStream_t s) {
   int rc = dtype == 1 ? run_stats<half_t>(x, nullptr, nullptr, part, B, HW, C, cs, s)

@@ -13,11 +13,13 @@
 // extra columns are zero (packing.pack_conv_weight_rows).
 #include "cfen_common.hpp"
 #include "cfen_conv.hpp"
+#include "cfen_internal.hpp"
 
 namespace {
 
 template <typename T, int PIXB, int KS, int R>
-__global__ __launch_bounds__(256) void k_conv_tile(ConvDesc d, int nblk) {
+__global__ __launch_bounds__(256) void k_conv_tile(Grouped<ConvDesc> dg, int nblk) {
+  const ConvDesc& d = dg.g[blockIdx.z];
   constexpr int SZ = (int)sizeof(T), EPL = Mma<T>::EPL, KC = Mma<T>::KC;
   constexpr int CSI = PIXB / SZ;              // channel stride of the input map
   constexpr int TPC = 64 / PIXB;              // taps per 64-byte chunk
@@ -122,30 +124,36 @@ __global__ __launch_bounds__(256) void k_conv_tile(ConvDesc d, int nblk) {
 constexpr int TILE_R = 8;
 
 template <typename T, int PIXB, int KS>
-int launch_tile(const ConvDesc& d, hipStream_t s) {
+int launch_tile(int ng, const ConvDesc* dp, hipStream_t s) {
+  const ConvDesc& d = dp[0];
+  Grouped<ConvDesc> dg;
+  for (int g = 0; g < CFEN_MAX_GROUPS; ++g) dg.g[g] = dp[g < ng ? g : 0];
   const long long nblk = (long long)d.B * (d.Hin / TILE_R) * (d.Win / 64);
-  CFEN_LAUNCH((k_conv_tile<T, PIXB, KS, TILE_R>), dim3(cfen_grid8(nblk)), dim3(256), 0, s, d, (int)nblk);
+  CFEN_LAUNCH((k_conv_tile<T, PIXB, KS, TILE_R>), dim3(cfen_grid8(nblk), 1, ng), dim3(256), 0, s, dg, (int)nblk);
   CFEN_CHECK_LAUNCH("conv (tile)");
   return CFEN_OK;
 }
 
 template <typename T>
-int launch_conv_tile(const ConvDesc& d, int k, hipStream_t s) {
-  const int pixb = d.cs_in * (int)sizeof(T);
+int launch_conv_tile(int ng, const ConvDesc* dp, int k, hipStream_t s) {
+  for (int g = 0; g < ng; ++g) {
+    const ConvDesc& d = dp[g];
   CFEN_CHECK_ARG(cfen_aligned16(d.src[0]) && cfen_aligned16(d.weight) && cfen_aligned16(d.out) && cfen_aligned16(d.scale) &&
                  cfen_aligned16(d.shift) && cfen_aligned16(d.res[0]) && cfen_aligned16(d.res[1]), "conv: pointers must be 16-byte aligned");
   CFEN_CHECK_ARG(d.src[0] && d.weight && d.out && d.scale && d.shift, "conv: null pointer");
   CFEN_CHECK_ARG(!(d.out_nchw_f32 && (d.res[0] || d.res[1])), "conv: residuals unsupported with NCHW output");
   CFEN_CHECK_ARG(d.out_nchw_f32 || (d.cs_out % 4 == 0 && d.cs_out <= 16), "conv: cs_out=%d must be a multiple of 4 and <= 16", d.cs_out);
-  CFEN_CHECK_ARG(!d.pad_reflect || (k / 2 < d.Hin && k / 2 < d.Win), "conv: reflection pad larger than the image");
+    CFEN_CHECK_ARG(!d.pad_reflect || (k / 2 < d.Hin && k / 2 < d.Win), "conv: reflection pad larger than the image");
+  }
+  const int pixb = dp[0].cs_in * (int)sizeof(T);
   if constexpr (sizeof(T) == 2) {
-    if (pixb == 16 && k == 5) return launch_tile<T, 16, 5>(d, s);
-    if (pixb == 32 && k == 3) return launch_tile<T, 32, 3>(d, s);
-    if (pixb == 32 && k == 7) return launch_tile<T, 32, 7>(d, s);
+    if (pixb == 16 && k == 5) return launch_tile<T, 16, 5>(ng, dp, s);
+    if (pixb == 32 && k == 3) return launch_tile<T, 32, 3>(ng, dp, s);
+    if (pixb == 32 && k == 7) return launch_tile<T, 32, 7>(ng, dp, s);
   } else {
-    if (pixb == 32 && k == 5) return launch_tile<T, 32, 5>(d, s);
-    if (pixb == 64 && k == 3) return launch_tile<T, 64, 3>(d, s);
-    if (pixb == 64 && k == 7) return launch_tile<T, 64, 7>(d, s);
+    if (pixb == 32 && k == 5) return launch_tile<T, 32, 5>(ng, dp, s);
+    if (pixb == 64 && k == 3) return launch_tile<T, 64, 3>(ng, dp, s);
+    if (pixb == 64 && k == 7) return launch_tile<T, 64, 7>(ng, dp, s);
   }
   cfen_set_error("conv (rows layout): kernel %dx%d over %d-byte pixels has no tiled instantiation", k, k, pixb);
   return CFEN_ERR_ARG;
@@ -166,14 +174,21 @@ int cfen_conv_tile_kpad(int dtype, int k, int cs_in) {
   return k * ncr * (dtype == 1 ? 32 : 16);
 }
 
-int cfen_conv_tile_impl(int dtype, const ConvDesc* d, int k, hipStream_t s) {
+int cfen_conv_tile_impl(int dtype, const ConvDesc* d, int k, hipStream_t s) { return cfen_conv_tile_impl_g(dtype, 1, d, k, s); }
+
+int cfen_conv_tile_impl_g(int dtype, int ng, const ConvDesc* dp, int k, hipStream_t s) {
+  CFEN_CHECK_ARG(ng >= 1 && ng <= CFEN_MAX_GROUPS && dp, "conv (rows layout): 1..%d problems per launch", CFEN_MAX_GROUPS);
+  for (int g = 0; g < ng; ++g) {
+    const ConvDesc* d = dp + g;
+    CFEN_CHECK_ARG(d->B == dp->B && d->Hin == dp->Hin && d->Win == dp->Win && d->cs_in == dp->cs_in, "conv (rows layout): grouped problems must have the same geometry");
   CFEN_CHECK_ARG(cfen_conv_tile_supported(dtype, 0, k, d->in_stride, k / 2, 1, d->cs_in, d->Cout_pad, d->Hin, d->Win) && d->nphase == 1 &&
                  d->Hout == d->Hin && d->Wout == d->Win,
                  "conv (rows layout): unsupported geometry k=%d cs_in=%d Cout_pad=%d %dx%d", k, d->cs_in, d->Cout_pad, d->Hin, d->Win);
   CFEN_CHECK_ARG(d->Kpad == cfen_conv_tile_kpad(dtype, k, d->cs_in), "conv (rows layout): Kpad=%d, expected %d", d->Kpad,
                  cfen_conv_tile_kpad(dtype, k, d->cs_in));
-  if (dtype == 1) return launch_conv_tile<half_t>(*d, k, s);
-  return launch_conv_tile<float>(*d, k, s);
+  }
+  if (dtype == 1) return launch_conv_tile<half_t>(ng, dp, k, s);
+  return launch_conv_tile<float>(ng, dp, k, s);
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -192,7 +207,8 @@ template <int PIXB> CFEN_DEV int convt_swz(int col) {
 }
 
 template <typename T, int PIXB, int TN, int NX, int RY>
-__global__ __launch_bounds__(256) void k_convT_tile(ConvDesc d, int nblk) {
+__global__ __launch_bounds__(256) void k_convT_tile(Grouped<ConvDesc> dg, int nblk) {
+  const ConvDesc& d = dg.g[blockIdx.z];
   constexpr int SZ = (int)sizeof(T), EPL = Mma<T>::EPL, KC = Mma<T>::KC;
   constexpr int CPT = PIXB / 64;                 // chunks per tap
   constexpr int TW = 16 * NX;                    // base pixels per tile row
@@ -302,9 +318,12 @@ __global__ __launch_bounds__(256) void k_convT_tile(ConvDesc d, int nblk) {
 }
 
 template <typename T, int PIXB, int TN, int NX, int RY>
-int launch_convT_tile(const ConvDesc& d, hipStream_t s) {
+int launch_convT_tile(int ng, const ConvDesc* dp, hipStream_t s) {
+  const ConvDesc& d = dp[0];
+  Grouped<ConvDesc> dg;
+  for (int g = 0; g < CFEN_MAX_GROUPS; ++g) dg.g[g] = dp[g < ng ? g : 0];
   const long long nblk = (long long)d.B * (d.Hin / RY) * (d.Win / (16 * NX));
-  CFEN_LAUNCH((k_convT_tile<T, PIXB, TN, NX, RY>), dim3(cfen_grid8(nblk)), dim3(256), 0, s, d, (int)nblk);
+  CFEN_LAUNCH((k_convT_tile<T, PIXB, TN, NX, RY>), dim3(cfen_grid8(nblk), 1, ng), dim3(256), 0, s, dg, (int)nblk);
   CFEN_CHECK_LAUNCH("convT (tile)");
   return CFEN_OK;
 }
@@ -324,7 +343,14 @@ bool cfen_convT_tile_supported(int dtype, int cs_in, int Cout_pad, int Hin, int 
 
 int cfen_convT_tile_kpad(int dtype, int cs_in) { return 4 * convt_pixb(dtype, cs_in) / (dtype == 1 ? 2 : 4); }
 
-int cfen_convT_tile_impl(int dtype, const ConvDesc* d, hipStream_t s) {
+int cfen_convT_tile_impl(int dtype, const ConvDesc* d, hipStream_t s) { return cfen_convT_tile_impl_g(dtype, 1, d, s); }
+
+int cfen_convT_tile_impl_g(int dtype, int ng, const ConvDesc* dp, hipStream_t s) {
+  CFEN_CHECK_ARG(ng >= 1 && ng <= CFEN_MAX_GROUPS && dp, "convT (rows layout): 1..%d problems per launch", CFEN_MAX_GROUPS);
+  for (int g = 0; g < ng; ++g) {
+    const ConvDesc* d = dp + g;
+    CFEN_CHECK_ARG(d->B == dp->B && d->Hin == dp->Hin && d->Win == dp->Win && d->cs_in == dp->cs_in && d->Cout_pad == dp->Cout_pad,
+                   "convT (rows layout): grouped problems must have the same geometry");
   CFEN_CHECK_ARG(d->nphase == 4 && cfen_convT_tile_supported(dtype, d->cs_in, d->Cout_pad, d->Hin, d->Win),
                  "convT (rows layout): unsupported geometry cs_in=%d Cout_pad=%d %dx%d dtype=%d", d->cs_in, d->Cout_pad, d->Hin, d->Win, dtype);
   CFEN_CHECK_ARG(d->Kpad == cfen_convT_tile_kpad(dtype, d->cs_in), "convT (rows layout): Kpad=%d, expected %d", d->Kpad,
@@ -333,8 +359,9 @@ int cfen_convT_tile_impl(int dtype, const ConvDesc* d, hipStream_t s) {
                  cfen_aligned16(d->shift) && d->src[0] && d->weight && d->out && d->scale && d->shift, "convT: null or misaligned pointer");
   CFEN_CHECK_ARG(!d->res[0] && !d->res[1] && !d->out_nchw_f32 && d->cs_out % 4 == 0 && d->cs_out <= d->Cout_pad && d->act != 2,
                  "convT (rows layout): residuals / NCHW output / tanh unsupported");
-  const int pixb = convt_pixb(dtype, d->cs_in);
-  if (pixb == 64) return launch_convT_tile<half_t, 64, 1, 2, CT_RY>(*d, s);
-  if (pixb == 128) return launch_convT_tile<half_t, 128, 2, 2, CT_RY>(*d, s);
-  return launch_convT_tile<half_t, 192, 3, 1, CT_RY>(*d, s);
+  }
+  const int pixb = convt_pixb(dtype, dp->cs_in);
+  if (pixb == 64) return launch_convT_tile<half_t, 64, 1, 2, CT_RY>(ng, dp, s);
+  if (pixb == 128) return launch_convT_tile<half_t, 128, 2, 2, CT_RY>(ng, dp, s);
+  return launch_convT_tile<half_t, 192, 3, 1, CT_RY>(ng, dp, s);
 }

@@ -56,7 +56,6 @@ template <typename T> struct GemmArgs {
   // token m = (image, window, patch), k = (i, j, c) -> pixel (y + i, x + j), channel c.
   const T* gmap;
   int gH, gW, gcs, gC, gws, gp;
-  int wtiled;   // W is stored [N / 96][K / BK][96][BK]: one K-step of a 96-feature tile is one contiguous 12 KiB block
 };
 
 // pointer to channel 0 of the top-left pixel of token m's patch
@@ -130,7 +129,8 @@ constexpr int G_PIECES = G_BKB / 16;   // 16-byte pieces per row
 constexpr int G_LOADS = G_ROWS * G_PIECES / 256;   // 7 pieces per thread
 
 template <typename T>
-__global__ __launch_bounds__(256) void k_gemm_nt(GemmArgs<T> a) {
+__global__ __launch_bounds__(256) void k_gemm_nt(Grouped<GemmArgs<T>> ga) {
+  const GemmArgs<T>& a = ga.g[blockIdx.z];
   constexpr int EPL = Mma<T>::EPL;
   constexpr int BK = G_BKB / (int)sizeof(T);
   constexpr int NCH = BK / Mma<T>::KC;   // fragment chunks per stage (2)
@@ -223,7 +223,8 @@ CFEN_DEV void dma16(const void* g, unsigned char* l) {
 
 // NS LDS stages form a ring: NS - 1 K-steps of DMA are in flight while one is consumed, one barrier per K-step.
 template <typename T, int TM, int NS>   // block tile = 96 features x 32*TM tokens; a wave owns 3 x TM MFMA tiles
-__global__ __launch_bounds__(256) void k_gemm_dma(GemmArgs<T> a) {
+__global__ __launch_bounds__(256) void k_gemm_dma(Grouped<GemmArgs<T>> ga) {
+  const GemmArgs<T>& a = ga.g[blockIdx.z];
   constexpr int EPL = Mma<T>::EPL;
   constexpr int BK = G_BKB / (int)sizeof(T);
   constexpr int NCH = BK / Mma<T>::KC;   // 2
@@ -248,17 +249,16 @@ __global__ __launch_bounds__(256) void k_gemm_dma(GemmArgs<T> a) {
     const int row = i * 32 + wave * 8 + (lane >> 3), slot = lane & 7;
     const int piece = slot ^ (row & 7);
     const bool gx = a.gmap && row >= G_BN;   // gathered token row: gptr = patch origin, the piece offset is added per K-step
-    const T* base = row < G_BN ? (a.wtiled ? a.W + ((size_t)tn * (a.K / BK) * G_BN + row) * BK : a.W + (size_t)min(n0 + row, a.N - 1) * a.ldw)
+    const T* base = row < G_BN ? a.W + (size_t)min(n0 + row, a.N - 1) * a.ldw
                                : gx ? gather_pix(a, min(m0 + row - G_BN, a.M - 1)) : a.X + (size_t)min(m0 + row - G_BN, a.M - 1) * a.ldx;
     gptr[i] = gx ? base : base + piece * EPL;
     gpc[i] = gx ? piece * EPL : -1;
   }
 #define CFEN_GEMM_DMA_ISSUE(kt_, buf_)                                                                              \
   _Pragma("unroll") for (int i_ = 0; i_ < LOADS; ++i_)                                                              \
-      dma16(gptr[i_] + ((i_ >= 3 && gpc[i_] >= 0) ? gather_off(a, (kt_) * BK + gpc[i_]) : (kt_) * (i_ < 3 ? wstep : BK)),  \
+      dma16(gptr[i_] + ((i_ >= 3 && gpc[i_] >= 0) ? gather_off(a, (kt_) * BK + gpc[i_]) : (kt_) * BK),                       \
             lds + (buf_) * STAGE + (i_ * 256 + wave * 64) * 16)
 
-  const int wstep = a.wtiled ? G_BN * BK : BK;   // elements between consecutive K-steps of a weight row
   floatx4 acc[3][TM];
 #pragma unroll
   for (int i = 0; i < 3; ++i)
@@ -315,7 +315,8 @@ __global__ __launch_bounds__(256) void k_gemm_dma(GemmArgs<T> a) {
 // from global memory into MFMA fragments (32 contiguous bytes per lane per step), no staging, no barrier
 // in the loop.  Same epilogue as k_gemm_nt.
 template <typename T>
-__global__ __launch_bounds__(256) void k_gemm_skinny(GemmArgs<T> a) {
+__global__ __launch_bounds__(256) void k_gemm_skinny(Grouped<GemmArgs<T>> ga) {
+  const GemmArgs<T>& a = ga.g[blockIdx.z];
   constexpr int EPL = Mma<T>::EPL, KS = 2 * Mma<T>::KC;
   typedef typename Mma<T>::frag frag;
   __shared__ floatx4 red[4][4][64];
@@ -363,42 +364,50 @@ __global__ __launch_bounds__(256) void k_gemm_skinny(GemmArgs<T> a) {
 }
 
 template <typename T>
-int launch_gemm(const void* X, int ldx, const void* W, int ldw, const float* bias, const void* R, int ldr,
-                const void* P, int period, void* Y, int ldy, int M, int N, int K, int relu, hipStream_t s, const CfenTokGather* tg) {
+int launch_gemm(int ng, const CfenGemmPtrs* gp, int ldx, int ldw, int ldr, int period, int ldy, int M, int N, int K, int relu, hipStream_t s,
+                const CfenTokGather* tg) {
   constexpr int EPL = Mma<T>::EPL;
-  if (tg) {   // X and R are the patch tokens of an NHWC map
-    CFEN_CHECK_ARG(tg->map && cfen_aligned16(tg->map) && tg->C % EPL == 0 && tg->cs % EPL == 0 && tg->cs >= tg->C && tg->p > 0 &&
-                   tg->ws % tg->p == 0 && tg->H % tg->ws == 0 && tg->W % tg->ws == 0, "gemm (gather): bad token geometry");
-    CFEN_CHECK_ARG(K == tg->p * tg->p * tg->C && N == K && !R, "gemm (gather): needs N == K == p*p*C and no separate residual");
+  CFEN_CHECK_ARG(ng >= 1 && ng <= CFEN_MAX_GROUPS && gp, "gemm: 1..%d problems per launch", CFEN_MAX_GROUPS);
+  if (tg) {   // X and R are the patch tokens of an NHWC map (gp[g].gmap)
+    CFEN_CHECK_ARG(tg->C % EPL == 0 && tg->cs % EPL == 0 && tg->cs >= tg->C && tg->p > 0 && tg->ws % tg->p == 0 && tg->H % tg->ws == 0 &&
+                   tg->W % tg->ws == 0, "gemm (gather): bad token geometry");
+    CFEN_CHECK_ARG(K == tg->p * tg->p * tg->C && N == K, "gemm (gather): needs N == K == p*p*C");
     const int tw = tg->ws / tg->p;
     CFEN_CHECK_ARG(M == tg->B * (tg->H / tg->ws) * (tg->W / tg->ws) * tw * tw, "gemm (gather): M does not match the map");
-    X = tg->map; ldx = K;   // placeholders for the generic checks below
+    ldx = K;
   }
   CFEN_CHECK_ARG(M > 0 && N > 0 && K > 0, "gemm: empty problem M=%d N=%d K=%d", M, N, K);
   CFEN_CHECK_ARG(N % 4 == 0 && K % EPL == 0, "gemm: N (%d) must be a multiple of 4 and K (%d) of %d", N, K, EPL);
-  CFEN_CHECK_ARG(ldx % EPL == 0 && ldw % EPL == 0 && ldy % 4 == 0 && (!R || ldr % 4 == 0), "gemm: misaligned leading dimension");
-  CFEN_CHECK_ARG(ldx >= K && ldw >= K && ldy >= N && (!R || ldr >= N), "gemm: leading dimension smaller than row");
-  CFEN_CHECK_ARG(cfen_aligned16(X) && cfen_aligned16(W) && cfen_aligned16(Y) && cfen_aligned16(R) && cfen_aligned16(P) &&
-                 cfen_aligned16(bias), "gemm: pointers must be 16-byte aligned");
-  CFEN_CHECK_ARG(!P || period > 0, "gemm: position table needs a period");
-  GemmArgs<T> a{(const T*)X, (const T*)W, bias, (const T*)R, (const T*)P, (T*)Y, M, N, K, ldx, ldw, ldr, ldy, period, relu};
-  if (tg) {
-    a.gmap = (const T*)tg->map; a.gH = tg->H; a.gW = tg->W; a.gcs = tg->cs; a.gC = tg->C; a.gws = tg->ws; a.gp = tg->p;
+  CFEN_CHECK_ARG(ldx % EPL == 0 && ldw % EPL == 0 && ldy % 4 == 0 && ldx >= K && ldw >= K && ldy >= N, "gemm: bad leading dimension");
+  Grouped<GemmArgs<T>> ga;
+  memset(&ga, 0, sizeof(ga));
+  for (int g = 0; g < ng; ++g) {
+    const CfenGemmPtrs& q = gp[g];
+    CFEN_CHECK_ARG((tg ? (q.gmap && !q.R) : q.X != nullptr) && q.W && q.Y, "gemm: null operand (problem %d)", g);
+    CFEN_CHECK_ARG(!q.R || (ldr % 4 == 0 && ldr >= N), "gemm: bad residual leading dimension");
+    CFEN_CHECK_ARG(cfen_aligned16(q.X) && cfen_aligned16(q.W) && cfen_aligned16(q.Y) && cfen_aligned16(q.R) && cfen_aligned16(q.P) &&
+                   cfen_aligned16(q.bias) && cfen_aligned16(q.gmap), "gemm: pointers must be 16-byte aligned");
+    CFEN_CHECK_ARG(!q.P || period > 0, "gemm: position table needs a period");
+    CFEN_CHECK_ARG((q.R == nullptr) == (gp[0].R == nullptr) && (q.P == nullptr) == (gp[0].P == nullptr) && (q.bias == nullptr) == (gp[0].bias == nullptr),
+                   "gemm: grouped problems must use the same epilogue operands");
+    GemmArgs<T>& a = ga.g[g];
+    a.X = (const T*)(tg ? q.gmap : q.X); a.W = (const T*)q.W; a.bias = q.bias; a.R = (const T*)q.R; a.P = (const T*)q.P; a.Y = (T*)q.Y;
+    a.M = M; a.N = N; a.K = K; a.ldx = ldx; a.ldw = ldw; a.ldr = ldr; a.ldy = ldy; a.period = period; a.relu = relu;
+    if (tg) {
+      a.gmap = (const T*)q.gmap; a.gH = tg->H; a.gW = tg->W; a.gcs = tg->cs; a.gC = tg->C; a.gws = tg->ws; a.gp = tg->p;
+    }
   }
-  a.wtiled = cfen_tune_gemm_wtiled_experiment() && N % G_BN == 0;
   const int forced = cfen_tune_gemm_kernel();
   const bool k128 = (K * (int)sizeof(T)) % G_BKB == 0;
   CFEN_CHECK_ARG(forced <= 0 || k128, "gemm: k_gemm_skinny / k_gemm_dma need K * sizeof(T) %% 128 == 0");
   // Kernel choice from kernel times measured with COLD caches (tools/bench_gemm_cold.py: in the network the 540 MB of
   // weights stream from HBM, a warm-cache microbenchmark picks the wrong variants), MI355X, batch 8:
-  //   K not a multiple of 128 bytes (LViT level 1, K = 96)           -> register-staged k_gemm_nt (zero-fills the K tail)
+  //   K not a multiple of 128 bytes (LViT level 1, K = 96)            -> register-staged k_gemm_nt (zero-fills the K tail)
   //   <= 128 tokens against <= 2048 features (GViT-3 square / K-heavy) -> k_gemm_skinny (in-workgroup split-K)
-  //   >= 1024 tiles of 96 x 64 (LViT)                                 -> k_gemm_dma 96 x 64, 2 stages: occupancy (4 WG/CU) wins
-  //   few tiles (GViT: weight streaming, <= 2 workgroups per CU anyway) -> k_gemm_dma 96 x 32 with a 4-stage ring: what
-  //     bounds these is HBM latency x bytes in flight, and LDS is free to spend on it
-  //   in between                                                      -> k_gemm_dma 96 x 32, 2 stages
-  const long long tiles64 = (long long)((N + G_BN - 1) / G_BN) * ((M + 63) / 64);
-  const long long tiles32 = (long long)((N + G_BN - 1) / G_BN) * ((M + 31) / 32);
+  //   >= 1024 tiles of 96 x 64 per launch (LViT)                      -> k_gemm_dma 96 x 64: occupancy (4 WG/CU) wins
+  //   otherwise (GViT)                                                -> k_gemm_dma 96 x 32
+  const long long tiles64 = (long long)ng * ((N + G_BN - 1) / G_BN) * ((M + 63) / 64);
+  const long long tiles32 = (long long)ng * ((N + G_BN - 1) / G_BN) * ((M + 31) / 32);
   int kern = forced < 0 ? -1 : forced % 10, stages = forced < 0 ? 2 : 2 + forced / 10;
   if (kern < 0) {
     const int pick = !k128 ? 0 : (M <= 128 && N <= 2048 && !tg) ? 1 : tiles64 >= 1024 ? cfen_tune_gemm_large() : tiles32 <= 512 ? cfen_tune_gemm_small() : 5;
@@ -408,21 +417,21 @@ int launch_gemm(const void* X, int ldx, const void* W, int ldw, const float* bia
   CFEN_CHECK_ARG(!(tg && kern == 1), "gemm (gather): k_gemm_skinny does not gather");
   if (kern < 2) stages = 2;
   const int bn = kern == 1 ? 16 : G_BN, bm = kern == 0 || kern == 2 ? 128 : kern == 3 ? 96 : kern == 4 || kern == 1 ? 64 : 32;
-  a.map = make_tile_map((N + bn - 1) / bn, (M + bm - 1) / bm, (double)N * K * sizeof(T), (double)M * K * sizeof(T));
-  const long long blocks = 8LL * a.map.cn * a.map.cm;
+  const TileMap map = make_tile_map((N + bn - 1) / bn, (M + bm - 1) / bm, (double)N * K * sizeof(T), (double)M * K * sizeof(T));
+  for (int g = 0; g < ng; ++g) ga.g[g].map = map;
+  const long long blocks = 8LL * map.cn * map.cm;
   CFEN_CHECK_ARG(blocks < (1LL << 31), "gemm: problem too large for one launch");
-  const dim3 grid((unsigned)blocks);
+  const dim3 grid((unsigned)blocks, 1, (unsigned)ng);
   switch (kern + 10 * (stages - 2)) {
-    case 0: case 10: case 20: CFEN_LAUNCH(k_gemm_nt<T>, grid, dim3(256), 0, s, a); break;
-    case 1: case 11: case 21: CFEN_LAUNCH(k_gemm_skinny<T>, grid, dim3(256), 0, s, a); break;
-    case 2: case 12: case 22: CFEN_LAUNCH((k_gemm_dma<T, 4, 2>), grid, dim3(256), 0, s, a); break;
-    case 3: CFEN_LAUNCH((k_gemm_dma<T, 3, 2>), grid, dim3(256), 0, s, a); break;
-    case 13: case 23: CFEN_LAUNCH((k_gemm_dma<T, 3, 2>), grid, dim3(256), 0, s, a); break;
-    case 4: CFEN_LAUNCH((k_gemm_dma<T, 2, 2>), grid, dim3(256), 0, s, a); break;
-    case 14: case 24: CFEN_LAUNCH((k_gemm_dma<T, 2, 3>), grid, dim3(256), 0, s, a); break;
-    case 5: CFEN_LAUNCH((k_gemm_dma<T, 1, 2>), grid, dim3(256), 0, s, a); break;
-    case 15: CFEN_LAUNCH((k_gemm_dma<T, 1, 3>), grid, dim3(256), 0, s, a); break;
-    default: CFEN_LAUNCH((k_gemm_dma<T, 1, 4>), grid, dim3(256), 0, s, a); break;
+    case 0: case 10: case 20: CFEN_LAUNCH(k_gemm_nt<T>, grid, dim3(256), 0, s, ga); break;
+    case 1: case 11: case 21: CFEN_LAUNCH(k_gemm_skinny<T>, grid, dim3(256), 0, s, ga); break;
+    case 2: case 12: case 22: CFEN_LAUNCH((k_gemm_dma<T, 4, 2>), grid, dim3(256), 0, s, ga); break;
+    case 3: case 13: case 23: CFEN_LAUNCH((k_gemm_dma<T, 3, 2>), grid, dim3(256), 0, s, ga); break;
+    case 4: CFEN_LAUNCH((k_gemm_dma<T, 2, 2>), grid, dim3(256), 0, s, ga); break;
+    case 14: case 24: CFEN_LAUNCH((k_gemm_dma<T, 2, 3>), grid, dim3(256), 0, s, ga); break;
+    case 5: CFEN_LAUNCH((k_gemm_dma<T, 1, 2>), grid, dim3(256), 0, s, ga); break;
+    case 15: CFEN_LAUNCH((k_gemm_dma<T, 1, 3>), grid, dim3(256), 0, s, ga); break;
+    default: CFEN_LAUNCH((k_gemm_dma<T, 1, 4>), grid, dim3(256), 0, s, ga); break;
   }
   CFEN_CHECK_LAUNCH("gemm");
   return CFEN_OK;
@@ -430,10 +439,6 @@ int launch_gemm(const void* X, int ldx, const void* W, int ldw, const float* bia
 
 }  // namespace
 
-int& cfen_tune_gemm_wtiled_experiment() {
-  static int v = 0;
-  return v;
-}
 int& cfen_tune_gemm_large() {
   static int v = 4;
   return v;
@@ -447,20 +452,24 @@ int& cfen_tune_gemm_kernel() {
   return v;
 }
 
-int cfen_gemm_impl(int dtype, const void* X, int ldx, const void* W, int ldw, const float* bias, const void* R, int ldr,
-                   const void* P, int period, void* Y, int ldy, int M, int N, int K, int relu, hipStream_t s) {
-  if (dtype == 1) return launch_gemm<half_t>(X, ldx, W, ldw, bias, R, ldr, P, period, Y, ldy, M, N, K, relu, s, nullptr);
-  if (dtype == 0) return launch_gemm<float>(X, ldx, W, ldw, bias, R, ldr, P, period, Y, ldy, M, N, K, relu, s, nullptr);
+int cfen_gemm_impl_g(int dtype, int ng, const CfenGemmPtrs* gp, int ldx, int ldw, int ldr, int period, int ldy, int M, int N, int K, int relu,
+                     const CfenTokGather* tg, hipStream_t s) {
+  if (dtype == 1) return launch_gemm<half_t>(ng, gp, ldx, ldw, ldr, period, ldy, M, N, K, relu, s, tg);
+  if (dtype == 0) return launch_gemm<float>(ng, gp, ldx, ldw, ldr, period, ldy, M, N, K, relu, s, tg);
   cfen_set_error("gemm: unknown dtype %d", dtype);
   return CFEN_ERR_ARG;
+}
+
+int cfen_gemm_impl(int dtype, const void* X, int ldx, const void* W, int ldw, const float* bias, const void* R, int ldr,
+                   const void* P, int period, void* Y, int ldy, int M, int N, int K, int relu, hipStream_t s) {
+  const CfenGemmPtrs q{X, W, bias, R, P, Y, nullptr};
+  return cfen_gemm_impl_g(dtype, 1, &q, ldx, ldw, ldr, period, ldy, M, N, K, relu, nullptr, s);
 }
 
 int cfen_embed_gather_impl(int dtype, const CfenTokGather* tg, const void* W, int ldw, const float* bias, const void* P, int period,
                            void* Y, int ldy, int M, hipStream_t s) {
   CFEN_CHECK_ARG(tg != nullptr, "embed_gather: null geometry");
   const int D = tg->p * tg->p * tg->C;
-  if (dtype == 1) return launch_gemm<half_t>(nullptr, 0, W, ldw, bias, nullptr, 0, P, period, Y, ldy, M, D, D, 0, s, tg);
-  if (dtype == 0) return launch_gemm<float>(nullptr, 0, W, ldw, bias, nullptr, 0, P, period, Y, ldy, M, D, D, 0, s, tg);
-  cfen_set_error("embed_gather: unknown dtype %d", dtype);
-  return CFEN_ERR_ARG;
+  const CfenGemmPtrs q{nullptr, W, bias, nullptr, P, Y, tg->map};
+  return cfen_gemm_impl_g(dtype, 1, &q, D, ldw, 0, period, ldy, M, D, D, 0, tg, s);
 }

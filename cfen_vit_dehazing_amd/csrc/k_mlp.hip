@@ -38,7 +38,8 @@ template <> struct Pack<float> {
 // ND = D/16 n-tiles, TM = token tiles per wave, NW = waves per workgroup, HCH = hidden units per LDS stage
 // WPE = waves per SIMD the register allocation must leave room for
 template <typename T, int ND, int TM, int NW, int HCH, int WPE>
-__global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) void k_mlp(MlpArgs a) {
+__global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) void k_mlp(Grouped<MlpArgs> ga) {
+  const MlpArgs& a = ga.g[blockIdx.z];
   constexpr int KC = Mma<T>::KC, EPL = Mma<T>::EPL, SZ = (int)sizeof(T);
   constexpr int NPC = Pack<T>::NPC;
   constexpr int NT = NW * 64;
@@ -239,7 +240,10 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(WPE, WP
 }
 
 template <typename T, int ND, int TM, int NW, int HCH, int WPE>
-int launch_mlp_t(const MlpArgs& a, hipStream_t s) {
+int launch_mlp_t(int ng, const MlpArgs* ap, hipStream_t s) {
+  const MlpArgs& a = ap[0];
+  Grouped<MlpArgs> ga;
+  for (int g = 0; g < CFEN_MAX_GROUPS; ++g) ga.g[g] = ap[g < ng ? g : 0];
   constexpr int SZ = (int)sizeof(T), D = ND * 16;
   constexpr size_t smem = 2 * (size_t)(HCH * (D * SZ + 16) + D * (HCH * SZ + 16));
   CFEN_CHECK_ARG(a.H % HCH == 0, "mlp: hidden dim %d must be a multiple of %d", a.H, HCH);
@@ -254,13 +258,13 @@ int launch_mlp_t(const MlpArgs& a, hipStream_t s) {
     }
     attr_set = true;
   }
-  CFEN_LAUNCH((k_mlp<T, ND, TM, NW, HCH, WPE>), dim3((unsigned)blocks), dim3(NW * 64), smem, s, a);
+  CFEN_LAUNCH((k_mlp<T, ND, TM, NW, HCH, WPE>), dim3((unsigned)blocks, 1, ng), dim3(NW * 64), smem, s, ga);
   CFEN_CHECK_LAUNCH("mlp");
   return CFEN_OK;
 }
 
 template <typename T>
-int launch_mlp(const MlpArgs& a, hipStream_t s) {
+int check_mlp(const MlpArgs& a) {
   constexpr int KC = Mma<T>::KC;
   CFEN_CHECK_ARG(a.M > 0 && a.H > 0 && a.H % (2 * KC) == 0, "mlp: hidden dim %d must be a positive multiple of %d", a.H, 2 * KC);
   CFEN_CHECK_ARG(a.X && a.W1a && a.W2a && a.b1a && a.b2a, "mlp: null pointer");
@@ -275,15 +279,26 @@ int launch_mlp(const MlpArgs& a, hipStream_t s) {
   CFEN_CHECK_ARG(cfen_aligned16(a.X) && cfen_aligned16(a.Y) && cfen_aligned16(a.fmap) && cfen_aligned16(a.W1a) && cfen_aligned16(a.W2a) &&
                  cfen_aligned16(a.W1b) && cfen_aligned16(a.W2b) && cfen_aligned16(a.b1a) && cfen_aligned16(a.b2a) && cfen_aligned16(a.b1b) &&
                  cfen_aligned16(a.b2b) && cfen_aligned16(a.ln_g) && cfen_aligned16(a.ln_b), "mlp: pointers must be 16-byte aligned");
+  CFEN_CHECK_ARG(a.D == 96 || a.D == 192, "mlp: fused kernel supports D in {96,192}, got %d", a.D);
+  return CFEN_OK;
+}
+
+template <typename T>
+int launch_mlp(int ng, const MlpArgs* ap, hipStream_t s) {
+  constexpr int KC = Mma<T>::KC;
+  CFEN_CHECK_ARG(ng >= 1 && ng <= CFEN_MAX_GROUPS && ap, "mlp: 1..%d problems per launch", CFEN_MAX_GROUPS);
+  for (int g = 0; g < ng; ++g) {
+    int rc = check_mlp<T>(ap[g]);
+    if (rc) return rc;
+    CFEN_CHECK_ARG(ap[g].M == ap[0].M && ap[g].D == ap[0].D && ap[g].H == ap[0].H && (ap[g].W1b == nullptr) == (ap[0].W1b == nullptr) &&
+                   (ap[g].ln_g == nullptr) == (ap[0].ln_g == nullptr), "mlp: grouped problems must have the same shape");
+  }
   const int small = cfen_tune_mlp_small_tiles();
-  switch (a.D) {
-    case 96: return small ? launch_mlp_t<T, 6, 2, 4, 2 * KC, 2>(a, s)     // 128 tokens / WG, 2 waves per SIMD
-                          : launch_mlp_t<T, 6, 4, 4, 2 * KC, 1>(a, s);    // 256 tokens / WG, 24 KB stages
-    case 192: return small ? launch_mlp_t<T, 12, 1, 4, KC, 2>(a, s)       // 64 tokens / WG, 2 waves per SIMD
-                           : launch_mlp_t<T, 12, 2, 4, KC, 1>(a, s);      // 128 tokens / WG, 24 KB stages
-    default:
-      cfen_set_error("mlp: fused kernel supports D in {96,192}, got %d", a.D);
-      return CFEN_ERR_ARG;
+  switch (ap[0].D) {
+    case 96: return small ? launch_mlp_t<T, 6, 2, 4, 2 * KC, 2>(ng, ap, s)     // 128 tokens / WG, 2 waves per SIMD
+                          : launch_mlp_t<T, 6, 4, 4, 2 * KC, 1>(ng, ap, s);    // 256 tokens / WG, 24 KB stages
+    default: return small ? launch_mlp_t<T, 12, 1, 4, KC, 2>(ng, ap, s)        // 64 tokens / WG, 2 waves per SIMD
+                          : launch_mlp_t<T, 12, 2, 4, KC, 1>(ng, ap, s);       // 128 tokens / WG, 24 KB stages
   }
 }
 
@@ -298,9 +313,10 @@ int& cfen_tune_mlp_small_tiles() {
 
 bool cfen_mlp_supported(int D, int H, int dtype) { return (D == 96 || D == 192) && H % (dtype == 1 ? 64 : 32) == 0; }
 
-int cfen_mlp_impl(int dtype, const MlpArgs* a, hipStream_t s) {
-  if (dtype == 1) return launch_mlp<half_t>(*a, s);
-  if (dtype == 0) return launch_mlp<float>(*a, s);
+int cfen_mlp_impl_g(int dtype, int ng, const MlpArgs* a, hipStream_t s) {
+  if (dtype == 1) return launch_mlp<half_t>(ng, a, s);
+  if (dtype == 0) return launch_mlp<float>(ng, a, s);
   cfen_set_error("mlp: unknown dtype %d", dtype);
   return CFEN_ERR_ARG;
 }
+int cfen_mlp_impl(int dtype, const MlpArgs* a, hipStream_t s) { return cfen_mlp_impl_g(dtype, 1, a, s); }

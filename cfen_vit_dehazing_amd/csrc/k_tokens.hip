@@ -23,7 +23,9 @@ struct TokGeom {
 };
 
 template <typename T>
-__global__ __launch_bounds__(256) void k_patchify(const T* __restrict__ fmap, T* __restrict__ tok, TokGeom g, long long nvec) {
+__global__ __launch_bounds__(256) void k_patchify(PtrG<const T> fmapg, PtrG<T> tokg, TokGeom g, long long nvec) {
+  const T* __restrict__ fmap = fmapg.p[blockIdx.z];
+  T* __restrict__ tok = tokg.p[blockIdx.z];
   constexpr int EPL = Vec16<T>::N;
   const int cv = g.C / EPL;               // vectors per pixel
   const int D = g.p * g.p * g.C;
@@ -66,7 +68,9 @@ __global__ __launch_bounds__(256) void k_patchify(const T* __restrict__ fmap, T*
 }
 
 template <typename T>
-__global__ __launch_bounds__(256) void k_unpatchify(const T* __restrict__ tok, T* __restrict__ fmap, TokGeom g, long long nvec) {
+__global__ __launch_bounds__(256) void k_unpatchify(PtrG<const T> tokg, PtrG<T> fmapg, TokGeom g, long long nvec) {
+  const T* __restrict__ tok = tokg.p[blockIdx.z];
+  T* __restrict__ fmap = fmapg.p[blockIdx.z];
   constexpr int EPL = Vec16<T>::N;
   const int cv = g.C / EPL;
   const int D = g.p * g.p * g.C;
@@ -101,8 +105,10 @@ CFEN_DEV void up2_src(int dst, int n, int& i0, int& i1, float& w1) {
 }
 
 template <typename T>
-__global__ __launch_bounds__(256) void k_upsample4(const T* __restrict__ small, T* __restrict__ out, int B, int h, int w, int C,
+__global__ __launch_bounds__(256) void k_upsample4(PtrG<const T> smallg, PtrG<T> outg, int B, int h, int w, int C,
                                                    int cs_in, int cs_out, long long nvec) {
+  const T* __restrict__ small = smallg.p[blockIdx.z];
+  T* __restrict__ out = outg.p[blockIdx.z];
   constexpr int EPL = Vec16<T>::N;
   const int cv = C / EPL;
   const int H = 4 * h, W = 4 * w;
@@ -182,50 +188,70 @@ int check_geom(const TokGeom& g, const char* what) {
 }
 
 template <typename T>
-int run_patchify(const void* fmap, void* tok, TokGeom g, int inverse, hipStream_t s) {
+int run_patchify(int ng, const void* const* fmap, void* const* tok, TokGeom g, int inverse, hipStream_t s) {
   int rc = check_geom<T>(g, inverse ? "unpatchify" : "patchify");
   if (rc) return rc;
-  CFEN_CHECK_ARG(cfen_aligned16(fmap) && cfen_aligned16(tok), "patchify: pointers must be 16-byte aligned");
+  CFEN_CHECK_ARG(ng >= 1 && ng <= CFEN_MAX_GROUPS, "patchify: 1..%d problems per launch", CFEN_MAX_GROUPS);
   CFEN_CHECK_ARG(!(inverse && g.pool != 1), "unpatchify: pool must be 1");
+  PtrG<const T> src{};
+  PtrG<T> dst{};
+  for (int k = 0; k < ng; ++k) {
+    CFEN_CHECK_ARG(fmap[k] && tok[k] && cfen_aligned16(fmap[k]) && cfen_aligned16(tok[k]), "patchify: pointers must be non-null and 16-byte aligned");
+    src.p[k] = (const T*)(inverse ? tok[k] : fmap[k]);
+    dst.p[k] = (T*)(inverse ? const_cast<void*>(fmap[k]) : tok[k]);
+  }
   const long long nvec = (long long)g.B * g.H * g.W * g.C / Vec16<T>::N;
   if (inverse)
-    CFEN_LAUNCH(k_unpatchify<T>, dim3(grid_for(nvec)), dim3(256), 0, s, (const T*)tok, (T*)fmap, g, nvec);
+    CFEN_LAUNCH(k_unpatchify<T>, dim3(grid_for(nvec), 1, ng), dim3(256), 0, s, src, dst, g, nvec);
   else
-    CFEN_LAUNCH(k_patchify<T>, dim3(grid_for(nvec)), dim3(256), 0, s, (const T*)fmap, (T*)tok, g, nvec);
+    CFEN_LAUNCH(k_patchify<T>, dim3(grid_for(nvec), 1, ng), dim3(256), 0, s, src, dst, g, nvec);
   CFEN_CHECK_LAUNCH("patchify");
+  return CFEN_OK;
+}
+
+template <typename T>
+int run_upsample4(int ng, const void* const* small, void* const* out, int B, int h, int w, int C, int cs_in, int cs_out, hipStream_t s) {
+  constexpr int EPL = Vec16<T>::N;
+  CFEN_CHECK_ARG(B > 0 && h > 0 && w > 0 && C > 0, "upsample4: empty problem");
+  CFEN_CHECK_ARG(ng >= 1 && ng <= CFEN_MAX_GROUPS, "upsample4: 1..%d problems per launch", CFEN_MAX_GROUPS);
+  CFEN_CHECK_ARG(C % EPL == 0 && cs_in % EPL == 0 && cs_out % EPL == 0, "upsample4: channels must be multiples of %d", EPL);
+  PtrG<const T> src{};
+  PtrG<T> dst{};
+  for (int k = 0; k < ng; ++k) {
+    CFEN_CHECK_ARG(small[k] && out[k] && cfen_aligned16(small[k]) && cfen_aligned16(out[k]), "upsample4: pointers must be non-null and 16-byte aligned");
+    src.p[k] = (const T*)small[k]; dst.p[k] = (T*)out[k];
+  }
+  const long long nvec = (long long)B * 16 * h * w * (C / EPL);
+  CFEN_LAUNCH(k_upsample4<T>, dim3(grid_for(nvec), 1, ng), dim3(256), 0, s, src, dst, B, h, w, C, cs_in, cs_out, nvec);
+  CFEN_CHECK_LAUNCH("upsample4");
   return CFEN_OK;
 }
 
 }  // namespace
 
-int cfen_patchify_impl(int dtype, const void* fmap, void* tok, int B, int H, int W, int C, int cs, int ws, int p, int pool,
-                       int inverse, hipStream_t s) {
+// inverse: fmap[] are the maps written from tok[]
+int cfen_patchify_impl_g(int dtype, int ng, const void* const* fmap, void* const* tok, int B, int H, int W, int C, int cs, int ws, int p, int pool,
+                         int inverse, hipStream_t s) {
   TokGeom g{B, H, W, C, cs, ws, p, pool};
-  if (dtype == 1) return run_patchify<half_t>(fmap, tok, g, inverse, s);
-  if (dtype == 0) return run_patchify<float>(fmap, tok, g, inverse, s);
+  if (dtype == 1) return run_patchify<half_t>(ng, fmap, tok, g, inverse, s);
+  if (dtype == 0) return run_patchify<float>(ng, fmap, tok, g, inverse, s);
   cfen_set_error("patchify: unknown dtype %d", dtype);
   return CFEN_ERR_ARG;
 }
+int cfen_patchify_impl(int dtype, const void* fmap, void* tok, int B, int H, int W, int C, int cs, int ws, int p, int pool,
+                       int inverse, hipStream_t s) {
+  return cfen_patchify_impl_g(dtype, 1, &fmap, &tok, B, H, W, C, cs, ws, p, pool, inverse, s);
+}
 
+int cfen_upsample4_impl_g(int dtype, int ng, const void* const* small, void* const* out, int B, int h, int w, int C, int cs_in, int cs_out,
+                          hipStream_t s) {
+  if (dtype == 1) return run_upsample4<half_t>(ng, small, out, B, h, w, C, cs_in, cs_out, s);
+  if (dtype == 0) return run_upsample4<float>(ng, small, out, B, h, w, C, cs_in, cs_out, s);
+  cfen_set_error("upsample4: unknown dtype %d", dtype);
+  return CFEN_ERR_ARG;
+}
 int cfen_upsample4_impl(int dtype, const void* small, void* out, int B, int h, int w, int C, int cs_in, int cs_out, hipStream_t s) {
-  CFEN_CHECK_ARG(B > 0 && h > 0 && w > 0 && C > 0, "upsample4: empty problem");
-  CFEN_CHECK_ARG(cfen_aligned16(small) && cfen_aligned16(out), "upsample4: pointers must be 16-byte aligned");
-  if (dtype == 1) {
-    CFEN_CHECK_ARG(C % 8 == 0 && cs_in % 8 == 0 && cs_out % 8 == 0, "upsample4: channels must be multiples of 8");
-    long long nvec = (long long)B * 16 * h * w * (C / 8);
-    CFEN_LAUNCH(k_upsample4<half_t>, dim3(grid_for(nvec)), dim3(256), 0, s, (const half_t*)small, (half_t*)out, B, h, w, C, cs_in,
-                       cs_out, nvec);
-  } else if (dtype == 0) {
-    CFEN_CHECK_ARG(C % 4 == 0 && cs_in % 4 == 0 && cs_out % 4 == 0, "upsample4: channels must be multiples of 4");
-    long long nvec = (long long)B * 16 * h * w * (C / 4);
-    CFEN_LAUNCH(k_upsample4<float>, dim3(grid_for(nvec)), dim3(256), 0, s, (const float*)small, (float*)out, B, h, w, C, cs_in,
-                       cs_out, nvec);
-  } else {
-    cfen_set_error("upsample4: unknown dtype %d", dtype);
-    return CFEN_ERR_ARG;
-  }
-  CFEN_CHECK_LAUNCH("upsample4");
-  return CFEN_OK;
+  return cfen_upsample4_impl_g(dtype, 1, &small, &out, B, h, w, C, cs_in, cs_out, s);
 }
 
 int cfen_nchw_to_nhwc_impl(int dtype, const float* in, void* out, int B, int C, int H, int W, int cs, hipStream_t s) {
