@@ -29,6 +29,11 @@ class ConvArgsC(ctypes.Structure):
                [(n, c_void_p) for n in ("src0", "src1", "weight", "scale", "shift", "res0", "res1", "out")]
 
 
+class EmbedQkvArgsC(ctypes.Structure):
+    _fields_ = [("fmap", c_void_p)] + [(n, ctypes.c_int32) for n in ("B", "H", "W", "C", "cs", "ws", "p")] + \
+               [(n, c_void_p) for n in ("we", "be", "pos", "ln_gamma", "ln_beta", "wqkv", "x1", "qkv")] + [("eps", c_float)]
+
+
 class MlpArgsC(ctypes.Structure):
     _fields_ = [(n, c_void_p) for n in ("x", "y", "fmap", "ln_gamma", "ln_beta", "w1a", "b1a", "w2a", "b2a", "w1b", "b1b", "w2b", "b2b")] + \
                [("M", ctypes.c_int64), ("D", ctypes.c_int32), ("H", ctypes.c_int32), ("eps", c_float)] + \
@@ -58,6 +63,7 @@ SIGNATURES = {
     "cfen_net_flops_per_image": (ctypes.c_double, [_P]),
     "cfen_gemm_nt": (_I, [_I, _P, _I, _P, _I, _P, _P, _I, _P, _I, _P, _I, _I, _I, _I, _I, _P]),
     "cfen_embed_gather": (_I, [_I, _P, _I, _I, _I, _I, _I, _I, _I, _P, _I, _P, _P, _I, _P, _I, _P]),
+    "cfen_embed_qkv": (_I, [_I, ctypes.POINTER(EmbedQkvArgsC), _P]),
     "cfen_layernorm": (_I, [_I, _P, _P, _P, _P, _I, _I, c_float, _P]),
     "cfen_attention": (_I, [_I, _P, _P, _I, _I, _I, _I, _P]),
     "cfen_mlp_block": (_I, [_I, ctypes.POINTER(MlpArgsC), _P]),

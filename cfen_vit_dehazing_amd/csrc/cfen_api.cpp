@@ -81,6 +81,16 @@ int cfen_embed_gather(int dtype, const void* fmap, int B, int H, int W, int C, i
   return cfen_embed_gather_impl(dtype, &tg, weight, ldw, bias, pos, period, Y, ldy, B * (H / ws) * (W / ws) * tw * tw, (hipStream_t)stream);
 }
 
+int cfen_embed_qkv(int dtype, const cfen_embed_qkv_args* a, void* stream) {
+  CFEN_CHECK_ARG(a != nullptr, "embed_qkv: null args");
+  CFEN_CHECK_ARG(a->B > 0 && a->ws > 0 && a->p > 0 && a->ws % a->p == 0 && a->H > 0 && a->W > 0 && a->H % a->ws == 0 && a->W % a->ws == 0,
+                 "embed_qkv: bad geometry");
+  const int tw = a->ws / a->p;
+  CfenEmbedQkvArgs q{a->fmap, a->B, a->H, a->W, a->C, a->cs, a->ws, a->p, a->we, a->be, a->pos, a->ln_gamma, a->ln_beta, a->wqkv, a->x1, a->qkv,
+                     (long long)a->B * (a->H / a->ws) * (a->W / a->ws) * tw * tw, a->p * a->p * a->C, a->eps};
+  return cfen_embed_qkv_impl_g(dtype, 1, &q, (hipStream_t)stream);
+}
+
 int cfen_tune(const char* key, int value) {
   CFEN_CHECK_ARG(key != nullptr, "tune: null key");
   if (!strcmp(key, "gemm.kernel")) {
@@ -91,6 +101,10 @@ int cfen_tune(const char* key, int value) {
   if (!strcmp(key, "gemm.large") || !strcmp(key, "gemm.small")) {
     CFEN_CHECK_ARG(value % 10 >= 2 && value % 10 <= 5 && value >= 2 && value <= 25, "tune: %s must be tile 2 .. 5 (+10 / +20 for 3 / 4 LDS stages)", key);
     (key[5] == 'l' ? cfen_tune_gemm_large() : cfen_tune_gemm_small()) = value;
+    return CFEN_OK;
+  }
+  if (!strcmp(key, "net.fused_front_max_dim")) {
+    cfen_tune_fused_front_max_dim() = value;
     return CFEN_OK;
   }
   if (!strcmp(key, "net.skip_classes")) {

@@ -12,6 +12,17 @@ int cfen_gemm_impl(int dtype, const void* X, int ldx, const void* W, int ldw, co
 struct CfenTokGather { const void* map; int B, H, W, C, cs, ws, p; };
 int cfen_embed_gather_impl(int dtype, const CfenTokGather* tg, const void* W, int ldw, const float* bias, const void* P, int period,
                            void* Y, int ldy, int M, hipStream_t s);
+// LViT front half fused (k_embed.hip): gather + linear_encoding + residual + position + LayerNorm + qkv projection
+struct CfenEmbedQkvArgs {
+  const void* fmap; int B, H, W, C, cs, ws, p;        // NHWC map the patch tokens are gathered from
+  const void* We; const float* be; const void* pos;   // [D][D] (k axis in packing.kperm32 order for fp16), [D], [S][D]
+  const float* ln_g; const float* ln_b;
+  const void* Wqkv;                                   // [3D][D], k axis as We
+  void* X1; void* QKV;                                // [M][D], [M][3D]
+  long long M; int D; float eps;
+};
+bool cfen_embed_qkv_supported(int D);
+int cfen_embed_qkv_impl_g(int dtype, int ng, const CfenEmbedQkvArgs* a, hipStream_t s);
 // grouped launches (cfen_common.hpp: CFEN_MAX_GROUPS problems of identical geometry, one launch)
 struct CfenGemmPtrs { const void* X; const void* W; const float* bias; const void* R; const void* P; void* Y; const void* gmap; };
 int cfen_gemm_impl_g(int dtype, int ng, const CfenGemmPtrs* gp, int ldx, int ldw, int ldr, int period, int ldy, int M, int N, int K, int relu,
@@ -50,3 +61,4 @@ int& cfen_tune_gemm_small();    // ... and for smaller ones ("gemm.small")
 int& cfen_tune_embed_gather();  // 1 (default): LViT embedding gathers its tokens from the map; 0: separate k_patchify ("net.embed_gather")
 int& cfen_tune_mlp_small_tiles();   // 1: fused MLP with half-size token tiles per wave (more waves in flight) ("mlp.small_tiles")
 int& cfen_tune_skip_classes();    // bit mask of kernel classes NOT launched by the net (marginal-cost timing; outputs invalid) ("net.skip_classes")
+int& cfen_tune_fused_front_max_dim();   // k_embed_qkv is used for LViT embedding dims <= this (0 = never) ("net.fused_front_max_dim")

@@ -21,6 +21,10 @@ int& cfen_tune_skip_classes() {
   static int v = 0;
   return v;
 }
+int& cfen_tune_fused_front_max_dim() {
+  static int v = 192;
+  return v;
+}
 int& cfen_tune_embed_gather() {
   static int v = 1;
   return v;
@@ -43,6 +47,7 @@ struct Vit {
   int mapH;   // edge of the map the tokens tile (pooled edge for GViT)
   int ws;     // window edge on that map
   bool fused_mlp;   // LN2+FFN+mlp_head+fold run as one k_mlp launch
+  bool fused_front; // gather+embedding+LN1+qkv run as one k_embed_qkv launch
 };
 struct ConvLayer {
   int kind, k, stride, pad, reflect, nsrc, Cin, Cin_real, Cout, Cout_pad, Kpad, nphase, ntaps, out_edge;
@@ -234,6 +239,7 @@ int cfen_net::build() {
   size_t max_md_l = 0, max_mh_l = 0, max_md_g = 0, max_mh_g = 0, max_small = 0;
   for (Vit& v : vits) {
     v.fused_mlp = !v.global && cfen_mlp_supported(v.D, v.hidden, cfg.dtype);
+    v.fused_front = !v.global && cfen_embed_qkv_supported(v.D);
     CFEN_CHECK_ARG(v.mapH % v.ws == 0 && v.ws % v.p == 0 && v.S >= 1, "net: %s does not tile its map", v.name.c_str());
     const size_t ntok = (size_t)B * (v.mapH / v.ws) * (v.mapH / v.ws) * v.S;
     (v.global ? max_md_g : max_md_l) = std::max(v.global ? max_md_g : max_md_l, ntok * v.D);
@@ -241,6 +247,7 @@ int cfen_net::build() {
     if (v.global) max_small = std::max(max_small, (size_t)B * v.mapH * v.mapH * v.C);
     const std::string& n = v.name;
     need(n + ".embed.w", (size_t)v.D * v.D * esz); need(n + ".embed.b", (size_t)v.D * 4);
+    if (v.fused_front) { need(n + ".embed.wk", (size_t)v.D * v.D * esz); need(n + ".qkv.wk", (size_t)3 * v.D * v.D * esz); }
     need(n + ".pos", (size_t)v.S * v.D * esz);
     need(n + ".ln1.g", (size_t)v.D * 4); need(n + ".ln1.b", (size_t)v.D * 4);
     need(n + ".qkv.w", (size_t)3 * v.D * v.D * esz);
@@ -383,7 +390,7 @@ int cfen_net::run_vit_g(int ng, const VitCall* vc, int scr0) {
   for (int g = 0; g < ng; ++g) {
     const Vit& w = *vc[g].v;
     CFEN_CHECK_ARG(w.global == v.global && w.D == v.D && w.hidden == v.hidden && w.S == v.S && w.mapH == v.mapH && w.heads == v.heads &&
-                   w.fused_mlp == v.fused_mlp && bufs.at(vc[g].in).cs == bi.cs && bufs.at(vc[g].out).cs == bo.cs,
+                   w.fused_mlp == v.fused_mlp && w.fused_front == v.fused_front && bufs.at(vc[g].in).cs == bi.cs && bufs.at(vc[g].out).cs == bo.cs,
                    "net: %s and %s cannot share launches", v.name.c_str(), w.name.c_str());
     const Scratch& q = scr_set[scr0 + 2 * g];
     X0[g] = at(q.x0); X1[g] = at(q.x1); YN[g] = at(q.yn); QKV[g] = at(q.qkv); ATT[g] = at(q.att); HID[g] = at(q.hid);
@@ -403,26 +410,36 @@ int cfen_net::run_vit_g(int ng, const VitCall* vc, int scr0) {
                            pname ? P(nm[g] + pname) : nullptr, Y[g], tg ? IN[g] : nullptr};
     return cfen_gemm_impl_g(dt, ng, gp, K, K, N, v.S, N, M, N, K, relu, tg, stream);
   };
-  if (v.global || !cfen_tune_embed_gather()) {
-    step("patchify");
-    TRYP(K_TOKEN, 0, cfen_patchify_impl_g(dt, ng, IN, X0, B, v.mapH, v.mapH, v.C, bi.cs, v.ws, v.p, v.global ? 4 : 1, 0, stream));
-    // x = linear_encoding(x) + x + pos                                      (v3:1143,1166)
-    step("embed");
-    TRYP(K_GEMM, 2 * Md * D * D, gemm(cX0, ".embed.w", ".embed.b", X0, ".pos", X1, v.D, v.D, 0, nullptr));
-  } else {
-    // LViT: the window / patch gather rides on the embedding GEMM's loader, no token buffer is written
-    step("embed");
-    CfenTokGather tg{nullptr, B, v.mapH, v.mapH, v.C, bi.cs, v.ws, v.p};
-    TRYP(K_GEMM, 2 * Md * D * D, gemm(nullptr, ".embed.w", ".embed.b", nullptr, ".pos", X1, v.D, v.D, 0, &tg));
-  }
   const float* lg[3];
   const float* lb[3];
-  // src = src + out_proj(MHA(LN1(src)))                                      (v3:1383-1386)
-  step("ln1");
-  for (int g = 0; g < ng; ++g) { lg[g] = Pf(nm[g] + ".ln1.g"); lb[g] = Pf(nm[g] + ".ln1.b"); }
-  TRYP(K_LNORM, 0, cfen_layernorm_impl_g(dt, ng, cX1, YN, lg, lb, M, v.D, 1e-5f, stream));
-  step("qkv");
-  TRYP(K_GEMM, 6 * Md * D * D, gemm(cYN, ".qkv.w", nullptr, nullptr, nullptr, QKV, 3 * v.D, v.D, 0, nullptr));
+  if (v.fused_front && v.D <= cfen_tune_fused_front_max_dim()) {
+    // LViT levels 1-2: gather + linear_encoding + residual + position + LN1 + qkv in one launch, x -> X1, QKV (k_embed.hip)
+    CfenEmbedQkvArgs e[3];
+    for (int g = 0; g < ng; ++g)
+      e[g] = CfenEmbedQkvArgs{IN[g], B, v.mapH, v.mapH, v.C, bi.cs, v.ws, v.p, P(nm[g] + ".embed.wk"), Pf(nm[g] + ".embed.b"), P(nm[g] + ".pos"),
+                              Pf(nm[g] + ".ln1.g"), Pf(nm[g] + ".ln1.b"), P(nm[g] + ".qkv.wk"), X1[g], QKV[g], M, v.D, 1e-5f};
+    step("embed_ln_qkv");
+    TRYP(K_GEMM, 8 * Md * D * D, cfen_embed_qkv_impl_g(dt, ng, e, stream));
+  } else {
+    if (v.global || !cfen_tune_embed_gather()) {
+      step("patchify");
+      TRYP(K_TOKEN, 0, cfen_patchify_impl_g(dt, ng, IN, X0, B, v.mapH, v.mapH, v.C, bi.cs, v.ws, v.p, v.global ? 4 : 1, 0, stream));
+      // x = linear_encoding(x) + x + pos                                      (v3:1143,1166)
+      step("embed");
+      TRYP(K_GEMM, 2 * Md * D * D, gemm(cX0, ".embed.w", ".embed.b", X0, ".pos", X1, v.D, v.D, 0, nullptr));
+    } else {
+      // LViT: the window / patch gather rides on the embedding GEMM's loader, no token buffer is written
+      step("embed");
+      CfenTokGather tg{nullptr, B, v.mapH, v.mapH, v.C, bi.cs, v.ws, v.p};
+      TRYP(K_GEMM, 2 * Md * D * D, gemm(nullptr, ".embed.w", ".embed.b", nullptr, ".pos", X1, v.D, v.D, 0, &tg));
+    }
+    // src = src + out_proj(MHA(LN1(src)))                                      (v3:1383-1386)
+    step("ln1");
+    for (int g = 0; g < ng; ++g) { lg[g] = Pf(nm[g] + ".ln1.g"); lb[g] = Pf(nm[g] + ".ln1.b"); }
+    TRYP(K_LNORM, 0, cfen_layernorm_impl_g(dt, ng, cX1, YN, lg, lb, M, v.D, 1e-5f, stream));
+    step("qkv");
+    TRYP(K_GEMM, 6 * Md * D * D, gemm(cYN, ".qkv.w", nullptr, nullptr, nullptr, QKV, 3 * v.D, v.D, 0, nullptr));
+  }
   step("attention");
   TRYP(K_ATTN, 4 * Md * v.S * D, cfen_attention_impl_g(dt, ng, cQKV, ATT, B * nwin, v.S, v.heads, v.D / v.heads, stream));
   step("proj");

@@ -1,0 +1,192 @@
+// LViT front half in one launch (levels 1 and 2, D = 96 / 192):
+//     x   = patch tokens gathered from the NHWC map               (Crop2x2 + F.unfold, v3:1025-1056, 1140)
+//     y   = W_e x + b_e + x + pos[token % S]                      (linear_encoding + residual + position, v3:1143, 1166)   -> X1
+//     qkv = W_qkv LayerNorm(y)                                    (norm1 + in_proj of nn.MultiheadAttention, v3:1364-1371) -> QKV
+// replacing patchify + embedding GEMM + LayerNorm + qkv GEMM and their three intermediate tensors.  Same structure as
+// k_mlp.hip: a wave owns TM*16 tokens whose features live in fp32 MFMA accumulators (rows = features, columns = tokens);
+// an accumulator tile pair IS the B operand of the next GEMM (weights' k axis pre-permuted on the host, packing.kperm32),
+// LayerNorm reduces over a lane's registers + two lane swaps.  The weights (18 + 55 KB at D = 96) are read as MFMA A
+// fragments straight from L1/L2 -- every wave of the chip reads the same few kilobytes.
+#include "cfen_common.hpp"
+#include "cfen_internal.hpp"
+
+namespace {
+
+template <typename T> struct PackB;
+template <> struct PackB<half_t> {
+  static constexpr int NPC = 2;   // accumulator n-tiles per K chunk
+  static CFEN_DEV half8 make(const floatx4* t) {
+    half8 f = {(half_t)t[0][0], (half_t)t[0][1], (half_t)t[0][2], (half_t)t[0][3],
+               (half_t)t[1][0], (half_t)t[1][1], (half_t)t[1][2], (half_t)t[1][3]};
+    return f;
+  }
+};
+template <> struct PackB<float> {
+  static constexpr int NPC = 1;
+  static CFEN_DEV floatx4 make(const floatx4* t) { return t[0]; }
+};
+
+template <typename T, int ND, int TM, int NW>
+__global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_embed_qkv(Grouped<CfenEmbedQkvArgs> ga) {
+  const CfenEmbedQkvArgs& a = ga.g[blockIdx.z];
+  constexpr int KC = Mma<T>::KC, EPL = Mma<T>::EPL;
+  constexpr int NPC = PackB<T>::NPC;
+  constexpr int D = ND * 16;
+  constexpr int NCH = ND / NPC;
+  typedef typename Mma<T>::frag frag;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, r16 = lane & 15, h = lane >> 4;
+  const long long tok0 = ((long long)blockIdx.x * NW + wave) * (TM * 16);
+  if (tok0 >= a.M) return;
+
+  // ---- gather x^T into accumulator layout: acc[i][j][r] = tok[token j*16 + r16][feature i*16 + 4h + r] ----
+  const int tw = a.ws / a.p, S = tw * tw, nwx = a.W / a.ws, nwy = a.H / a.ws;
+  floatx4 acc[ND][TM];
+  long long tk[TM];
+#pragma unroll
+  for (int j = 0; j < TM; ++j) {
+    long long t = tok0 + j * 16 + r16;
+    if (t >= a.M) t = a.M - 1;
+    tk[j] = t;
+    const int tt = (int)(t % S);
+    const long long wi = t / S;
+    const int wx = (int)(wi % nwx), wy = (int)((wi / nwx) % nwy);
+    const long long b = wi / ((long long)nwx * nwy);
+    const int y0 = wy * a.ws + (tt / tw) * a.p, x0 = wx * a.ws + (tt % tw) * a.p;
+    const T* pix = (const T*)a.fmap + ((b * a.H + y0) * a.W + x0) * a.cs;
+#pragma unroll
+    for (int i = 0; i < ND; ++i) {
+      const int f = i * 16 + 4 * h;
+      const int ij = f / a.C, c = f - ij * a.C;
+      acc[i][j] = load4<T>(pix + ((ij / a.p) * a.W + (ij % a.p)) * a.cs + c);
+    }
+  }
+  frag xb[NCH][TM];
+#pragma unroll
+  for (int j = 0; j < TM; ++j)
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+      floatx4 t[NPC];
+#pragma unroll
+      for (int u = 0; u < NPC; ++u) t[u] = acc[c * NPC + u][j];
+      xb[c][j] = PackB<T>::make(t);
+    }
+
+  // ---- y = W_e x + b_e + x + pos ----
+  const T* We = (const T*)a.We + (size_t)r16 * D + h * EPL;
+#pragma unroll
+  for (int i = 0; i < ND; ++i) {
+    const floatx4 bb = *reinterpret_cast<const floatx4*>(a.be + i * 16 + 4 * h);
+#pragma unroll
+    for (int j = 0; j < TM; ++j) acc[i][j] += bb + load4<T>((const T*)a.pos + (size_t)(tk[j] % S) * D + i * 16 + 4 * h);
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+      const frag af = load_frag<T>(We + (size_t)i * 16 * D + c * KC);
+#pragma unroll
+      for (int j = 0; j < TM; ++j) acc[i][j] = Mma<T>::mma(af, xb[c][j], acc[i][j]);
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < TM; ++j) {
+    if (tok0 + j * 16 + r16 >= a.M) continue;
+    T* yp = (T*)a.X1 + tk[j] * D + 4 * h;
+#pragma unroll
+    for (int i = 0; i < ND; ++i) store4<T>(yp + i * 16, acc[i][j]);
+  }
+
+  // ---- LayerNorm(y) -> B fragments (two passes over registers, statistics in fp32) ----
+#pragma unroll
+  for (int j = 0; j < TM; ++j) {
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < ND; ++i) s += acc[i][j][0] + acc[i][j][1] + acc[i][j][2] + acc[i][j][3];
+    s = col_sum(s);
+    const float mean = s * (1.f / D);
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < ND; ++i)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float d = acc[i][j][r] - mean;
+        q += d * d;
+      }
+    q = col_sum(q);
+    const float rstd = rsqrtf(q * (1.f / D) + a.eps);
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+      floatx4 t[NPC];
+#pragma unroll
+      for (int u = 0; u < NPC; ++u) {
+        const int i = c * NPC + u;
+        const floatx4 g = *reinterpret_cast<const floatx4*>(a.ln_g + i * 16 + 4 * h);
+        const floatx4 b = *reinterpret_cast<const floatx4*>(a.ln_b + i * 16 + 4 * h);
+        t[u] = (acc[i][j] - mean) * rstd * g + b;
+      }
+      xb[c][j] = PackB<T>::make(t);
+    }
+  }
+
+  // ---- qkv = W_qkv LN(y): 3D output features, one 16-feature tile at a time, straight to HBM ----
+  const T* Wq = (const T*)a.Wqkv + (size_t)r16 * D + h * EPL;
+#pragma unroll 2
+  for (int i = 0; i < 3 * ND; ++i) {
+    floatx4 q[TM];
+#pragma unroll
+    for (int j = 0; j < TM; ++j) q[j] = floatx4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+      const frag af = load_frag<T>(Wq + (size_t)i * 16 * D + c * KC);
+#pragma unroll
+      for (int j = 0; j < TM; ++j) q[j] = Mma<T>::mma(af, xb[c][j], q[j]);
+    }
+#pragma unroll
+    for (int j = 0; j < TM; ++j)
+      if (tok0 + j * 16 + r16 < a.M) store4<T>((T*)a.QKV + tk[j] * (3 * D) + i * 16 + 4 * h, q[j]);
+  }
+}
+
+template <typename T, int ND, int TM>
+int launch_embed_qkv(int ng, const CfenEmbedQkvArgs* ap, hipStream_t s) {
+  constexpr int NW = 4;
+  Grouped<CfenEmbedQkvArgs> ga;
+  for (int g = 0; g < CFEN_MAX_GROUPS; ++g) ga.g[g] = ap[g < ng ? g : 0];
+  const long long per = (long long)NW * TM * 16, blocks = (ap[0].M + per - 1) / per;
+  CFEN_CHECK_ARG(blocks > 0 && blocks < (1ll << 31), "embed_qkv: bad grid");
+  CFEN_LAUNCH((k_embed_qkv<T, ND, TM, NW>), dim3((unsigned)blocks, 1, ng), dim3(NW * 64), 0, s, ga);
+  CFEN_CHECK_LAUNCH("embed_qkv");
+  return CFEN_OK;
+}
+
+template <typename T>
+int run_embed_qkv(int ng, const CfenEmbedQkvArgs* ap, hipStream_t s) {
+  constexpr int EPL = Mma<T>::EPL;
+  CFEN_CHECK_ARG(ng >= 1 && ng <= CFEN_MAX_GROUPS && ap, "embed_qkv: 1..%d problems per launch", CFEN_MAX_GROUPS);
+  for (int g = 0; g < ng; ++g) {
+    const CfenEmbedQkvArgs& a = ap[g];
+    CFEN_CHECK_ARG(a.fmap && a.We && a.be && a.pos && a.ln_g && a.ln_b && a.Wqkv && a.X1 && a.QKV, "embed_qkv: null pointer");
+    CFEN_CHECK_ARG(cfen_aligned16(a.fmap) && cfen_aligned16(a.We) && cfen_aligned16(a.be) && cfen_aligned16(a.pos) && cfen_aligned16(a.ln_g) &&
+                   cfen_aligned16(a.ln_b) && cfen_aligned16(a.Wqkv) && cfen_aligned16(a.X1) && cfen_aligned16(a.QKV), "embed_qkv: pointers must be 16-byte aligned");
+    CFEN_CHECK_ARG(a.C > 0 && a.C % EPL == 0 && a.C % 4 == 0 && a.cs % EPL == 0 && a.cs >= a.C && a.p > 0 && a.ws % a.p == 0 && a.H % a.ws == 0 &&
+                   a.W % a.ws == 0 && a.B > 0, "embed_qkv: bad token geometry");
+    const int tw = a.ws / a.p;
+    CFEN_CHECK_ARG(a.D == a.p * a.p * a.C && a.M == (long long)a.B * (a.H / a.ws) * (a.W / a.ws) * tw * tw, "embed_qkv: D / M do not match the map");
+    CFEN_CHECK_ARG(a.D == ap[0].D && a.M == ap[0].M, "embed_qkv: grouped problems must have the same shape");
+  }
+  switch (ap[0].D) {
+    case 96: return launch_embed_qkv<T, 6, 4>(ng, ap, s);
+    case 192: return launch_embed_qkv<T, 12, 2>(ng, ap, s);
+    default:
+      cfen_set_error("embed_qkv: fused kernel supports D in {96,192}, got %d", ap[0].D);
+      return CFEN_ERR_ARG;
+  }
+}
+
+}  // namespace
+
+bool cfen_embed_qkv_supported(int D) { return D == 96 || D == 192; }
+
+int cfen_embed_qkv_impl_g(int dtype, int ng, const CfenEmbedQkvArgs* a, hipStream_t s) {
+  if (dtype == 1) return run_embed_qkv<half_t>(ng, a, s);
+  if (dtype == 0) return run_embed_qkv<float>(ng, a, s);
+  cfen_set_error("embed_qkv: unknown dtype %d", dtype);
+  return CFEN_ERR_ARG;
+}

@@ -100,6 +100,22 @@ def embed_gather(fmap, C, ws, p, w, bias, pos):
     return out
 
 
+def embed_qkv(fmap, C, ws, p, we, be, pos, ln_g, ln_b, wqkv, eps=1e-5):
+    """fused LViT front half (D = p*p*C in {96,192}); we / wqkv with the k axis in packing.kperm32 order for fp16.
+    Returns (x1 [M,D], qkv [M,3D])."""
+    from ._lib import EmbedQkvArgsC
+    _cuda(fmap, we, be, pos, ln_g, ln_b, wqkv)
+    B, H, W, cs = fmap.shape
+    D = p * p * C
+    M = B * H * W // (p * p)
+    x1 = torch.empty(M, D, dtype=fmap.dtype, device=fmap.device)
+    qkv = torch.empty(M, 3 * D, dtype=fmap.dtype, device=fmap.device)
+    a = EmbedQkvArgsC(fmap=fmap.data_ptr(), B=B, H=H, W=W, C=C, cs=cs, ws=ws, p=p, we=we.data_ptr(), be=be.data_ptr(), pos=pos.data_ptr(),
+                      ln_gamma=ln_g.data_ptr(), ln_beta=ln_b.data_ptr(), wqkv=wqkv.data_ptr(), x1=x1.data_ptr(), qkv=qkv.data_ptr(), eps=eps)
+    check(_lib.load().cfen_embed_qkv(dtype_code(fmap.dtype), ctypes.byref(a), current_stream()), "embed_qkv")
+    return x1, qkv
+
+
 def unpatchify(tok, B, H, W, C, cs, ws, p):
     _cuda(tok)
     fmap = torch.zeros(B, H, W, cs, dtype=tok.dtype, device=tok.device)

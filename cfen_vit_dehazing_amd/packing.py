@@ -50,6 +50,11 @@ def mlp_is_fused(g, dtype):
     return g.kind == "lvit" and g.dim in FUSED_MLP_DIMS and g.hidden % (64 if dtype == torch.float16 else 32) == 0
 
 
+def front_is_fused(g):
+    """mirror of cfen_embed_qkv_supported (csrc/k_embed.hip): LViT levels 1 and 2 run gather + embedding + LN1 + qkv as one kernel"""
+    return g.kind == "lvit" and g.dim in (96, 192)
+
+
 def pack_vit(sd, g, dtype):
     n = g.name
     perm = token_perm(g.channels, g.patch)
@@ -68,6 +73,12 @@ def pack_vit(sd, g, dtype):
         n + ".head1.w": sd[n + ".mlp_head.0.weight"][:, perm].to(dtype), n + ".head1.b": sd[n + ".mlp_head.0.bias"].to(f32),
         n + ".head2.w": sd[n + ".mlp_head.3.weight"][perm].to(dtype), n + ".head2.b": sd[n + ".mlp_head.3.bias"][perm].to(f32),
     }
+    if front_is_fused(g):
+        # same matrices, k axis re-slotted so that accumulator tile pairs feed the MFMA directly (fp16 only)
+        # (the plain layout stays: "net.fused_front" can switch the fused kernel off per embedding dim)
+        for nm in ("embed", "qkv"):
+            w = out[n + "." + nm + ".w"]
+            out[n + "." + nm + ".wk"] = (w[:, kperm32(g.dim)] if dtype == torch.float16 else w).contiguous()
     if mlp_is_fused(g, dtype):
         # the fused MLP kernel replaces the four separate GEMMs: same matrices, k axis re-slotted (fp16 only)
         for a, b in (("ffn1", "ffn2"), ("head1", "head2")):

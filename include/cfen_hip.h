@@ -101,6 +101,18 @@ int cfen_gemm_nt(int dtype, const void* X, int ldx, const void* W, int ldw, cons
  * D = p*p*C, W is [D][D] (ldw), Y is [M][D] (ldy).                                        (v3:1140-1143, 1166) */
 int cfen_embed_gather(int dtype, const void* fmap, int B, int H, int W, int C, int cs, int ws, int p, const void* weight, int ldw,
                       const float* bias, const void* pos, int period, void* Y, int ldy, void* stream);
+/* LViT front half in one launch (D = p*p*C in {96, 192}): tok = patchify(fmap);  y = We tok + be + tok + pos[m % S] -> x1 [M][D];
+ * qkv = Wqkv LayerNorm(y) -> qkv [M][3D].  We [D][D] and Wqkv [3D][D] with the k axis in packing.kperm32 order for CFEN_F16.
+ *                                                                                      (v3:1140-1143, 1166, 1364-1371) */
+typedef struct cfen_embed_qkv_args {
+  const void* fmap; int32_t B, H, W, C, cs, ws, p;
+  const void* we; const float* be; const void* pos;
+  const float* ln_gamma; const float* ln_beta;
+  const void* wqkv;
+  void* x1; void* qkv;
+  float eps;
+} cfen_embed_qkv_args;
+int cfen_embed_qkv(int dtype, const cfen_embed_qkv_args* a, void* stream);
 /* LayerNorm over the last dim (eps as given), gamma/beta fp32                       (v3:1370-1371) */
 int cfen_layernorm(int dtype, const void* X, void* Y, const float* gamma, const float* beta, int M, int D, float eps, void* stream);
 /* softmax(QK^T/sqrt(dh))V per (sequence, head); QKV is [nseq*S][3*heads*dh], out [nseq*S][heads*dh]  (v3:1364) */

@@ -167,6 +167,33 @@ def test_embed_gather_equals_patchify_then_gemm(dtype, C, H, W, ws):
     close(got, ref, tol(dtype, 4))
 
 
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("C,H,W,ws", [(24, 64, 32, 32), (48, 32, 48, 16)])
+def test_embed_qkv_fused_front(dtype, C, H, W, ws):
+    """k_embed_qkv (gather + embedding + residual + pos + LN1 + qkv in one launch) against fp64 and the unfused chain"""
+    d = dev()
+    B, p, D = 3, 2, 4 * C
+    S = (ws // p) ** 2
+    fmap = ops.to_nhwc(rnd((B, C, H, W), 1, dtype)).to(d)
+    we = rnd((D, D), 2, dtype, 1 / math.sqrt(D)); be = rnd((D,), 3, torch.float32, 0.1)
+    pos = rnd((S, D), 4, dtype)
+    g, b = 1 + rnd((D,), 5, torch.float32, 0.1), rnd((D,), 6, torch.float32, 0.1)
+    wq = rnd((3 * D, D), 7, dtype, 1 / math.sqrt(D))
+    perm = packing.kperm32(D) if dtype == torch.float16 else torch.arange(D)
+    x1, qkv = ops.embed_qkv(fmap, C, ws, p, we[:, perm].contiguous().to(d), be.to(d), pos.to(d), g.to(d), b.to(d), wq[:, perm].contiguous().to(d))
+    tok = ops.patchify(fmap, C, ws, p)
+    t64 = tok.double().cpu()
+    y = t64 @ we.double().t() + be.double() + t64 + pos.double().repeat(tok.shape[0] // S, 1)
+    close(x1, y, tol(dtype, 4))
+    ln = F.layer_norm(y, (D,), g.double(), b.double(), 1e-5)
+    close(qkv, ln @ wq.double().t(), tol(dtype, 6))
+    # the unfused kernels on the same operands agree to rounding
+    y_u = ops.gemm_nt(tok, we.to(d), bias=be.to(d), residual=tok, pos=pos.to(d))
+    q_u = ops.gemm_nt(ops.layernorm(y_u, g.to(d), b.to(d)), wq.to(d))
+    close(x1, y_u.double(), tol(dtype, 4))
+    close(qkv, q_u.double(), tol(dtype, 8))
+
+
 # ---------------------------------------------------------------------------------------------------
 def run_conv(dtype, x, w, b, k, stride, pad, reflect=False, an=None, act=0, res=None, nchw=False, x2=None):
     kc = 32 if dtype == torch.float16 else 16
