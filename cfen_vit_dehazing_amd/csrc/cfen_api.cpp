@@ -143,6 +143,10 @@ int cfen_conv2d(int dtype, const cfen_conv_args* a, void* stream) {
   d.res[0] = a->res0; d.res[1] = a->res1; d.cs_res = a->cs_res;
   d.out = a->out; d.cs_out = a->cs_out; d.Cout_pad = a->Cout_pad; d.Cout = a->Cout;
   d.out_nchw_f32 = a->out_nchw_f32;
+  if (a->wlayout == 2) {
+    CFEN_CHECK_ARG(a->kind == 0 && a->k == 7 && a->nsrc == 1 && a->stride == 1 && a->pad == 3, "conv2d: Toeplitz layout is for 7x7 stride-1 same-size convolutions");
+    return cfen_conv7_tz_impl_g(dtype, 1, &d, (hipStream_t)stream);
+  }
   if (a->wlayout == 1 && a->kind == 1) return cfen_convT_tile_impl(dtype, &d, (hipStream_t)stream);
   if (a->wlayout == 1) {
     CFEN_CHECK_ARG(a->kind == 0 && a->nsrc == 1 && a->stride == 1 && a->pad == a->k / 2, "conv2d: rows layout needs a stride-1 same-size Conv2d");

@@ -51,6 +51,10 @@ int cfen_convT_tile_impl(int dtype, const ConvDesc* d, hipStream_t s);
 int cfen_conv_impl_g(int dtype, int ng, const ConvDesc* d, hipStream_t s);
 int cfen_conv_tile_impl_g(int dtype, int ng, const ConvDesc* d, int k, hipStream_t s);
 int cfen_convT_tile_impl_g(int dtype, int ng, const ConvDesc* d, hipStream_t s);
+// 7x7, <= 4 output channels, fp32 NCHW output: Toeplitz-expanded weights [16][7][10 taps][16] (k_conv_tile.hip: k_conv7_tz)
+bool cfen_conv7_tz_supported(int dtype, int k, int stride, int pad, int nsrc, int cs_in, int Cout, int out_nchw_f32, int H, int W);
+int cfen_conv7_tz_kpad();
+int cfen_conv7_tz_impl_g(int dtype, int ng, const ConvDesc* d, hipStream_t s);
 size_t cfen_stats_workspace_bytes(int B, int C);
 int cfen_instnorm_relu_impl(int dtype, void* x, float* part, int B, int HW, int C, int cs, float eps, hipStream_t s);
 int cfen_cfsm2g_impl(int dtype, const void* x0, const void* x1, const void* x2, void* out, const float* w, float* part, int B, int HW,

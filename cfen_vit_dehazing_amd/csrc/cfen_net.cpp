@@ -52,6 +52,7 @@ struct Vit {
 struct ConvLayer {
   int kind, k, stride, pad, reflect, nsrc, Cin, Cin_real, Cout, Cout_pad, Kpad, nphase, ntaps, out_edge;
   bool tile;   // LDS-tiled kernel, weights "<layer>.wr" in the rows layout
+  bool tz;     // Toeplitz 7x7 kernel (tails), weights "<layer>.wz"
 };
 
 inline int cs_of(int C) { return cfen_round_up(C, 8); }
@@ -153,8 +154,11 @@ struct cfen_net {
       c.tile = cfen_conv_tile_supported(cfg.dtype, kind, k, stride, pad, nsrc, Cin, c.Cout_pad, out_edge, out_edge);
       if (c.tile) c.Kpad = cfen_conv_tile_kpad(cfg.dtype, k, Cin);
     }
+    c.tz = n.size() > 6 && n.compare(n.size() - 6, 6, ".conv7") == 0 &&
+           cfen_conv7_tz_supported(cfg.dtype, k, stride, pad, nsrc, Cin, Cout, 1, out_edge, out_edge);   // the tails write fp32 NCHW
+    if (c.tz) { c.tile = false; c.Kpad = cfen_conv7_tz_kpad(); }
     convs[n] = c;
-    need(n + (c.tile ? ".wr" : ".w"), (size_t)c.nphase * c.Cout_pad * c.Kpad * esz);
+    need(n + (c.tz ? ".wz" : c.tile ? ".wr" : ".w"), (size_t)c.nphase * c.Cout_pad * c.Kpad * esz);
     need(n + ".scale", (size_t)c.Cout_pad * 4);
     need(n + ".shift", (size_t)c.Cout_pad * 4);
   }
@@ -336,7 +340,7 @@ int cfen_net::run_conv_g(int ng, const ConvCall* cc, int act) {
   for (int g = 0; g < ng; ++g) {
     const ConvCall& q = cc[g];
     const ConvLayer& c = convs.at(q.layer);
-    CFEN_CHECK_ARG(c.kind == c0.kind && c.k == c0.k && c.tile == c0.tile && c.Cout_pad == c0.Cout_pad && c.Kpad == c0.Kpad,
+    CFEN_CHECK_ARG(c.kind == c0.kind && c.k == c0.k && c.tile == c0.tile && c.tz == c0.tz && c.Cout_pad == c0.Cout_pad && c.Kpad == c0.Kpad,
                    "net: %s and %s cannot share a launch", cc[0].layer.c_str(), q.layer.c_str());
     const Buf& bi = bufs.at(q.in0);
     if (c.kind == 0)
@@ -345,7 +349,7 @@ int cfen_net::run_conv_g(int ng, const ConvCall* cc, int act) {
       cfen_desc_convT4(&d[g], cfg.batch, bi.H, bi.W, bi.cs, c.Cin);
     d[g].src[0] = map_ptr(q.in0);
     d[g].src[1] = q.in1.empty() ? nullptr : map_ptr(q.in1);
-    d[g].weight = P(q.layer + (c.tile ? ".wr" : ".w")); d[g].Kpad = c.Kpad;
+    d[g].weight = P(q.layer + (c.tz ? ".wz" : c.tile ? ".wr" : ".w")); d[g].Kpad = c.Kpad;
     d[g].scale = Pf(q.layer + ".scale"); d[g].shift = Pf(q.layer + ".shift");
     d[g].act = act;
     d[g].Cout = c.Cout; d[g].Cout_pad = c.Cout_pad;
@@ -363,7 +367,9 @@ int cfen_net::run_conv_g(int ng, const ConvCall* cc, int act) {
                                    : 2.0 * c.Cout * (double)c.Cin_real * c.nsrc * c.k * c.k * e * e);
   }
   label = cc[0].layer + (ng > 1 ? " (x" + std::to_string(ng) + ")" : "");
-  if (c0.tile && c0.kind == 1)
+  if (c0.tz)
+    TRYP(K_CONV, fl, cfen_conv7_tz_impl_g(cfg.dtype, ng, d, stream));
+  else if (c0.tile && c0.kind == 1)
     TRYP(K_CONV, fl, cfen_convT_tile_impl_g(cfg.dtype, ng, d, stream));
   else if (c0.tile)
     TRYP(K_CONV, fl, cfen_conv_tile_impl_g(cfg.dtype, ng, d, c0.k, stream));

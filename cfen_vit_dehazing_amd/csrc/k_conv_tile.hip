@@ -365,3 +365,129 @@ int cfen_convT_tile_impl_g(int dtype, int ng, const ConvDesc* dp, hipStream_t s)
   if (pixb == 128) return launch_convT_tile<half_t, 128, 2, 2, CT_RY>(ng, dp, s);
   return launch_convT_tile<half_t, 192, 3, 1, CT_RY>(ng, dp, s);
 }
+
+// ---------------------------------------------------------------------------------------------------------------
+// 7x7 convolution with <= 4 output channels (the tails, v3:354-355: 12 -> 3 / 1 channels behind ReflectionPad2d(3), tanh,
+// fp32 NCHW output).  With 3 output channels a 16-row MFMA is 81 % padding; here the 16 rows are (channel co, pixel
+// offset dxo) pairs, co < 4, dxo < 4: column j of the MFMA stands for the 4 adjacent output pixels 4j .. 4j+3 and the
+// weight matrix is the Toeplitz expansion  Wz[(co, dxo)][dy][kx'][ci] = w[co][dy][kx' - dxo][ci]  (0 <= kx' - dxo < 7,
+// kx' < 10 -> 5 chunks of 2 taps per input row).  3.2x fewer MFMAs per pixel than the per-pixel-column kernel above, and
+// a lane ends up with 4 CONSECUTIVE pixels of one channel: 16-byte NCHW stores.
+// Workgroup = 64 x 16 output pixels, wave w owns rows 4w .. 4w+3 across the full width; the 22 x 70 pixel halo is staged
+// once, its 16-byte pieces XOR-swizzled (slot ^= group & 6, group = pixel / 4) so that every ds_read_b128 lane group
+// is conflict-free for all five chunk positions (found by exhaustive search over linear swizzles).
+namespace {
+
+constexpr int Z_RW = 4, Z_ROWS = 4 * Z_RW + 6, Z_WT = 72, Z_RB = Z_WT * 32, Z_NCH = 5, Z_KPAD = 7 * Z_NCH * 32;
+
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_conv7_tz(Grouped<ConvDesc> dg, int nblk) {
+  const ConvDesc& d = dg.g[blockIdx.z];
+  typedef half_t T;
+  typedef Mma<T>::frag frag;
+  constexpr int NPIECE = Z_ROWS * Z_WT * 2, NIT = (NPIECE + 255) / 256;
+  __shared__ __attribute__((aligned(16))) unsigned char lds[Z_ROWS * Z_RB];
+
+  const int blk = (int)xcd_chunked_block(blockIdx.x, gridDim.x);
+  if (blk >= nblk) return;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r16 = lane & 15, h = lane >> 4;
+  const int tiles_x = d.Win / 64, tiles_y = d.Hin / (4 * Z_RW);
+  const int tx = blk % tiles_x, ty = (blk / tiles_x) % tiles_y, b = blk / (tiles_x * tiles_y);
+  const int x0 = tx * 64, y0 = ty * 4 * Z_RW;
+  const unsigned char* src = (const unsigned char*)d.src[0] + (size_t)b * d.Hin * d.Win * 32;
+
+  frag stg[NIT];
+#pragma unroll
+  for (int i = 0; i < NIT; ++i) {
+    const int idx = tid + i * 256;
+    const int q = idx & 1, P = (idx >> 1) % Z_WT, row = (idx >> 1) / Z_WT;
+    int gy = y0 - 3 + row, gx = x0 - 3 + P;
+    bool ok = idx < NPIECE && P < 70;
+    if (d.pad_reflect) {
+      gy = gy < 0 ? -gy : (gy >= d.Hin ? 2 * d.Hin - 2 - gy : gy);
+      gx = gx < 0 ? -gx : (gx >= d.Win ? 2 * d.Win - 2 - gx : gx);
+    } else {
+      ok = ok && gy >= 0 && gy < d.Hin && gx >= 0 && gx < d.Win;
+    }
+    stg[i] = ok ? *reinterpret_cast<const frag*>(src + ((size_t)gy * d.Win + gx) * 32 + q * 16) : Mma<T>::zero();
+  }
+  frag wf[7][Z_NCH];
+  {
+    const T* wp = (const T*)d.weight + (size_t)r16 * Z_KPAD + h * 8;
+#pragma unroll
+    for (int dy = 0; dy < 7; ++dy)
+#pragma unroll
+      for (int c = 0; c < Z_NCH; ++c) wf[dy][c] = load_frag<T>(wp + (dy * Z_NCH + c) * 32);
+  }
+#pragma unroll
+  for (int i = 0; i < NIT; ++i) {
+    const int idx = tid + i * 256;
+    const int q = idx & 1, P = (idx >> 1) % Z_WT, row = (idx >> 1) / Z_WT;
+    const int slot = 2 * P + q, G = P >> 2;
+    if (idx < NPIECE) *reinterpret_cast<frag*>(&lds[row * Z_RB + (((slot & ~7) | ((slot & 7) ^ (G & 6))) << 4)]) = stg[i];
+  }
+  __syncthreads();
+
+  floatx4 acc[Z_RW];
+#pragma unroll
+  for (int r = 0; r < Z_RW; ++r) acc[r] = floatx4{0.f, 0.f, 0.f, 0.f};
+  const unsigned char* lp = lds + wave * Z_RW * Z_RB;
+#pragma unroll
+  for (int iy = 0; iy < Z_RW + 6; ++iy) {
+#pragma unroll
+    for (int c = 0; c < Z_NCH; ++c) {
+      const int G = r16 + (c >> 1);
+      const frag bf = *reinterpret_cast<const frag*>(lp + iy * Z_RB + ((8 * G + ((4 * (c & 1) + h) ^ (G & 6))) << 4));
+#pragma unroll
+      for (int r = 0; r < Z_RW; ++r) {
+        const int dy = iy - r;
+        if (dy >= 0 && dy < 7) acc[r] = Mma<T>::mma(wf[dy][c], bf, acc[r]);
+      }
+    }
+  }
+
+  // lane (j = r16, h): channel co = h, output pixels x0 + 4j .. +3 of row y0 + 4*wave + r
+  if (h < d.Cout) {
+    const float sc = d.scale[h], sh = d.shift[h];
+    float* o = (float*)d.out + (((size_t)b * d.Cout + h) * d.Hin + y0 + wave * Z_RW) * d.Win + x0 + 4 * r16;
+#pragma unroll
+    for (int r = 0; r < Z_RW; ++r) {
+      floatx4 v = acc[r] * sc + sh;
+      if (d.act == 1) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
+      } else if (d.act == 2) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = tanhf(v[e]);
+      }
+      *reinterpret_cast<floatx4*>(o + (size_t)r * d.Win) = v;
+    }
+  }
+}
+
+}  // namespace
+
+// geometry of the Toeplitz 7x7 kernel (mirrored by packing.conv_uses_toeplitz7)
+bool cfen_conv7_tz_supported(int dtype, int k, int stride, int pad, int nsrc, int cs_in, int Cout, int out_nchw_f32, int H, int W) {
+  return dtype == 1 && k == 7 && stride == 1 && pad == 3 && nsrc == 1 && cs_in == 16 && Cout >= 1 && Cout <= 4 && out_nchw_f32 && H % (4 * Z_RW) == 0 &&
+         W % 64 == 0;
+}
+int cfen_conv7_tz_kpad() { return Z_KPAD; }
+
+int cfen_conv7_tz_impl_g(int dtype, int ng, const ConvDesc* dp, hipStream_t s) {
+  CFEN_CHECK_ARG(ng >= 1 && ng <= CFEN_MAX_GROUPS && dp, "conv7 (toeplitz): 1..%d problems per launch", CFEN_MAX_GROUPS);
+  Grouped<ConvDesc> dg;
+  for (int g = 0; g < ng; ++g) {
+    const ConvDesc& d = dp[g];
+    CFEN_CHECK_ARG(cfen_conv7_tz_supported(dtype, 7, d.in_stride, 3, 1, d.cs_in, d.Cout, d.out_nchw_f32, d.Hin, d.Win) && d.nphase == 1 &&
+                   d.Hout == d.Hin && d.Wout == d.Win && d.Kpad == Z_KPAD, "conv7 (toeplitz): unsupported geometry or weight layout");
+    CFEN_CHECK_ARG(d.B == dp[0].B && d.Hin == dp[0].Hin && d.Win == dp[0].Win, "conv7 (toeplitz): grouped problems must have the same geometry");
+    CFEN_CHECK_ARG(d.src[0] && d.weight && d.out && d.scale && d.shift && cfen_aligned16(d.src[0]) && cfen_aligned16(d.weight) && cfen_aligned16(d.out),
+                   "conv7 (toeplitz): null or misaligned pointer");
+    CFEN_CHECK_ARG(!d.pad_reflect || (3 < d.Hin && 3 < d.Win), "conv7 (toeplitz): reflection pad larger than the image");
+  }
+  for (int g = 0; g < CFEN_MAX_GROUPS; ++g) dg.g[g] = dp[g < ng ? g : 0];
+  const long long nblk = (long long)dp[0].B * (dp[0].Hin / (4 * Z_RW)) * (dp[0].Win / 64);
+  CFEN_LAUNCH(k_conv7_tz, dim3(cfen_grid8(nblk), 1, ng), dim3(256), 0, s, dg, (int)nblk);
+  CFEN_CHECK_LAUNCH("conv7 (toeplitz)");
+  return CFEN_OK;
+}

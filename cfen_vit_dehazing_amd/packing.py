@@ -116,6 +116,23 @@ def conv_uses_rows_layout(dtype, k, stride, pad, nsrc, cs_in, cout, H, W):
     return (pixb == 32 and k == 5) or (pixb == 64 and k in (3, 7))
 
 
+def conv_uses_toeplitz7(dtype, k, stride, pad, nsrc, cs_in, cout, nchw_f32, H, W):
+    """mirror of cfen_conv7_tz_supported (csrc/k_conv_tile.hip: k_conv7_tz)"""
+    return (dtype == torch.float16 and k == 7 and stride == 1 and pad == 3 and nsrc == 1 and cs_in == 16 and 1 <= cout <= 4 and nchw_f32
+            and H % 16 == 0 and W % 64 == 0)
+
+
+def pack_conv7_toeplitz(w, dtype):
+    """Conv2d weight (Cout<=4, Cin<=16, 7, 7) -> [1][16][7*10*16]: row co*4 + dxo holds w[co][:, ky, kx' - dxo] at tap kx' (zero outside),
+    so one MFMA column stands for 4 adjacent output pixels."""
+    cout, cin = w.shape[0], w.shape[1]
+    wz = torch.zeros(4, 4, 7, 10, 16, dtype=dtype, device=w.device)
+    wp = w.permute(0, 2, 3, 1).to(dtype)          # (co, ky, kx, ci)
+    for dxo in range(4):
+        wz[:cout, dxo, :, dxo:dxo + 7, :cin] = wp
+    return wz.reshape(1, 16, 7 * 10 * 16)
+
+
 def pack_conv_weight_rows(w, cin_pad, dtype):
     """Conv2d weight (Cout<=16, Cin, k, k) -> [1][16][k*KSP*cin_pad]: tap-major, every kernel row padded with zero
     taps to a whole number of 64-byte chunks (KSP taps)."""
@@ -203,7 +220,9 @@ def pack_state_dict(sd, cfg: NetConfig, dtype=torch.float16):
         # rows = (stride, pad) of a full-resolution layer that may run on the LDS-tiled kernel
         w = sd[key + ".weight"]
         cp = round_up(w.shape[0], 16)
-        if rows and conv_uses_rows_layout(dtype, w.shape[2], rows[0], rows[1], 1, cs_of(cin), w.shape[0], full, full):
+        if rows and name.endswith(".conv7") and conv_uses_toeplitz7(dtype, w.shape[2], rows[0], rows[1], 1, cs_of(cin), w.shape[0], True, full, full):
+            out[name + ".wz"] = pack_conv7_toeplitz(w, dtype)
+        elif rows and conv_uses_rows_layout(dtype, w.shape[2], rows[0], rows[1], 1, cs_of(cin), w.shape[0], full, full):
             out[name + ".wr"] = pack_conv_weight_rows(w, cs_of(cin), dtype)
         else:
             out[name + ".w"] = pack_conv_weight(w, cs_of(cin), kc, dtype)

@@ -155,7 +155,8 @@ typedef struct cfen_conv_args {
   int32_t act;            /* 0 none, 1 ReLU, 2 tanh */
   int32_t out_nchw_f32;   /* write (B,Cout,H,W) fp32 instead of NHWC */
   int32_t cs_res;
-  int32_t wlayout;        /* 0 tap-major, 1 rows (see above) */
+  int32_t wlayout;        /* 0 tap-major, 1 rows (see above), 2 Toeplitz 7x7 (fp16, cs_in 16, Cout <= 4, fp32 NCHW output, H % 16 == 0,
+                             W % 64 == 0): [16 rows = co*4 + dxo][7][10 taps][16], w[co][ky][kx' - dxo][ci], Kpad 1120 */
   const void* src0;
   const void* src1;
   const void* weight;

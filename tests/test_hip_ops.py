@@ -285,6 +285,31 @@ def test_conv_rows_layout_reflect7_tanh_nchw(dtype):
         close(got, want, tol(dtype, 2))
 
 
+def test_conv7_toeplitz_reflect_tanh_nchw():
+    """k_conv7_tz (4 pixels per MFMA column, Toeplitz weights): tails of the generator, vs torch and vs the rows-layout kernel"""
+    dtype, d = torch.float16, dev()
+    x = rnd((2, 12, 32, 128), 1, dtype)
+    for cout, reflect in ((3, True), (1, True), (4, False)):
+        assert packing.conv_uses_toeplitz7(dtype, 7, 1, 3, 1, 16, cout, True, 32, 128)
+        w = rnd((cout, 12, 7, 7), 2, dtype, 0.3 / math.sqrt(12 * 49))
+        b = rnd((cout,), 3, torch.float32, 0.1)
+        xp = F.pad(x.double(), (3, 3, 3, 3), mode="reflect") if reflect else F.pad(x.double(), (3, 3, 3, 3))
+        want = torch.tanh(F.conv2d(xp, w.double(), b.double()))
+        s, t = packing.affine(b, cout_pad=16)
+        got = ops.conv2d(ops.to_nhwc(x).to(d), packing.pack_conv7_toeplitz(w, dtype)[0].to(d), s.to(d), t.to(d), 16, cout, k=7, stride=1, pad=3,
+                         reflect=reflect, act=2, nchw_f32=True, toeplitz=True)
+        assert got.dtype == torch.float32 and got.shape == want.shape
+        close(got, want, tol(dtype, 2))
+        close(got, run_conv_rows(dtype, x, w, b, 7, reflect=reflect, act=2, nchw=True).double(), tol(dtype, 2))
+    # one-hot taps: pure shifted copies, exact
+    w = torch.zeros(3, 12, 7, 7)
+    w[0, 5, 0, 6] = 1.0; w[1, 7, 6, 0] = 1.0; w[2, 0, 3, 3] = 1.0
+    s, t = packing.affine(torch.zeros(3), cout_pad=16)
+    got = ops.conv2d(ops.to_nhwc(x).to(d), packing.pack_conv7_toeplitz(w.to(dtype), dtype)[0].to(d), s.to(d), t.to(d), 16, 3, k=7, stride=1, pad=3,
+                     act=0, nchw_f32=True, toeplitz=True)
+    assert torch.equal(got.cpu(), F.conv2d(x.float(), w, padding=3))
+
+
 def test_conv_rows_layout_rejects_unsupported_geometry():
     x = rnd((1, 12, 12, 64), 1, torch.float16)          # H not a multiple of 8
     wp = packing.pack_conv_weight_rows(rnd((12, 12, 3, 3), 2, torch.float16), 16, torch.float16)[0]
