@@ -13,7 +13,7 @@ import collections, csv, json, sys
 
 CLASS_OF = (("k_gemm_nt", "gemm"), ("k_gemm_skinny", "gemm"), ("k_gemm", "gemm"), ("k_attention", "attention"), ("k_layernorm", "layernorm"),
             ("k_patchify", "tokens"), ("k_unpatchify", "tokens"), ("k_upsample4", "tokens"), ("k_nchw_to_nhwc", "tokens"),
-            ("k_conv", "conv"), ("k_chan_stats", "norm"), ("k_instnorm", "norm"), ("k_cfsm", "norm"), ("k_mlp", "mlp"))
+            ("k_conv", "conv"), ("k_convT", "conv"), ("k_conv7", "conv"), ("k_chan_stats", "norm"), ("k_instnorm", "norm"), ("k_cfsm", "norm"), ("k_mlp", "mlp"), ("k_embed_qkv", "gemm"))
 
 
 def fold(path, counter):
