@@ -35,7 +35,7 @@ class EmbedQkvArgsC(ctypes.Structure):
 
 
 class MlpArgsC(ctypes.Structure):
-    _fields_ = [(n, c_void_p) for n in ("x", "y", "fmap", "ln_gamma", "ln_beta", "w1a", "b1a", "w2a", "b2a", "w1b", "b1b", "w2b", "b2b")] + \
+    _fields_ = [(n, c_void_p) for n in ("x", "y", "fmap", "att", "w_proj", "ln_gamma", "ln_beta", "w1a", "b1a", "w2a", "b2a", "w1b", "b1b", "w2b", "b2b")] + \
                [("M", ctypes.c_int64), ("D", ctypes.c_int32), ("H", ctypes.c_int32), ("eps", c_float)] + \
                [(n, ctypes.c_int32) for n in ("mapH", "mapW", "C", "cs", "ws", "p")]
 

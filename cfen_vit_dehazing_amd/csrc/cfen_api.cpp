@@ -50,6 +50,7 @@ int cfen_mlp_block(int dtype, const cfen_mlp_args* a, void* stream) {
   CFEN_CHECK_ARG(a != nullptr, "mlp_block: null args");
   MlpArgs m{};
   m.X = a->x; m.Y = a->y; m.fmap = a->fmap; m.ln_g = a->ln_gamma; m.ln_b = a->ln_beta;
+  m.A = a->att; m.Wp = a->w_proj;
   m.W1a = a->w1a; m.b1a = a->b1a; m.W2a = a->w2a; m.b2a = a->b2a;
   m.W1b = a->w1b; m.b1b = a->b1b; m.W2b = a->w2b; m.b2b = a->b2b;
   m.M = a->M; m.D = a->D; m.H = a->H; m.eps = a->eps;

@@ -4,6 +4,8 @@
 
 struct MlpArgs {
   const void* X;        // [M][D] tokens in
+  const void* A; const void* Wp;   // optional prologue: x <- x + Wp A^T-rows, i.e. x[m] += Wp A[m]  (A [M][D] = attention output, Wp [D][D]
+                                   // natural k order: out_proj + residual of the attention block, v3:1386)
   void* Y;              // [M][D] tokens out (may alias X), or null when fmap is set
   void* fmap;           // optional: fold the result into an NHWC map (unpatchify fused)
   const float* ln_g;    // LayerNorm before stage a (null = none)

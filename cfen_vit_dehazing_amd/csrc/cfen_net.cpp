@@ -448,9 +448,11 @@ int cfen_net::run_vit_g(int ng, const VitCall* vc, int scr0) {
   }
   step("attention");
   TRYP(K_ATTN, 4 * Md * v.S * D, cfen_attention_impl_g(dt, ng, cQKV, ATT, B * nwin, v.S, v.heads, v.D / v.heads, stream));
-  step("proj");
   const void* cATT[3] = {ATT[0], ATT[1], ATT[2]};
-  TRYP(K_GEMM, 2 * Md * D * D, gemm(cATT, ".proj.w", nullptr, X1, nullptr, X1, v.D, v.D, 0, nullptr));
+  if (!v.fused_mlp) {
+    step("proj");
+    TRYP(K_GEMM, 2 * Md * D * D, gemm(cATT, ".proj.w", nullptr, X1, nullptr, X1, v.D, v.D, 0, nullptr));
+  }
   if (v.fused_mlp) {
     // LN2 + FFN + residual + mlp_head + residual + fold, hidden activations never leave registers (k_mlp.hip)
     MlpArgs m[3];
@@ -458,14 +460,15 @@ int cfen_net::run_vit_g(int ng, const VitCall* vc, int scr0) {
       const std::string& n = nm[g];
       m[g] = MlpArgs{};
       m[g].X = X1[g]; m[g].Y = nullptr; m[g].fmap = v.global ? SM[g] : OUT[g];
+      m[g].A = ATT[g]; m[g].Wp = P(n + ".proj.w");   // out_proj + residual ride on the kernel's token load
       m[g].ln_g = Pf(n + ".ln2.g"); m[g].ln_b = Pf(n + ".ln2.b");
       m[g].W1a = P(n + ".ffn1.wk"); m[g].b1a = Pf(n + ".ffn1.b"); m[g].W2a = P(n + ".ffn2.wk"); m[g].b2a = Pf(n + ".ffn2.b");
       m[g].W1b = P(n + ".head1.wk"); m[g].b1b = Pf(n + ".head1.b"); m[g].W2b = P(n + ".head2.wk"); m[g].b2b = Pf(n + ".head2.b");
       m[g].M = M; m[g].D = v.D; m[g].H = v.hidden; m[g].eps = 1e-5f;
       m[g].mapH = v.mapH; m[g].mapW = v.mapH; m[g].C = v.C; m[g].cs = v.global ? v.C : bo.cs; m[g].ws = v.ws; m[g].p = v.p;
     }
-    step("mlp_fused");
-    TRYP(K_MLP, 8 * Md * D * Hd, cfen_mlp_impl_g(dt, ng, m, stream));
+    step("proj_mlp_fused");
+    TRYP(K_MLP, 8 * Md * D * Hd + 2 * Md * D * D, cfen_mlp_impl_g(dt, ng, m, stream));
   } else {
     // src = src + linear2(relu(linear1(LN2(src))))                             (v3:1387-1389)
     step("ln2");

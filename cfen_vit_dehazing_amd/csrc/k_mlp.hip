@@ -72,6 +72,28 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(WPE, WP
     for (int i = 0; i < ND; ++i) acc[i][j] = load4<T>(xp + i * 16);
   }
 
+  if (a.Wp) {   // x += Wp att: the attention block's out_proj + residual, operands straight from L1/L2 (natural k order)
+    const T* Wp = (const T*)a.Wp + (size_t)r16 * D + h * EPL;
+    constexpr int NKC = D / KC;
+    frag ab[NKC][TM];
+#pragma unroll
+    for (int j = 0; j < TM; ++j) {
+      long long t = tok0 + j * 16 + r16;
+      if (t >= a.M) t = a.M - 1;
+      const T* ap = (const T*)a.A + t * D + h * EPL;
+#pragma unroll
+      for (int c = 0; c < NKC; ++c) ab[c][j] = load_frag<T>(ap + c * KC);
+    }
+#pragma unroll
+    for (int i = 0; i < ND; ++i)
+#pragma unroll
+      for (int c = 0; c < NKC; ++c) {
+        const frag af = load_frag<T>(Wp + (size_t)i * 16 * D + c * KC);
+#pragma unroll
+        for (int j = 0; j < TM; ++j) acc[i][j] = Mma<T>::mma(af, ab[c][j], acc[i][j]);
+      }
+  }
+
   frag xb[NCH][TM];
 #pragma unroll 1
   for (int stage = 0; stage < 2; ++stage) {
@@ -271,6 +293,7 @@ int check_mlp(const MlpArgs& a) {
   CFEN_CHECK_ARG((a.W1b == nullptr) == (a.W2b == nullptr) && (!a.W1b || (a.b1b && a.b2b)), "mlp: incomplete second stage");
   CFEN_CHECK_ARG((a.ln_g == nullptr) == (a.ln_b == nullptr), "mlp: LayerNorm needs gamma and beta");
   CFEN_CHECK_ARG(a.Y || a.fmap, "mlp: no output");
+  CFEN_CHECK_ARG((a.A == nullptr) == (a.Wp == nullptr) && cfen_aligned16(a.A) && cfen_aligned16(a.Wp), "mlp: projection prologue needs A and Wp");
   if (a.fmap) {
     CFEN_CHECK_ARG(a.C > 0 && a.C % 4 == 0 && a.cs >= a.C && a.cs % 4 == 0 && a.p > 0 && a.ws % a.p == 0 && a.mapH % a.ws == 0 &&
                    a.mapW % a.ws == 0 && a.p * a.p * a.C == a.D, "mlp: bad fold geometry");
@@ -291,7 +314,8 @@ int launch_mlp(int ng, const MlpArgs* ap, hipStream_t s) {
     int rc = check_mlp<T>(ap[g]);
     if (rc) return rc;
     CFEN_CHECK_ARG(ap[g].M == ap[0].M && ap[g].D == ap[0].D && ap[g].H == ap[0].H && (ap[g].W1b == nullptr) == (ap[0].W1b == nullptr) &&
-                   (ap[g].ln_g == nullptr) == (ap[0].ln_g == nullptr), "mlp: grouped problems must have the same shape");
+                   (ap[g].ln_g == nullptr) == (ap[0].ln_g == nullptr) && (ap[g].Wp == nullptr) == (ap[0].Wp == nullptr),
+                   "mlp: grouped problems must have the same shape");
   }
   const int small = cfen_tune_mlp_small_tiles();
   switch (ap[0].D) {

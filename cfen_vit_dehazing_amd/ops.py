@@ -54,14 +54,17 @@ def attention(qkv, nseq, S, heads):
     return out
 
 
-def mlp_block(x, w1a, b1a, w2a, b2a, ln=None, second=None, fold=None):
+def mlp_block(x, w1a, b1a, w2a, b2a, ln=None, second=None, fold=None, proj=None):
     """Fused y1 = x + W2a relu(W1a LN(x)+b1a) + b2a [; y2 = y1 + W2b relu(W1b y1 + b1b) + b2b].
     Weights must already carry packing.kperm32 on their k axis for fp16.  fold = (B, H, W, C, cs, ws, p) writes
-    the result into a fresh NHWC map instead of a token matrix."""
+    the result into a fresh NHWC map instead of a token matrix.  proj = (att, w_proj): x is first replaced by x + att @ w_proj.T."""
     _cuda(x, w1a, b1a, w2a, b2a)
     M, D = x.shape
     a = MlpArgsC(x=x.data_ptr(), w1a=w1a.data_ptr(), b1a=b1a.data_ptr(), w2a=w2a.data_ptr(), b2a=b2a.data_ptr(), M=M, D=D,
                  H=w1a.shape[0], eps=1e-5)
+    if proj is not None:
+        _cuda(*proj)
+        a.att, a.w_proj = proj[0].data_ptr(), proj[1].data_ptr()
     if ln is not None:
         _cuda(*ln)
         a.ln_gamma, a.ln_beta = ln[0].data_ptr(), ln[1].data_ptr()

@@ -119,11 +119,13 @@ int cfen_layernorm(int dtype, const void* X, void* Y, const float* gamma, const 
 int cfen_attention(int dtype, const void* qkv, void* out, int nseq, int S, int heads, int dh, void* stream);
 /* Fused token MLP block (D in {96,192}; H a multiple of 64 (fp16) / 32 (fp32)):
  *   y1 = x + W2a relu(W1a LN(x) + b1a) + b2a  (LN skipped when ln_gamma is NULL);  y2 = y1 + W2b relu(W1b y1 + b1b) + b2b
- *   (second stage skipped when W1b is NULL).  Output: token-major `y` and/or folded into the NHWC map `fmap`
+ *   (second stage skipped when W1b is NULL).  With att / w_proj ([M][D] / [D][D], natural k order) x is first replaced by
+ *   x + w_proj att, the attention block's output projection and residual.  Output: token-major `y` and/or folded into the NHWC map `fmap`
  *   (F.fold + Join2x2: map H x W, channels C with stride cs, window ws, patch p).  Weights [H][D] / [D][H] with
  *   the k axis in packing.kperm32 order for CFEN_F16 (natural order for CFEN_F32).   (v3:1387-1389, 1173, 1186) */
 typedef struct cfen_mlp_args {
   const void* x; void* y; void* fmap;
+  const void* att; const void* w_proj;   /* optional prologue x <- x + w_proj att (out_proj + residual, v3:1386); both NULL = none */
   const float* ln_gamma; const float* ln_beta;
   const void* w1a; const float* b1a; const void* w2a; const float* b2a;
   const void* w1b; const float* b1b; const void* w2b; const float* b2b;

@@ -168,6 +168,24 @@ def test_embed_gather_equals_patchify_then_gemm(dtype, C, H, W, ws):
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("D", [96, 192])
+def test_mlp_block_with_projection_prologue(dtype, D):
+    """k_mlp with the attention out_proj + residual folded into its token load"""
+    d = dev()
+    M, H = 300, 4 * D
+    x, att = rnd((M, D), 1, dtype), rnd((M, D), 2, dtype)
+    wp = rnd((D, D), 3, dtype, 1 / math.sqrt(D))
+    w1, w2 = rnd((H, D), 4, dtype, 1 / math.sqrt(D)), rnd((D, H), 5, dtype, 1 / math.sqrt(H))
+    b1, b2 = rnd((H,), 6, torch.float32, 0.1), rnd((D,), 7, torch.float32, 0.1)
+    g, b = 1 + rnd((D,), 8, torch.float32, 0.1), rnd((D,), 9, torch.float32, 0.1)
+    x1 = x.double() + att.double() @ wp.double().t()
+    want = x1 + torch.relu(F.layer_norm(x1, (D,), g.double(), b.double(), 1e-5) @ w1.double().t() + b1.double()) @ w2.double().t() + b2.double()
+    pk = (lambda w: w[:, packing.kperm32(w.shape[1])].contiguous()) if dtype == torch.float16 else (lambda w: w)
+    got = ops.mlp_block(x.to(d), pk(w1).to(d), b1.to(d), pk(w2).to(d), b2.to(d), ln=(g.to(d), b.to(d)), proj=(att.to(d), wp.to(d)))
+    close(got, want, tol(dtype, 8))
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
 @pytest.mark.parametrize("C,H,W,ws", [(24, 64, 32, 32), (48, 32, 48, 16)])
 def test_embed_qkv_fused_front(dtype, C, H, W, ws):
     """k_embed_qkv (gather + embedding + residual + pos + LN1 + qkv in one launch) against fp64 and the unfused chain"""
