@@ -113,7 +113,7 @@ int cfen_tune(const char* key, int value) {
     return CFEN_OK;
   }
   if (!strcmp(key, "mlp.small_tiles")) {
-    cfen_tune_mlp_small_tiles() = value != 0;
+    cfen_tune_mlp_small_tiles() = value;
     return CFEN_OK;
   }
   if (!strcmp(key, "net.embed_gather")) {

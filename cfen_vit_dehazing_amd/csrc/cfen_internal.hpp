@@ -63,6 +63,7 @@ int& cfen_tune_gemm_kernel();   // -1 auto, 0 tiled, 1 skinny (cfen_tune "gemm.k
 int& cfen_tune_gemm_large();    // k_gemm_dma tile id (2..5) for problems with >= 1024 tiles of 96 x 64 ("gemm.large")
 int& cfen_tune_gemm_small();    // ... and for smaller ones ("gemm.small")
 int& cfen_tune_embed_gather();  // 1 (default): LViT embedding gathers its tokens from the map; 0: separate k_patchify ("net.embed_gather")
-int& cfen_tune_mlp_small_tiles();   // 1: fused MLP with half-size token tiles per wave (more waves in flight) ("mlp.small_tiles")
+int& cfen_tune_mlp_small_tiles();   // fused-MLP tiling ("mlp.small_tiles"): 0 256/128 tokens per 4-wave WG at 1 wave/SIMD, 1 half-size token tiles at
+                                    // 2 waves/SIMD, 2 as 1 but TM = 2 for D = 192 (register-capped), 3 (default) 8-wave WGs: half the weight re-streaming
 int& cfen_tune_skip_classes();    // bit mask of kernel classes NOT launched by the net (marginal-cost timing; outputs invalid) ("net.skip_classes")
 int& cfen_tune_fused_front_max_dim();   // k_embed_qkv is used for LViT embedding dims <= this (0 = never) ("net.fused_front_max_dim")

@@ -319,9 +319,12 @@ int launch_mlp(int ng, const MlpArgs* ap, hipStream_t s) {
   }
   const int small = cfen_tune_mlp_small_tiles();
   switch (ap[0].D) {
-    case 96: return small ? launch_mlp_t<T, 6, 2, 4, 2 * KC, 2>(ng, ap, s)     // 128 tokens / WG, 2 waves per SIMD
+    case 96: return small == 3 ? launch_mlp_t<T, 6, 2, 8, 2 * KC, 2>(ng, ap, s)   // 256 tokens / WG in 8 waves: half the weight re-streaming
+                  : small ? launch_mlp_t<T, 6, 2, 4, 2 * KC, 2>(ng, ap, s)     // 128 tokens / WG, 2 waves per SIMD
                           : launch_mlp_t<T, 6, 4, 4, 2 * KC, 1>(ng, ap, s);    // 256 tokens / WG, 24 KB stages
-    default: return small ? launch_mlp_t<T, 12, 1, 4, KC, 2>(ng, ap, s)        // 64 tokens / WG, 2 waves per SIMD
+    default: return small == 3 ? launch_mlp_t<T, 12, 2, 8, KC, 2>(ng, ap, s)   // 256 tokens / WG in 8 waves
+                  : small == 2 ? launch_mlp_t<T, 12, 2, 4, KC, 2>(ng, ap, s)   // 128 tokens / WG, registers capped for 2 waves per SIMD
+                  : small ? launch_mlp_t<T, 12, 1, 4, KC, 2>(ng, ap, s)        // 64 tokens / WG, 2 waves per SIMD
                           : launch_mlp_t<T, 12, 2, 4, KC, 1>(ng, ap, s);       // 128 tokens / WG, 24 KB stages
   }
 }
@@ -331,7 +334,7 @@ int launch_mlp(int ng, const MlpArgs* ap, hipStream_t s) {
 // D = 384 (LViT level 3, 8192 tokens per batch of 8) does not fill the chip with 128-token workgroups and its
 // 4.7 MB of weights per instance exceed what one CU can stream per token tile: the tiled GEMM path is faster there.
 int& cfen_tune_mlp_small_tiles() {
-  static int v = 1;
+  static int v = 3;
   return v;
 }
 
