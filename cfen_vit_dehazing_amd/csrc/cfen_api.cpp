@@ -92,6 +92,13 @@ int cfen_embed_qkv(int dtype, const cfen_embed_qkv_args* a, void* stream) {
   return cfen_embed_qkv_impl_g(dtype, 1, &q, (hipStream_t)stream);
 }
 
+int cfen_u8hwc_to_nhwc(int dtype, const unsigned char* in, void* out, int B, int H, int W, int cs, void* stream) {
+  return cfen_u8hwc_to_nhwc_impl(dtype, in, out, B, H, W, cs, (hipStream_t)stream);
+}
+int cfen_tensor2im_u8(const float* in, unsigned char* out, int C, int H, int W, void* stream) {
+  return cfen_tensor2im_u8_impl(in, out, C, H, W, (hipStream_t)stream);
+}
+
 int cfen_tune(const char* key, int value) {
   CFEN_CHECK_ARG(key != nullptr, "tune: null key");
   if (!strcmp(key, "gemm.kernel")) {

@@ -40,6 +40,8 @@ int cfen_patchify_impl(int dtype, const void* fmap, void* tok, int B, int H, int
                        hipStream_t s);
 int cfen_upsample4_impl(int dtype, const void* small, void* out, int B, int h, int w, int C, int cs_in, int cs_out, hipStream_t s);
 int cfen_nchw_to_nhwc_impl(int dtype, const float* in, void* out, int B, int C, int H, int W, int cs, hipStream_t s);
+int cfen_tensor2im_u8_impl(const float* in, unsigned char* out, int C, int H, int W, hipStream_t s);
+int cfen_u8hwc_to_nhwc_impl(int dtype, const unsigned char* in, void* out, int B, int H, int W, int cs, hipStream_t s);
 int cfen_conv_impl(int dtype, const ConvDesc* d, hipStream_t s);
 // LDS-tiled stride-1 path (k_conv_tile.hip); weights in the "rows" layout, d->Kpad == cfen_conv_tile_kpad
 bool cfen_conv_tile_supported(int dtype, int kind, int k, int stride, int pad, int nsrc, int cs_in, int Cout_pad, int H, int W);

@@ -171,6 +171,33 @@ __global__ __launch_bounds__(256) void k_nchw_to_nhwc(const float* __restrict__ 
   }
 }
 
+// (x + 1) / 2 * 255 then a truncating cast, no clamp, 1-channel tensors tiled to 3: util/util.py:12-24 on device.
+// in: (C,H,W) fp32, out: (H,W,3) uint8.  The reference computes in float32 (numpy keeps the tensor's dtype) -- so do we.
+__global__ __launch_bounds__(256) void k_tensor2im_u8(const float* __restrict__ in, unsigned char* __restrict__ out, int C, long long npix) {
+  for (long long p = (long long)blockIdx.x * 256 + threadIdx.x; p < npix; p += (long long)gridDim.x * 256) {
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      const float v = in[(C == 1 ? 0 : c) * npix + p];
+      out[p * 3 + c] = (unsigned char)(int)((v + 1.f) / 2.0f * 255.0f);
+    }
+  }
+}
+
+// ToTensor + Normalize((0.5,)*3, (0.5,)*3) (data/base_dataset.py:44-46) fused with the NHWC layout change:
+// in: (B,H,W,3) uint8, out: NHWC T with channel stride cs, value v / 255 * 2 - 1 evaluated as ((v / 255) - 0.5) / 0.5 in fp32.
+template <typename T>
+__global__ __launch_bounds__(256) void k_u8hwc_to_nhwc(const unsigned char* __restrict__ in, T* __restrict__ out, int cs, long long npix) {
+  constexpr int EPL = Vec16<T>::N;
+  for (long long p = (long long)blockIdx.x * 256 + threadIdx.x; p < npix; p += (long long)gridDim.x * 256) {
+    for (int c0 = 0; c0 < cs; c0 += EPL) {
+      float o[EPL];
+#pragma unroll
+      for (int e = 0; e < EPL; ++e) o[e] = (c0 + e < 3) ? ((float)in[p * 3 + c0 + e] / 255.0f - 0.5f) / 0.5f : 0.f;
+      Vec16<T>::store(out + p * cs + c0, o);
+    }
+  }
+}
+
 inline unsigned grid_for(long long n) {
   long long g = (n + 255) / 256;
   return (unsigned)(g < 1 ? 1 : (g > 16384 ? 16384 : g));
@@ -252,6 +279,31 @@ int cfen_upsample4_impl_g(int dtype, int ng, const void* const* small, void* con
 }
 int cfen_upsample4_impl(int dtype, const void* small, void* out, int B, int h, int w, int C, int cs_in, int cs_out, hipStream_t s) {
   return cfen_upsample4_impl_g(dtype, 1, &small, &out, B, h, w, C, cs_in, cs_out, s);
+}
+
+int cfen_tensor2im_u8_impl(const float* in, unsigned char* out, int C, int H, int W, hipStream_t s) {
+  CFEN_CHECK_ARG(in && out && (C == 1 || C == 3) && H > 0 && W > 0, "tensor2im_u8: needs a (1|3,H,W) fp32 tensor");
+  const long long npix = (long long)H * W;
+  CFEN_LAUNCH(k_tensor2im_u8, dim3(grid_for(npix)), dim3(256), 0, s, in, out, C, npix);
+  CFEN_CHECK_LAUNCH("tensor2im_u8");
+  return CFEN_OK;
+}
+
+int cfen_u8hwc_to_nhwc_impl(int dtype, const unsigned char* in, void* out, int B, int H, int W, int cs, hipStream_t s) {
+  CFEN_CHECK_ARG(in && out && B > 0 && H > 0 && W > 0 && cs >= 3 && cfen_aligned16(out), "u8hwc_to_nhwc: bad arguments");
+  const long long npix = (long long)B * H * W;
+  if (dtype == 1) {
+    CFEN_CHECK_ARG(cs % 8 == 0, "u8hwc_to_nhwc: cs must be a multiple of 8");
+    CFEN_LAUNCH(k_u8hwc_to_nhwc<half_t>, dim3(grid_for(npix)), dim3(256), 0, s, in, (half_t*)out, cs, npix);
+  } else if (dtype == 0) {
+    CFEN_CHECK_ARG(cs % 4 == 0, "u8hwc_to_nhwc: cs must be a multiple of 4");
+    CFEN_LAUNCH(k_u8hwc_to_nhwc<float>, dim3(grid_for(npix)), dim3(256), 0, s, in, (float*)out, cs, npix);
+  } else {
+    cfen_set_error("u8hwc_to_nhwc: unknown dtype %d", dtype);
+    return CFEN_ERR_ARG;
+  }
+  CFEN_CHECK_LAUNCH("u8hwc_to_nhwc");
+  return CFEN_OK;
 }
 
 int cfen_nchw_to_nhwc_impl(int dtype, const float* in, void* out, int B, int C, int H, int W, int cs, hipStream_t s) {

@@ -194,6 +194,28 @@ def cfsm2g(x0, x1, x2, w, C):
     return out
 
 
+def tensor2im_u8(x):
+    """(1|3,H,W) fp32 CUDA tensor in [-1,1] -> (H,W,3) uint8 CUDA tensor; util.tensor2im on the device"""
+    _cuda(x)
+    if x.dim() != 3 or x.dtype != torch.float32 or not x.is_contiguous():
+        raise ValueError("tensor2im_u8 needs a contiguous (C,H,W) float32 tensor")
+    C, H, W = x.shape
+    out = torch.empty(H, W, 3, dtype=torch.uint8, device=x.device)
+    check(_lib.load().cfen_tensor2im_u8(ptr(x), ptr(out), C, H, W, current_stream()), "tensor2im_u8")
+    return out
+
+
+def u8hwc_to_nhwc(img, cs, dtype):
+    """(B,H,W,3) uint8 CUDA tensor -> normalised NHWC [B,H,W,cs] of `dtype` (ToTensor + Normalize(0.5, 0.5) + layout)"""
+    _cuda(img)
+    if img.dim() != 4 or img.shape[3] != 3 or img.dtype != torch.uint8 or not img.is_contiguous():
+        raise ValueError("u8hwc_to_nhwc needs a contiguous (B,H,W,3) uint8 tensor")
+    B, H, W, _ = img.shape
+    out = torch.empty(B, H, W, cs, dtype=dtype, device=img.device)
+    check(_lib.load().cfen_u8hwc_to_nhwc(dtype_code(dtype), ptr(img), ptr(out), B, H, W, cs, current_stream()), "u8hwc_to_nhwc")
+    return out
+
+
 def to_nhwc(x, cs=None, dtype=None):
     """NCHW torch tensor -> zero-padded NHWC (test helper; plain torch, not on the product path)."""
     B, C, H, W = x.shape

@@ -13,6 +13,10 @@ def tensor2im(input_image, imtype=np.uint8):
         image_tensor = input_image.data
     else:
         return input_image
+    if image_tensor.is_cuda and image_tensor.dim() == 3 and imtype == np.uint8:
+        # same arithmetic on the device (csrc/k_tokens.hip: k_tensor2im_u8): only H*W*3 bytes cross PCIe instead of fp32 planes
+        from .. import ops
+        return ops.tensor2im_u8(image_tensor.float().contiguous()).cpu().numpy()
     image_numpy = image_tensor.cpu().float().numpy()
     if image_numpy.shape[0] == 1:
         image_numpy = np.tile(image_numpy, (3, 1, 1))

@@ -141,6 +141,11 @@ int cfen_unpatchify(int dtype, const void* tokens, void* fmap, int B, int H, int
 /* two successive bilinear x2 upsamples, align_corners=False                           (v3:1323) */
 int cfen_upsample4(int dtype, const void* small, void* out, int B, int h, int w, int C, int cs_in, int cs_out, void* stream);
 int cfen_nchw_to_nhwc(int dtype, const float* in, void* out, int B, int C, int H, int W, int cs, void* stream);
+/* pre / post-processing on the device:
+ * uint8 (B,H,W,3) image -> NHWC T, channels zero-padded to cs, v -> ((v/255) - 0.5) / 0.5   (ToTensor + Normalize, data/base_dataset.py:44-46)
+ * (1|3,H,W) fp32 in [-1,1] -> (H,W,3) uint8, (x+1)/2*255 truncated, 1 channel tiled to 3    (tensor2im, util/util.py:12-24)              */
+int cfen_u8hwc_to_nhwc(int dtype, const unsigned char* in, void* out, int B, int H, int W, int cs, void* stream);
+int cfen_tensor2im_u8(const float* in, unsigned char* out, int C, int H, int W, void* stream);
 
 /* Conv2d / ConvTranspose2d(4,2,1) as implicit GEMM with fused affine + activation + residuals.
  * kind 0: Conv2d(k, stride, pad) over nsrc (1|2) channel-concatenated inputs; kind 1: ConvTranspose2d k4 s2 p1.

@@ -3,6 +3,7 @@
 Tolerances: CFEN_F32 runs exact-fp32 MFMA -> 2e-5 * scale; CFEN_F16 stores fp16 and accumulates fp32 ->
 inputs are rounded to fp16 first and the result may differ by fp16 output rounding (2^-10 relative)."""
 import math
+import os
 
 import numpy as np
 import pytest
@@ -137,6 +138,27 @@ def test_upsample4(dtype):
     want = cfen_oracle.upsample2_bilinear(cfen_oracle.upsample2_bilinear(x.double()))
     got = ops.from_nhwc(ops.upsample4(ops.to_nhwc(x).to(dev())), C)
     close(got, want, tol(dtype))
+
+
+def test_tensor2im_u8_matches_reference_vectors(golden_dir):
+    """device tensor2im against the vectors captured from the reference's util.tensor2im (edge values, 1-channel tiling)"""
+    import numpy as np
+    kat = np.load(os.path.join(golden_dir, "ops_kat.npz"))
+    for xk, yk in (("t2i/x", "t2i/y"), ("t2i/x3", "t2i/y3")):
+        got = ops.tensor2im_u8(torch.from_numpy(kat[xk]).contiguous().to(dev()))
+        assert np.array_equal(got.cpu().numpy(), kat[yk])
+    x = torch.rand(3, 37, 53) * 2 - 1
+    from cfen_vit_dehazing_amd.util import util
+    assert np.array_equal(ops.tensor2im_u8(x.to(dev())).cpu().numpy(), util.tensor2im(x))
+
+
+def test_u8hwc_to_nhwc_equals_totensor_normalize():
+    img = torch.randint(0, 256, (2, 24, 40, 3), dtype=torch.uint8)
+    want = ((img.permute(0, 3, 1, 2).float() / 255.0) - 0.5) / 0.5          # ToTensor + Normalize(0.5, 0.5)
+    for dtype in DTYPES:
+        got = ops.u8hwc_to_nhwc(img.to(dev()), 8, dtype)
+        assert got.shape == (2, 24, 40, 8) and float(got[..., 3:].abs().max()) == 0.0
+        assert torch.equal(got[..., :3].cpu(), want.permute(0, 2, 3, 1).to(dtype))
 
 
 def test_nchw_to_nhwc():
