@@ -111,6 +111,10 @@ int cfen_tune(const char* key, int value) {
     (key[5] == 'l' ? cfen_tune_gemm_large() : cfen_tune_gemm_small()) = value;
     return CFEN_OK;
   }
+  if (!strcmp(key, "gemm.splitk")) {
+    cfen_tune_gemm_splitk() = value != 0;
+    return CFEN_OK;
+  }
   if (!strcmp(key, "net.fused_front_max_dim")) {
     cfen_tune_fused_front_max_dim() = value;
     return CFEN_OK;

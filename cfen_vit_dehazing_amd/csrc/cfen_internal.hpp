@@ -26,7 +26,8 @@ int cfen_embed_qkv_impl_g(int dtype, int ng, const CfenEmbedQkvArgs* a, hipStrea
 // grouped launches (cfen_common.hpp: CFEN_MAX_GROUPS problems of identical geometry, one launch)
 struct CfenGemmPtrs { const void* X; const void* W; const float* bias; const void* R; const void* P; void* Y; const void* gmap; };
 int cfen_gemm_impl_g(int dtype, int ng, const CfenGemmPtrs* gp, int ldx, int ldw, int ldr, int period, int ldy, int M, int N, int K, int relu,
-                     const CfenTokGather* tg, hipStream_t s);   // tg: geometry only, the maps are gp[g].gmap
+                     const CfenTokGather* tg, hipStream_t s, float* const* splitk_ws, size_t splitk_ws_bytes);
+// tg: geometry only, the maps are gp[g].gmap.  splitk_ws (may be null): one fp32 scratch per problem for split-K partial sums
 int cfen_patchify_impl_g(int dtype, int ng, const void* const* fmap, void* const* tok, int B, int H, int W, int C, int cs, int ws, int p, int pool,
                          int inverse, hipStream_t s);
 int cfen_upsample4_impl_g(int dtype, int ng, const void* const* small, void* const* out, int B, int h, int w, int C, int cs_in, int cs_out,
@@ -69,3 +70,4 @@ int& cfen_tune_mlp_small_tiles();   // fused-MLP tiling ("mlp.small_tiles"): 0 2
                                     // 2 waves/SIMD, 2 as 1 but TM = 2 for D = 192 (register-capped), 3 (default) 8-wave WGs: half the weight re-streaming
 int& cfen_tune_skip_classes();    // bit mask of kernel classes NOT launched by the net (marginal-cost timing; outputs invalid) ("net.skip_classes")
 int& cfen_tune_fused_front_max_dim();   // k_embed_qkv is used for LViT embedding dims <= this (0 = never) ("net.fused_front_max_dim")
+int& cfen_tune_gemm_splitk();     // 1 (default): K-heavy few-token GEMMs run split-K when the caller provides scratch ("gemm.splitk")

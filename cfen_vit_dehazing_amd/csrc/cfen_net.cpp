@@ -405,6 +405,8 @@ int cfen_net::run_vit_g(int ng, const VitCall* vc, int scr0) {
     cX0[g] = X0[g]; cX1[g] = X1[g]; cYN[g] = YN[g]; cQKV[g] = QKV[g]; cSM[g] = SM[g];
     nm[g] = w.name;
   }
+  const void* cHIDp[3] = {HID[0], HID[1], HID[2]};
+  const size_t scratch_stretch = scr_set[scr0].hid - scr_set[scr0].yn;   // bytes from YN to the end of QKV
   const double Md = (double)M * ng, D = v.D, Hd = v.hidden;
   auto step = [&](const char* what) { if (profiling) label = nm[0] + (ng > 1 ? " (x" + std::to_string(ng) + ")" : "") + ":" + what; };
   // Y = act(X W^T + bias) + R + P for every member; operand arrays are indexed by member
@@ -414,7 +416,13 @@ int cfen_net::run_vit_g(int ng, const VitCall* vc, int scr0) {
     for (int g = 0; g < ng; ++g)
       gp[g] = CfenGemmPtrs{tg ? nullptr : X[g], P(nm[g] + wname), bname ? Pf(nm[g] + bname) : nullptr, R ? R[g] : nullptr,
                            pname ? P(nm[g] + pname) : nullptr, Y[g], tg ? IN[g] : nullptr};
-    return cfen_gemm_impl_g(dt, ng, gp, K, K, N, v.S, N, M, N, K, relu, tg, stream);
+    // split-K scratch: the YN | ATT | QKV stretch of the member's scratch set (contiguous, 5 * md elements), free while the
+    // FFN / mlp_head GEMMs run -- the only K-heavy ones
+    float* ws[3] = {nullptr, nullptr, nullptr};
+    const bool ffn = X == (const void* const*)cHIDp;
+    if (ffn)
+      for (int g = 0; g < ng; ++g) ws[g] = (float*)YN[g];
+    return cfen_gemm_impl_g(dt, ng, gp, K, K, N, v.S, N, M, N, K, relu, tg, stream, ffn ? ws : nullptr, ffn ? scratch_stretch : 0);
   };
   const float* lg[3];
   const float* lb[3];
@@ -474,7 +482,7 @@ int cfen_net::run_vit_g(int ng, const VitCall* vc, int scr0) {
     step("ln2");
     for (int g = 0; g < ng; ++g) { lg[g] = Pf(nm[g] + ".ln2.g"); lb[g] = Pf(nm[g] + ".ln2.b"); }
     TRYP(K_LNORM, 0, cfen_layernorm_impl_g(dt, ng, cX1, YN, lg, lb, M, v.D, 1e-5f, stream));
-    const void* cHID[3] = {HID[0], HID[1], HID[2]};
+    const void* const* cHID = cHIDp;
     step("ffn1");
     TRYP(K_GEMM, 2 * Md * D * Hd, gemm(cYN, ".ffn1.w", ".ffn1.b", nullptr, nullptr, HID, v.hidden, v.D, 1, nullptr));
     step("ffn2");

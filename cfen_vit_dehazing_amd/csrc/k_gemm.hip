@@ -56,6 +56,10 @@ template <typename T> struct GemmArgs {
   // token m = (image, window, patch), k = (i, j, c) -> pixel (y + i, x + j), channel c.
   const T* gmap;
   int gH, gW, gcs, gC, gws, gp;
+  // optional split-K (k_gemm_dma only): blockIdx.y = K slice; partial sums go to `part` [nsplit][M][N] fp32 and
+  // k_gemm_splitk_finish adds them in slice order and applies the epilogue -- deterministic, no atomics
+  float* part;
+  int nsplit;
 };
 
 // pointer to channel 0 of the top-left pixel of token m's patch
@@ -273,7 +277,15 @@ __global__ __launch_bounds__(256) void k_gemm_dma(Grouped<GemmArgs<T>> ga) {
   for (int j = 0; j < TM; ++j) boff[j] = (G_BN + wm * 16 * TM + j * 16 + r16) * G_BKB;
   const int sw = r16 & 7;   // every fragment row of this lane has (row & 7) == (r16 & 7): all tile offsets are multiples of 16
 
-  const int nk = a.K / BK;
+  const int nk = a.K / BK / a.nsplit;          // K-steps of this slice
+  {
+    const int kbeg = (int)blockIdx.y * nk * BK;
+#pragma unroll
+    for (int i = 0; i < LOADS; ++i) {
+      if (gpc[i] >= 0) gpc[i] += kbeg;         // gathered rows recompute their offset from the absolute k
+      else gptr[i] += kbeg;
+    }
+  }
 #pragma unroll
   for (int st = 0; st < NS - 1; ++st)
     if (st < nk) CFEN_GEMM_DMA_ISSUE(st, st);
@@ -305,8 +317,38 @@ __global__ __launch_bounds__(256) void k_gemm_dma(Grouped<GemmArgs<T>> ga) {
     buf = buf + 1 == NS ? 0 : buf + 1;
   }
 
+  if (a.nsplit > 1) {   // fp32 partial tile of this K slice
+    float* pp = a.part + (size_t)blockIdx.y * a.M * a.N;
+    const int n = n0 + wn * 48 + 4 * h, m = m0 + wm * 16 * TM + r16;
+#pragma unroll
+    for (int j = 0; j < TM; ++j)
+#pragma unroll
+      for (int i = 0; i < 3; ++i)
+        if (m + 16 * j < a.M && n + 16 * i < a.N) *reinterpret_cast<floatx4*>(pp + (size_t)(m + 16 * j) * a.N + n + 16 * i) = acc[i][j];
+    return;
+  }
   gemm_epilogue<T, TM>(a, acc, n0 + wn * 48 + 4 * h, m0 + wm * 16 * TM + r16);
 #undef CFEN_GEMM_DMA_ISSUE
+}
+
+// Second pass of a split-K GEMM: Y = act(sum_s part[s] + bias) + R + P, slices added in index order.
+template <typename T>
+__global__ __launch_bounds__(256) void k_gemm_splitk_finish(Grouped<GemmArgs<T>> ga) {
+  const GemmArgs<T>& a = ga.g[blockIdx.z];
+  const long long nvec = (long long)a.M * (a.N / 4);
+  for (long long idx = (long long)blockIdx.x * 256 + threadIdx.x; idx < nvec; idx += (long long)gridDim.x * 256) {
+    const int m = (int)(idx / (a.N / 4)), n = (int)(idx % (a.N / 4)) * 4;
+    floatx4 v = *reinterpret_cast<const floatx4*>(a.part + (size_t)m * a.N + n);
+    for (int sidx = 1; sidx < a.nsplit; ++sidx) v += *reinterpret_cast<const floatx4*>(a.part + ((size_t)sidx * a.M + m) * a.N + n);
+    if (a.bias) v += *reinterpret_cast<const floatx4*>(a.bias + n);
+    if (a.relu) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f);
+    }
+    if (a.R) v += load4<T>(a.R + (size_t)m * a.ldr + n);
+    if (a.P) v += load4<T>(a.P + (size_t)(m % a.period) * a.N + n);
+    store4<T>(a.Y + (size_t)m * a.ldy + n, v);
+  }
 }
 
 // Small-M variant (GViT: 128..2048 tokens per batch against weight matrices of up to 6144 x 1536): the
@@ -365,7 +407,7 @@ __global__ __launch_bounds__(256) void k_gemm_skinny(Grouped<GemmArgs<T>> ga) {
 
 template <typename T>
 int launch_gemm(int ng, const CfenGemmPtrs* gp, int ldx, int ldw, int ldr, int period, int ldy, int M, int N, int K, int relu, hipStream_t s,
-                const CfenTokGather* tg) {
+                const CfenTokGather* tg, float* const* splitk_ws, size_t splitk_ws_bytes) {
   constexpr int EPL = Mma<T>::EPL;
   CFEN_CHECK_ARG(ng >= 1 && ng <= CFEN_MAX_GROUPS && gp, "gemm: 1..%d problems per launch", CFEN_MAX_GROUPS);
   if (tg) {   // X and R are the patch tokens of an NHWC map (gp[g].gmap)
@@ -393,6 +435,7 @@ int launch_gemm(int ng, const CfenGemmPtrs* gp, int ldx, int ldw, int ldr, int p
     GemmArgs<T>& a = ga.g[g];
     a.X = (const T*)(tg ? q.gmap : q.X); a.W = (const T*)q.W; a.bias = q.bias; a.R = (const T*)q.R; a.P = (const T*)q.P; a.Y = (T*)q.Y;
     a.M = M; a.N = N; a.K = K; a.ldx = ldx; a.ldw = ldw; a.ldr = ldr; a.ldy = ldy; a.period = period; a.relu = relu;
+    a.nsplit = 1;
     if (tg) {
       a.gmap = (const T*)q.gmap; a.gH = tg->H; a.gW = tg->W; a.gcs = tg->cs; a.gC = tg->C; a.gws = tg->ws; a.gp = tg->p;
     }
@@ -409,6 +452,15 @@ int launch_gemm(int ng, const CfenGemmPtrs* gp, int ldx, int ldw, int ldr, int p
   const long long tiles64 = (long long)ng * ((N + G_BN - 1) / G_BN) * ((M + 63) / 64);
   const long long tiles32 = (long long)ng * ((N + G_BN - 1) / G_BN) * ((M + 31) / 32);
   int kern = forced < 0 ? -1 : forced % 10, stages = forced < 0 ? 2 : 2 + forced / 10;
+  // K-heavy GEMMs with a handful of tokens (GViT-3 ffn2 / head2: 128 x 1536 x 6144): one 96 x 128 tile per feature block
+  // so the weights are read once, K cut into slices for parallelism, partial sums reduced by a second tiny launch
+  int nsplit = 1;
+  if (forced < 0 && k128 && splitk_ws && !tg && M <= 128 && K >= 4 * N && cfen_tune_gemm_splitk()) {
+    const int nk = K / (G_BKB / (int)sizeof(T));
+    nsplit = 8;
+    while (nsplit > 1 && (nk % nsplit || (size_t)nsplit * M * N * sizeof(float) > splitk_ws_bytes)) nsplit /= 2;
+    if (nsplit > 1) { kern = 2; stages = 2; }
+  }
   if (kern < 0) {
     const int pick = !k128 ? 0 : (M <= 128 && N <= 2048 && !tg) ? 1 : tiles64 >= 1024 ? cfen_tune_gemm_large() : tiles32 <= 512 ? cfen_tune_gemm_small() : 5;
     kern = pick % 10;
@@ -418,10 +470,15 @@ int launch_gemm(int ng, const CfenGemmPtrs* gp, int ldx, int ldw, int ldr, int p
   if (kern < 2) stages = 2;
   const int bn = kern == 1 ? 16 : G_BN, bm = kern == 0 || kern == 2 ? 128 : kern == 3 ? 96 : kern == 4 || kern == 1 ? 64 : 32;
   const TileMap map = make_tile_map((N + bn - 1) / bn, (M + bm - 1) / bm, (double)N * K * sizeof(T), (double)M * K * sizeof(T));
-  for (int g = 0; g < ng; ++g) ga.g[g].map = map;
+  for (int g = 0; g < ng; ++g) {
+    ga.g[g].map = map;
+    ga.g[g].nsplit = nsplit;
+    ga.g[g].part = nsplit > 1 ? splitk_ws[g] : nullptr;
+    CFEN_CHECK_ARG(nsplit == 1 || (splitk_ws[g] && cfen_aligned16(splitk_ws[g])), "gemm: split-K workspace missing");
+  }
   const long long blocks = 8LL * map.cn * map.cm;
   CFEN_CHECK_ARG(blocks < (1LL << 31), "gemm: problem too large for one launch");
-  const dim3 grid((unsigned)blocks, 1, (unsigned)ng);
+  const dim3 grid((unsigned)blocks, (unsigned)nsplit, (unsigned)ng);
   switch (kern + 10 * (stages - 2)) {
     case 0: case 10: case 20: CFEN_LAUNCH(k_gemm_nt<T>, grid, dim3(256), 0, s, ga); break;
     case 1: case 11: case 21: CFEN_LAUNCH(k_gemm_skinny<T>, grid, dim3(256), 0, s, ga); break;
@@ -434,11 +491,20 @@ int launch_gemm(int ng, const CfenGemmPtrs* gp, int ldx, int ldw, int ldr, int p
     default: CFEN_LAUNCH((k_gemm_dma<T, 1, 4>), grid, dim3(256), 0, s, ga); break;
   }
   CFEN_CHECK_LAUNCH("gemm");
+  if (nsplit > 1) {
+    const long long nvec = (long long)M * (N / 4);
+    CFEN_LAUNCH(k_gemm_splitk_finish<T>, dim3((unsigned)((nvec + 255) / 256), 1, (unsigned)ng), dim3(256), 0, s, ga);
+    CFEN_CHECK_LAUNCH("gemm (split-K finish)");
+  }
   return CFEN_OK;
 }
 
 }  // namespace
 
+int& cfen_tune_gemm_splitk() {
+  static int v = 1;
+  return v;
+}
 int& cfen_tune_gemm_large() {
   static int v = 4;
   return v;
@@ -453,9 +519,9 @@ int& cfen_tune_gemm_kernel() {
 }
 
 int cfen_gemm_impl_g(int dtype, int ng, const CfenGemmPtrs* gp, int ldx, int ldw, int ldr, int period, int ldy, int M, int N, int K, int relu,
-                     const CfenTokGather* tg, hipStream_t s) {
-  if (dtype == 1) return launch_gemm<half_t>(ng, gp, ldx, ldw, ldr, period, ldy, M, N, K, relu, s, tg);
-  if (dtype == 0) return launch_gemm<float>(ng, gp, ldx, ldw, ldr, period, ldy, M, N, K, relu, s, tg);
+                     const CfenTokGather* tg, hipStream_t s, float* const* splitk_ws, size_t splitk_ws_bytes) {
+  if (dtype == 1) return launch_gemm<half_t>(ng, gp, ldx, ldw, ldr, period, ldy, M, N, K, relu, s, tg, splitk_ws, splitk_ws_bytes);
+  if (dtype == 0) return launch_gemm<float>(ng, gp, ldx, ldw, ldr, period, ldy, M, N, K, relu, s, tg, splitk_ws, splitk_ws_bytes);
   cfen_set_error("gemm: unknown dtype %d", dtype);
   return CFEN_ERR_ARG;
 }
@@ -463,7 +529,7 @@ int cfen_gemm_impl_g(int dtype, int ng, const CfenGemmPtrs* gp, int ldx, int ldw
 int cfen_gemm_impl(int dtype, const void* X, int ldx, const void* W, int ldw, const float* bias, const void* R, int ldr,
                    const void* P, int period, void* Y, int ldy, int M, int N, int K, int relu, hipStream_t s) {
   const CfenGemmPtrs q{X, W, bias, R, P, Y, nullptr};
-  return cfen_gemm_impl_g(dtype, 1, &q, ldx, ldw, ldr, period, ldy, M, N, K, relu, nullptr, s);
+  return cfen_gemm_impl_g(dtype, 1, &q, ldx, ldw, ldr, period, ldy, M, N, K, relu, nullptr, s, nullptr, 0);
 }
 
 int cfen_embed_gather_impl(int dtype, const CfenTokGather* tg, const void* W, int ldw, const float* bias, const void* P, int period,
@@ -471,5 +537,5 @@ int cfen_embed_gather_impl(int dtype, const CfenTokGather* tg, const void* W, in
   CFEN_CHECK_ARG(tg != nullptr, "embed_gather: null geometry");
   const int D = tg->p * tg->p * tg->C;
   const CfenGemmPtrs q{nullptr, W, bias, nullptr, P, Y, tg->map};
-  return cfen_gemm_impl_g(dtype, 1, &q, D, ldw, 0, period, ldy, M, D, D, 0, tg, s);
+  return cfen_gemm_impl_g(dtype, 1, &q, D, ldw, 0, period, ldy, M, D, D, 0, tg, s, nullptr, 0);
 }
