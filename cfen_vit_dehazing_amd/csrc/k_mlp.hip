@@ -75,23 +75,25 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(WPE, WP
   if (a.Wp) {   // x += Wp att: the attention block's out_proj + residual, operands straight from L1/L2 (natural k order)
     const T* Wp = (const T*)a.Wp + (size_t)r16 * D + h * EPL;
     constexpr int NKC = D / KC;
-    frag ab[NKC][TM];
+    const T* ap[TM];
 #pragma unroll
     for (int j = 0; j < TM; ++j) {
       long long t = tok0 + j * 16 + r16;
       if (t >= a.M) t = a.M - 1;
-      const T* ap = (const T*)a.A + t * D + h * EPL;
-#pragma unroll
-      for (int c = 0; c < NKC; ++c) ab[c][j] = load_frag<T>(ap + c * KC);
+      ap[j] = (const T*)a.A + t * D + h * EPL;
     }
 #pragma unroll
-    for (int i = 0; i < ND; ++i)
+    for (int c = 0; c < NKC; ++c) {   // k chunk outermost: only TM token fragments are live at a time
+      frag ab[TM];
 #pragma unroll
-      for (int c = 0; c < NKC; ++c) {
+      for (int j = 0; j < TM; ++j) ab[j] = load_frag<T>(ap[j] + c * KC);
+#pragma unroll
+      for (int i = 0; i < ND; ++i) {
         const frag af = load_frag<T>(Wp + (size_t)i * 16 * D + c * KC);
 #pragma unroll
-        for (int j = 0; j < TM; ++j) acc[i][j] = Mma<T>::mma(af, ab[c][j], acc[i][j]);
+        for (int j = 0; j < TM; ++j) acc[i][j] = Mma<T>::mma(af, ab[j], acc[i][j]);
       }
+    }
   }
 
   frag xb[NCH][TM];
@@ -319,10 +321,11 @@ int launch_mlp(int ng, const MlpArgs* ap, hipStream_t s) {
   }
   const int small = cfen_tune_mlp_small_tiles();
   switch (ap[0].D) {
-    case 96: return small == 3 ? launch_mlp_t<T, 6, 2, 8, 2 * KC, 2>(ng, ap, s)   // 256 tokens / WG in 8 waves: half the weight re-streaming
+    case 96: return small >= 3 ? launch_mlp_t<T, 6, 2, 8, 2 * KC, 2>(ng, ap, s)   // 256 tokens / WG in 8 waves: half the weight re-streaming
                   : small ? launch_mlp_t<T, 6, 2, 4, 2 * KC, 2>(ng, ap, s)     // 128 tokens / WG, 2 waves per SIMD
                           : launch_mlp_t<T, 6, 4, 4, 2 * KC, 1>(ng, ap, s);    // 256 tokens / WG, 24 KB stages
-    default: return small == 3 ? launch_mlp_t<T, 12, 2, 8, KC, 2>(ng, ap, s)   // 256 tokens / WG in 8 waves
+    default: return small == 4 ? launch_mlp_t<T, 12, 1, 8, KC, 2>(ng, ap, s)   // 128 tokens / WG in 8 waves, no spills
+                  : small == 3 ? launch_mlp_t<T, 12, 2, 8, KC, 2>(ng, ap, s)   // 256 tokens / WG in 8 waves
                   : small == 2 ? launch_mlp_t<T, 12, 2, 4, KC, 2>(ng, ap, s)   // 128 tokens / WG, registers capped for 2 waves per SIMD
                   : small ? launch_mlp_t<T, 12, 1, 4, KC, 2>(ng, ap, s)        // 64 tokens / WG, 2 waves per SIMD
                           : launch_mlp_t<T, 12, 2, 4, KC, 1>(ng, ap, s);       // 128 tokens / WG, 24 KB stages

@@ -53,3 +53,14 @@ def test_argument_errors_do_not_need_a_gpu():
     assert lib.cfen_net_create(ctypes.byref(h), ctypes.byref(cfg)) == 0
     assert abs(lib.cfen_net_flops_per_image(h) / 1e9 - 624.21) < 0.01
     lib.cfen_net_destroy(h)
+
+
+def test_tuning_knobs_validate_without_a_gpu():
+    from cfen_vit_dehazing_amd import _lib
+    lib = _lib.load()
+    assert lib.cfen_tune(b"no.such.knob", 1) == -1 and b"unknown key" in lib.cfen_last_error()
+    assert lib.cfen_tune(b"gemm.kernel", 99) == -1
+    assert lib.cfen_tune(b"gemm.large", 1) == -1            # tile ids are 2..5 (+10 / +20 for deeper rings)
+    for key, val in ((b"gemm.kernel", -1), (b"gemm.large", 4), (b"gemm.small", 5), (b"gemm.splitk", 1), (b"mlp.small_tiles", 3),
+                     (b"net.embed_gather", 1), (b"net.fused_front_max_dim", 192), (b"net.skip_classes", 0)):
+        assert lib.cfen_tune(key, val) == 0, key

@@ -188,3 +188,37 @@ def test_native_graph_replay_equals_eager():
     again = net(x)
     for a, b in zip(want, again):
         assert torch.equal(a, b)
+
+
+def test_profile_entries_label_every_launch():
+    """cfen_net_profile_entry: one labelled record per launch; the decoders' layers go out as grouped launches (x3)"""
+    cfg = NetConfig(24, 4, patch_size=8, load_size=64)
+    net = make_net(cfg, "fp16")
+    x = synthetic_input(2, cfg).to("cuda:0")
+    prof = net.profile(x)
+    launches = prof["launches"]
+    assert sum(prof[c][2] for c in net.KERNEL_CLASSES) == len(launches) > 50
+    labels = [l[0] for l in launches]
+    assert labels[0] == "input:nchw_to_nhwc" and any("(x3)" in l for l in labels) and any(l.startswith("tail_R.conv7") for l in labels)
+    assert all(ms > 0 for _, _, _, ms in launches)
+    assert abs(sum(f for _, _, f, _ in launches) - sum(prof[c][1] for c in net.KERNEL_CLASSES)) < 1e-3 * sum(prof[c][1] for c in net.KERNEL_CLASSES)
+
+
+def test_split_k_and_grouping_knobs_do_not_change_results():
+    """the split-K path (GViT-3 ffn2 / head2 at <= 128 tokens) and its plain counterpart agree to fp16 rounding, both deterministic"""
+    from cfen_vit_dehazing_amd import ops
+    cfg = NetConfig(24, 4, patch_size=32, load_size=256)
+    x = synthetic_input(1, cfg).to("cuda:0")
+    outs = {}
+    try:
+        for k in (1, 0):
+            ops.tune("gemm.splitk", k)
+            net = make_net(cfg, "fp16")
+            a = [o.clone() for o in net(x)]
+            b = [o.clone() for o in net(x)]
+            assert all(torch.equal(p, q) for p, q in zip(a, b))
+            outs[k] = a
+    finally:
+        ops.tune("gemm.splitk", 1)
+    for p, q in zip(outs[0], outs[1]):
+        assert float((p - q).abs().max()) < 5e-3
