@@ -111,6 +111,10 @@ int cfen_tune(const char* key, int value) {
     (key[5] == 'l' ? cfen_tune_gemm_large() : cfen_tune_gemm_small()) = value;
     return CFEN_OK;
   }
+  if (!strcmp(key, "embed.lds")) {
+    cfen_tune_embed_lds() = value & 3;
+    return CFEN_OK;
+  }
   if (!strcmp(key, "gemm.splitk")) {
     cfen_tune_gemm_splitk() = value != 0;
     return CFEN_OK;

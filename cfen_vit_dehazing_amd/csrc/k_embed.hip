@@ -144,6 +144,175 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(2, 2)))
   }
 }
 
+// Variant with the weights staged through LDS: 8 waves (TM*128 tokens) share each 16-feature weight tile instead of every
+// wave pulling all of W_e / W_qkv from L2 on its own -- at D = 192 that is 288 KB per 32 tokens.  NG tiles per stage,
+// double buffered, the next stage's global loads in flight during the MFMAs (as k_mlp.hip).
+template <typename T, int ND, int TM, int NG>
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_embed_qkv_lds(Grouped<CfenEmbedQkvArgs> ga) {
+  const CfenEmbedQkvArgs& a = ga.g[blockIdx.z];
+  constexpr int KC = Mma<T>::KC, EPL = Mma<T>::EPL, SZ = (int)sizeof(T);
+  constexpr int NPC = PackB<T>::NPC, NW = 8, NT = NW * 64;
+  constexpr int D = ND * 16, NCH = ND / NPC;
+  constexpr int ROWB = D * SZ + 32;                    // stride = 32 (mod 64) bytes: conflict-free ds_read_b128
+  constexpr int STAGE = NG * 16 * ROWB;
+  constexpr int PPR = D * SZ / 16, NP = NG * 16 * PPR; // 16-byte pieces per row / per stage
+  constexpr int NPF = (NP + NT - 1) / NT;
+  constexpr int NES = ND / NG, NQS = 3 * ND / NG;      // embedding / qkv stages
+  static_assert(ND % NG == 0 && 2 * STAGE <= 65536, "stage geometry");
+  typedef typename Mma<T>::frag frag;
+  __shared__ __attribute__((aligned(16))) unsigned char lds[2 * STAGE];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r16 = lane & 15, h = lane >> 4;
+  const long long tok0 = ((long long)blockIdx.x * NW + wave) * (TM * 16);
+
+  frag pf[NPF];
+  auto prefetch = [&](int st) {   // stage st: rows [st*NG*16, +NG*16) of W_e, then of W_qkv
+    const T* W = st < NES ? (const T*)a.We + (size_t)st * NG * 16 * D : (const T*)a.Wqkv + (size_t)(st - NES) * NG * 16 * D;
+#pragma unroll
+    for (int u = 0; u < NPF; ++u) {
+      const int id = tid + u * NT;
+      if (id < NP) pf[u] = load_frag<T>(W + (size_t)(id / PPR) * D + (id % PPR) * EPL);
+    }
+  };
+  auto commit = [&](unsigned char* buf) {
+#pragma unroll
+    for (int u = 0; u < NPF; ++u) {
+      const int id = tid + u * NT;
+      if (id < NP) *reinterpret_cast<frag*>(buf + (id / PPR) * ROWB + (id % PPR) * 16) = pf[u];
+    }
+  };
+  prefetch(0);
+
+  // ---- gather x^T into accumulator layout (tokens past M are clamped: the whole workgroup keeps hitting the barriers) ----
+  const int tw = a.ws / a.p, S = tw * tw, nwx = a.W / a.ws, nwy = a.H / a.ws;
+  floatx4 acc[ND][TM];
+  long long tk[TM];
+#pragma unroll
+  for (int j = 0; j < TM; ++j) {
+    long long t = tok0 + j * 16 + r16;
+    if (t >= a.M) t = a.M - 1;
+    tk[j] = t;
+    const int tt = (int)(t % S);
+    const long long wi = t / S;
+    const int wx = (int)(wi % nwx), wy = (int)((wi / nwx) % nwy);
+    const long long b = wi / ((long long)nwx * nwy);
+    const int y0 = wy * a.ws + (tt / tw) * a.p, x0 = wx * a.ws + (tt % tw) * a.p;
+    const T* pix = (const T*)a.fmap + ((b * a.H + y0) * a.W + x0) * a.cs;
+#pragma unroll
+    for (int i = 0; i < ND; ++i) {
+      const int f = i * 16 + 4 * h;
+      const int ij = f / a.C, c = f - ij * a.C;
+      acc[i][j] = load4<T>(pix + ((ij / a.p) * a.W + (ij % a.p)) * a.cs + c);
+    }
+  }
+  frag xb[NCH][TM];
+#pragma unroll
+  for (int j = 0; j < TM; ++j)
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+      floatx4 t[NPC];
+#pragma unroll
+      for (int u = 0; u < NPC; ++u) t[u] = acc[c * NPC + u][j];
+      xb[c][j] = PackB<T>::make(t);
+    }
+#pragma unroll
+  for (int i = 0; i < ND; ++i) {
+    const floatx4 bb = *reinterpret_cast<const floatx4*>(a.be + i * 16 + 4 * h);
+#pragma unroll
+    for (int j = 0; j < TM; ++j) acc[i][j] += bb + load4<T>((const T*)a.pos + (size_t)(tk[j] % S) * D + i * 16 + 4 * h);
+  }
+  commit(lds);
+  __syncthreads();
+
+  // ---- y = W_e x + (b_e + x + pos): embedding stages, accumulator indices are compile-time ----
+  const unsigned char* ap = lds + r16 * ROWB + h * 16;
+#pragma unroll
+  for (int st = 0; st < NES; ++st) {
+    prefetch(st + 1);                       // NES < NES + NQS: there is always a next stage
+#pragma unroll
+    for (int u = 0; u < NG; ++u)
+#pragma unroll
+      for (int c = 0; c < NCH; ++c) {
+        const frag af = *reinterpret_cast<const frag*>(ap + (st & 1) * STAGE + u * 16 * ROWB + c * 64);
+#pragma unroll
+        for (int j = 0; j < TM; ++j) acc[st * NG + u][j] = Mma<T>::mma(af, xb[c][j], acc[st * NG + u][j]);
+      }
+    commit(lds + ((st + 1) & 1) * STAGE);
+    __syncthreads();
+  }
+#pragma unroll
+  for (int j = 0; j < TM; ++j) {
+    if (tok0 + j * 16 + r16 >= a.M) continue;
+    T* yp = (T*)a.X1 + tk[j] * D + 4 * h;
+#pragma unroll
+    for (int i = 0; i < ND; ++i) store4<T>(yp + i * 16, acc[i][j]);
+  }
+  // ---- LayerNorm(y) -> B fragments ----
+#pragma unroll
+  for (int j = 0; j < TM; ++j) {
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < ND; ++i) s += acc[i][j][0] + acc[i][j][1] + acc[i][j][2] + acc[i][j][3];
+    s = col_sum(s);
+    const float mean = s * (1.f / D);
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < ND; ++i)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float d = acc[i][j][r] - mean;
+        q += d * d;
+      }
+    q = col_sum(q);
+    const float rstd = rsqrtf(q * (1.f / D) + a.eps);
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+      floatx4 t[NPC];
+#pragma unroll
+      for (int u = 0; u < NPC; ++u) {
+        const int i = c * NPC + u;
+        const floatx4 g = *reinterpret_cast<const floatx4*>(a.ln_g + i * 16 + 4 * h);
+        const floatx4 b = *reinterpret_cast<const floatx4*>(a.ln_b + i * 16 + 4 * h);
+        t[u] = (acc[i][j] - mean) * rstd * g + b;
+      }
+      xb[c][j] = PackB<T>::make(t);
+    }
+  }
+  // ---- qkv stages: every tile goes straight to HBM ----
+#pragma unroll 1
+  for (int sq = 0; sq < NQS; ++sq) {
+    const int st = NES + sq;
+    if (sq + 1 < NQS) prefetch(st + 1);
+#pragma unroll
+    for (int u = 0; u < NG; ++u) {
+      floatx4 q[TM];
+#pragma unroll
+      for (int j = 0; j < TM; ++j) q[j] = floatx4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int c = 0; c < NCH; ++c) {
+        const frag af = *reinterpret_cast<const frag*>(ap + (st & 1) * STAGE + u * 16 * ROWB + c * 64);
+#pragma unroll
+        for (int j = 0; j < TM; ++j) q[j] = Mma<T>::mma(af, xb[c][j], q[j]);
+      }
+#pragma unroll
+      for (int j = 0; j < TM; ++j)
+        if (tok0 + j * 16 + r16 < a.M) store4<T>((T*)a.QKV + tk[j] * (3 * D) + (sq * NG + u) * 16 + 4 * h, q[j]);
+    }
+    if (sq + 1 < NQS) commit(lds + ((st + 1) & 1) * STAGE);
+    __syncthreads();
+  }
+}
+
+template <typename T, int ND, int TM, int NG>
+int launch_embed_qkv_lds(int ng, const CfenEmbedQkvArgs* ap, hipStream_t s) {
+  Grouped<CfenEmbedQkvArgs> ga;
+  for (int g = 0; g < CFEN_MAX_GROUPS; ++g) ga.g[g] = ap[g < ng ? g : 0];
+  const long long per = 8LL * TM * 16, blocks = (ap[0].M + per - 1) / per;
+  CFEN_CHECK_ARG(blocks > 0 && blocks < (1ll << 31), "embed_qkv: bad grid");
+  CFEN_LAUNCH((k_embed_qkv_lds<T, ND, TM, NG>), dim3((unsigned)blocks, 1, ng), dim3(512), 0, s, ga);
+  CFEN_CHECK_LAUNCH("embed_qkv");
+  return CFEN_OK;
+}
+
 template <typename T, int ND, int TM>
 int launch_embed_qkv(int ng, const CfenEmbedQkvArgs* ap, hipStream_t s) {
   constexpr int NW = 4;
@@ -171,6 +340,11 @@ int run_embed_qkv(int ng, const CfenEmbedQkvArgs* ap, hipStream_t s) {
     CFEN_CHECK_ARG(a.D == a.p * a.p * a.C && a.M == (long long)a.B * (a.H / a.ws) * (a.W / a.ws) * tw * tw, "embed_qkv: D / M do not match the map");
     CFEN_CHECK_ARG(a.D == ap[0].D && a.M == ap[0].M, "embed_qkv: grouped problems must have the same shape");
   }
+  const int lds = cfen_tune_embed_lds();   // bit 0: D = 96, bit 1: D = 192 use the LDS-staged variant
+  if constexpr (sizeof(T) == 2) {   // the fp32 stages would not fit 64 KB of LDS
+    if (ap[0].D == 96 && (lds & 1)) return launch_embed_qkv_lds<T, 6, 4, 6>(ng, ap, s);
+    if (ap[0].D == 192 && (lds & 2)) return launch_embed_qkv_lds<T, 12, 2, 4>(ng, ap, s);
+  }
   switch (ap[0].D) {
     case 96: return launch_embed_qkv<T, 6, 4>(ng, ap, s);
     case 192: return launch_embed_qkv<T, 12, 2>(ng, ap, s);
@@ -181,6 +355,11 @@ int run_embed_qkv(int ng, const CfenEmbedQkvArgs* ap, hipStream_t s) {
 }
 
 }  // namespace
+
+int& cfen_tune_embed_lds() {
+  static int v = 2;
+  return v;
+}
 
 bool cfen_embed_qkv_supported(int D) { return D == 96 || D == 192; }
 

@@ -220,7 +220,16 @@ def test_embed_qkv_fused_front(dtype, C, H, W, ws):
     g, b = 1 + rnd((D,), 5, torch.float32, 0.1), rnd((D,), 6, torch.float32, 0.1)
     wq = rnd((3 * D, D), 7, dtype, 1 / math.sqrt(D))
     perm = packing.kperm32(D) if dtype == torch.float16 else torch.arange(D)
-    x1, qkv = ops.embed_qkv(fmap, C, ws, p, we[:, perm].contiguous().to(d), be.to(d), pos.to(d), g.to(d), b.to(d), wq[:, perm].contiguous().to(d))
+    res = []
+    try:
+        for lds in (0, 3):                  # weights straight from L2 / staged through LDS (fp16 only): same arithmetic
+            ops.tune("embed.lds", lds)
+            res.append(ops.embed_qkv(fmap, C, ws, p, we[:, perm].contiguous().to(d), be.to(d), pos.to(d), g.to(d), b.to(d),
+                                     wq[:, perm].contiguous().to(d)))
+    finally:
+        ops.tune("embed.lds", 2)
+    assert torch.equal(res[0][0], res[1][0]) and torch.equal(res[0][1], res[1][1])
+    x1, qkv = res[1]
     tok = ops.patchify(fmap, C, ws, p)
     t64 = tok.double().cpu()
     y = t64 @ we.double().t() + be.double() + t64 + pos.double().repeat(tok.shape[0] // S, 1)
