@@ -81,6 +81,8 @@ def main():
     ap.add_argument("--hidden-dim-ratio", type=int, default=4)
     ap.add_argument("--load-size", type=int, default=256, help="256 -> 512x512 images")
     ap.add_argument("--no-graph", action="store_true", help="launch eagerly instead of replaying a hipGraph")
+    ap.add_argument("--gather-dtype", default="auto", choices=["auto", "fp16", "fp32"],
+                    help="wire type of the output all-gather (N > 1); auto = the compute dtype")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=20.0)
     args = ap.parse_args()
@@ -113,7 +115,8 @@ def main():
     net.to(dev)
     x = synthetic_input(B, cfg, seed0=rank * B).to(dev)
     slabs = [torch.empty(7 * B * n * n, dtype=torch.float32, device=dev) for _ in range(2)]
-    gather = OutputGatherer(world, slabs[0].numel(), dev) if world > 1 else None
+    gdt = args.dtype if args.gather_dtype == "auto" else args.gather_dtype
+    gather = OutputGatherer(world, slabs[0].numel(), dev, torch.float16 if gdt == "fp16" else torch.float32) if world > 1 else None
 
     net(x, out=slabs[0])                       # packs weights, builds the plan
     torch.cuda.synchronize()
@@ -180,6 +183,7 @@ def main():
             "config": {"workload": "batch=%d/GPU %dx%d n_feats=24 hidden_dim_ratio=%d %s, weights random-init (seeded generator)"
                                    % (B, n, n, args.hidden_dim_ratio, args.dtype),
                        "global_batch": world * B, "parallelism": "dp%d" % world, "graph": graphs is not None,
+                       "gather_dtype": (gdt if world > 1 else None),
                        "gflop_per_image": round(flops_img / 1e9, 2)},
             "roofline": {"bound": "mfma", "kernel": dom, "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s",
                          "frac": round(ach / peak, 5), "traffic": pmc_traffic(dom),

@@ -32,12 +32,17 @@ def merge_gathered(gathered, world, batch, n):
 
 
 class OutputGatherer:
-    """Double-buffered asynchronous all-gather of equally sized per-rank slabs."""
+    """Double-buffered asynchronous all-gather of equally sized per-rank slabs.
+
+    `dtype` is the wire type.  The kernels write fp32 slabs; with the fp16 compute path the slab is converted to fp16 on
+    the communication stream before it is gathered (outputs are tanh values in (-1, 1): the 2^-11 rounding is below the
+    fp16 path's own error), which halves the xGMI traffic -- 29 MB instead of 59 MB per rank at 8 images of 512x512."""
 
     def __init__(self, world, numel, device, dtype=torch.float32):
-        self.world, self.numel = world, numel
+        self.world, self.numel, self.dtype = world, numel, dtype
         self.cuda = torch.device(device).type == "cuda"
         self.bufs = [torch.empty(world * numel, dtype=dtype, device=device) for _ in range(2)]
+        self.stage = [torch.empty(numel, dtype=dtype, device=device) for _ in range(2)] if dtype != torch.float32 else None
         self.stream = torch.cuda.Stream(device) if self.cuda else None
         self.events = [None, None]
 
@@ -47,15 +52,23 @@ class OutputGatherer:
             torch.cuda.current_stream().wait_event(self.events[slot])
 
     def launch(self, slab, slot):
+        convert = self.stage is not None and slab.dtype != self.dtype
         if not self.cuda:
-            dist.all_gather_into_tensor(self.bufs[slot], slab)
+            src = self.stage[slot].copy_(slab) if convert else slab
+            dist.all_gather_into_tensor(self.bufs[slot], src)
             return self.bufs[slot]
         self.stream.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(self.stream):
-            work = dist.all_gather_into_tensor(self.bufs[slot], slab, async_op=True)
-            work.wait()                                   # side stream now orders after the collective
             ev = torch.cuda.Event()
-            ev.record(self.stream)
+            if convert:
+                src = self.stage[slot].copy_(slab)        # the slab is free again as soon as this copy is done
+                ev.record(self.stream)
+            else:
+                src = slab
+            work = dist.all_gather_into_tensor(self.bufs[slot], src, async_op=True)
+            work.wait()                                   # side stream now orders after the collective
+            if not convert:
+                ev.record(self.stream)
         self.events[slot] = ev
         return self.bufs[slot]
 

@@ -48,9 +48,16 @@ def _worker(rank, world, port, q):
     gathered = g.launch(slab, 0)
     g.wait_all()
     merged = merge_gathered(gathered, world, B, n)
+    # fp16 wire type (what bench.py uses with the fp16 compute path): converted on the way out, 2^-11 rounding of values in (-1, 1)
+    g16 = OutputGatherer(world, slab.numel(), "cpu", torch.float16)
+    g16.before_write(1)
+    merged16 = merge_gathered(g16.launch(slab, 1), world, B, n)
+    g16.wait_all()
     if rank == 0:
         with torch.no_grad():
             whole = cfen_oracle.forward(sd, x, cfg.num_heads, cfg.patch_size)
+        err16 = max(float((a.float() - b).abs().max()) for a, b in zip(merged16, whole))
+        assert merged16[0].dtype == torch.float16 and err16 <= 2.0 ** -11, err16
         q.put(max(float((a - b).abs().max()) for a, b in zip(merged, whole)))
     dist.barrier()
     dist.destroy_process_group()
