@@ -28,35 +28,89 @@ MFMA_PEAK_TFLOPS = {"fp16": 2500.0, "fp32": 157.3}     # /opt/skills/guides/MI35
 
 def cpu_baseline(cfg, seconds=20.0):
     """The CPU oracle (a port of the reference forward, pinned to it by tests/golden) timed on the
-    host cores on a bounded sample: batch-1 forwards at the benchmark's image size for ~`seconds`."""
+    host cores on a bounded sample: batch-1 forwards at the benchmark's image size for ~`seconds`.
+    torch's default thread count on a 128-core host oversubscribes a batch-1 forward (0.15 img/s there against the reference's
+    0.93 img/s on 8 cores): two thread counts are tried and the faster one is the reported value."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import cfen_oracle
     from cfen_vit_dehazing_amd.manifest import generate_state_dict, synthetic_input
     sd = generate_state_dict(cfg, seed=0, with_dead=False)
     x = synthetic_input(1, cfg)
-    with torch.no_grad():
-        cfen_oracle.forward(sd, x, cfg.num_heads, cfg.patch_size)          # warm-up
-        times = []
-        t_end = time.time() + seconds
-        while time.time() < t_end and len(times) < 30:
-            t0 = time.time()
-            cfen_oracle.forward(sd, x, cfg.num_heads, cfg.patch_size)
-            times.append(time.time() - t0)
-    times.sort()
-    med = times[len(times) // 2]
-    return {"value": round(1.0 / med, 4), "unit": "images/sec", "cores": torch.get_num_threads(), "kind": "port",
-            "sample": "%d batch-1 fp32 forwards of the CPU oracle at %dx%d (median)" % (len(times), cfg.image_size, cfg.image_size)}
+    ncpu = os.cpu_count() or 8
+    tried = {}
+    default_threads = torch.get_num_threads()
+    try:
+        for nt in sorted({min(8, ncpu), min(32, ncpu)}):
+            torch.set_num_threads(nt)
+            with torch.no_grad():
+                cfen_oracle.forward(sd, x, cfg.num_heads, cfg.patch_size)          # warm-up
+                times = []
+                t_end = time.time() + seconds / 2
+                while time.time() < t_end and len(times) < 15:
+                    t0 = time.time()
+                    cfen_oracle.forward(sd, x, cfg.num_heads, cfg.patch_size)
+                    times.append(time.time() - t0)
+            times.sort()
+            tried[nt] = (1.0 / times[len(times) // 2], len(times))
+    finally:
+        torch.set_num_threads(default_threads)
+    best = max(tried, key=lambda k: tried[k][0])
+    return {"value": round(tried[best][0], 4), "unit": "images/sec", "cores": best, "kind": "port",
+            "sample": "batch-1 fp32 forwards of the CPU oracle at %dx%d, median per thread count: %s (host has %d logical cores)"
+                      % (cfg.image_size, cfg.image_size,
+                         ", ".join("%d threads %.3f img/s over %d runs" % (k, v[0], v[1]) for k, v in sorted(tried.items())), ncpu)}
 
 
-def pmc_traffic(kernel_class):
-    """HBM bytes per launch of a kernel class from the latest committed rocprofv3 PMC summary (tools/pmc_summary.py:
-    FETCH_SIZE and WRITE_SIZE passes of this same command, fetch doubled as the gfx950 guide prescribes); None if absent."""
+def kernel_key(label, cls):
+    """per-launch label of cfen_net_profile ("localvit_decoder_02r (x3):proj_mlp_fused", "tail_R.conv7 (x3)") -> the kernel it ran:
+    block kind + level + step for transformer launches, the layer family for convolutions"""
+    name, _, step = label.partition(":")
+    name = name.split(" ")[0]
+    if name.startswith(("localvit", "globalvit")):
+        return "%s%s:%s" % ("lvit" if name.startswith("local") else "gvit", name.split("_0")[1][0], step)
+    fam = name.rstrip("0123456789rsd") if not name.startswith("tail_") else "tail." + name.split(".")[-1]
+    return "%s:%s" % (cls, fam + (":" + step if step else ""))
+
+
+KERNEL_OF_STEP = {"embed_ln_qkv": "k_embed_qkv", "proj_mlp_fused": "k_mlp", "attention": "k_attention_win", "embed": "k_gemm_dma", "qkv": "k_gemm_dma",
+                  "proj": "k_gemm_dma", "ffn1": "k_gemm_dma", "ffn2": "k_gemm_dma", "head1": "k_gemm_dma", "head2": "k_gemm_dma"}
+
+
+def self_check(net, x, outs, cfg, dtype):
+    """The benchmarked computation is validated where it is timed: image 0 of the LAST graph replay against (a) its own batch-1
+    eager forward and (b) the reference vectors of tests/golden (made by importing the reference, tools/gen_golden.py) when
+    the configuration has a fixture.  Returns max-abs differences."""
+    import numpy as np
+    res = {}
+    one = net(x[0:1].clone())
+    res["image0_vs_batch1_eager"] = max(float((a[0:1] - b).abs().max()) for a, b in zip(outs, one))
+    fix = os.path.join(ROOT, "tests", "golden", "net_full%d_nf%d_hdr%d.npz" % (cfg.image_size, cfg.n_feats, cfg.hidden_dim_ratio))
+    if os.path.exists(fix):
+        z = np.load(fix)
+        n = cfg.image_size
+        c0 = n // 2 - 32
+        worst = 0.0
+        for nm, o in zip(("xr", "xs", "xd"), outs):
+            o0 = o[0:1].float().cpu()
+            worst = max(worst, float((o0[:, :, c0:c0 + 64, c0:c0 + 64] - torch.from_numpy(z["crop/" + nm])).abs().max()),
+                        float((o0[:, :, 3::8, 5::8] - torch.from_numpy(z["strided/" + nm])).abs().max()))
+        res["image0_vs_reference_vectors"] = worst
+    bar = 3e-2 if dtype == "fp16" else 1e-3
+    res["bar"] = bar
+    res["ok"] = all(v <= bar for k, v in res.items() if k.startswith("image0"))
+    return res
+
+
+def pmc_traffic(kernel):
+    """HBM bytes per launch of the dominant kernel from the latest committed rocprofv3 PMC summary (tools/pmc_summary.py:
+    separate FETCH_SIZE and WRITE_SIZE passes of this same command, fetch doubled as the gfx950 guide prescribes).
+    A cross-reference to profiles/, not a live measurement: None when the summary has no entry for this kernel."""
     import glob
     files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic.json")))
     if not files:
         return None
     try:
-        return json.load(open(files[-1]))["classes"][kernel_class]["hbm_bytes_per_launch"]
+        return json.load(open(files[-1]))["bench_kernels"][kernel]["hbm_bytes_per_launch"]
     except (KeyError, ValueError, OSError):
         return None
 
@@ -74,7 +128,9 @@ def apply_tuning():
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=30)
+    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--min-seconds", type=float, default=1.0,
+                    help="the K-step timed region is repeated until this much time has been measured; value = median repetition")
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--batch", type=int, default=8, help="images per GPU")
     ap.add_argument("--dtype", default="fp16", choices=["fp16", "fp32"])
@@ -145,19 +201,35 @@ def main():
         step(i)
     if gather is not None:
         gather.wait_all()
-    barrier()
-    t0 = time.perf_counter()
-    for i in range(args.steps):
-        step(i)
-    if gather is not None:
-        gather.wait_all()
-    barrier()
-    dt = time.perf_counter() - t0
-    if dist is not None:
-        t = torch.tensor([dt], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
 
+    def timed_region():
+        """EXACTLY args.steps steps between two (barrier + synchronize) brackets; MAX over ranks"""
+        barrier()
+        t0 = time.perf_counter()
+        for i in range(args.steps):
+            step(i)
+        if gather is not None:
+            gather.wait_all()
+        barrier()
+        dt = time.perf_counter() - t0
+        if dist is not None:
+            t = torch.tensor([dt], dtype=torch.float64, device=dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt = float(t.item())
+        return dt
+
+    # a 20-step region is 70 ms: clock ramp and launch jitter dominate it.  The region is repeated (every repetition is the
+    # contract's K-step measurement) until >= --min-seconds have been timed; the reported value is the MEDIAN repetition.
+    reps = [timed_region()]
+    while sum(reps) < args.min_seconds and len(reps) < 200:
+        if dist is not None:          # all ranks must agree on the number of repetitions
+            flag = torch.tensor([1.0 if sum(reps) < args.min_seconds else 0.0], device=dev)
+            dist.all_reduce(flag, op=dist.ReduceOp.MAX)
+            if flag.item() == 0:
+                break
+        reps.append(timed_region())
+    srt = sorted(reps)
+    dt = srt[len(srt) // 2]
     ms_step = dt / args.steps * 1e3
     ips = world * B * args.steps / dt
 
@@ -170,12 +242,24 @@ def main():
         for name in net.KERNEL_CLASSES:
             runs = sorted(p[name][0] for p in profs)
             classes[name] = {"ms": round(runs[1], 4), "launches": profs[0][name][2], "gflop": round(profs[0][name][1] / 1e9, 2)}
-        dom = max((c for c in classes if classes[c]["gflop"] > 0), key=lambda c: classes[c]["ms"])
-        ach = classes[dom]["gflop"] / classes[dom]["ms"]            # GFLOP / ms == TFLOP/s
         peak = MFMA_PEAK_TFLOPS[args.dtype]
         for c in classes.values():
             c["tflops"] = round(c["gflop"] / c["ms"], 2) if c["ms"] > 0 and c["gflop"] > 0 else None
+        # per-KERNEL table from the per-launch records of the median profile: the roofline line names the dominant kernel
+        kern = {}
+        mid = sorted(profs, key=lambda p: sum(p[n][0] for n in net.KERNEL_CLASSES))[1]
+        for label, cls, fl, ms in mid["launches"]:
+            k = kern.setdefault(kernel_key(label, cls), {"ms": 0.0, "gflop": 0.0, "launches": 0})
+            k["ms"] += ms; k["gflop"] += fl / 1e9; k["launches"] += 1
+        for k in kern.values():
+            k["ms"] = round(k["ms"], 4); k["gflop"] = round(k["gflop"], 2)
+            k["tflops"] = round(k["gflop"] / k["ms"], 1) if k["gflop"] > 0 and k["ms"] > 0 else None
+        dom = max((k for k in kern if kern[k]["gflop"] > 0), key=lambda k: kern[k]["ms"])
+        ach = kern[dom]["gflop"] / kern[dom]["ms"]                   # GFLOP / ms == TFLOP/s
+        dom_launch_ms = kern[dom]["ms"] / kern[dom]["launches"]
         whole = ips / world * flops_img / 1e12
+        from cfen_vit_dehazing_amd.parallel import split_slab
+        check = self_check(net, x, split_slab(slabs[(args.steps - 1) & 1], B, n), cfg, args.dtype)   # what the last timed step wrote
         result = {
             "metric": "images/sec @512x512 n_feats=24", "value": round(ips, 2), "unit": "images/sec", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_step, 3), "higher_is_better": True,
@@ -185,10 +269,17 @@ def main():
                        "global_batch": world * B, "parallelism": "dp%d" % world, "graph": graphs is not None,
                        "gather_dtype": (gdt if world > 1 else None),
                        "gflop_per_image": round(flops_img / 1e9, 2)},
-            "roofline": {"bound": "mfma", "kernel": dom, "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s",
+            "roofline": {"bound": "mfma", "kernel": "%s [%s]" % (dom, KERNEL_OF_STEP.get(dom.split(":")[-1], "?")),
+                         "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s",
                          "frac": round(ach / peak, 5), "traffic": pmc_traffic(dom),
+                         "launch_ms": round(dom_launch_ms, 4), "launches_per_step": kern[dom]["launches"],
+                         "algorithmic_gflop_per_launch": round(kern[dom]["gflop"] / kern[dom]["launches"], 2),
                          "whole_forward_tflops": round(whole, 2), "whole_forward_frac": round(whole / peak, 5)},
+            "timing": {"repetitions": len(reps), "timed_seconds": round(sum(reps), 3), "ms_per_step_min": round(srt[0] / args.steps * 1e3, 3),
+                       "ms_per_step_max": round(srt[-1] / args.steps * 1e3, 3)},
+            "self_check": check,
             "kernel_classes": classes,
+            "kernels": dict(sorted(kern.items(), key=lambda kv: -kv[1]["ms"])[:12]),
         }
         if world == 1 and not args.no_cpu_baseline:
             result["cpu_baseline"] = cpu_baseline(cfg, args.cpu_seconds)

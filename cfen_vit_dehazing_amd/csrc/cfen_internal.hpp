@@ -60,6 +60,10 @@ int cfen_conv7_tz_kpad();
 int cfen_conv7_tz_impl_g(int dtype, int ng, const ConvDesc* d, hipStream_t s);
 size_t cfen_stats_workspace_bytes(int B, int C);
 int cfen_instnorm_relu_impl(int dtype, void* x, float* part, int B, int HW, int C, int cs, float eps, hipStream_t s);
+// ActNorm2d first-call init from the raw layer output x (NHWC, B images): per-channel statistics over the batch -> folded
+// (scale, shift) epilogue table + raw (weight, bias) in an_out[2][Cpad]                      (models/actnorm.py:25-37)
+int cfen_actnorm_init_impl(int dtype, const void* x, float* part, int B, int HW, int C, int cs, int Cpad, const float* conv_bias, float* scale,
+                           float* shift, float* an_out, hipStream_t s);
 int cfen_cfsm2g_impl(int dtype, const void* x0, const void* x1, const void* x2, void* out, const float* w, float* part, int B, int HW,
                      int C, int cs, hipStream_t s);
 int& cfen_tune_gemm_kernel();   // -1 auto, 0 tiled, 1 skinny (cfen_tune "gemm.kernel")

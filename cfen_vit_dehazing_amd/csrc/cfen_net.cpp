@@ -71,6 +71,11 @@ struct cfen_net {
   struct Scratch { size_t x0, x1, yn, qkv, att, hid, small; };
   Scratch scr_set[6];
   size_t o_stats_set[3] = {0, 0, 0};
+  // ActNorm2d layers whose parameters are still uninitialised (models/actnorm.py:25-37): the next EAGER forward runs the layer
+  // raw (conv + bias), takes batch statistics, writes the folded epilogue table in place and the raw (weight, bias) pair to an_out
+  struct AnPending { const float* ones; const float* conv_bias; float* an_out; };
+  std::map<std::string, AnPending> an_pending;
+  int input_u8 = 0;                // 1: x is uint8 HWC (B,H,W,3), normalised to [-1,1] by the first launch (data/base_dataset.py:44-46)
   int blk_kind = 0;                // 0 CNN, 1 GViT block, 2 LViT block (selects bits 8.. / 16.. of "net.skip_classes")
   unsigned char* base = nullptr;   // workspace of the current / last forward
   hipStream_t stream = nullptr;    // stream of the lane being enqueued
@@ -335,6 +340,37 @@ int cfen_net::build() {
 
 int cfen_net::run_conv_g(int ng, const ConvCall* cc, int act) {
   ConvDesc d[CFEN_MAX_GROUPS];
+  if (!an_pending.empty()) {
+    bool any = false;
+    for (int g = 0; g < ng; ++g) any = any || an_pending.count(cc[g].layer);
+    if (any && ng > 1) {   // initialise member by member
+      for (int g = 0; g < ng; ++g) TRY(run_conv_g(1, cc + g, act));
+      return CFEN_OK;
+    }
+    if (any) {
+      CFEN_CHECK_ARG(!cfen_recorder() && !profiling, "net: ActNorm '%s' is uninitialised; run one plain forward before capturing / profiling",
+                     cc[0].layer.c_str());
+      CFEN_CHECK_ARG(!cc[0].nchw_out, "net: ActNorm init on an NCHW output layer");
+      const AnPending ap = an_pending.at(cc[0].layer);
+      const ConvLayer& c = convs.at(cc[0].layer);
+      const Buf& bo = bufs.at(cc[0].out);
+      an_pending.erase(cc[0].layer);
+      // 1. raw layer output x = conv + conv_bias (no activation, no residual) into the layer's own buffer
+      Param keep_s = params.at(cc[0].layer + ".scale"), keep_t = params.at(cc[0].layer + ".shift");
+      params[cc[0].layer + ".scale"].ptr = ap.ones;
+      params[cc[0].layer + ".shift"].ptr = ap.conv_bias;
+      ConvCall raw = cc[0];
+      raw.res0.clear(); raw.res1.clear();
+      int rc = run_conv_g(1, &raw, 0);
+      params[cc[0].layer + ".scale"] = keep_s;
+      params[cc[0].layer + ".shift"] = keep_t;
+      if (rc) return rc;
+      // 2. batch statistics -> epilogue table (written in place) + raw ActNorm parameters
+      TRY(cfen_actnorm_init_impl(cfg.dtype, map_ptr(cc[0].out), (float*)at(o_stats_set[2]), cfg.batch, bo.H * bo.W, c.Cout, bo.cs, c.Cout_pad,
+                                 ap.conv_bias, (float*)const_cast<void*>(keep_s.ptr), (float*)const_cast<void*>(keep_t.ptr), ap.an_out, stream));
+      // 3. fall through: the layer again, now with its real epilogue
+    }
+  }
   const ConvLayer& c0 = convs.at(cc[0].layer);
   double fl = 0.0;
   for (int g = 0; g < ng; ++g) {
@@ -613,8 +649,13 @@ int cfen_net::forward(const float* x, float* xr, float* xs, float* xd) {
   stream = s0;
   float* stats = (float*)at(o_stats_set[0]);
   const Buf& bin = bufs.at("input");
-  label = "input:nchw_to_nhwc";
-  TRYP(K_TOKEN, 0, cfen_nchw_to_nhwc_impl(dt, x, map_ptr("input"), B, 3, 2 * N, 2 * N, bin.cs, stream));
+  if (input_u8) {
+    label = "input:u8hwc_to_nhwc";
+    TRYP(K_TOKEN, 0, cfen_u8hwc_to_nhwc_impl(dt, (const unsigned char*)x, map_ptr("input"), B, 2 * N, 2 * N, bin.cs, stream));
+  } else {
+    label = "input:nchw_to_nhwc";
+    TRYP(K_TOKEN, 0, cfen_nchw_to_nhwc_impl(dt, x, map_ptr("input"), B, 3, 2 * N, 2 * N, bin.cs, stream));
+  }
   // head: conv5x5 + ResBlock                                                   (v3:123-127,395)
   TRY(run_conv("head.0.0", "input", nullptr, nullptr, nullptr, 0, "head.conv5", nullptr));
   TRY(run_conv("head.0.1.body.0", "head.conv5", nullptr, nullptr, nullptr, 1, "head.res_mid", nullptr));
@@ -666,6 +707,23 @@ int cfen_net_set_param(cfen_net* net, const char* name, const void* dev_ptr, siz
   CFEN_CHECK_ARG(it->second.need == nbytes, "set_param: '%s' needs %zu bytes, got %zu", name, it->second.need, nbytes);
   CFEN_CHECK_ARG(cfen_aligned16(dev_ptr), "set_param: '%s' must be 16-byte aligned", name);
   it->second.ptr = dev_ptr;
+  return CFEN_OK;
+}
+
+int cfen_net_actnorm_pending(cfen_net* net, const char* layer, const float* ones, const float* conv_bias, float* an_out) {
+  CFEN_CHECK_ARG(net && layer && ones && conv_bias && an_out, "actnorm_pending: null argument");
+  auto it = net->convs.find(layer);
+  CFEN_CHECK_ARG(it != net->convs.end(), "actnorm_pending: unknown layer '%s'", layer);
+  CFEN_CHECK_ARG(cfen_aligned16(ones) && cfen_aligned16(conv_bias) && cfen_aligned16(an_out), "actnorm_pending: pointers must be 16-byte aligned");
+  net->an_pending[layer] = cfen_net::AnPending{ones, conv_bias, an_out};
+  return CFEN_OK;
+}
+
+int cfen_net_actnorm_pending_count(const cfen_net* net) { return net ? (int)net->an_pending.size() : 0; }
+
+int cfen_net_set_input_u8(cfen_net* net, int enabled) {
+  CFEN_CHECK_ARG(net != nullptr, "set_input_u8: null net");
+  net->input_u8 = enabled ? 1 : 0;
   return CFEN_OK;
 }
 

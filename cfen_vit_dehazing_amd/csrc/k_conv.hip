@@ -334,6 +334,33 @@ __global__ __launch_bounds__(256) void k_cfsm_apply(const T* __restrict__ x0, co
   }
 }
 
+// ActNorm2d data-dependent first-call initialisation (models/actnorm.py:25-37) from the statistics of the raw layer output
+// x = conv + conv_bias over the WHOLE batch: bias_an = -mean, weight_an = -0.5 log(max(var_unbiased, 0.2)); written as the folded
+// epilogue table (scale = exp(weight_an), shift = (conv_bias + bias_an) * scale) and as the raw (weight_an, bias_an) pair.
+__global__ __launch_bounds__(128) void k_actnorm_finalize(const float* __restrict__ part, int B, int HW, int C, int Cs, const float* __restrict__ conv_bias,
+                                                          float* __restrict__ scale, float* __restrict__ shift, float* __restrict__ an_out,
+                                                          int Cpad) {
+  const int c = threadIdx.x;
+  if (c >= Cpad) return;
+  if (c >= C) { scale[c] = 0.f; shift[c] = 0.f; an_out[c] = 0.f; an_out[Cpad + c] = 0.f; return; }
+  double s = 0.0, q = 0.0;
+  for (int b = 0; b < B; ++b)
+    for (int k = 0; k < ST_CHUNKS; ++k) {
+      const float* o = part + (((size_t)b * ST_CHUNKS + k) * 3) * Cs;   // statistics were taken over the map's Cs (padded) channels
+      s += (double)o[c]; q += (double)o[Cs + c];
+    }
+  const double n = (double)B * HW;
+  const double mean = s / n;
+  double var = (q - s * mean) / (n - 1.0);
+  if (var < 0.2) var = 0.2;
+  const float w = (float)(-0.5 * log(var)), bb = (float)(-mean);
+  const float sc = expf(w);
+  scale[c] = sc;
+  shift[c] = (conv_bias[c] + bb) * sc;
+  an_out[c] = w;
+  an_out[Cpad + c] = bb;
+}
+
 template <typename T>
 int run_stats(const void* x0, const void* x1, const void* x2, float* part, int B, int HW, int C, int cs, hipStream_t s) {
   constexpr int EPL = Vec16<T>::N;
@@ -378,6 +405,17 @@ int cfen_instnorm_relu_impl(int dtype, void* x, float* part, int B, int HW, int 
     CFEN_LAUNCH(k_instnorm_relu<float>, dim3(grid_img(nvec), B), dim3(256), 0, s, (float*)x, part, HW, C, cs, eps, nvec);
   }
   CFEN_CHECK_LAUNCH("instnorm");
+  return CFEN_OK;
+}
+
+int cfen_actnorm_init_impl(int dtype, const void* x, float* part, int B, int HW, int C, int cs, int Cpad, const float* conv_bias, float* scale,
+                           float* shift, float* an_out, hipStream_t s) {
+  CFEN_CHECK_ARG(conv_bias && scale && shift && an_out && Cpad <= 128 && C <= Cpad && (long long)B * HW > 1, "actnorm_init: bad arguments");
+  int rc = dtype == 1 ? run_stats<half_t>(x, nullptr, nullptr, part, B, HW, cs, cs, s)   // all cs channels: the padded ones hold zeros
+                      : dtype == 0 ? run_stats<float>(x, nullptr, nullptr, part, B, HW, cs, cs, s) : CFEN_ERR_ARG;
+  if (rc) return rc;
+  CFEN_LAUNCH(k_actnorm_finalize, dim3(1), dim3(128), 0, s, (const float*)part, B, HW, C, cs, conv_bias, scale, shift, an_out, Cpad);
+  CFEN_CHECK_LAUNCH("actnorm_init");
   return CFEN_OK;
 }
 

@@ -35,10 +35,15 @@ def to_normalized_tensor(img):
     return (t - 0.5) / 0.5
 
 
+def to_u8_hwc(img):
+    """--u8_input: the decoded image as it is, (H,W,3) uint8; ToTensor + Normalize happen on the device (csrc/k_tokens.hip: k_u8hwc_to_nhwc)."""
+    return torch.from_numpy(np.asarray(img, dtype=np.uint8).copy())
+
+
 def get_transform(opt):
     mode = opt.resize_or_crop
     if mode in ('resize', 'none'):
-        return to_normalized_tensor
+        return to_u8_hwc if getattr(opt, 'u8_input', False) else to_normalized_tensor
     if mode in ('resize_only', 'scale_width'):
         def f(img):
             w, h = img.size
@@ -63,7 +68,7 @@ class DECVITDATA(torch.utils.data.Dataset):
         else:                                   # the reference samples randomly unless --sb (dec_vit_data.py:51-58)
             B_path = self.B_paths[random.randint(0, self.B_size - 1)]
         B = self.transform(Image.open(B_path).convert('RGB'))
-        if self.opt.output_nc == 1 and self.opt.which_direction != 'BtoA' or self.opt.input_nc == 1 and self.opt.which_direction == 'BtoA':
+        if B.dtype != torch.uint8 and self.opt.output_nc == 1 and self.opt.which_direction != 'BtoA' or self.opt.input_nc == 1 and self.opt.which_direction == 'BtoA':
             B = (B[0, ...] * 0.299 + B[1, ...] * 0.587 + B[2, ...] * 0.114).unsqueeze(0)
         return {'B': B, 'B_paths': B_path}
 

@@ -29,8 +29,14 @@ class _Node(nn.Module):
     """Anonymous container so dotted reference keys map onto a real module tree."""
 
 
-def _build_tree(root, manifest, materialize_dead):
+def _build_tree(root, manifest):
+    """Register every LIVE entry of the manifest as a parameter / buffer under its dotted reference key.  The 208.6 M parameters
+    the forward never reads (`decoder.*`, `query_embed`, `sub_mean`, `add_mean`: v3:1158-1168, common.py:16-26) are not
+    registered: they would cost 0.83 GB of host memory and ride along on every .to(device).  dec_ipt keeps what a checkpoint
+    holds for them in `_dead` (CPU) and hands it back from state_dict()."""
     for key, shape, dt in manifest:
+        if _is_dead(key):
+            continue
         parts = key.split(".")
         mod = root
         for p in parts[:-1]:
@@ -43,9 +49,7 @@ def _build_tree(root, manifest, materialize_dead):
             else:
                 mod.register_buffer(parts[-1], torch.tensor(0))            # ActNorm `initialized` (models/actnorm.py:16)
         else:
-            dead = _is_dead(key)
-            t = torch.zeros(shape) if (materialize_dead or not dead) else torch.zeros(shape)
-            mod.register_parameter(parts[-1], nn.Parameter(t, requires_grad=False))
+            mod.register_parameter(parts[-1], nn.Parameter(torch.zeros(shape), requires_grad=False))
 
 
 class dec_ipt(nn.Module):
@@ -55,15 +59,62 @@ class dec_ipt(nn.Module):
         self.cfg = config_from_opt(opt) if not isinstance(opt, NetConfig) else opt
         self.scale_idx = 0
         self.compute_dtype = _DTYPES[compute_dtype]
-        _build_tree(self, state_manifest(self.cfg), True)
+        self._manifest = state_manifest(self.cfg)
+        _build_tree(self, self._manifest)
+        self._dead = {}              # dead key -> CPU tensor, as loaded from a checkpoint (absent = zeros of the manifest shape)
         self._packed = None          # {name: device tensor}
-        self._nets = {}              # batch -> (handle, workspace tensor)
+        self._packed_dev = None
+        self._an_pending = {}        # packed layer name -> (ActNorm key prefix, conv bias, an_out): uninitialised ActNorm2d layers
+        self._nets = {}              # (batch, input kind) -> (handle, workspace tensor)
+        self._graph_keep = []
+        self._graphs = []            # capture() handle -> (net key, native graph id)
         self._last = None
+        self.serial_plan = bool(os.environ.get("CFEN_SERIAL"))     # single-lane launch plan (debugging / A-B)
 
     # ---- parameter management ---------------------------------------------------------------
+    def state_dict(self, *args, **kw):
+        """The reference's 958 keys in the reference's order; dead entries come from the loaded checkpoint (zeros otherwise)."""
+        live = super().state_dict(*args, **kw)
+        prefix = kw.get("prefix", args[1] if len(args) > 1 else "")
+        out = type(live)()
+        for key, shape, dt in self._manifest:
+            k = prefix + key
+            if k in live:
+                out[k] = live[k]
+            else:
+                t = self._dead.get(key)
+                out[k] = t if t is not None else torch.zeros(()).expand(shape)       # no storage until someone asks for it
+        for k, v in live.items():
+            if k not in out:
+                out[k] = v
+        if hasattr(live, "_metadata"):
+            out._metadata = live._metadata
+        return out
+
     def load_state_dict(self, state_dict, strict=True, **kw):
-        r = super().load_state_dict(state_dict, strict=strict, **kw)
+        live, dead = {}, {}
+        shapes = {key: shape for key, shape, dt in self._manifest if _is_dead(key)}
+        for k, v in state_dict.items():
+            if k in shapes:
+                if tuple(v.shape) != tuple(shapes[k]):
+                    raise RuntimeError("size mismatch for %s: copying a param with shape %s from checkpoint, the shape in current model "
+                                       "is %s" % (k, tuple(v.shape), tuple(shapes[k])))
+                dead[k] = v.detach().cpu()
+            else:
+                live[k] = v
+        if strict:
+            missing = [k for k in shapes if k not in dead]
+            if missing:
+                raise RuntimeError("Error(s) in loading state_dict for dec_ipt: Missing key(s) in state_dict: %s"
+                                   % ", ".join('"%s"' % k for k in missing[:8]) + (" ..." if len(missing) > 8 else ""))
+        r = super().load_state_dict(live, strict=strict, **kw)
+        self._dead = dead
         self.invalidate()
+        return r
+
+    def _apply(self, fn, *a, **kw):
+        r = super()._apply(fn, *a, **kw)
+        self.invalidate()            # packed copies and nets hold pointers into the old device
         return r
 
     def invalidate(self):
@@ -76,6 +127,8 @@ class dec_ipt(nn.Module):
         for h, _ in self._nets.values():
             lib.cfen_net_destroy(h)
         self._nets = {}
+        self._graph_keep = []        # captured graphs died with their nets
+        self._graphs = []
         self._last = None
 
     def __del__(self):
@@ -96,20 +149,29 @@ class dec_ipt(nn.Module):
         return sd
 
     def _ensure_packed(self, device):
+        if self._packed is not None and self._packed_dev != device:
+            self.invalidate()
         if self._packed is None:
-            packed = pack_state_dict(self._live_state(device), self.cfg, self.compute_dtype)
+            pending = {}
+            packed = pack_state_dict(self._live_state(device), self.cfg, self.compute_dtype, pending=pending)
             self._packed = {k: v.to(device).contiguous() for k, v in packed.items()}
+            self._packed_dev = device
+            # uninitialised ActNorm2d layers: (key prefix, conv bias [Cout_pad], an_out [2][Cout_pad]) on the device
+            self._an_pending = {n: (an, b.to(device).contiguous(), torch.zeros(2, b.numel(), dtype=torch.float32, device=device))
+                                for n, (an, b) in pending.items()}
+            self._ones = torch.ones(128, dtype=torch.float32, device=device)
         return self._packed
 
-    def _net_for(self, batch, device):
-        if batch in self._nets:
-            return self._nets[batch]
-        lib = _lib.load()
+    def _net_for(self, batch, device, u8=False):
         packed = self._ensure_packed(device)
+        key = (batch, bool(u8), bool(self.serial_plan))
+        if key in self._nets:
+            return self._nets[key]
+        lib = _lib.load()
         c = self.cfg
         cc = NetConfigC(batch=batch, n_feats=c.n_feats, hidden_dim_ratio=c.hidden_dim_ratio, patch_size=c.patch_size,
                         load_size=c.load_size, num_heads=c.num_heads, dtype=_lib.dtype_code(self.compute_dtype),
-                        reserved=1 if os.environ.get("CFEN_SERIAL") else 0)     # bit 0: single-stream launch plan
+                        reserved=1 if self.serial_plan else 0)     # bit 0: single-stream launch plan
         h = ctypes.c_void_p()
         check(lib.cfen_net_create(ctypes.byref(h), ctypes.byref(cc)), "cfen_net_create")
         for name, t in packed.items():
@@ -117,9 +179,30 @@ class dec_ipt(nn.Module):
         buf = ctypes.create_string_buffer(4096)
         if lib.cfen_net_missing_params(h, buf, 4096):
             raise CfenError("packed parameters missing: " + buf.value.decode())
+        if u8:
+            check(lib.cfen_net_set_input_u8(h, 1), "cfen_net_set_input_u8")
         ws = torch.empty(lib.cfen_net_workspace_bytes(h), dtype=torch.uint8, device=device)
-        self._nets[batch] = (h, ws)
-        return self._nets[batch]
+        self._nets[key] = (h, ws)
+        return self._nets[key]
+
+    def _arm_actnorm_init(self, h):
+        """Uninitialised ActNorm2d layers are initialised by the next eager forward, from that batch (models/actnorm.py:25-37)."""
+        lib = _lib.load()
+        for name, (an, bias, an_out) in self._an_pending.items():
+            check(lib.cfen_net_actnorm_pending(h, name.encode(), ptr(self._ones), ptr(bias), ptr(an_out)), "cfen_net_actnorm_pending")
+
+    def _finish_actnorm_init(self):
+        """Copy the device-computed ActNorm parameters into the module (so state_dict() / save_networks see what the reference's
+        first forward would have left) and flip `initialized`.  The packed epilogue tables were updated in place by the kernel."""
+        mods = dict(self.named_modules())
+        for name, (an, bias, an_out) in self._an_pending.items():
+            m = mods[an]
+            c = m.weight.numel()
+            with torch.no_grad():
+                m.weight.copy_(an_out[0, :c])
+                m.bias.copy_(an_out[1, :c])
+                m.initialized.fill_(1)
+        self._an_pending = {}
 
     # ---- forward ----------------------------------------------------------------------------
     KERNEL_CLASSES = ("gemm", "attention", "layernorm", "tokens", "conv", "norm", "mlp")
@@ -135,12 +218,14 @@ class dec_ipt(nn.Module):
         `x` and the outputs must stay alive and in place while the graph is replayed."""
         res = {}
         outs = self._run(x, out, res, capture=True)
-        self._graph_keep = getattr(self, "_graph_keep", []) + [(x, outs)]
-        return res["gid"], outs
+        self._graph_keep.append((x, outs))
+        self._graphs.append((self._last, res["gid"]))
+        return len(self._graphs) - 1, outs
 
-    def replay(self, gid, batch=None):
-        h, _ = self._nets[batch if batch is not None else self._last]
-        check(_lib.load().cfen_net_graph_launch(h, gid, current_stream()), "cfen_net_graph_launch")
+    def replay(self, gid):
+        key, native = self._graphs[gid]
+        h, _ = self._nets[key]
+        check(_lib.load().cfen_net_graph_launch(h, native, current_stream()), "cfen_net_graph_launch")
 
     def profile(self, x):
         """One forward with HIP events around every launch: {class: (ms, algorithmic flops, launches)}."""
@@ -152,15 +237,24 @@ class dec_ipt(nn.Module):
         if not x.is_cuda:
             raise CfenError("the HIP generator needs a CUDA(HIP) tensor; there is no CPU fallback (got %s)" % x.device)
         n = self.cfg.image_size
-        if x.dim() != 4 or x.shape[1] != self.cfg.n_colors or x.shape[2] != n or x.shape[3] != n:
-            raise RuntimeError("input must be (B,%d,%d,%d) for --loadSize %d --patch_size %d (image size is baked into the "
-                               "network, reference v3:1186); got %s" % (self.cfg.n_colors, n, n, self.cfg.load_size,
-                                                                       self.cfg.patch_size, tuple(x.shape)))
-        if capture and (not x.is_contiguous() or x.dtype != torch.float32):
-            raise ValueError("capture() needs a contiguous float32 input (its address is baked into the graph)")
-        x = x.contiguous().float()
+        u8 = x.dtype == torch.uint8          # (B,H,W,3) uint8 as decoded from the file: normalised on the device (data/base_dataset.py:44-46)
+        want = (n, n, self.cfg.n_colors) if u8 else (self.cfg.n_colors, n, n)
+        if x.dim() != 4 or tuple(x.shape[1:]) != want:
+            raise RuntimeError("input must be (B,%d,%d,%d) float or (B,%d,%d,%d) uint8 for --loadSize %d --patch_size %d (image size is "
+                               "baked into the network, reference v3:1186); got %s %s" % (self.cfg.n_colors, n, n, n, n, self.cfg.n_colors,
+                                                                                       self.cfg.load_size, self.cfg.patch_size,
+                                                                                       tuple(x.shape), x.dtype))
+        if capture and (not x.is_contiguous() or x.dtype not in (torch.float32, torch.uint8)):
+            raise ValueError("capture() needs a contiguous float32 / uint8 input (its address is baked into the graph)")
+        x = x.contiguous() if u8 else x.contiguous().float()
         B = x.shape[0]
-        h, ws = self._net_for(B, x.device)
+        h, ws = self._net_for(B, x.device, u8)
+        init_actnorm = bool(self._an_pending)
+        if init_actnorm:
+            if capture or prof is not None:
+                raise CfenError("ActNorm2d layers are uninitialised: run one plain forward (it initialises them from its batch, "
+                                "models/actnorm.py:25-37) before capture() / profile()")
+            self._arm_actnorm_init(h)
         if out is None:
             out = torch.empty(7 * B * n * n, dtype=torch.float32, device=x.device)
         elif out.dtype != torch.float32 or out.numel() != 7 * B * n * n or not out.is_contiguous() or out.device != x.device:
@@ -189,7 +283,9 @@ class dec_ipt(nn.Module):
                 detail.append((lab.value.decode(), self.KERNEL_CLASSES[cls.value], f.value, t.value))
                 i += 1
             prof["launches"] = detail
-        self._last = B
+        if init_actnorm:
+            self._finish_actnorm_init()
+        self._last = (B, bool(u8), bool(self.serial_plan))
         return [xr, xs, xd]
 
     def set_scale(self, scale_idx):
@@ -207,9 +303,10 @@ class dec_ipt(nn.Module):
                                          ctypes.byref(W)), "cfen_net_stage")
         esz = 2 if self.compute_dtype == torch.float16 else 4
         off = p.value - ws.data_ptr()
-        n = self._last * H.value * W.value * cs.value
+        B = self._last[0]
+        n = B * H.value * W.value * cs.value
         flat = ws[off:off + n * esz].view(self.compute_dtype)
-        return flat.view(self._last, H.value, W.value, cs.value)[..., :C.value].permute(0, 3, 1, 2).float().contiguous()
+        return flat.view(B, H.value, W.value, cs.value)[..., :C.value].permute(0, 3, 1, 2).float().contiguous()
 
     def flops_per_image(self):
         if not self._nets:
@@ -262,9 +359,13 @@ def define_G(opt, conv=None, compute_dtype=None):
     """Counterpart of define_G/init_net (v3:93-100, 77-83): build, move to GPU, initialise.  Multi-GPU
     is one process per GPU (parallel.py), not nn.DataParallel, so gpu_ids[0] is the only device used."""
     if compute_dtype is None:
-        compute_dtype = {"single": "fp32", "half": "fp16"}.get(getattr(opt, "precision", "half"), "fp16")
+        compute_dtype = {"single": "fp32", "half": "fp16"}.get(getattr(opt, "precision", "single"), "fp32")
     net = dec_ipt(opt, conv, compute_dtype=compute_dtype)
     gpu_ids = getattr(opt, "gpu_ids", [])
+    if len(gpu_ids) > 1:
+        raise NotImplementedError("--gpu_ids %s: the reference wraps the net in nn.DataParallel (v3:77-83); here multi-GPU is one process "
+                                  "per GPU (cfen_vit_dehazing_amd/parallel.py, `python -m torch.distributed.run --nproc-per-node N ...`) -- "
+                                  "pass one id per process" % (gpu_ids,))
     if len(gpu_ids) > 0:
         assert torch.cuda.is_available()
         net.to(gpu_ids[0])

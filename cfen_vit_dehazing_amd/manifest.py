@@ -114,14 +114,36 @@ def _is_dead(key):
             or key.startswith("sub_mean.") or key.startswith("add_mean."))
 
 
-def _gen(key, shape, dtype, seed):
+def _gen_reference_init(key, shape, g):
+    """What `define_G` leaves in a fresh reference module (init_weights v3:49-74 with init_type 'kaiming' + nn defaults):
+    every Conv / ConvTranspose / Linear weight kaiming_normal_(a=0, mode='fan_in') with torch's fan_in = size(1) * k*k,
+    their biases 0, LayerNorm 1 / 0, MHA in_proj kaiming_uniform_(a=sqrt(5)) = U(+-1/sqrt(fan_in)) (v3:1377), embeddings N(0,1)
+    (v3:1330).  ActNorm weight / bias are uninitialised memory there (models/actnorm.py:12-13): zeros here, `initialized` = 0."""
+    leaf = key.rsplit(".", 1)[-1]
+    if len(shape) >= 2:
+        if ".pe.weight" in key or key.endswith("query_embed.weight"):
+            return torch.randn(shape, generator=g)
+        fan_in = 1
+        for s in shape[1:]:
+            fan_in *= s
+        if "in_proj_weight" in key:
+            return (torch.rand(shape, generator=g) * 2 - 1) / math.sqrt(fan_in)
+        return torch.randn(shape, generator=g) * math.sqrt(2.0 / fan_in)
+    if ".norm" in key and leaf == "weight":
+        return torch.ones(shape)
+    return torch.zeros(shape)
+
+
+def _gen(key, shape, dtype, seed, mode="trained"):
     g = torch.Generator()
     g.manual_seed((zlib.crc32(key.encode()) ^ (seed * 0x9E3779B1)) & 0x7FFFFFFF)
     if dtype == torch.int64:
         if key.endswith("position_ids"):
             return torch.arange(shape[1]).expand(1, -1).clone()
-        return torch.tensor(1)                                    # ActNorm `initialized`
+        return torch.tensor(0 if mode == "reference_init" else 1)   # ActNorm `initialized`
     leaf = key.rsplit(".", 1)[-1]
+    if mode == "reference_init" and not (key.startswith("sub_mean") or key.startswith("add_mean")):
+        return _gen_reference_init(key, shape, g)
     if key.startswith("sub_mean") or key.startswith("add_mean"):
         # common.py:16-26 MeanShift constants (dead in forward); keep the reference's values
         if leaf == "weight":
@@ -155,11 +177,13 @@ def _gen(key, shape, dtype, seed):
     return 0.05 * torch.randn(shape, generator=g)                 # biases (conv, linear, ActNorm)
 
 
-def generate_state_dict(cfg: NetConfig, seed=0, with_dead=True, dtype=torch.float32):
-    """Deterministic stand-in for a trained checkpoint, keyed exactly like the reference's."""
+def generate_state_dict(cfg: NetConfig, seed=0, with_dead=True, dtype=torch.float32, mode="trained"):
+    """Deterministic stand-in for a checkpoint, keyed exactly like the reference's.
+    mode "trained": a distribution shaped like a trained net (damped residual branches, ActNorm initialised);
+    mode "reference_init": the distribution `define_G` itself produces (see _gen_reference_init), ActNorm uninitialised."""
     sd = {}
     for key, shape, dt in state_manifest(cfg, with_dead=with_dead):
-        t = _gen(key, shape, dt, seed)
+        t = _gen(key, shape, dt, seed, mode)
         if dt != torch.int64:
             t = t.to(dtype)
         sd[key] = t

@@ -1,5 +1,7 @@
 """DECHLGVIT of the reference (models/model_iid_dehazing.py:14-156), inference subset.  `netG` is the
 HIP-backed generator; `forward` is `[fake_R, fake_S, fake_A] = netG(real_B)` (model_iid_dehazing.py:140-143)."""
+import torch
+
 from .base_model import BaseModel
 
 
@@ -19,8 +21,15 @@ class DECHLGVIT(BaseModel):
         # any other --model_G leaves netG undefined, as the reference's if/elif chain does (-> AttributeError)
 
     def set_input(self, input):
-        self.real_B = input['B'].to(self.device)            # hazy image, H2D copy
+        B = input['B'].to(self.device)                      # hazy image, H2D copy
         self.image_paths = input['B_paths']
+        if B.dtype == torch.uint8:
+            # --u8_input: (B,H,W,3) uint8 goes to the generator as it is (normalised by the plan's first launch);
+            # `real_B` of get_current_visuals stays what the reference shows: the normalised float image
+            self._net_in = B
+            self.real_B = (B.permute(0, 3, 1, 2).float() / 255.0 - 0.5) / 0.5
+        else:
+            self._net_in = self.real_B = B
 
     def forward(self):
-        [self.fake_R, self.fake_S, self.fake_A] = self.netG(self.real_B)
+        [self.fake_R, self.fake_S, self.fake_A] = self.netG(self._net_in)

@@ -199,15 +199,17 @@ def affine(bias, an_w=None, an_b=None, cout_pad=None):
     return s, t
 
 
-def _check_actnorm(sd, prefix):
-    if int(sd[prefix + ".initialized"]) != 1:
-        raise NotImplementedError(
-            "ActNorm2d '%s' is not initialised (models/actnorm.py:25-37 would fill it from the first batch); "
-            "load a checkpoint or call init_actnorm_from_data() first" % prefix)
+def _actnorm_ready(sd, prefix):
+    return int(sd[prefix + ".initialized"]) == 1
 
 
-def pack_state_dict(sd, cfg: NetConfig, dtype=torch.float16):
-    """reference state_dict (tensors on any one device) -> packed tensors on the same device."""
+def pack_state_dict(sd, cfg: NetConfig, dtype=torch.float16, pending=None):
+    """reference state_dict (tensors on any one device) -> packed tensors on the same device.
+
+    An ActNorm2d whose `initialized` buffer is 0 holds no parameters yet: the reference fills it from the statistics of its first
+    batch (models/actnorm.py:25-37).  Such a layer gets a neutral epilogue table here and is reported in `pending`
+    ({packed layer name: (ActNorm key prefix, conv bias padded to Cout_pad)}); hipnet.dec_ipt hands those layers to
+    cfen_net_actnorm_pending, and the first forward initialises them on the device.  Without a `pending` dict this raises."""
     kc = 32 if dtype == torch.float16 else 16
     nf, h = cfg.n_feats, cfg.n_feats // 2
     out = {}
@@ -226,12 +228,19 @@ def pack_state_dict(sd, cfg: NetConfig, dtype=torch.float16):
             out[name + ".wr"] = pack_conv_weight_rows(w, cs_of(cin), dtype)
         else:
             out[name + ".w"] = pack_conv_weight(w, cs_of(cin), kc, dtype)
-        if an:
-            _check_actnorm(sd, an)
-            s, t = affine(sd[key + ".bias"], sd[an + ".weight"], sd[an + ".bias"], cp)
-        else:
+        out[name + ".scale"], out[name + ".shift"] = epilogue(name, key, an, cp)
+
+    def epilogue(name, key, an, cp):
+        if an and not _actnorm_ready(sd, an):
+            if pending is None:
+                raise NotImplementedError("ActNorm2d '%s' is not initialised (models/actnorm.py:25-37 fills it from the first batch); "
+                                          "pack with a `pending` dict so that the first forward initialises it on the device" % an)
             s, t = affine(sd[key + ".bias"], cout_pad=cp)
-        out[name + ".scale"], out[name + ".shift"] = s, t
+            pending[name] = (an, t.clone())
+            return s, t
+        if an:
+            return affine(sd[key + ".bias"], sd[an + ".weight"], sd[an + ".bias"], cp)
+        return affine(sd[key + ".bias"], cout_pad=cp)
 
     def convT(name, key, cin, an=None, edge=None):
         w = sd[key + ".weight"]
@@ -240,12 +249,7 @@ def pack_state_dict(sd, cfg: NetConfig, dtype=torch.float16):
             out[name + ".wr"] = pack_convT_weight_rows(w, cs_of(cin), dtype)
         else:
             out[name + ".w"] = pack_convT_weight(w, cs_of(cin), kc, dtype)
-        if an:
-            _check_actnorm(sd, an)
-            s, t = affine(sd[key + ".bias"], sd[an + ".weight"], sd[an + ".bias"], cp)
-        else:
-            s, t = affine(sd[key + ".bias"], cout_pad=cp)
-        out[name + ".scale"], out[name + ".shift"] = s, t
+        out[name + ".scale"], out[name + ".shift"] = epilogue(name, key, an, cp)
 
     conv("head.0.0", "head.0.0", 3, rows=(1, 2))
     conv("head.0.1.body.0", "head.0.1.body.0", h, rows=(1, 1))

@@ -18,6 +18,15 @@ def shard_range(total, world, rank):
     return lo, lo + base + (1 if rank < rem else 0)
 
 
+def even_shard(total, world, rank):
+    """shard_range for the all-gather path: all_gather_into_tensor and merge_gathered need equally sized per-rank slabs, so a
+    global batch that does not divide by the world size is refused here instead of hanging in the collective."""
+    if total % world:
+        raise ValueError("global batch %d is not divisible by world size %d: OutputGatherer needs equal per-rank slabs "
+                         "(pad the batch, or gather with per-rank sizes)" % (total, world))
+    return shard_range(total, world, rank)
+
+
 def split_slab(slab, batch, n):
     """flat [xr | xs | xd] slab of one rank -> views (B,3,n,n), (B,1,n,n), (B,3,n,n)."""
     px = batch * n * n
@@ -52,6 +61,9 @@ class OutputGatherer:
             torch.cuda.current_stream().wait_event(self.events[slot])
 
     def launch(self, slab, slot):
+        if slab.numel() != self.numel:
+            raise ValueError("slab has %d elements, the gatherer was built for %d per rank (every rank must hand over the same size)"
+                             % (slab.numel(), self.numel))
         convert = self.stage is not None and slab.dtype != self.dtype
         if not self.cuda:
             src = self.stage[slot].copy_(slab) if convert else slab

@@ -67,6 +67,19 @@ size_t cfen_net_workspace_bytes(const cfen_net* net);
 /* register one packed parameter (layout: cfen_vit_dehazing_amd/packing.py); the pointer must stay
  * valid for the life of the net.  `nbytes` is checked against what the layer needs.               */
 int cfen_net_set_param(cfen_net* net, const char* name, const void* dev_ptr, size_t nbytes);
+/* ActNorm2d first-call initialisation (models/actnorm.py:25-37).  Mark `layer` (a conv / conv-transpose layer followed by
+ * ActNorm2d, packing.py names) as uninitialised: the next EAGER cfen_net_forward runs it raw (`ones` [Cout_pad] of 1.0f as scale,
+ * `conv_bias` [Cout_pad] as shift), takes per-channel statistics of that output over the whole batch, overwrites the layer's
+ * registered "<layer>.scale" / "<layer>.shift" tables in place with the folded ActNorm epilogue and stores the raw parameters
+ * an_out[0][c] = weight = -0.5 log(max(var_unbiased, 0.2)), an_out[1][c] = bias = -mean  (an_out is [2][Cout_pad] fp32), then runs the
+ * layer normally -- the outputs of that forward are those of the reference's first forward.  Capture / profile refuse while
+ * layers are pending.                                                                                                         */
+int cfen_net_actnorm_pending(cfen_net* net, const char* layer, const float* ones, const float* conv_bias, float* an_out);
+int cfen_net_actnorm_pending_count(const cfen_net* net);
+/* Input format of cfen_net_forward / _graph_capture / _profile: 0 (default) x is fp32 NCHW in [-1,1]; 1: x is uint8 HWC
+ * (B,H,W,3) as decoded from the image file, normalised (v/255 - 0.5)/0.5 on the device by the plan's first launch
+ * (ToTensor + Normalize(0.5, 0.5), data/base_dataset.py:44-46).  Pass the uint8 pointer through the `x` argument.            */
+int cfen_net_set_input_u8(cfen_net* net, int enabled);
 /* names still missing, written as a ';'-separated list into buf; returns the count                */
 int cfen_net_missing_params(const cfen_net* net, char* buf, size_t buflen);
 /* x: (B,3,H,W) fp32 NCHW in [-1,1];  xr: (B,3,H,W), xs: (B,1,H,W), xd: (B,3,H,W) fp32 NCHW        */

@@ -73,9 +73,12 @@ def instance_norm(x, eps=1e-5):
 
 
 def actnorm(sd, prefix, x):
-    """models/actnorm.py:22-42 with `initialized == 1`: y = (x + bias) * exp(weight)."""
+    """models/actnorm.py:22-42: y = (x + bias) * exp(weight); when `initialized` is 0 the parameters are first filled from this
+    batch (actnorm.py:25-37) and written back into `sd`, exactly as the reference module mutates itself on its first forward."""
     if int(sd[prefix + ".initialized"]) != 1:
-        raise ValueError("oracle expects initialised ActNorm parameters (%s)" % prefix)
+        w, b = actnorm_init_params(x)
+        sd[prefix + ".weight"], sd[prefix + ".bias"] = w, b
+        sd[prefix + ".initialized"] = torch.tensor(1)
     return (x + sd[prefix + ".bias"].view(1, -1, 1, 1)) * torch.exp(sd[prefix + ".weight"]).view(1, -1, 1, 1)
 
 

@@ -20,6 +20,8 @@
 #include <math.h>
 #include <stddef.h>
 
+#define DCN_ORACLE_MAX_K 8192   /* channels per group x taps */
+
 static float bilinear(const float* im, int H, int W, float h, float w) {
   int h_low = (int)floorf(h), w_low = (int)floorf(w);
   int h_high = h_low + 1, w_high = w_low + 1;
@@ -45,32 +47,43 @@ int dcn_oracle_forward(const float* im, const float* offset, const float* mask, 
   if (Ho < 1 || Wo < 1 || H < kh || W < kw) return -1;
   const int Cg = C / group, Cog = Cout / group, cpdg = C / dg, kk = kh * kw;
   const size_t HWo = (size_t)Ho * Wo;
+  const int Kg = Cg * kk;
+  if (Kg > DCN_ORACLE_MAX_K) return -1;
+  /* One output pixel at a time: its column (the reference's deformable_im2col, one sample per (channel, tap)) is built once
+   * and contracted with every output channel's weights (the reference's addmm_), k ascending, in double.  Rows of the
+   * output are independent: the optional OpenMP loop changes nothing in the arithmetic. */
+#pragma omp parallel for collapse(2) schedule(static)
   for (int b = 0; b < B; ++b)
-    for (int g = 0; g < group; ++g)
-      for (int co = 0; co < Cog; ++co)
-        for (int ho = 0; ho < Ho; ++ho)
-          for (int wo = 0; wo < Wo; ++wo) {
+    for (int ho = 0; ho < Ho; ++ho) {
+      float col[DCN_ORACLE_MAX_K];
+      for (int g = 0; g < group; ++g)
+        for (int wo = 0; wo < Wo; ++wo) {
+          for (int c = 0; c < Cg; ++c) {
+            const int cim = g * Cg + c, dgi = cim / cpdg;
+            const float* imp = im + ((size_t)b * C + cim) * H * W;
+            const float* offp = offset + ((size_t)b * dg + dgi) * 2 * kk * HWo;
+            const float* mp = mask ? mask + ((size_t)b * dg + dgi) * kk * HWo : NULL;
+            for (int i = 0; i < kh; ++i)
+              for (int j = 0; j < kw; ++j) {
+                const int ij = i * kw + j;
+                const float oh = offp[(size_t)(2 * ij) * HWo + (size_t)ho * Wo + wo];
+                const float ow = offp[(size_t)(2 * ij + 1) * HWo + (size_t)ho * Wo + wo];
+                const float h_im = (float)(ho * sh - ph + i * dh) + oh;
+                const float w_im = (float)(wo * sw - pw + j * dw) + ow;
+                float val = 0.f;
+                if (h_im > -1 && w_im > -1 && h_im < H && w_im < W) val = bilinear(imp, H, W, h_im, w_im);
+                if (mp) val *= mp[(size_t)ij * HWo + (size_t)ho * Wo + wo];
+                col[c * kk + ij] = val;
+              }
+          }
+          for (int co = 0; co < Cog; ++co) {
+            const float* wp = weight + ((size_t)(g * Cog + co)) * Kg;
             double acc = 0.0;
-            for (int c = 0; c < Cg; ++c) {
-              const int cim = g * Cg + c, dgi = cim / cpdg;
-              const float* imp = im + ((size_t)b * C + cim) * H * W;
-              const float* offp = offset + ((size_t)b * dg + dgi) * 2 * kk * HWo;
-              const float* mp = mask ? mask + ((size_t)b * dg + dgi) * kk * HWo : NULL;
-              for (int i = 0; i < kh; ++i)
-                for (int j = 0; j < kw; ++j) {
-                  const int ij = i * kw + j;
-                  const float oh = offp[(size_t)(2 * ij) * HWo + (size_t)ho * Wo + wo];
-                  const float ow = offp[(size_t)(2 * ij + 1) * HWo + (size_t)ho * Wo + wo];
-                  const float h_im = (float)(ho * sh - ph + i * dh) + oh;
-                  const float w_im = (float)(wo * sw - pw + j * dw) + ow;
-                  float val = 0.f;
-                  if (h_im > -1 && w_im > -1 && h_im < H && w_im < W) val = bilinear(imp, H, W, h_im, w_im);
-                  if (mp) val *= mp[(size_t)ij * HWo + (size_t)ho * Wo + wo];
-                  acc += (double)weight[(((size_t)(g * Cog + co)) * Cg + c) * kk + ij] * (double)val;
-                }
-            }
+            for (int k = 0; k < Kg; ++k) acc += (double)wp[k] * (double)col[k];
             if (bias) acc += bias[g * Cog + co];
             out[(((size_t)b * Cout + g * Cog + co) * Ho + ho) * Wo + wo] = (float)acc;
           }
+        }
+    }
   return 0;
 }

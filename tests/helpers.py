@@ -18,6 +18,11 @@ def load_net_fixture(name):
     return cfg, int(z["batch"]), z
 
 
+def weight_mode(name):
+    """fixtures named refinit_* were made with the reference's own init distribution and uninitialised ActNorm (tools/gen_golden.py)"""
+    return "reference_init" if name.startswith("refinit") else "trained"
+
+
 def sample_idx(name, numel, n=512):
     g = torch.Generator()
     g.manual_seed(zlib.crc32(name.encode()) & 0x7FFFFFFF)

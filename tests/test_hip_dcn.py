@@ -71,3 +71,22 @@ def test_error_behaviour_matches_reference():
         dcn.deform_conv(x.cpu(), torch.zeros(2, 18, 8, 8), w.cpu(), 1, 1)                           # CPU tensors (:36-37)
     with pytest.raises(RuntimeError):
         dcn.deform_conv(x, torch.zeros(2, 16, 8, 8, device=DEV), w, 1, 1)                            # offset channels (.cpp:129-130)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.float16])
+@pytest.mark.parametrize("C,H,dg", [(24, 256, 1), (24, 256, 8), (48, 128, 1), (48, 128, 8), (96, 64, 1), (96, 64, 8)])
+def test_deform_conv_at_the_generator_feature_map_shapes(dtype, C, H, dg):
+    """(B,24,256,256) / (B,48,128,128) / (B,96,64,64), 3x3 s1 p1, deformable groups 1 and 8, v1 and v2.
+    Batch 2 (the oracle is scalar C); offsets of +-2 pixels reach over the borders."""
+    B = 2
+    x, w = rnd((B, C, H, H), 11), rnd((C, C, 3, 3), 12, (C * 9) ** -0.5)
+    off = rnd((B, dg * 18, H, H), 13, 2.0)
+    mask = torch.sigmoid(rnd((B, dg * 9, H, H), 14))
+    bias = rnd((C,), 15)
+    xq, wq, oq, mq, bq = (t.to(dtype) for t in (x, w, off, mask, bias))
+    want1 = dcn_oracle.deform_conv(xq.float(), oq.float(), wq.float(), 1, 1, 1, 1, dg)
+    got1 = dcn.deform_conv(xq.to(DEV), oq.to(DEV), wq.to(DEV), 1, 1, 1, 1, dg)
+    assert float((got1.float().cpu() - want1).abs().max()) <= tol(dtype)
+    want2 = dcn_oracle.deform_conv(xq.float(), oq.float(), wq.float(), 1, 1, 1, 1, dg, mask=mq.float(), bias=bq.float())
+    got2 = dcn.modulated_deform_conv(xq.to(DEV), oq.to(DEV), mq.to(DEV), wq.to(DEV), bq.to(DEV), 1, 1, 1, 1, dg)
+    assert float((got2.float().cpu() - want2).abs().max()) <= tol(dtype)

@@ -13,14 +13,14 @@ import cfen_oracle
 from cfen_vit_dehazing_amd.config import NetConfig
 from cfen_vit_dehazing_amd.hipnet import dec_ipt
 from cfen_vit_dehazing_amd.manifest import generate_state_dict, synthetic_input
-from helpers import load_net_fixture, check_outputs, check_stages
+from helpers import load_net_fixture, check_outputs, check_stages, weight_mode
 
 pytestmark = pytest.mark.gpu
 
 
-def make_net(cfg, dtype, seed=0):
+def make_net(cfg, dtype, seed=0, mode="trained", sd=None):
     net = dec_ipt(cfg, compute_dtype=dtype)
-    net.load_state_dict(generate_state_dict(cfg, seed=seed), strict=True)
+    net.load_state_dict(sd if sd is not None else generate_state_dict(cfg, seed=seed, mode=mode), strict=True)
     return net.to("cuda:0")
 
 
@@ -222,3 +222,151 @@ def test_split_k_and_grouping_knobs_do_not_change_results():
         ops.tune("gemm.splitk", 1)
     for p, q in zip(outs[0], outs[1]):
         assert float((p - q).abs().max()) < 5e-3
+
+
+# ---- the benchmarked configurations themselves (BASELINE.json configs 2, 4, 5), fp16, replayed from the hipGraph ----------------
+
+def _crop(t):
+    n = t.shape[-1]
+    c0 = n // 2 - 32
+    return t[:, :, c0:c0 + 64, c0:c0 + 64]
+
+
+def _fp16_vs_fixture(z, outs, x, max_abs_bar):
+    """image 0 of `outs` against the reference vectors: max-abs on crop + strided samples, and PSNR / SSIM of the 64x64 centre crop
+    against a common target (the input crop) must move by <= 0.01 dB / 1e-4 relative to the reference's own outputs"""
+    first = [o[0:1].float().cpu() for o in outs]
+    worst = check_outputs(z, first, max_abs_bar)
+    tgt = _crop(x[0:1].float().cpu())
+    for nm, o in zip(("xr", "xs", "xd"), first):
+        ref = torch.from_numpy(z["crop/" + nm])
+        got = _crop(o)
+        t = tgt[:, :ref.shape[1]]
+        dp = abs(cfen_oracle.psnr(ref, t) - cfen_oracle.psnr(got, t))
+        ds = abs(cfen_oracle.ssim(ref, t) - cfen_oracle.ssim(got, t))
+        assert dp <= 0.01 and ds <= 1e-4, "%s: dPSNR %.4f dB dSSIM %.2e" % (nm, dp, ds)
+    return worst
+
+
+@pytest.mark.parametrize("name,batch", [("full512_nf24_hdr4", 8), ("full512_nf24_hdr2", 16), ("full1024_nf24_hdr4", 4)])
+def test_fp16_benchmark_configs_graph_replay_vs_reference_vectors(name, batch):
+    """exactly what bench.py times: batch B, fp16, hipGraph replay.  Image 0 is the fixture's input (seed 0); the other images
+    must equal their own batch-1 eager forward up to fp16 rounding (the few-token GViT GEMMs pick other kernels at other batch sizes)"""
+    cfg, _, z = load_net_fixture(name)
+    net = make_net(cfg, "fp16")
+    x = synthetic_input(batch, cfg).to("cuda:0")
+    eager = [o.clone() for o in net(x)]
+    gid, outs = net.capture(x)
+    for o in outs:
+        o.zero_()
+    net.replay(gid)
+    net.replay(gid)
+    torch.cuda.synchronize()
+    for a, b in zip(eager, outs):
+        assert torch.equal(a, b)                                   # replay is bitwise the eager plan
+    worst = _fp16_vs_fixture(z, outs, x, 3e-2)
+    print("%s B=%d fp16 graph: image 0 max-abs vs reference vectors %.2e" % (name, batch, worst))
+    for i in sorted({1, batch // 2, batch - 1}):
+        one = net(x[i:i + 1].clone())
+        for a, b in zip(outs, one):
+            d = float((a[i:i + 1] - b).abs().max())
+            assert d <= 1e-2, "image %d differs from its batch-1 forward by %.3e" % (i, d)
+    del net
+    torch.cuda.empty_cache()
+
+
+def test_two_lane_plan_equals_serial_plan_bitwise_full_size():
+    """GViT beside LViT on a second lane must not change a single bit (512x512, B=2, eager and graph)"""
+    cfg = NetConfig(24, 4, patch_size=32, load_size=256)
+    net = make_net(cfg, "fp16")
+    x = synthetic_input(2, cfg).to("cuda:0")
+    two = [o.clone() for o in net(x)]
+    gid, gouts = net.capture(x)
+    net.replay(gid)
+    torch.cuda.synchronize()
+    net.serial_plan = True
+    one = [o.clone() for o in net(x)]
+    for a, b, c in zip(two, one, gouts):
+        assert torch.equal(a, b) and torch.equal(a, c)
+
+
+def test_repeated_forwards_are_bit_reproducible_at_benchmark_size():
+    """tools/stress_determinism.py as a test: B=8 512x512 fp16, eager and graph alternating, with unrelated GEMM noise on a third stream"""
+    cfg = NetConfig(24, 4, patch_size=32, load_size=256)
+    net = make_net(cfg, "fp16")
+    x = synthetic_input(8, cfg).to("cuda:0")
+    ref = [o.clone() for o in net(x)]
+    gid, gout = net.capture(x)
+    big = torch.randn(4096, 4096, device="cuda:0").half()
+    side = torch.cuda.Stream()
+    bad = []
+    for it in range(24):
+        if it % 3 == 2:
+            with torch.cuda.stream(side):
+                for _ in range(4):
+                    torch.mm(big, big)
+        if it % 2:
+            for o in gout:
+                o.zero_()
+            net.replay(gid)
+            outs = gout
+        else:
+            outs = net(x)
+        torch.cuda.synchronize()
+        if not all(torch.equal(a, b) for a, b in zip(ref, outs)):
+            bad.append(it)
+    assert not bad, "runs %s differ bitwise from the first" % bad
+
+
+# ---- weights as the reference's define_G leaves them + ActNorm2d first-call initialisation on the device (A9) -----------------
+
+@pytest.mark.parametrize("name", ["refinit_tiny_nf24_hdr4", "refinit_full512_nf24_hdr4"])
+def test_reference_init_weights_and_device_actnorm_init_fp32(name):
+    """define_G + forward without a checkpoint: the first forward fills the 24 ActNorm2d layers from its batch
+    (models/actnorm.py:25-37) on the device; parameters and outputs equal those of the reference's first forward"""
+    cfg, batch, z = load_net_fixture(name)
+    net = make_net(cfg, "fp32", mode="reference_init")
+    assert int(net.state_dict()["lgcat_conv_e01.1.initialized"]) == 0
+    x = synthetic_input(batch, cfg).to("cuda:0")
+    outs = [o.clone() for o in net(x)]
+    sd = net.state_dict()
+    for k in [str(v) for v in z["actnorm_names"]]:
+        assert int(sd[k + ".initialized"]) == 1
+        dw = float(np.abs(sd[k + ".weight"].cpu().numpy() - z["actnorm_w/" + k]).max())
+        db = float(np.abs(sd[k + ".bias"].cpu().numpy() - z["actnorm_b/" + k]).max())
+        assert dw <= 2e-4 and db <= 2e-3 * max(1.0, float(np.abs(z["actnorm_b/" + k]).max())), "%s: dweight %.2e dbias %.2e" % (k, dw, db)
+    worst = check_outputs(z, outs, 1e-3)                                       # the north_star fp32 bar
+    again = net(x)                                                              # now initialised: same tables, same bits
+    for a, b in zip(outs, again):
+        assert torch.equal(a, b)
+    print("%s fp32 with device ActNorm init: outputs max-abs vs reference %.2e" % (name, worst))
+
+
+def test_reference_init_weights_fp16_psnr_ssim_full512():
+    """fp16 path on the reference's own init distribution (kaiming residual branches, N(0,1) position table): both with the
+    reference's ActNorm parameters loaded and with ActNorm initialised on the device from fp16 activations"""
+    name = "refinit_full512_nf24_hdr4"
+    cfg, batch, z = load_net_fixture(name)
+    sd = generate_state_dict(cfg, seed=0, mode="reference_init")
+    x = synthetic_input(batch, cfg).to("cuda:0")
+    net = make_net(cfg, "fp16", sd=sd)                                          # device init
+    w1 = _fp16_vs_fixture(z, net(x), x, 6e-2)
+    for k in [str(v) for v in z["actnorm_names"]]:
+        sd[k + ".weight"], sd[k + ".bias"] = torch.from_numpy(z["actnorm_w/" + k]), torch.from_numpy(z["actnorm_b/" + k])
+        sd[k + ".initialized"] = torch.tensor(1)
+    net2 = make_net(cfg, "fp16", sd=sd)
+    w2 = _fp16_vs_fixture(z, net2(x), x, 6e-2)
+    print("refinit full512 fp16: max-abs vs reference %.2e (device ActNorm init) / %.2e (reference ActNorm parameters)" % (w1, w2))
+
+
+def test_uint8_input_equals_host_normalised_input():
+    """--u8_input: (B,H,W,3) uint8 straight into the plan == ToTensor + Normalize(0.5, 0.5) on the host (data/base_dataset.py:44-46)"""
+    cfg = NetConfig(24, 4, patch_size=8, load_size=64)
+    net = make_net(cfg, "fp32")
+    g = torch.Generator(); g.manual_seed(3)
+    u8 = torch.randint(0, 256, (2, 128, 128, 3), generator=g, dtype=torch.uint8)
+    xf = ((u8.permute(0, 3, 1, 2).float() / 255.0) - 0.5) / 0.5
+    a = [o.clone() for o in net(xf.to("cuda:0"))]
+    b = net(u8.to("cuda:0"))
+    for p, q in zip(a, b):
+        assert torch.equal(p, q)

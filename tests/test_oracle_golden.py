@@ -7,7 +7,7 @@ import torch
 
 import cfen_oracle
 from cfen_vit_dehazing_amd.manifest import generate_state_dict, synthetic_input
-from helpers import GOLDEN, load_net_fixture, check_stages, check_outputs
+from helpers import GOLDEN, load_net_fixture, check_stages, check_outputs, weight_mode
 
 TOL_OUT = 5e-6
 TOL_STAGE = 5e-5
@@ -15,7 +15,7 @@ TOL_STAGE = 5e-5
 
 def _run(name):
     cfg, batch, z = load_net_fixture(name)
-    sd = generate_state_dict(cfg, seed=0, with_dead=False)
+    sd = generate_state_dict(cfg, seed=0, with_dead=False, mode=weight_mode(name))
     x = synthetic_input(batch, cfg)
     st = {}
     with torch.no_grad():
@@ -25,7 +25,17 @@ def _run(name):
     for nm, o in zip(("xr", "xs", "xd"), outs):
         stat = z["stat/" + nm]
         assert abs(float(o.mean()) - stat[0]) < 1e-5 and abs(float(o.std()) - stat[1]) < 1e-5
+    if name.startswith("refinit"):      # the first forward initialised every ActNorm2d from its batch (models/actnorm.py:25-37)
+        for k in [str(v) for v in z["actnorm_names"]]:
+            assert int(sd[k + ".initialized"]) == 1
+            assert np.allclose(sd[k + ".weight"].numpy(), z["actnorm_w/" + k], atol=2e-6), k
+            assert np.allclose(sd[k + ".bias"].numpy(), z["actnorm_b/" + k], atol=2e-5), k
     return outs
+
+
+def test_oracle_reference_init_weights_and_actnorm_first_call():
+    """weights as define_G leaves them (kaiming, N(0,1) positions) + ActNorm2d initialised by the first forward, as the reference does"""
+    _run("refinit_tiny_nf24_hdr4")
 
 
 @pytest.mark.parametrize("name", ["tiny_nf24_hdr4", "tiny_nf24_hdr2", "small_nf24_hdr4"])

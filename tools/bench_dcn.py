@@ -1,0 +1,67 @@
+#!/usr/bin/env python3
+"""Deformable-conv forward (DCNv1 / DCNv2) at the feature-map shapes of the v3 generator:
+(B,24,256,256), (B,48,128,128), (B,96,64,64), 3x3, stride 1, pad 1, deformable groups 1 and 8.  Prints one JSON line per case:
+kernel time (HIP events on the launch stream, median of repetitions), achieved GB/s against the ALGORITHMIC bytes of SURVEY 8d
+(input + offsets (+ mask) + output + weights, each once) and the HBM peak, and the MFMA rate of its 2*Cout*C*9*H*W contraction.
+
+    python tools/bench_dcn.py [--batch 8] [--dtype fp16] [--check]      (--check: compare one image with the C oracle)"""
+import argparse, json, os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from cfen_vit_dehazing_amd import dcn
+
+HBM_PEAK = 8000.0   # GB/s, MI355X_MICROARCH.md
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--batch", type=int, default=8)
+    ap.add_argument("--dtype", default="fp16", choices=["fp16", "fp32"])
+    ap.add_argument("--reps", type=int, default=30)
+    ap.add_argument("--check", action="store_true")
+    args = ap.parse_args()
+    dt = torch.float16 if args.dtype == "fp16" else torch.float32
+    esz = 2 if dt == torch.float16 else 4
+    dev = "cuda:0"
+    B = args.batch
+    if args.check:
+        sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle"))
+        import dcn_oracle
+    flush = torch.empty(300 * 1024 * 1024, dtype=torch.uint8, device=dev)       # > Infinity Cache: every timed launch starts cold
+    for C, H in ((24, 256), (48, 128), (96, 64)):
+        for dg in (1, 8):
+            g = torch.Generator().manual_seed(C * 10 + dg)
+            x = torch.randn(B, C, H, H, generator=g).to(dt).to(dev)
+            w = (torch.randn(C, C, 3, 3, generator=g) * (C * 9) ** -0.5).to(dt).to(dev)
+            off = (torch.randn(B, dg * 18, H, H, generator=g) * 2.0).to(dt).to(dev)
+            mask = torch.sigmoid(torch.randn(B, dg * 9, H, H, generator=g)).to(dt).to(dev)
+            bias = torch.randn(C, generator=g).to(dt).to(dev)
+            for ver in (1, 2):
+                fn = (lambda: dcn.deform_conv(x, off, w, 1, 1, 1, 1, dg)) if ver == 1 else \
+                     (lambda: dcn.modulated_deform_conv(x, off, mask, w, bias, 1, 1, 1, 1, dg))
+                out = fn()
+                torch.cuda.synchronize()
+                times = []
+                for _ in range(args.reps):
+                    flush.zero_()
+                    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    a.record(); fn(); b.record()
+                    torch.cuda.synchronize()
+                    times.append(a.elapsed_time(b))
+                times.sort()
+                ms = times[len(times) // 2]
+                px = B * H * H
+                elems = C * px + (2 if ver == 1 else 3) * dg * 9 * px + C * px + C * C * 9
+                gbs = elems * esz / ms / 1e6
+                tf = (2.0 * C * C * 9 + 8.0 * C * 9) * px / ms / 1e9
+                rec = {"op": "dcn_v%d" % ver, "shape": [B, C, H, H], "deformable_groups": dg, "dtype": args.dtype, "us": round(ms * 1e3, 1),
+                       "algorithmic_MB": round(elems * esz / 1e6, 2), "GBps": round(gbs, 1), "hbm_frac": round(gbs / HBM_PEAK, 4), "TFLOPs": round(tf, 2)}
+                if args.check:
+                    want = dcn_oracle.deform_conv(x[:1].float().cpu(), off[:1].float().cpu(), w.float().cpu(), 1, 1, 1, 1, dg,
+                                                  **({} if ver == 1 else {"mask": mask[:1].float().cpu(), "bias": bias.float().cpu()}))
+                    rec["max_abs_vs_oracle_image0"] = float((out[:1].float().cpu() - want).abs().max())
+                print(json.dumps(rec), flush=True)
+
+
+if __name__ == "__main__":
+    main()

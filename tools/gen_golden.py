@@ -39,7 +39,16 @@ CONFIGS = {
     "full512_nf24_hdr4": (NetConfig(24, 4, patch_size=32, load_size=256), 1, False),
     "full512_nf24_hdr2": (NetConfig(24, 2, patch_size=32, load_size=256), 1, False),
     "full1024_nf24_hdr4": (NetConfig(24, 4, patch_size=64, load_size=512), 1, False),
+    # weights drawn from what the reference's own define_G / init_weights leaves (v3:49-74, 1330, 1377), ActNorm2d uninitialised:
+    # the reference's first forward initialises its 24 ActNorm layers from the batch (models/actnorm.py:25-37); the fixture
+    # holds those parameters next to the outputs of that same forward
+    "refinit_tiny_nf24_hdr4": (NetConfig(24, 4, patch_size=8, load_size=64), 2, True),
+    "refinit_full512_nf24_hdr4": (NetConfig(24, 4, patch_size=32, load_size=256), 1, False),
 }
+
+
+def weight_mode(name):
+    return "reference_init" if name.startswith("refinit") else "trained"
 
 STAGE_MODULES = None
 
@@ -134,11 +143,11 @@ class StageRecorder:
         return self.out
 
 
-def run_reference(v3, common, cfg, batch, dtype=torch.float32):
+def run_reference(v3, common, cfg, batch, dtype=torch.float32, mode="trained"):
     opt = opt_for(cfg)
     torch.manual_seed(0)
     net = v3.dec_ipt(opt, common.default_conv)
-    sd = generate_state_dict(cfg, seed=0)
+    sd = generate_state_dict(cfg, seed=0, mode=mode)
     missing = net.load_state_dict(sd, strict=True)
     net = net.to(dtype)
     x = synthetic_input(batch, cfg).to(dtype)
@@ -164,8 +173,9 @@ def dump_manifest(net, path):
 def gen_net(v3, common, name):
     cfg, batch, full = CONFIGS[name]
     print("== %s: reference forward (B=%d, %dx%d)" % (name, batch, cfg.image_size, cfg.image_size), flush=True)
-    net, sd, x, outs, stages = run_reference(v3, common, cfg, batch)
-    dump_manifest(net, os.path.join(GOLD, "state_manifest_%s.txt" % name))
+    net, sd, x, outs, stages = run_reference(v3, common, cfg, batch, mode=weight_mode(name))
+    if not name.startswith("refinit"):
+        dump_manifest(net, os.path.join(GOLD, "state_manifest_%s.txt" % name))
     data = {"batch": np.int64(batch), "cfg": np.array([cfg.n_feats, cfg.hidden_dim_ratio, cfg.patch_size, cfg.load_size], np.int64)}
     names = stage_names()
     assert len(names) == 58 and all(n in stages for n in names), [n for n in names if n not in stages]
@@ -185,6 +195,15 @@ def gen_net(v3, common, name):
             c0 = n // 2 - 32
             data["crop/" + nm] = o[:, :, c0:c0 + 64, c0:c0 + 64].numpy().copy()
             data["strided/" + nm] = o[:, :, 3::8, 5::8].numpy().copy()
+    if name.startswith("refinit"):
+        # the ActNorm parameters the reference's first forward computed (and its `initialized` flags, now 1)
+        after = net.state_dict()
+        an = [k[:-len(".initialized")] for k in after if k.endswith(".initialized")]
+        assert len(an) == 24 and all(int(after[k + ".initialized"]) == 1 for k in an)
+        data["actnorm_names"] = np.array(an)
+        for k in an:
+            data["actnorm_w/" + k] = after[k + ".weight"].numpy().copy()
+            data["actnorm_b/" + k] = after[k + ".bias"].numpy().copy()
     np.savez_compressed(os.path.join(GOLD, "net_%s.npz" % name), **data)
     for nm, o in zip(("xr", "xs", "xd"), outs):
         print("   %s mean %.4f std %.4f min %.4f max %.4f" % ((nm,) + tuple(data["stat/" + nm])))
@@ -192,8 +211,12 @@ def gen_net(v3, common, name):
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import cfen_oracle
     st = {}
+    sd = generate_state_dict(cfg, seed=0, mode=weight_mode(name))      # fresh copy: load_state_dict shares no storage, but be explicit
     with torch.no_grad():
         o2 = cfen_oracle.forward(sd, x, cfg.num_heads, cfg.patch_size, stages=st)
+    if name.startswith("refinit"):
+        worst_an = max(float((sd[k + ".weight"] - torch.from_numpy(data["actnorm_w/" + k])).abs().max()) for k in data["actnorm_names"])
+        print("   oracle ActNorm init vs reference: worst |dweight| %.3e" % worst_an)
     for nm, a, b in zip(("xr", "xs", "xd"), outs, o2):
         print("   oracle vs reference %s: max-abs %.3e" % (nm, (a - b).abs().max().item()))
     worst = max((stages[n] - st[n]).abs().max().item() for n in names)
