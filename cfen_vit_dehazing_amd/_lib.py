@@ -31,7 +31,7 @@ class ConvArgsC(ctypes.Structure):
 
 class EmbedQkvArgsC(ctypes.Structure):
     _fields_ = [("fmap", c_void_p)] + [(n, ctypes.c_int32) for n in ("B", "H", "W", "C", "cs", "ws", "p")] + \
-               [(n, c_void_p) for n in ("we", "be", "pos", "ln_gamma", "ln_beta", "wqkv", "x1", "qkv")] + [("eps", c_float)]
+               [(n, c_void_p) for n in ("we", "be", "pos", "ln_gamma", "ln_beta", "wqkv", "x1", "qkv")] + [("eps", c_float), ("head_major_heads", ctypes.c_int32)]
 
 
 class MlpArgsC(ctypes.Structure):
@@ -71,6 +71,7 @@ SIGNATURES = {
     "cfen_embed_qkv": (_I, [_I, ctypes.POINTER(EmbedQkvArgsC), _P]),
     "cfen_layernorm": (_I, [_I, _P, _P, _P, _P, _I, _I, c_float, _P]),
     "cfen_attention": (_I, [_I, _P, _P, _I, _I, _I, _I, _P]),
+    "cfen_attention_head_major": (_I, [_I, _P, _P, _I, _I, _I, _I, _P]),
     "cfen_mlp_block": (_I, [_I, ctypes.POINTER(MlpArgsC), _P]),
     "cfen_patchify": (_I, [_I, _P, _P] + [_I] * 8 + [_P]),
     "cfen_unpatchify": (_I, [_I, _P, _P] + [_I] * 7 + [_P]),

@@ -88,8 +88,12 @@ int cfen_embed_qkv(int dtype, const cfen_embed_qkv_args* a, void* stream) {
                  "embed_qkv: bad geometry");
   const int tw = a->ws / a->p;
   CfenEmbedQkvArgs q{a->fmap, a->B, a->H, a->W, a->C, a->cs, a->ws, a->p, a->we, a->be, a->pos, a->ln_gamma, a->ln_beta, a->wqkv, a->x1, a->qkv,
-                     (long long)a->B * (a->H / a->ws) * (a->W / a->ws) * tw * tw, a->p * a->p * a->C, a->eps};
+                     (long long)a->B * (a->H / a->ws) * (a->W / a->ws) * tw * tw, a->p * a->p * a->C, a->eps, a->head_major_heads};
   return cfen_embed_qkv_impl_g(dtype, 1, &q, (hipStream_t)stream);
+}
+
+int cfen_attention_head_major(int dtype, const void* qkv, void* out, int nseq, int S, int heads, int dh, void* stream) {
+  return cfen_attention_hm_impl_g(dtype, 1, &qkv, &out, nseq, S, heads, dh, (hipStream_t)stream);
 }
 
 int cfen_u8hwc_to_nhwc(int dtype, const unsigned char* in, void* out, int B, int H, int W, int cs, void* stream) {
@@ -129,6 +133,10 @@ int cfen_tune(const char* key, int value) {
   }
   if (!strcmp(key, "mlp.small_tiles")) {
     cfen_tune_mlp_small_tiles() = value;
+    return CFEN_OK;
+  }
+  if (!strcmp(key, "net.attn_head_major")) {
+    cfen_tune_attn_head_major() = value != 0;
     return CFEN_OK;
   }
   if (!strcmp(key, "net.embed_gather")) {

@@ -20,6 +20,7 @@ struct CfenEmbedQkvArgs {
   const void* Wqkv;                                   // [3D][D], k axis as We
   void* X1; void* QKV;                                // [M][D], [M][3D]
   long long M; int D; float eps;
+  int hm_heads;   // > 0: QKV is written head-major, [(window * heads + head) * 3 + {q,k,v}][S][D / heads] (k_attention_hm's input)
 };
 bool cfen_embed_qkv_supported(int D);
 int cfen_embed_qkv_impl_g(int dtype, int ng, const CfenEmbedQkvArgs* a, hipStream_t s);
@@ -35,6 +36,9 @@ int cfen_upsample4_impl_g(int dtype, int ng, const void* const* small, void* con
 int cfen_attention_impl_g(int dtype, int ng, const void* const* qkv, void* const* out, int nseq, int S, int heads, int dh, hipStream_t s);
 int cfen_layernorm_impl_g(int dtype, int ng, const void* const* X, void* const* Y, const float* const* g, const float* const* b, int M, int D,
                           float eps, hipStream_t s);
+// window attention on the head-major qkv layout (see CfenEmbedQkvArgs::hm_heads); fp16, head_dim 24, S in {64, 256}
+bool cfen_attention_hm_supported(int dtype, int S, int dh);
+int cfen_attention_hm_impl_g(int dtype, int ng, const void* const* qkv, void* const* out, int nseq, int S, int heads, int dh, hipStream_t s);
 int cfen_attention_impl(int dtype, const void* qkv, void* out, int nseq, int S, int heads, int dh, hipStream_t s);
 int cfen_layernorm_impl(int dtype, const void* X, void* Y, const float* g, const float* b, int M, int D, float eps, hipStream_t s);
 int cfen_patchify_impl(int dtype, const void* fmap, void* tok, int B, int H, int W, int C, int cs, int ws, int p, int pool, int inverse,
@@ -75,4 +79,5 @@ int& cfen_tune_mlp_small_tiles();   // fused-MLP tiling ("mlp.small_tiles"): 0 2
 int& cfen_tune_skip_classes();    // bit mask of kernel classes NOT launched by the net (marginal-cost timing; outputs invalid) ("net.skip_classes")
 int& cfen_tune_fused_front_max_dim();   // k_embed_qkv is used for LViT embedding dims <= this (0 = never) ("net.fused_front_max_dim")
 int& cfen_tune_gemm_splitk();     // 1 (default): K-heavy few-token GEMMs run split-K when the caller provides scratch ("gemm.splitk")
+int& cfen_tune_attn_head_major();   // 1 (default): LViT levels with a fused front half hand qkv to attention head-major ("net.attn_head_major")
 int& cfen_tune_embed_lds();        // k_embed_qkv weights through LDS: bit 0 for D = 96, bit 1 for D = 192 ("embed.lds")

@@ -29,6 +29,10 @@ int& cfen_tune_embed_gather() {
   static int v = 1;
   return v;
 }
+int& cfen_tune_attn_head_major() {
+  static int v = 1;
+  return v;
+}
 
 namespace {
 
@@ -462,12 +466,15 @@ int cfen_net::run_vit_g(int ng, const VitCall* vc, int scr0) {
   };
   const float* lg[3];
   const float* lb[3];
+  bool head_major = false;   // the fused front half writes qkv per (window, head) for k_attention_hm
   if (v.fused_front && v.D <= cfen_tune_fused_front_max_dim()) {
     // LViT levels 1-2: gather + linear_encoding + residual + position + LN1 + qkv in one launch, x -> X1, QKV (k_embed.hip)
     CfenEmbedQkvArgs e[3];
+    head_major = cfen_tune_attn_head_major() && cfen_attention_hm_supported(dt, v.S, v.D / v.heads);
     for (int g = 0; g < ng; ++g)
       e[g] = CfenEmbedQkvArgs{IN[g], B, v.mapH, v.mapH, v.C, bi.cs, v.ws, v.p, P(nm[g] + ".embed.wk"), Pf(nm[g] + ".embed.b"), P(nm[g] + ".pos"),
-                              Pf(nm[g] + ".ln1.g"), Pf(nm[g] + ".ln1.b"), P(nm[g] + ".qkv.wk"), X1[g], QKV[g], M, v.D, 1e-5f};
+                              Pf(nm[g] + ".ln1.g"), Pf(nm[g] + ".ln1.b"), P(nm[g] + ".qkv.wk"), X1[g], QKV[g], M, v.D, 1e-5f,
+                              head_major ? v.heads : 0};
     step("embed_ln_qkv");
     TRYP(K_GEMM, 8 * Md * D * D, cfen_embed_qkv_impl_g(dt, ng, e, stream));
   } else {
@@ -491,7 +498,10 @@ int cfen_net::run_vit_g(int ng, const VitCall* vc, int scr0) {
     TRYP(K_GEMM, 6 * Md * D * D, gemm(cYN, ".qkv.w", nullptr, nullptr, nullptr, QKV, 3 * v.D, v.D, 0, nullptr));
   }
   step("attention");
-  TRYP(K_ATTN, 4 * Md * v.S * D, cfen_attention_impl_g(dt, ng, cQKV, ATT, B * nwin, v.S, v.heads, v.D / v.heads, stream));
+  if (head_major)
+    TRYP(K_ATTN, 4 * Md * v.S * D, cfen_attention_hm_impl_g(dt, ng, cQKV, ATT, B * nwin, v.S, v.heads, v.D / v.heads, stream));
+  else
+    TRYP(K_ATTN, 4 * Md * v.S * D, cfen_attention_impl_g(dt, ng, cQKV, ATT, B * nwin, v.S, v.heads, v.D / v.heads, stream));
   const void* cATT[3] = {ATT[0], ATT[1], ATT[2]};
   if (!v.fused_mlp) {
     step("proj");

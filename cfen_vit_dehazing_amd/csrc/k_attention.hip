@@ -283,6 +283,90 @@ __global__ __launch_bounds__(256) void k_attention_win(PtrG<const T> QKVg, PtrG<
   }
 }
 
+// Window attention on the HEAD-MAJOR qkv layout that k_embed_qkv writes for LViT levels 1-2 (fp16, head_dim 24, S = 64 / 256):
+//     qkv[(window * heads + head) * 3 + {q, k, v}][S][24]
+// so the q, k and v blocks of one (window, head) are three contiguous 12 KB runs: the staging loads are fully coalesced 16-byte
+// pieces (the row-major [M][3D] layout hands every workgroup 48-byte slivers of 576-byte rows -- 2.7x the algorithmic traffic in
+// rocprof).  K is staged row-major with a 96-byte pitch (conflict-free ds_read_b128, dims 24..31 zeroed); V is staged ROW-major as
+// well (96-byte pitch, feature 24 = 1.0 so that row 24 of O^T is the softmax denominator) and read as the transposed MFMA operand
+// with ds_read_b64_tr_b16 -- no transposing scatter of 4-byte pairs into LDS.  Same two-pass softmax as k_attention_win.
+typedef __attribute__((__vector_size__(4 * sizeof(__fp16)))) __fp16 fp16x4_t;
+CFEN_DEV half4 lds_read_tr4(const unsigned char* p) {
+  const fp16x4_t v = __builtin_amdgcn_ds_read_tr16_b64_v4f16((__attribute__((address_space(3))) fp16x4_t*)p);
+  half4 o;
+  __builtin_memcpy(&o, &v, 8);
+  return o;
+}
+
+template <int NKT>
+__global__ __launch_bounds__(256) void k_attention_hm(PtrG<const half_t> QKVg, PtrG<half_t> Og, int D, int heads, float scale_log2, int nblk) {
+  constexpr int S = NKT * 16, DH = 24, KP = 96, VP = 96;
+  __shared__ __attribute__((aligned(16))) unsigned char Kl[S * KP];
+  __shared__ __attribute__((aligned(16))) unsigned char Vl[S * VP];
+  const half_t* __restrict__ QKV = QKVg.p[blockIdx.z];
+  half_t* __restrict__ O = Og.p[blockIdx.z];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r16 = lane & 15, h = lane >> 4;
+  const int blk = (int)xcd_chunked_block(blockIdx.x, gridDim.x);
+  if (blk >= nblk) return;
+  const int head = blk % heads, seq = blk / heads;
+  const half_t* Qp = QKV + (size_t)blk * 3 * S * DH;
+  const half_t* Kp = Qp + S * DH;
+  const half_t* Vp = Kp + S * DH;
+
+  for (int idx = tid; idx < S * 4; idx += 256) {
+    const int row = idx >> 2, c = idx & 3;
+    half8 kv = Mma<half_t>::zero(), vv = Mma<half_t>::zero();
+    vv[0] = (half_t)1.0f;                                      // piece 3 of a V row: feature 24 = 1 (denominator row), 25..31 = 0
+    if (c < 3) {
+      kv = load_frag<half_t>(Kp + row * DH + c * 8);
+      vv = load_frag<half_t>(Vp + row * DH + c * 8);
+    }
+    *reinterpret_cast<half8*>(Kl + row * KP + c * 16) = kv;
+    *reinterpret_cast<half8*>(Vl + row * VP + c * 16) = vv;
+  }
+  __syncthreads();
+
+  const float c = scale_log2;
+  const int li = lane & 15;
+  const unsigned char* vbase = Vl + (4 * h + (li >> 2)) * VP + (li & 3) * 8;   // tr-read: lane 4q+p of a 16-lane group -> row q, columns 4p..4p+3
+#pragma unroll 1
+  for (int qt = wave; qt < NKT; qt += 4) {
+    const int q0 = qt * 16;
+    const half8 qf = h < 3 ? load_frag<half_t>(Qp + (q0 + r16) * DH + h * 8) : Mma<half_t>::zero();
+    floatx4 st[NKT];
+#pragma unroll
+    for (int t = 0; t < NKT; ++t)
+      st[t] = Mma<half_t>::mma(*reinterpret_cast<const half8*>(Kl + (t * 16 + r16) * KP + h * 16), qf, floatx4{0.f, 0.f, 0.f, 0.f});
+    float mx = -1e30f;
+#pragma unroll
+    for (int t = 0; t < NKT; ++t) mx = fmaxf(fmaxf(mx, fmaxf(st[t][0], st[t][1])), fmaxf(st[t][2], st[t][3]));
+    mx = col_max(mx);
+    const float mc = -mx * c;
+#pragma unroll
+    for (int t = 0; t < NKT; ++t)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) st[t][r] = __builtin_amdgcn_exp2f(fmaf(st[t][r], c, mc));
+    floatx4 o[2] = {floatx4{0.f, 0.f, 0.f, 0.f}, floatx4{0.f, 0.f, 0.f, 0.f}};
+#pragma unroll
+    for (int kb = 0; kb < NKT / 2; ++kb) {
+      const half8 b = {(half_t)st[2 * kb][0], (half_t)st[2 * kb][1], (half_t)st[2 * kb][2], (half_t)st[2 * kb][3],
+                       (half_t)st[2 * kb + 1][0], (half_t)st[2 * kb + 1][1], (half_t)st[2 * kb + 1][2], (half_t)st[2 * kb + 1][3]};
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const half4 lo = lds_read_tr4(vbase + (kb * 32) * VP + i * 32);        // keys kb*32 + 4h .. +3, feature i*16 + (lane & 15)
+        const half4 hi = lds_read_tr4(vbase + (kb * 32 + 16) * VP + i * 32);   // keys kb*32 + 16 + 4h .. +3
+        const half8 a = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+        o[i] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, o[i], 0, 0, 0);
+      }
+    }
+    const float l = col_sum(h == 2 ? o[1][0] : 0.f);   // row 24 of O^T (tile 1, lane group 2, register 0) = sum of the probabilities
+    const float inv = 1.f / l;
+    half_t* op = O + ((size_t)seq * S + q0 + r16) * D + head * DH + 4 * h;
+    store4<half_t>(op, o[0] * inv);
+    if (h < 2) store4<half_t>(op + 16, o[1] * inv);
+  }
+}
+
 template <typename T, int NDT, int NKT>
 int launch_attn_win(int ng, const void* const* qkv, void* const* out, int nseq, int heads, int dh, size_t smem, hipStream_t s) {
   const float scale_log2 = 1.4426950408889634f / sqrtf((float)dh);
@@ -443,6 +527,27 @@ int cfen_attention_impl_g(int dtype, int ng, const void* const* qkv, void* const
   cfen_set_error("attention: unknown dtype %d", dtype);
   return CFEN_ERR_ARG;
 }
+bool cfen_attention_hm_supported(int dtype, int S, int dh) { return dtype == 1 && dh == 24 && (S == 256 || S == 64); }
+
+int cfen_attention_hm_impl_g(int dtype, int ng, const void* const* qkv, void* const* out, int nseq, int S, int heads, int dh, hipStream_t s) {
+  CFEN_CHECK_ARG(cfen_attention_hm_supported(dtype, S, dh), "attention (head-major): fp16, head_dim 24, S in {64, 256} only");
+  CFEN_CHECK_ARG(ng >= 1 && ng <= CFEN_MAX_GROUPS && nseq > 0 && heads > 0 && (long long)nseq * heads < (1ll << 31), "attention (head-major): bad problem");
+  PtrG<const half_t> qg{};
+  PtrG<half_t> og{};
+  for (int g = 0; g < ng; ++g) {
+    CFEN_CHECK_ARG(qkv[g] && out[g] && cfen_aligned16(qkv[g]) && cfen_aligned16(out[g]), "attention (head-major): pointers must be non-null and 16-byte aligned");
+    qg.p[g] = (const half_t*)qkv[g]; og.p[g] = (half_t*)out[g];
+  }
+  const float scale_log2 = 1.4426950408889634f / sqrtf((float)dh);
+  const dim3 grid(cfen_grid8((long long)nseq * heads), 1, ng);
+  if (S == 256)
+    CFEN_LAUNCH((k_attention_hm<16>), grid, dim3(256), 0, s, qg, og, heads * dh, heads, scale_log2, nseq * heads);
+  else
+    CFEN_LAUNCH((k_attention_hm<4>), grid, dim3(256), 0, s, qg, og, heads * dh, heads, scale_log2, nseq * heads);
+  CFEN_CHECK_LAUNCH("attention (head-major)");
+  return CFEN_OK;
+}
+
 int cfen_attention_impl(int dtype, const void* qkv, void* out, int nseq, int S, int heads, int dh, hipStream_t s) {
   return cfen_attention_impl_g(dtype, 1, &qkv, &out, nseq, S, heads, dh, s);
 }

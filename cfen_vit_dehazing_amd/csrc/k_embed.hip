@@ -26,6 +26,14 @@ template <> struct PackB<float> {
   static CFEN_DEV floatx4 make(const floatx4* t) { return t[0]; }
 };
 
+
+// element offset of feature f (a multiple of 4) of a qkv row inside its (window, head) triple for the head-major layout:
+// [(window * heads + head) * 3 + part][S][dh], part = f / D; relative to the window's first element, without the token term
+CFEN_DEV long long hm_feature_off(int f, int D, int heads, int S) {
+  const int dh = D / heads, part = f / D, fd = f - part * D, hd = fd / dh, d = fd - hd * dh;
+  return (long long)((hd * 3 + part) * S) * dh + d;
+}
+
 template <typename T, int ND, int TM, int NW>
 __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_embed_qkv(Grouped<CfenEmbedQkvArgs> ga) {
   const CfenEmbedQkvArgs& a = ga.g[blockIdx.z];
@@ -125,6 +133,11 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(2, 2)))
     }
   }
 
+  // element offset of each token's qkv row: row-major [M][3D], or the token term of the head-major layout
+  long long qrow[TM];
+#pragma unroll
+  for (int j = 0; j < TM; ++j)
+    qrow[j] = a.hm_heads ? (tk[j] / S) * (3LL * S * D) + (tk[j] % S) * (D / a.hm_heads) : tk[j] * (3LL * D);
   // ---- qkv = W_qkv LN(y): 3D output features, one 16-feature tile at a time, straight to HBM ----
   const T* Wq = (const T*)a.Wqkv + (size_t)r16 * D + h * EPL;
 #pragma unroll 2
@@ -138,9 +151,10 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(2, 2)))
 #pragma unroll
       for (int j = 0; j < TM; ++j) q[j] = Mma<T>::mma(af, xb[c][j], q[j]);
     }
+    const long long fo = a.hm_heads ? hm_feature_off(i * 16 + 4 * h, D, a.hm_heads, S) : i * 16 + 4 * h;
 #pragma unroll
     for (int j = 0; j < TM; ++j)
-      if (tok0 + j * 16 + r16 < a.M) store4<T>((T*)a.QKV + tk[j] * (3 * D) + i * 16 + 4 * h, q[j]);
+      if (tok0 + j * 16 + r16 < a.M) store4<T>((T*)a.QKV + qrow[j] + fo, q[j]);
   }
 }
 
@@ -277,6 +291,11 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
       xb[c][j] = PackB<T>::make(t);
     }
   }
+  // element offset of each token's qkv row: row-major [M][3D], or the token term of the head-major layout
+  long long qrow[TM];
+#pragma unroll
+  for (int j = 0; j < TM; ++j)
+    qrow[j] = a.hm_heads ? (tk[j] / S) * (3LL * S * D) + (tk[j] % S) * (D / a.hm_heads) : tk[j] * (3LL * D);
   // ---- qkv stages: every tile goes straight to HBM ----
 #pragma unroll 1
   for (int sq = 0; sq < NQS; ++sq) {
@@ -293,9 +312,12 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 #pragma unroll
         for (int j = 0; j < TM; ++j) q[j] = Mma<T>::mma(af, xb[c][j], q[j]);
       }
+      {
+        const long long fo = a.hm_heads ? hm_feature_off((sq * NG + u) * 16 + 4 * h, D, a.hm_heads, S) : (sq * NG + u) * 16 + 4 * h;
 #pragma unroll
-      for (int j = 0; j < TM; ++j)
-        if (tok0 + j * 16 + r16 < a.M) store4<T>((T*)a.QKV + tk[j] * (3 * D) + (sq * NG + u) * 16 + 4 * h, q[j]);
+        for (int j = 0; j < TM; ++j)
+          if (tok0 + j * 16 + r16 < a.M) store4<T>((T*)a.QKV + qrow[j] + fo, q[j]);
+      }
     }
     if (sq + 1 < NQS) commit(lds + ((st + 1) & 1) * STAGE);
     __syncthreads();
@@ -338,7 +360,8 @@ int run_embed_qkv(int ng, const CfenEmbedQkvArgs* ap, hipStream_t s) {
                    a.W % a.ws == 0 && a.B > 0, "embed_qkv: bad token geometry");
     const int tw = a.ws / a.p;
     CFEN_CHECK_ARG(a.D == a.p * a.p * a.C && a.M == (long long)a.B * (a.H / a.ws) * (a.W / a.ws) * tw * tw, "embed_qkv: D / M do not match the map");
-    CFEN_CHECK_ARG(a.D == ap[0].D && a.M == ap[0].M, "embed_qkv: grouped problems must have the same shape");
+    CFEN_CHECK_ARG(a.D == ap[0].D && a.M == ap[0].M && a.hm_heads == ap[0].hm_heads, "embed_qkv: grouped problems must have the same shape");
+    CFEN_CHECK_ARG(a.hm_heads >= 0 && (a.hm_heads == 0 || (a.D % a.hm_heads == 0 && (a.D / a.hm_heads) % 4 == 0)), "embed_qkv: bad head count %d", a.hm_heads);
   }
   const int lds = cfen_tune_embed_lds();   // bit 0: D = 96, bit 1: D = 192 use the LDS-staged variant
   if constexpr (sizeof(T) == 2) {   // the fp32 stages would not fit 64 KB of LDS

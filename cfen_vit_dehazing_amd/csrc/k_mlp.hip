@@ -15,6 +15,7 @@
 //     chunk's global loads in flight during the MFMAs (register prefetch, two barriers per chunk).
 // HBM traffic per instance: read x once, write y2 once (+ weights from L2).
 #include <stdlib.h>
+#include <type_traits>
 #include "cfen_common.hpp"
 #include "cfen_mlp.hpp"
 #include "cfen_internal.hpp"
@@ -263,6 +264,309 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(WPE, WP
   }
 }
 
+
+// ------------------------------------------------------------------------------------------------------------------------------
+// k_mlp2 (fp16): the same chain, rebuilt around what k_mlp's disassembly showed to cost most of its time --
+//   * every hidden chunk started with a dependent GLOBAL load of its bias slice in front of the first MFMA;
+//   * the compiler issued each weight-fragment ds_read just before the MFMA pair that uses it (one exposed LDS latency per 2 MFMAs);
+//   * the weight slices went global -> registers -> ds_write_b128 (13 LDS-path cycles per wave-instruction, 12+ VGPRs).
+// Here a chunk of the hidden dimension (W1 slice, W2 slice and the bias slice) lands in LDS by LDS-DMA (global_load_lds_dwordx4:
+// no VGPRs, no ds_write), two stages, one raw s_barrier per chunk with the next chunk's DMA in flight across it; the MFMAs run in
+// groups of 3 weight fragments x TM token tiles with the NEXT group's fragments (and bias vector) already loading into a second
+// register set (software pipeline pinned with sched_barrier), rows padded by 32 bytes (pitch = 32 mod 64: conflict-free
+// ds_read_b128, the pad pieces are dead DMA lanes); ReLU runs packed on the fp16 pair (v_pk_max_f16) after the conversion.
+template <int I, int N, class F>
+CFEN_DEV void static_for(F&& f) {
+  if constexpr (I < N) {
+    f(std::integral_constant<int, I>{});
+    static_for<I + 1, N>(f);
+  }
+}
+
+CFEN_DEV void mlp_dma16(const void* g, unsigned char* l) {
+  __builtin_amdgcn_global_load_lds(g, (__attribute__((address_space(3))) void*)l, 16, 0, 0);
+}
+
+template <int ND, int TM, int NW, int HCH>
+__global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_mlp2(Grouped<MlpArgs> ga) {
+  typedef half_t T;
+  const MlpArgs& a = ga.g[blockIdx.z];
+  constexpr int KC = 32, EPL = 8;
+  constexpr int NT = NW * 64;
+  constexpr int D = ND * 16;
+  constexpr int NCH = ND / 2;                     // 32-deep K chunks over D
+  constexpr int NSUB = HCH / KC;                  // 32-unit hidden sub-steps per staged chunk
+  constexpr int P1 = D * 2 + 32, P2 = HCH * 2 + 32;   // LDS row pitches (bytes), = 32 (mod 64)
+  constexpr int PP1 = P1 / 16, PP2 = P2 / 16;     // 16-byte pieces per LDS row (the last two of each row are padding)
+  constexpr int N1 = HCH * PP1 / 64, N2 = D * PP2 / 64;   // DMA wave-instructions (64 pieces = 1 KiB) per region
+  static_assert(HCH * PP1 % 64 == 0 && D * PP2 % 64 == 0 && HCH * 4 <= 1024, "regions must be whole DMA instructions");
+  constexpr int NINS = N1 + N2 + 1;               // + 1 for the bias slice
+  constexpr int STAGE = NINS * 1024;
+  constexpr int NI = (NINS + NW - 1) / NW;        // DMA instructions per wave per chunk
+  constexpr int R2 = N1 * 1024, R3 = (N1 + N2) * 1024;
+  static_assert(2 * STAGE <= 65536, "static LDS");
+  static_assert(NCH % 3 == 0 && ND % 3 == 0, "fragment groups of 3");
+  typedef half8 frag;
+  __shared__ __attribute__((aligned(1024))) unsigned char lds[2 * STAGE];
+
+  const int tid = threadIdx.x, lane = tid & 63, r16 = lane & 15, h = lane >> 4;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const long long tok0 = ((long long)blockIdx.x * NW + wave) * (TM * 16);
+  const int nhc = a.H / HCH;
+
+  // ---- DMA plan: instruction i of this wave fills LDS block blk = i * NW + wave of the stage; this lane's piece of it ----
+  // region of a block (wave-uniform): 0 = W1 slice, 1 = W2 slice, 2 = bias slice; off[i] = byte offset of the lane's source piece
+  // inside the region's matrix for chunk 0 (pad pieces re-read a real piece: they are never read back from LDS)
+  unsigned off[NI];
+#pragma unroll
+  for (int i = 0; i < NI; ++i) {
+    const int blk = i * NW + wave;
+    const int pc = lane;                            // piece inside the block
+    if (blk < N1) {
+      const int id = blk * 64 + pc, row = id / PP1, col = min(id % PP1, PP1 - 3);
+      off[i] = (unsigned)(row * D * 2 + col * 16);                       // W1[hc*HCH + row][col*8 ..]
+    } else if (blk < N1 + N2) {
+      const int id = (blk - N1) * 64 + pc, row = id / PP2, col = min(id % PP2, PP2 - 3);
+      off[i] = (unsigned)row * (unsigned)(a.H * 2) + (unsigned)(col * 16);   // W2[row][hc*HCH + col*8 ..]
+    } else {
+      off[i] = (unsigned)(min(pc, HCH * 4 / 16 - 1) * 16);               // b1[hc*HCH + 4*pc ..]
+    }
+  }
+  auto issue = [&](int t, int buf) {   // chunk t of the flattened (stage a, stage b) sequence -> LDS stage `buf`
+    const bool sb = t >= nhc;
+    const int hc = sb ? t - nhc : t;
+    const unsigned char* W1 = (const unsigned char*)(sb ? a.W1b : a.W1a) + (size_t)hc * HCH * D * 2;
+    const unsigned char* W2 = (const unsigned char*)(sb ? a.W2b : a.W2a) + (size_t)hc * HCH * 2;
+    const unsigned char* B1 = (const unsigned char*)(sb ? a.b1b : a.b1a) + (size_t)hc * HCH * 4;
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+      const int blk = i * NW + wave;
+      if (blk < NINS) {
+        const unsigned char* base = blk < N1 ? W1 : blk < N1 + N2 ? W2 : B1;
+        mlp_dma16(base + off[i], lds + buf * STAGE + blk * 1024);
+      }
+    }
+  };
+  const int nchunks = a.W1b ? 2 * nhc : nhc;
+  issue(0, 0);
+
+  // ---- load x^T into accumulator layout: acc[i][j][r] = x[token j*16+r16][feature i*16+4h+r] ----
+  floatx4 acc[ND][TM];
+  const T* X = (const T*)a.X;
+#pragma unroll
+  for (int j = 0; j < TM; ++j) {
+    long long t = tok0 + j * 16 + r16;
+    if (t >= a.M) t = a.M - 1;
+    const T* xp = X + t * D + 4 * h;
+#pragma unroll
+    for (int i = 0; i < ND; ++i) acc[i][j] = load4<T>(xp + i * 16);
+  }
+  if (a.Wp) {   // x += Wp att: out_proj + residual of the attention block, operands straight from L1/L2 (natural k order)
+    const T* Wp = (const T*)a.Wp + (size_t)r16 * D + h * EPL;
+    constexpr int NKC = D / KC;
+    const T* ap[TM];
+#pragma unroll
+    for (int j = 0; j < TM; ++j) {
+      long long t = tok0 + j * 16 + r16;
+      if (t >= a.M) t = a.M - 1;
+      ap[j] = (const T*)a.A + t * D + h * EPL;
+    }
+#pragma unroll
+    for (int c = 0; c < NKC; ++c) {
+      frag ab[TM];
+#pragma unroll
+      for (int j = 0; j < TM; ++j) ab[j] = load_frag<T>(ap[j] + c * KC);
+#pragma unroll
+      for (int i = 0; i < ND; ++i) {
+        const frag af = load_frag<T>(Wp + (size_t)i * 16 * D + c * KC);
+#pragma unroll
+        for (int j = 0; j < TM; ++j) acc[i][j] = Mma<T>::mma(af, ab[j], acc[i][j]);
+      }
+    }
+  }
+
+  frag xb[NCH][TM];
+  // stage-a input: LayerNorm(x) (or x) as B fragments; residual + output bias go into the accumulators
+  if (a.ln_g) {
+#pragma unroll
+    for (int j = 0; j < TM; ++j) {
+      float sm = 0.f;
+#pragma unroll
+      for (int i = 0; i < ND; ++i) sm += acc[i][j][0] + acc[i][j][1] + acc[i][j][2] + acc[i][j][3];
+      sm = col_sum(sm);
+      const float mean = sm * (1.f / D);
+      float q = 0.f;
+#pragma unroll
+      for (int i = 0; i < ND; ++i)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float d = acc[i][j][r] - mean;
+          q += d * d;
+        }
+      q = col_sum(q);
+      const float rstd = rsqrtf(q * (1.f / D) + a.eps);
+#pragma unroll
+      for (int c = 0; c < NCH; ++c) {
+        floatx4 t[2];
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+          const int i = c * 2 + u;
+          const floatx4 g = *reinterpret_cast<const floatx4*>(a.ln_g + i * 16 + 4 * h);
+          const floatx4 b = *reinterpret_cast<const floatx4*>(a.ln_b + i * 16 + 4 * h);
+          t[u] = (acc[i][j] - mean) * rstd * g + b;
+        }
+        xb[c][j] = Pack<T>::make(t);
+      }
+    }
+  } else {
+#pragma unroll
+    for (int j = 0; j < TM; ++j)
+#pragma unroll
+      for (int c = 0; c < NCH; ++c) {
+        floatx4 t[2] = {acc[c * 2][j], acc[c * 2 + 1][j]};
+        xb[c][j] = Pack<T>::make(t);
+      }
+  }
+#pragma unroll
+  for (int i = 0; i < ND; ++i) {
+    const floatx4 bb = *reinterpret_cast<const floatx4*>(a.b2a + i * 16 + 4 * h);
+#pragma unroll
+    for (int j = 0; j < TM; ++j) acc[i][j] += bb;
+  }
+
+  // fragment groups of one 32-unit sub-step: 2 * NCH/3 FFN1 groups (u, chunk triple), then ND/3 FFN2 groups (feature-tile triple)
+  constexpr int G1 = 2 * (NCH / 3), G2 = ND / 3, GS = G1 + G2, NG = NSUB * GS;
+  const int a1 = r16 * P1 + h * 16;            // lane part of a W1 fragment address
+  const int a2 = R2 + r16 * P2 + h * 16;       // ... of a W2 fragment address
+  const int a3 = R3 + 16 * h;                  // ... of a bias vector address
+
+  auto chunk = [&](int t) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // chunk t has landed (this wave's share)
+    __builtin_amdgcn_s_barrier();                      // ... everyone's share; and every wave is done reading the other stage
+    if (t + 1 < nchunks) issue(t + 1, (t + 1) & 1);
+    const unsigned char* buf = lds + (t & 1) * STAGE;
+
+    frag F[2][3];
+    floatx4 bia[2];
+    floatx4 hacc[2][TM];
+    frag hb[TM];
+    auto load_group = [&](auto gc, frag (&f)[3], floatx4& bv) {
+      constexpr int g = decltype(gc)::value, sub = g / GS, gi = g % GS;
+      if constexpr (gi < G1) {
+        constexpr int u = gi / (NCH / 3), cg = gi % (NCH / 3);
+#pragma unroll
+        for (int k = 0; k < 3; ++k) f[k] = *reinterpret_cast<const frag*>(buf + a1 + (sub * KC + u * 16) * P1 + (cg * 3 + k) * 64);
+        if constexpr (cg == 0) bv = *reinterpret_cast<const floatx4*>(buf + a3 + (sub * KC + u * 16) * 4);
+      } else {
+        constexpr int ig = gi - G1;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) f[k] = *reinterpret_cast<const frag*>(buf + a2 + ((ig * 3 + k) * 16) * P2 + sub * 64);
+      }
+    };
+    auto run_group = [&](auto gc, const frag (&f)[3], const floatx4& bv) {
+      constexpr int g = decltype(gc)::value, gi = g % GS;
+      if constexpr (gi < G1) {
+        constexpr int u = gi / (NCH / 3), cg = gi % (NCH / 3);
+        if constexpr (cg == 0) {
+#pragma unroll
+          for (int j = 0; j < TM; ++j) hacc[u][j] = bv;
+        }
+#pragma unroll
+        for (int k = 0; k < 3; ++k)
+#pragma unroll
+          for (int j = 0; j < TM; ++j) hacc[u][j] = Mma<T>::mma(f[k], xb[cg * 3 + k][j], hacc[u][j]);
+      } else {
+        constexpr int ig = gi - G1;
+        if constexpr (ig == 0) {   // relu(hidden) -> B fragments: convert, then a packed max on the fp16 pairs
+#pragma unroll
+          for (int j = 0; j < TM; ++j) {
+            floatx4 tt[2] = {hacc[0][j], hacc[1][j]};
+            const half8 v = Pack<T>::make(tt);
+            half8 z;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) z[e] = (half_t)0;
+            hb[j] = __builtin_elementwise_max(v, z);
+          }
+        }
+#pragma unroll
+        for (int k = 0; k < 3; ++k)
+#pragma unroll
+          for (int j = 0; j < TM; ++j) acc[ig * 3 + k][j] = Mma<T>::mma(f[k], hb[j], acc[ig * 3 + k][j]);
+      }
+    };
+    load_group(std::integral_constant<int, 0>{}, F[0], bia[0]);
+    static_for<0, NG>([&](auto gc) {
+      constexpr int g = decltype(gc)::value;
+      if constexpr (g + 1 < NG) load_group(std::integral_constant<int, g + 1>{}, F[(g + 1) & 1], bia[(g + 1) & 1]);
+      __builtin_amdgcn_sched_barrier(0);
+      run_group(gc, F[g & 1], bia[g & 1]);
+      __builtin_amdgcn_sched_barrier(0);
+    });
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // this wave's reads of the stage are complete before it reaches the next barrier
+  };
+#pragma unroll 1
+  for (int t = 0; t < nhc; ++t) chunk(t);
+  if (a.W1b) {   // stage b: its input is the stage-a result, which becomes the new residual
+#pragma unroll
+    for (int j = 0; j < TM; ++j)
+#pragma unroll
+      for (int c = 0; c < NCH; ++c) {
+        floatx4 tt[2] = {acc[c * 2][j], acc[c * 2 + 1][j]};
+        xb[c][j] = Pack<T>::make(tt);
+      }
+#pragma unroll
+    for (int i = 0; i < ND; ++i) {
+      const floatx4 bb = *reinterpret_cast<const floatx4*>(a.b2b + i * 16 + 4 * h);
+#pragma unroll
+      for (int j = 0; j < TM; ++j) acc[i][j] += bb;
+    }
+#pragma unroll 1
+    for (int t = nhc; t < 2 * nhc; ++t) chunk(t);
+  }
+
+  // ---- epilogue: token-major store, or fold + window join into the NHWC map ----
+#pragma unroll
+  for (int j = 0; j < TM; ++j) {
+    const long long t = tok0 + j * 16 + r16;
+    if (t >= a.M) continue;
+    if (!a.fmap) {
+      T* yp = (T*)a.Y + t * D + 4 * h;
+#pragma unroll
+      for (int i = 0; i < ND; ++i) store4<T>(yp + i * 16, acc[i][j]);
+    } else {
+      const int tw = a.ws / a.p, S = tw * tw;
+      const int nwx = a.mapW / a.ws, nwy = a.mapH / a.ws;
+      const int tt = (int)(t % S);
+      const long long wi = t / S;
+      const int wx = (int)(wi % nwx), wy = (int)((wi / nwx) % nwy);
+      const long long b = wi / ((long long)nwx * nwy);
+      const int y0 = wy * a.ws + (tt / tw) * a.p, x0 = wx * a.ws + (tt % tw) * a.p;
+#pragma unroll
+      for (int i = 0; i < ND; ++i) {
+        const int f = i * 16 + 4 * h;
+        const int ij = f / a.C, c = f - ij * a.C;
+        const int pi = ij / a.p, pj = ij - pi * a.p;
+        T* dst = (T*)a.fmap + ((b * a.mapH + y0 + pi) * a.mapW + x0 + pj) * a.cs + c;
+        store4<T>(dst, acc[i][j]);
+      }
+    }
+  }
+}
+
+template <int ND, int TM, int NW, int HCH>
+int launch_mlp2_t(int ng, const MlpArgs* ap, hipStream_t s) {
+  const MlpArgs& a = ap[0];
+  Grouped<MlpArgs> ga;
+  for (int g = 0; g < CFEN_MAX_GROUPS; ++g) ga.g[g] = ap[g < ng ? g : 0];
+  CFEN_CHECK_ARG(a.H % HCH == 0, "mlp: hidden dim %d must be a multiple of %d", a.H, HCH);
+  const long long per = (long long)NW * TM * 16;
+  const long long blocks = (a.M + per - 1) / per;
+  CFEN_CHECK_ARG(blocks > 0 && blocks < (1ll << 31), "mlp: bad grid");
+  CFEN_LAUNCH((k_mlp2<ND, TM, NW, HCH>), dim3((unsigned)blocks, 1, ng), dim3(NW * 64), 0, s, ga);
+  CFEN_CHECK_LAUNCH("mlp");
+  return CFEN_OK;
+}
+
 template <typename T, int ND, int TM, int NW, int HCH, int WPE>
 int launch_mlp_t(int ng, const MlpArgs* ap, hipStream_t s) {
   const MlpArgs& a = ap[0];
@@ -320,6 +624,18 @@ int launch_mlp(int ng, const MlpArgs* ap, hipStream_t s) {
                    "mlp: grouped problems must have the same shape");
   }
   const int small = cfen_tune_mlp_small_tiles();
+  if constexpr (sizeof(T) == 2) {
+    // small >= 10: the LDS-DMA / software-pipelined kernel (k_mlp2).  Tens digit = D 96 variant, ones digit = D 192 variant:
+    //   D = 96 : 1x 256 tokens / 4-wave WG (TM 4; default), 2x 512 tokens / 8-wave WG (TM 4), 3x 256 tokens / 8-wave WG (TM 2), 4x as 3x with 32-unit stages
+    //   D = 192: x0 128 tokens / 4-wave WG (TM 2; default), x1 256 tokens / 8-wave WG (TM 2)
+    // (MI355X, batch 8, cold caches, tools/bench_mlp_variants.py: 4-wave workgroups win -- two of them share a CU and their barriers interleave)
+    if (small >= 10) {
+      const int v96 = small / 10, v192 = small % 10;
+      if (ap[0].D == 96) return v96 == 2 ? launch_mlp2_t<6, 4, 8, 64>(ng, ap, s) : v96 == 3 ? launch_mlp2_t<6, 2, 8, 64>(ng, ap, s)
+                              : v96 == 4 ? launch_mlp2_t<6, 2, 8, 32>(ng, ap, s) : launch_mlp2_t<6, 4, 4, 64>(ng, ap, s);
+      return v192 == 1 ? launch_mlp2_t<12, 2, 8, 32>(ng, ap, s) : launch_mlp2_t<12, 2, 4, 32>(ng, ap, s);
+    }
+  }
   switch (ap[0].D) {
     case 96: return small >= 3 ? launch_mlp_t<T, 6, 2, 8, 2 * KC, 2>(ng, ap, s)   // 256 tokens / WG in 8 waves: half the weight re-streaming
                   : small ? launch_mlp_t<T, 6, 2, 4, 2 * KC, 2>(ng, ap, s)     // 128 tokens / WG, 2 waves per SIMD
@@ -337,7 +653,7 @@ int launch_mlp(int ng, const MlpArgs* ap, hipStream_t s) {
 // D = 384 (LViT level 3, 8192 tokens per batch of 8) does not fill the chip with 128-token workgroups and its
 // 4.7 MB of weights per instance exceed what one CU can stream per token tile: the tiled GEMM path is faster there.
 int& cfen_tune_mlp_small_tiles() {
-  static int v = 3;
+  static int v = 10;
   return v;
 }
 

@@ -54,6 +54,16 @@ def attention(qkv, nseq, S, heads):
     return out
 
 
+def attention_head_major(qkv, nseq, S, heads):
+    """qkv in the head-major layout of embed_qkv(head_major_heads=heads) -> [nseq*S, D] row-major"""
+    _cuda(qkv)
+    D = qkv.numel() // (3 * nseq * S)
+    out = torch.empty(nseq * S, D, dtype=qkv.dtype, device=qkv.device)
+    check(_lib.load().cfen_attention_head_major(dtype_code(qkv.dtype), ptr(qkv), ptr(out), nseq, S, heads, D // heads, current_stream()),
+          "attention_head_major")
+    return out
+
+
 def mlp_block(x, w1a, b1a, w2a, b2a, ln=None, second=None, fold=None, proj=None):
     """Fused y1 = x + W2a relu(W1a LN(x)+b1a) + b2a [; y2 = y1 + W2b relu(W1b y1 + b1b) + b2b].
     Weights must already carry packing.kperm32 on their k axis for fp16.  fold = (B, H, W, C, cs, ws, p) writes
@@ -103,7 +113,7 @@ def embed_gather(fmap, C, ws, p, w, bias, pos):
     return out
 
 
-def embed_qkv(fmap, C, ws, p, we, be, pos, ln_g, ln_b, wqkv, eps=1e-5):
+def embed_qkv(fmap, C, ws, p, we, be, pos, ln_g, ln_b, wqkv, eps=1e-5, head_major_heads=0):
     """fused LViT front half (D = p*p*C in {96,192}); we / wqkv with the k axis in packing.kperm32 order for fp16.
     Returns (x1 [M,D], qkv [M,3D])."""
     from ._lib import EmbedQkvArgsC
@@ -114,7 +124,8 @@ def embed_qkv(fmap, C, ws, p, we, be, pos, ln_g, ln_b, wqkv, eps=1e-5):
     x1 = torch.empty(M, D, dtype=fmap.dtype, device=fmap.device)
     qkv = torch.empty(M, 3 * D, dtype=fmap.dtype, device=fmap.device)
     a = EmbedQkvArgsC(fmap=fmap.data_ptr(), B=B, H=H, W=W, C=C, cs=cs, ws=ws, p=p, we=we.data_ptr(), be=be.data_ptr(), pos=pos.data_ptr(),
-                      ln_gamma=ln_g.data_ptr(), ln_beta=ln_b.data_ptr(), wqkv=wqkv.data_ptr(), x1=x1.data_ptr(), qkv=qkv.data_ptr(), eps=eps)
+                      ln_gamma=ln_g.data_ptr(), ln_beta=ln_b.data_ptr(), wqkv=wqkv.data_ptr(), x1=x1.data_ptr(), qkv=qkv.data_ptr(), eps=eps,
+                      head_major_heads=head_major_heads)
     check(_lib.load().cfen_embed_qkv(dtype_code(fmap.dtype), ctypes.byref(a), current_stream()), "embed_qkv")
     return x1, qkv
 

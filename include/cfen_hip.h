@@ -39,8 +39,10 @@ const char* cfen_last_error(void);
  *                  96 x 128 / 96 / 64 / 32 (features x tokens) tile (1..5 need K * element size to be a multiple of 128 bytes)
  *   "embed.lds": k_embed_qkv stages its weights through LDS for D = 96 (bit 0) / D = 192 (bit 1); default 2
  *   "gemm.splitk": 1 (default) K-heavy few-token GEMMs inside the net run split-K (scratch from the workspace), 0 never
- *   "mlp.small_tiles": fused-MLP tiling 0..3 (default 3);  "net.fused_front_max_dim": largest LViT embedding dim that uses k_embed_qkv
+ *   "mlp.small_tiles": fused-MLP kernel variant: 0..4 the register-staged k_mlp tilings, >= 10 (default 10) the LDS-DMA k_mlp2 (tens digit:
+ *                  D = 96 variant, ones digit: D = 192 variant, see k_mlp.hip);  "net.fused_front_max_dim": largest LViT embedding dim that uses k_embed_qkv
  *   "net.skip_classes": bit mask of kernel classes the net does NOT launch (what-if timing only, outputs invalid)
+ *   "net.attn_head_major": 1 (default) LViT levels with a fused front half pass qkv to attention per (window, head); 0 row-major [M][3D]
  *   "net.embed_gather": 1 (default) the LViT embedding GEMM gathers its patch tokens from the map, 0 separate patchify launch
  *                  (read when a forward is enqueued or a graph is built)
  *   "gemm.large" / "gemm.small": the k_gemm_dma tile (2..5) the shape rule uses for problems with >= / < 1024 tiles of 96 x 64 */
@@ -128,12 +130,18 @@ typedef struct cfen_embed_qkv_args {
   const void* wqkv;
   void* x1; void* qkv;
   float eps;
+  int32_t head_major_heads;   /* 0: qkv is [M][3D] row-major; > 0 (= number of heads): qkv is written per (window, head),
+                                 [(window * heads + head) * 3 + {q, k, v}][S][D / heads] -- the input of cfen_attention_head_major */
 } cfen_embed_qkv_args;
 int cfen_embed_qkv(int dtype, const cfen_embed_qkv_args* a, void* stream);
 /* LayerNorm over the last dim (eps as given), gamma/beta fp32                       (v3:1370-1371) */
 int cfen_layernorm(int dtype, const void* X, void* Y, const float* gamma, const float* beta, int M, int D, float eps, void* stream);
 /* softmax(QK^T/sqrt(dh))V per (sequence, head); QKV is [nseq*S][3*heads*dh], out [nseq*S][heads*dh]  (v3:1364) */
 int cfen_attention(int dtype, const void* qkv, void* out, int nseq, int S, int heads, int dh, void* stream);
+/* the same attention reading the head-major qkv layout of cfen_embed_qkv (head_major_heads = heads): the q, k and v of one
+ * (sequence, head) are contiguous [S][dh] blocks.  CFEN_F16, dh = 24, S in {64, 256} (every LViT window of the 512x512 configs);
+ * out stays [nseq*S][heads*dh] row-major.                                                                       (v3:1364) */
+int cfen_attention_head_major(int dtype, const void* qkv, void* out, int nseq, int S, int heads, int dh, void* stream);
 /* Fused token MLP block (D in {96,192}; H a multiple of 64 (fp16) / 32 (fp32)):
  *   y1 = x + W2a relu(W1a LN(x) + b1a) + b2a  (LN skipped when ln_gamma is NULL);  y2 = y1 + W2b relu(W1b y1 + b1b) + b2b
  *   (second stage skipped when W1b is NULL).  With att / w_proj ([M][D] / [D][D], natural k order) x is first replaced by

@@ -93,6 +93,23 @@ def test_attention(dtype, nseq, S, heads, dh):
     close(got, attn_ref(qkv, nseq, S, heads), tol(dtype, 3))
 
 
+def to_head_major(qkv, nseq, S, heads):
+    """[nseq*S][3D] row-major -> [(seq * heads + head) * 3 + {q,k,v}][S][dh] (what cfen_embed_qkv writes with head_major_heads)"""
+    dh = qkv.shape[1] // 3 // heads
+    return qkv.view(nseq, S, 3, heads, dh).permute(0, 3, 2, 1, 4).contiguous().view(-1)
+
+
+@pytest.mark.parametrize("nseq,S,heads", [(3, 256, 4), (5, 256, 8), (2, 64, 4), (9, 64, 16)])
+def test_attention_head_major_layout(nseq, S, heads):
+    qkv = rnd((nseq * S, 3 * heads * 24), 7, torch.float16, 1.5)
+    got = ops.attention_head_major(to_head_major(qkv, nseq, S, heads).to(dev()), nseq, S, heads)
+    close(got, attn_ref(qkv, nseq, S, heads), tol(torch.float16, 3))
+    # a dominating key late in the sequence (the softmax maximum is not among the first keys)
+    qkv[200 % S, heads * 24:heads * 24 + 24] = qkv[3, :24] * 25
+    got = ops.attention_head_major(to_head_major(qkv, nseq, S, heads).to(dev()), nseq, S, heads)
+    close(got, attn_ref(qkv, nseq, S, heads), tol(torch.float16, 3))
+
+
 @pytest.mark.parametrize("dtype", DTYPES)
 def test_attention_spiky_scores(dtype):
     # one key dominates late in the sequence: exercises the online-softmax rescale
@@ -230,6 +247,17 @@ def test_embed_qkv_fused_front(dtype, C, H, W, ws):
         ops.tune("embed.lds", 2)
     assert torch.equal(res[0][0], res[1][0]) and torch.equal(res[0][1], res[1][1])
     x1, qkv = res[1]
+    # head-major store (input layout of cfen_attention_head_major): the same values, laid out per (window, head)
+    heads = D // 24
+    nwin = B * (H // ws) * (W // ws)
+    for lds in (0, 3):
+        ops.tune("embed.lds", lds)
+        try:
+            x1h, qkvh = ops.embed_qkv(fmap, C, ws, p, we[:, perm].contiguous().to(d), be.to(d), pos.to(d), g.to(d), b.to(d),
+                                      wq[:, perm].contiguous().to(d), head_major_heads=heads)
+        finally:
+            ops.tune("embed.lds", 2)
+        assert torch.equal(x1h, x1) and torch.equal(qkvh.view(-1), to_head_major(qkv, nwin, S, heads))
     tok = ops.patchify(fmap, C, ws, p)
     t64 = tok.double().cpu()
     y = t64 @ we.double().t() + be.double() + t64 + pos.double().repeat(tok.shape[0] // S, 1)
