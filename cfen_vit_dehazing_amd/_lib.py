@@ -81,8 +81,9 @@ SIGNATURES = {
     "cfen_stats_workspace": (c_size_t, [_I, _I]),
     "cfen_instnorm_relu": (_I, [_I, _P, _P, _I, _I, _I, _I, c_float, _P]),
     "cfen_cfsm2g": (_I, [_I, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P]),
-    "cfen_deform_conv_forward": (_I, [_I, _P, _P, _P, _P] + [_I] * 16 + [_P]),
-    "cfen_modulated_deform_conv_forward": (_I, [_I, _P, _P, _P, _P, _P, _P] + [_I] * 16 + [_P]),
+    "cfen_deform_conv_columns_bytes": (c_size_t, [_I] * 9),
+    "cfen_deform_conv_forward": (_I, [_I, _P, _P, _P, _P] + [_I] * 16 + [_P, c_size_t, _P]),
+    "cfen_modulated_deform_conv_forward": (_I, [_I, _P, _P, _P, _P, _P, _P] + [_I] * 16 + [_P, c_size_t, _P]),
 }
 
 _lib = None

@@ -29,9 +29,12 @@ template <> struct PackB<float> {
 
 // element offset of feature f (a multiple of 4) of a qkv row inside its (window, head) triple for the head-major layout:
 // [(window * heads + head) * 3 + part][S][dh], part = f / D; relative to the window's first element, without the token term
-CFEN_DEV long long hm_feature_off(int f, int D, int heads, int S) {
-  const int dh = D / heads, part = f / D, fd = f - part * D, hd = fd / dh, d = fd - hd * dh;
-  return (long long)((hd * 3 + part) * S) * dh + d;
+// (head_dim is 24 wherever this layout is used -- k_attention_hm is built for it -- so every division here is by a constant)
+constexpr int HM_DH = 24;
+template <int D>
+CFEN_DEV int hm_feature_off(int f, int S) {
+  const int part = f / D, fd = f - part * D, hd = fd / HM_DH, d = fd - hd * HM_DH;
+  return ((hd * 3 + part) * S) * HM_DH + d;
 }
 
 template <typename T, int ND, int TM, int NW>
@@ -137,7 +140,7 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(2, 2)))
   long long qrow[TM];
 #pragma unroll
   for (int j = 0; j < TM; ++j)
-    qrow[j] = a.hm_heads ? (tk[j] / S) * (3LL * S * D) + (tk[j] % S) * (D / a.hm_heads) : tk[j] * (3LL * D);
+    qrow[j] = a.hm_heads ? (tk[j] / S) * (3LL * S * D) + (tk[j] % S) * HM_DH : tk[j] * (3LL * D);
   // ---- qkv = W_qkv LN(y): 3D output features, one 16-feature tile at a time, straight to HBM ----
   const T* Wq = (const T*)a.Wqkv + (size_t)r16 * D + h * EPL;
 #pragma unroll 2
@@ -151,7 +154,7 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(2, 2)))
 #pragma unroll
       for (int j = 0; j < TM; ++j) q[j] = Mma<T>::mma(af, xb[c][j], q[j]);
     }
-    const long long fo = a.hm_heads ? hm_feature_off(i * 16 + 4 * h, D, a.hm_heads, S) : i * 16 + 4 * h;
+    const long long fo = a.hm_heads ? hm_feature_off<D>(i * 16 + 4 * h, S) : i * 16 + 4 * h;
 #pragma unroll
     for (int j = 0; j < TM; ++j)
       if (tok0 + j * 16 + r16 < a.M) store4<T>((T*)a.QKV + qrow[j] + fo, q[j]);
@@ -295,7 +298,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   long long qrow[TM];
 #pragma unroll
   for (int j = 0; j < TM; ++j)
-    qrow[j] = a.hm_heads ? (tk[j] / S) * (3LL * S * D) + (tk[j] % S) * (D / a.hm_heads) : tk[j] * (3LL * D);
+    qrow[j] = a.hm_heads ? (tk[j] / S) * (3LL * S * D) + (tk[j] % S) * HM_DH : tk[j] * (3LL * D);
   // ---- qkv stages: every tile goes straight to HBM ----
 #pragma unroll 1
   for (int sq = 0; sq < NQS; ++sq) {
@@ -313,7 +316,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         for (int j = 0; j < TM; ++j) q[j] = Mma<T>::mma(af, xb[c][j], q[j]);
       }
       {
-        const long long fo = a.hm_heads ? hm_feature_off((sq * NG + u) * 16 + 4 * h, D, a.hm_heads, S) : (sq * NG + u) * 16 + 4 * h;
+        const long long fo = a.hm_heads ? hm_feature_off<D>((sq * NG + u) * 16 + 4 * h, S) : (sq * NG + u) * 16 + 4 * h;
 #pragma unroll
         for (int j = 0; j < TM; ++j)
           if (tok0 + j * 16 + r16 < a.M) store4<T>((T*)a.QKV + qrow[j] + fo, q[j]);
@@ -361,7 +364,8 @@ int run_embed_qkv(int ng, const CfenEmbedQkvArgs* ap, hipStream_t s) {
     const int tw = a.ws / a.p;
     CFEN_CHECK_ARG(a.D == a.p * a.p * a.C && a.M == (long long)a.B * (a.H / a.ws) * (a.W / a.ws) * tw * tw, "embed_qkv: D / M do not match the map");
     CFEN_CHECK_ARG(a.D == ap[0].D && a.M == ap[0].M && a.hm_heads == ap[0].hm_heads, "embed_qkv: grouped problems must have the same shape");
-    CFEN_CHECK_ARG(a.hm_heads >= 0 && (a.hm_heads == 0 || (a.D % a.hm_heads == 0 && (a.D / a.hm_heads) % 4 == 0)), "embed_qkv: bad head count %d", a.hm_heads);
+    CFEN_CHECK_ARG(a.hm_heads == 0 || (a.hm_heads > 0 && a.D == a.hm_heads * HM_DH), "embed_qkv: the head-major layout needs head_dim %d (D = %d, heads = %d)",
+                   HM_DH, a.D, a.hm_heads);
   }
   const int lds = cfen_tune_embed_lds();   // bit 0: D = 96, bit 1: D = 192 use the LDS-staged variant
   if constexpr (sizeof(T) == 2) {   // the fp32 stages would not fit 64 KB of LDS

@@ -510,7 +510,7 @@ int& cfen_tune_gemm_large() {
   return v;
 }
 int& cfen_tune_gemm_small() {
-  static int v = 5;
+  static int v = 15;   // 96 x 32 tiles, 3-stage ring: the few-token GViT GEMMs are latency bound (one K-step per memory round trip with 2 stages)
   return v;
 }
 int& cfen_tune_gemm_kernel() {

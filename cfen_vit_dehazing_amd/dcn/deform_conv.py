@@ -26,6 +26,14 @@ def _contig(*ts):
     return [t.contiguous() if t is not None else None for t in ts]
 
 
+def _columns(input, weight, groups):
+    """The reference allocates `columns` / `ones` scratch tensors per call (deform_conv.py:31, 106-107) and hands them to the extension;
+    here `columns` is the scratch of the HIP kernel's NHWC / tap-major operand copies (csrc/k_dcn.hip).  (buffer, nbytes)."""
+    B, C, H, W = input.shape
+    n = _lib.load().cfen_deform_conv_columns_bytes(dtype_code(input.dtype), B, C, H, W, weight.size(0), weight.size(2), weight.size(3), groups)
+    return torch.empty(max(int(n), 16), dtype=torch.uint8, device=input.device), int(n)
+
+
 class DeformConvFunction(Function):
     @staticmethod
     def forward(ctx, input, offset, weight, stride=1, padding=0, dilation=1, groups=1, deformable_groups=1, im2col_step=64):
@@ -46,11 +54,12 @@ class DeformConvFunction(Function):
             raise RuntimeError("invalid number of input planes, expected: %d, but got: %d" % (weight.size(1) * groups, input.size(1)))
         input, offset, weight = _contig(input, offset.to(input.dtype), weight.to(input.dtype))
         B, C, H, W = input.shape
+        columns, nbytes = _columns(input, weight, groups)
         # note the reference passes W before H here (deform_conv.py:41-46)
         check(_lib.load().cfen_deform_conv_forward(
             dtype_code(input.dtype), ptr(input), ptr(weight), ptr(offset), ptr(output), B, C, H, W, weight.size(0),
             weight.size(3), weight.size(2), stride[1], stride[0], padding[1], padding[0], dilation[1], dilation[0],
-            groups, deformable_groups, cur_im2col_step, current_stream()), "deform_conv_forward")
+            groups, deformable_groups, cur_im2col_step, ptr(columns), nbytes, current_stream()), "deform_conv_forward")
         return output
 
     @staticmethod
@@ -88,11 +97,12 @@ class ModulatedDeformConvFunction(Function):
             raise RuntimeError("Input shape and kernel channels wont match: (%d vs %d)." % (input.size(1), weight.size(1) * groups))
         input, offset, mask, weight, bias = _contig(input, offset.to(input.dtype), mask.to(input.dtype), weight.to(input.dtype),
                                                     bias.to(input.dtype) if with_bias else None)
+        columns, nbytes = _columns(input, weight, groups)
         # scalar stride / padding / dilation, h before w (deform_conv.py:117-119)
         check(_lib.load().cfen_modulated_deform_conv_forward(
             dtype_code(input.dtype), ptr(input), ptr(weight), ptr(bias), ptr(offset), ptr(mask), ptr(output), n, input.size(1),
             height, width, channels_out, kernel_h, kernel_w, stride, stride, padding, padding, dilation, dilation, groups,
-            deformable_groups, int(with_bias), current_stream()), "modulated_deform_conv_forward")
+            deformable_groups, int(with_bias), ptr(columns), nbytes, current_stream()), "modulated_deform_conv_forward")
         return output
 
     @staticmethod

@@ -209,16 +209,20 @@ int cfen_cfsm2g(int dtype, const void* x0, const void* x1, const void* x2, void*
                 int C, int cs, void* stream);
 
 /* ---- deformable convolution (replaces the pybind module of dcn/src/deform_conv_cuda.cpp:681-695) ---- */
-/* deform_conv_forward_cuda (dcn/src/deform_conv_cuda.cpp:151-156): NCHW tensors; note the reference
- * passes W before H for kernel/stride/pad/dilation here.  `columns`/`ones` buffers are not needed.  */
+/* deform_conv_forward_cuda (dcn/src/deform_conv_cuda.cpp:151-156): NCHW tensors; note the reference passes W before H for
+ * kernel/stride/pad/dilation here.  `columns` is the reference's scratch tensor of that name: device memory of at least
+ * cfen_deform_conv_columns_bytes() bytes, 16-byte aligned (the kernel keeps an NHWC copy of the input and tap-major weights
+ * there -- the column matrix itself is never materialised; the reference's `ones` buffer has no counterpart).  With columns ==
+ * NULL (or too small, or C/group not a multiple of the 16-byte channel vector) a slower kernel gathers from the NCHW planes. */
+size_t cfen_deform_conv_columns_bytes(int dtype, int B, int Cin, int H, int W, int Cout, int kH, int kW, int group);
 int cfen_deform_conv_forward(int dtype, const void* input, const void* weight, const void* offset, void* output, int B, int Cin, int H,
                              int W, int Cout, int kW, int kH, int dW, int dH, int padW, int padH, int dilationW, int dilationH, int group,
-                             int deformable_group, int im2col_step, void* stream);
-/* modulated_deform_conv_cuda_forward (dcn/src/deform_conv_cuda.cpp:486-492): h before w; bias may be NULL */
+                             int deformable_group, int im2col_step, void* columns, size_t columns_bytes, void* stream);
+/* modulated_deform_conv_cuda_forward (dcn/src/deform_conv_cuda.cpp:486-492): h before w; bias may be NULL; columns as above */
 int cfen_modulated_deform_conv_forward(int dtype, const void* input, const void* weight, const void* bias, const void* offset,
                                        const void* mask, void* output, int B, int Cin, int H, int W, int Cout, int kernel_h, int kernel_w,
                                        int stride_h, int stride_w, int pad_h, int pad_w, int dilation_h, int dilation_w, int group,
-                                       int deformable_group, int with_bias, void* stream);
+                                       int deformable_group, int with_bias, void* columns, size_t columns_bytes, void* stream);
 
 #ifdef __cplusplus
 }
