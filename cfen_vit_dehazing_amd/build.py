@@ -10,12 +10,16 @@ SOURCES = ["k_gemm.hip", "k_attention.hip", "k_tokens.hip", "k_conv.hip", "k_con
 # per-file codegen flags.  k_attention: the softmax is VALU bound -- drop fmaxf's NaN canonicalisation (no NaNs can
 # occur: masked scores are -1e30, not -inf) and let MFMA results land in VGPRs instead of AGPR + v_accvgpr_read.
 EXTRA_FLAGS = {"k_attention.hip": ["-fno-honor-nans", "-mllvm", "-amdgpu-mfma-vgpr-form=1"]}
-# every file: no packed-fp32 VALU code (v_pk_fma_f32 / v_pk_mul_f32 / v_pk_add_f32).  On MI355X the HIGH lane of those
-# instructions was measured to return wrong values in a wave whose CU is shared with MFMA-heavy waves of ANOTHER kernel
-# (other stream / other graph branch): single 128-byte runs of odd channels off by one interpolation tap in k_upsample4,
-# perturbed LayerNorm sums in k_mlp -- never when the kernel has the chip to itself.  With the feature off the
-# multi-lane plan is bit-reproducible (tools/stress_determinism.py: 0 differing runs of 60 eager / 60 graph; 16/16
-# before).  The host pass of hipcc does not know the feature and says so; that warning is filtered below.
+# every file: no packed-fp32 VALU code (v_pk_fma_f32 / v_pk_mul_f32 / v_pk_add_f32).  WHY, honestly: round 1 attributed a run-to-run
+# nondeterminism of the two-lane plan to these instructions ("wrong high lane beside another kernel's MFMA waves").  Round 2 tested that
+# claim (tools/repro_pk_fma.py, profiles/r02_pk_fma_repro.json): a stand-alone v_pk_fma_f32 / v_pk_mul_f32 kernel beside an MFMA kernel
+# shows 0 mismatches in 180 launches, and this library built WITH packed-fp32 code generation (6713 such instructions) is bit-reproducible
+# over 60 eager + graph forwards under GEMM noise, exactly like the shipped build.  The claim is RETRACTED: what fixed the nondeterminism
+# was the other half of that commit (cross-lane reductions moved from ds_bpermute to DPP / v_permlane*_swap, the V^T staging rewrite).
+# The flag stays for a measured reason of its own: beside MFMAs a v_pk_fma_f32 costs more issue time than the two v_fma_f32 it replaces
+# (/opt/skills/guides/MI355X_MICROARCH.md, "price of one filler beside MFMAs": +22..26 cycles per pair) and hipcc SLP-packs the fp32
+# epilogues of every MFMA kernel here.  Correctness does not depend on it; check_no_packed_fp32() only reports.
+# The host pass of hipcc does not know the feature and says so; that warning is filtered below.
 DEVICE_FLAGS = ["-Xclang", "-target-feature", "-Xclang", "-packed-fp32-ops"]
 _HOST_NOISE = "is not a recognized feature for this target"
 
@@ -24,9 +28,38 @@ def _newer(a, b):
     return not os.path.exists(b) or os.path.getmtime(a) > os.path.getmtime(b)
 
 
-def build(force=False, verbose=False):
+def check_no_packed_fp32(lib=LIB):
+    """Disassemble the device code of the linked library and count v_pk_{fma,mul,add}_f32 (see DEVICE_FLAGS: a performance choice,
+    CFEN_CXXFLAGS or another hipcc could silently undo it).  Returns the number of such instructions (0 = as intended), None
+    when llvm-objdump is not available."""
+    import re
+    import shutil
+    import tempfile
+    objdump = os.path.join(os.path.dirname(os.path.realpath(os.environ.get("HIPCC", "/opt/rocm/bin/hipcc"))), "..", "lib", "llvm", "bin", "llvm-objdump")
+    if not os.path.exists(objdump):
+        objdump = "/opt/rocm/lib/llvm/bin/llvm-objdump"
+    if not os.path.exists(objdump):
+        return None
+    tmp = tempfile.mkdtemp(prefix="cfen_disasm_")
+    try:
+        so = shutil.copy(lib, os.path.join(tmp, "lib.so"))
+        subprocess.run([objdump, "--offloading", so], stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, check=False)   # extracts the bundles beside it
+        n = 0
+        for f in sorted(os.listdir(tmp)):
+            if "amdgcn" in f:
+                out = subprocess.run([objdump, "-d", os.path.join(tmp, f)], capture_output=True, text=True, check=False).stdout
+                n += len(re.findall(r"\bv_pk_(?:fma|mul|add)_f32\b", out))
+        return n
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+
+
+def build(force=False, verbose=False, packed_fp32=False, lib=None, objdir=None):
+    """packed_fp32 / lib / objdir: A/B build of the same sources WITH packed-fp32 code generation into another library
+    (tools/repro_pk_fma.py); the shipped build is build()."""
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-    objdir = os.path.join(HERE, "build")
+    lib = lib or LIB
+    objdir = objdir or os.path.join(HERE, "build")
     os.makedirs(objdir, exist_ok=True)
     headers = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".hpp")]
     headers.append(os.path.join(os.path.dirname(HERE), "include", "cfen_hip.h"))
@@ -41,7 +74,7 @@ def build(force=False, verbose=False):
         objs.append(obj)
         if force or _newer(path, obj) or any(_newer(h, obj) for h in headers):
             cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-x", "hip", "-c", path, "-o", obj,
-                   "-Wall", "-Wno-unused-function"] + DEVICE_FLAGS + EXTRA_FLAGS.get(src, []) + os.environ.get("CFEN_CXXFLAGS", "").split()
+                   "-Wall", "-Wno-unused-function"] + ([] if packed_fp32 else DEVICE_FLAGS) + EXTRA_FLAGS.get(src, []) + os.environ.get("CFEN_CXXFLAGS", "").split()
             if verbose:
                 print(" ".join(cmd), flush=True)
             procs.append((src, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)))
@@ -55,12 +88,17 @@ def build(force=False, verbose=False):
             print(out)
     if failed:
         raise RuntimeError("hipcc failed")
-    if procs or not os.path.exists(LIB):
-        cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs
+    if procs or not os.path.exists(lib):
+        cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", lib] + objs
         if verbose:
             print(" ".join(cmd), flush=True)
         subprocess.check_call(cmd)
-    return LIB
+        if not packed_fp32:
+            n = check_no_packed_fp32(lib)
+            if n:
+                sys.stderr.write("note: libcfen_hip.so contains %d packed-fp32 VALU instructions (DEVICE_FLAGS overridden?): slower beside "
+                                 "MFMAs, results unaffected\n" % n)
+    return lib
 
 
 if __name__ == "__main__":

@@ -9,6 +9,8 @@ from dataclasses import dataclass
 from types import SimpleNamespace
 
 BRANCHES = ("r", "s", "d")
+# opt.model_G -> variant of the generator family (reference models/model_iid_dehazing.py:84-95)
+VARIANTS = {"iid_hlgvit_crs_gd4_cfs_v3": "v3", "iid_hlgvit_crs_gd4_cfs": "cfs"}
 
 
 @dataclass(frozen=True)
@@ -32,12 +34,20 @@ class NetConfig:
     patch_size: int = 32      # LViT window edge in feature-map pixels (opt.patch_size)
     patch_dim: int = 2
     num_heads: int = 4
-    load_size: int = 256      # edge of the half-resolution feature map xf (opt.loadSize)
+    load_size: int = 256      # edge of the level-1 feature map xf (opt.loadSize)
     n_colors: int = 3
+    variant: str = "v3"       # which sibling generator (opt.model_G, models/model_iid_dehazing.py:84-95), see VARIANTS
 
     @property
     def image_size(self):
-        return 2 * self.load_size
+        """v3 runs its three levels on a stride-2 down-sampled map (ds_conv_e01, v3:297-298, 396); `cfs` keeps full resolution
+        (networks_iid_hlgvit_crs_gd4_cfs.py:368: xf = head(input)), so there the image IS the level-1 map."""
+        return self.load_size if self.variant == "cfs" else 2 * self.load_size
+
+    @property
+    def head_channels(self):
+        """channels of the head CNN / tails: n_feats/2 at twice the resolution (v3:123-127), n_feats at level-1 resolution (cfs :117-121)"""
+        return self.n_feats if self.variant == "cfs" else self.n_feats // 2
 
     def level_channels(self, level):
         return self.n_feats << (level - 1)
@@ -106,10 +116,13 @@ def config_from_opt(opt):
         raise NotImplementedError("num_layers != 1 is not supported")
     if getattr(opt, "dropout_rate", 0) != 0:
         raise NotImplementedError("dropout_rate != 0 is not supported (inference path)")
+    model_g = getattr(opt, "model_G", "iid_hlgvit_crs_gd4_cfs_v3")
+    if model_g not in VARIANTS:
+        raise NotImplementedError("--model_G %s is not built on the HIP path (available: %s)" % (model_g, ", ".join(sorted(VARIANTS))))
     cfg = NetConfig(n_feats=int(opt.n_feats), hidden_dim_ratio=int(opt.hidden_dim_ratio),
                     patch_size=int(opt.patch_size), patch_dim=int(getattr(opt, "patch_dim", 2)),
                     num_heads=int(getattr(opt, "num_heads", 4)), load_size=int(opt.loadSize),
-                    n_colors=int(getattr(opt, "n_colors", 3)))
+                    n_colors=int(getattr(opt, "n_colors", 3)), variant=VARIANTS[model_g])
     cfg.validate()
     return cfg
 
@@ -118,6 +131,6 @@ def default_opt(**overrides):
     """The subset of reference flags the hot path reads, with BASELINE.json's values."""
     o = dict(n_feats=24, hidden_dim_ratio=4, patch_size=32, patch_dim=2, num_heads=4, num_layers=1,
              num_queries=1, dropout_rate=0, no_mlp=False, pos_every=False, no_pos=False, no_norm=False,
-             loadSize=256, rgb_range=255, n_colors=3, init_type="kaiming", gpu_ids=[])
+             loadSize=256, rgb_range=255, n_colors=3, init_type="kaiming", gpu_ids=[], model_G="iid_hlgvit_crs_gd4_cfs_v3")
     o.update(overrides)
     return SimpleNamespace(**o)

@@ -80,6 +80,9 @@ struct cfen_net {
   struct AnPending { const float* ones; const float* conv_bias; float* an_out; };
   std::map<std::string, AnPending> an_pending;
   int input_u8 = 0;                // 1: x is uint8 HWC (B,H,W,3), normalised to [-1,1] by the first launch (data/base_dataset.py:44-46)
+  bool cfs = false;                // sibling generator networks_iid_hlgvit_crs_gd4_cfs.py (cfg.reserved bits 8..15 == 1): the three levels run at the
+                                   // image's own resolution -- no ds_conv_e01 / us_conv_d01*, n_feats channels in head and tails
+  int full = 0;                    // image edge
   int blk_kind = 0;                // 0 CNN, 1 GViT block, 2 LViT block (selects bits 8.. / 16.. of "net.skip_classes")
   unsigned char* base = nullptr;   // workspace of the current / last forward
   hipStream_t stream = nullptr;    // stream of the lane being enqueued
@@ -223,6 +226,10 @@ int cfen_net::build() {
   CFEN_CHECK_ARG(cfg.num_heads > 0 && (nf * 4) % cfg.num_heads == 0, "net: embedding dim not divisible by heads");
   CFEN_CHECK_ARG(4 * nf <= 128, "net: n_feats > 32 unsupported");
   CFEN_CHECK_ARG(cfg.hidden_dim_ratio > 0, "net: hidden_dim_ratio must be positive");
+  const int variant = (cfg.reserved >> 8) & 0xff;
+  CFEN_CHECK_ARG(variant == 0 || variant == 1, "net: unknown generator variant %d (0 = ..._cfs_v3, 1 = ..._cfs)", variant);
+  cfs = variant == 1;
+  full = cfs ? N : 2 * N;
 
   // ---- transformer instances (reference v3:136-246) ----
   static const char* br = "rsd";
@@ -274,11 +281,11 @@ int cfen_net::build() {
   }
 
   // ---- convolution layers ----
-  const int h = nf / 2;
-  add_conv("head.0.0", 0, 5, 1, 2, 0, 1, 3, h, 2 * N);
-  add_conv("head.0.1.body.0", 0, 3, 1, 1, 0, 1, h, h, 2 * N);
-  add_conv("head.0.1.body.2", 0, 3, 1, 1, 0, 1, h, h, 2 * N);
-  add_conv("ds_conv_e01", 0, 3, 2, 1, 0, 1, h, nf, N);
+  const int h = cfs ? nf : nf / 2;
+  add_conv("head.0.0", 0, 5, 1, 2, 0, 1, 3, h, full);
+  add_conv("head.0.1.body.0", 0, 3, 1, 1, 0, 1, h, h, full);
+  add_conv("head.0.1.body.2", 0, 3, 1, 1, 0, 1, h, h, full);
+  if (!cfs) add_conv("ds_conv_e01", 0, 3, 2, 1, 0, 1, h, nf, N);
   add_conv("ds_conv_e02", 0, 3, 2, 1, 0, 1, nf, 2 * nf, N / 2);
   add_conv("ds_conv_e03", 0, 3, 2, 1, 0, 1, 2 * nf, 4 * nf, N / 4);
   for (int l = 1; l <= 3; ++l) add_conv("lgcat_conv_e0" + std::to_string(l), 0, 1, 1, 0, 0, 2, nf << (l - 1), nf << (l - 1), N >> (l - 1));
@@ -288,24 +295,24 @@ int cfen_net::build() {
       add_conv("lgcat_conv_d0" + std::to_string(l) + t, 0, 1, 1, 0, 0, 2, nf << (l - 1), nf << (l - 1), N >> (l - 1));
     add_conv("us_conv_d03" + t, 1, 4, 2, 1, 0, 1, 4 * nf, 2 * nf, N / 2);
     add_conv("us_conv_d02" + t, 1, 4, 2, 1, 0, 1, 2 * nf, nf, N);
-    add_conv("us_conv_d01" + t, 1, 4, 2, 1, 0, 1, nf, h, 2 * N);
+    if (!cfs) add_conv("us_conv_d01" + t, 1, 4, 2, 1, 0, 1, nf, h, 2 * N);
     if (b < 2) {
       add_conv("sk_conv_d03" + t, 0, 1, 1, 0, 0, 2, 2 * nf, 2 * nf, N / 2);
       add_conv("sk_conv_d02" + t, 0, 1, 1, 0, 0, 2, nf, nf, N);
     }
     const std::string T(1, (char)(br[b] - 32));
-    add_conv("tail_" + T + ".conv3", 0, 3, 1, 1, 0, 1, h, h, 2 * N);
-    add_conv("tail_" + T + ".conv7", 0, 7, 1, 3, 1, 1, h, b == 1 ? 1 : 3, 2 * N);
+    add_conv("tail_" + T + ".conv3", 0, 3, 1, 1, 0, 1, h, h, full);
+    add_conv("tail_" + T + ".conv7", 0, 7, 1, 3, 1, 1, h, b == 1 ? 1 : 3, full);
   }
   need("cfsm2g_d03d.w", (size_t)4 * 2 * (2 * nf / 4) * (2 * nf) * 4);
   need("cfsm2g_d02d.w", (size_t)4 * 2 * (nf / 4) * nf * 4);
 
   // ---- workspace ----
-  add_map("input", 3, 2 * N);
-  add_map("head.conv5", h, 2 * N);
-  add_map("head.res_mid", h, 2 * N);
-  add_map("head", h, 2 * N);
-  add_map("ds_conv_e01", nf, N);
+  add_map("input", 3, full);
+  add_map("head.conv5", h, full);
+  add_map("head.res_mid", h, full);
+  add_map("head", h, full);
+  if (!cfs) add_map("ds_conv_e01", nf, N);
   for (int l = 1; l <= 3; ++l) {
     const std::string L = std::to_string(l);
     const int C = nf << (l - 1), E = N >> (l - 1);
@@ -323,10 +330,10 @@ int cfen_net::build() {
       add_map("localvit_decoder_0" + L + t, C, E);
       add_map("globalvit_decoder_0" + L + t, C, E);
       add_map("lgcat_conv_d0" + L + t, C, E);
-      if (l < 3) add_map("us_conv_d0" + L + t, C / 2, 2 * E);
+      if (l < 3 && !(cfs && l == 1)) add_map("us_conv_d0" + L + t, C / 2, 2 * E);
       if (l > 1) add_map(b == 2 ? "cfsm2g_d0" + L + "d" : "sk_conv_d0" + L + t, C / 2, 2 * E);
     }
-    add_map(std::string("tail_") + (char)(br[b] - 32) + ".mid", h, 2 * N);
+    add_map(std::string("tail_") + (char)(br[b] - 32) + ".mid", h, full);
   }
   for (int k = 0; k < 6; ++k) {
     const bool g = k & 1;             // odd sets serve GViT lanes: far fewer tokens
@@ -624,7 +631,11 @@ int cfen_net::run_decoder(float* const* outs, hipStream_t sm, hipStream_t sg) {
     names("lgcat_conv_d0" + L, out);
     // `xr = us_conv_d01r(r_d_01 + xf)` (v3:696,852,1008): the extra `+ xf` rides along as a second residual of the
     // level-1 fuse conv, so stage lgcat_conv_d01* holds (reference stage + xf).
-    TRY(run_level_g(3, tags, l, in, l == 1 ? "ds_conv_e01" : nullptr, out, sm, sg));
+    TRY(run_level_g(3, tags, l, in, l == 1 ? (cfs ? "head" : "ds_conv_e01") : nullptr, out, sm, sg));
+    if (cfs && l == 1) {   // cfs:669,823,977: the tails read d_01 + xf (folded into lgcat_conv_d01*'s epilogue) directly
+      for (int g = 0; g < 3; ++g) up[g] = out[g];
+      break;
+    }
     names("us_conv_d0" + L, up);
     ConvCall c[3];
     for (int g = 0; g < 3; ++g) c[g] = ConvCall{up[g], out[g], "", "", "", up[g], nullptr};
@@ -661,10 +672,10 @@ int cfen_net::forward(const float* x, float* xr, float* xs, float* xd) {
   const Buf& bin = bufs.at("input");
   if (input_u8) {
     label = "input:u8hwc_to_nhwc";
-    TRYP(K_TOKEN, 0, cfen_u8hwc_to_nhwc_impl(dt, (const unsigned char*)x, map_ptr("input"), B, 2 * N, 2 * N, bin.cs, stream));
+    TRYP(K_TOKEN, 0, cfen_u8hwc_to_nhwc_impl(dt, (const unsigned char*)x, map_ptr("input"), B, full, full, bin.cs, stream));
   } else {
     label = "input:nchw_to_nhwc";
-    TRYP(K_TOKEN, 0, cfen_nchw_to_nhwc_impl(dt, x, map_ptr("input"), B, 3, 2 * N, 2 * N, bin.cs, stream));
+    TRYP(K_TOKEN, 0, cfen_nchw_to_nhwc_impl(dt, x, map_ptr("input"), B, 3, full, full, bin.cs, stream));
   }
   // head: conv5x5 + ResBlock                                                   (v3:123-127,395)
   TRY(run_conv("head.0.0", "input", nullptr, nullptr, nullptr, 0, "head.conv5", nullptr));
@@ -679,8 +690,12 @@ int cfen_net::forward(const float* x, float* xr, float* xs, float* xd) {
   };
   std::string in = "head";
   for (int l = 1; l <= 3; ++l) {
-    const std::string L = std::to_string(l), ds = "ds_conv_e0" + L, out = "lgcat_conv_e0" + L;
-    TRY(down(ds, in));
+    const std::string L = std::to_string(l), out = "lgcat_conv_e0" + L;
+    std::string ds = "ds_conv_e0" + L;
+    if (cfs && l == 1)
+      ds = "head";             // cfs:368: xf = head(input), level 1 runs at the image's own resolution
+    else
+      TRY(down(ds, in));
     TRY(run_level_g(1, "e", l, &ds, nullptr, &out, s0, sg));
     in = out;
   }

@@ -21,6 +21,7 @@ from .config import NetConfig, config_from_opt
 from .manifest import state_manifest, _is_dead
 from .packing import pack_state_dict
 
+_VARIANT_CODE = {"v3": 0, "cfs": 1}       # cfen_net_config.reserved bits 8..15 (csrc/cfen_net.cpp)
 _DTYPES = {"fp16": torch.float16, "half": torch.float16, "fp32": torch.float32, "single": torch.float32,
            torch.float16: torch.float16, torch.float32: torch.float32}
 
@@ -154,7 +155,10 @@ class dec_ipt(nn.Module):
         if self._packed is None:
             pending = {}
             packed = pack_state_dict(self._live_state(device), self.cfg, self.compute_dtype, pending=pending)
-            self._packed = {k: v.to(device).contiguous() for k, v in packed.items()}
+            self._packed = {k: v.to(device).contiguous() for k, v in packed.items() if not isinstance(v, str)}
+            for k, v in packed.items():          # "@other": the same device tensor under a second name (shared modules)
+                if isinstance(v, str):
+                    self._packed[k] = self._packed[v[1:]]
             self._packed_dev = device
             # uninitialised ActNorm2d layers: (key prefix, conv bias [Cout_pad], an_out [2][Cout_pad]) on the device
             self._an_pending = {n: (an, b.to(device).contiguous(), torch.zeros(2, b.numel(), dtype=torch.float32, device=device))
@@ -171,7 +175,7 @@ class dec_ipt(nn.Module):
         c = self.cfg
         cc = NetConfigC(batch=batch, n_feats=c.n_feats, hidden_dim_ratio=c.hidden_dim_ratio, patch_size=c.patch_size,
                         load_size=c.load_size, num_heads=c.num_heads, dtype=_lib.dtype_code(self.compute_dtype),
-                        reserved=1 if self.serial_plan else 0)     # bit 0: single-stream launch plan
+                        reserved=(1 if self.serial_plan else 0) | (_VARIANT_CODE[c.variant] << 8))   # bit 0: single-stream plan; bits 8..15: variant
         h = ctypes.c_void_p()
         check(lib.cfen_net_create(ctypes.byref(h), ctypes.byref(cc)), "cfen_net_create")
         for name, t in packed.items():

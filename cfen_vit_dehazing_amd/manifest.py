@@ -56,7 +56,8 @@ def _vit_entries(g, with_dead=True):
 def state_manifest(cfg: NetConfig, with_dead=True):
     """[(key, shape, torch.dtype)] in the reference's state_dict order."""
     nf = cfg.n_feats
-    h = nf // 2
+    h = cfg.head_channels
+    cfs = cfg.variant == "cfs"      # networks_iid_hlgvit_crs_gd4_cfs.py: no ds_conv_e01 / us_conv_d01*, tail_color shared by R and D
     out = []
 
     def add(k, shape, dtype=torch.float32):
@@ -85,10 +86,11 @@ def state_manifest(cfg: NetConfig, with_dead=True):
             conv_an("lgcat_conv_d0%d%s" % (l, b), *lg[l])
     add("ds_conv_e02.0.weight", (2 * nf, nf, 3, 3)); add("ds_conv_e02.0.bias", (2 * nf,))
     add("ds_conv_e03.0.weight", (4 * nf, 2 * nf, 3, 3)); add("ds_conv_e03.0.bias", (4 * nf,))
-    add("ds_conv_e01.0.weight", (nf, h, 3, 3)); add("ds_conv_e01.0.bias", (nf,))
+    if not cfs:
+        add("ds_conv_e01.0.weight", (nf, h, 3, 3)); add("ds_conv_e01.0.bias", (nf,))
     for b in BRANCHES:
         add("us_conv_d03%s.0.weight" % b, (4 * nf, 2 * nf, 4, 4)); add("us_conv_d03%s.0.bias" % b, (2 * nf,))
-        for nm, cin, cout in (("us_conv_d02" + b, 2 * nf, nf), ("us_conv_d01" + b, nf, h)):
+        for nm, cin, cout in ((("us_conv_d02" + b, 2 * nf, nf),) if cfs else (("us_conv_d02" + b, 2 * nf, nf), ("us_conv_d01" + b, nf, h))):
             add(nm + ".0.weight", (cin, cout, 4, 4)); add(nm + ".0.bias", (cout,))
             add(nm + ".1.weight", (cout,)); add(nm + ".1.bias", (cout,))
             add(nm + ".1.initialized", (), torch.int64)
@@ -100,12 +102,13 @@ def state_manifest(cfg: NetConfig, with_dead=True):
         for fc in ("fc_avg_cf1", "fc_avg_cf2", "fc_max_cf1", "fc_max_cf2"):
             add("%s.%s.0.weight" % (nm, fc), (bk, c, 1, 1))
             add("%s.%s.2.weight" % (nm, fc), (c, bk, 1, 1))
-    for t, cout in (("tail_R", cfg.n_colors), ("tail_D", cfg.n_colors)):
+    gray = "tail_gray" if cfs else "tail_S"
+    for t, cout in ((("tail_color", cfg.n_colors),) if cfs else (("tail_R", cfg.n_colors), ("tail_D", cfg.n_colors))):
         add(t + ".0.1.weight", (h, h, 3, 3)); add(t + ".0.1.bias", (h,))
         add(t + ".0.2.weight", (h,)); add(t + ".0.2.bias", (h,)); add(t + ".0.2.initialized", (), torch.int64)
         add(t + ".0.5.weight", (cout, h, 7, 7)); add(t + ".0.5.bias", (cout,))
-    add("tail_S.0.1.weight", (h, h, 3, 3)); add("tail_S.0.1.bias", (h,))
-    add("tail_S.0.4.weight", (1, h, 7, 7)); add("tail_S.0.4.bias", (1,))
+    add(gray + ".0.1.weight", (h, h, 3, 3)); add(gray + ".0.1.bias", (h,))
+    add(gray + ".0.4.weight", (1, h, 7, 7)); add(gray + ".0.4.bias", (1,))
     return out
 
 

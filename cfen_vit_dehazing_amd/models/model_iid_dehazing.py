@@ -18,6 +18,9 @@ class DECHLGVIT(BaseModel):
         if opt.model_G == 'iid_hlgvit_crs_gd4_cfs_v3':
             from . import networks_iid_hlgvit_crs_gd4_cfs_v3
             self.netG = networks_iid_hlgvit_crs_gd4_cfs_v3.define_G(opt, None)
+        elif opt.model_G == 'iid_hlgvit_crs_gd4_cfs':             # models/model_iid_dehazing.py:84-86
+            from . import networks_iid_hlgvit_crs_gd4_cfs
+            self.netG = networks_iid_hlgvit_crs_gd4_cfs.define_G(opt, None)
         # any other --model_G leaves netG undefined, as the reference's if/elif chain does (-> AttributeError)
 
     def set_input(self, input):

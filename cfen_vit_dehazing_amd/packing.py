@@ -211,12 +211,13 @@ def pack_state_dict(sd, cfg: NetConfig, dtype=torch.float16, pending=None):
     ({packed layer name: (ActNorm key prefix, conv bias padded to Cout_pad)}); hipnet.dec_ipt hands those layers to
     cfen_net_actnorm_pending, and the first forward initialises them on the device.  Without a `pending` dict this raises."""
     kc = 32 if dtype == torch.float16 else 16
-    nf, h = cfg.n_feats, cfg.n_feats // 2
+    nf, h = cfg.n_feats, cfg.head_channels
+    cfs = cfg.variant == "cfs"      # sibling generator networks_iid_hlgvit_crs_gd4_cfs.py: see config.NetConfig.image_size
     out = {}
     for g in cfg.vit_instances():
         out.update(pack_vit(sd, g, dtype))
 
-    full = 2 * cfg.load_size
+    full = cfg.image_size
 
     def conv(name, key, cin, an=None, rows=None):
         # rows = (stride, pad) of a full-resolution layer that may run on the LDS-tiled kernel
@@ -254,7 +255,8 @@ def pack_state_dict(sd, cfg: NetConfig, dtype=torch.float16, pending=None):
     conv("head.0.0", "head.0.0", 3, rows=(1, 2))
     conv("head.0.1.body.0", "head.0.1.body.0", h, rows=(1, 1))
     conv("head.0.1.body.2", "head.0.1.body.2", h, rows=(1, 1))
-    conv("ds_conv_e01", "ds_conv_e01.0", h)
+    if not cfs:
+        conv("ds_conv_e01", "ds_conv_e01.0", h)
     conv("ds_conv_e02", "ds_conv_e02.0", nf)
     conv("ds_conv_e03", "ds_conv_e03.0", 2 * nf)
     for l in (1, 2, 3):
@@ -264,23 +266,31 @@ def pack_state_dict(sd, cfg: NetConfig, dtype=torch.float16, pending=None):
         for l in (1, 2, 3):
             n = "lgcat_conv_d0%d%s" % (l, b)
             conv(n, n + ".0", nf << (l - 1), an=n + ".1")
-        convT("us_conv_d03" + b, "us_conv_d03%s.0" % b, 4 * nf, edge=full // 8)
-        convT("us_conv_d02" + b, "us_conv_d02%s.0" % b, 2 * nf, an="us_conv_d02%s.1" % b, edge=full // 4)
-        convT("us_conv_d01" + b, "us_conv_d01%s.0" % b, nf, an="us_conv_d01%s.1" % b, edge=full // 2)
+        convT("us_conv_d03" + b, "us_conv_d03%s.0" % b, 4 * nf, edge=cfg.load_size // 4)
+        convT("us_conv_d02" + b, "us_conv_d02%s.0" % b, 2 * nf, an="us_conv_d02%s.1" % b, edge=cfg.load_size // 2)
+        if not cfs:
+            convT("us_conv_d01" + b, "us_conv_d01%s.0" % b, nf, an="us_conv_d01%s.1" % b, edge=cfg.load_size)
         if b != "d":
             conv("sk_conv_d03" + b, "sk_conv_d03%s.0" % b, 2 * nf, an="sk_conv_d03%s.1" % b)
             conv("sk_conv_d02" + b, "sk_conv_d02%s.0" % b, nf, an="sk_conv_d02%s.1" % b)
         T = "tail_" + b.upper()
-        if b == "s":
-            conv(T + ".conv3", T + ".0.1", h, rows=(1, 1))
-            conv(T + ".conv7", T + ".0.4", h, rows=(1, 3))
+        src = T if not cfs else ("tail_gray" if b == "s" else "tail_color")   # cfs: R and D share tail_color (cfs:334-345, 669, 977)
+        if cfs and b == "d":
+            # the same module as tail_R: the packed entries are aliases ("@name"), so a device-side ActNorm initialisation of
+            # tail_R.conv3's epilogue table (first forward, models/actnorm.py:25-37) is what tail_D.conv3 reads too
+            for part in (".conv3.w", ".conv3.wr", ".conv3.scale", ".conv3.shift", ".conv7.w", ".conv7.wr", ".conv7.wz", ".conv7.scale", ".conv7.shift"):
+                if "tail_R" + part in out:
+                    out[T + part] = "@tail_R" + part
+        elif b == "s":
+            conv(T + ".conv3", src + ".0.1", h, rows=(1, 1))
+            conv(T + ".conv7", src + ".0.4", h, rows=(1, 3))
         else:
-            conv(T + ".conv3", T + ".0.1", h, an=T + ".0.2", rows=(1, 1))
-            conv(T + ".conv7", T + ".0.5", h, rows=(1, 3))
+            conv(T + ".conv3", src + ".0.1", h, an=src + ".0.2", rows=(1, 1))
+            conv(T + ".conv7", src + ".0.5", h, rows=(1, 3))
     for n in ("cfsm2g_d03d", "cfsm2g_d02d"):
         parts = []
         for fc in ("fc_avg_cf1", "fc_avg_cf2", "fc_max_cf1", "fc_max_cf2"):
             parts.append(sd["%s.0.%s.0.weight" % (n, fc)].float().reshape(-1))
             parts.append(sd["%s.0.%s.2.weight" % (n, fc)].float().reshape(-1))
         out[n + ".w"] = torch.cat(parts)
-    return {k: v.contiguous() for k, v in out.items()}
+    return {k: (v if isinstance(v, str) else v.contiguous()) for k, v in out.items()}

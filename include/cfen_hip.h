@@ -59,7 +59,9 @@ typedef struct cfen_net_config {
   int32_t load_size;        /* edge of the half-resolution map xf, base_options.py:16          */
   int32_t num_heads;        /* base_options.py:192                                             */
   int32_t dtype;            /* CFEN_F32 | CFEN_F16                                             */
-  int32_t reserved;
+  int32_t reserved;         /* bit 0: single-lane launch plan; bits 8..15: generator variant (models/model_iid_dehazing.py:84-92):
+                               0 networks_iid_hlgvit_crs_gd4_cfs_v3 (image edge 2*load_size), 1 networks_iid_hlgvit_crs_gd4_cfs
+                               (full-resolution head, no ds_conv_e01 / us_conv_d01*, image edge = load_size)                    */
 } cfen_net_config;
 
 int cfen_net_create(cfen_net** out, const cfen_net_config* cfg);

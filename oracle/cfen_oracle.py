@@ -204,10 +204,10 @@ def head(sd, x):
 
 
 def tail(sd, name, x):
-    """v3:348-383 (Upsampler is empty: common.py:64-81 with log2(1) = 0 stages)."""
+    """v3:348-383 / cfs:334-358 (Upsampler is empty: common.py:64-81 with log2(1) = 0 stages)."""
     p = name + ".0"
     x = F.conv2d(x, sd[p + ".1.weight"], sd[p + ".1.bias"], padding=1)
-    if name != "tail_S":
+    if name not in ("tail_S", "tail_gray"):
         x = actnorm(sd, p + ".2", x)
         last = p + ".5"
     else:
@@ -220,10 +220,13 @@ def tail(sd, name, x):
 # --------------------------------------------------------------------------------------------
 # whole network
 # --------------------------------------------------------------------------------------------
-def forward(sd, x, num_heads=4, patch_size=32, stages=None):
+def forward(sd, x, num_heads=4, patch_size=32, stages=None, variant="v3"):
     """dec_ipt.forward (v3:392-1020).  x: (B,3,H,W) in [-1,1] -> [xr (B,3,H,W), xs (B,1,H,W), xd (B,3,H,W)].
-    If `stages` is a dict it receives the 58 top-level stage outputs named as in SURVEY Appendix D."""
+    If `stages` is a dict it receives the 58 top-level stage outputs named as in SURVEY Appendix D.
+    variant "cfs" = models/networks_iid_hlgvit_crs_gd4_cfs.py:362-980: the same three levels run on the head's own (full-resolution)
+    output -- no ds_conv_e01 / us_conv_d01* -- and the tails (tail_color shared by R and D, tail_gray for S) read `d_01 + xf` directly."""
     ws = patch_size
+    cfs = variant == "cfs"
 
     def rec(name, t):
         if stages is not None:
@@ -243,7 +246,7 @@ def forward(sd, x, num_heads=4, patch_size=32, stages=None):
         return rec(cn, conv_actnorm_relu(sd, cn, torch.cat((lo, gl), 1)) + xin)
 
     xh = rec("head", head(sd, x))
-    xf = rec("ds_conv_e01", ds_conv(sd, "ds_conv_e01", xh))
+    xf = xh if cfs else rec("ds_conv_e01", ds_conv(sd, "ds_conv_e01", xh))
     x_e_01 = level("e", 1, xf)
     x_e_01_ds = rec("ds_conv_e02", ds_conv(sd, "ds_conv_e02", x_e_01))
     x_e_02 = level("e", 2, x_e_01_ds)
@@ -268,9 +271,12 @@ def forward(sd, x, num_heads=4, patch_size=32, stages=None):
         else:
             in1 = rec("sk_conv_d02" + t, conv_actnorm_relu(sd, "sk_conv_d02" + t, torch.cat((u2, x_e_01), 1)))
         d1 = level(t, 1, in1)
-        u1 = rec("us_conv_d01" + t, us_conv(sd, "us_conv_d01" + t, d1 + xf, "an"))                      # v3:696,852,1008
         tn = "tail_" + t.upper()
-        outs[t] = rec(tn, tail(sd, tn, u1))
+        if cfs:
+            outs[t] = rec(tn, tail(sd, "tail_gray" if t == "s" else "tail_color", d1 + xf))              # cfs:669,823,977
+        else:
+            u1 = rec("us_conv_d01" + t, us_conv(sd, "us_conv_d01" + t, d1 + xf, "an"))                  # v3:696,852,1008
+            outs[t] = rec(tn, tail(sd, tn, u1))
     return [outs["r"], outs["s"], outs["d"]]
 
 

@@ -14,7 +14,7 @@ GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 def load_net_fixture(name):
     z = np.load(os.path.join(GOLDEN, "net_%s.npz" % name))
     nf, hdr, ps, ls = [int(v) for v in z["cfg"]]
-    cfg = NetConfig(nf, hdr, patch_size=ps, load_size=ls)
+    cfg = NetConfig(nf, hdr, patch_size=ps, load_size=ls, variant="cfs" if name.startswith("cfs") else "v3")
     return cfg, int(z["batch"]), z
 
 

@@ -370,3 +370,40 @@ def test_uint8_input_equals_host_normalised_input():
     b = net(u8.to("cuda:0"))
     for p, q in zip(a, b):
         assert torch.equal(p, q)
+
+
+# ---- sibling generator --model_G iid_hlgvit_crs_gd4_cfs (models/networks_iid_hlgvit_crs_gd4_cfs.py): same kernels, second launch plan ---------
+
+def _cfs_stages(net, z):
+    st = {}
+    xf = net.stage("head")
+    for n in [str(s) for s in z["stage_names"]]:
+        if n.startswith("tail_"):
+            continue
+        t = net.stage(n)
+        if n.startswith("lgcat_conv_d01"):
+            t = t - xf                      # `+ xf` (cfs:669,823,977) rides on this stage's epilogue
+        st[n] = t
+    return st
+
+
+@pytest.mark.parametrize("name", ["cfs_tiny_nf24_hdr4", "cfs_full256_nf24_hdr4"])
+def test_cfs_variant_fp32_all_stages_and_fp16(name):
+    cfg, batch, z = load_net_fixture(name)
+    assert cfg.variant == "cfs" and cfg.image_size == cfg.load_size
+    net = make_net(cfg, "fp32")
+    x = synthetic_input(batch, cfg).to("cuda:0")
+    outs = net(x)
+    st = _cfs_stages(net, z)
+    for nm, o in zip(("tail_R", "tail_S", "tail_D"), outs):
+        st[nm] = o
+    check_stages(z, st, 3e-4, rel_sum=2e-4)
+    wo = check_outputs(z, outs, 1e-4)
+    net16 = make_net(cfg, "fp16")
+    w16 = check_outputs(z, net16(x), 3e-2)
+    gid, gouts = net16.capture(x)
+    net16.replay(gid)
+    torch.cuda.synchronize()
+    for a, b in zip(net16(x), gouts):
+        assert torch.equal(a, b)
+    print("%s: fp32 outputs max-abs vs reference %.2e, fp16 %.2e" % (name, wo, w16))

@@ -19,7 +19,7 @@ def _run(name):
     x = synthetic_input(batch, cfg)
     st = {}
     with torch.no_grad():
-        outs = cfen_oracle.forward(sd, x, cfg.num_heads, cfg.patch_size, stages=st)
+        outs = cfen_oracle.forward(sd, x, cfg.num_heads, cfg.patch_size, stages=st, variant=cfg.variant)
     check_outputs(z, outs, TOL_OUT)
     check_stages(z, st, TOL_STAGE)
     for nm, o in zip(("xr", "xs", "xd"), outs):
@@ -38,7 +38,7 @@ def test_oracle_reference_init_weights_and_actnorm_first_call():
     _run("refinit_tiny_nf24_hdr4")
 
 
-@pytest.mark.parametrize("name", ["tiny_nf24_hdr4", "tiny_nf24_hdr2", "small_nf24_hdr4"])
+@pytest.mark.parametrize("name", ["tiny_nf24_hdr4", "tiny_nf24_hdr2", "small_nf24_hdr4", "cfs_tiny_nf24_hdr4"])
 def test_oracle_small_nets(name):
     _run(name)
 

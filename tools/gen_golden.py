@@ -42,6 +42,9 @@ CONFIGS = {
     # weights drawn from what the reference's own define_G / init_weights leaves (v3:49-74, 1330, 1377), ActNorm2d uninitialised:
     # the reference's first forward initialises its 24 ActNorm layers from the batch (models/actnorm.py:25-37); the fixture
     # holds those parameters next to the outputs of that same forward
+    # sibling generator models/networks_iid_hlgvit_crs_gd4_cfs.py (--model_G iid_hlgvit_crs_gd4_cfs): full-resolution head, no ds/us stage
+    "cfs_tiny_nf24_hdr4": (NetConfig(24, 4, patch_size=8, load_size=64, variant="cfs"), 2, True),
+    "cfs_full256_nf24_hdr4": (NetConfig(24, 4, patch_size=32, load_size=256, variant="cfs"), 1, False),
     "refinit_tiny_nf24_hdr4": (NetConfig(24, 4, patch_size=8, load_size=64), 2, True),
     "refinit_full512_nf24_hdr4": (NetConfig(24, 4, patch_size=32, load_size=256), 1, False),
 }
@@ -53,10 +56,15 @@ def weight_mode(name):
 STAGE_MODULES = None
 
 
-def import_reference():
-    sys.path.insert(0, REF)
-    from models import networks_iid_hlgvit_crs_gd4_cfs_v3 as v3, common   # noqa
-    return v3, common
+REF_MODULE = {"v3": "networks_iid_hlgvit_crs_gd4_cfs_v3", "cfs": "networks_iid_hlgvit_crs_gd4_cfs"}
+
+
+def import_reference(variant="v3"):
+    import importlib
+    if REF not in sys.path:
+        sys.path.insert(0, REF)
+    from models import common   # noqa
+    return importlib.import_module("models." + REF_MODULE[variant]), common
 
 
 def opt_for(cfg):
@@ -64,16 +72,17 @@ def opt_for(cfg):
                        loadSize=cfg.load_size, num_heads=cfg.num_heads, patch_dim=cfg.patch_dim)
 
 
-def stage_names():
-    names = ["head", "ds_conv_e01"]
+def stage_names(variant="v3"):
+    names = ["head"] if variant == "cfs" else ["head", "ds_conv_e01"]
     for l in (1, 2, 3):
         names += ["localvit_encoder_0%d" % l, "globalvit_encoder_0%d" % l, "lgcat_conv_e0%d" % l]
         if l < 3:
             names.append("ds_conv_e0%d" % (l + 1))
     for t in "rsd":
         for l in (3, 2, 1):
-            names += ["localvit_decoder_0%d%s" % (l, t), "globalvit_decoder_0%d%s" % (l, t),
-                      "lgcat_conv_d0%d%s" % (l, t), "us_conv_d0%d%s" % (l, t)]
+            names += ["localvit_decoder_0%d%s" % (l, t), "globalvit_decoder_0%d%s" % (l, t), "lgcat_conv_d0%d%s" % (l, t)]
+            if not (variant == "cfs" and l == 1):
+                names.append("us_conv_d0%d%s" % (l, t))
             if l > 1:
                 names.append(("cfsm2g_d0%dd" % l) if t == "d" else ("sk_conv_d0%d%s" % (l, t)))
         names.append("tail_" + t.upper())
@@ -103,12 +112,23 @@ class StageRecorder:
                     or name.startswith("sk_conv") or name.startswith("cfsm2g") or name in ("head", "tail_R", "tail_S", "tail_D"):
                 tgt = mod[0] if name in ("head", "tail_R", "tail_S", "tail_D") else mod
                 tgt.register_forward_hook(self._hook(name))
+            elif name == "tail_gray":
+                mod[0].register_forward_hook(self._hook("tail_S"))
+            elif name == "tail_color":          # called for R first, then for D (cfs:669, 977)
+                mod[0].register_forward_hook(self._seq_hook(["tail_R", "tail_D"]))
             elif name.startswith("lgcat"):
                 mod.register_forward_hook(self._hook(name + "#pre"))
 
     def _hook(self, name):
         def f(m, i, o):
             self.out[name] = o.detach().clone()
+        return f
+
+    def _seq_hook(self, names):
+        it = iter(names)
+
+        def f(m, i, o):
+            self.out[next(it)] = o.detach().clone()
         return f
 
     def _lv_hook(self, name):
@@ -144,6 +164,7 @@ class StageRecorder:
 
 
 def run_reference(v3, common, cfg, batch, dtype=torch.float32, mode="trained"):
+    v3, common = import_reference(cfg.variant)
     opt = opt_for(cfg)
     torch.manual_seed(0)
     net = v3.dec_ipt(opt, common.default_conv)
@@ -177,8 +198,8 @@ def gen_net(v3, common, name):
     if not name.startswith("refinit"):
         dump_manifest(net, os.path.join(GOLD, "state_manifest_%s.txt" % name))
     data = {"batch": np.int64(batch), "cfg": np.array([cfg.n_feats, cfg.hidden_dim_ratio, cfg.patch_size, cfg.load_size], np.int64)}
-    names = stage_names()
-    assert len(names) == 58 and all(n in stages for n in names), [n for n in names if n not in stages]
+    names = stage_names(cfg.variant)
+    assert len(names) == (54 if cfg.variant == "cfs" else 58) and all(n in stages for n in names), [n for n in names if n not in stages]
     data["stage_names"] = np.array(names)
     for n in names:
         t = stages[n]
@@ -213,7 +234,7 @@ def gen_net(v3, common, name):
     st = {}
     sd = generate_state_dict(cfg, seed=0, mode=weight_mode(name))      # fresh copy: load_state_dict shares no storage, but be explicit
     with torch.no_grad():
-        o2 = cfen_oracle.forward(sd, x, cfg.num_heads, cfg.patch_size, stages=st)
+        o2 = cfen_oracle.forward(sd, x, cfg.num_heads, cfg.patch_size, stages=st, variant=cfg.variant)
     if name.startswith("refinit"):
         worst_an = max(float((sd[k + ".weight"] - torch.from_numpy(data["actnorm_w/" + k])).abs().max()) for k in data["actnorm_names"])
         print("   oracle ActNorm init vs reference: worst |dweight| %.3e" % worst_an)
