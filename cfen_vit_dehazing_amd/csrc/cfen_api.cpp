@@ -116,7 +116,7 @@ int cfen_tune(const char* key, int value) {
     return CFEN_OK;
   }
   if (!strcmp(key, "embed.lds")) {
-    cfen_tune_embed_lds() = value & 3;
+    cfen_tune_embed_lds() = value & 7;
     return CFEN_OK;
   }
   if (!strcmp(key, "gemm.splitk")) {

@@ -7,6 +7,7 @@
 // an accumulator tile pair IS the B operand of the next GEMM (weights' k axis pre-permuted on the host, packing.kperm32),
 // LayerNorm reduces over a lane's registers + two lane swaps.  The weights (18 + 55 KB at D = 96) are read as MFMA A
 // fragments straight from L1/L2 -- every wave of the chip reads the same few kilobytes.
+#include <type_traits>
 #include "cfen_common.hpp"
 #include "cfen_internal.hpp"
 
@@ -327,6 +328,220 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   }
 }
 
+// ------------------------------------------------------------------------------------------------------------------------------
+// k_embed_qkv2 (fp16): the same front half with the weight stream rebuilt like k_mlp2 (k_mlp.hip).  rocprofv3 showed the waves of
+// both variants above parked on s_waitcnt / barriers for 54-58 % of their cycles: the D = 96 kernel loads every weight fragment from
+// L2 right before the MFMAs that use it, the LDS variant stages through registers with two barriers per 64 weight rows.  Here the
+// 4 D rows of [W_e ; W_qkv] stream through a two-stage LDS ring by LDS-DMA, RS rows per chunk, one raw s_barrier per chunk with the
+// next chunk's DMA in flight; fragments are read in groups of three with the next group already loading (software pipeline pinned
+// with sched_barrier); rows padded to a 32 (mod 64)-byte pitch.  The qkv tiles are stored while the next chunk's DMA is in flight, so
+// the landing wait is a COUNTED vmcnt (the stores issued after the DMA may stay outstanding; CDNA4 counts loads and stores together).
+template <int I, int N, class F>
+CFEN_DEV void eq_static_for(F&& f) {
+  if constexpr (I < N) {
+    f(std::integral_constant<int, I>{});
+    eq_static_for<I + 1, N>(f);
+  }
+}
+
+// (a __device__ helper, not a call inside the lambda: hipcc's host pass drops the stub of a kernel whose lambda calls this builtin)
+CFEN_DEV void eq_dma16(const void* g, unsigned char* l) {
+  __builtin_amdgcn_global_load_lds(g, (__attribute__((address_space(3))) void*)l, 16, 0, 0);
+}
+
+template <int ND, int TM, int NW, int RS>
+__global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_embed_qkv2(Grouped<CfenEmbedQkvArgs> ga) {
+  typedef half_t T;
+  const CfenEmbedQkvArgs& a = ga.g[blockIdx.z];
+  constexpr int KC = 32, EPL = 8;
+  constexpr int D = ND * 16, NCH = ND / 2, RT = RS / 16;
+  constexpr int P1 = D * 2 + 32, PP1 = P1 / 16;
+  constexpr int NINS = RS * PP1 / 64;                 // DMA wave-instructions per chunk
+  constexpr int NI = (NINS + NW - 1) / NW;
+  constexpr int STAGE = NINS * 1024;
+  constexpr int NEC = D / RS, NQC = 3 * D / RS;       // embedding / qkv chunks
+  constexpr int GPT = NCH / 3;                        // fragment groups per row tile
+  constexpr int NG = RT * GPT;                        // ... per chunk
+  static_assert(RS % 16 == 0 && RS * PP1 % 64 == 0 && D % RS == 0 && NCH % 3 == 0, "chunk geometry");
+  typedef half8 frag;
+  __shared__ __attribute__((aligned(1024))) unsigned char lds[2 * STAGE];
+  const int tid = threadIdx.x, lane = tid & 63, r16 = lane & 15, h = lane >> 4;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const long long tok0 = ((long long)blockIdx.x * NW + wave) * (TM * 16);   // the launcher guarantees M % (NW * TM * 16) == 0
+
+  unsigned off[NI];
+#pragma unroll
+  for (int i = 0; i < NI; ++i) {
+    const int id = (i * NW + wave) * 64 + lane, row = id / PP1, col = min(id % PP1, PP1 - 3);
+    off[i] = (unsigned)(row * D * 2 + col * 16);
+  }
+  auto issue = [&](int c, int buf) {   // chunk c: rows [c * RS, +RS) of [W_e ; W_qkv]
+    const unsigned char* W = c < NEC ? (const unsigned char*)a.We + (size_t)c * RS * D * 2 : (const unsigned char*)a.Wqkv + (size_t)(c - NEC) * RS * D * 2;
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+      const int blk = i * NW + wave;
+      if (blk < NINS) eq_dma16(W + off[i], lds + buf * STAGE + blk * 1024);
+    }
+  };
+  issue(0, 0);
+
+  // ---- gather x^T into accumulator layout ----
+  const int tw = a.ws / a.p, S = tw * tw, nwx = a.W / a.ws, nwy = a.H / a.ws;
+  floatx4 acc[ND][TM];
+  long long tk[TM];
+#pragma unroll
+  for (int j = 0; j < TM; ++j) {
+    const long long t = tok0 + j * 16 + r16;
+    tk[j] = t;
+    const int tt = (int)(t % S);
+    const long long wi = t / S;
+    const int wx = (int)(wi % nwx), wy = (int)((wi / nwx) % nwy);
+    const long long b = wi / ((long long)nwx * nwy);
+    const int y0 = wy * a.ws + (tt / tw) * a.p, x0 = wx * a.ws + (tt % tw) * a.p;
+    const T* pix = (const T*)a.fmap + ((b * a.H + y0) * a.W + x0) * a.cs;
+#pragma unroll
+    for (int i = 0; i < ND; ++i) {
+      const int f = i * 16 + 4 * h;
+      const int ij = f / a.C, c = f - ij * a.C;
+      acc[i][j] = load4<T>(pix + ((ij / a.p) * a.W + (ij % a.p)) * a.cs + c);
+    }
+  }
+  frag xb[NCH][TM];
+#pragma unroll
+  for (int j = 0; j < TM; ++j)
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+      floatx4 t[2] = {acc[c * 2][j], acc[c * 2 + 1][j]};
+      xb[c][j] = PackB<T>::make(t);
+    }
+#pragma unroll
+  for (int i = 0; i < ND; ++i) {
+    const floatx4 bb = *reinterpret_cast<const floatx4*>(a.be + i * 16 + 4 * h);
+#pragma unroll
+    for (int j = 0; j < TM; ++j) acc[i][j] += bb + load4<T>((const T*)a.pos + (size_t)(tk[j] % S) * D + i * 16 + 4 * h);
+  }
+
+  const int a1 = r16 * P1 + h * 16;
+  auto load_g = [&](const unsigned char* buf, auto gc, frag (&f)[3]) {
+    constexpr int g = decltype(gc)::value, u = g / GPT, cg = g % GPT;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) f[k] = *reinterpret_cast<const frag*>(buf + a1 + (u * 16) * P1 + (cg * 3 + k) * 64);
+  };
+
+  // ---- y = W_e x + (b_e + x + pos): embedding chunks (accumulator indices are compile-time) ----
+  eq_static_for<0, NEC>([&](auto cc) {
+    constexpr int c = decltype(cc)::value;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    issue(c + 1, (c + 1) & 1);                           // NEC < NEC + NQC: there is always a next chunk
+    const unsigned char* buf = lds + (c & 1) * STAGE;
+    frag F[2][3];
+    load_g(buf, std::integral_constant<int, 0>{}, F[0]);
+    eq_static_for<0, NG>([&](auto gc) {
+      constexpr int g = decltype(gc)::value, u = g / GPT, cg = g % GPT;
+      if constexpr (g + 1 < NG) load_g(buf, std::integral_constant<int, g + 1>{}, F[(g + 1) & 1]);
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int k = 0; k < 3; ++k)
+#pragma unroll
+        for (int j = 0; j < TM; ++j) acc[c * RT + u][j] = Mma<T>::mma(F[g & 1][k], xb[cg * 3 + k][j], acc[c * RT + u][j]);
+      __builtin_amdgcn_sched_barrier(0);
+    });
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  });
+#pragma unroll
+  for (int j = 0; j < TM; ++j) {
+    T* yp = (T*)a.X1 + tk[j] * D + 4 * h;
+#pragma unroll
+    for (int i = 0; i < ND; ++i) store4<T>(yp + i * 16, acc[i][j]);
+  }
+  // ---- LayerNorm(y) -> B fragments ----
+#pragma unroll
+  for (int j = 0; j < TM; ++j) {
+    float sm = 0.f;
+#pragma unroll
+    for (int i = 0; i < ND; ++i) sm += acc[i][j][0] + acc[i][j][1] + acc[i][j][2] + acc[i][j][3];
+    sm = col_sum(sm);
+    const float mean = sm * (1.f / D);
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < ND; ++i)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float d = acc[i][j][r] - mean;
+        q += d * d;
+      }
+    q = col_sum(q);
+    const float rstd = rsqrtf(q * (1.f / D) + a.eps);
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+      floatx4 t[2];
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        const int i = c * 2 + u;
+        const floatx4 g = *reinterpret_cast<const floatx4*>(a.ln_g + i * 16 + 4 * h);
+        const floatx4 b = *reinterpret_cast<const floatx4*>(a.ln_b + i * 16 + 4 * h);
+        t[u] = (acc[i][j] - mean) * rstd * g + b;
+      }
+      xb[c][j] = PackB<T>::make(t);
+    }
+  }
+  long long qrow[TM];
+#pragma unroll
+  for (int j = 0; j < TM; ++j)
+    qrow[j] = a.hm_heads ? (tk[j] / S) * (3LL * S * D) + (tk[j] % S) * HM_DH : tk[j] * (3LL * D);
+
+  // ---- qkv chunks: every tile goes straight to HBM ----
+#pragma unroll 1
+  for (int cq = 0; cq < NQC; ++cq) {
+    const int c = NEC + cq;
+    // chunk c has landed when at most the RT * TM tile stores issued after its DMA are still outstanding (first qkv chunk: the X1
+    // stores and LayerNorm parameter loads sit behind the DMA too -- drain)
+    if (cq == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(RT * TM) : "memory");
+    __builtin_amdgcn_s_barrier();
+    if (cq + 1 < NQC) issue(c + 1, (c + 1) & 1);
+    const unsigned char* buf = lds + (c & 1) * STAGE;
+    frag F[2][3];
+    floatx4 q[TM];
+    load_g(buf, std::integral_constant<int, 0>{}, F[0]);
+    eq_static_for<0, NG>([&](auto gc) {
+      constexpr int g = decltype(gc)::value, u = g / GPT, cg = g % GPT;
+      if constexpr (g + 1 < NG) load_g(buf, std::integral_constant<int, g + 1>{}, F[(g + 1) & 1]);
+      __builtin_amdgcn_sched_barrier(0);
+      if constexpr (cg == 0) {
+#pragma unroll
+        for (int j = 0; j < TM; ++j) q[j] = floatx4{0.f, 0.f, 0.f, 0.f};
+      }
+#pragma unroll
+      for (int k = 0; k < 3; ++k)
+#pragma unroll
+        for (int j = 0; j < TM; ++j) q[j] = Mma<T>::mma(F[g & 1][k], xb[cg * 3 + k][j], q[j]);
+      if constexpr (cg == GPT - 1) {
+        const int f = (cq * RT + u) * 16 + 4 * h;
+        const long long fo = a.hm_heads ? hm_feature_off<D>(f, S) : f;
+#pragma unroll
+        for (int j = 0; j < TM; ++j) store4<T>((T*)a.QKV + qrow[j] + fo, q[j]);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    });
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  }
+}
+
+template <int ND, int TM, int NW, int RS>
+int launch_embed_qkv2(int ng, const CfenEmbedQkvArgs* ap, hipStream_t s) {
+  Grouped<CfenEmbedQkvArgs> ga;
+  for (int g = 0; g < CFEN_MAX_GROUPS; ++g) ga.g[g] = ap[g < ng ? g : 0];
+  const long long per = (long long)NW * TM * 16;
+  CFEN_CHECK_ARG(ap[0].M % per == 0, "embed_qkv2: token count must be a multiple of %lld", per);
+  const long long blocks = ap[0].M / per;
+  CFEN_CHECK_ARG(blocks > 0 && blocks < (1ll << 31), "embed_qkv: bad grid");
+  CFEN_LAUNCH((k_embed_qkv2<ND, TM, NW, RS>), dim3((unsigned)blocks, 1, ng), dim3(NW * 64), 0, s, ga);
+  CFEN_CHECK_LAUNCH("embed_qkv");
+  return CFEN_OK;
+}
+
 template <typename T, int ND, int TM, int NG>
 int launch_embed_qkv_lds(int ng, const CfenEmbedQkvArgs* ap, hipStream_t s) {
   Grouped<CfenEmbedQkvArgs> ga;
@@ -369,6 +584,10 @@ int run_embed_qkv(int ng, const CfenEmbedQkvArgs* ap, hipStream_t s) {
   }
   const int lds = cfen_tune_embed_lds();   // bit 0: D = 96, bit 1: D = 192 use the LDS-staged variant
   if constexpr (sizeof(T) == 2) {   // the fp32 stages would not fit 64 KB of LDS
+    if (lds & 4) {   // LDS-DMA ring + pipelined fragment groups (k_embed_qkv2); needs whole workgroups of tokens
+      if (ap[0].D == 96 && ap[0].M % 256 == 0) return launch_embed_qkv2<6, 4, 4, 32>(ng, ap, s);
+      if (ap[0].D == 192 && ap[0].M % 128 == 0) return launch_embed_qkv2<12, 2, 4, 32>(ng, ap, s);
+    }
     if (ap[0].D == 96 && (lds & 1)) return launch_embed_qkv_lds<T, 6, 4, 6>(ng, ap, s);
     if (ap[0].D == 192 && (lds & 2)) return launch_embed_qkv_lds<T, 12, 2, 4>(ng, ap, s);
   }
@@ -384,7 +603,7 @@ int run_embed_qkv(int ng, const CfenEmbedQkvArgs* ap, hipStream_t s) {
 }  // namespace
 
 int& cfen_tune_embed_lds() {
-  static int v = 2;
+  static int v = 6;
   return v;
 }
 

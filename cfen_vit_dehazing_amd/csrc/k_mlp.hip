@@ -332,7 +332,24 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(2, 2)))
       off[i] = (unsigned)(min(pc, HCH * 4 / 16 - 1) * 16);               // b1[hc*HCH + 4*pc ..]
     }
   }
-  auto issue = [&](int t, int buf) {   // chunk t of the flattened (stage a, stage b) sequence -> LDS stage `buf`
+  // Flattened chunk sequence T: [projection phase: D/32 chunks of 32 rows of Wp (W1-shaped region only)] [stage a: nhc chunks]
+  // [stage b: nhc chunks]; LDS stage = T & 1.
+  constexpr int NPC = D / 32;                       // projection chunks
+  constexpr int N1P = 32 * PP1 / 64;                // DMA instructions of one projection chunk
+  static_assert(32 * PP1 % 64 == 0 && N1P <= N1, "projection chunk must be whole DMA instructions inside the W1 region");
+  const int npc = a.Wp ? NPC : 0;
+  const int nchunks = npc + (a.W1b ? 2 * nhc : nhc);
+  auto issue = [&](int T, int buf) {
+    if (T < npc) {
+      const unsigned char* Wp = (const unsigned char*)a.Wp + (size_t)T * 32 * D * 2;
+#pragma unroll
+      for (int i = 0; i < NI; ++i) {
+        const int blk = i * NW + wave;
+        if (blk < N1P) mlp_dma16(Wp + off[i], lds + buf * STAGE + blk * 1024);
+      }
+      return;
+    }
+    const int t = T - npc;
     const bool sb = t >= nhc;
     const int hc = sb ? t - nhc : t;
     const unsigned char* W1 = (const unsigned char*)(sb ? a.W1b : a.W1a) + (size_t)hc * HCH * D * 2;
@@ -347,7 +364,13 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(2, 2)))
       }
     }
   };
-  const int nchunks = a.W1b ? 2 * nhc : nhc;
+  // chunk T has landed and is visible to every wave; the other stage is free: start filling it with chunk T + 1
+  auto begin_chunk = [&](int T) -> const unsigned char* {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    if (T + 1 < nchunks) issue(T + 1, (T + 1) & 1);
+    return lds + (T & 1) * STAGE;
+  };
   issue(0, 0);
 
   // ---- load x^T into accumulator layout: acc[i][j][r] = x[token j*16+r16][feature i*16+4h+r] ----
@@ -361,31 +384,43 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(2, 2)))
 #pragma unroll
     for (int i = 0; i < ND; ++i) acc[i][j] = load4<T>(xp + i * 16);
   }
-  if (a.Wp) {   // x += Wp att: out_proj + residual of the attention block, operands straight from L1/L2 (natural k order)
-    const T* Wp = (const T*)a.Wp + (size_t)r16 * D + h * EPL;
-    constexpr int NKC = D / KC;
-    const T* ap[TM];
+  const int a1 = r16 * P1 + h * 16;            // lane part of a W1-region fragment address
+  frag xb[NCH][TM];
+  if (a.Wp) {   // x += Wp att (out_proj + residual of the attention block, v3:1386): Wp streams through the same DMA ring, 32 rows a chunk;
+                // the attention output is this phase's B operand and borrows xb (natural k order on both sides)
 #pragma unroll
     for (int j = 0; j < TM; ++j) {
       long long t = tok0 + j * 16 + r16;
       if (t >= a.M) t = a.M - 1;
-      ap[j] = (const T*)a.A + t * D + h * EPL;
+      const T* ap = (const T*)a.A + t * D + h * EPL;
+#pragma unroll
+      for (int c = 0; c < NCH; ++c) xb[c][j] = load_frag<T>(ap + c * KC);
     }
+    constexpr int GP = 2 * (NCH / 3);   // fragment groups per projection chunk: (row tile u, chunk triple cg)
+    static_for<0, NPC>([&](auto tpc) {
+      constexpr int tp = decltype(tpc)::value;
+      const unsigned char* buf = begin_chunk(tp);
+      frag F[2][3];
+      auto load_p = [&](auto gc, frag (&f)[3]) {
+        constexpr int g = decltype(gc)::value, u = g / (NCH / 3), cg = g % (NCH / 3);
 #pragma unroll
-    for (int c = 0; c < NKC; ++c) {
-      frag ab[TM];
+        for (int k = 0; k < 3; ++k) f[k] = *reinterpret_cast<const frag*>(buf + a1 + (u * 16) * P1 + (cg * 3 + k) * 64);
+      };
+      load_p(std::integral_constant<int, 0>{}, F[0]);
+      static_for<0, GP>([&](auto gc) {
+        constexpr int g = decltype(gc)::value, u = g / (NCH / 3), cg = g % (NCH / 3);
+        if constexpr (g + 1 < GP) load_p(std::integral_constant<int, g + 1>{}, F[(g + 1) & 1]);
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-      for (int j = 0; j < TM; ++j) ab[j] = load_frag<T>(ap[j] + c * KC);
+        for (int k = 0; k < 3; ++k)
 #pragma unroll
-      for (int i = 0; i < ND; ++i) {
-        const frag af = load_frag<T>(Wp + (size_t)i * 16 * D + c * KC);
-#pragma unroll
-        for (int j = 0; j < TM; ++j) acc[i][j] = Mma<T>::mma(af, ab[j], acc[i][j]);
-      }
-    }
+          for (int j = 0; j < TM; ++j) acc[2 * tp + u][j] = Mma<T>::mma(F[g & 1][k], xb[cg * 3 + k][j], acc[2 * tp + u][j]);
+        __builtin_amdgcn_sched_barrier(0);
+      });
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    });
   }
 
-  frag xb[NCH][TM];
   // stage-a input: LayerNorm(x) (or x) as B fragments; residual + output bias go into the accumulators
   if (a.ln_g) {
 #pragma unroll
@@ -436,15 +471,11 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(2, 2)))
 
   // fragment groups of one 32-unit sub-step: 2 * NCH/3 FFN1 groups (u, chunk triple), then ND/3 FFN2 groups (feature-tile triple)
   constexpr int G1 = 2 * (NCH / 3), G2 = ND / 3, GS = G1 + G2, NG = NSUB * GS;
-  const int a1 = r16 * P1 + h * 16;            // lane part of a W1 fragment address
   const int a2 = R2 + r16 * P2 + h * 16;       // ... of a W2 fragment address
   const int a3 = R3 + 16 * h;                  // ... of a bias vector address
 
   auto chunk = [&](int t) {
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // chunk t has landed (this wave's share)
-    __builtin_amdgcn_s_barrier();                      // ... everyone's share; and every wave is done reading the other stage
-    if (t + 1 < nchunks) issue(t + 1, (t + 1) & 1);
-    const unsigned char* buf = lds + (t & 1) * STAGE;
+    const unsigned char* buf = begin_chunk(npc + t);
 
     frag F[2][3];
     floatx4 bia[2];
@@ -633,6 +664,8 @@ int launch_mlp(int ng, const MlpArgs* ap, hipStream_t s) {
       const int v96 = small / 10, v192 = small % 10;
       if (ap[0].D == 96) return v96 == 2 ? launch_mlp2_t<6, 4, 8, 64>(ng, ap, s) : v96 == 3 ? launch_mlp2_t<6, 2, 8, 64>(ng, ap, s)
                               : v96 == 4 ? launch_mlp2_t<6, 2, 8, 32>(ng, ap, s) : launch_mlp2_t<6, 4, 4, 64>(ng, ap, s);
+      // x2: 192 tokens / 6-wave WG -- the grouped decoder launch (3 x 32768 tokens) is then exactly one round of 2 WGs per CU
+      if (v192 == 2 || (v192 == 3 && (long long)ng * ap[0].M >= 3 * 32768)) return launch_mlp2_t<12, 2, 6, 32>(ng, ap, s);
       return v192 == 1 ? launch_mlp2_t<12, 2, 8, 32>(ng, ap, s) : launch_mlp2_t<12, 2, 4, 32>(ng, ap, s);
     }
   }

@@ -239,24 +239,25 @@ def test_embed_qkv_fused_front(dtype, C, H, W, ws):
     perm = packing.kperm32(D) if dtype == torch.float16 else torch.arange(D)
     res = []
     try:
-        for lds in (0, 3):                  # weights straight from L2 / staged through LDS (fp16 only): same arithmetic
+        for lds in (0, 3, 4):               # weights straight from L2 / staged through LDS / LDS-DMA ring (fp16 only): same arithmetic
             ops.tune("embed.lds", lds)
             res.append(ops.embed_qkv(fmap, C, ws, p, we[:, perm].contiguous().to(d), be.to(d), pos.to(d), g.to(d), b.to(d),
                                      wq[:, perm].contiguous().to(d)))
     finally:
-        ops.tune("embed.lds", 2)
+        ops.tune("embed.lds", 6)
     assert torch.equal(res[0][0], res[1][0]) and torch.equal(res[0][1], res[1][1])
+    assert torch.equal(res[0][0], res[2][0]) and torch.equal(res[0][1], res[2][1])
     x1, qkv = res[1]
     # head-major store (input layout of cfen_attention_head_major): the same values, laid out per (window, head)
     heads = D // 24
     nwin = B * (H // ws) * (W // ws)
-    for lds in (0, 3):
+    for lds in (0, 3, 4):
         ops.tune("embed.lds", lds)
         try:
             x1h, qkvh = ops.embed_qkv(fmap, C, ws, p, we[:, perm].contiguous().to(d), be.to(d), pos.to(d), g.to(d), b.to(d),
                                       wq[:, perm].contiguous().to(d), head_major_heads=heads)
         finally:
-            ops.tune("embed.lds", 2)
+            ops.tune("embed.lds", 6)
         assert torch.equal(x1h, x1) and torch.equal(qkvh.view(-1), to_head_major(qkv, nwin, S, heads))
     tok = ops.patchify(fmap, C, ws, p)
     t64 = tok.double().cpu()

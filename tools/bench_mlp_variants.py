@@ -18,7 +18,7 @@ def timed(f):
     return s.elapsed_time(e) * 1e3
 
 
-for D, M, variants in ((96, 131072, (3, 10, 20, 30, 40)), (96, 3 * 131072, (3, 10, 20, 30, 40)), (192, 32768, (3, 10, 11)), (192, 3 * 32768, (3, 10, 11))):
+for D, M, variants in ((96, 131072, (3, 10, 20, 30, 40)), (96, 3 * 131072, (3, 10, 20, 30, 40)), (192, 32768, (3, 10, 11, 12)), (192, 3 * 32768, (3, 10, 11, 12))):
     H = 4 * D
     g = torch.Generator(device="cpu").manual_seed(D)
     x = torch.randn(M, D, generator=g).half().to(d)
