@@ -8,7 +8,9 @@ kernel time (HIP events on the launch stream, median of repetitions), achieved G
 import argparse, json, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
-from cfen_vit_dehazing_amd import dcn
+from cfen_vit_dehazing_amd import dcn, ops
+for kv in filter(None, os.environ.get("CFEN_TUNE", "").split(",")):
+    ops.tune(kv.split("=")[0], int(kv.split("=")[1]))
 
 HBM_PEAK = 8000.0   # GB/s, MI355X_MICROARCH.md
 
