@@ -25,8 +25,16 @@ def short(name):
     """"_ZN12_GLOBAL__N_15k_mlpIDF16_Li12ELi2E...E" / "(anonymous namespace)::k_conv7_tz(...)" -> "k_mlp<f16,12,2,...>": kernel + template arguments"""
     import re
     m = re.match(r"_ZN12_GLOBAL__N_1(\d+)", name)
-    if not m:
-        return name.replace("(anonymous namespace)::", "").split("(")[0][:72]
+    if not m:      # already demangled by the profiler: "void (anonymous namespace)::k_mlp2<12, 2, 4, 32>(Grouped<MlpArgs>)"
+        d = name.replace("(anonymous namespace)::", "").replace("void ", "")
+        depth, cut = 0, len(d)
+        for i, ch in enumerate(d):
+            depth += ch == "<"
+            depth -= ch == ">"
+            if ch == "(" and depth == 0:
+                cut = i
+                break
+        return d[:cut].replace(" ", "")[:72]
     n = int(m.group(1))
     base, rest = name[m.end():m.end() + n], name[m.end() + n:]
     args = []
@@ -43,6 +51,20 @@ def short(name):
             else:
                 break
     return base + ("<" + ",".join(args) + ">" if args else "")
+
+
+# bench.py kernel key (block kind + level : step) -> the kernel instantiation that runs it, where that is one-to-one
+BENCH_KEY = (("lvit1:proj_mlp_fused", "k_mlp2<6,"), ("lvit2:proj_mlp_fused", "k_mlp2<12,"), ("lvit1:embed_ln_qkv", "k_embed_qkv2<6,"),
+             ("lvit2:embed_ln_qkv", "k_embed_qkv2<12,"))
+
+
+def bench_kernels(rows):
+    out = {}
+    for key, frag in BENCH_KEY:
+        for r in rows:
+            if r["kernel"].startswith(frag) and r["hbm_bytes_per_launch"] is not None:
+                out[key] = {"kernel": r["kernel"], "hbm_bytes_per_launch": round(r["hbm_bytes_per_launch"])}
+    return out
 
 
 def load(path):
@@ -112,7 +134,7 @@ def main():
                                                         1024.0 * write[k]["WRITE_SIZE"] / max(1.0, write[k]["n"]) if k in write else 0.0, r["hbm_bytes_per_launch"]))
         json.dump({"source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes), fetch doubled per the gfx950 guide; keyed by kernel symbol",
                    "kernels": {r["kernel"]: {"hbm_bytes_per_launch": round(r["hbm_bytes_per_launch"])} for r in rows if r["hbm_bytes_per_launch"] is not None},
-                   "bench_kernels": {}}, open(out + "_pmc_traffic.json", "w"), indent=1)
+                   "bench_kernels": bench_kernels(rows)}, open(out + "_pmc_traffic.json", "w"), indent=1)
 
 
 if __name__ == "__main__":
