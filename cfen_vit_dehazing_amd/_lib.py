@@ -40,6 +40,12 @@ class MlpArgsC(ctypes.Structure):
                [(n, ctypes.c_int32) for n in ("mapH", "mapW", "C", "cs", "ws", "p")]
 
 
+class LvitArgsC(ctypes.Structure):
+    _fields_ = [("fmap", c_void_p), ("out", c_void_p)] + [(n, ctypes.c_int32) for n in ("B", "H", "W", "C", "cs_in", "cs_out", "ws", "p")] + \
+               [(n, c_void_p) for n in ("we", "be", "pos", "ln1_gamma", "ln1_beta", "wkv", "wq", "wp", "ln2_gamma", "ln2_beta",
+                                        "w1a", "b1a", "w2a", "b2a", "w1b", "b1b", "w2b", "b2b")] + [("hidden", ctypes.c_int32), ("eps", c_float)]
+
+
 # every symbol include/cfen_hip.h declares: (restype, argtypes)
 _I = c_int
 _P = c_void_p
@@ -73,6 +79,7 @@ SIGNATURES = {
     "cfen_attention": (_I, [_I, _P, _P, _I, _I, _I, _I, _P]),
     "cfen_attention_head_major": (_I, [_I, _P, _P, _I, _I, _I, _I, _P]),
     "cfen_mlp_block": (_I, [_I, ctypes.POINTER(MlpArgsC), _P]),
+    "cfen_lvit_window": (_I, [_I, ctypes.POINTER(LvitArgsC), _P]),
     "cfen_patchify": (_I, [_I, _P, _P] + [_I] * 8 + [_P]),
     "cfen_unpatchify": (_I, [_I, _P, _P] + [_I] * 7 + [_P]),
     "cfen_upsample4": (_I, [_I, _P, _P] + [_I] * 6 + [_P]),

@@ -8,6 +8,8 @@
 #include "cfen_conv.hpp"
 #include "cfen_internal.hpp"
 #include "cfen_mlp.hpp"
+#include "cfen_lvit.hpp"
+#include <math.h>
 
 static thread_local char g_err[512] = "";
 
@@ -56,6 +58,14 @@ int cfen_mlp_block(int dtype, const cfen_mlp_args* a, void* stream) {
   m.M = a->M; m.D = a->D; m.H = a->H; m.eps = a->eps;
   m.mapH = a->mapH; m.mapW = a->mapW; m.C = a->C; m.cs = a->cs; m.ws = a->ws; m.p = a->p;
   return cfen_mlp_impl(dtype, &m, (hipStream_t)stream);
+}
+
+int cfen_lvit_window(int dtype, const cfen_lvit_args* a, void* stream) {
+  CFEN_CHECK_ARG(a != nullptr, "lvit_window: null args");
+  LvitArgs v{a->fmap, a->out, a->B, a->H, a->W, a->C, a->cs_in, a->cs_out, a->ws, a->p, a->we, a->be, a->pos, a->ln1_gamma, a->ln1_beta,
+             a->wkv, a->wq, a->wp, a->ln2_gamma, a->ln2_beta, a->w1a, a->b1a, a->w2a, a->b2a, a->w1b, a->b1b, a->w2b, a->b2b, a->hidden, a->eps,
+             1.4426950408889634f / sqrtf(24.f)};
+  return cfen_lvit_window_impl_g(dtype, 1, &v, (hipStream_t)stream);
 }
 
 int cfen_patchify(int dtype, const void* fmap, void* tokens, int B, int H, int W, int C, int cs, int ws, int p, int pool, void* stream) {
@@ -133,6 +143,14 @@ int cfen_tune(const char* key, int value) {
   }
   if (!strcmp(key, "mlp.small_tiles")) {
     cfen_tune_mlp_small_tiles() = value;
+    return CFEN_OK;
+  }
+  if (!strcmp(key, "lvit.shape")) {
+    cfen_tune_lvit_shape() = value;
+    return CFEN_OK;
+  }
+  if (!strcmp(key, "net.lvit_window")) {
+    cfen_tune_lvit_window() = value != 0;
     return CFEN_OK;
   }
   if (!strcmp(key, "net.attn_head_major")) {

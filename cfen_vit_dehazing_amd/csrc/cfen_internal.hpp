@@ -79,5 +79,6 @@ int& cfen_tune_mlp_small_tiles();   // fused-MLP tiling ("mlp.small_tiles"): 0 2
 int& cfen_tune_skip_classes();    // bit mask of kernel classes NOT launched by the net (marginal-cost timing; outputs invalid) ("net.skip_classes")
 int& cfen_tune_fused_front_max_dim();   // k_embed_qkv is used for LViT embedding dims <= this (0 = never) ("net.fused_front_max_dim")
 int& cfen_tune_gemm_splitk();     // 1 (default): K-heavy few-token GEMMs run split-K when the caller provides scratch ("gemm.splitk")
+int& cfen_tune_lvit_window();        // 1 (default): LViT level 1 runs as one k_lvit_window launch per instance group ("net.lvit_window")
 int& cfen_tune_attn_head_major();   // 1 (default): LViT levels with a fused front half hand qkv to attention head-major ("net.attn_head_major")
 int& cfen_tune_embed_lds();        // k_embed_qkv weights through LDS: bit 0 for D = 96, bit 1 for D = 192 ("embed.lds")

@@ -5,6 +5,7 @@
 //
 // Workspace layout = one NHWC buffer per top-level stage output (so parity tests can read every
 // stage of SURVEY Appendix D after a forward) + token scratch shared by all 24 transformer blocks.
+#include <math.h>
 #include <stdlib.h>
 #include <algorithm>
 #include <map>
@@ -16,6 +17,7 @@
 #include "cfen_conv.hpp"
 #include "cfen_internal.hpp"
 #include "cfen_mlp.hpp"
+#include "cfen_lvit.hpp"
 
 int& cfen_tune_skip_classes() {
   static int v = 0;
@@ -26,6 +28,10 @@ int& cfen_tune_fused_front_max_dim() {
   return v;
 }
 int& cfen_tune_embed_gather() {
+  static int v = 1;
+  return v;
+}
+int& cfen_tune_lvit_window() {
   static int v = 1;
   return v;
 }
@@ -52,6 +58,7 @@ struct Vit {
   int ws;     // window edge on that map
   bool fused_mlp;   // LN2+FFN+mlp_head+fold run as one k_mlp launch
   bool fused_front; // gather+embedding+LN1+qkv run as one k_embed_qkv launch
+  bool fused_window;// the whole block runs as one k_lvit_window launch (one workgroup per window)
 };
 struct ConvLayer {
   int kind, k, stride, pad, reflect, nsrc, Cin, Cin_real, Cout, Cout_pad, Kpad, nphase, ntaps, out_edge;
@@ -260,6 +267,7 @@ int cfen_net::build() {
   for (Vit& v : vits) {
     v.fused_mlp = !v.global && cfen_mlp_supported(v.D, v.hidden, cfg.dtype);
     v.fused_front = !v.global && cfen_embed_qkv_supported(v.D);
+    v.fused_window = !v.global && v.fused_mlp && v.fused_front && cfen_lvit_window_supported(cfg.dtype, v.D, v.heads, v.S, v.hidden);
     CFEN_CHECK_ARG(v.mapH % v.ws == 0 && v.ws % v.p == 0 && v.S >= 1, "net: %s does not tile its map", v.name.c_str());
     const size_t ntok = (size_t)B * (v.mapH / v.ws) * (v.mapH / v.ws) * v.S;
     (v.global ? max_md_g : max_md_l) = std::max(v.global ? max_md_g : max_md_l, ntok * v.D);
@@ -268,6 +276,9 @@ int cfen_net::build() {
     const std::string& n = v.name;
     need(n + ".embed.w", (size_t)v.D * v.D * esz); need(n + ".embed.b", (size_t)v.D * 4);
     if (v.fused_front) { need(n + ".embed.wk", (size_t)v.D * v.D * esz); need(n + ".qkv.wk", (size_t)3 * v.D * v.D * esz); }
+    if (v.fused_window) {
+      need(n + ".lw.wkv", (size_t)2 * v.D * v.D * esz); need(n + ".lw.wq", (size_t)v.heads * 32 * v.D * esz); need(n + ".lw.wp", (size_t)v.heads * v.D * 32 * esz);
+    }
     need(n + ".pos", (size_t)v.S * v.D * esz);
     need(n + ".ln1.g", (size_t)v.D * 4); need(n + ".ln1.b", (size_t)v.D * 4);
     need(n + ".qkv.w", (size_t)3 * v.D * v.D * esz);
@@ -471,6 +482,20 @@ int cfen_net::run_vit_g(int ng, const VitCall* vc, int scr0) {
       for (int g = 0; g < ng; ++g) ws[g] = (float*)YN[g];
     return cfen_gemm_impl_g(dt, ng, gp, K, K, N, v.S, N, M, N, K, relu, tg, stream, ffn ? ws : nullptr, ffn ? scratch_stretch : 0);
   };
+  if (v.fused_window && cfen_tune_lvit_window()) {
+    // LViT level 1: one workgroup per window, embed -> attention -> MLP -> fold with q / k / v / attention output on chip (k_lvit.hip)
+    LvitArgs w[3];
+    for (int g = 0; g < ng; ++g) {
+      const std::string& n = nm[g];
+      w[g] = LvitArgs{IN[g], OUT[g], B, v.mapH, v.mapH, v.C, bi.cs, bo.cs, v.ws, v.p, P(n + ".embed.wk"), Pf(n + ".embed.b"), P(n + ".pos"),
+                      Pf(n + ".ln1.g"), Pf(n + ".ln1.b"), P(n + ".lw.wkv"), P(n + ".lw.wq"), P(n + ".lw.wp"), Pf(n + ".ln2.g"), Pf(n + ".ln2.b"),
+                      P(n + ".ffn1.wk"), Pf(n + ".ffn1.b"), P(n + ".ffn2.wk"), Pf(n + ".ffn2.b"), P(n + ".head1.wk"), Pf(n + ".head1.b"),
+                      P(n + ".head2.wk"), Pf(n + ".head2.b"), v.hidden, 1e-5f, 1.4426950408889634f / sqrtf((float)(v.D / v.heads))};
+    }
+    step("window_block_fused");
+    TRYP(K_MLP, 8 * Md * D * D + 4 * Md * v.S * D + 8 * Md * D * Hd + 2 * Md * D * D, cfen_lvit_window_impl_g(dt, ng, w, stream));
+    return CFEN_OK;
+  }
   const float* lg[3];
   const float* lb[3];
   bool head_major = false;   // the fused front half writes qkv per (window, head) for k_attention_hm

@@ -1,0 +1,461 @@
+// One LViT block per workgroup-window, everything between the input map and the output map on chip.
+//
+// Replaces, for an LViT instance with embedding dim D = 96 (level 1: C = 24, 4 heads of 24, 32x32-pixel windows = 256 tokens), the
+// launch chain k_embed_qkv2 -> k_attention_hm -> k_mlp2 and their X1 / QKV / ATT round trips through HBM:
+//   Crop2x2 + unfold + linear_encoding + residual + position          (v3:1025-1056, 1140-1143, 1166)
+//   norm1 + nn.MultiheadAttention(bias=False) + residual               (v3:1364-1371, 1383-1386)
+//   norm2 + linear1/ReLU/linear2 + residual, mlp_head + residual       (v3:1387-1389, 1173)
+//   fold + Join2x2                                                     (v3:1176-1186, 1046-1056)
+//
+// A workgroup of 8 waves owns ONE window; wave w owns its tokens 32w .. 32w+31 for the whole chain.  As in k_mlp2 / k_embed_qkv2 the
+// residual stream of a token tile lives in fp32 MFMA accumulators (rows = features, columns = tokens), an accumulator tile pair is the
+// B operand of the next GEMM, and every weight matrix streams through a two-stage LDS ring by LDS-DMA in 32-row chunks (one raw
+// s_barrier per chunk, next chunk in flight, fragment groups of three software-pipelined).  What is new:
+//   * K and V of the whole window (256 keys x 4 heads x 24 dims, fp16) stay in LDS (2 x 56 KB; a kernel node may use the CU's full
+//     160 KB of LDS -- tools/repro/lds_graph_probe.hip).  The K/V chunks of the qkv projection write their tiles there instead of HBM.
+//   * Attention is run as "an MLP whose activation is softmax(Q K^T) V": the chunk of head h carries W_q[h] (32 rows) and the
+//     32-column slice of the out-projection that belongs to h.  Q_h = W_q[h] LN1(x) comes out of the MFMA as the B operand of
+//     S^T = K_h Q_h^T (the rows of W_q[h] are laid out on the host so that the accumulator pair packs into natural d order, padded
+//     24 -> 32 with zero rows); the softmax runs in registers exactly as in k_attention_hm (V read as the transposed operand with
+//     ds_read_b64_tr_b16); O_h^T packs into the B operand of x += W_p[:, h] O_h.  Neither q, k, v nor the attention output ever
+//     exists in HBM.
+// HBM traffic of an instance: read the map once, write it once, weights from L2.
+#include <type_traits>
+#include "cfen_common.hpp"
+#include "cfen_lvit.hpp"
+
+namespace {
+
+template <int I, int N, class F>
+CFEN_DEV void lv_static_for(F&& f) {
+  if constexpr (I < N) {
+    f(std::integral_constant<int, I>{});
+    lv_static_for<I + 1, N>(f);
+  }
+}
+
+CFEN_DEV void lv_dma16(const void* g, unsigned char* l) {
+  __builtin_amdgcn_global_load_lds(g, (__attribute__((address_space(3))) void*)l, 16, 0, 0);
+}
+
+typedef __attribute__((__vector_size__(4 * sizeof(__fp16)))) __fp16 lv_fp16x4;
+CFEN_DEV half4 lv_read_tr4(const unsigned char* p) {
+  const lv_fp16x4 v = __builtin_amdgcn_ds_read_tr16_b64_v4f16((__attribute__((address_space(3))) lv_fp16x4*)p);
+  half4 o;
+  __builtin_memcpy(&o, &v, 8);
+  return o;
+}
+
+CFEN_DEV half8 lv_pack(floatx4 a, floatx4 b) {
+  half8 f = {(half_t)a[0], (half_t)a[1], (half_t)a[2], (half_t)a[3], (half_t)b[0], (half_t)b[1], (half_t)b[2], (half_t)b[3]};
+  return f;
+}
+
+// ND = D / 16 (6); NW waves x TM token tiles of 16 = the 256 tokens of one window (8 x 2 at two waves per SIMD, or 4 x 4 with one wave
+// per SIMD and the whole 512-register file); 4 heads of 24
+template <int ND, int NW, int TM>
+__global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(NW / 4, NW / 4))) void k_lvit_window(Grouped<LvitArgs> ga) {
+  typedef half_t T;
+  typedef half8 frag;
+  const LvitArgs& a = ga.g[blockIdx.z];
+  constexpr int KC = 32, S = 256, DH = 24, NH = 4;
+  static_assert(NW * TM * 16 == S, "one workgroup = one window");
+  constexpr int D = ND * 16, NCH = ND / 2;
+  static_assert(D == NH * DH && NCH == 3, "built for D = 96: 4 heads of 24, one fragment group per row tile");
+  constexpr int P1 = D * 2 + 32, PP1 = P1 / 16;            // R1: 32 weight rows of D, pitch 224 B
+  constexpr int P2 = 64 + 32, PP2 = P2 / 16;               // R2: D rows of a 32-wide k slice, pitch 96 B
+  constexpr int N1 = 32 * PP1 / 64, N2 = D * PP2 / 64;     // DMA wave-instructions per region (7, 9)
+  static_assert(32 * PP1 % 64 == 0 && D * PP2 % 64 == 0, "regions must be whole DMA instructions");
+  constexpr int NINS = N1 + N2 + 1, STAGE = NINS * 1024, NI = (NINS + NW - 1) / NW;
+  constexpr int R2 = N1 * 1024, R3 = (N1 + N2) * 1024;
+  constexpr int KVP = NH * DH * 2 + 32;                    // K / V row pitch: 4 heads x 24 dims, 224 B (= 32 mod 64)
+  constexpr int KOFF = 0, VOFF = S * KVP, RING = 2 * S * KVP;
+  static_assert(RING + 2 * STAGE <= 160 * 1024, "LDS");
+  __shared__ __attribute__((aligned(1024))) unsigned char lds[RING + 2 * STAGE];
+  unsigned char* ring = lds + RING;
+
+  const int tid = threadIdx.x, lane = tid & 63, r16 = lane & 15, h = lane >> 4;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int nhc = a.Hm / 32;
+  constexpr int NE = D / 32, NKV = 2 * D / 32, NA = NH;    // embedding / K+V / attention chunks
+  const int nchunks = NE + NKV + NA + 2 * nhc;
+
+  // ---- DMA plan (as k_mlp2): instruction i of this wave fills block i * NW + wave of the stage ----
+  unsigned off[NI];
+#pragma unroll
+  for (int i = 0; i < NI; ++i) {
+    const int blk = i * NW + wave;
+    if (blk < N1) {
+      const int id = blk * 64 + lane, row = id / PP1, col = min(id % PP1, PP1 - 3);
+      off[i] = (unsigned)(row * D * 2 + col * 16);
+    } else if (blk < N1 + N2) {
+      const int id = (blk - N1) * 64 + lane, row = id / PP2, col = min(id % PP2, PP2 - 3);
+      off[i] = (unsigned)((row << 8) | (col * 16));        // row and byte column of an R2 piece: the row stride depends on the chunk kind
+    } else {
+      off[i] = (unsigned)(min(lane, 7) * 16);
+    }
+  }
+  auto issue = [&](int t, int buf) {
+    const unsigned char* r1 = nullptr;
+    const unsigned char* r2 = nullptr;
+    const unsigned char* r3 = nullptr;
+    unsigned stride2 = 0;
+    if (t < NE) {
+      r1 = (const unsigned char*)a.We + (size_t)t * 32 * D * 2;
+    } else if (t < NE + NKV) {
+      r1 = (const unsigned char*)a.Wkv + (size_t)(t - NE) * 32 * D * 2;
+    } else if (t < NE + NKV + NA) {
+      const int hl = t - NE - NKV;
+      r1 = (const unsigned char*)a.Wq + (size_t)hl * 32 * D * 2;
+      r2 = (const unsigned char*)a.Wp + (size_t)hl * D * 64;
+      stride2 = 64;
+    } else {
+      const int m = t - NE - NKV - NA;
+      const bool sb = m >= nhc;
+      const int hc = sb ? m - nhc : m;
+      r1 = (const unsigned char*)(sb ? a.W1b : a.W1a) + (size_t)hc * 32 * D * 2;
+      r2 = (const unsigned char*)(sb ? a.W2b : a.W2a) + (size_t)hc * 64;
+      r3 = (const unsigned char*)(sb ? a.b1b : a.b1a) + (size_t)hc * 128;
+      stride2 = (unsigned)a.Hm * 2;
+    }
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+      const int blk = i * NW + wave;
+      unsigned char* dst = ring + buf * STAGE + blk * 1024;
+      if (blk < N1) lv_dma16(r1 + off[i], dst);
+      else if (blk < N1 + N2) { if (r2) lv_dma16(r2 + (off[i] >> 8) * stride2 + (off[i] & 255), dst); }
+      else if (blk < NINS) { if (r3) lv_dma16(r3 + off[i], dst); }
+    }
+  };
+  auto begin_chunk = [&](int t) -> const unsigned char* {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    if (t + 1 < nchunks) issue(t + 1, (t + 1) & 1);
+    return ring + (t & 1) * STAGE;
+  };
+  issue(0, 0);
+
+  // the 32 pad bytes of every K / V row are read by the last head's padded fragments: they must hold finite values
+  for (int r = tid; r < 2 * S; r += NW * 64) {
+    half8 z = Mma<T>::zero();
+    unsigned char* row = lds + (r < S ? KOFF : VOFF) + (r & (S - 1)) * KVP + NH * DH * 2;
+    *reinterpret_cast<half8*>(row) = z;
+    *reinterpret_cast<half8*>(row + 16) = z;
+  }
+
+  // ---- window / token geometry ----
+  const int nwx = a.W / a.ws, nwy = a.H / a.ws;
+  const int win = blockIdx.x;
+  const int wx = win % nwx, wy = (win / nwx) % nwy, b = win / (nwx * nwy);
+  const int tw = a.ws / a.p;                               // 16 tokens per window row
+  int tok[TM];
+  floatx4 acc[ND][TM];
+#pragma unroll
+  for (int j = 0; j < TM; ++j) {
+    const int t = wave * (TM * 16) + j * 16 + r16;
+    tok[j] = t;
+    const int y0 = wy * a.ws + (t / tw) * a.p, x0 = wx * a.ws + (t % tw) * a.p;
+    const T* pix = (const T*)a.fmap + (((size_t)b * a.H + y0) * a.W + x0) * a.cs_in;
+#pragma unroll
+    for (int i = 0; i < ND; ++i) {
+      const int f = i * 16 + 4 * h;
+      const int ij = f / a.C, c = f - ij * a.C;
+      acc[i][j] = load4<T>(pix + ((ij / a.p) * a.W + (ij % a.p)) * a.cs_in + c);
+    }
+  }
+  frag xb[NCH][TM];
+#pragma unroll
+  for (int j = 0; j < TM; ++j)
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) xb[c][j] = lv_pack(acc[c * 2][j], acc[c * 2 + 1][j]);
+#pragma unroll
+  for (int i = 0; i < ND; ++i) {
+    const floatx4 bb = *reinterpret_cast<const floatx4*>(a.be + i * 16 + 4 * h);
+#pragma unroll
+    for (int j = 0; j < TM; ++j) acc[i][j] += bb + load4<T>((const T*)a.pos + (size_t)tok[j] * D + i * 16 + 4 * h);
+  }
+
+  const int a1 = r16 * P1 + h * 16;            // lane part of an R1 fragment address
+  const int a2 = R2 + r16 * P2 + h * 16;       // ... R2
+  const int a3 = R3 + 16 * h;                  // ... bias vector
+  // R1 fragment group (row tile u of the chunk): NCH = 3 fragments
+  auto load_r1 = [&](const unsigned char* buf, int u, frag (&f)[3]) {
+#pragma unroll
+    for (int k = 0; k < 3; ++k) f[k] = *reinterpret_cast<const frag*>(buf + a1 + (u * 16) * P1 + k * 64);
+  };
+  // R2 fragment group: feature-row tiles 3 ig .. 3 ig + 2 of the chunk's 32-wide k slice
+  auto load_r2 = [&](const unsigned char* buf, int ig, frag (&f)[3]) {
+#pragma unroll
+    for (int k = 0; k < 3; ++k) f[k] = *reinterpret_cast<const frag*>(buf + a2 + ((ig * 3 + k) * 16) * P2);
+  };
+  auto layer_norm_to_xb = [&](const float* gamma, const float* beta) {
+#pragma unroll
+    for (int j = 0; j < TM; ++j) {
+      float sm = 0.f;
+#pragma unroll
+      for (int i = 0; i < ND; ++i) sm += acc[i][j][0] + acc[i][j][1] + acc[i][j][2] + acc[i][j][3];
+      sm = col_sum(sm);
+      const float mean = sm * (1.f / D);
+      float q = 0.f;
+#pragma unroll
+      for (int i = 0; i < ND; ++i)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float d = acc[i][j][r] - mean;
+          q += d * d;
+        }
+      q = col_sum(q);
+      const float rstd = rsqrtf(q * (1.f / D) + a.eps);
+#pragma unroll
+      for (int c = 0; c < NCH; ++c) {
+        floatx4 t2[2];
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+          const int i = c * 2 + u;
+          const floatx4 g = *reinterpret_cast<const floatx4*>(gamma + i * 16 + 4 * h);
+          const floatx4 bt = *reinterpret_cast<const floatx4*>(beta + i * 16 + 4 * h);
+          t2[u] = (acc[i][j] - mean) * rstd * g + bt;
+        }
+        xb[c][j] = lv_pack(t2[0], t2[1]);
+      }
+    }
+  };
+
+  // ---- y = W_e x + (b_e + x + pos): embedding chunks (accumulator indices are compile-time) ----
+  lv_static_for<0, NE>([&](auto cc) {
+    constexpr int c = decltype(cc)::value;
+    const unsigned char* buf = begin_chunk(c);
+    frag F[2][3];
+    load_r1(buf, 0, F[0]);
+    load_r1(buf, 1, F[1]);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int u = 0; u < 2; ++u)
+#pragma unroll
+      for (int k = 0; k < 3; ++k)
+#pragma unroll
+        for (int j = 0; j < TM; ++j) acc[c * 2 + u][j] = Mma<T>::mma(F[u][k], xb[k][j], acc[c * 2 + u][j]);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  });
+  layer_norm_to_xb(a.ln1_g, a.ln1_b);        // acc keeps x1 (the residual stream); xb = LN1(x1)
+
+  // ---- K and V of the window -> LDS: rows [0, 96) of Wkv are the K features of the 4 heads, rows [96, 192) the V features ----
+#pragma unroll 1
+  for (int c = 0; c < NKV; ++c) {
+    const unsigned char* buf = begin_chunk(NE + c);
+    frag F[2][3];
+    load_r1(buf, 0, F[0]);
+    load_r1(buf, 1, F[1]);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      floatx4 q[TM];
+#pragma unroll
+      for (int j = 0; j < TM; ++j) q[j] = floatx4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int k = 0; k < 3; ++k)
+#pragma unroll
+        for (int j = 0; j < TM; ++j) q[j] = Mma<T>::mma(F[u][k], xb[k][j], q[j]);
+      const int t = c * 2 + u;                           // feature tile 0..11: K tiles 0..5, V tiles 0..5
+      unsigned char* base = lds + (t < ND ? KOFF : VOFF) + (t < ND ? t : t - ND) * 32 + 8 * h;
+#pragma unroll
+      for (int j = 0; j < TM; ++j) {
+        const half4 v = {(half_t)q[j][0], (half_t)q[j][1], (half_t)q[j][2], (half_t)q[j][3]};
+        *reinterpret_cast<half4*>(base + tok[j] * KVP) = v;
+      }
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  }
+
+  // ---- attention, one head per chunk: Q_h = W_q[h] LN1(x) -> softmax(K_h Q_h^T) -> O_h -> x += W_p[:, h] O_h ----
+  const float cs = a.scale_log2;
+  const int li = lane & 15;
+  const int vlane = (4 * h + (li >> 2)) * KVP + (li & 3) * 8;     // tr-read: lane 4q+p of a 16-lane group -> key row q, columns 4p..4p+3
+#pragma unroll 1
+  for (int hl = 0; hl < NA; ++hl) {
+    const unsigned char* buf = begin_chunk(NE + NKV + hl);     // the first of these barriers also publishes every wave's K / V tiles
+    frag F[2][3];
+    load_r1(buf, 0, F[0]);
+    load_r1(buf, 1, F[1]);
+    __builtin_amdgcn_sched_barrier(0);
+    floatx4 hq[2][TM];
+#pragma unroll
+    for (int u = 0; u < 2; ++u)
+#pragma unroll
+      for (int j = 0; j < TM; ++j) hq[u][j] = floatx4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int u = 0; u < 2; ++u)
+#pragma unroll
+      for (int k = 0; k < 3; ++k)
+#pragma unroll
+        for (int j = 0; j < TM; ++j) hq[u][j] = Mma<T>::mma(F[u][k], xb[k][j], hq[u][j]);
+    frag att[TM];
+    const unsigned char* Kh = lds + KOFF + hl * (DH * 2) + r16 * KVP + h * 16;
+    const unsigned char* Vh = lds + VOFF + hl * (DH * 2) + vlane;
+#pragma unroll
+    for (int j = 0; j < TM; ++j) {
+      const frag qb = lv_pack(hq[0][j], hq[1][j]);           // Q_h^T for 16 queries: k slot 8h'+e holds d = 8h'+e (host row layout), d >= 24 zero
+      floatx4 st[S / 16];
+#pragma unroll
+      for (int t = 0; t < S / 16; ++t)
+        st[t] = Mma<T>::mma(*reinterpret_cast<const frag*>(Kh + (t * 16) * KVP), qb, floatx4{0.f, 0.f, 0.f, 0.f});
+      float mx = -1e30f;
+#pragma unroll
+      for (int t = 0; t < S / 16; ++t) mx = fmaxf(fmaxf(mx, fmaxf(st[t][0], st[t][1])), fmaxf(st[t][2], st[t][3]));
+      mx = col_max(mx);
+      const float mc = -mx * cs;
+      float rs = 0.f;
+#pragma unroll
+      for (int t = 0; t < S / 16; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float pv = __builtin_amdgcn_exp2f(fmaf(st[t][r], cs, mc));
+          st[t][r] = pv;
+          rs += pv;
+        }
+      floatx4 o[2] = {floatx4{0.f, 0.f, 0.f, 0.f}, floatx4{0.f, 0.f, 0.f, 0.f}};
+#pragma unroll
+      for (int kb = 0; kb < S / 32; ++kb) {
+        const frag pb = lv_pack(st[2 * kb], st[2 * kb + 1]);
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+          const half4 lo = lv_read_tr4(Vh + (kb * 32) * KVP + i * 32);
+          const half4 hi = lv_read_tr4(Vh + (kb * 32 + 16) * KVP + i * 32);
+          const frag va = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+          o[i] = __builtin_amdgcn_mfma_f32_16x16x32_f16(va, pb, o[i], 0, 0, 0);
+        }
+      }
+      const float inv = 1.f / col_sum(rs);
+      att[j] = lv_pack(o[0] * inv, o[1] * inv);              // rows d >= 24 of O^T are another head's values: W_p's columns for them are zero
+    }
+    // x += W_p[:, h] O_h
+    frag G[2][3];
+    load_r2(buf, 0, G[0]);
+    load_r2(buf, 1, G[1]);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int ig = 0; ig < 2; ++ig)
+#pragma unroll
+      for (int k = 0; k < 3; ++k)
+#pragma unroll
+        for (int j = 0; j < TM; ++j) acc[ig * 3 + k][j] = Mma<T>::mma(G[ig][k], att[j], acc[ig * 3 + k][j]);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  }
+
+  // ---- y1 = x + W2a relu(W1a LN2(x) + b1a) + b2a;  y2 = y1 + W2b relu(W1b y1 + b1b) + b2b (as k_mlp2, 32 hidden units a chunk) ----
+  layer_norm_to_xb(a.ln2_g, a.ln2_b);
+#pragma unroll
+  for (int i = 0; i < ND; ++i) {
+    const floatx4 bb = *reinterpret_cast<const floatx4*>(a.b2a + i * 16 + 4 * h);
+#pragma unroll
+    for (int j = 0; j < TM; ++j) acc[i][j] += bb;
+  }
+  auto mlp_chunk = [&](int t) {
+    const unsigned char* buf = begin_chunk(t);
+    frag F[2][3], G[2][3];
+    floatx4 bia[2];
+    load_r1(buf, 0, F[0]);
+    bia[0] = *reinterpret_cast<const floatx4*>(buf + a3);
+    load_r1(buf, 1, F[1]);
+    bia[1] = *reinterpret_cast<const floatx4*>(buf + a3 + 64);
+    __builtin_amdgcn_sched_barrier(0);
+    floatx4 hacc[2][TM];
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+#pragma unroll
+      for (int j = 0; j < TM; ++j) hacc[u][j] = bia[u];
+#pragma unroll
+      for (int k = 0; k < 3; ++k)
+#pragma unroll
+        for (int j = 0; j < TM; ++j) hacc[u][j] = Mma<T>::mma(F[u][k], xb[k][j], hacc[u][j]);
+      if (u == 0) {
+        load_r2(buf, 0, G[0]);
+        load_r2(buf, 1, G[1]);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+    frag hb[TM];
+#pragma unroll
+    for (int j = 0; j < TM; ++j) {
+      const half8 v = lv_pack(hacc[0][j], hacc[1][j]);
+      hb[j] = __builtin_elementwise_max(v, Mma<T>::zero());
+    }
+#pragma unroll
+    for (int ig = 0; ig < 2; ++ig)
+#pragma unroll
+      for (int k = 0; k < 3; ++k)
+#pragma unroll
+        for (int j = 0; j < TM; ++j) acc[ig * 3 + k][j] = Mma<T>::mma(G[ig][k], hb[j], acc[ig * 3 + k][j]);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  };
+  const int t0 = NE + NKV + NA;
+#pragma unroll 1
+  for (int t = 0; t < nhc; ++t) mlp_chunk(t0 + t);
+#pragma unroll
+  for (int j = 0; j < TM; ++j)
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) xb[c][j] = lv_pack(acc[c * 2][j], acc[c * 2 + 1][j]);
+#pragma unroll
+  for (int i = 0; i < ND; ++i) {
+    const floatx4 bb = *reinterpret_cast<const floatx4*>(a.b2b + i * 16 + 4 * h);
+#pragma unroll
+    for (int j = 0; j < TM; ++j) acc[i][j] += bb;
+  }
+#pragma unroll 1
+  for (int t = nhc; t < 2 * nhc; ++t) mlp_chunk(t0 + t);
+
+  // ---- fold + window join into the output map ----
+#pragma unroll
+  for (int j = 0; j < TM; ++j) {
+    const int t = tok[j];
+    const int y0 = wy * a.ws + (t / tw) * a.p, x0 = wx * a.ws + (t % tw) * a.p;
+#pragma unroll
+    for (int i = 0; i < ND; ++i) {
+      const int f = i * 16 + 4 * h;
+      const int ij = f / a.C, c = f - ij * a.C;
+      T* dst = (T*)a.out + (((size_t)b * a.H + y0 + ij / a.p) * a.W + x0 + ij % a.p) * a.cs_out + c;
+      store4<T>(dst, acc[i][j]);
+    }
+  }
+}
+
+}  // namespace
+
+int& cfen_tune_lvit_shape() {   // 0: 8 waves x 2 token tiles (two waves per SIMD); 1: 4 waves x 4 token tiles (one wave per SIMD, 512 registers)
+  static int v = 0;
+  return v;
+}
+
+bool cfen_lvit_window_supported(int dtype, int D, int heads, int S, int hidden) {
+  return dtype == 1 && D == 96 && heads == 4 && S == 256 && hidden > 0 && hidden % 32 == 0;
+}
+
+int cfen_lvit_window_impl_g(int dtype, int ng, const LvitArgs* ap, hipStream_t s) {
+  CFEN_CHECK_ARG(ng >= 1 && ng <= CFEN_MAX_GROUPS && ap, "lvit_window: 1..%d problems per launch", CFEN_MAX_GROUPS);
+  Grouped<LvitArgs> ga;
+  for (int g = 0; g < CFEN_MAX_GROUPS; ++g) ga.g[g] = ap[g < ng ? g : 0];
+  for (int g = 0; g < ng; ++g) {
+    const LvitArgs& a = ap[g];
+    const int D = a.p * a.p * a.C, tw = a.p ? a.ws / a.p : 0;
+    CFEN_CHECK_ARG(a.p > 0 && a.ws > 0 && a.ws % a.p == 0 && cfen_lvit_window_supported(dtype, D, 4, tw * tw, a.Hm),
+                   "lvit_window: fp16, C = 24, p = 2, 32-pixel windows (256 tokens of dim 96, 4 heads), hidden %% 32 == 0 only");
+    CFEN_CHECK_ARG(a.B > 0 && a.H % a.ws == 0 && a.W % a.ws == 0 && a.cs_in >= a.C && a.cs_out >= a.C && a.cs_in % 4 == 0 && a.cs_out % 4 == 0 && a.C % 4 == 0,
+                   "lvit_window: bad map geometry");
+    CFEN_CHECK_ARG(a.fmap && a.out && a.We && a.be && a.pos && a.ln1_g && a.ln1_b && a.Wkv && a.Wq && a.Wp && a.ln2_g && a.ln2_b && a.W1a && a.b1a &&
+                   a.W2a && a.b2a && a.W1b && a.b1b && a.W2b && a.b2b, "lvit_window: null pointer");
+    CFEN_CHECK_ARG(cfen_aligned16(a.fmap) && cfen_aligned16(a.out) && cfen_aligned16(a.We) && cfen_aligned16(a.be) && cfen_aligned16(a.pos) &&
+                   cfen_aligned16(a.ln1_g) && cfen_aligned16(a.ln1_b) && cfen_aligned16(a.Wkv) && cfen_aligned16(a.Wq) && cfen_aligned16(a.Wp) &&
+                   cfen_aligned16(a.ln2_g) && cfen_aligned16(a.ln2_b) && cfen_aligned16(a.W1a) && cfen_aligned16(a.b1a) && cfen_aligned16(a.W2a) &&
+                   cfen_aligned16(a.b2a) && cfen_aligned16(a.W1b) && cfen_aligned16(a.b1b) && cfen_aligned16(a.W2b) && cfen_aligned16(a.b2b),
+                   "lvit_window: pointers must be 16-byte aligned");
+    CFEN_CHECK_ARG(a.B == ap[0].B && a.H == ap[0].H && a.W == ap[0].W && a.Hm == ap[0].Hm, "lvit_window: grouped problems must have the same shape");
+  }
+  const long long blocks = (long long)ap[0].B * (ap[0].H / ap[0].ws) * (ap[0].W / ap[0].ws);
+  CFEN_CHECK_ARG(blocks > 0 && blocks < (1ll << 31), "lvit_window: bad grid");
+  if (cfen_tune_lvit_shape() == 1)
+    CFEN_LAUNCH((k_lvit_window<6, 4, 4>), dim3((unsigned)blocks, 1, ng), dim3(256), 0, s, ga);
+  else
+    CFEN_LAUNCH((k_lvit_window<6, 8, 2>), dim3((unsigned)blocks, 1, ng), dim3(512), 0, s, ga);
+  CFEN_CHECK_LAUNCH("lvit_window");
+  return CFEN_OK;
+}

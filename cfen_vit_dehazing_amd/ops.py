@@ -92,6 +92,23 @@ def mlp_block(x, w1a, b1a, w2a, b2a, ln=None, second=None, fold=None, proj=None)
     return out
 
 
+def lvit_window(fmap, C, ws, p, packed, name, hidden, cs_out=None, eps=1e-5):
+    """whole LViT block (C = 24, p = 2, ws = 32) map -> map in one launch; `packed` = packing.pack_vit + packing.pack_lvit_window entries of `name`"""
+    from ._lib import LvitArgsC
+    _cuda(fmap)
+    B, H, W, cs = fmap.shape
+    cs_out = cs if cs_out is None else cs_out
+    out = torch.zeros(B, H, W, cs_out, dtype=fmap.dtype, device=fmap.device)
+    g = lambda k: packed[name + k].data_ptr()
+    a = LvitArgsC(fmap=fmap.data_ptr(), out=out.data_ptr(), B=B, H=H, W=W, C=C, cs_in=cs, cs_out=cs_out, ws=ws, p=p,
+                  we=g(".embed.wk"), be=g(".embed.b"), pos=g(".pos"), ln1_gamma=g(".ln1.g"), ln1_beta=g(".ln1.b"),
+                  wkv=g(".lw.wkv"), wq=g(".lw.wq"), wp=g(".lw.wp"), ln2_gamma=g(".ln2.g"), ln2_beta=g(".ln2.b"),
+                  w1a=g(".ffn1.wk"), b1a=g(".ffn1.b"), w2a=g(".ffn2.wk"), b2a=g(".ffn2.b"),
+                  w1b=g(".head1.wk"), b1b=g(".head1.b"), w2b=g(".head2.wk"), b2b=g(".head2.b"), hidden=hidden, eps=eps)
+    check(_lib.load().cfen_lvit_window(dtype_code(fmap.dtype), ctypes.byref(a), current_stream()), "lvit_window")
+    return out
+
+
 def patchify(fmap, C, ws, p, pool=1):
     """fmap: NHWC [B,Hf,Wf,cs] -> tokens [B*nwin*S, p*p*C] in (i,j,c) feature order."""
     _cuda(fmap)

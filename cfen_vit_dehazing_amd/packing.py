@@ -55,6 +55,48 @@ def front_is_fused(g):
     return g.kind == "lvit" and g.dim in (96, 192)
 
 
+def lvit_q_rows(dh=24):
+    """Row layout of one head's W_q for k_lvit_window (csrc/k_lvit.hip): 32 rows = two 16-row MFMA tiles (a, b) such that the
+    accumulator tile PAIR packs into the next MFMA's B operand with k slot s holding head dim d = s: tile a row 4h+j is d = 8h+j,
+    tile b row 4h+j is d = 8h+4+j (h = 0..3, j = 0..3); -1 marks the zero rows of the padding dims d >= dh."""
+    rows = []
+    for half in (0, 4):
+        for r in range(16):
+            d = 8 * (r // 4) + half + r % 4
+            rows.append(d if d < dh else -1)
+    return rows
+
+
+def window_fusable(g, dtype):
+    """mirror of cfen_lvit_window_supported (csrc/k_lvit.hip): LViT level 1 (D = 96, 4 heads of 24, 256-token windows), fp16"""
+    return g.kind == "lvit" and dtype == torch.float16 and g.dim == 96 and g.heads == 4 and g.seq == 256 and g.hidden % 32 == 0
+
+
+def pack_lvit_window(sd, g, dtype):
+    """extra weight layouts of the one-workgroup-per-window LViT kernel: K/V rows, per-head W_q tiles, per-head out_proj slices"""
+    n, D, dh = g.name, g.dim, g.dim // g.heads
+    perm = token_perm(g.channels, g.patch)
+    kp = kperm32(D)
+    e = n + ".encoder.layers.0"
+    w_in = sd[e + ".self_attn.in_proj_weight"][:, perm][:, kp]            # [3D][D], input features in token order, k axis slotted
+    wq_all, wk, wv = w_in[:D], w_in[D:2 * D], w_in[2 * D:]
+    rows = lvit_q_rows(dh)
+    wq = torch.zeros(g.heads, 32, D, dtype=w_in.dtype, device=w_in.device)
+    for hd in range(g.heads):
+        for r, d in enumerate(rows):
+            if d >= 0:
+                wq[hd, r] = wq_all[hd * dh + d]
+    w_out = sd[e + ".self_attn.out_proj.weight"][perm]                    # [D][D]: rows in token order, columns = attention features
+    slot_d = kperm32(32)
+    wp = torch.zeros(g.heads, D, 32, dtype=w_in.dtype, device=w_in.device)
+    for hd in range(g.heads):
+        for s_, d in enumerate(slot_d.tolist()):
+            if d < dh:
+                wp[hd, :, s_] = w_out[:, hd * dh + d]
+    return {n + ".lw.wkv": torch.cat((wk, wv), 0).to(dtype).contiguous(), n + ".lw.wq": wq.to(dtype).contiguous(),
+            n + ".lw.wp": wp.to(dtype).contiguous()}
+
+
 def pack_vit(sd, g, dtype):
     n = g.name
     perm = token_perm(g.channels, g.patch)
@@ -79,6 +121,8 @@ def pack_vit(sd, g, dtype):
         for nm in ("embed", "qkv"):
             w = out[n + "." + nm + ".w"]
             out[n + "." + nm + ".wk"] = (w[:, kperm32(g.dim)] if dtype == torch.float16 else w).contiguous()
+    if window_fusable(g, dtype):
+        out.update(pack_lvit_window(sd, g, dtype))
     if mlp_is_fused(g, dtype):
         # the fused MLP kernel replaces the four separate GEMMs: same matrices, k axis re-slotted (fp16 only)
         for a, b in (("ffn1", "ffn2"), ("head1", "head2")):
