@@ -39,6 +39,14 @@ int cfen_gemm_nt(int dtype, const void* X, int ldx, const void* W, int ldw, cons
   return cfen_gemm_impl(dtype, X, ldx, W, ldw, bias, R, ldr, P, period, Y, ldy, M, N, K, relu, (hipStream_t)stream);
 }
 
+int cfen_gemm_ln(int dtype, const void* X, int ldx, const void* Wl, int ldw, const float* s, const float* bias, void* Y, int ldy, int M, int N,
+                 int K, int relu, float eps, void* stream) {
+  CFEN_CHECK_ARG(s != nullptr, "gemm_ln: the row sums of the folded weight are required");
+  CFEN_CHECK_ARG(eps == cfen_gemm_lnf_eps(), "gemm_ln: eps must be %g (the generator's only LayerNorm eps)", (double)cfen_gemm_lnf_eps());
+  const CfenGemmPtrs q{X, Wl, bias, nullptr, nullptr, Y, nullptr, s};
+  return cfen_gemm_impl_g(dtype, 1, &q, ldx, ldw, 0, 1, ldy, M, N, K, relu, nullptr, (hipStream_t)stream, nullptr, 0);
+}
+
 int cfen_layernorm(int dtype, const void* X, void* Y, const float* gamma, const float* beta, int M, int D, float eps, void* stream) {
   CFEN_CHECK_ARG(gamma && beta, "layernorm: gamma/beta required");
   return cfen_layernorm_impl(dtype, X, Y, gamma, beta, M, D, eps, (hipStream_t)stream);
@@ -131,6 +139,10 @@ int cfen_tune(const char* key, int value) {
   }
   if (!strcmp(key, "gemm.splitk")) {
     cfen_tune_gemm_splitk() = value != 0;
+    return CFEN_OK;
+  }
+  if (!strcmp(key, "net.ln_fold")) {
+    cfen_tune_ln_fold() = value != 0;
     return CFEN_OK;
   }
   if (!strcmp(key, "net.fused_front_max_dim")) {

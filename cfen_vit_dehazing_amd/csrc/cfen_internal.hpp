@@ -7,6 +7,7 @@ struct ConvDesc;
 
 int cfen_gemm_impl(int dtype, const void* X, int ldx, const void* W, int ldw, const float* bias, const void* R, int ldr, const void* P,
                    int period, void* Y, int ldy, int M, int N, int K, int relu, hipStream_t s);
+float& cfen_gemm_lnf_eps();   // LayerNorm eps used by the LN-folded GEMMs (1e-5, the only value the generator uses)
 // Y = tok W^T + bias + tok + P[m % period]  with tok = the patch tokens of an NHWC map, gathered by the GEMM's loader
 // (window partition + unfold + linear_encoding + residual + position add in one launch; v3:1025-1056,1140-1143,1166)
 struct CfenTokGather { const void* map; int B, H, W, C, cs, ws, p; };
@@ -25,7 +26,13 @@ struct CfenEmbedQkvArgs {
 bool cfen_embed_qkv_supported(int D);
 int cfen_embed_qkv_impl_g(int dtype, int ng, const CfenEmbedQkvArgs* a, hipStream_t s);
 // grouped launches (cfen_common.hpp: CFEN_MAX_GROUPS problems of identical geometry, one launch)
-struct CfenGemmPtrs { const void* X; const void* W; const float* bias; const void* R; const void* P; void* Y; const void* gmap; };
+struct CfenGemmPtrs {
+  const void* X; const void* W; const float* bias; const void* R; const void* P; void* Y; const void* gmap;
+  // LayerNorm folded into the GEMM (k_gemm_dma only): X is the un-normalised row x, W = W0 * gamma (columns scaled on the host),
+  // lnf_s[n] = sum_k W[n][k], bias = W0 beta + b0:  Y = act(rstd_m (x W^T - mean_m lnf_s) + bias) + ...; mean / rstd of every row are
+  // accumulated by the workgroup from the X tiles it stages anyway.  null = plain GEMM.
+  const float* lnf_s;
+};
 int cfen_gemm_impl_g(int dtype, int ng, const CfenGemmPtrs* gp, int ldx, int ldw, int ldr, int period, int ldy, int M, int N, int K, int relu,
                      const CfenTokGather* tg, hipStream_t s, float* const* splitk_ws, size_t splitk_ws_bytes);
 // tg: geometry only, the maps are gp[g].gmap.  splitk_ws (may be null): one fp32 scratch per problem for split-K partial sums
@@ -77,6 +84,7 @@ int& cfen_tune_embed_gather();  // 1 (default): LViT embedding gathers its token
 int& cfen_tune_mlp_small_tiles();   // fused-MLP tiling ("mlp.small_tiles"): 0 256/128 tokens per 4-wave WG at 1 wave/SIMD, 1 half-size token tiles at
                                     // 2 waves/SIMD, 2 as 1 but TM = 2 for D = 192 (register-capped), 3 (default) 8-wave WGs: half the weight re-streaming
 int& cfen_tune_skip_classes();    // bit mask of kernel classes NOT launched by the net (marginal-cost timing; outputs invalid) ("net.skip_classes")
+int& cfen_tune_ln_fold();               // 1: LN1 / LN2 of the blocks without a fused kernel ride on the qkv / ffn1 GEMM ("net.ln_fold")
 int& cfen_tune_fused_front_max_dim();   // k_embed_qkv is used for LViT embedding dims <= this (0 = never) ("net.fused_front_max_dim")
 int& cfen_tune_gemm_splitk();     // 1 (default): K-heavy few-token GEMMs run split-K when the caller provides scratch ("gemm.splitk")
 int& cfen_tune_lvit_window();        // 1 (default): LViT level 1 runs as one k_lvit_window launch per instance group ("net.lvit_window")

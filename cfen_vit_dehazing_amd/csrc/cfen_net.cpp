@@ -23,6 +23,10 @@ int& cfen_tune_skip_classes() {
   static int v = 0;
   return v;
 }
+int& cfen_tune_ln_fold() {
+  static int v = 1;
+  return v;
+}
 int& cfen_tune_fused_front_max_dim() {
   static int v = 192;
   return v;
@@ -58,6 +62,7 @@ struct Vit {
   int ws;     // window edge on that map
   bool fused_mlp;   // LN2+FFN+mlp_head+fold run as one k_mlp launch
   bool fused_front; // gather+embedding+LN1+qkv run as one k_embed_qkv launch
+  bool ln_fold1, ln_fold2;   // LN1 / LN2 ride on the qkv / ffn1 GEMM (k_gemm_dma row statistics + folded weights), no LayerNorm launch
   bool fused_window;// the whole block runs as one k_lvit_window launch (one workgroup per window)
 };
 struct ConvLayer {
@@ -268,6 +273,8 @@ int cfen_net::build() {
     v.fused_mlp = !v.global && cfen_mlp_supported(v.D, v.hidden, cfg.dtype);
     v.fused_front = !v.global && cfen_embed_qkv_supported(v.D);
     v.fused_window = !v.global && v.fused_mlp && v.fused_front && cfen_lvit_window_supported(cfg.dtype, v.D, v.heads, v.S, v.hidden);
+    v.ln_fold1 = !v.fused_front && (v.D * esz) % 128 == 0;
+    v.ln_fold2 = !v.fused_mlp && (v.D * esz) % 128 == 0;
     CFEN_CHECK_ARG(v.mapH % v.ws == 0 && v.ws % v.p == 0 && v.S >= 1, "net: %s does not tile its map", v.name.c_str());
     const size_t ntok = (size_t)B * (v.mapH / v.ws) * (v.mapH / v.ws) * v.S;
     (v.global ? max_md_g : max_md_l) = std::max(v.global ? max_md_g : max_md_l, ntok * v.D);
@@ -283,6 +290,8 @@ int cfen_net::build() {
     need(n + ".ln1.g", (size_t)v.D * 4); need(n + ".ln1.b", (size_t)v.D * 4);
     need(n + ".qkv.w", (size_t)3 * v.D * v.D * esz);
     need(n + ".proj.w", (size_t)v.D * v.D * esz);
+    if (v.ln_fold1) { need(n + ".qkv.wl", (size_t)3 * v.D * v.D * esz); need(n + ".qkv.s", (size_t)3 * v.D * 4); need(n + ".qkv.bl", (size_t)3 * v.D * 4); }
+    if (v.ln_fold2) { need(n + ".ffn1.wl", (size_t)v.hidden * v.D * esz); need(n + ".ffn1.s", (size_t)v.hidden * 4); need(n + ".ffn1.bl", (size_t)v.hidden * 4); }
     need(n + ".ln2.g", (size_t)v.D * 4); need(n + ".ln2.b", (size_t)v.D * 4);
     const char* wn = v.fused_mlp ? ".wk" : ".w";
     need(n + ".ffn1" + wn, (size_t)v.hidden * v.D * esz); need(n + ".ffn1.b", (size_t)v.hidden * 4);
@@ -473,7 +482,7 @@ int cfen_net::run_vit_g(int ng, const VitCall* vc, int scr0) {
     CfenGemmPtrs gp[3];
     for (int g = 0; g < ng; ++g)
       gp[g] = CfenGemmPtrs{tg ? nullptr : X[g], P(nm[g] + wname), bname ? Pf(nm[g] + bname) : nullptr, R ? R[g] : nullptr,
-                           pname ? P(nm[g] + pname) : nullptr, Y[g], tg ? IN[g] : nullptr};
+                           pname ? P(nm[g] + pname) : nullptr, Y[g], tg ? IN[g] : nullptr, nullptr};
     // split-K scratch: the YN | ATT | QKV stretch of the member's scratch set (contiguous, 5 * md elements), free while the
     // FFN / mlp_head GEMMs run -- the only K-heavy ones
     float* ws[3] = {nullptr, nullptr, nullptr};
@@ -481,6 +490,13 @@ int cfen_net::run_vit_g(int ng, const VitCall* vc, int scr0) {
     if (ffn)
       for (int g = 0; g < ng; ++g) ws[g] = (float*)YN[g];
     return cfen_gemm_impl_g(dt, ng, gp, K, K, N, v.S, N, M, N, K, relu, tg, stream, ffn ? ws : nullptr, ffn ? scratch_stretch : 0);
+  };
+  // Y = act(LN(X) W0^T + b0) with the LayerNorm folded: parameters `lname`.wl / .s / .bl (packing.ln_folded)
+  auto gemm_ln = [&](const void* const* X, const std::string& lname, void* const* Y, int N, int K, int relu) -> int {
+    CfenGemmPtrs gp[3];
+    for (int g = 0; g < ng; ++g)
+      gp[g] = CfenGemmPtrs{X[g], P(nm[g] + lname + ".wl"), Pf(nm[g] + lname + ".bl"), nullptr, nullptr, Y[g], nullptr, Pf(nm[g] + lname + ".s")};
+    return cfen_gemm_impl_g(dt, ng, gp, K, K, N, v.S, N, M, N, K, relu, nullptr, stream, nullptr, 0);
   };
   if (v.fused_window && cfen_tune_lvit_window()) {
     // LViT level 1: one workgroup per window, embed -> attention -> MLP -> fold with q / k / v / attention output on chip (k_lvit.hip)
@@ -523,11 +539,16 @@ int cfen_net::run_vit_g(int ng, const VitCall* vc, int scr0) {
       TRYP(K_GEMM, 2 * Md * D * D, gemm(nullptr, ".embed.w", ".embed.b", nullptr, ".pos", X1, v.D, v.D, 0, &tg));
     }
     // src = src + out_proj(MHA(LN1(src)))                                      (v3:1383-1386)
-    step("ln1");
-    for (int g = 0; g < ng; ++g) { lg[g] = Pf(nm[g] + ".ln1.g"); lb[g] = Pf(nm[g] + ".ln1.b"); }
-    TRYP(K_LNORM, 0, cfen_layernorm_impl_g(dt, ng, cX1, YN, lg, lb, M, v.D, 1e-5f, stream));
-    step("qkv");
-    TRYP(K_GEMM, 6 * Md * D * D, gemm(cYN, ".qkv.w", nullptr, nullptr, nullptr, QKV, 3 * v.D, v.D, 0, nullptr));
+    if (v.ln_fold1 && cfen_tune_ln_fold()) {
+      step("ln1_qkv");
+      TRYP(K_GEMM, 6 * Md * D * D, gemm_ln(cX1, ".qkv", QKV, 3 * v.D, v.D, 0));
+    } else {
+      step("ln1");
+      for (int g = 0; g < ng; ++g) { lg[g] = Pf(nm[g] + ".ln1.g"); lb[g] = Pf(nm[g] + ".ln1.b"); }
+      TRYP(K_LNORM, 0, cfen_layernorm_impl_g(dt, ng, cX1, YN, lg, lb, M, v.D, 1e-5f, stream));
+      step("qkv");
+      TRYP(K_GEMM, 6 * Md * D * D, gemm(cYN, ".qkv.w", nullptr, nullptr, nullptr, QKV, 3 * v.D, v.D, 0, nullptr));
+    }
   }
   step("attention");
   if (head_major)
@@ -557,12 +578,17 @@ int cfen_net::run_vit_g(int ng, const VitCall* vc, int scr0) {
     TRYP(K_MLP, 8 * Md * D * Hd + 2 * Md * D * D, cfen_mlp_impl_g(dt, ng, m, stream));
   } else {
     // src = src + linear2(relu(linear1(LN2(src))))                             (v3:1387-1389)
-    step("ln2");
-    for (int g = 0; g < ng; ++g) { lg[g] = Pf(nm[g] + ".ln2.g"); lb[g] = Pf(nm[g] + ".ln2.b"); }
-    TRYP(K_LNORM, 0, cfen_layernorm_impl_g(dt, ng, cX1, YN, lg, lb, M, v.D, 1e-5f, stream));
     const void* const* cHID = cHIDp;
-    step("ffn1");
-    TRYP(K_GEMM, 2 * Md * D * Hd, gemm(cYN, ".ffn1.w", ".ffn1.b", nullptr, nullptr, HID, v.hidden, v.D, 1, nullptr));
+    if (v.ln_fold2 && cfen_tune_ln_fold()) {
+      step("ln2_ffn1");
+      TRYP(K_GEMM, 2 * Md * D * Hd, gemm_ln(cX1, ".ffn1", HID, v.hidden, v.D, 1));
+    } else {
+      step("ln2");
+      for (int g = 0; g < ng; ++g) { lg[g] = Pf(nm[g] + ".ln2.g"); lb[g] = Pf(nm[g] + ".ln2.b"); }
+      TRYP(K_LNORM, 0, cfen_layernorm_impl_g(dt, ng, cX1, YN, lg, lb, M, v.D, 1e-5f, stream));
+      step("ffn1");
+      TRYP(K_GEMM, 2 * Md * D * Hd, gemm(cYN, ".ffn1.w", ".ffn1.b", nullptr, nullptr, HID, v.hidden, v.D, 1, nullptr));
+    }
     step("ffn2");
     TRYP(K_GEMM, 2 * Md * D * Hd, gemm(cHID, ".ffn2.w", ".ffn2.b", X1, nullptr, X1, v.D, v.hidden, 0, nullptr));
     // x = mlp_head(x) + x                                                      (v3:1173)

@@ -60,6 +60,9 @@ template <typename T> struct GemmArgs {
   // k_gemm_splitk_finish adds them in slice order and applies the epilogue -- deterministic, no atomics
   float* part;
   int nsplit;
+  // optional LayerNorm fold (k_gemm_dma, nsplit == 1, K = the whole row): see CfenGemmPtrs::lnf_s
+  const float* lnf_s;
+  float lnf_eps;
 };
 
 // pointer to channel 0 of the top-left pixel of token m's patch
@@ -79,6 +82,20 @@ template <typename T> CFEN_DEV int gather_off(const GemmArgs<T>& a, int k) {
 // Epilogue of the 3 x 4 tile block of one wave: the lane owns Y[m + 16 j][n + 16 i .. +3].  All residual / position
 // loads are issued before the first store (R may alias Y element for element -- in-place residual -- so the compiler
 // must not be left to order them: it would wait for every load separately), bias is read once.
+// LN-fold: acc <- rstd_m * (acc - mean_m * s_n) for the lane's (token m + 16 j, features n + 16 i .. +3); stats[row] = (mean, rstd)
+template <typename T, int TM>
+CFEN_DEV void gemm_lnfold(const GemmArgs<T>& a, floatx4 (&acc)[3][TM], int n, const float* stats, int mloc) {
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {
+    const floatx4 sn = n + 16 * i < a.N ? *reinterpret_cast<const floatx4*>(a.lnf_s + n + 16 * i) : floatx4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int j = 0; j < TM; ++j) {
+      const float mean = stats[2 * (mloc + 16 * j)], rstd = stats[2 * (mloc + 16 * j) + 1];
+      acc[i][j] = (acc[i][j] - sn * mean) * rstd;
+    }
+  }
+}
+
 template <typename T, int TM>
 CFEN_DEV void gemm_epilogue(const GemmArgs<T>& a, floatx4 (&acc)[3][TM], int n, int m) {
   typedef typename Mma<T>::out4 out4;
@@ -289,6 +306,11 @@ __global__ __launch_bounds__(256) void k_gemm_dma(Grouped<GemmArgs<T>> ga) {
 #pragma unroll
   for (int st = 0; st < NS - 1; ++st)
     if (st < nk) CFEN_GEMM_DMA_ISSUE(st, st);
+  // LN-fold: thread (row = tid / 8 (+ 32 per extra token tile), piece = tid % 8) sums x and x^2 of its 16 bytes of every staged X tile
+  float ls[TM], lq[TM];
+#pragma unroll
+  for (int j = 0; j < TM; ++j) ls[j] = lq[j] = 0.f;
+  const int lnoff = (G_BN + (tid >> 3)) * G_BKB + (tid & 7) * 16;
   int buf = 0, fill = NS - 1;   // ring slots: `buf` is consumed at this step, `fill` receives K-step kt + NS - 1
   for (int kt = 0; kt < nk; ++kt) {
     // K-step kt must have landed; the younger K-steps (at most NS - 2 groups of LOADS DMAs) may stay in flight
@@ -299,6 +321,15 @@ __global__ __launch_bounds__(256) void k_gemm_dma(Grouped<GemmArgs<T>> ga) {
     __builtin_amdgcn_s_barrier();   // K-step kt visible to all waves; all waves are done with the slot consumed at kt - 1
     if (kt + NS - 1 < nk) CFEN_GEMM_DMA_ISSUE(kt + NS - 1, fill);
     const unsigned char* st = lds + buf * STAGE;
+    if (a.lnf_s) {
+#pragma unroll
+      for (int j = 0; j < TM; ++j) {
+        float v[EPL];
+        Vec16<T>::load(reinterpret_cast<const T*>(st + lnoff + j * 32 * G_BKB), v);
+#pragma unroll
+        for (int e = 0; e < EPL; ++e) { ls[j] += v[e]; lq[j] += v[e] * v[e]; }
+      }
+    }
 #pragma unroll
     for (int c = 0; c < NCH; ++c) {
       const int po = ((c * 4 + h) ^ sw) << 4;
@@ -326,6 +357,25 @@ __global__ __launch_bounds__(256) void k_gemm_dma(Grouped<GemmArgs<T>> ga) {
       for (int i = 0; i < 3; ++i)
         if (m + 16 * j < a.M && n + 16 * i < a.N) *reinterpret_cast<floatx4*>(pp + (size_t)(m + 16 * j) * a.N + n + 16 * i) = acc[i][j];
     return;
+  }
+  if (a.lnf_s) {   // row statistics: reduce the 8 threads of a row (8 consecutive lanes), publish (mean, rstd) per row through LDS
+    __builtin_amdgcn_s_barrier();            // every wave is done reading the last stage: the ring is free
+    float* stats = reinterpret_cast<float*>(lds);
+#pragma unroll
+    for (int j = 0; j < TM; ++j) {
+      float sv = ls[j], qv = lq[j];
+      sv += dpp_mov<0xB1>(sv); qv += dpp_mov<0xB1>(qv);
+      sv += dpp_mov<0x4E>(sv); qv += dpp_mov<0x4E>(qv);
+      sv += dpp_mov<0x141>(sv); qv += dpp_mov<0x141>(qv);
+      if ((tid & 7) == 0) {
+        const float mean = sv / (float)a.K;
+        const float var = fmaxf(qv / (float)a.K - mean * mean, 0.f);
+        stats[2 * ((tid >> 3) + 32 * j)] = mean;
+        stats[2 * ((tid >> 3) + 32 * j) + 1] = rsqrtf(var + a.lnf_eps);
+      }
+    }
+    __syncthreads();
+    gemm_lnfold<T, TM>(a, acc, n0 + wn * 48 + 4 * h, stats, wm * 16 * TM + r16);
   }
   gemm_epilogue<T, TM>(a, acc, n0 + wn * 48 + 4 * h, m0 + wm * 16 * TM + r16);
 #undef CFEN_GEMM_DMA_ISSUE
@@ -436,12 +486,18 @@ int launch_gemm(int ng, const CfenGemmPtrs* gp, int ldx, int ldw, int ldr, int p
     a.X = (const T*)(tg ? q.gmap : q.X); a.W = (const T*)q.W; a.bias = q.bias; a.R = (const T*)q.R; a.P = (const T*)q.P; a.Y = (T*)q.Y;
     a.M = M; a.N = N; a.K = K; a.ldx = ldx; a.ldw = ldw; a.ldr = ldr; a.ldy = ldy; a.period = period; a.relu = relu;
     a.nsplit = 1;
+    a.lnf_s = q.lnf_s;
+    a.lnf_eps = cfen_gemm_lnf_eps();
     if (tg) {
       a.gmap = (const T*)q.gmap; a.gH = tg->H; a.gW = tg->W; a.gcs = tg->cs; a.gC = tg->C; a.gws = tg->ws; a.gp = tg->p;
     }
   }
-  const int forced = cfen_tune_gemm_kernel();
+  const bool lnf = gp[0].lnf_s != nullptr;
+  for (int g = 0; g < ng; ++g)
+    CFEN_CHECK_ARG((gp[g].lnf_s != nullptr) == lnf && cfen_aligned16(gp[g].lnf_s), "gemm: grouped problems must all (or none) fold a LayerNorm");
+  const int forced = lnf ? -1 : cfen_tune_gemm_kernel();
   const bool k128 = (K * (int)sizeof(T)) % G_BKB == 0;
+  CFEN_CHECK_ARG(!lnf || (k128 && !tg), "gemm (LayerNorm fold): needs K * sizeof(T) %% 128 == 0 and a plain token matrix");
   CFEN_CHECK_ARG(forced <= 0 || k128, "gemm: k_gemm_skinny / k_gemm_dma need K * sizeof(T) %% 128 == 0");
   // Kernel choice from kernel times measured with COLD caches (tools/bench_gemm_cold.py: in the network the 540 MB of
   // weights stream from HBM, a warm-cache microbenchmark picks the wrong variants), MI355X, batch 8:
@@ -455,14 +511,14 @@ int launch_gemm(int ng, const CfenGemmPtrs* gp, int ldx, int ldw, int ldr, int p
   // K-heavy GEMMs with a handful of tokens (GViT-3 ffn2 / head2: 128 x 1536 x 6144): one 96 x 128 tile per feature block
   // so the weights are read once, K cut into slices for parallelism, partial sums reduced by a second tiny launch
   int nsplit = 1;
-  if (forced < 0 && k128 && splitk_ws && !tg && M <= 128 && K >= 4 * N && cfen_tune_gemm_splitk()) {
+  if (forced < 0 && k128 && splitk_ws && !tg && !lnf && M <= 128 && K >= 4 * N && cfen_tune_gemm_splitk()) {
     const int nk = K / (G_BKB / (int)sizeof(T));
     nsplit = 8;
     while (nsplit > 1 && (nk % nsplit || (size_t)nsplit * M * N * sizeof(float) > splitk_ws_bytes)) nsplit /= 2;
     if (nsplit > 1) { kern = 2; stages = 2; }
   }
   if (kern < 0) {
-    const int pick = !k128 ? 0 : (M <= 128 && N <= 2048 && !tg) ? 1 : tiles64 >= 1024 ? cfen_tune_gemm_large() : tiles32 <= 512 ? cfen_tune_gemm_small() : 5;
+    const int pick = !k128 ? 0 : (M <= 128 && N <= 2048 && !tg && !lnf) ? 1 : tiles64 >= 1024 ? cfen_tune_gemm_large() : tiles32 <= 512 ? cfen_tune_gemm_small() : 5;
     kern = pick % 10;
     stages = 2 + pick / 10;
   }
@@ -501,6 +557,10 @@ int launch_gemm(int ng, const CfenGemmPtrs* gp, int ldx, int ldw, int ldr, int p
 
 }  // namespace
 
+float& cfen_gemm_lnf_eps() {
+  static float v = 1e-5f;
+  return v;
+}
 int& cfen_tune_gemm_splitk() {
   static int v = 1;
   return v;
@@ -528,7 +588,7 @@ int cfen_gemm_impl_g(int dtype, int ng, const CfenGemmPtrs* gp, int ldx, int ldw
 
 int cfen_gemm_impl(int dtype, const void* X, int ldx, const void* W, int ldw, const float* bias, const void* R, int ldr,
                    const void* P, int period, void* Y, int ldy, int M, int N, int K, int relu, hipStream_t s) {
-  const CfenGemmPtrs q{X, W, bias, R, P, Y, nullptr};
+  const CfenGemmPtrs q{X, W, bias, R, P, Y, nullptr, nullptr};
   return cfen_gemm_impl_g(dtype, 1, &q, ldx, ldw, ldr, period, ldy, M, N, K, relu, nullptr, s, nullptr, 0);
 }
 
@@ -536,6 +596,6 @@ int cfen_embed_gather_impl(int dtype, const CfenTokGather* tg, const void* W, in
                            void* Y, int ldy, int M, hipStream_t s) {
   CFEN_CHECK_ARG(tg != nullptr, "embed_gather: null geometry");
   const int D = tg->p * tg->p * tg->C;
-  const CfenGemmPtrs q{nullptr, W, bias, nullptr, P, Y, tg->map};
+  const CfenGemmPtrs q{nullptr, W, bias, nullptr, P, Y, tg->map, nullptr};
   return cfen_gemm_impl_g(dtype, 1, &q, D, ldw, 0, period, ldy, M, D, D, 0, tg, s, nullptr, 0);
 }

@@ -37,6 +37,17 @@ def gemm_nt(x, w, bias=None, residual=None, pos=None, relu=False, out=None):
     return out
 
 
+def gemm_ln(x, wl, s, bias=None, relu=False, eps=1e-5):
+    """act(LayerNorm-statistics(x) applied to x @ wl.T: rstd (x wl^T - mean s) + bias); wl / s / bias from packing.ln_folded"""
+    _cuda(x, wl, s, bias)
+    M, K = x.shape
+    N = wl.shape[0]
+    out = torch.empty(M, N, dtype=x.dtype, device=x.device)
+    check(_lib.load().cfen_gemm_ln(dtype_code(x.dtype), ptr(x), K, ptr(wl), K, ptr(s), ptr(bias), ptr(out), N, M, N, K, int(relu), eps,
+                                   current_stream()), "gemm_ln")
+    return out
+
+
 def layernorm(x, gamma, beta, eps=1e-5):
     _cuda(x, gamma, beta)
     out = torch.empty_like(x)

@@ -97,6 +97,16 @@ def pack_lvit_window(sd, g, dtype):
             n + ".lw.wp": wp.to(dtype).contiguous()}
 
 
+def ln_folded(w_packed, gamma, beta, bias, name, dtype, w_full):
+    """entries `name`.wl / .s / .bl of a Linear that follows a LayerNorm (gamma, beta): see pack_vit"""
+    w64 = w_full.double()
+    wl = (w64 * gamma.double()[None, :]).to(dtype)
+    bl = w64 @ beta.double()
+    if bias is not None:
+        bl = bl + bias.double()
+    return {name + ".wl": wl.contiguous(), name + ".s": wl.double().sum(1).float(), name + ".bl": bl.float()}
+
+
 def pack_vit(sd, g, dtype):
     n = g.name
     perm = token_perm(g.channels, g.patch)
@@ -115,6 +125,14 @@ def pack_vit(sd, g, dtype):
         n + ".head1.w": sd[n + ".mlp_head.0.weight"][:, perm].to(dtype), n + ".head1.b": sd[n + ".mlp_head.0.bias"].to(f32),
         n + ".head2.w": sd[n + ".mlp_head.3.weight"][perm].to(dtype), n + ".head2.b": sd[n + ".mlp_head.3.bias"][perm].to(f32),
     }
+    # LayerNorm folded into the following GEMM (csrc/k_gemm.hip: CfenGemmPtrs::lnf_s) wherever the block is not a fused kernel:
+    # LN(x) W^T + b = rstd (x (W gamma)^T - mean s) + (W beta + b) with s = row sums of the ROUNDED W gamma (so the mean cancels exactly)
+    if not front_is_fused(g):
+        out.update(ln_folded(out[n + ".qkv.w"], out[n + ".ln1.g"], out[n + ".ln1.b"], None, n + ".qkv", dtype,
+                             sd[e + ".self_attn.in_proj_weight"][:, perm]))
+    if not mlp_is_fused(g, dtype):
+        out.update(ln_folded(out[n + ".ffn1.w"], out[n + ".ln2.g"], out[n + ".ln2.b"], out[n + ".ffn1.b"], n + ".ffn1", dtype,
+                             sd[e + ".linear1.weight"][:, perm]))
     if front_is_fused(g):
         # same matrices, k axis re-slotted so that accumulator tile pairs feed the MFMA directly (fp16 only)
         # (the plain layout stays: "net.fused_front" can switch the fused kernel off per embedding dim)

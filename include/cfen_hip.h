@@ -43,6 +43,7 @@ const char* cfen_last_error(void);
  *                  D = 96 variant, ones digit: D = 192 variant, see k_mlp.hip);  "net.fused_front_max_dim": largest LViT embedding dim that uses k_embed_qkv
  *   "net.skip_classes": bit mask of kernel classes the net does NOT launch (what-if timing only, outputs invalid)
  *   "net.attn_head_major": 1 (default) LViT levels with a fused front half pass qkv to attention per (window, head); 0 row-major [M][3D]
+ *   "net.ln_fold": 1 (default) LN1 / LN2 of GViT and LViT level 3 are folded into the qkv / ffn1 GEMMs (cfen_gemm_ln), 0 separate LayerNorm launches
  *   "net.embed_gather": 1 (default) the LViT embedding GEMM gathers its patch tokens from the map, 0 separate patchify launch
  *                  (read when a forward is enqueued or a graph is built)
  *   "gemm.large" / "gemm.small": the k_gemm_dma tile (2..5) the shape rule uses for problems with >= / < 1024 tiles of 96 x 64 */
@@ -117,6 +118,12 @@ double cfen_net_flops_per_image(const cfen_net* net);
 /* Y[m][n] = act(sum_k X[m][k] W[n][k] + bias[n]) + R[m][n] + P[m % period][n]      (nn.Linear family) */
 int cfen_gemm_nt(int dtype, const void* X, int ldx, const void* W, int ldw, const float* bias, const void* R, int ldr, const void* P,
                  int period, void* Y, int ldy, int M, int N, int K, int relu, void* stream);
+/* Linear after a LayerNorm with the LayerNorm folded into the GEMM (TransformerEncoderLayer norm1 -> in_proj, norm2 -> linear1: v3:1383-1389):
+ *   Y[m][n] = act(rstd_m (sum_k X[m][k] Wl[n][k] - mean_m s[n]) + bias[n]),  mean_m / rstd_m = LayerNorm statistics of row m of X over K,
+ * with Wl = W * gamma (columns), s[n] = sum_k Wl[n][k] of the ROUNDED Wl, bias = W beta + b -- what cfen_net_forward runs for the blocks
+ * that have no fused kernel (GViT, LViT level 3).  K * element size must be a multiple of 128 bytes; eps must be 1e-5. */
+int cfen_gemm_ln(int dtype, const void* X, int ldx, const void* Wl, int ldw, const float* s, const float* bias, void* Y, int ldy, int M, int N,
+                 int K, int relu, float eps, void* stream);
 /* LViT token embedding without a token buffer: tok = patchify(fmap) (window partition + unfold, as cfen_patchify with pool 1)
  * is gathered by the GEMM's loader;  Y[m][n] = sum_k tok[m][k] W[n][k] + bias[n] + tok[m][n] + pos[m % period][n],
  * D = p*p*C, W is [D][D] (ldw), Y is [M][D] (ldy).                                        (v3:1140-1143, 1166) */

@@ -76,6 +76,28 @@ def test_layernorm(dtype, M, D):
     close(ops.layernorm(x.to(dev()), g.to(dev()), b.to(dev())), want, tol(dtype, 4))
 
 
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("M,D,N,relu", [(2048, 384, 1152, 0), (100, 384, 768, 1), (32, 1536, 4608, 0), (7, 3072, 96, 1), (300, 6144, 192, 1)])
+def test_gemm_with_layernorm_folded(dtype, M, D, N, relu):
+    """norm1 -> in_proj and norm2 -> linear1 (v3:1383-1389) as ONE GEMM on the un-normalised rows (cfen_gemm_ln, packing.ln_folded);
+    rows carry a mean of half their spread, like the residual stream, so the mean * s cancellation is exercised"""
+    from cfen_vit_dehazing_amd.packing import ln_folded
+    x = rnd((M, D), 1, dtype, 2.0) + 1.0
+    w = rnd((N, D), 2, torch.float32, D ** -0.5)
+    g, b, bias = 1 + 0.1 * rnd((D,), 3, torch.float32), 0.1 * rnd((D,), 4, torch.float32), rnd((N,), 5, torch.float32)
+    want = cfen_oracle.layer_norm(x.double(), g.double(), b.double()) @ w.double().t() + bias.double()
+    if relu:
+        want = want.relu()
+    f = ln_folded(None, g, b, bias, "l", dtype, w)
+    got = ops.gemm_ln(x.to(dev()), f["l.wl"].to(dev()), f["l.s"].to(dev()), f["l.bl"].to(dev()), relu=bool(relu))
+    close(got, want, tol(dtype, 8))
+    if D > 2048:   # cfen_layernorm's own limit (the generator's widest token is 1536)
+        return
+    # the same numbers through the two-launch path the fold replaces
+    two = ops.gemm_nt(ops.layernorm(x.to(dev()), g.to(dev()), b.to(dev())), w.to(dtype).to(dev()), bias.to(dev()), relu=bool(relu))
+    close(two, want, tol(dtype, 8))
+
+
 def attn_ref(qkv, nseq, S, heads):
     D = qkv.shape[1] // 3
     dh = D // heads
