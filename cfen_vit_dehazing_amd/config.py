@@ -10,7 +10,10 @@ from types import SimpleNamespace
 
 BRANCHES = ("r", "s", "d")
 # opt.model_G -> variant of the generator family (reference models/model_iid_dehazing.py:84-95)
-VARIANTS = {"iid_hlgvit_crs_gd4_cfs_v3": "v3", "iid_hlgvit_crs_gd4_cfs": "cfs"}
+VARIANTS = {"iid_hlgvit_crs_gd4_cfs_v3": "v3", "iid_hlgvit_crs_gd4_cfs": "cfs", "iid_hlgvit_crs_gd4": "crs", "iid_hlgvit_crs_gd4_cfs_v5": "v5"}
+# variants whose three levels run at the image's own resolution (no ds_conv_e01 / us_conv_d01*, n_feats channels in head and tails,
+# tail_color shared by R and D): networks_iid_hlgvit_crs_gd4_cfs.py:368 and networks_iid_hlgvit_crs_gd4.py:368 (xf = head(input))
+FULL_RES_VARIANTS = ("cfs", "crs")
 
 
 @dataclass(frozen=True)
@@ -19,12 +22,19 @@ class VitGeom:
     name: str
     kind: str          # "lvit" | "gvit"
     level: int         # 1..3
-    channels: int      # C of the feature map it runs on
+    channels: int      # C of the map its tokens are cut from (v5 LViT: the conv_shrink output, a quarter of the level's channels)
     patch: int         # 2 (LViT) or 4 (GViT, after 4x avg-pool)
     seq: int           # tokens per window / per pooled image
     dim: int           # embedding dim D = C * patch^2
     heads: int
     hidden: int        # FFN / mlp_head hidden width
+    shrink: int = 1    # v5 LViT (networks_iid_hlgvit_crs_gd4_cfs_v5.py:1101-1106,1139,1190): 1x1 conv_shrink to C/4 channels in front of
+                       # the block and conv_extend back to C behind it; `channels`, `dim`, `hidden` are the shrunk sizes
+
+    @property
+    def map_channels(self):
+        """channels of the level's feature map the instance reads and writes"""
+        return self.channels * self.shrink
 
 
 @dataclass(frozen=True)
@@ -42,12 +52,16 @@ class NetConfig:
     def image_size(self):
         """v3 runs its three levels on a stride-2 down-sampled map (ds_conv_e01, v3:297-298, 396); `cfs` keeps full resolution
         (networks_iid_hlgvit_crs_gd4_cfs.py:368: xf = head(input)), so there the image IS the level-1 map."""
-        return self.load_size if self.variant == "cfs" else 2 * self.load_size
+        return self.load_size if self.variant in FULL_RES_VARIANTS else 2 * self.load_size
 
     @property
     def head_channels(self):
         """channels of the head CNN / tails: n_feats/2 at twice the resolution (v3:123-127), n_feats at level-1 resolution (cfs :117-121)"""
-        return self.n_feats if self.variant == "cfs" else self.n_feats // 2
+        return self.n_feats if self.variant in FULL_RES_VARIANTS else self.n_feats // 2
+
+    @property
+    def full_res(self):
+        return self.variant in FULL_RES_VARIANTS
 
     def level_channels(self, level):
         return self.n_feats << (level - 1)
@@ -65,6 +79,8 @@ class NetConfig:
             raise ValueError("only patch_dim=2 is supported (reference default)")
         if self.n_feats % 8 != 0:
             raise ValueError("n_feats must be a multiple of 8")
+        if self.variant == "v5" and (self.n_feats // 4 * self.patch_dim ** 2) % self.num_heads:
+            raise ValueError("v5: the shrunk embedding dim (n_feats) must be divisible by num_heads")
         if (self.load_size // 4) % 16 != 0 and self.load_size // 16 < 1:
             raise ValueError("loadSize too small")
 
@@ -76,9 +92,11 @@ class NetConfig:
 
         def lv(name, level):
             c = self.level_channels(level)
+            shrink = 4 if self.variant == "v5" else 1        # v5:1086-1097: embedding_dim // 4, hidden_dim // 4, num_channels // 4
+            c //= shrink
             d = c * p * p
             return VitGeom(name, "lvit", level, c, p, seq_l, d, self.num_heads << (level - 1),
-                           d * self.hidden_dim_ratio)
+                           d * self.hidden_dim_ratio, shrink)
 
         def gv(name, level):
             c = self.level_channels(level)

@@ -21,7 +21,13 @@ from .config import NetConfig, BRANCHES
 
 def _vit_entries(g, with_dead=True):
     D, H, S = g.dim, g.hidden, g.seq
-    e = [
+    e = []
+    if g.shrink > 1:       # v5 LViT: conv_shrink / conv_extend = Conv2d 1x1 + ActNorm2d (+ ReLU), registered first (v5:1101-1104)
+        c, cm = g.channels, g.map_channels
+        for nm, cout, cin in (("conv_shrink", c, cm), ("conv_extend", cm, c)):
+            e += [(nm + ".0.weight", (cout, cin, 1, 1)), (nm + ".0.bias", (cout,)), (nm + ".1.weight", (cout,)), (nm + ".1.bias", (cout,)),
+                  (nm + ".1.initialized", ())]
+    e += [
         ("linear_encoding.weight", (D, D)), ("linear_encoding.bias", (D,)),
         ("mlp_head.0.weight", (H, D)), ("mlp_head.0.bias", (H,)),
         ("mlp_head.3.weight", (D, H)), ("mlp_head.3.bias", (D,)),
@@ -57,7 +63,8 @@ def state_manifest(cfg: NetConfig, with_dead=True):
     """[(key, shape, torch.dtype)] in the reference's state_dict order."""
     nf = cfg.n_feats
     h = cfg.head_channels
-    cfs = cfg.variant == "cfs"      # networks_iid_hlgvit_crs_gd4_cfs.py: no ds_conv_e01 / us_conv_d01*, tail_color shared by R and D
+    cfs = cfg.full_res              # networks_iid_hlgvit_crs_gd4_cfs.py / ..._crs_gd4.py: no ds_conv_e01 / us_conv_d01*, tail_color shared by R and D
+    crs = cfg.variant == "crs"      # networks_iid_hlgvit_crs_gd4.py:327-330,364: D's skip fuse is a 1x1 conv over three maps, + a never-called SpatialPyramid
     out = []
 
     def add(k, shape, dtype=torch.float32):
@@ -71,7 +78,7 @@ def state_manifest(cfg: NetConfig, with_dead=True):
     add("head.0.1.body.2.weight", (h, h, 3, 3)); add("head.0.1.body.2.bias", (h,))
     for g in cfg.vit_instances():
         for k, shape in _vit_entries(g, with_dead):
-            add(g.name + "." + k, shape, torch.int64 if k.endswith("position_ids") else torch.float32)
+            add(g.name + "." + k, shape, torch.int64 if k.endswith(("position_ids", ".initialized")) else torch.float32)
 
     def conv_an(name, cout, cin, k=1):
         add(name + ".0.weight", (cout, cin, k, k)); add(name + ".0.bias", (cout,))
@@ -97,7 +104,10 @@ def state_manifest(cfg: NetConfig, with_dead=True):
     for b in ("r", "s"):
         conv_an("sk_conv_d03" + b, 2 * nf, 4 * nf)
         conv_an("sk_conv_d02" + b, nf, 2 * nf)
-    for nm, c in (("cfsm2g_d03d.0", 2 * nf), ("cfsm2g_d02d.0", nf)):
+    if crs:
+        conv_an("sk_conv_d03d", 2 * nf, 6 * nf)
+        conv_an("sk_conv_d02d", nf, 3 * nf)
+    for nm, c in (() if crs else (("cfsm2g_d03d.0", 2 * nf), ("cfsm2g_d02d.0", nf))):
         bk = c // 4
         for fc in ("fc_avg_cf1", "fc_avg_cf2", "fc_max_cf1", "fc_max_cf2"):
             add("%s.%s.0.weight" % (nm, fc), (bk, c, 1, 1))
@@ -109,12 +119,20 @@ def state_manifest(cfg: NetConfig, with_dead=True):
         add(t + ".0.5.weight", (cout, h, 7, 7)); add(t + ".0.5.bias", (cout,))
     add(gray + ".0.1.weight", (h, h, 3, 3)); add(gray + ".0.1.bias", (h,))
     add(gray + ".0.4.weight", (1, h, 7, 7)); add(gray + ".0.4.bias", (1,))
+    if crs and with_dead:           # SpatialPyramid (crs:1441-1465), constructed at crs:364, its only call is commented out (crs:985)
+        add("sp.refine1.weight", (32, 10, 3, 3)); add("sp.refine1.bias", (32,))
+        add("sp.refine2.weight", (32, 32, 3, 3)); add("sp.refine2.bias", (32,))
+        for k in ("1010", "1020", "1030", "1040", "1050"):
+            add("sp.conv%s.weight" % k, (16, 32, 1, 1)); add("sp.conv%s.bias" % k, (16,))
+        add("sp.refine3.0.weight", (3, 112, 3, 3)); add("sp.refine3.0.bias", (3,))
+        for k, c in (("batch20", 20), ("batch1", 1)):
+            add("sp.%s.weight" % k, (c,)); add("sp.%s.bias" % k, (c,)); add("sp.%s.initialized" % k, (), torch.int64)
     return out
 
 
 def _is_dead(key):
     return (".decoder." in key or key.endswith("query_embed.weight")
-            or key.startswith("sub_mean.") or key.startswith("add_mean."))
+            or key.startswith("sub_mean.") or key.startswith("add_mean.") or key.startswith("sp."))
 
 
 def _gen_reference_init(key, shape, g):

@@ -147,12 +147,33 @@ def vit_tokens(sd, prefix, tok, heads, taps=None):
     return x
 
 
-def lvit(sd, prefix, x, heads, ws, p=2):
-    """All windows of one LViT instance at once. x: (B,C,H,W)."""
+def lvit(sd, prefix, x, heads, ws, p=2, shrink=False):
+    """All windows of one LViT instance at once. x: (B,C,H,W).
+    shrink (networks_iid_hlgvit_crs_gd4_cfs_v5.py:1139,1190): Conv2d 1x1 C -> C/4 + ActNorm2d + ReLU in front of the tokens and the
+    mirror-image conv_extend behind the fold.  Both are per-pixel once the ActNorm is initialised, so they commute with the window split;
+    an UNINITIALISED ActNorm there takes its statistics from the module's first call = the first window of the reference's crop
+    recursion (the top-left one, v5:403-410), all B images."""
     B, C, H, W = x.shape
+    if shrink:
+        y = F.conv2d(x, sd[prefix + ".conv_shrink.0.weight"], sd[prefix + ".conv_shrink.0.bias"])
+        _actnorm_first_window(sd, prefix + ".conv_shrink.1", y, ws)
+        x = torch.relu(actnorm(sd, prefix + ".conv_shrink.1", y))
+        C = x.shape[1]
     xw = window_partition(x, ws)
     t = vit_tokens(sd, prefix, unfold_tokens(xw, p), heads)
-    return window_merge(fold_tokens(t, C, ws, ws, p), B, H, W)
+    out = window_merge(fold_tokens(t, C, ws, ws, p), B, H, W)
+    if shrink:
+        y = F.conv2d(out, sd[prefix + ".conv_extend.0.weight"], sd[prefix + ".conv_extend.0.bias"])
+        _actnorm_first_window(sd, prefix + ".conv_extend.1", y, ws)
+        out = torch.relu(actnorm(sd, prefix + ".conv_extend.1", y))
+    return out
+
+
+def _actnorm_first_window(sd, prefix, y, ws):
+    if int(sd[prefix + ".initialized"]) != 1:
+        w, b = actnorm_init_params(y[:, :, :ws, :ws])
+        sd[prefix + ".weight"], sd[prefix + ".bias"] = w, b
+        sd[prefix + ".initialized"] = torch.tensor(1)
 
 
 def gvit(sd, prefix, x, heads, p=4):
@@ -224,9 +245,14 @@ def forward(sd, x, num_heads=4, patch_size=32, stages=None, variant="v3"):
     """dec_ipt.forward (v3:392-1020).  x: (B,3,H,W) in [-1,1] -> [xr (B,3,H,W), xs (B,1,H,W), xd (B,3,H,W)].
     If `stages` is a dict it receives the 58 top-level stage outputs named as in SURVEY Appendix D.
     variant "cfs" = models/networks_iid_hlgvit_crs_gd4_cfs.py:362-980: the same three levels run on the head's own (full-resolution)
-    output -- no ds_conv_e01 / us_conv_d01* -- and the tails (tail_color shared by R and D, tail_gray for S) read `d_01 + xf` directly."""
+    output -- no ds_conv_e01 / us_conv_d01* -- and the tails (tail_color shared by R and D, tail_gray for S) read `d_01 + xf` directly.
+    variant "crs" = models/networks_iid_hlgvit_crs_gd4.py:366-987: as "cfs" with sk_conv_d03d / sk_conv_d02d (1x1 conv over the three
+    decoders' upsampled maps) where cfs has CFSM2G.  variant "v5" = models/networks_iid_hlgvit_crs_gd4_cfs_v5.py: v3 whose LViT blocks
+    sit between a 1x1 conv_shrink (C -> C/4) and conv_extend (C/4 -> C), v5:1139,1190."""
     ws = patch_size
-    cfs = variant == "cfs"
+    cfs = variant in ("cfs", "crs")
+    crs = variant == "crs"          # networks_iid_hlgvit_crs_gd4.py:854,889: D's skip fuse is sk_conv_d0Xd over cat(D, R, S) instead of CFSM2G
+    v5 = variant == "v5"            # networks_iid_hlgvit_crs_gd4_cfs_v5.py: v3 with the LViT blocks on a quarter of the channels
 
     def rec(name, t):
         if stages is not None:
@@ -241,7 +267,7 @@ def forward(sd, x, num_heads=4, patch_size=32, stages=None, variant="v3"):
         else:
             ln, gn, cn = ("localvit_decoder_0%d%s" % (l, tag), "globalvit_decoder_0%d%s" % (l, tag),
                           "lgcat_conv_d0%d%s" % (l, tag))
-        lo = rec(ln, lvit(sd, ln, xin, heads, ws))
+        lo = rec(ln, lvit(sd, ln, xin, heads, ws, shrink=v5))
         gl = rec(gn, gvit(sd, gn, xin, heads))
         return rec(cn, conv_actnorm_relu(sd, cn, torch.cat((lo, gl), 1)) + xin)
 
@@ -259,14 +285,18 @@ def forward(sd, x, num_heads=4, patch_size=32, stages=None, variant="v3"):
         d3 = level(t, 3, x_e_03)
         u3 = rec("us_conv_d03" + t, us_conv(sd, "us_conv_d03" + t, d3, "in"))
         ups[(t, 3)] = u3
-        if t == "d":
+        if t == "d" and crs:
+            in2 = rec("sk_conv_d03d", conv_actnorm_relu(sd, "sk_conv_d03d", torch.cat((u3, ups[("r", 3)], ups[("s", 3)]), 1)))   # crs:854
+        elif t == "d":
             in2 = rec("cfsm2g_d03d", cfsm2g(sd, "cfsm2g_d03d.0", u3, ups[("r", 3)], ups[("s", 3)]))   # v3:885
         else:
             in2 = rec("sk_conv_d03" + t, conv_actnorm_relu(sd, "sk_conv_d03" + t, torch.cat((u3, x_e_02), 1)))
         d2 = level(t, 2, in2)
         u2 = rec("us_conv_d02" + t, us_conv(sd, "us_conv_d02" + t, d2, "an"))
         ups[(t, 2)] = u2
-        if t == "d":
+        if t == "d" and crs:
+            in1 = rec("sk_conv_d02d", conv_actnorm_relu(sd, "sk_conv_d02d", torch.cat((u2, ups[("r", 2)], ups[("s", 2)]), 1)))   # crs:889
+        elif t == "d":
             in1 = rec("cfsm2g_d02d", cfsm2g(sd, "cfsm2g_d02d.0", u2, ups[("r", 2)], ups[("s", 2)]))   # v3:920
         else:
             in1 = rec("sk_conv_d02" + t, conv_actnorm_relu(sd, "sk_conv_d02" + t, torch.cat((u2, x_e_01), 1)))

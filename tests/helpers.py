@@ -14,8 +14,17 @@ GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 def load_net_fixture(name):
     z = np.load(os.path.join(GOLDEN, "net_%s.npz" % name))
     nf, hdr, ps, ls = [int(v) for v in z["cfg"]]
-    cfg = NetConfig(nf, hdr, patch_size=ps, load_size=ls, variant="cfs" if name.startswith("cfs") else "v3")
+    cfg = NetConfig(nf, hdr, patch_size=ps, load_size=ls, variant=variant_of(name))
     return cfg, int(z["batch"]), z
+
+
+def variant_of(name):
+    """fixture name -> generator variant (config.VARIANTS): [refinit_]{cfs,crs,v5}_* are the sibling generators, the rest is v3"""
+    base = name[len("refinit_"):] if name.startswith("refinit_") else name
+    for v in ("cfs", "crs", "v5"):
+        if base.startswith(v + "_"):
+            return v
+    return "v3"
 
 
 def weight_mode(name):

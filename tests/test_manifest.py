@@ -17,14 +17,19 @@ CASES = {
     "full1024_nf24_hdr4": NetConfig(24, 4, patch_size=64, load_size=512),
     "cfs_tiny_nf24_hdr4": NetConfig(24, 4, patch_size=8, load_size=64, variant="cfs"),       # networks_iid_hlgvit_crs_gd4_cfs.py
     "cfs_full256_nf24_hdr4": NetConfig(24, 4, patch_size=32, load_size=256, variant="cfs"),
+    "crs_tiny_nf24_hdr4": NetConfig(24, 4, patch_size=8, load_size=64, variant="crs"),       # networks_iid_hlgvit_crs_gd4.py
+    "crs_full256_nf24_hdr4": NetConfig(24, 4, patch_size=32, load_size=256, variant="crs"),
+    "v5_tiny_nf24_hdr4": NetConfig(24, 4, patch_size=8, load_size=64, variant="v5"),         # networks_iid_hlgvit_crs_gd4_cfs_v5.py
+    "v5_full512_nf24_hdr4": NetConfig(24, 4, patch_size=32, load_size=256, variant="v5"),
 }
+N_KEYS = {"cfs": 934, "crs": 950, "v5": 1078}
 
 
 @pytest.mark.parametrize("name", sorted(CASES))
 def test_manifest_matches_reference_listing(name, golden_dir):
     want = [l.split() for l in open(os.path.join(golden_dir, "state_manifest_%s.txt" % name)) if l.strip()]
     got = state_manifest(CASES[name])
-    assert len(got) == len(want) == (934 if name.startswith("cfs") else 958)
+    assert len(got) == len(want) == N_KEYS.get(name.split("_")[0], 958)
     for (k, shape, dt), (wk, wshape, wdt) in zip(got, want):
         assert k == wk
         assert ("x".join(str(s) for s in shape) or "scalar") == wshape, k

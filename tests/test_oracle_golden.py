@@ -38,7 +38,14 @@ def test_oracle_reference_init_weights_and_actnorm_first_call():
     _run("refinit_tiny_nf24_hdr4")
 
 
-@pytest.mark.parametrize("name", ["tiny_nf24_hdr4", "tiny_nf24_hdr2", "small_nf24_hdr4", "cfs_tiny_nf24_hdr4"])
+def test_oracle_v5_actnorm_first_call_takes_the_first_window():
+    """v5's conv_shrink / conv_extend ActNorm2d sit inside the LViT module, which the reference calls once per window: their
+    data-dependent init sees the top-left window only (networks_iid_hlgvit_crs_gd4_cfs_v5.py:403-440, 1139, 1190); 48 ActNorm layers"""
+    _run("refinit_v5_tiny_nf24_hdr4")
+
+
+@pytest.mark.parametrize("name", ["tiny_nf24_hdr4", "tiny_nf24_hdr2", "small_nf24_hdr4", "cfs_tiny_nf24_hdr4", "crs_tiny_nf24_hdr4",
+                                  "v5_tiny_nf24_hdr4"])
 def test_oracle_small_nets(name):
     _run(name)
 

@@ -45,6 +45,13 @@ CONFIGS = {
     # sibling generator models/networks_iid_hlgvit_crs_gd4_cfs.py (--model_G iid_hlgvit_crs_gd4_cfs): full-resolution head, no ds/us stage
     "cfs_tiny_nf24_hdr4": (NetConfig(24, 4, patch_size=8, load_size=64, variant="cfs"), 2, True),
     "cfs_full256_nf24_hdr4": (NetConfig(24, 4, patch_size=32, load_size=256, variant="cfs"), 1, False),
+    # networks_iid_hlgvit_crs_gd4.py (--model_G iid_hlgvit_crs_gd4): cfs with a 3-map 1x1 skip conv instead of CFSM2G (+ dead SpatialPyramid)
+    "crs_tiny_nf24_hdr4": (NetConfig(24, 4, patch_size=8, load_size=64, variant="crs"), 2, True),
+    "crs_full256_nf24_hdr4": (NetConfig(24, 4, patch_size=32, load_size=256, variant="crs"), 1, False),
+    # networks_iid_hlgvit_crs_gd4_cfs_v5.py (--model_G iid_hlgvit_crs_gd4_cfs_v5): v3 with the LViT blocks between conv_shrink / conv_extend
+    "v5_tiny_nf24_hdr4": (NetConfig(24, 4, patch_size=8, load_size=64, variant="v5"), 2, True),
+    "v5_full512_nf24_hdr4": (NetConfig(24, 4, patch_size=32, load_size=256, variant="v5"), 1, False),
+    "refinit_v5_tiny_nf24_hdr4": (NetConfig(24, 4, patch_size=8, load_size=64, variant="v5"), 2, True),
     "refinit_tiny_nf24_hdr4": (NetConfig(24, 4, patch_size=8, load_size=64), 2, True),
     "refinit_full512_nf24_hdr4": (NetConfig(24, 4, patch_size=32, load_size=256), 1, False),
 }
@@ -56,7 +63,8 @@ def weight_mode(name):
 STAGE_MODULES = None
 
 
-REF_MODULE = {"v3": "networks_iid_hlgvit_crs_gd4_cfs_v3", "cfs": "networks_iid_hlgvit_crs_gd4_cfs"}
+REF_MODULE = {"v3": "networks_iid_hlgvit_crs_gd4_cfs_v3", "cfs": "networks_iid_hlgvit_crs_gd4_cfs", "crs": "networks_iid_hlgvit_crs_gd4",
+              "v5": "networks_iid_hlgvit_crs_gd4_cfs_v5"}
 
 
 def import_reference(variant="v3"):
@@ -73,7 +81,8 @@ def opt_for(cfg):
 
 
 def stage_names(variant="v3"):
-    names = ["head"] if variant == "cfs" else ["head", "ds_conv_e01"]
+    full_res = variant in ("cfs", "crs")
+    names = ["head"] if full_res else ["head", "ds_conv_e01"]
     for l in (1, 2, 3):
         names += ["localvit_encoder_0%d" % l, "globalvit_encoder_0%d" % l, "lgcat_conv_e0%d" % l]
         if l < 3:
@@ -81,10 +90,10 @@ def stage_names(variant="v3"):
     for t in "rsd":
         for l in (3, 2, 1):
             names += ["localvit_decoder_0%d%s" % (l, t), "globalvit_decoder_0%d%s" % (l, t), "lgcat_conv_d0%d%s" % (l, t)]
-            if not (variant == "cfs" and l == 1):
+            if not (full_res and l == 1):
                 names.append("us_conv_d0%d%s" % (l, t))
             if l > 1:
-                names.append(("cfsm2g_d0%dd" % l) if t == "d" else ("sk_conv_d0%d%s" % (l, t)))
+                names.append(("cfsm2g_d0%dd" % l) if (t == "d" and variant != "crs") else ("sk_conv_d0%d%s" % (l, t)))
         names.append("tail_" + t.upper())
     return names
 
@@ -199,7 +208,7 @@ def gen_net(v3, common, name):
         dump_manifest(net, os.path.join(GOLD, "state_manifest_%s.txt" % name))
     data = {"batch": np.int64(batch), "cfg": np.array([cfg.n_feats, cfg.hidden_dim_ratio, cfg.patch_size, cfg.load_size], np.int64)}
     names = stage_names(cfg.variant)
-    assert len(names) == (54 if cfg.variant == "cfs" else 58) and all(n in stages for n in names), [n for n in names if n not in stages]
+    assert len(names) == (54 if cfg.full_res else 58) and all(n in stages for n in names), [n for n in names if n not in stages]
     data["stage_names"] = np.array(names)
     for n in names:
         t = stages[n]
@@ -220,7 +229,7 @@ def gen_net(v3, common, name):
         # the ActNorm parameters the reference's first forward computed (and its `initialized` flags, now 1)
         after = net.state_dict()
         an = [k[:-len(".initialized")] for k in after if k.endswith(".initialized")]
-        assert len(an) == 24 and all(int(after[k + ".initialized"]) == 1 for k in an)
+        assert len(an) == (48 if cfg.variant == "v5" else 24) and all(int(after[k + ".initialized"]) == 1 for k in an)
         data["actnorm_names"] = np.array(an)
         for k in an:
             data["actnorm_w/" + k] = after[k + ".weight"].numpy().copy()
