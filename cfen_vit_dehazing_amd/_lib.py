@@ -26,7 +26,7 @@ class ConvArgsC(ctypes.Structure):
     _fields_ = [(n, ctypes.c_int32) for n in
                 ("kind", "k", "stride", "pad", "reflect", "nsrc", "B", "Hin", "Win", "Cin", "cs_in",
                  "Cout", "Cout_pad", "Kpad", "cs_out", "act", "out_nchw_f32", "cs_res", "wlayout")] + \
-               [(n, c_void_p) for n in ("src0", "src1", "weight", "scale", "shift", "res0", "res1", "out")]
+               [(n, c_void_p) for n in ("src0", "src1", "weight", "scale", "shift", "res0", "res1", "out", "src2")]
 
 
 class EmbedQkvArgsC(ctypes.Structure):

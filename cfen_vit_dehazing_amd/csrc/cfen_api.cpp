@@ -181,9 +181,9 @@ int cfen_conv2d(int dtype, const cfen_conv_args* a, void* stream) {
   CFEN_CHECK_ARG(a != nullptr, "conv2d: null args");
   ConvDesc d;
   if (a->kind == 0) {
-    CFEN_CHECK_ARG(a->k >= 1 && a->k <= 7 && a->stride >= 1 && a->stride <= 2 && a->nsrc >= 1 && a->nsrc <= 2 &&
+    CFEN_CHECK_ARG(a->k >= 1 && a->k <= 7 && a->stride >= 1 && a->stride <= 2 && a->nsrc >= 1 && a->nsrc <= 3 &&
                    a->k * a->k * a->nsrc <= CFEN_MAX_TAPS, "conv2d: unsupported kernel/stride/nsrc");
-    CFEN_CHECK_ARG(a->nsrc == 1 || a->src1, "conv2d: src1 missing");
+    CFEN_CHECK_ARG((a->nsrc < 2 || a->src1) && (a->nsrc < 3 || a->src2), "conv2d: src1 / src2 missing");
     cfen_desc_conv(&d, a->B, a->Hin, a->Win, a->cs_in, a->Cin, a->k, a->stride, a->pad, a->reflect, a->nsrc);
   } else if (a->kind == 1) {
     cfen_desc_convT4(&d, a->B, a->Hin, a->Win, a->cs_in, a->Cin);
@@ -191,7 +191,7 @@ int cfen_conv2d(int dtype, const cfen_conv_args* a, void* stream) {
     cfen_set_error("conv2d: unknown kind %d", a->kind);
     return CFEN_ERR_ARG;
   }
-  d.src[0] = a->src0; d.src[1] = a->src1;
+  d.src[0] = a->src0; d.src[1] = a->src1; d.src[2] = a->src2;
   d.weight = a->weight; d.Kpad = a->Kpad;
   d.scale = a->scale; d.shift = a->shift; d.act = a->act;
   d.res[0] = a->res0; d.res[1] = a->res1; d.cs_res = a->cs_res;

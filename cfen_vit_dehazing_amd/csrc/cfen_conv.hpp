@@ -8,12 +8,12 @@
 
 struct ConvTap {
   int8_t dy, dx;   // input offset relative to base*in_stride
-  int8_t src;      // 0/1: which input tensor (1x1 conv over a channel concat reads two)
+  int8_t src;      // 0..2: which input tensor (a 1x1 conv over a channel concat reads two or three)
   int8_t pad_;
 };
 
 struct ConvDesc {
-  const void* src[2];
+  const void* src[3];
   int Hin, Win, cs_in, Cin;      // Cin = channels consumed per tap (<= cs_in)
   const void* weight;            // [nphase][Cout_pad][Kpad], k = tap*Cin + c, zero padded
   int Kpad;

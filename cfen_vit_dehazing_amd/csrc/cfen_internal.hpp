@@ -42,7 +42,7 @@ int cfen_upsample4_impl_g(int dtype, int ng, const void* const* small, void* con
                           hipStream_t s);
 int cfen_attention_impl_g(int dtype, int ng, const void* const* qkv, void* const* out, int nseq, int S, int heads, int dh, hipStream_t s);
 int cfen_layernorm_impl_g(int dtype, int ng, const void* const* X, void* const* Y, const float* const* g, const float* const* b, int M, int D,
-                          float eps, hipStream_t s);
+                          float eps, hipStream_t s, int Dn = 0);   // Dn: real entries per row when the rows carry zero padding slots (0 = D)
 // window attention on the head-major qkv layout (see CfenEmbedQkvArgs::hm_heads); fp16, head_dim 24, S in {64, 256}
 bool cfen_attention_hm_supported(int dtype, int S, int dh);
 int cfen_attention_hm_impl_g(int dtype, int ng, const void* const* qkv, void* const* out, int nseq, int S, int heads, int dh, hipStream_t s);

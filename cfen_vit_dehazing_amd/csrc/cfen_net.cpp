@@ -58,6 +58,12 @@ struct Vit {
   std::string name;
   bool global;
   int level, C, p, S, D, heads, hidden;
+  // v5 LViT (networks_iid_hlgvit_crs_gd4_cfs_v5.py:1086-1106): the block runs on a quarter of the level's channels (6 / 12 / 24), between a 1x1
+  // conv_shrink and conv_extend.  Those maps live at channel stride 8 / 16 / 24, so C, D count the zero slots of the padded token row;
+  // Dn = real embedding dim (LayerNorm statistics), dh = head dim padded to 8 (real 6; the packer zero-fills and folds the softmax scale
+  // into W_q), Da = heads * dh = width of q, k, v and of the attention output.  Everywhere else Dn = Da = D, dh = D / heads.
+  int Dn, Da, dh, Cmap;
+  bool shrink;
   int mapH;   // edge of the map the tokens tile (pooled edge for GViT)
   int ws;     // window edge on that map
   bool fused_mlp;   // LN2+FFN+mlp_head+fold run as one k_mlp launch
@@ -89,11 +95,15 @@ struct cfen_net {
   size_t o_stats_set[3] = {0, 0, 0};
   // ActNorm2d layers whose parameters are still uninitialised (models/actnorm.py:25-37): the next EAGER forward runs the layer
   // raw (conv + bias), takes batch statistics, writes the folded epilogue table in place and the raw (weight, bias) pair to an_out
-  struct AnPending { const float* ones; const float* conv_bias; float* an_out; };
+  // win > 0: the layer sits inside a v5 LViT module, which the reference calls once per window -- its first call (the one that
+  // initialises) sees the top-left win x win window of every image only (v5:403-440)
+  struct AnPending { const float* ones; const float* conv_bias; float* an_out; int win; };
   std::map<std::string, AnPending> an_pending;
   int input_u8 = 0;                // 1: x is uint8 HWC (B,H,W,3), normalised to [-1,1] by the first launch (data/base_dataset.py:44-46)
-  bool cfs = false;                // sibling generator networks_iid_hlgvit_crs_gd4_cfs.py (cfg.reserved bits 8..15 == 1): the three levels run at the
-                                   // image's own resolution -- no ds_conv_e01 / us_conv_d01*, n_feats channels in head and tails
+  bool cfs = false;                // sibling generators networks_iid_hlgvit_crs_gd4_cfs.py / ..._crs_gd4.py (cfg.reserved bits 8..15 == 1 / 2): the three
+                                   // levels run at the image's own resolution -- no ds_conv_e01 / us_conv_d01*, n_feats channels in head and tails
+  bool crs = false;                // ..._crs_gd4.py (variant 2): D's skip fuse is a 1x1 conv over (D, R, S) upsampled maps instead of CFSM2G (crs:854,889)
+  bool v5 = false;                 // ..._cfs_v5.py (variant 3): v3 with every LViT block between conv_shrink / conv_extend
   int full = 0;                    // image edge
   int blk_kind = 0;                // 0 CNN, 1 GViT block, 2 LViT block (selects bits 8.. / 16.. of "net.skip_classes")
   unsigned char* base = nullptr;   // workspace of the current / last forward
@@ -193,7 +203,7 @@ struct cfen_net {
 
   int build();
   // one convolution of up to CFEN_MAX_GROUPS same-shaped layers (the R / S / D copies of a decoder layer) as ONE launch
-  struct ConvCall { std::string layer, in0, in1, res0, res1, out; float* nchw_out = nullptr; };   // "" = absent
+  struct ConvCall { std::string layer, in0, in1, res0, res1, out; float* nchw_out = nullptr; std::string in2 = ""; };   // "" = absent
   int run_conv_g(int ng, const ConvCall* c, int act);
   int run_conv(const std::string& layer, const std::string& in0, const char* in1, const char* res0, const char* res1, int act,
                const std::string& out, float* nchw_out) {
@@ -239,8 +249,11 @@ int cfen_net::build() {
   CFEN_CHECK_ARG(4 * nf <= 128, "net: n_feats > 32 unsupported");
   CFEN_CHECK_ARG(cfg.hidden_dim_ratio > 0, "net: hidden_dim_ratio must be positive");
   const int variant = (cfg.reserved >> 8) & 0xff;
-  CFEN_CHECK_ARG(variant == 0 || variant == 1, "net: unknown generator variant %d (0 = ..._cfs_v3, 1 = ..._cfs)", variant);
-  cfs = variant == 1;
+  CFEN_CHECK_ARG(variant >= 0 && variant <= 3, "net: unknown generator variant %d (0 = ..._cfs_v3, 1 = ..._cfs, 2 = ..._crs_gd4, 3 = ..._cfs_v5)", variant);
+  cfs = variant == 1 || variant == 2;
+  crs = variant == 2;
+  v5 = variant == 3;
+  CFEN_CHECK_ARG(!v5 || nf % cfg.num_heads == 0, "net (v5): shrunk embedding dim (n_feats) not divisible by heads");
   full = cfs ? N : 2 * N;
 
   // ---- transformer instances (reference v3:136-246) ----
@@ -250,6 +263,13 @@ int cfen_net::build() {
     v.name = name; v.global = false; v.level = l; v.C = nf << (l - 1); v.p = 2;
     v.ws = cfg.patch_size; v.mapH = N >> (l - 1);
     v.S = (v.ws / 2) * (v.ws / 2); v.D = v.C * 4; v.heads = cfg.num_heads << (l - 1); v.hidden = v.D * cfg.hidden_dim_ratio;
+    v.Cmap = v.C; v.Dn = v.Da = v.D; v.dh = v.D / v.heads; v.shrink = false;
+    if (v5) {
+      const int Cq = v.C / 4;                      // v5:1095-1109
+      v.shrink = true;
+      v.C = cs_of(Cq); v.D = v.C * 4; v.Dn = Cq * 4; v.hidden = v.Dn * cfg.hidden_dim_ratio;
+      v.dh = cfen_round_up(v.Dn / v.heads, 8); v.Da = v.heads * v.dh;
+    }
     vits.push_back(v);
   };
   auto gv = [&](const std::string& name, int l) {
@@ -258,6 +278,7 @@ int cfen_net::build() {
     v.mapH = (N >> (l - 1)) / 4; v.ws = v.mapH;
     v.S = (v.mapH / 4) * (v.mapH / 4); v.D = v.C * 16; v.heads = cfg.num_heads << (l - 1);
     v.hidden = v.D * cfg.hidden_dim_ratio;
+    v.Cmap = v.C; v.Dn = v.Da = v.D; v.dh = v.D / v.heads; v.shrink = false;
     if (name == "globalvit_encoder_02") v.hidden = v.C * 4 * cfg.hidden_dim_ratio;   // v3:200 quirk (patch_dim, not patch_dim*2)
     vits.push_back(v);
   };
@@ -270,14 +291,15 @@ int cfen_net::build() {
 
   size_t max_md_l = 0, max_mh_l = 0, max_md_g = 0, max_mh_g = 0, max_small = 0;
   for (Vit& v : vits) {
-    v.fused_mlp = !v.global && cfen_mlp_supported(v.D, v.hidden, cfg.dtype);
-    v.fused_front = !v.global && cfen_embed_qkv_supported(v.D);
+    v.fused_mlp = !v.global && !v.shrink && cfen_mlp_supported(v.D, v.hidden, cfg.dtype);
+    v.fused_front = !v.global && !v.shrink && cfen_embed_qkv_supported(v.D);
     v.fused_window = !v.global && v.fused_mlp && v.fused_front && cfen_lvit_window_supported(cfg.dtype, v.D, v.heads, v.S, v.hidden);
-    v.ln_fold1 = !v.fused_front && (v.D * esz) % 128 == 0;
-    v.ln_fold2 = !v.fused_mlp && (v.D * esz) % 128 == 0;
+    v.ln_fold1 = !v.fused_front && v.Dn == v.D && (v.D * esz) % 128 == 0;
+    v.ln_fold2 = !v.fused_mlp && v.Dn == v.D && (v.D * esz) % 128 == 0;
+    CFEN_CHECK_ARG(v.Dn % v.heads == 0, "net: %s embedding dim %d not divisible by %d heads", v.name.c_str(), v.Dn, v.heads);
     CFEN_CHECK_ARG(v.mapH % v.ws == 0 && v.ws % v.p == 0 && v.S >= 1, "net: %s does not tile its map", v.name.c_str());
     const size_t ntok = (size_t)B * (v.mapH / v.ws) * (v.mapH / v.ws) * v.S;
-    (v.global ? max_md_g : max_md_l) = std::max(v.global ? max_md_g : max_md_l, ntok * v.D);
+    (v.global ? max_md_g : max_md_l) = std::max(v.global ? max_md_g : max_md_l, ntok * std::max(v.D, v.Da));
     (v.global ? max_mh_g : max_mh_l) = std::max(v.global ? max_mh_g : max_mh_l, ntok * v.hidden);
     if (v.global) max_small = std::max(max_small, (size_t)B * v.mapH * v.mapH * v.C);
     const std::string& n = v.name;
@@ -288,9 +310,9 @@ int cfen_net::build() {
     }
     need(n + ".pos", (size_t)v.S * v.D * esz);
     need(n + ".ln1.g", (size_t)v.D * 4); need(n + ".ln1.b", (size_t)v.D * 4);
-    need(n + ".qkv.w", (size_t)3 * v.D * v.D * esz);
-    need(n + ".proj.w", (size_t)v.D * v.D * esz);
-    if (v.ln_fold1) { need(n + ".qkv.wl", (size_t)3 * v.D * v.D * esz); need(n + ".qkv.s", (size_t)3 * v.D * 4); need(n + ".qkv.bl", (size_t)3 * v.D * 4); }
+    need(n + ".qkv.w", (size_t)3 * v.Da * v.D * esz);
+    need(n + ".proj.w", (size_t)v.D * v.Da * esz);
+    if (v.ln_fold1) { need(n + ".qkv.wl", (size_t)3 * v.Da * v.D * esz); need(n + ".qkv.s", (size_t)3 * v.Da * 4); need(n + ".qkv.bl", (size_t)3 * v.Da * 4); }
     if (v.ln_fold2) { need(n + ".ffn1.wl", (size_t)v.hidden * v.D * esz); need(n + ".ffn1.s", (size_t)v.hidden * 4); need(n + ".ffn1.bl", (size_t)v.hidden * 4); }
     need(n + ".ln2.g", (size_t)v.D * 4); need(n + ".ln2.b", (size_t)v.D * 4);
     const char* wn = v.fused_mlp ? ".wk" : ".w";
@@ -316,16 +338,23 @@ int cfen_net::build() {
     add_conv("us_conv_d03" + t, 1, 4, 2, 1, 0, 1, 4 * nf, 2 * nf, N / 2);
     add_conv("us_conv_d02" + t, 1, 4, 2, 1, 0, 1, 2 * nf, nf, N);
     if (!cfs) add_conv("us_conv_d01" + t, 1, 4, 2, 1, 0, 1, nf, h, 2 * N);
-    if (b < 2) {
-      add_conv("sk_conv_d03" + t, 0, 1, 1, 0, 0, 2, 2 * nf, 2 * nf, N / 2);
-      add_conv("sk_conv_d02" + t, 0, 1, 1, 0, 0, 2, nf, nf, N);
+    if (b < 2 || crs) {   // crs:327-330: sk_conv_d03d / sk_conv_d02d read three maps
+      add_conv("sk_conv_d03" + t, 0, 1, 1, 0, 0, b < 2 ? 2 : 3, 2 * nf, 2 * nf, N / 2);
+      add_conv("sk_conv_d02" + t, 0, 1, 1, 0, 0, b < 2 ? 2 : 3, nf, nf, N);
     }
     const std::string T(1, (char)(br[b] - 32));
     add_conv("tail_" + T + ".conv3", 0, 3, 1, 1, 0, 1, h, h, full);
     add_conv("tail_" + T + ".conv7", 0, 7, 1, 3, 1, 1, h, b == 1 ? 1 : 3, full);
   }
-  need("cfsm2g_d03d.w", (size_t)4 * 2 * (2 * nf / 4) * (2 * nf) * 4);
-  need("cfsm2g_d02d.w", (size_t)4 * 2 * (nf / 4) * nf * 4);
+  if (!crs) {
+    need("cfsm2g_d03d.w", (size_t)4 * 2 * (2 * nf / 4) * (2 * nf) * 4);
+    need("cfsm2g_d02d.w", (size_t)4 * 2 * (nf / 4) * nf * 4);
+  }
+  for (const Vit& v : vits)
+    if (v.shrink) {     // v5:1101-1104: Conv2d 1x1 + ActNorm2d + ReLU on either side of the block
+      add_conv(v.name + ".shrink", 0, 1, 1, 0, 0, 1, v.Cmap, v.Cmap / 4, v.mapH);
+      add_conv(v.name + ".extend", 0, 1, 1, 0, 0, 1, v.Cmap / 4, v.Cmap, v.mapH);
+    }
 
   // ---- workspace ----
   add_map("input", 3, full);
@@ -351,10 +380,15 @@ int cfen_net::build() {
       add_map("globalvit_decoder_0" + L + t, C, E);
       add_map("lgcat_conv_d0" + L + t, C, E);
       if (l < 3 && !(cfs && l == 1)) add_map("us_conv_d0" + L + t, C / 2, 2 * E);
-      if (l > 1) add_map(b == 2 ? "cfsm2g_d0" + L + "d" : "sk_conv_d0" + L + t, C / 2, 2 * E);
+      if (l > 1) add_map(b == 2 && !crs ? "cfsm2g_d0" + L + "d" : "sk_conv_d0" + L + t, C / 2, 2 * E);
     }
     add_map(std::string("tail_") + (char)(br[b] - 32) + ".mid", h, full);
   }
+  for (const Vit& v : vits)
+    if (v.shrink) {
+      add_map(v.name + ".shrunk", v.Cmap / 4, v.mapH);   // conv_shrink output = the map the tokens are cut from
+      add_map(v.name + ".tok", v.Cmap / 4, v.mapH);      // folded block output = conv_extend input
+    }
   for (int k = 0; k < 6; ++k) {
     const bool g = k & 1;             // odd sets serve GViT lanes: far fewer tokens
     const size_t md = g ? max_md_g : max_md_l, mh = g ? max_mh_g : max_mh_l;
@@ -397,7 +431,23 @@ int cfen_net::run_conv_g(int ng, const ConvCall* cc, int act) {
       params[cc[0].layer + ".shift"] = keep_t;
       if (rc) return rc;
       // 2. batch statistics -> epilogue table (written in place) + raw ActNorm parameters
-      TRY(cfen_actnorm_init_impl(cfg.dtype, map_ptr(cc[0].out), (float*)at(o_stats_set[2]), cfg.batch, bo.H * bo.W, c.Cout, bo.cs, c.Cout_pad,
+      const void* xs = map_ptr(cc[0].out);
+      int hw = bo.H * bo.W;
+      if (ap.win > 0 && ap.win < bo.H) {
+        // the reference module saw one window per call: statistics over the top-left window of every image, gathered into LViT scratch
+        // (free here: the shrink conv runs before its block, the extend conv after the block's fold)
+        unsigned char* tmp = (unsigned char*)at(scr_set[0].x0);
+        const size_t row = (size_t)ap.win * bo.cs * esz, img = row * ap.win;
+        for (int b = 0; b < cfg.batch; ++b)
+          if (hipMemcpy2DAsync(tmp + b * img, row, (const unsigned char*)xs + (size_t)b * bo.H * bo.W * bo.cs * esz, (size_t)bo.W * bo.cs * esz, row,
+                               ap.win, hipMemcpyDeviceToDevice, stream) != hipSuccess) {
+            cfen_set_error("net: window copy for the ActNorm init of '%s' failed", cc[0].layer.c_str());
+            return CFEN_ERR_HIP;
+          }
+        xs = tmp;
+        hw = ap.win * ap.win;
+      }
+      TRY(cfen_actnorm_init_impl(cfg.dtype, xs, (float*)at(o_stats_set[2]), cfg.batch, hw, c.Cout, bo.cs, c.Cout_pad,
                                  ap.conv_bias, (float*)const_cast<void*>(keep_s.ptr), (float*)const_cast<void*>(keep_t.ptr), ap.an_out, stream));
       // 3. fall through: the layer again, now with its real epilogue
     }
@@ -416,6 +466,8 @@ int cfen_net::run_conv_g(int ng, const ConvCall* cc, int act) {
       cfen_desc_convT4(&d[g], cfg.batch, bi.H, bi.W, bi.cs, c.Cin);
     d[g].src[0] = map_ptr(q.in0);
     d[g].src[1] = q.in1.empty() ? nullptr : map_ptr(q.in1);
+    d[g].src[2] = q.in2.empty() ? nullptr : map_ptr(q.in2);
+    CFEN_CHECK_ARG((c.nsrc >= 2) == !q.in1.empty() && (c.nsrc >= 3) == !q.in2.empty(), "net: %s reads %d maps", q.layer.c_str(), c.nsrc);
     d[g].weight = P(q.layer + (c.tz ? ".wz" : c.tile ? ".wr" : ".w")); d[g].Kpad = c.Kpad;
     d[g].scale = Pf(q.layer + ".scale"); d[g].shift = Pf(q.layer + ".shift");
     d[g].act = act;
@@ -462,7 +514,7 @@ int cfen_net::run_vit_g(int ng, const VitCall* vc, int scr0) {
   std::string nm[3];
   for (int g = 0; g < ng; ++g) {
     const Vit& w = *vc[g].v;
-    CFEN_CHECK_ARG(w.global == v.global && w.D == v.D && w.hidden == v.hidden && w.S == v.S && w.mapH == v.mapH && w.heads == v.heads &&
+    CFEN_CHECK_ARG(w.global == v.global && w.D == v.D && w.Dn == v.Dn && w.Da == v.Da && w.hidden == v.hidden && w.S == v.S && w.mapH == v.mapH && w.heads == v.heads &&
                    w.fused_mlp == v.fused_mlp && w.fused_front == v.fused_front && bufs.at(vc[g].in).cs == bi.cs && bufs.at(vc[g].out).cs == bo.cs,
                    "net: %s and %s cannot share launches", v.name.c_str(), w.name.c_str());
     const Scratch& q = scr_set[scr0 + 2 * g];
@@ -474,7 +526,7 @@ int cfen_net::run_vit_g(int ng, const VitCall* vc, int scr0) {
   }
   const void* cHIDp[3] = {HID[0], HID[1], HID[2]};
   const size_t scratch_stretch = scr_set[scr0].hid - scr_set[scr0].yn;   // bytes from YN to the end of QKV
-  const double Md = (double)M * ng, D = v.D, Hd = v.hidden;
+  const double Md = (double)M * ng, D = v.Dn, Hd = v.hidden;   // algorithmic flops count the real embedding dim
   auto step = [&](const char* what) { if (profiling) label = nm[0] + (ng > 1 ? " (x" + std::to_string(ng) + ")" : "") + ":" + what; };
   // Y = act(X W^T + bias) + R + P for every member; operand arrays are indexed by member
   auto gemm = [&](const void* const* X, const char* wname, const char* bname, void* const* R, const char* pname, void* const* Y, int N, int K,
@@ -541,24 +593,24 @@ int cfen_net::run_vit_g(int ng, const VitCall* vc, int scr0) {
     // src = src + out_proj(MHA(LN1(src)))                                      (v3:1383-1386)
     if (v.ln_fold1 && cfen_tune_ln_fold()) {
       step("ln1_qkv");
-      TRYP(K_GEMM, 6 * Md * D * D, gemm_ln(cX1, ".qkv", QKV, 3 * v.D, v.D, 0));
+      TRYP(K_GEMM, 6 * Md * D * D, gemm_ln(cX1, ".qkv", QKV, 3 * v.Da, v.D, 0));
     } else {
       step("ln1");
       for (int g = 0; g < ng; ++g) { lg[g] = Pf(nm[g] + ".ln1.g"); lb[g] = Pf(nm[g] + ".ln1.b"); }
-      TRYP(K_LNORM, 0, cfen_layernorm_impl_g(dt, ng, cX1, YN, lg, lb, M, v.D, 1e-5f, stream));
+      TRYP(K_LNORM, 0, cfen_layernorm_impl_g(dt, ng, cX1, YN, lg, lb, M, v.D, 1e-5f, stream, v.Dn));
       step("qkv");
-      TRYP(K_GEMM, 6 * Md * D * D, gemm(cYN, ".qkv.w", nullptr, nullptr, nullptr, QKV, 3 * v.D, v.D, 0, nullptr));
+      TRYP(K_GEMM, 6 * Md * D * D, gemm(cYN, ".qkv.w", nullptr, nullptr, nullptr, QKV, 3 * v.Da, v.D, 0, nullptr));
     }
   }
   step("attention");
   if (head_major)
     TRYP(K_ATTN, 4 * Md * v.S * D, cfen_attention_hm_impl_g(dt, ng, cQKV, ATT, B * nwin, v.S, v.heads, v.D / v.heads, stream));
   else
-    TRYP(K_ATTN, 4 * Md * v.S * D, cfen_attention_impl_g(dt, ng, cQKV, ATT, B * nwin, v.S, v.heads, v.D / v.heads, stream));
+    TRYP(K_ATTN, 4 * Md * v.S * D, cfen_attention_impl_g(dt, ng, cQKV, ATT, B * nwin, v.S, v.heads, v.dh, stream));
   const void* cATT[3] = {ATT[0], ATT[1], ATT[2]};
   if (!v.fused_mlp) {
     step("proj");
-    TRYP(K_GEMM, 2 * Md * D * D, gemm(cATT, ".proj.w", nullptr, X1, nullptr, X1, v.D, v.D, 0, nullptr));
+    TRYP(K_GEMM, 2 * Md * D * D, gemm(cATT, ".proj.w", nullptr, X1, nullptr, X1, v.D, v.Da, 0, nullptr));
   }
   if (v.fused_mlp) {
     // LN2 + FFN + residual + mlp_head + residual + fold, hidden activations never leave registers (k_mlp.hip)
@@ -585,7 +637,7 @@ int cfen_net::run_vit_g(int ng, const VitCall* vc, int scr0) {
     } else {
       step("ln2");
       for (int g = 0; g < ng; ++g) { lg[g] = Pf(nm[g] + ".ln2.g"); lb[g] = Pf(nm[g] + ".ln2.b"); }
-      TRYP(K_LNORM, 0, cfen_layernorm_impl_g(dt, ng, cX1, YN, lg, lb, M, v.D, 1e-5f, stream));
+      TRYP(K_LNORM, 0, cfen_layernorm_impl_g(dt, ng, cX1, YN, lg, lb, M, v.D, 1e-5f, stream, v.Dn));
       step("ffn1");
       TRYP(K_GEMM, 2 * Md * D * Hd, gemm(cYN, ".ffn1.w", ".ffn1.b", nullptr, nullptr, HID, v.hidden, v.D, 1, nullptr));
     }
@@ -632,7 +684,22 @@ int cfen_net::run_level_g(int ng, const char* tags, int l, const std::string* in
   stream = lane_g;
   TRY(run_vit_g(ng, gv, 1));
   stream = sm;
-  TRY(run_vit_g(ng, lv, 0));
+  if (lv[0].v->shrink) {
+    // v5:1139,1190: x = conv_shrink(x) ... x = conv_extend(x); both are per-pixel, so they run on the whole map around the windowed block
+    ConvCall sh[3], ex[3];
+    for (int g = 0; g < ng; ++g) {
+      const std::string& ln = lv[g].out;
+      sh[g] = ConvCall{ln + ".shrink", in[g], "", "", "", ln + ".shrunk", nullptr};
+      ex[g] = ConvCall{ln + ".extend", ln + ".tok", "", "", "", ln, nullptr};
+      lv[g].in = ln + ".shrunk";
+      lv[g].out = ln + ".tok";
+    }
+    TRY(run_conv_g(ng, sh, 1));
+    TRY(run_vit_g(ng, lv, 0));
+    TRY(run_conv_g(ng, ex, 1));
+  } else {
+    TRY(run_vit_g(ng, lv, 0));
+  }
   TRY(order(lane_g, sm));
   return run_conv_g(ng, fuse, 1);
 }
@@ -664,12 +731,17 @@ int cfen_net::run_decoder(float* const* outs, hipStream_t sm, hipStream_t sg) {
   for (int l = 2; l >= 1; --l) {
     const std::string L = std::to_string(l), Lup = std::to_string(l + 1);
     // ---- skip fuse: D through CFSM2G over (D, R, S) upsampled maps, R and S through a 1x1 conv with the encoder skip ----
-    const std::string cf = "cfsm2g_d0" + Lup + "d";
+    const std::string cf = crs ? "sk_conv_d0" + Lup + "d" : "cfsm2g_d0" + Lup + "d";
     {
       const Buf& bu = bufs.at(cf);
       label = cf;
-      TRYP(K_NORM, 0, cfen_cfsm2g_impl(dt, map_ptr("us_conv_d0" + Lup + "d"), map_ptr("us_conv_d0" + Lup + "r"), map_ptr("us_conv_d0" + Lup + "s"),
-                                       map_ptr(cf), Pf(cf + ".w"), (float*)at(o_stats_set[1]), B, bu.H * bu.W, bu.C, bu.cs, stream));
+      if (crs) {   // crs:854,889: sk_conv_d0Xd(cat(D, R, S upsampled maps))
+        ConvCall c3{cf, "us_conv_d0" + Lup + "d", "us_conv_d0" + Lup + "r", "", "", cf, nullptr, "us_conv_d0" + Lup + "s"};
+        TRY(run_conv_g(1, &c3, 1));
+      } else {
+        TRYP(K_NORM, 0, cfen_cfsm2g_impl(dt, map_ptr("us_conv_d0" + Lup + "d"), map_ptr("us_conv_d0" + Lup + "r"), map_ptr("us_conv_d0" + Lup + "s"),
+                                         map_ptr(cf), Pf(cf + ".w"), (float*)at(o_stats_set[1]), B, bu.H * bu.W, bu.C, bu.cs, stream));
+      }
       ConvCall c[2];
       for (int g = 0; g < 2; ++g) {
         const std::string sk = "sk_conv_d0" + Lup + tags[g];
@@ -791,7 +863,9 @@ int cfen_net_actnorm_pending(cfen_net* net, const char* layer, const float* ones
   auto it = net->convs.find(layer);
   CFEN_CHECK_ARG(it != net->convs.end(), "actnorm_pending: unknown layer '%s'", layer);
   CFEN_CHECK_ARG(cfen_aligned16(ones) && cfen_aligned16(conv_bias) && cfen_aligned16(an_out), "actnorm_pending: pointers must be 16-byte aligned");
-  net->an_pending[layer] = cfen_net::AnPending{ones, conv_bias, an_out};
+  const std::string ln(layer);
+  const bool in_lvit = ln.size() > 7 && (ln.compare(ln.size() - 7, 7, ".shrink") == 0 || ln.compare(ln.size() - 7, 7, ".extend") == 0);
+  net->an_pending[layer] = cfen_net::AnPending{ones, conv_bias, an_out, in_lvit ? net->cfg.patch_size : 0};
   return CFEN_OK;
 }
 
@@ -945,7 +1019,7 @@ double cfen_net_flops_per_image(const cfen_net* net) {
   double f = 0.0;
   for (const Vit& v : net->vits) {   // 2T(5D^2 + 4DH) + 4 T S D
     const double T = (double)(v.mapH / v.ws) * (v.mapH / v.ws) * v.S;
-    f += 2.0 * T * (5.0 * v.D * v.D + 4.0 * (double)v.D * v.hidden) + 4.0 * T * v.S * v.D;
+    f += 2.0 * T * (5.0 * v.Dn * v.Dn + 4.0 * (double)v.Dn * v.hidden) + 4.0 * T * v.S * v.Dn;
   }
   for (const auto& kv : net->convs) {
     const ConvLayer& c = kv.second;

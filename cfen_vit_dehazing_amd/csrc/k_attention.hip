@@ -439,8 +439,11 @@ int dispatch_attn(int ng, const void* const* qkv, void* const* out, int nseq, in
 // LayerNorm over the last dim, statistics in fp32 (two passes over registers).  A row is handled by a
 // group of G = 16, 32 or 64 lanes (G >= D / (16-byte vector)), so a wave normalises 4 / 2 / 1 rows and all
 // lanes carry data even for the 192-byte rows of LViT level 1.
+// Dn <= D: the row's trailing / interleaved padding entries are exact zeros that do not belong to the normalised vector
+// (v5 LViT: 6- and 12-channel maps live at a channel stride of 8 / 16, so a token row carries zero slots); statistics are over
+// the Dn real entries, the padding slots get gamma = beta = 0 from the packer.
 template <typename T, int MAXV, int G>
-__global__ __launch_bounds__(256) void k_layernorm(PtrG<const T> Xg, PtrG<T> Yg, PtrG<const float> gg, PtrG<const float> bg, int M, int D, float eps) {
+__global__ __launch_bounds__(256) void k_layernorm(PtrG<const T> Xg, PtrG<T> Yg, PtrG<const float> gg, PtrG<const float> bg, int M, int D, float eps, int Dn) {
   const T* __restrict__ X = Xg.p[blockIdx.z];
   T* __restrict__ Y = Yg.p[blockIdx.z];
   const float* __restrict__ g = gg.p[blockIdx.z];
@@ -465,7 +468,7 @@ __global__ __launch_bounds__(256) void k_layernorm(PtrG<const T> Xg, PtrG<T> Yg,
     }
   }
   sum = group_sum<G>(sum);
-  const float mean = sum / (float)D;
+  const float mean = sum / (float)Dn;
   float sq = 0.f;
 #pragma unroll
   for (int i = 0; i < MAXV; ++i) {
@@ -479,7 +482,8 @@ __global__ __launch_bounds__(256) void k_layernorm(PtrG<const T> Xg, PtrG<T> Yg,
     }
   }
   sq = group_sum<G>(sq);
-  const float rstd = rsqrtf(sq / (float)D + eps);
+  sq -= (float)(D - Dn) * mean * mean;              // the zero slots each added (0 - mean)^2
+  const float rstd = rsqrtf(fmaxf(sq, 0.f) / (float)Dn + eps);
   if (!live) return;
   T* y = Y + row * D;
 #pragma unroll
@@ -495,9 +499,11 @@ __global__ __launch_bounds__(256) void k_layernorm(PtrG<const T> Xg, PtrG<T> Yg,
 }
 
 template <typename T, int MAXV>
-int launch_ln(int ng, const void* const* X, void* const* Y, const float* const* g, const float* const* b, int M, int D, float eps, hipStream_t s) {
+int launch_ln(int ng, const void* const* X, void* const* Y, const float* const* g, const float* const* b, int M, int D, float eps, hipStream_t s, int Dn) {
   constexpr int EPL = Vec16<T>::N;
   CFEN_CHECK_ARG(M > 0 && D > 0, "layernorm: empty problem");
+  if (Dn <= 0) Dn = D;
+  CFEN_CHECK_ARG(Dn <= D, "layernorm: %d real entries in rows of %d", Dn, D);
   CFEN_CHECK_ARG(D % EPL == 0 && D <= 64 * MAXV * EPL, "layernorm: D=%d unsupported (multiple of %d, <= %d)", D, EPL, 64 * MAXV * EPL);
   CFEN_CHECK_ARG(ng >= 1 && ng <= CFEN_MAX_GROUPS, "layernorm: 1..%d problems per launch", CFEN_MAX_GROUPS);
   PtrG<const T> xg{};
@@ -509,11 +515,11 @@ int launch_ln(int ng, const void* const* X, void* const* Y, const float* const* 
   }
   const int nvec = D / EPL;
   if (nvec <= 16) {
-    CFEN_LAUNCH((k_layernorm<T, 1, 16>), dim3((M + 15) / 16, 1, ng), dim3(256), 0, s, xg, yg, gg, bg, M, D, eps);
+    CFEN_LAUNCH((k_layernorm<T, 1, 16>), dim3((M + 15) / 16, 1, ng), dim3(256), 0, s, xg, yg, gg, bg, M, D, eps, Dn);
   } else if (nvec <= 32) {
-    CFEN_LAUNCH((k_layernorm<T, 1, 32>), dim3((M + 7) / 8, 1, ng), dim3(256), 0, s, xg, yg, gg, bg, M, D, eps);
+    CFEN_LAUNCH((k_layernorm<T, 1, 32>), dim3((M + 7) / 8, 1, ng), dim3(256), 0, s, xg, yg, gg, bg, M, D, eps, Dn);
   } else {
-    CFEN_LAUNCH((k_layernorm<T, MAXV, 64>), dim3((M + 3) / 4, 1, ng), dim3(256), 0, s, xg, yg, gg, bg, M, D, eps);
+    CFEN_LAUNCH((k_layernorm<T, MAXV, 64>), dim3((M + 3) / 4, 1, ng), dim3(256), 0, s, xg, yg, gg, bg, M, D, eps, Dn);
   }
   CFEN_CHECK_LAUNCH("layernorm");
   return CFEN_OK;
@@ -553,12 +559,12 @@ int cfen_attention_impl(int dtype, const void* qkv, void* out, int nseq, int S, 
 }
 
 int cfen_layernorm_impl_g(int dtype, int ng, const void* const* X, void* const* Y, const float* const* g, const float* const* b, int M, int D,
-                          float eps, hipStream_t s) {
-  if (dtype == 1) return launch_ln<half_t, 4>(ng, X, Y, g, b, M, D, eps, s);
-  if (dtype == 0) return launch_ln<float, 8>(ng, X, Y, g, b, M, D, eps, s);
+                          float eps, hipStream_t s, int Dn) {
+  if (dtype == 1) return launch_ln<half_t, 4>(ng, X, Y, g, b, M, D, eps, s, Dn);
+  if (dtype == 0) return launch_ln<float, 8>(ng, X, Y, g, b, M, D, eps, s, Dn);
   cfen_set_error("layernorm: unknown dtype %d", dtype);
   return CFEN_ERR_ARG;
 }
 int cfen_layernorm_impl(int dtype, const void* X, void* Y, const float* g, const float* b, int M, int D, float eps, hipStream_t s) {
-  return cfen_layernorm_impl_g(dtype, 1, &X, &Y, &g, &b, M, D, eps, s);
+  return cfen_layernorm_impl_g(dtype, 1, &X, &Y, &g, &b, M, D, eps, s, 0);
 }

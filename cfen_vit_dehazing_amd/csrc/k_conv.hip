@@ -3,7 +3,7 @@
 // One kernel covers every convolution of the v3 generator:
 //   head 5x5 (v3:123-127, common.py:11-14), ResBlock / tail 3x3 (common.py:41-62, v3:351), tail 7x7 behind
 //   ReflectionPad2d(3) (v3:354-355), stride-2 3x3 down-convs (v3:292-298), 1x1 fuse convs over a channel
-//   concat of two maps (v3:255-284, 329-338: the cat is never materialised, each source is a "tap"), and
+//   concat of two or three maps (v3:255-284, 329-338, crs_gd4:327-330: the cat is never materialised, each source is a "tap"), and
 //   ConvTranspose2d(k4,s2,p1) (v3:301-322) as four output-parity phases of 2x2 taps.
 // The epilogue applies a per-channel affine (conv bias and ActNorm2d y=(x+b)*exp(w) folded together,
 // models/actnorm.py:39-42), ReLU/tanh, up to two residual adds, and writes NHWC T or NCHW fp32.
@@ -60,7 +60,7 @@ __global__ __launch_bounds__(256) void k_conv(Grouped<ConvDesc> dg) {
     if (t < d.ntaps) {
       const int tp = taps_l[t];
       const int dy = (int)(signed char)((tp >> 8) & 0xff), dx = (int)(signed char)(tp & 0xff);
-      const T* sp = (const T*)d.src[(tp >> 16) & 1];
+      const T* sp = (const T*)d.src[(tp >> 16) & 3];
 #pragma unroll
       for (int j = 0; j < TM; ++j) {
         int iy = py[j] * d.in_stride + dy, ix = px[j] * d.in_stride + dx;
@@ -148,10 +148,12 @@ int check_conv(const ConvDesc& d) {
   CFEN_CHECK_ARG(d.out_nchw_f32 || (d.cs_out % 4 == 0 && d.cs_out <= d.Cout_pad), "conv: cs_out=%d must be a multiple of 4 and <= Cout_pad",
                  d.cs_out);
   CFEN_CHECK_ARG(!(d.out_nchw_f32 && (d.res[0] || d.res[1])), "conv: residuals unsupported with NCHW output");
-  CFEN_CHECK_ARG(cfen_aligned16(d.src[0]) && cfen_aligned16(d.src[1]) && cfen_aligned16(d.weight) && cfen_aligned16(d.out) &&
+  CFEN_CHECK_ARG(cfen_aligned16(d.src[0]) && cfen_aligned16(d.src[1]) && cfen_aligned16(d.src[2]) && cfen_aligned16(d.weight) && cfen_aligned16(d.out) &&
                  cfen_aligned16(d.scale) && cfen_aligned16(d.shift) && cfen_aligned16(d.res[0]) && cfen_aligned16(d.res[1]),
                  "conv: pointers must be 16-byte aligned");
   CFEN_CHECK_ARG(d.src[0] && d.weight && d.out && d.scale && d.shift, "conv: null pointer");
+  for (int i = 0; i < d.ntaps * d.nphase; ++i)
+    CFEN_CHECK_ARG(d.taps[i].src >= 0 && d.taps[i].src < 3 && d.src[d.taps[i].src], "conv: tap %d reads source %d, which is missing", i, (int)d.taps[i].src);
   if (d.pad_reflect) {
     int maxd = 0;
     for (int i = 0; i < d.ntaps * d.nphase; ++i) {

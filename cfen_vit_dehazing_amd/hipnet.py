@@ -21,7 +21,7 @@ from .config import NetConfig, config_from_opt
 from .manifest import state_manifest, _is_dead
 from .packing import pack_state_dict
 
-_VARIANT_CODE = {"v3": 0, "cfs": 1}       # cfen_net_config.reserved bits 8..15 (csrc/cfen_net.cpp)
+_VARIANT_CODE = {"v3": 0, "cfs": 1, "crs": 2, "v5": 3}       # cfen_net_config.reserved bits 8..15 (csrc/cfen_net.cpp)
 _DTYPES = {"fp16": torch.float16, "half": torch.float16, "fp32": torch.float32, "single": torch.float32,
            torch.float16: torch.float16, torch.float32: torch.float32}
 
@@ -84,7 +84,7 @@ class dec_ipt(nn.Module):
                 out[k] = live[k]
             else:
                 t = self._dead.get(key)
-                out[k] = t if t is not None else torch.zeros(()).expand(shape)       # no storage until someone asks for it
+                out[k] = t if t is not None else torch.zeros((), dtype=dt).expand(shape)       # no storage until someone asks for it
         for k, v in live.items():
             if k not in out:
                 out[k] = v

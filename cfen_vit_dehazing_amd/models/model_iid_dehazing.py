@@ -21,6 +21,9 @@ class DECHLGVIT(BaseModel):
         elif opt.model_G == 'iid_hlgvit_crs_gd4_cfs':             # models/model_iid_dehazing.py:84-86
             from . import networks_iid_hlgvit_crs_gd4_cfs
             self.netG = networks_iid_hlgvit_crs_gd4_cfs.define_G(opt, None)
+        elif opt.model_G in ('iid_hlgvit_crs_gd4', 'iid_hlgvit_crs_gd4_cfs_v5'):     # models/model_iid_dehazing.py:50-53, 93-95
+            from .. import hipnet                             # same module class, the variant comes from opt.model_G (config.VARIANTS)
+            self.netG = hipnet.define_G(opt, None)
         # any other --model_G leaves netG undefined, as the reference's if/elif chain does (-> AttributeError)
 
     def set_input(self, input):

@@ -183,10 +183,10 @@ def nchw_to_nhwc(x, cs, dtype):
 
 
 def conv2d(src0, weight, scale, shift, cin, cout, k=3, stride=1, pad=1, reflect=False, src1=None, transpose=False, act=0,
-           res0=None, res1=None, cs_out=None, nchw_f32=False, rows_layout=False, toeplitz=False):
+           res0=None, res1=None, cs_out=None, nchw_f32=False, rows_layout=False, toeplitz=False, src2=None):
     """src*: NHWC [B,H,W,cs]; weight/scale/shift packed by packing.pack_conv*_weight / affine.
     rows_layout: weight from packing.pack_conv_weight_rows -> the LDS-tiled stride-1 kernel."""
-    _cuda(src0, src1, weight, scale, shift, res0, res1)
+    _cuda(src0, src1, src2, weight, scale, shift, res0, res1)
     B, Hin, Win, cs_in = src0.shape
     cout_pad = round_up(cout, 16)
     if transpose:
@@ -199,12 +199,13 @@ def conv2d(src0, weight, scale, shift, cin, cout, k=3, stride=1, pad=1, reflect=
     else:
         cs_out = cs_out or round_up(cout, 8)
         out = torch.zeros(B, Hout, Wout, cs_out, dtype=src0.dtype, device=src0.device)
-    a = ConvArgsC(kind=1 if transpose else 0, k=k, stride=stride, pad=pad, reflect=int(reflect), nsrc=2 if src1 is not None else 1,
+    a = ConvArgsC(kind=1 if transpose else 0, k=k, stride=stride, pad=pad, reflect=int(reflect), nsrc=3 if src2 is not None else 2 if src1 is not None else 1,
                   B=B, Hin=Hin, Win=Win, Cin=cin, cs_in=cs_in, Cout=cout, Cout_pad=cout_pad, Kpad=weight.shape[-1], cs_out=cs_out,
                   act=act, out_nchw_f32=int(nchw_f32), cs_res=cs_out, wlayout=2 if toeplitz else int(rows_layout),
                   src0=src0.data_ptr(), src1=src1.data_ptr() if src1 is not None else None, weight=weight.data_ptr(),
                   scale=scale.data_ptr(), shift=shift.data_ptr(), res0=res0.data_ptr() if res0 is not None else None,
-                  res1=res1.data_ptr() if res1 is not None else None, out=out.data_ptr())
+                  res1=res1.data_ptr() if res1 is not None else None, out=out.data_ptr(),
+                  src2=src2.data_ptr() if src2 is not None else None)
     check(_lib.load().cfen_conv2d(dtype_code(src0.dtype), ctypes.byref(a), current_stream()), "conv2d")
     return out
 

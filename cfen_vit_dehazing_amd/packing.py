@@ -47,12 +47,12 @@ FUSED_MLP_DIMS = (96, 192)
 
 def mlp_is_fused(g, dtype):
     # LViT only: GViT has too few tokens per image to fill the chip with 128-token workgroups
-    return g.kind == "lvit" and g.dim in FUSED_MLP_DIMS and g.hidden % (64 if dtype == torch.float16 else 32) == 0
+    return g.kind == "lvit" and g.shrink == 1 and g.dim in FUSED_MLP_DIMS and g.hidden % (64 if dtype == torch.float16 else 32) == 0
 
 
 def front_is_fused(g):
     """mirror of cfen_embed_qkv_supported (csrc/k_embed.hip): LViT levels 1 and 2 run gather + embedding + LN1 + qkv as one kernel"""
-    return g.kind == "lvit" and g.dim in (96, 192)
+    return g.kind == "lvit" and g.shrink == 1 and g.dim in (96, 192)
 
 
 def lvit_q_rows(dh=24):
@@ -69,7 +69,7 @@ def lvit_q_rows(dh=24):
 
 def window_fusable(g, dtype):
     """mirror of cfen_lvit_window_supported (csrc/k_lvit.hip): LViT level 1 (D = 96, 4 heads of 24, 256-token windows), fp16"""
-    return g.kind == "lvit" and dtype == torch.float16 and g.dim == 96 and g.heads == 4 and g.seq == 256 and g.hidden % 32 == 0
+    return g.kind == "lvit" and g.shrink == 1 and dtype == torch.float16 and g.dim == 96 and g.heads == 4 and g.seq == 256 and g.hidden % 32 == 0
 
 
 def pack_lvit_window(sd, g, dtype):
@@ -107,7 +107,72 @@ def ln_folded(w_packed, gamma, beta, bias, name, dtype, w_full):
     return {name + ".wl": wl.contiguous(), name + ".s": wl.double().sum(1).float(), name + ".bl": bl.float()}
 
 
+def pack_vit_shrunk(sd, g, dtype):
+    """v5 LViT (networks_iid_hlgvit_crs_gd4_cfs_v5.py:1086-1127): the block runs on C/4 = 6 / 12 / 24 channels.  Those maps live at a
+    channel stride of 8 / 16 / 24 (16-byte pixel vectors), so a token row has D_pad = p*p*cs slots of which D = p*p*C are real, and the
+    6-wide heads are padded to 8.  Every matrix is scattered into its zero-padded layout here, once:
+      residual-stream axis: ref feature f = c*p*p + i*p + j  ->  slot (i*p + j)*cs + c          (padding slots: zero rows / columns,
+                                                                                                 gamma = beta = bias = 0)
+      attention axis:       ref feature a = head*dh + d      ->  slot head*dh_pad + d
+    and 1/sqrt(dh) = sqrt(dh_pad/dh) / sqrt(dh_pad): the kernel scales by 1/sqrt(dh_pad), the factor sqrt(dh_pad/dh) rides on W_q.
+    csrc/cfen_net.cpp (Vit::Dn, Da, dh) normalises over the D real entries and runs the attention kernel at head_dim dh_pad."""
+    import math
+    n, C, p, D, H, heads = g.name, g.channels, g.patch, g.dim, g.hidden, g.heads
+    cs = cs_of(C)
+    Dp = p * p * cs
+    dh = D // heads
+    dhp = round_up(dh, 8)
+    Da = heads * dhp
+    f = torch.arange(D)
+    c, ij = f // (p * p), f % (p * p)
+    pos = ij * cs + c                                              # slot of ref feature f in the padded token row
+    a = torch.arange(D)
+    apos = (a // dh) * dhp + a % dh                                # slot of attention feature a
+    e = n + ".encoder.layers.0"
+    f32 = torch.float32
+    dev = sd[n + ".linear_encoding.weight"].device
+    pos, apos = pos.to(dev), apos.to(dev)
+
+    def mat(w, rows, nrows, cols, ncols):
+        out = torch.zeros(nrows, ncols, dtype=torch.float32, device=dev)
+        r = rows if rows is not None else torch.arange(nrows, device=dev)
+        cidx = cols if cols is not None else torch.arange(ncols, device=dev)
+        out[r[:, None], cidx[None, :]] = w.float()
+        return out.to(dtype).contiguous()
+
+    def vec(v, idx, nrows):
+        out = torch.zeros(nrows, dtype=f32, device=dev)
+        out[idx] = v.float()
+        return out
+
+    w_in = sd[e + ".self_attn.in_proj_weight"].float()
+    qkv = torch.zeros(3 * Da, Dp, dtype=torch.float32, device=dev)
+    for t in range(3):
+        blk = w_in[t * D:(t + 1) * D] * (math.sqrt(dhp / dh) if t == 0 else 1.0)
+        qkv[(t * Da + apos)[:, None], pos[None, :]] = blk
+    return {
+        n + ".embed.w": mat(sd[n + ".linear_encoding.weight"], pos, Dp, pos, Dp), n + ".embed.b": vec(sd[n + ".linear_encoding.bias"], pos, Dp),
+        n + ".pos": mat(sd[n + ".position_encoding.pe.weight"][:g.seq], None, g.seq, pos, Dp),
+        n + ".ln1.g": vec(sd[e + ".norm1.weight"], pos, Dp), n + ".ln1.b": vec(sd[e + ".norm1.bias"], pos, Dp),
+        n + ".qkv.w": qkv.to(dtype).contiguous(),
+        n + ".proj.w": mat(sd[e + ".self_attn.out_proj.weight"], pos, Dp, apos, Da),
+        n + ".ln2.g": vec(sd[e + ".norm2.weight"], pos, Dp), n + ".ln2.b": vec(sd[e + ".norm2.bias"], pos, Dp),
+        n + ".ffn1.w": mat(sd[e + ".linear1.weight"], None, H, pos, Dp), n + ".ffn1.b": sd[e + ".linear1.bias"].to(f32),
+        n + ".ffn2.w": mat(sd[e + ".linear2.weight"], pos, Dp, None, H), n + ".ffn2.b": vec(sd[e + ".linear2.bias"], pos, Dp),
+        n + ".head1.w": mat(sd[n + ".mlp_head.0.weight"], None, H, pos, Dp), n + ".head1.b": sd[n + ".mlp_head.0.bias"].to(f32),
+        n + ".head2.w": mat(sd[n + ".mlp_head.3.weight"], pos, Dp, None, H), n + ".head2.b": vec(sd[n + ".mlp_head.3.bias"], pos, Dp),
+    }
+
+
 def pack_vit(sd, g, dtype):
+    if g.shrink > 1:
+        out = pack_vit_shrunk(sd, g, dtype)
+        # where the padded row has no padding (24 channels) the LayerNorm fold of the unfused path applies as everywhere else
+        if cs_of(g.channels) == g.channels and (g.dim * (2 if dtype == torch.float16 else 4)) % 128 == 0:
+            n, e = g.name, g.name + ".encoder.layers.0"
+            out.update(ln_folded(None, out[n + ".ln1.g"], out[n + ".ln1.b"], None, n + ".qkv", dtype, out[n + ".qkv.w"].float()))
+            out.update(ln_folded(None, out[n + ".ln2.g"], out[n + ".ln2.b"], out[n + ".ffn1.b"], n + ".ffn1", dtype, out[n + ".ffn1.w"].float()))
+        return out
     n = g.name
     perm = token_perm(g.channels, g.patch)
     e = n + ".encoder.layers.0"
@@ -155,7 +220,10 @@ def pack_conv_weight(w, cin_pad, kc, dtype):
     """Conv2d weight (Cout, Cin_total, k, k) with Cin_total = nsrc*Cin -> [1][Cout_pad][Kpad]; taps are
     (src, ky, kx) so a 1x1 conv over a concat keeps its natural channel order."""
     cout, cin_total, k, _ = w.shape
-    if k == 1:
+    if k == 1 and cin_total < cin_pad:
+        flat = torch.zeros(cout, cin_pad, dtype=w.dtype, device=w.device)   # one source at a padded channel stride (v5 conv_extend: 6 -> 8)
+        flat[:, :cin_total] = w.reshape(cout, cin_total)
+    elif k == 1:
         nsrc_cin = cin_total                                   # concat sources are unpadded (C % 8 == 0)
         flat = w.reshape(cout, nsrc_cin)
     else:
@@ -274,7 +342,8 @@ def pack_state_dict(sd, cfg: NetConfig, dtype=torch.float16, pending=None):
     cfen_net_actnorm_pending, and the first forward initialises them on the device.  Without a `pending` dict this raises."""
     kc = 32 if dtype == torch.float16 else 16
     nf, h = cfg.n_feats, cfg.head_channels
-    cfs = cfg.variant == "cfs"      # sibling generator networks_iid_hlgvit_crs_gd4_cfs.py: see config.NetConfig.image_size
+    cfs = cfg.full_res              # sibling generators networks_iid_hlgvit_crs_gd4_cfs.py / ..._crs_gd4.py: see config.NetConfig.image_size
+    crs = cfg.variant == "crs"
     out = {}
     for g in cfg.vit_instances():
         out.update(pack_vit(sd, g, dtype))
@@ -314,6 +383,10 @@ def pack_state_dict(sd, cfg: NetConfig, dtype=torch.float16, pending=None):
             out[name + ".w"] = pack_convT_weight(w, cs_of(cin), kc, dtype)
         out[name + ".scale"], out[name + ".shift"] = epilogue(name, key, an, cp)
 
+    for g in cfg.vit_instances():
+        if g.shrink > 1:            # v5:1101-1104 conv_shrink / conv_extend (Conv2d 1x1 + ActNorm2d + ReLU)
+            conv(g.name + ".shrink", g.name + ".conv_shrink.0", g.map_channels, an=g.name + ".conv_shrink.1")
+            conv(g.name + ".extend", g.name + ".conv_extend.0", g.channels, an=g.name + ".conv_extend.1")
     conv("head.0.0", "head.0.0", 3, rows=(1, 2))
     conv("head.0.1.body.0", "head.0.1.body.0", h, rows=(1, 1))
     conv("head.0.1.body.2", "head.0.1.body.2", h, rows=(1, 1))
@@ -332,7 +405,7 @@ def pack_state_dict(sd, cfg: NetConfig, dtype=torch.float16, pending=None):
         convT("us_conv_d02" + b, "us_conv_d02%s.0" % b, 2 * nf, an="us_conv_d02%s.1" % b, edge=cfg.load_size // 2)
         if not cfs:
             convT("us_conv_d01" + b, "us_conv_d01%s.0" % b, nf, an="us_conv_d01%s.1" % b, edge=cfg.load_size)
-        if b != "d":
+        if b != "d" or crs:         # crs:327-330: D's skip fuse is a 1x1 conv too, over three maps
             conv("sk_conv_d03" + b, "sk_conv_d03%s.0" % b, 2 * nf, an="sk_conv_d03%s.1" % b)
             conv("sk_conv_d02" + b, "sk_conv_d02%s.0" % b, nf, an="sk_conv_d02%s.1" % b)
         T = "tail_" + b.upper()
@@ -349,7 +422,7 @@ def pack_state_dict(sd, cfg: NetConfig, dtype=torch.float16, pending=None):
         else:
             conv(T + ".conv3", src + ".0.1", h, an=src + ".0.2", rows=(1, 1))
             conv(T + ".conv7", src + ".0.5", h, rows=(1, 3))
-    for n in ("cfsm2g_d03d", "cfsm2g_d02d"):
+    for n in (() if crs else ("cfsm2g_d03d", "cfsm2g_d02d")):
         parts = []
         for fc in ("fc_avg_cf1", "fc_avg_cf2", "fc_max_cf1", "fc_max_cf2"):
             parts.append(sd["%s.0.%s.0.weight" % (n, fc)].float().reshape(-1))

@@ -199,7 +199,8 @@ int cfen_u8hwc_to_nhwc(int dtype, const unsigned char* in, void* out, int B, int
 int cfen_tensor2im_u8(const float* in, unsigned char* out, int C, int H, int W, void* stream);
 
 /* Conv2d / ConvTranspose2d(4,2,1) as implicit GEMM with fused affine + activation + residuals.
- * kind 0: Conv2d(k, stride, pad) over nsrc (1|2) channel-concatenated inputs; kind 1: ConvTranspose2d k4 s2 p1.
+ * kind 0: Conv2d(k, stride, pad) over nsrc (1..3) channel-concatenated inputs (src0 | src1 | src2, the concat is never
+ * materialised: v3:488 torch.cat((local, global), 1); crs_gd4:854 cat of three); kind 1: ConvTranspose2d k4 s2 p1.
  * weight: packed [nphase][Cout_pad][Kpad] (packing.py); scale/shift: [Cout_pad] fp32.
  * wlayout 0: k = tap*Cin + c (any geometry).  wlayout 1 ("rows", LDS-tiled kernel): stride 1, pad k/2, one source,
  * Cout <= 16, H % 8 == 0, W % 64 == 0, pixel stride 16/32/64 bytes; each kernel row is padded with zero taps to a
@@ -223,6 +224,7 @@ typedef struct cfen_conv_args {
   const void* res0;
   const void* res1;
   void* out;
+  const void* src2;       /* third concatenated input (nsrc == 3), else NULL */
 } cfen_conv_args;
 int cfen_conv2d(int dtype, const cfen_conv_args* a, void* stream);
 

@@ -64,3 +64,33 @@ def test_tuning_knobs_validate_without_a_gpu():
     for key, val in ((b"gemm.kernel", -1), (b"gemm.large", 4), (b"gemm.small", 15), (b"gemm.splitk", 1), (b"mlp.small_tiles", 10),
                      (b"net.attn_head_major", 1), (b"net.embed_gather", 1), (b"net.fused_front_max_dim", 192), (b"net.skip_classes", 0)):
         assert lib.cfen_tune(key, val) == 0, key       # (the shipped defaults: the knobs are process-wide)
+
+
+@pytest.mark.parametrize("variant", ["v3", "cfs", "crs", "v5"])
+@pytest.mark.parametrize("dtype", ["fp16", "fp32"])
+def test_packed_parameters_are_exactly_what_the_launch_plan_asks_for(variant, dtype):
+    """packing.pack_state_dict (host) and cfen_net::build (csrc/cfen_net.cpp) must agree on every packed name and byte size, for each of
+    the four generators; set_param only records the pointer, so this runs without a GPU"""
+    import torch
+    from cfen_vit_dehazing_amd import _lib
+    from cfen_vit_dehazing_amd.config import NetConfig
+    from cfen_vit_dehazing_amd.hipnet import _VARIANT_CODE
+    from cfen_vit_dehazing_amd.manifest import generate_state_dict
+    from cfen_vit_dehazing_amd.packing import pack_state_dict
+    lib = _lib.load()
+    cfg = NetConfig(24, 4, patch_size=8, load_size=64, variant=variant)
+    td = torch.float16 if dtype == "fp16" else torch.float32
+    packed = pack_state_dict(generate_state_dict(cfg, seed=0, with_dead=False), cfg, td)
+    cc = _lib.NetConfigC(batch=2, n_feats=24, hidden_dim_ratio=4, patch_size=8, load_size=64, num_heads=4, dtype=_lib.dtype_code(td),
+                         reserved=_VARIANT_CODE[variant] << 8)
+    h = ctypes.c_void_p()
+    assert lib.cfen_net_create(ctypes.byref(h), ctypes.byref(cc)) == 0, lib.cfen_last_error()
+    keep = {}
+    for name, t in packed.items():
+        if isinstance(t, str):
+            t = packed[t[1:]]
+        keep[name] = t = t.contiguous()
+        assert lib.cfen_net_set_param(h, name.encode(), ctypes.c_void_p(t.data_ptr()), t.numel() * t.element_size()) == 0, lib.cfen_last_error()
+    buf = ctypes.create_string_buffer(1 << 16)
+    assert lib.cfen_net_missing_params(h, buf, 1 << 16) == 0, buf.value[:400]
+    lib.cfen_net_destroy(h)

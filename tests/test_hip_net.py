@@ -372,11 +372,12 @@ def test_uint8_input_equals_host_normalised_input():
         assert torch.equal(p, q)
 
 
-# ---- sibling generator --model_G iid_hlgvit_crs_gd4_cfs (models/networks_iid_hlgvit_crs_gd4_cfs.py): same kernels, second launch plan ---------
+# ---- sibling generators --model_G iid_hlgvit_crs_gd4_cfs / iid_hlgvit_crs_gd4 / iid_hlgvit_crs_gd4_cfs_v5 (models/networks_iid_hlgvit_crs_gd4_cfs.py,
+# ..._crs_gd4.py, ..._cfs_v5.py): same kernels, other launch plans ---------
 
 def _cfs_stages(net, z):
     st = {}
-    xf = net.stage("head")
+    xf = net.stage("head" if net.cfg.full_res else "ds_conv_e01")
     for n in [str(s) for s in z["stage_names"]]:
         if n.startswith("tail_"):
             continue
@@ -387,10 +388,11 @@ def _cfs_stages(net, z):
     return st
 
 
-@pytest.mark.parametrize("name", ["cfs_tiny_nf24_hdr4", "cfs_full256_nf24_hdr4"])
-def test_cfs_variant_fp32_all_stages_and_fp16(name):
+@pytest.mark.parametrize("name", ["cfs_tiny_nf24_hdr4", "cfs_full256_nf24_hdr4", "crs_tiny_nf24_hdr4", "crs_full256_nf24_hdr4",
+                                  "v5_tiny_nf24_hdr4", "v5_full512_nf24_hdr4"])
+def test_sibling_variants_fp32_all_stages_and_fp16(name):
     cfg, batch, z = load_net_fixture(name)
-    assert cfg.variant == "cfs" and cfg.image_size == cfg.load_size
+    assert cfg.variant == name.split("_")[0] and cfg.image_size == (cfg.load_size if cfg.full_res else 2 * cfg.load_size)
     net = make_net(cfg, "fp32")
     x = synthetic_input(batch, cfg).to("cuda:0")
     outs = net(x)
@@ -407,3 +409,25 @@ def test_cfs_variant_fp32_all_stages_and_fp16(name):
     for a, b in zip(net16(x), gouts):
         assert torch.equal(a, b)
     print("%s: fp32 outputs max-abs vs reference %.2e, fp16 %.2e" % (name, wo, w16))
+
+
+def test_v5_reference_init_actnorm_first_window_on_the_device():
+    """v5's 48 ActNorm2d layers: the 24 inside the LViT modules are initialised from the first (top-left) window only, because the
+    reference calls an LViT module once per window (networks_iid_hlgvit_crs_gd4_cfs_v5.py:403-440, 1139, 1190; models/actnorm.py:25-37)"""
+    name = "refinit_v5_tiny_nf24_hdr4"
+    cfg, batch, z = load_net_fixture(name)
+    net = make_net(cfg, "fp32", mode="reference_init")
+    x = synthetic_input(batch, cfg).to("cuda:0")
+    outs = [o.clone() for o in net(x)]
+    sd = net.state_dict()
+    names = [str(v) for v in z["actnorm_names"]]
+    assert len(names) == 48 and sum(".conv_shrink." in k or ".conv_extend." in k for k in names) == 24
+    for k in names:
+        assert int(sd[k + ".initialized"]) == 1
+        dw = float(np.abs(sd[k + ".weight"].cpu().numpy() - z["actnorm_w/" + k]).max())
+        db = float(np.abs(sd[k + ".bias"].cpu().numpy() - z["actnorm_b/" + k]).max())
+        assert dw <= 2e-4 and db <= 2e-3 * max(1.0, float(np.abs(z["actnorm_b/" + k]).max())), "%s: dweight %.2e dbias %.2e" % (k, dw, db)
+    worst = check_outputs(z, outs, 1e-3)
+    for a, b in zip(outs, net(x)):
+        assert torch.equal(a, b)
+    print("%s fp32 with device ActNorm init (windowed for the in-LViT layers): outputs max-abs vs reference %.2e" % (name, worst))
