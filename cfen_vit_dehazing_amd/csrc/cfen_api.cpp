@@ -133,6 +133,16 @@ int cfen_tune(const char* key, int value) {
     (key[5] == 'l' ? cfen_tune_gemm_large() : cfen_tune_gemm_small()) = value;
     return CFEN_OK;
   }
+  if (!strcmp(key, "gemm.big")) {
+    CFEN_CHECK_ARG(value == 0 || value == 6, "tune: gemm.big is 0 (off) or 6 (192 x 128 tiles)");
+    cfen_tune_gemm_big() = value;
+    return CFEN_OK;
+  }
+  if (!strcmp(key, "gemm.big_min_tiles")) {
+    CFEN_CHECK_ARG(value >= 1, "tune: gemm.big_min_tiles must be positive");
+    cfen_tune_gemm_big_min_tiles() = value;
+    return CFEN_OK;
+  }
   if (!strcmp(key, "embed.lds")) {
     cfen_tune_embed_lds() = value & 7;
     return CFEN_OK;

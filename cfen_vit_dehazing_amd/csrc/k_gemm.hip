@@ -83,10 +83,10 @@ template <typename T> CFEN_DEV int gather_off(const GemmArgs<T>& a, int k) {
 // loads are issued before the first store (R may alias Y element for element -- in-place residual -- so the compiler
 // must not be left to order them: it would wait for every load separately), bias is read once.
 // LN-fold: acc <- rstd_m * (acc - mean_m * s_n) for the lane's (token m + 16 j, features n + 16 i .. +3); stats[row] = (mean, rstd)
-template <typename T, int TM>
-CFEN_DEV void gemm_lnfold(const GemmArgs<T>& a, floatx4 (&acc)[3][TM], int n, const float* stats, int mloc) {
+template <typename T, int TM, int TN = 3>
+CFEN_DEV void gemm_lnfold(const GemmArgs<T>& a, floatx4 (&acc)[TN][TM], int n, const float* stats, int mloc) {
 #pragma unroll
-  for (int i = 0; i < 3; ++i) {
+  for (int i = 0; i < TN; ++i) {
     const floatx4 sn = n + 16 * i < a.N ? *reinterpret_cast<const floatx4*>(a.lnf_s + n + 16 * i) : floatx4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int j = 0; j < TM; ++j) {
@@ -96,22 +96,56 @@ CFEN_DEV void gemm_lnfold(const GemmArgs<T>& a, floatx4 (&acc)[3][TM], int n, co
   }
 }
 
-template <typename T, int TM>
-CFEN_DEV void gemm_epilogue(const GemmArgs<T>& a, floatx4 (&acc)[3][TM], int n, int m) {
+template <typename T, int TM, int TN = 3>
+CFEN_DEV void gemm_epilogue(const GemmArgs<T>& a, floatx4 (&acc)[TN][TM], int n, int m) {
   typedef typename Mma<T>::out4 out4;
-  floatx4 bias[3];
-  bool nok[3];
+  floatx4 bias[TN];
+  bool nok[TN];
 #pragma unroll
-  for (int i = 0; i < 3; ++i) {
+  for (int i = 0; i < TN; ++i) {
     nok[i] = n + 16 * i < a.N;
     bias[i] = (a.bias && nok[i]) ? *reinterpret_cast<const floatx4*>(a.bias + n + 16 * i) : floatx4{0.f, 0.f, 0.f, 0.f};
   }
-  out4 rv[3][TM], pv[3][TM];
+  if constexpr (TN > 3) {
+    // big wave tiles (96 accumulator registers): one token column at a time, so only TN residual vectors are live beside the accumulators
+#pragma unroll
+    for (int j = 0; j < TM; ++j) {
+      const int mj = m + 16 * j;
+      if (mj >= a.M) continue;
+      out4 rv[TN], pv[TN];
+#pragma unroll
+      for (int i = 0; i < TN; ++i) {
+        if (a.gmap && nok[i]) rv[i] = *reinterpret_cast<const out4*>(gather_pix(a, mj) + gather_off(a, n + 16 * i));
+        else if (a.R && nok[i]) rv[i] = *reinterpret_cast<const out4*>(a.R + (size_t)mj * a.ldr + n + 16 * i);
+        if (a.P && nok[i]) pv[i] = *reinterpret_cast<const out4*>(a.P + (size_t)(mj % a.period) * a.N + n + 16 * i);
+      }
+#pragma unroll
+      for (int i = 0; i < TN; ++i) {
+        if (!nok[i]) continue;
+        floatx4 v = acc[i][j] + bias[i];
+        if (a.relu) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f);
+        }
+        if (a.R || a.gmap) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) v[r] += (float)rv[i][r];
+        }
+        if (a.P) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) v[r] += (float)pv[i][r];
+        }
+        store4<T>(a.Y + (size_t)mj * a.ldy + n + 16 * i, v);
+      }
+    }
+    return;
+  }
+  out4 rv[TN][TM], pv[TN][TM];
 #pragma unroll
   for (int j = 0; j < TM; ++j) {
     const int mj = m + 16 * j;
 #pragma unroll
-    for (int i = 0; i < 3; ++i) {
+    for (int i = 0; i < TN; ++i) {
       const bool ok = nok[i] && mj < a.M;
       if (a.gmap && ok) rv[i][j] = *reinterpret_cast<const out4*>(gather_pix(a, mj) + gather_off(a, n + 16 * i));
       else if (a.R && ok) rv[i][j] = *reinterpret_cast<const out4*>(a.R + (size_t)mj * a.ldr + n + 16 * i);
@@ -123,7 +157,7 @@ CFEN_DEV void gemm_epilogue(const GemmArgs<T>& a, floatx4 (&acc)[3][TM], int n, 
     const int mj = m + 16 * j;
     if (mj >= a.M) continue;
 #pragma unroll
-    for (int i = 0; i < 3; ++i) {
+    for (int i = 0; i < TN; ++i) {
       if (!nok[i]) continue;
       floatx4 v = acc[i][j] + bias[i];
       if (a.relu) {
@@ -243,16 +277,19 @@ CFEN_DEV void dma16(const void* g, unsigned char* l) {
 }
 
 // NS LDS stages form a ring: NS - 1 K-steps of DMA are in flight while one is consumed, one barrier per K-step.
-template <typename T, int TM, int NS>   // block tile = 96 features x 32*TM tokens; a wave owns 3 x TM MFMA tiles
-__global__ __launch_bounds__(256) void k_gemm_dma(Grouped<GemmArgs<T>> ga) {
+// TN = 6, TM = 4 (192 x 128 block, 96 x 64 per wave): per K-step a wave reads (6 + 4) fragments for 24 MFMAs instead of (3 + 2) for 6
+// and the L2 -> LDS traffic per flop halves -- and it is slower on every GEMM of this network, see cfen_tune_gemm_big().
+template <typename T, int TM, int NS, int TN = 3>   // block tile = 32*TN features x 32*TM tokens; a wave owns TN x TM MFMA tiles
+__global__ __launch_bounds__(256, (TN > 3 && NS == 2) ? 2 : 1) void k_gemm_dma(Grouped<GemmArgs<T>> ga) {
   const GemmArgs<T>& a = ga.g[blockIdx.z];
   constexpr int EPL = Mma<T>::EPL;
   constexpr int BK = G_BKB / (int)sizeof(T);
   constexpr int NCH = BK / Mma<T>::KC;   // 2
+  constexpr int G_BN = 32 * TN;          // (shadows the file-level 96 of the other kernels)
   constexpr int BM = 32 * TM, ROWS = G_BN + BM, LOADS = ROWS / 32;
   constexpr int STAGE = ROWS * G_BKB;    // 28 KiB at TM = 4
   typedef typename Mma<T>::frag frag;
-  static_assert(NS * STAGE <= 65536, "static LDS");
+  static_assert(NS * STAGE <= 160 * 1024, "LDS");
   __shared__ __attribute__((aligned(1024))) unsigned char lds[NS * STAGE];
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -277,19 +314,19 @@ __global__ __launch_bounds__(256) void k_gemm_dma(Grouped<GemmArgs<T>> ga) {
   }
 #define CFEN_GEMM_DMA_ISSUE(kt_, buf_)                                                                              \
   _Pragma("unroll") for (int i_ = 0; i_ < LOADS; ++i_)                                                              \
-      dma16(gptr[i_] + ((i_ >= 3 && gpc[i_] >= 0) ? gather_off(a, (kt_) * BK + gpc[i_]) : (kt_) * BK),                       \
+      dma16(gptr[i_] + ((i_ >= TN && gpc[i_] >= 0) ? gather_off(a, (kt_) * BK + gpc[i_]) : (kt_) * BK),                       \
             lds + (buf_) * STAGE + (i_ * 256 + wave * 64) * 16)
 
-  floatx4 acc[3][TM];
+  floatx4 acc[TN][TM];
 #pragma unroll
-  for (int i = 0; i < 3; ++i)
+  for (int i = 0; i < TN; ++i)
 #pragma unroll
     for (int j = 0; j < TM; ++j) acc[i][j] = floatx4{0.f, 0.f, 0.f, 0.f};
 
   // fragment read offsets: row r, chunk c, quarter h -> r*128 + (((c*4 + h) ^ (r & 7)) << 4)
-  int aoff[3], boff[TM];
+  int aoff[TN], boff[TM];
 #pragma unroll
-  for (int i = 0; i < 3; ++i) aoff[i] = (wn * 48 + i * 16 + r16) * G_BKB;
+  for (int i = 0; i < TN; ++i) aoff[i] = (wn * 16 * TN + i * 16 + r16) * G_BKB;
 #pragma unroll
   for (int j = 0; j < TM; ++j) boff[j] = (G_BN + wm * 16 * TM + j * 16 + r16) * G_BKB;
   const int sw = r16 & 7;   // every fragment row of this lane has (row & 7) == (r16 & 7): all tile offsets are multiples of 16
@@ -333,13 +370,13 @@ __global__ __launch_bounds__(256) void k_gemm_dma(Grouped<GemmArgs<T>> ga) {
 #pragma unroll
     for (int c = 0; c < NCH; ++c) {
       const int po = ((c * 4 + h) ^ sw) << 4;
-      frag af[3], bf[TM];
+      frag af[TN], bf[TM];
 #pragma unroll
-      for (int i = 0; i < 3; ++i) af[i] = *reinterpret_cast<const frag*>(st + aoff[i] + po);
+      for (int i = 0; i < TN; ++i) af[i] = *reinterpret_cast<const frag*>(st + aoff[i] + po);
 #pragma unroll
       for (int j = 0; j < TM; ++j) bf[j] = *reinterpret_cast<const frag*>(st + boff[j] + po);
 #pragma unroll
-      for (int i = 0; i < 3; ++i)
+      for (int i = 0; i < TN; ++i)
 #pragma unroll
         for (int j = 0; j < TM; ++j) acc[i][j] = Mma<T>::mma(af[i], bf[j], acc[i][j]);
     }
@@ -350,11 +387,11 @@ __global__ __launch_bounds__(256) void k_gemm_dma(Grouped<GemmArgs<T>> ga) {
 
   if (a.nsplit > 1) {   // fp32 partial tile of this K slice
     float* pp = a.part + (size_t)blockIdx.y * a.M * a.N;
-    const int n = n0 + wn * 48 + 4 * h, m = m0 + wm * 16 * TM + r16;
+    const int n = n0 + wn * 16 * TN + 4 * h, m = m0 + wm * 16 * TM + r16;
 #pragma unroll
     for (int j = 0; j < TM; ++j)
 #pragma unroll
-      for (int i = 0; i < 3; ++i)
+      for (int i = 0; i < TN; ++i)
         if (m + 16 * j < a.M && n + 16 * i < a.N) *reinterpret_cast<floatx4*>(pp + (size_t)(m + 16 * j) * a.N + n + 16 * i) = acc[i][j];
     return;
   }
@@ -375,9 +412,9 @@ __global__ __launch_bounds__(256) void k_gemm_dma(Grouped<GemmArgs<T>> ga) {
       }
     }
     __syncthreads();
-    gemm_lnfold<T, TM>(a, acc, n0 + wn * 48 + 4 * h, stats, wm * 16 * TM + r16);
+    gemm_lnfold<T, TM, TN>(a, acc, n0 + wn * 16 * TN + 4 * h, stats, wm * 16 * TM + r16);
   }
-  gemm_epilogue<T, TM>(a, acc, n0 + wn * 48 + 4 * h, m0 + wm * 16 * TM + r16);
+  gemm_epilogue<T, TM, TN>(a, acc, n0 + wn * 16 * TN + 4 * h, m0 + wm * 16 * TM + r16);
 #undef CFEN_GEMM_DMA_ISSUE
 }
 
@@ -517,6 +554,12 @@ int launch_gemm(int ng, const CfenGemmPtrs* gp, int ldx, int ldw, int ldr, int p
     while (nsplit > 1 && (nk % nsplit || (size_t)nsplit * M * N * sizeof(float) > splitk_ws_bytes)) nsplit /= 2;
     if (nsplit > 1) { kern = 2; stages = 2; }
   }
+  // many tokens against >= 768 features (LViT-3 / GViT-1 qkv, ffn1, head1): 192 x 128 tiles when they still fill the chip
+  const long long tiles_big = (long long)ng * ((N + 191) / 192) * ((M + 127) / 128);
+  if (kern < 0 && k128 && cfen_tune_gemm_big() > 0 && N >= 768 && tiles_big >= cfen_tune_gemm_big_min_tiles()) {
+    kern = 6;
+    stages = 2 + cfen_tune_gemm_big() / 10;
+  }
   if (kern < 0) {
     const int pick = !k128 ? 0 : (M <= 128 && N <= 2048 && !tg && !lnf) ? 1 : tiles64 >= 1024 ? cfen_tune_gemm_large() : tiles32 <= 512 ? cfen_tune_gemm_small() : 5;
     kern = pick % 10;
@@ -524,7 +567,7 @@ int launch_gemm(int ng, const CfenGemmPtrs* gp, int ldx, int ldw, int ldr, int p
   }
   CFEN_CHECK_ARG(!(tg && kern == 1), "gemm (gather): k_gemm_skinny does not gather");
   if (kern < 2) stages = 2;
-  const int bn = kern == 1 ? 16 : G_BN, bm = kern == 0 || kern == 2 ? 128 : kern == 3 ? 96 : kern == 4 || kern == 1 ? 64 : 32;
+  const int bn = kern == 1 ? 16 : kern == 6 ? 192 : G_BN, bm = kern == 0 || kern == 2 || kern == 6 ? 128 : kern == 3 ? 96 : kern == 4 || kern == 1 ? 64 : 32;
   const TileMap map = make_tile_map((N + bn - 1) / bn, (M + bm - 1) / bm, (double)N * K * sizeof(T), (double)M * K * sizeof(T));
   for (int g = 0; g < ng; ++g) {
     ga.g[g].map = map;
@@ -544,6 +587,7 @@ int launch_gemm(int ng, const CfenGemmPtrs* gp, int ldx, int ldw, int ldr, int p
     case 14: case 24: CFEN_LAUNCH((k_gemm_dma<T, 2, 3>), grid, dim3(256), 0, s, ga); break;
     case 5: CFEN_LAUNCH((k_gemm_dma<T, 1, 2>), grid, dim3(256), 0, s, ga); break;
     case 15: CFEN_LAUNCH((k_gemm_dma<T, 1, 3>), grid, dim3(256), 0, s, ga); break;
+    case 6: case 16: case 26: CFEN_LAUNCH((k_gemm_dma<T, 4, 2, 6>), grid, dim3(256), 0, s, ga); break;
     default: CFEN_LAUNCH((k_gemm_dma<T, 1, 4>), grid, dim3(256), 0, s, ga); break;
   }
   CFEN_CHECK_LAUNCH("gemm");
@@ -563,6 +607,18 @@ float& cfen_gemm_lnf_eps() {
 }
 int& cfen_tune_gemm_splitk() {
   static int v = 1;
+  return v;
+}
+// 0 (default): off; 6: 192 x 128 tiles, 2-stage ring (80 KB of LDS, two workgroups a CU).  MEASURED (MI355X, B = 8, round 2): the
+// LViT-3 / GViT-1 qkv, ffn1, head1 GEMMs are 5 - 25 % SLOWER on it (ln1_qkv x3 60 -> 76 us, ln2_ffn1 x3 75 -> 80 us; a 3-stage
+// one-workgroup-a-CU variant 104 / 119 us): with K = 384 a tile is 6 dependent K-steps, the kernel is bound by the latency of that
+// chain and what hides it is the number of workgroups a CU holds, not the bytes or LDS reads per flop.  Kept as a tested variant.
+int& cfen_tune_gemm_big() {
+  static int v = 0;
+  return v;
+}
+int& cfen_tune_gemm_big_min_tiles() {   // the 192 x 128 tile is used when a launch has at least this many of them
+  static int v = 256;
   return v;
 }
 int& cfen_tune_gemm_large() {

@@ -98,6 +98,50 @@ def test_gemm_with_layernorm_folded(dtype, M, D, N, relu):
     close(two, want, tol(dtype, 8))
 
 
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("kernel", [6])
+@pytest.mark.parametrize("M,N,K", [(4096, 1536, 384), (300, 1000, 384), (1000, 1152, 1536), (130, 776, 128), (128, 192, 64)])
+def test_gemm_big_tile(dtype, kernel, M, N, K):
+    """k_gemm_dma<TM = 4, TN = 6>: 192 x 128 block tile (96 x 64 per wave; a measured-slower variant kept behind "gemm.big"); ragged M
+    and N, every epilogue operand, in-place residual"""
+    x, w = rnd((M, K), 1, dtype), rnd((N, K), 2, dtype, 1 / math.sqrt(K))
+    bias, res, pos = rnd((N,), 3, torch.float32), rnd((M, N), 4, dtype), rnd((16, N), 5, dtype)
+    ref = x.double() @ w.double().t()
+    d = dev()
+    ops.tune("gemm.kernel", kernel)
+    try:
+        close(ops.gemm_nt(x.to(d), w.to(d)), ref, tol(dtype, 4), "plain")
+        want = torch.relu(ref + bias.double()) + res.double() + pos.double()[torch.arange(M) % 16]
+        close(ops.gemm_nt(x.to(d), w.to(d), bias=bias.to(d), residual=res.to(d), pos=pos.to(d), relu=True), want, tol(dtype, 8), "bias+relu+res+pos")
+        r = res.to(d).clone()
+        ops.gemm_nt(x.to(d), w.to(d), residual=r, out=r)
+        close(r, ref + res.double(), tol(dtype, 8), "in-place residual")
+        base = ops.gemm_nt(x.to(d), w.to(d), bias=bias.to(d), relu=True)
+    finally:
+        ops.tune("gemm.kernel", -1)
+    other = ops.gemm_nt(x.to(d), w.to(d), bias=bias.to(d), relu=True)          # the shape rule's own choice: same sums, same order of K
+    assert torch.equal(base, other) or float((base.float() - other.float()).abs().max()) <= tol(dtype, 4)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_gemm_big_tile_with_layernorm_folded(dtype):
+    from cfen_vit_dehazing_amd.packing import ln_folded
+    M, D, N = 2048, 384, 1536
+    x = rnd((M, D), 1, dtype, 2.0) + 1.0
+    w = rnd((N, D), 2, torch.float32, D ** -0.5)
+    g, b, bias = 1 + 0.1 * rnd((D,), 3, torch.float32), 0.1 * rnd((D,), 4, torch.float32), rnd((N,), 5, torch.float32)
+    want = (cfen_oracle.layer_norm(x.double(), g.double(), b.double()) @ w.double().t() + bias.double()).relu()
+    f = ln_folded(None, g, b, bias, "l", dtype, w)
+    ops.tune("gemm.big_min_tiles", 1)
+    try:
+        ops.tune("gemm.big", 6)
+        got = ops.gemm_ln(x.to(dev()), f["l.wl"].to(dev()), f["l.s"].to(dev()), f["l.bl"].to(dev()), relu=True)
+        close(got, want, tol(dtype, 8))
+    finally:
+        ops.tune("gemm.big", 0)
+        ops.tune("gemm.big_min_tiles", 256)
+
+
 def attn_ref(qkv, nseq, S, heads):
     D = qkv.shape[1] // 3
     dh = D // heads
