@@ -32,6 +32,10 @@ struct CfenGemmPtrs {
   // lnf_s[n] = sum_k W[n][k], bias = W0 beta + b0:  Y = act(rstd_m (x W^T - mean_m lnf_s) + bias) + ...; mean / rstd of every row are
   // accumulated by the workgroup from the X tiles it stages anyway.  null = plain GEMM.
   const float* lnf_s;
+  // W is stored tile-major instead of row-major: [ceil(N / 96)][K * sizeof(T) / 128][96 rows][128 bytes], rows past N zero (packing.pack_wtile).
+  // One K-step of a 96-feature tile is then ONE contiguous 12 KB run of HBM instead of 96 pieces of 128 bytes a whole row apart --
+  // what the few-token GViT GEMMs (weights streamed once from HBM, 0.5 GB per forward) are bound by.  k_gemm_dma with 96-feature tiles only.
+  int wtile = 0;
 };
 int cfen_gemm_impl_g(int dtype, int ng, const CfenGemmPtrs* gp, int ldx, int ldw, int ldr, int period, int ldy, int M, int N, int K, int relu,
                      const CfenTokGather* tg, hipStream_t s, float* const* splitk_ws, size_t splitk_ws_bytes);

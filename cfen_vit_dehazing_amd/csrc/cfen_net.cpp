@@ -104,6 +104,8 @@ struct cfen_net {
                                    // levels run at the image's own resolution -- no ds_conv_e01 / us_conv_d01*, n_feats channels in head and tails
   bool crs = false;                // ..._crs_gd4.py (variant 2): D's skip fuse is a 1x1 conv over (D, R, S) upsampled maps instead of CFSM2G (crs:854,889)
   bool v5 = false;                 // ..._cfs_v5.py (variant 3): v3 with every LViT block between conv_shrink / conv_extend
+  bool wtile = false;              // cfg.reserved bit 1: GViT weights are packed tile-major (CfenGemmPtrs::wtile, packing.pack_wtile)
+  size_t wbytes(const Vit& v, int N, int K) const { return (size_t)(v.global && wtile ? cfen_round_up(N, 96) : N) * K * esz; }
   int full = 0;                    // image edge
   int blk_kind = 0;                // 0 CNN, 1 GViT block, 2 LViT block (selects bits 8.. / 16.. of "net.skip_classes")
   unsigned char* base = nullptr;   // workspace of the current / last forward
@@ -253,6 +255,7 @@ int cfen_net::build() {
   cfs = variant == 1 || variant == 2;
   crs = variant == 2;
   v5 = variant == 3;
+  wtile = (cfg.reserved & 2) != 0;
   CFEN_CHECK_ARG(!v5 || nf % cfg.num_heads == 0, "net (v5): shrunk embedding dim (n_feats) not divisible by heads");
   full = cfs ? N : 2 * N;
 
@@ -303,23 +306,23 @@ int cfen_net::build() {
     (v.global ? max_mh_g : max_mh_l) = std::max(v.global ? max_mh_g : max_mh_l, ntok * v.hidden);
     if (v.global) max_small = std::max(max_small, (size_t)B * v.mapH * v.mapH * v.C);
     const std::string& n = v.name;
-    need(n + ".embed.w", (size_t)v.D * v.D * esz); need(n + ".embed.b", (size_t)v.D * 4);
+    need(n + ".embed.w", wbytes(v, v.D, v.D)); need(n + ".embed.b", (size_t)v.D * 4);
     if (v.fused_front) { need(n + ".embed.wk", (size_t)v.D * v.D * esz); need(n + ".qkv.wk", (size_t)3 * v.D * v.D * esz); }
     if (v.fused_window) {
       need(n + ".lw.wkv", (size_t)2 * v.D * v.D * esz); need(n + ".lw.wq", (size_t)v.heads * 32 * v.D * esz); need(n + ".lw.wp", (size_t)v.heads * v.D * 32 * esz);
     }
     need(n + ".pos", (size_t)v.S * v.D * esz);
     need(n + ".ln1.g", (size_t)v.D * 4); need(n + ".ln1.b", (size_t)v.D * 4);
-    need(n + ".qkv.w", (size_t)3 * v.Da * v.D * esz);
-    need(n + ".proj.w", (size_t)v.D * v.Da * esz);
-    if (v.ln_fold1) { need(n + ".qkv.wl", (size_t)3 * v.Da * v.D * esz); need(n + ".qkv.s", (size_t)3 * v.Da * 4); need(n + ".qkv.bl", (size_t)3 * v.Da * 4); }
-    if (v.ln_fold2) { need(n + ".ffn1.wl", (size_t)v.hidden * v.D * esz); need(n + ".ffn1.s", (size_t)v.hidden * 4); need(n + ".ffn1.bl", (size_t)v.hidden * 4); }
+    need(n + ".qkv.w", wbytes(v, 3 * v.Da, v.D));
+    need(n + ".proj.w", wbytes(v, v.D, v.Da));
+    if (v.ln_fold1) { need(n + ".qkv.wl", wbytes(v, 3 * v.Da, v.D)); need(n + ".qkv.s", (size_t)3 * v.Da * 4); need(n + ".qkv.bl", (size_t)3 * v.Da * 4); }
+    if (v.ln_fold2) { need(n + ".ffn1.wl", wbytes(v, v.hidden, v.D)); need(n + ".ffn1.s", (size_t)v.hidden * 4); need(n + ".ffn1.bl", (size_t)v.hidden * 4); }
     need(n + ".ln2.g", (size_t)v.D * 4); need(n + ".ln2.b", (size_t)v.D * 4);
     const char* wn = v.fused_mlp ? ".wk" : ".w";
-    need(n + ".ffn1" + wn, (size_t)v.hidden * v.D * esz); need(n + ".ffn1.b", (size_t)v.hidden * 4);
-    need(n + ".ffn2" + wn, (size_t)v.hidden * v.D * esz); need(n + ".ffn2.b", (size_t)v.D * 4);
-    need(n + ".head1" + wn, (size_t)v.hidden * v.D * esz); need(n + ".head1.b", (size_t)v.hidden * 4);
-    need(n + ".head2" + wn, (size_t)v.hidden * v.D * esz); need(n + ".head2.b", (size_t)v.D * 4);
+    need(n + ".ffn1" + wn, wbytes(v, v.hidden, v.D)); need(n + ".ffn1.b", (size_t)v.hidden * 4);
+    need(n + ".ffn2" + wn, wbytes(v, v.D, v.hidden)); need(n + ".ffn2.b", (size_t)v.D * 4);
+    need(n + ".head1" + wn, wbytes(v, v.hidden, v.D)); need(n + ".head1.b", (size_t)v.hidden * 4);
+    need(n + ".head2" + wn, wbytes(v, v.D, v.hidden)); need(n + ".head2.b", (size_t)v.D * 4);
   }
 
   // ---- convolution layers ----
@@ -534,7 +537,7 @@ int cfen_net::run_vit_g(int ng, const VitCall* vc, int scr0) {
     CfenGemmPtrs gp[3];
     for (int g = 0; g < ng; ++g)
       gp[g] = CfenGemmPtrs{tg ? nullptr : X[g], P(nm[g] + wname), bname ? Pf(nm[g] + bname) : nullptr, R ? R[g] : nullptr,
-                           pname ? P(nm[g] + pname) : nullptr, Y[g], tg ? IN[g] : nullptr, nullptr};
+                           pname ? P(nm[g] + pname) : nullptr, Y[g], tg ? IN[g] : nullptr, nullptr, v.global && wtile};
     // split-K scratch: the YN | ATT | QKV stretch of the member's scratch set (contiguous, 5 * md elements), free while the
     // FFN / mlp_head GEMMs run -- the only K-heavy ones
     float* ws[3] = {nullptr, nullptr, nullptr};
@@ -547,7 +550,8 @@ int cfen_net::run_vit_g(int ng, const VitCall* vc, int scr0) {
   auto gemm_ln = [&](const void* const* X, const std::string& lname, void* const* Y, int N, int K, int relu) -> int {
     CfenGemmPtrs gp[3];
     for (int g = 0; g < ng; ++g)
-      gp[g] = CfenGemmPtrs{X[g], P(nm[g] + lname + ".wl"), Pf(nm[g] + lname + ".bl"), nullptr, nullptr, Y[g], nullptr, Pf(nm[g] + lname + ".s")};
+      gp[g] = CfenGemmPtrs{X[g], P(nm[g] + lname + ".wl"), Pf(nm[g] + lname + ".bl"), nullptr, nullptr, Y[g], nullptr, Pf(nm[g] + lname + ".s"),
+                           v.global && wtile};
     return cfen_gemm_impl_g(dt, ng, gp, K, K, N, v.S, N, M, N, K, relu, nullptr, stream, nullptr, 0);
   };
   if (v.fused_window && cfen_tune_lvit_window()) {

@@ -63,6 +63,7 @@ template <typename T> struct GemmArgs {
   // optional LayerNorm fold (k_gemm_dma, nsplit == 1, K = the whole row): see CfenGemmPtrs::lnf_s
   const float* lnf_s;
   float lnf_eps;
+  int wtile;   // W is tile-major (CfenGemmPtrs::wtile)
 };
 
 // pointer to channel 0 of the top-left pixel of token m's patch
@@ -307,16 +308,17 @@ __global__ __launch_bounds__(256, (TN > 3 && NS == 2) ? 2 : 1) void k_gemm_dma(G
     const int row = i * 32 + wave * 8 + (lane >> 3), slot = lane & 7;
     const int piece = slot ^ (row & 7);
     const bool gx = a.gmap && row >= G_BN;   // gathered token row: gptr = patch origin, the piece offset is added per K-step
-    const T* base = row < G_BN ? a.W + (size_t)min(n0 + row, a.N - 1) * a.ldw
+    const T* base = row < G_BN ? (a.wtile ? a.W + ((size_t)tn * (a.K / BK) * G_BN + row) * BK : a.W + (size_t)min(n0 + row, a.N - 1) * a.ldw)
                                : gx ? gather_pix(a, min(m0 + row - G_BN, a.M - 1)) : a.X + (size_t)min(m0 + row - G_BN, a.M - 1) * a.ldx;
     gptr[i] = gx ? base : base + piece * EPL;
     gpc[i] = gx ? piece * EPL : -1;
   }
 #define CFEN_GEMM_DMA_ISSUE(kt_, buf_)                                                                              \
   _Pragma("unroll") for (int i_ = 0; i_ < LOADS; ++i_)                                                              \
-      dma16(gptr[i_] + ((i_ >= TN && gpc[i_] >= 0) ? gather_off(a, (kt_) * BK + gpc[i_]) : (kt_) * BK),                       \
+      dma16(gptr[i_] + (i_ < TN ? (kt_) * wstep : gpc[i_] >= 0 ? gather_off(a, (kt_) * BK + gpc[i_]) : (kt_) * BK),           \
             lds + (buf_) * STAGE + (i_ * 256 + wave * 64) * 16)
 
+  const int wstep = a.wtile ? G_BN * BK : BK;   // elements from one K-step of a weight row to the next
   floatx4 acc[TN][TM];
 #pragma unroll
   for (int i = 0; i < TN; ++i)
@@ -337,7 +339,7 @@ __global__ __launch_bounds__(256, (TN > 3 && NS == 2) ? 2 : 1) void k_gemm_dma(G
 #pragma unroll
     for (int i = 0; i < LOADS; ++i) {
       if (gpc[i] >= 0) gpc[i] += kbeg;         // gathered rows recompute their offset from the absolute k
-      else gptr[i] += kbeg;
+      else gptr[i] += i < TN ? (int)blockIdx.y * nk * wstep : kbeg;
     }
   }
 #pragma unroll
@@ -525,6 +527,8 @@ int launch_gemm(int ng, const CfenGemmPtrs* gp, int ldx, int ldw, int ldr, int p
     a.nsplit = 1;
     a.lnf_s = q.lnf_s;
     a.lnf_eps = cfen_gemm_lnf_eps();
+    a.wtile = q.wtile;
+    CFEN_CHECK_ARG(q.wtile == gp[0].wtile, "gemm: grouped problems must share the weight layout");
     if (tg) {
       a.gmap = (const T*)q.gmap; a.gH = tg->H; a.gW = tg->W; a.gcs = tg->cs; a.gC = tg->C; a.gws = tg->ws; a.gp = tg->p;
     }
@@ -564,6 +568,11 @@ int launch_gemm(int ng, const CfenGemmPtrs* gp, int ldx, int ldw, int ldr, int p
     const int pick = !k128 ? 0 : (M <= 128 && N <= 2048 && !tg && !lnf) ? 1 : tiles64 >= 1024 ? cfen_tune_gemm_large() : tiles32 <= 512 ? cfen_tune_gemm_small() : 5;
     kern = pick % 10;
     stages = 2 + pick / 10;
+  }
+  if (gp[0].wtile) {   // tile-major weights: the LDS-DMA kernel with 96-feature tiles (the skinny / register-staged kernels read rows)
+    CFEN_CHECK_ARG(k128, "gemm (tile-major weights): needs K * sizeof(T) %% 128 == 0");
+    if (kern == 1) { kern = 5; stages = 2 + cfen_tune_gemm_small() / 10; }
+    CFEN_CHECK_ARG(kern >= 2 && kern <= 5, "gemm (tile-major weights): kernel %d reads row-major weights", kern);
   }
   CFEN_CHECK_ARG(!(tg && kern == 1), "gemm (gather): k_gemm_skinny does not gather");
   if (kern < 2) stages = 2;

@@ -71,6 +71,8 @@ class dec_ipt(nn.Module):
         self._graphs = []            # capture() handle -> (net key, native graph id)
         self._last = None
         self.serial_plan = bool(os.environ.get("CFEN_SERIAL"))     # single-lane launch plan (debugging / A-B)
+        # GViT weights tile-major (packing.pack_wtile; cfen_net_config.reserved bit 1): +1 % measured (3.34 -> 3.30 ms at B = 8); CFEN_WTILE=0 = row-major
+        self.wtile = os.environ.get("CFEN_WTILE", "1") != "0"
 
     # ---- parameter management ---------------------------------------------------------------
     def state_dict(self, *args, **kw):
@@ -154,7 +156,7 @@ class dec_ipt(nn.Module):
             self.invalidate()
         if self._packed is None:
             pending = {}
-            packed = pack_state_dict(self._live_state(device), self.cfg, self.compute_dtype, pending=pending)
+            packed = pack_state_dict(self._live_state(device), self.cfg, self.compute_dtype, pending=pending, wtile=self.wtile)
             self._packed = {k: v.to(device).contiguous() for k, v in packed.items() if not isinstance(v, str)}
             for k, v in packed.items():          # "@other": the same device tensor under a second name (shared modules)
                 if isinstance(v, str):
@@ -175,7 +177,8 @@ class dec_ipt(nn.Module):
         c = self.cfg
         cc = NetConfigC(batch=batch, n_feats=c.n_feats, hidden_dim_ratio=c.hidden_dim_ratio, patch_size=c.patch_size,
                         load_size=c.load_size, num_heads=c.num_heads, dtype=_lib.dtype_code(self.compute_dtype),
-                        reserved=(1 if self.serial_plan else 0) | (_VARIANT_CODE[c.variant] << 8))   # bit 0: single-stream plan; bits 8..15: variant
+                        reserved=(1 if self.serial_plan else 0) | (2 if self.wtile else 0) | (_VARIANT_CODE[c.variant] << 8))
+        # bit 0: single-stream plan; bit 1: tile-major GViT weights; bits 8..15: variant
         h = ctypes.c_void_p()
         check(lib.cfen_net_create(ctypes.byref(h), ctypes.byref(cc)), "cfen_net_create")
         for name, t in packed.items():

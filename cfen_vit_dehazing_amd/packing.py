@@ -97,6 +97,21 @@ def pack_lvit_window(sd, g, dtype):
             n + ".lw.wp": wp.to(dtype).contiguous()}
 
 
+def pack_wtile(w):
+    """[N][K] row-major -> tile-major [ceil(N / 96)][K * esz / 128][96][128 / esz] flattened (rows past N zero): one K-step of a 96-feature
+    tile of k_gemm_dma is one contiguous 12 KB run (csrc/cfen_internal.hpp CfenGemmPtrs::wtile)"""
+    n, k = w.shape
+    bk = 128 // w.element_size()
+    assert k % bk == 0, "tile-major weights need K * sizeof(T) % 128 == 0"
+    n96 = round_up(n, 96)
+    wp = torch.zeros(n96, k, dtype=w.dtype, device=w.device)
+    wp[:n] = w
+    return wp.view(n96 // 96, 96, k // bk, bk).permute(0, 2, 1, 3).contiguous().view(-1)
+
+
+GVIT_WEIGHT_SUFFIXES = (".embed.w", ".qkv.w", ".qkv.wl", ".proj.w", ".ffn1.w", ".ffn1.wl", ".ffn2.w", ".head1.w", ".head2.w")
+
+
 def ln_folded(w_packed, gamma, beta, bias, name, dtype, w_full):
     """entries `name`.wl / .s / .bl of a Linear that follows a LayerNorm (gamma, beta): see pack_vit"""
     w64 = w_full.double()
@@ -333,7 +348,7 @@ def _actnorm_ready(sd, prefix):
     return int(sd[prefix + ".initialized"]) == 1
 
 
-def pack_state_dict(sd, cfg: NetConfig, dtype=torch.float16, pending=None):
+def pack_state_dict(sd, cfg: NetConfig, dtype=torch.float16, pending=None, wtile=False):
     """reference state_dict (tensors on any one device) -> packed tensors on the same device.
 
     An ActNorm2d whose `initialized` buffer is 0 holds no parameters yet: the reference fills it from the statistics of its first
@@ -346,7 +361,12 @@ def pack_state_dict(sd, cfg: NetConfig, dtype=torch.float16, pending=None):
     crs = cfg.variant == "crs"
     out = {}
     for g in cfg.vit_instances():
-        out.update(pack_vit(sd, g, dtype))
+        pv = pack_vit(sd, g, dtype)
+        if wtile and g.kind == "gvit":      # the GViT GEMMs stream their weights from HBM once per forward: tile-major (pack_wtile)
+            for k in list(pv):
+                if k.endswith(GVIT_WEIGHT_SUFFIXES):
+                    pv[k] = pack_wtile(pv[k].contiguous())
+        out.update(pv)
 
     full = cfg.image_size
 

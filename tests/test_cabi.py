@@ -66,9 +66,9 @@ def test_tuning_knobs_validate_without_a_gpu():
         assert lib.cfen_tune(key, val) == 0, key       # (the shipped defaults: the knobs are process-wide)
 
 
-@pytest.mark.parametrize("variant", ["v3", "cfs", "crs", "v5"])
+@pytest.mark.parametrize("variant,wtile", [("v3", False), ("v3", True), ("cfs", False), ("crs", False), ("v5", False), ("v5", True)])
 @pytest.mark.parametrize("dtype", ["fp16", "fp32"])
-def test_packed_parameters_are_exactly_what_the_launch_plan_asks_for(variant, dtype):
+def test_packed_parameters_are_exactly_what_the_launch_plan_asks_for(variant, wtile, dtype):
     """packing.pack_state_dict (host) and cfen_net::build (csrc/cfen_net.cpp) must agree on every packed name and byte size, for each of
     the four generators; set_param only records the pointer, so this runs without a GPU"""
     import torch
@@ -80,9 +80,9 @@ def test_packed_parameters_are_exactly_what_the_launch_plan_asks_for(variant, dt
     lib = _lib.load()
     cfg = NetConfig(24, 4, patch_size=8, load_size=64, variant=variant)
     td = torch.float16 if dtype == "fp16" else torch.float32
-    packed = pack_state_dict(generate_state_dict(cfg, seed=0, with_dead=False), cfg, td)
+    packed = pack_state_dict(generate_state_dict(cfg, seed=0, with_dead=False), cfg, td, wtile=wtile)
     cc = _lib.NetConfigC(batch=2, n_feats=24, hidden_dim_ratio=4, patch_size=8, load_size=64, num_heads=4, dtype=_lib.dtype_code(td),
-                         reserved=_VARIANT_CODE[variant] << 8)
+                         reserved=(_VARIANT_CODE[variant] << 8) | (2 if wtile else 0))
     h = ctypes.c_void_p()
     assert lib.cfen_net_create(ctypes.byref(h), ctypes.byref(cc)) == 0, lib.cfen_last_error()
     keep = {}
