@@ -19,6 +19,8 @@ def _load():
         _lib = ctypes.CDLL(so)
         _lib.dcn_oracle_forward.restype = ctypes.c_int
         _lib.dcn_oracle_forward.argtypes = [ctypes.c_void_p] * 6 + [ctypes.c_int] * 15
+        _lib.dcn_oracle_backward.restype = ctypes.c_int
+        _lib.dcn_oracle_backward.argtypes = [ctypes.c_void_p] * 10 + [ctypes.c_float] + [ctypes.c_int] * 15
     return _lib
 
 
@@ -43,3 +45,23 @@ def deform_conv(x, offset, weight, stride=1, padding=0, dilation=1, groups=1, de
     if rc != 0:
         raise ValueError("dcn_oracle: invalid shape")
     return out
+
+
+def deform_conv_backward(x, offset, weight, grad_out, stride=1, padding=0, dilation=1, groups=1, deformable_groups=1, mask=None,
+                         with_bias=False, scale=1.0):
+    """CPU float32 tensors -> dict(input, offset, mask, weight, bias) of gradients (mask / bias entries None when absent): the
+    reference's deform_conv_backward_input_cuda + deform_conv_backward_parameters_cuda (DCNv1) or modulated_deform_conv_cuda_backward."""
+    x, offset, weight, grad_out = (t.float().contiguous() for t in (x, offset, weight, grad_out))
+    mask = mask.float().contiguous() if mask is not None else None
+    (sh, sw), (ph, pw), (dh, dw) = _pair(stride), _pair(padding), _pair(dilation)
+    B, C, H, W = x.shape
+    Cout, _, kh, kw = weight.shape
+    g = {"input": torch.zeros_like(x), "offset": torch.zeros_like(offset), "mask": torch.zeros_like(mask) if mask is not None else None,
+         "weight": torch.zeros_like(weight), "bias": torch.zeros(Cout) if with_bias else None}
+    p = lambda t: ctypes.c_void_p(t.data_ptr()) if t is not None else None
+    rc = _load().dcn_oracle_backward(p(x), p(offset), p(mask), p(weight), p(grad_out), p(g["input"]), p(g["offset"]), p(g["mask"]),
+                                     p(g["weight"]), p(g["bias"]), scale, B, C, H, W, Cout, kh, kw, sh, sw, ph, pw, dh, dw, groups,
+                                     deformable_groups)
+    if rc != 0:
+        raise ValueError("dcn_oracle: invalid shape")
+    return g

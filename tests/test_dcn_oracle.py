@@ -75,3 +75,68 @@ def test_deformable_groups_use_their_own_offsets():
 def test_invalid_shapes_rejected():
     with pytest.raises(ValueError):
         dcn_oracle.deform_conv(torch.zeros(1, 3, 2, 2), torch.zeros(1, 18, 1, 1), torch.zeros(2, 3, 3, 3), 1, 0, 1, 1, 1)
+
+
+# ---- backward (oracle/dcn_oracle.c: dcn_oracle_backward) -------------------------------------------------------------------------------
+
+@pytest.mark.parametrize("k,stride,pad,dil,groups", [(3, 1, 1, 1, 1), (3, 2, 1, 1, 1), (3, 1, 2, 2, 2), (1, 1, 0, 1, 1)])
+def test_backward_at_zero_offsets_equals_conv2d_autograd(k, stride, pad, dil, groups):
+    x, w, b = rnd((2, 8, 9, 10), 1).requires_grad_(), rnd((6, 8 // groups, k, k), 2, 0.2).requires_grad_(), rnd((6,), 3).requires_grad_()
+    y = F.conv2d(x, w, b, stride, pad, dil, groups)
+    gy = rnd(tuple(y.shape), 4)
+    y.backward(gy)
+    off = torch.zeros(2, 2 * k * k, y.shape[2], y.shape[3])
+    mask = torch.ones(2, k * k, y.shape[2], y.shape[3])
+    for m in (None, mask):
+        g = dcn_oracle.deform_conv_backward(x.detach(), off, w.detach(), gy, stride, pad, dil, groups, 1, mask=m, with_bias=True)
+        assert torch.allclose(g["input"], x.grad, atol=2e-5)
+        assert torch.allclose(g["weight"], w.grad, atol=2e-4)
+        assert torch.allclose(g["bias"], b.grad, atol=2e-4)
+
+
+@pytest.mark.parametrize("dg,groups,with_mask", [(1, 1, False), (2, 1, True), (4, 2, True)])
+def test_backward_matches_finite_differences_of_the_forward_oracle(dg, groups, with_mask):
+    """d loss / d offset, d loss / d mask, d loss / d input, d loss / d weight of loss = <forward, grad_out>, against central differences of
+    dcn_oracle.deform_conv (itself pinned above).  Offsets are kept away from integer sample positions, where the bilinear sample has a kink."""
+    B, C, H, W, Cout, k = 1, 8, 7, 6, 4, 3
+    x, w = rnd((B, C, H, W), 11), rnd((Cout, C // groups, k, k), 12, 0.3)
+    g = torch.Generator().manual_seed(13)
+    off = (torch.rand(B, dg * 2 * k * k, H, W, generator=g) * 0.6 + 0.2) * (torch.randint(0, 2, (B, dg * 2 * k * k, H, W), generator=g) * 2 - 1) * 1.3
+    frac = off - off.floor()
+    off = torch.where((frac < 0.1) | (frac > 0.9), off.floor() + 0.5, off)
+    mask = torch.rand(B, dg * k * k, H, W, generator=g) if with_mask else None
+    gy = rnd((B, Cout, H, W), 14)
+    fwd = lambda x_, off_, w_, m_: float((dcn_oracle.deform_conv(x_, off_, w_, 1, 1, 1, groups, dg, mask=m_).double() * gy.double()).sum())
+    got = dcn_oracle.deform_conv_backward(x, off, w, gy, 1, 1, 1, groups, dg, mask=mask)
+    eps = 1e-2
+    picks = torch.randperm(off.numel(), generator=g)[:40]
+    for idx in picks.tolist():
+        d = torch.zeros(off.numel()); d[idx] = eps
+        d = d.view_as(off)
+        num = (fwd(x, off + d, w, mask) - fwd(x, off - d, w, mask)) / (2 * eps)
+        assert abs(num - float(got["offset"].flatten()[idx])) <= 2e-3 * max(1.0, abs(num)), (idx, num, float(got["offset"].flatten()[idx]))
+    for name, t in (("input", x), ("weight", w)) + ((("mask", mask),) if with_mask else ()):
+        for idx in torch.randperm(t.numel(), generator=g)[:25].tolist():
+            d = torch.zeros(t.numel()); d[idx] = eps
+            d = d.view_as(t)
+            def at(sign):
+                if name == "input":
+                    return fwd(x + sign * d, off, w, mask)
+                if name == "weight":
+                    return fwd(x, off, w + sign * d, mask)
+                return fwd(x, off, w, mask + sign * d)
+            num = (at(1) - at(-1)) / (2 * eps)                      # the forward is linear in each of these: exact up to fp32 rounding
+            assert abs(num - float(got[name].flatten()[idx])) <= 2e-3 * max(1.0, abs(num)), (name, idx)
+
+
+def test_backward_is_linear_in_grad_output_and_accumulates_weight_grads():
+    x, w = rnd((2, 4, 6, 6), 21), rnd((4, 4, 3, 3), 22, 0.3)
+    off, mask = rnd((2, 18, 6, 6), 23, 0.7), torch.rand(2, 9, 6, 6, generator=torch.Generator().manual_seed(24))
+    g1, g2 = rnd((2, 4, 6, 6), 25), rnd((2, 4, 6, 6), 26)
+    a = dcn_oracle.deform_conv_backward(x, off, w, g1, 1, 1, 1, 1, 1, mask=mask, with_bias=True)
+    b = dcn_oracle.deform_conv_backward(x, off, w, g2, 1, 1, 1, 1, 1, mask=mask, with_bias=True)
+    c = dcn_oracle.deform_conv_backward(x, off, w, g1 * 2 - g2, 1, 1, 1, 1, 1, mask=mask, with_bias=True)
+    for k in a:
+        assert torch.allclose(c[k], 2 * a[k] - b[k], atol=1e-4), k
+    half = dcn_oracle.deform_conv_backward(x, off, w, g1, 1, 1, 1, 1, 1, mask=mask, scale=0.5)
+    assert torch.allclose(half["weight"], 0.5 * a["weight"], atol=1e-5)       # deform_conv_backward_parameters_cuda's `scale`
