@@ -1,0 +1,389 @@
+// Deformable convolution backward (DCNv1 and modulated DCNv2): gradients w.r.t. input, offset, mask, weight, bias.
+//
+// Replaces, for the backward direction, the reference's CUDA extension:
+//   deformable_col2im_gpu_kernel / _coord_gpu_kernel                 dcn/src/deform_conv_cuda_kernel.cu:278-421
+//   modulated_deformable_col2im_gpu_kernel / _coord_gpu_kernel       dcn/src/deform_conv_cuda_kernel.cu:634-766
+//   get_gradient_weight / get_coordinate_weight                      dcn/src/deform_conv_cuda_kernel.cu:116-187
+//   deform_conv_backward_input_cuda / _parameters_cuda               dcn/src/deform_conv_cuda.cpp:260-484
+//   modulated_deform_conv_cuda_backward                              dcn/src/deform_conv_cuda.cpp:566-679
+//
+// Arithmetic is fp32 whatever the tensor type (gradients are sums over up to B*Hout*Wout terms), tensors are NCHW like the reference
+// API, scratch is the caller's `columns` buffer.  Five passes:
+//   1. k_dcnb_prep      layout copies: input -> NHWC fp32, grad_out -> pixel-major rows (GEMM operand) and channel-major rows over
+//                       all B*Hout*Wout pixels (MFMA operand of pass 5), weight -> per-group [tap*Cg + c][co] (transposed, tap-major)
+//   2. token GEMM       column gradients  gcol[pixel][g][tap*Cg + c] = sum_co grad_out[pixel][g][co] * W[g][co][c][tap]
+//                       (cfen_gemm_impl, exact-fp32 MFMA: the reference's per-image addmm_ of W^T and grad_out, .cpp:332-337)
+//   3. k_dcnb_scatter   one thread per (pixel, tap, deformable group): offsets / mask read once, the four bilinear corners set up once,
+//                       then for every channel of the group: atomic add of corner weight * gcol (* mask) into an NHWC fp32 image
+//                       (col2im), and the running sums for d/d offset_h, d/d offset_w, d/d mask (col2im_coord)
+//   4. k_dcnb_im2col    the forward's column matrix (masked bilinear samples), channel-major rows over all pixels
+//   5. k_dcnb_weight    grad_W[g][co][k] += scale * sum_pixels grad_out[co][pixel] * column[k][pixel]: exact-fp32 MFMA over 16-pixel
+//                       chunks, a wave owns 16 k x all co, partial sums of a workgroup's pixel range land with fp32 atomics
+// then small epilogue kernels write the NCHW / (Cout, Cg, kh, kw) results in the tensor type.  grad_input / grad_offset / grad_mask
+// are overwritten, grad_weight / grad_bias are accumulated into (the reference's addmm_ with beta = 1; its Python side passes zeros).
+// Like the reference (atomicAdd, .cu:322) the scatter makes grad_input run-to-run reproducible only up to fp32 summation order.
+#include <algorithm>
+#include "cfen_common.hpp"
+#include "cfen_internal.hpp"
+
+namespace {
+
+struct DcnBwd {
+  const void* im; const void* offset; const void* mask; const void* weight; const void* gout;
+  void* gin; void* goff; void* gmask; void* gweight; void* gbias;
+  int B, C, H, W, Cout, kh, kw, sh, sw, ph, pw, dh, dw, group, dg, Ho, Wo;
+  float scale;
+  // derived
+  int Cg, Cog, Cogp, kk, Kg, Kgp, cpdg;
+  long long P, Pp;          // B*Ho*Wo pixels; row pitch of the channel-major copies (multiple of 16)
+  // scratch (fp32)
+  float* xn;                // [B][H][W][C]
+  float* gn;                // [P][group][Cogp]
+  float* gc;                // [Cout][Pp]
+  float* wt;                // [group][Kgp][Cogp]
+  float* col;               // pass 2/3: [P][group][Kgp];  pass 4/5: [group][Kg][Pp]
+  float* gi;                // [B][H][W][C]
+  float* gw;                // [group][Cog][Kg]   (k = tap*Cg + c)
+};
+
+inline size_t up256(size_t v) { return (v + 255) / 256 * 256; }
+
+struct DcnBwdLayout { size_t xn, gn, gc, wt, col, gi, gw, total; };
+DcnBwdLayout dcnb_layout(int B, int C, int H, int W, int Cout, int kk, int Ho, int Wo, int group) {
+  const size_t Cg = C / group, Cog = Cout / group, Cogp = (Cog + 3) / 4 * 4, Kg = Cg * kk, Kgp = (Kg + 3) / 4 * 4;
+  const size_t P = (size_t)B * Ho * Wo, Pp = (P + 15) / 16 * 16;
+  DcnBwdLayout l;
+  size_t o = 0;
+  l.xn = o; o += up256((size_t)B * H * W * C * 4);
+  l.gn = o; o += up256(P * group * Cogp * 4);
+  l.gc = o; o += up256((size_t)Cout * Pp * 4);
+  l.wt = o; o += up256((size_t)group * Kgp * Cogp * 4);
+  l.col = o; o += up256(std::max(P * group * Kgp, (size_t)group * Kg * Pp) * 4);
+  l.gi = o; o += up256((size_t)B * H * W * C * 4);
+  l.gw = o; o += up256((size_t)group * Cog * Kg * 4);
+  l.total = o;
+  return l;
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void k_dcnb_prep(DcnBwd a, long long n1, long long n2, long long n3, long long n4) {
+  const long long HW = (long long)a.H * a.W, HWo = (long long)a.Ho * a.Wo;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n1 + n2 + n3 + n4; i += (long long)gridDim.x * 256) {
+    if (i < n1) {                                            // xn[b][p][c] = im[b][c][p]
+      const int c = (int)(i % a.C);
+      const long long bp = i / a.C, b = bp / HW, p = bp % HW;
+      a.xn[i] = (float)((const T*)a.im)[(b * a.C + c) * HW + p];
+    } else if (i < n1 + n2) {                                // gn[pix][g][ol] (zero in the padding lanes ol >= Cog)
+      const long long j = i - n1;
+      const int ol = (int)(j % a.Cogp), g = (int)((j / a.Cogp) % a.group);
+      const long long pix = j / ((long long)a.Cogp * a.group), b = pix / HWo, p = pix % HWo;
+      a.gn[j] = ol < a.Cog ? (float)((const T*)a.gout)[(b * a.Cout + g * a.Cog + ol) * HWo + p] : 0.f;
+    } else if (i < n1 + n2 + n3) {                           // gc[co][pix] (zero in the padding columns pix >= P)
+      const long long j = i - n1 - n2, pix = j % a.Pp;
+      const int co = (int)(j / a.Pp);
+      const long long b = pix / HWo, p = pix % HWo;
+      a.gc[j] = pix < a.P ? (float)((const T*)a.gout)[(b * a.Cout + co) * HWo + p] : 0.f;
+    } else {                                                 // wt[g][k = t*Cg + c][ol] = weight[g*Cog + ol][c][t]
+      const long long j = i - n1 - n2 - n3;
+      const int ol = (int)(j % a.Cogp), k = (int)((j / a.Cogp) % a.Kgp), g = (int)(j / ((long long)a.Cogp * a.Kgp));
+      float v = 0.f;
+      if (ol < a.Cog && k < a.Kg) {
+        const int t = k / a.Cg, c = k % a.Cg;
+        v = (float)((const T*)a.weight)[((long long)(g * a.Cog + ol) * a.Cg + c) * a.kk + t];
+      }
+      a.wt[j] = v;
+    }
+  }
+}
+
+// sample geometry of (pixel, tap): position, validity, corners (the reference's .cu:83-114 / 116-187 rules)
+struct DcnTap {
+  float h, w, lh, lw, m;
+  int hl, wl;
+  bool inside, ok0, ok1, ok2, ok3;
+};
+template <typename T>
+CFEN_DEV DcnTap dcnb_tap(const DcnBwd& a, long long b, long long p, int t, int dgi) {
+  const long long HWo = (long long)a.Ho * a.Wo;
+  const int ho = (int)(p / a.Wo), wo = (int)(p % a.Wo), i = t / a.kw, j = t % a.kw;
+  const T* off = (const T*)a.offset + (b * a.dg + dgi) * 2 * a.kk * HWo;
+  DcnTap s;
+  s.h = (float)(ho * a.sh - a.ph + i * a.dh) + (float)off[(long long)(2 * t) * HWo + p];
+  s.w = (float)(wo * a.sw - a.pw + j * a.dw) + (float)off[(long long)(2 * t + 1) * HWo + p];
+  s.m = a.mask ? (float)((const T*)a.mask)[((b * a.dg + dgi) * a.kk + t) * HWo + p] : 1.f;
+  s.inside = s.h > -1.f && s.w > -1.f && s.h < (float)a.H && s.w < (float)a.W;
+  s.hl = (int)floorf(s.h); s.wl = (int)floorf(s.w);
+  s.lh = s.h - (float)s.hl; s.lw = s.w - (float)s.wl;
+  const bool hlo = s.hl >= 0 && s.hl < a.H, hhi = s.hl + 1 >= 0 && s.hl + 1 < a.H;
+  const bool wlo = s.wl >= 0 && s.wl < a.W, whi = s.wl + 1 >= 0 && s.wl + 1 < a.W;
+  s.ok0 = hlo && wlo; s.ok1 = hlo && whi; s.ok2 = hhi && wlo; s.ok3 = hhi && whi;
+  return s;
+}
+
+// pass 3: col2im (grad_input, atomics into NHWC fp32) + col2im_coord (grad_offset, grad_mask)
+template <typename T>
+__global__ __launch_bounds__(256) void k_dcnb_scatter(DcnBwd a) {
+  const long long HWo = (long long)a.Ho * a.Wo, n = a.P * a.kk * a.dg;
+  for (long long idx = (long long)blockIdx.x * 256 + threadIdx.x; idx < n; idx += (long long)gridDim.x * 256) {
+    const long long pix = idx % a.P;
+    const int t = (int)((idx / a.P) % a.kk), dgi = (int)(idx / (a.P * a.kk));
+    const long long b = pix / HWo, p = pix % HWo;
+    const DcnTap s = dcnb_tap<T>(a, b, p, t, dgi);
+    float dH = 0.f, dW = 0.f, mv = 0.f;
+    if (s.inside) {
+      const float w0 = (1.f - s.lh) * (1.f - s.lw), w1 = (1.f - s.lh) * s.lw, w2 = s.lh * (1.f - s.lw), w3 = s.lh * s.lw;
+      const long long base = ((b * a.H + s.hl) * a.W + s.wl) * a.C;     // corner (hl, wl); others + C, + W*C, + (W+1)*C
+      const long long rowC = (long long)a.W * a.C;
+      const float* gcol = a.col + pix * ((long long)a.group * a.Kgp);
+      for (int c = dgi * a.cpdg; c < (dgi + 1) * a.cpdg; ++c) {
+        const int g = c / a.Cg, cl = c - g * a.Cg;
+        const float gv = gcol[g * a.Kgp + t * a.Cg + cl];
+        const float v0 = s.ok0 ? a.xn[base + c] : 0.f, v1 = s.ok1 ? a.xn[base + a.C + c] : 0.f;
+        const float v2 = s.ok2 ? a.xn[base + rowC + c] : 0.f, v3 = s.ok3 ? a.xn[base + rowC + a.C + c] : 0.f;
+        dH += gv * (-(1.f - s.lw) * v0 - s.lw * v1 + (1.f - s.lw) * v2 + s.lw * v3);
+        dW += gv * (-(1.f - s.lh) * v0 + (1.f - s.lh) * v1 - s.lh * v2 + s.lh * v3);
+        mv += gv * (w0 * v0 + w1 * v1 + w2 * v2 + w3 * v3);
+        if (a.gin) {
+          const float tg = gv * s.m;
+          if (s.ok0) unsafeAtomicAdd(a.gi + base + c, w0 * tg);
+          if (s.ok1) unsafeAtomicAdd(a.gi + base + a.C + c, w1 * tg);
+          if (s.ok2) unsafeAtomicAdd(a.gi + base + rowC + c, w2 * tg);
+          if (s.ok3) unsafeAtomicAdd(a.gi + base + rowC + a.C + c, w3 * tg);
+        }
+      }
+    }
+    if (a.goff) {
+      T* go = (T*)a.goff + (b * a.dg + dgi) * 2 * a.kk * HWo;
+      go[(long long)(2 * t) * HWo + p] = (T)(dH * s.m);
+      go[(long long)(2 * t + 1) * HWo + p] = (T)(dW * s.m);
+    }
+    if (a.gmask) ((T*)a.gmask)[((b * a.dg + dgi) * a.kk + t) * HWo + p] = (T)mv;
+  }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void k_dcnb_gin_out(DcnBwd a) {     // NHWC fp32 -> NCHW T
+  const long long HW = (long long)a.H * a.W, n = (long long)a.B * a.C * HW;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
+    const long long p = i % HW, bc = i / HW, b = bc / a.C;
+    const int c = (int)(bc % a.C);
+    ((T*)a.gin)[i] = (T)a.gi[(b * HW + p) * a.C + c];
+  }
+}
+
+// pass 4: column matrix of the forward, channel-major: col[g][k = t*Cg + cl][pix]  (pix < Pp; zero in the padding columns)
+template <typename T>
+__global__ __launch_bounds__(256) void k_dcnb_im2col(DcnBwd a) {
+  const long long HWo = (long long)a.Ho * a.Wo, n = a.Pp * a.kk * a.dg;
+  for (long long idx = (long long)blockIdx.x * 256 + threadIdx.x; idx < n; idx += (long long)gridDim.x * 256) {
+    const long long pix = idx % a.Pp;
+    const int t = (int)((idx / a.Pp) % a.kk), dgi = (int)(idx / (a.Pp * a.kk));
+    const bool live = pix < a.P;
+    const long long b = live ? pix / HWo : 0, p = live ? pix % HWo : 0;
+    const DcnTap s = dcnb_tap<T>(a, b, p, t, dgi);
+    const bool use = live && s.inside;
+    const float w0 = (1.f - s.lh) * (1.f - s.lw), w1 = (1.f - s.lh) * s.lw, w2 = s.lh * (1.f - s.lw), w3 = s.lh * s.lw;
+    const long long base = ((b * a.H + s.hl) * a.W + s.wl) * a.C, rowC = (long long)a.W * a.C;
+    for (int c = dgi * a.cpdg; c < (dgi + 1) * a.cpdg; ++c) {
+      const int g = c / a.Cg, cl = c - g * a.Cg;
+      float v = 0.f;
+      if (use) {
+        const float v0 = s.ok0 ? a.xn[base + c] : 0.f, v1 = s.ok1 ? a.xn[base + a.C + c] : 0.f;
+        const float v2 = s.ok2 ? a.xn[base + rowC + c] : 0.f, v3 = s.ok3 ? a.xn[base + rowC + a.C + c] : 0.f;
+        v = (w0 * v0 + w1 * v1 + w2 * v2 + w3 * v3) * s.m;
+      }
+      a.col[((long long)g * a.Kg + t * a.Cg + cl) * a.Pp + pix] = v;
+    }
+  }
+}
+
+// pass 5: gw[g][co][k] += scale * sum_pix gc[g*Cog + co][pix] * col[g][k][pix].  grid (pixel ranges, groups of 4 k tiles, conv groups);
+// wave w of a workgroup owns k tile 4*blockIdx.y + w and every co tile (<= 8 tiles: Cout / group <= 128).
+constexpr int DB_MAXOT = 8;
+__global__ __launch_bounds__(256) void k_dcnb_weight(DcnBwd a, int chunks_per_block) {
+  typedef Mma<float>::frag frag;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, r16 = lane & 15, h = lane >> 4;
+  const int g = blockIdx.z, kt = blockIdx.y * 4 + wave;
+  if (kt * 16 >= a.Kg) return;
+  const int not_ = (a.Cog + 15) / 16;
+  const long long nchunks = a.Pp / 16;
+  const long long c0 = (long long)blockIdx.x * chunks_per_block, c1 = min(nchunks, c0 + chunks_per_block);
+  floatx4 acc[DB_MAXOT];
+#pragma unroll
+  for (int i = 0; i < DB_MAXOT; ++i) acc[i] = floatx4{0.f, 0.f, 0.f, 0.f};
+  const float* brow = a.col + ((long long)g * a.Kg + min(kt * 16 + r16, a.Kg - 1)) * a.Pp + 4 * h;
+  const float* arow[DB_MAXOT];
+#pragma unroll
+  for (int i = 0; i < DB_MAXOT; ++i) arow[i] = a.gc + ((long long)g * a.Cog + min(i * 16 + r16, a.Cog - 1)) * a.Pp + 4 * h;
+  for (long long ch = c0; ch < c1; ++ch) {
+    const frag bf = *reinterpret_cast<const frag*>(brow + ch * 16);
+#pragma unroll
+    for (int i = 0; i < DB_MAXOT; ++i)
+      if (i < not_) acc[i] = Mma<float>::mma(*reinterpret_cast<const frag*>(arow[i] + ch * 16), bf, acc[i]);
+  }
+  // lane owns A rows (co) 4h .. 4h+3 of tile i for B row (k) r16
+  const int k = kt * 16 + r16;
+  if (k < a.Kg) {
+#pragma unroll
+    for (int i = 0; i < DB_MAXOT; ++i)
+      if (i < not_) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int co = i * 16 + 4 * h + r;
+          if (co < a.Cog) unsafeAtomicAdd(a.gw + ((long long)g * a.Cog + co) * a.Kg + k, a.scale * acc[i][r]);
+        }
+      }
+  }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void k_dcnb_weight_out(DcnBwd a) {   // grad_weight[co][c][t] += gw[g][col][t*Cg + c]
+  const long long n = (long long)a.Cout * a.Cg * a.kk;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
+    const int t = (int)(i % a.kk), c = (int)((i / a.kk) % a.Cg), co = (int)(i / ((long long)a.kk * a.Cg));
+    const int g = co / a.Cog, col = co % a.Cog;
+    T* dst = (T*)a.gweight + i;
+    *dst = (T)((float)*dst + a.gw[((long long)g * a.Cog + col) * a.Kg + t * a.Cg + c]);
+  }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void k_dcnb_bias(DcnBwd a) {        // grad_bias[co] += sum over all pixels of grad_out[co]
+  __shared__ float red[256];
+  const int co = blockIdx.x;
+  float s = 0.f;
+  for (long long p = threadIdx.x; p < a.P; p += 256) s += a.gc[(long long)co * a.Pp + p];
+  red[threadIdx.x] = s;
+  __syncthreads();
+  for (int st = 128; st > 0; st >>= 1) {
+    if ((int)threadIdx.x < st) red[threadIdx.x] += red[threadIdx.x + st];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) ((T*)a.gbias)[co] = (T)((float)((T*)a.gbias)[co] + red[0]);
+}
+
+unsigned grid_for(long long n) { return (unsigned)std::min<long long>((n + 255) / 256, 16384); }
+
+template <typename T>
+int run_dcn_backward(DcnBwd a, hipStream_t s) {
+  const bool want_in = a.gin || a.goff || a.gmask, want_par = a.gweight || a.gbias;
+  const long long HW = (long long)a.H * a.W;
+  const long long n1 = (long long)a.B * HW * a.C, n2 = a.P * a.group * a.Cogp, n3 = (long long)a.Cout * a.Pp, n4 = (long long)a.group * a.Kgp * a.Cogp;
+  CFEN_LAUNCH(k_dcnb_prep<T>, dim3(grid_for(n1 + n2 + n3 + n4)), dim3(256), 0, s, a, n1, n2, n3, n4);
+  CFEN_CHECK_LAUNCH("deform_conv backward (layout pre-pass)");
+  if (want_in) {
+    if (a.gin && hipMemsetAsync(a.gi, 0, (size_t)n1 * 4, s) != hipSuccess) { cfen_set_error("deform_conv backward: memset failed"); return CFEN_ERR_HIP; }
+    for (int g = 0; g < a.group; ++g) {   // gcol[pix][g][:] = gn[pix][g][:] . wt[g]^T
+      int rc = cfen_gemm_impl(0, a.gn + (size_t)g * a.Cogp, a.group * a.Cogp, a.wt + (size_t)g * a.Kgp * a.Cogp, a.Cogp, nullptr, nullptr, 0, nullptr, 0,
+                              a.col + (size_t)g * a.Kgp, a.group * a.Kgp, (int)a.P, a.Kgp, a.Cogp, 0, s);
+      if (rc) return rc;
+    }
+    CFEN_LAUNCH(k_dcnb_scatter<T>, dim3(grid_for(a.P * a.kk * a.dg)), dim3(256), 0, s, a);
+    CFEN_CHECK_LAUNCH("deform_conv backward (col2im)");
+    if (a.gin) {
+      CFEN_LAUNCH(k_dcnb_gin_out<T>, dim3(grid_for(n1)), dim3(256), 0, s, a);
+      CFEN_CHECK_LAUNCH("deform_conv backward (grad_input)");
+    }
+  }
+  if (a.gweight) {
+    if (hipMemsetAsync(a.gw, 0, (size_t)a.group * a.Cog * a.Kg * 4, s) != hipSuccess) { cfen_set_error("deform_conv backward: memset failed"); return CFEN_ERR_HIP; }
+    CFEN_LAUNCH(k_dcnb_im2col<T>, dim3(grid_for(a.Pp * a.kk * a.dg)), dim3(256), 0, s, a);
+    CFEN_CHECK_LAUNCH("deform_conv backward (im2col)");
+    const long long nchunks = a.Pp / 16;
+    const int kgroups = (a.Kg + 63) / 64;
+    long long ranges = std::max<long long>(1, std::min<long long>(nchunks, 2048 / std::max(1, kgroups * a.group)));
+    const int cpb = (int)((nchunks + ranges - 1) / ranges);
+    ranges = (nchunks + cpb - 1) / cpb;
+    CFEN_LAUNCH(k_dcnb_weight, dim3((unsigned)ranges, (unsigned)kgroups, (unsigned)a.group), dim3(256), 0, s, a, cpb);
+    CFEN_CHECK_LAUNCH("deform_conv backward (grad_weight)");
+    CFEN_LAUNCH(k_dcnb_weight_out<T>, dim3(grid_for((long long)a.Cout * a.Cg * a.kk)), dim3(256), 0, s, a);
+    CFEN_CHECK_LAUNCH("deform_conv backward (grad_weight out)");
+  }
+  if (a.gbias) {
+    CFEN_LAUNCH(k_dcnb_bias<T>, dim3((unsigned)a.Cout), dim3(256), 0, s, a);
+    CFEN_CHECK_LAUNCH("deform_conv backward (grad_bias)");
+  }
+  (void)want_par;
+  return CFEN_OK;
+}
+
+int dcn_backward(int dtype, DcnBwd a, void* columns, size_t columns_bytes, hipStream_t s) {
+  CFEN_CHECK_ARG(dtype == 0 || dtype == 1, "deform_conv backward: dtype %d unsupported (fp32, fp16)", dtype);
+  CFEN_CHECK_ARG(a.im && a.offset && a.weight && a.gout, "deform_conv backward: null tensor");
+  CFEN_CHECK_ARG(a.kw > 0 && a.kh > 0, "kernel size should be greater than zero, but got kH: %d kW: %d", a.kh, a.kw);
+  CFEN_CHECK_ARG(a.sw > 0 && a.sh > 0, "stride should be greater than zero, but got dH: %d dW: %d", a.sh, a.sw);
+  CFEN_CHECK_ARG(a.dw > 0 && a.dh > 0, "dilation should be greater than 0, but got dilationH: %d dilationW: %d", a.dh, a.dw);
+  CFEN_CHECK_ARG(a.B > 0 && a.C > 0 && a.Cout > 0 && a.group > 0 && a.dg > 0, "deform_conv backward: empty problem");
+  CFEN_CHECK_ARG(a.C % a.group == 0 && a.Cout % a.group == 0, "deform_conv backward: channels must be divisible by groups");
+  CFEN_CHECK_ARG(a.C % a.dg == 0, "input channels must divide deformable group size");
+  a.Ho = (a.H + 2 * a.ph - (a.dh * (a.kh - 1) + 1)) / a.sh + 1;
+  a.Wo = (a.W + 2 * a.pw - (a.dw * (a.kw - 1) + 1)) / a.sw + 1;
+  CFEN_CHECK_ARG(a.Ho >= 1 && a.Wo >= 1, "deform_conv backward: output size is too small");
+  a.Cg = a.C / a.group; a.Cog = a.Cout / a.group; a.Cogp = (a.Cog + 3) / 4 * 4; a.kk = a.kh * a.kw;
+  a.Kg = a.Cg * a.kk; a.Kgp = (a.Kg + 3) / 4 * 4; a.cpdg = a.C / a.dg;
+  a.P = (long long)a.B * a.Ho * a.Wo; a.Pp = (a.P + 15) / 16 * 16;
+  CFEN_CHECK_ARG(a.Cog <= 16 * DB_MAXOT, "deform_conv backward: more than %d output channels per group", 16 * DB_MAXOT);
+  CFEN_CHECK_ARG(a.P < (1ll << 31) && (long long)a.group * a.Kgp < (1ll << 31), "deform_conv backward: problem too large");
+  const DcnBwdLayout l = dcnb_layout(a.B, a.C, a.H, a.W, a.Cout, a.kk, a.Ho, a.Wo, a.group);
+  CFEN_CHECK_ARG(columns && cfen_aligned16(columns) && columns_bytes >= l.total,
+                 "deform_conv backward: `columns` scratch of at least %zu bytes (cfen_deform_conv_backward_bytes), 16-byte aligned, is required", l.total);
+  unsigned char* base = (unsigned char*)columns;
+  a.xn = (float*)(base + l.xn); a.gn = (float*)(base + l.gn); a.gc = (float*)(base + l.gc); a.wt = (float*)(base + l.wt);
+  a.col = (float*)(base + l.col); a.gi = (float*)(base + l.gi); a.gw = (float*)(base + l.gw);
+  return dtype == 1 ? run_dcn_backward<half_t>(a, s) : run_dcn_backward<float>(a, s);
+}
+
+}  // namespace
+
+extern "C" {
+
+size_t cfen_deform_conv_backward_bytes(int B, int Cin, int H, int W, int Cout, int kH, int kW, int Hout, int Wout, int group) {
+  if (B <= 0 || Cin <= 0 || H <= 0 || W <= 0 || Cout <= 0 || kH <= 0 || kW <= 0 || Hout <= 0 || Wout <= 0 || group <= 0 || Cin % group || Cout % group) return 0;
+  return dcnb_layout(B, Cin, H, W, Cout, kH * kW, Hout, Wout, group).total;
+}
+
+int cfen_deform_conv_backward_input(int dtype, const void* input, const void* offset, const void* gradOutput, void* gradInput, void* gradOffset,
+                                    const void* weight, int B, int Cin, int H, int W, int Cout, int kW, int kH, int dW, int dH, int padW,
+                                    int padH, int dilationW, int dilationH, int group, int deformable_group, int im2col_step, void* columns,
+                                    size_t columns_bytes, void* stream) {
+  CFEN_CHECK_ARG(im2col_step > 0 && B % (im2col_step < B ? im2col_step : B) == 0, "im2col step must divide batchsize");
+  CFEN_CHECK_ARG(gradInput && gradOffset, "deform_conv_backward_input: gradInput and gradOffset are required");
+  DcnBwd a{};
+  a.im = input; a.offset = offset; a.weight = weight; a.gout = gradOutput; a.gin = gradInput; a.goff = gradOffset;
+  a.B = B; a.C = Cin; a.H = H; a.W = W; a.Cout = Cout; a.kh = kH; a.kw = kW; a.sh = dH; a.sw = dW; a.ph = padH; a.pw = padW;
+  a.dh = dilationH; a.dw = dilationW; a.group = group; a.dg = deformable_group; a.scale = 1.f;
+  return dcn_backward(dtype, a, columns, columns_bytes, (hipStream_t)stream);
+}
+
+int cfen_deform_conv_backward_parameters(int dtype, const void* input, const void* offset, const void* gradOutput, void* gradWeight, int B,
+                                         int Cin, int H, int W, int Cout, int kW, int kH, int dW, int dH, int padW, int padH, int dilationW,
+                                         int dilationH, int group, int deformable_group, float scale, int im2col_step, void* columns,
+                                         size_t columns_bytes, void* stream) {
+  CFEN_CHECK_ARG(im2col_step > 0 && B % (im2col_step < B ? im2col_step : B) == 0, "im2col step must divide batchsize");
+  CFEN_CHECK_ARG(gradWeight, "deform_conv_backward_parameters: gradWeight is required");
+  DcnBwd a{};
+  a.im = input; a.offset = offset; a.weight = gradWeight /* shapes only: the pre-pass reads it, pass 5 does not use wt */; a.gout = gradOutput;
+  a.gweight = gradWeight;
+  a.B = B; a.C = Cin; a.H = H; a.W = W; a.Cout = Cout; a.kh = kH; a.kw = kW; a.sh = dH; a.sw = dW; a.ph = padH; a.pw = padW;
+  a.dh = dilationH; a.dw = dilationW; a.group = group; a.dg = deformable_group; a.scale = scale;
+  return dcn_backward(dtype, a, columns, columns_bytes, (hipStream_t)stream);
+}
+
+int cfen_modulated_deform_conv_backward(int dtype, const void* input, const void* weight, const void* bias, const void* offset, const void* mask,
+                                        void* grad_input, void* grad_weight, void* grad_bias, void* grad_offset, void* grad_mask,
+                                        const void* grad_output, int B, int Cin, int H, int W, int Cout, int kernel_h, int kernel_w, int stride_h,
+                                        int stride_w, int pad_h, int pad_w, int dilation_h, int dilation_w, int group, int deformable_group,
+                                        int with_bias, void* columns, size_t columns_bytes, void* stream) {
+  (void)bias;
+  CFEN_CHECK_ARG(mask != nullptr, "modulated_deform_conv_backward: mask is required");
+  CFEN_CHECK_ARG(grad_input && grad_weight && grad_offset && grad_mask, "modulated_deform_conv_backward: gradient tensors are required");
+  CFEN_CHECK_ARG(!with_bias || grad_bias, "modulated_deform_conv_backward: with_bias set but grad_bias is null");
+  DcnBwd a{};
+  a.im = input; a.offset = offset; a.mask = mask; a.weight = weight; a.gout = grad_output;
+  a.gin = grad_input; a.goff = grad_offset; a.gmask = grad_mask; a.gweight = grad_weight; a.gbias = with_bias ? grad_bias : nullptr;
+  a.B = B; a.C = Cin; a.H = H; a.W = W; a.Cout = Cout; a.kh = kernel_h; a.kw = kernel_w; a.sh = stride_h; a.sw = stride_w;
+  a.ph = pad_h; a.pw = pad_w; a.dh = dilation_h; a.dw = dilation_w; a.group = group; a.dg = deformable_group; a.scale = 1.f;
+  return dcn_backward(dtype, a, columns, columns_bytes, (hipStream_t)stream);
+}
+
+}  // extern "C"

@@ -1,12 +1,12 @@
 """Deformable convolution operator with the reference's Python API, backed by the HIP kernel.
 
-Mirrors dcn/deform_conv.py of the reference (functions :15-154, modules :161-329) for the FORWARD
-direction: same call signatures, argument meaning, error behaviour (ValueError for non-4D input and
-too-small outputs, AssertionError when im2col_step does not divide the batch, NotImplementedError for
-CPU tensors).  The pybind module `deform_conv_cuda` (dcn/src/deform_conv_cuda.cpp:681-695) is replaced
-by two C-ABI entry points of libcfen_hip.so; the `columns` / `ones` scratch tensors of the reference
-do not exist because the column matrix is never materialised (csrc/k_dcn.hip).
-Backward is out of scope for the inference path and raises NotImplementedError.
+Mirrors dcn/deform_conv.py of the reference (functions :15-154, modules :161-329): same call signatures,
+argument meaning, error behaviour (ValueError for non-4D input and too-small outputs, AssertionError when
+im2col_step does not divide the batch, NotImplementedError for CPU tensors).  The pybind module
+`deform_conv_cuda` (dcn/src/deform_conv_cuda.cpp:681-695) is replaced by C-ABI entry points of
+libcfen_hip.so: forward (csrc/k_dcn.hip; the column matrix is never materialised, the `columns` tensor is
+the kernel's operand scratch) and backward (csrc/k_dcn_bwd.hip: grad_input / grad_offset / grad_mask /
+grad_weight / grad_bias, fp32 arithmetic), so the functions are differentiable like the reference's.
 """
 import logging
 import math
@@ -14,6 +14,7 @@ import math
 import torch
 import torch.nn as nn
 from torch.autograd import Function
+from torch.autograd.function import once_differentiable
 from torch.nn.modules.utils import _pair
 
 from .. import _lib
@@ -34,12 +35,20 @@ def _columns(input, weight, groups):
     return torch.empty(max(int(n), 16), dtype=torch.uint8, device=input.device), int(n)
 
 
+def _backward_scratch(input, weight, out_hw, groups):
+    B, C, H, W = input.shape
+    n = _lib.load().cfen_deform_conv_backward_bytes(B, C, H, W, weight.size(0), weight.size(2), weight.size(3), out_hw[0], out_hw[1], groups)
+    return torch.empty(max(int(n), 16), dtype=torch.uint8, device=input.device), int(n)
+
+
 class DeformConvFunction(Function):
     @staticmethod
     def forward(ctx, input, offset, weight, stride=1, padding=0, dilation=1, groups=1, deformable_groups=1, im2col_step=64):
         if input is not None and input.dim() != 4:
             raise ValueError("Expected 4D tensor as input, got {}D tensor instead.".format(input.dim()))
         stride, padding, dilation = _pair(stride), _pair(padding), _pair(dilation)
+        ctx.stride, ctx.padding, ctx.dilation = stride, padding, dilation
+        ctx.groups, ctx.deformable_groups, ctx.im2col_step = groups, deformable_groups, im2col_step
         output = input.new_empty(DeformConvFunction._output_size(input, weight, padding, dilation, stride))
         if not input.is_cuda:
             raise NotImplementedError
@@ -53,6 +62,7 @@ class DeformConvFunction(Function):
         if input.size(1) != weight.size(1) * groups:
             raise RuntimeError("invalid number of input planes, expected: %d, but got: %d" % (weight.size(1) * groups, input.size(1)))
         input, offset, weight = _contig(input, offset.to(input.dtype), weight.to(input.dtype))
+        ctx.save_for_backward(input, offset, weight)
         B, C, H, W = input.shape
         columns, nbytes = _columns(input, weight, groups)
         # note the reference passes W before H here (deform_conv.py:41-46)
@@ -63,8 +73,31 @@ class DeformConvFunction(Function):
         return output
 
     @staticmethod
+    @once_differentiable
     def backward(ctx, grad_output):
-        raise NotImplementedError("deform_conv backward is outside the inference hot path (SURVEY 8f)")
+        """dcn/deform_conv.py:49-80: grad_input + grad_offset when either is needed, grad_weight when needed"""
+        input, offset, weight = ctx.saved_tensors
+        grad_input = grad_offset = grad_weight = None
+        if not grad_output.is_cuda:
+            raise NotImplementedError
+        cur_im2col_step = min(ctx.im2col_step, input.shape[0])
+        assert (input.shape[0] % cur_im2col_step) == 0, 'im2col step must divide batchsize'
+        grad_output = grad_output.to(input.dtype).contiguous()
+        B, C, H, W = input.shape
+        geom = (B, C, H, W, weight.size(0), weight.size(3), weight.size(2), ctx.stride[1], ctx.stride[0], ctx.padding[1], ctx.padding[0],
+                ctx.dilation[1], ctx.dilation[0], ctx.groups, ctx.deformable_groups)
+        columns, nbytes = _backward_scratch(input, weight, grad_output.shape[2:], ctx.groups)
+        lib, dt = _lib.load(), dtype_code(input.dtype)
+        if ctx.needs_input_grad[0] or ctx.needs_input_grad[1]:
+            grad_input = torch.zeros_like(input)
+            grad_offset = torch.zeros_like(offset)
+            check(lib.cfen_deform_conv_backward_input(dt, ptr(input), ptr(offset), ptr(grad_output), ptr(grad_input), ptr(grad_offset), ptr(weight),
+                                                      *geom, cur_im2col_step, ptr(columns), nbytes, current_stream()), "deform_conv_backward_input")
+        if ctx.needs_input_grad[2]:
+            grad_weight = torch.zeros_like(weight)
+            check(lib.cfen_deform_conv_backward_parameters(dt, ptr(input), ptr(offset), ptr(grad_output), ptr(grad_weight), *geom, 1.0,
+                                                           cur_im2col_step, ptr(columns), nbytes, current_stream()), "deform_conv_backward_parameters")
+        return (grad_input, grad_offset, grad_weight, None, None, None, None, None, None)
 
     @staticmethod
     def _output_size(input, weight, padding, dilation, stride):
@@ -97,6 +130,8 @@ class ModulatedDeformConvFunction(Function):
             raise RuntimeError("Input shape and kernel channels wont match: (%d vs %d)." % (input.size(1), weight.size(1) * groups))
         input, offset, mask, weight, bias = _contig(input, offset.to(input.dtype), mask.to(input.dtype), weight.to(input.dtype),
                                                     bias.to(input.dtype) if with_bias else None)
+        ctx.stride, ctx.padding, ctx.dilation, ctx.groups, ctx.deformable_groups, ctx.with_bias = stride, padding, dilation, groups, deformable_groups, with_bias
+        ctx.save_for_backward(input, offset, mask, weight)
         columns, nbytes = _columns(input, weight, groups)
         # scalar stride / padding / dilation, h before w (deform_conv.py:117-119)
         check(_lib.load().cfen_modulated_deform_conv_forward(
@@ -106,8 +141,23 @@ class ModulatedDeformConvFunction(Function):
         return output
 
     @staticmethod
+    @once_differentiable
     def backward(ctx, grad_output):
-        raise NotImplementedError("modulated_deform_conv backward is outside the inference hot path (SURVEY 8f)")
+        """dcn/deform_conv.py:122-145: all five gradients in one extension call"""
+        if not grad_output.is_cuda:
+            raise NotImplementedError
+        input, offset, mask, weight = ctx.saved_tensors
+        grad_output = grad_output.to(input.dtype).contiguous()
+        grad_input, grad_offset, grad_mask, grad_weight = (torch.zeros_like(t) for t in (input, offset, mask, weight))
+        grad_bias = torch.zeros(weight.size(0), dtype=input.dtype, device=input.device) if ctx.with_bias else None
+        B, C, H, W = input.shape
+        columns, nbytes = _backward_scratch(input, weight, grad_output.shape[2:], ctx.groups)
+        check(_lib.load().cfen_modulated_deform_conv_backward(
+            dtype_code(input.dtype), ptr(input), ptr(weight), None, ptr(offset), ptr(mask), ptr(grad_input), ptr(grad_weight), ptr(grad_bias),
+            ptr(grad_offset), ptr(grad_mask), ptr(grad_output), B, C, H, W, weight.size(0), weight.size(2), weight.size(3), ctx.stride, ctx.stride,
+            ctx.padding, ctx.padding, ctx.dilation, ctx.dilation, ctx.groups, ctx.deformable_groups, int(ctx.with_bias), ptr(columns), nbytes,
+            current_stream()), "modulated_deform_conv_backward")
+        return (grad_input, grad_offset, grad_mask, grad_weight, grad_bias, None, None, None, None, None)
 
 
 deform_conv = DeformConvFunction.apply

@@ -252,6 +252,30 @@ int cfen_modulated_deform_conv_forward(int dtype, const void* input, const void*
                                        int stride_h, int stride_w, int pad_h, int pad_w, int dilation_h, int dilation_w, int group,
                                        int deformable_group, int with_bias, void* columns, size_t columns_bytes, void* stream);
 
+/* ---- deformable convolution, backward direction ----
+ * NCHW tensors of `dtype`, arithmetic in fp32.  `columns`: device scratch of at least cfen_deform_conv_backward_bytes() bytes, 16-byte
+ * aligned (required: NHWC / transposed operand copies, the column-gradient matrix, fp32 accumulators).  gradInput / gradOffset / grad_mask
+ * are OVERWRITTEN; gradWeight / grad_bias are ACCUMULATED INTO (the reference's addmm_ with beta = 1: its Python side passes zeros).
+ * grad_input is summed with fp32 atomics like the reference's col2im (dcn/src/deform_conv_cuda_kernel.cu:322): reproducible up to
+ * summation order. */
+size_t cfen_deform_conv_backward_bytes(int B, int Cin, int H, int W, int Cout, int kH, int kW, int Hout, int Wout, int group);
+/* deform_conv_backward_input_cuda (dcn/src/deform_conv_cuda.cpp:260-265): W before H, as in the forward */
+int cfen_deform_conv_backward_input(int dtype, const void* input, const void* offset, const void* gradOutput, void* gradInput, void* gradOffset,
+                                    const void* weight, int B, int Cin, int H, int W, int Cout, int kW, int kH, int dW, int dH, int padW,
+                                    int padH, int dilationW, int dilationH, int group, int deformable_group, int im2col_step, void* columns,
+                                    size_t columns_bytes, void* stream);
+/* deform_conv_backward_parameters_cuda (dcn/src/deform_conv_cuda.cpp:370-376): gradWeight += scale * d loss / d weight */
+int cfen_deform_conv_backward_parameters(int dtype, const void* input, const void* offset, const void* gradOutput, void* gradWeight, int B,
+                                         int Cin, int H, int W, int Cout, int kW, int kH, int dW, int dH, int padW, int padH, int dilationW,
+                                         int dilationH, int group, int deformable_group, float scale, int im2col_step, void* columns,
+                                         size_t columns_bytes, void* stream);
+/* modulated_deform_conv_cuda_backward (dcn/src/deform_conv_cuda.cpp:566-574): h before w; `bias` is unused (shape only in the reference) */
+int cfen_modulated_deform_conv_backward(int dtype, const void* input, const void* weight, const void* bias, const void* offset, const void* mask,
+                                        void* grad_input, void* grad_weight, void* grad_bias, void* grad_offset, void* grad_mask,
+                                        const void* grad_output, int B, int Cin, int H, int W, int Cout, int kernel_h, int kernel_w, int stride_h,
+                                        int stride_w, int pad_h, int pad_w, int dilation_h, int dilation_w, int group, int deformable_group,
+                                        int with_bias, void* columns, size_t columns_bytes, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -90,3 +90,67 @@ def test_deform_conv_at_the_generator_feature_map_shapes(dtype, C, H, dg):
     want2 = dcn_oracle.deform_conv(xq.float(), oq.float(), wq.float(), 1, 1, 1, 1, dg, mask=mq.float(), bias=bq.float())
     got2 = dcn.modulated_deform_conv(xq.to(DEV), oq.to(DEV), mq.to(DEV), wq.to(DEV), bq.to(DEV), 1, 1, 1, 1, dg)
     assert float((got2.float().cpu() - want2).abs().max()) <= tol(dtype)
+
+
+# ---- backward (csrc/k_dcn_bwd.hip) through autograd of the reference-shaped functions, against oracle/dcn_oracle.c -----------------------
+
+def _grad_close(got, want, dtype, what):
+    scale = max(1.0, float(want.abs().max()))
+    d = float((got.float().cpu() - want).abs().max())
+    bar = (3e-4 if dtype == torch.float32 else 2e-2) * scale
+    assert d <= bar, "%s: max-abs %.3e > %.1e (scale %.2f)" % (what, d, bar, scale)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.float16])
+@pytest.mark.parametrize("B,C,H,Cout,k,stride,pad,dil,groups,dg", [
+    (2, 24, 16, 24, 3, 1, 1, 1, 1, 1), (1, 48, 12, 48, 3, 1, 1, 1, 1, 8), (2, 8, 13, 6, 3, 2, 1, 1, 1, 2), (1, 8, 12, 12, 5, 1, 2, 1, 2, 1),
+    (1, 6, 10, 20, 3, 1, 2, 2, 1, 3), (3, 3, 9, 5, 1, 1, 0, 1, 1, 1)])
+def test_deform_conv_backward_v1_and_v2(dtype, B, C, H, Cout, k, stride, pad, dil, groups, dg):
+    x, w = rnd((B, C, H, H + 3), 1), rnd((Cout, C // groups, k, k), 2, (C // groups * k * k) ** -0.5)
+    Ho = (H + 2 * pad - (dil * (k - 1) + 1)) // stride + 1
+    Wo = (H + 3 + 2 * pad - (dil * (k - 1) + 1)) // stride + 1
+    off, mask, bias = rnd((B, dg * 2 * k * k, Ho, Wo), 3, 1.5), torch.rand(B, dg * k * k, Ho, Wo, generator=torch.Generator().manual_seed(4)), rnd((Cout,), 5)
+    gy = rnd((B, Cout, Ho, Wo), 6)
+    if dtype == torch.float16:                  # the oracle sees what the kernel sees
+        x, w, off, mask, gy = (t.half().float() for t in (x, w, off, mask, gy))
+    leaf = lambda t: t.to(DEV).to(dtype).requires_grad_()
+    # DCNv1
+    xi, oi, wi = leaf(x), leaf(off), leaf(w)
+    y = dcn.deform_conv(xi, oi, wi, stride, pad, dil, groups, dg)
+    y.backward(gy.to(DEV).to(dtype))
+    want = dcn_oracle.deform_conv_backward(x, off, w, gy, stride, pad, dil, groups, dg)
+    _grad_close(xi.grad, want["input"], dtype, "v1 grad_input")
+    _grad_close(oi.grad, want["offset"], dtype, "v1 grad_offset")
+    _grad_close(wi.grad, want["weight"], dtype, "v1 grad_weight")
+    # DCNv2 (+ mask, + bias)
+    xi, oi, mi, wi, bi = leaf(x), leaf(off), leaf(mask), leaf(w), leaf(bias)
+    y = dcn.modulated_deform_conv(xi, oi, mi, wi, bi, stride, pad, dil, groups, dg)
+    y.backward(gy.to(DEV).to(dtype))
+    want = dcn_oracle.deform_conv_backward(x, off, w, gy, stride, pad, dil, groups, dg, mask=mask, with_bias=True)
+    for name, t in (("input", xi), ("offset", oi), ("mask", mi), ("weight", wi), ("bias", bi)):
+        _grad_close(t.grad, want[name], dtype, "v2 grad_" + name)
+
+
+def test_deform_conv_backward_only_weight_or_only_input_is_requested():
+    """dcn/deform_conv.py:62-80: the two extension calls are made independently, by needs_input_grad"""
+    x, w, off = rnd((1, 8, 10, 10), 1), rnd((8, 8, 3, 3), 2, 0.2), rnd((1, 18, 10, 10), 3)
+    gy = rnd((1, 8, 10, 10), 4)
+    want = dcn_oracle.deform_conv_backward(x, off, w, gy, 1, 1, 1, 1, 1)
+    wi = w.to(DEV).requires_grad_()
+    dcn.deform_conv(x.to(DEV), off.to(DEV), wi, 1, 1, 1, 1, 1).backward(gy.to(DEV))
+    _grad_close(wi.grad, want["weight"], torch.float32, "grad_weight alone")
+    xi = x.to(DEV).requires_grad_()
+    dcn.deform_conv(xi, off.to(DEV), w.to(DEV), 1, 1, 1, 1, 1).backward(gy.to(DEV))
+    _grad_close(xi.grad, want["input"], torch.float32, "grad_input alone")
+
+
+def test_deform_conv_pack_trains_one_sgd_step_like_conv2d_at_init():
+    """DeformConvPack at init (zero offset conv) is a plain conv: its weight gradient equals conv2d's (deform_conv.py:222-231)"""
+    torch.manual_seed(0)
+    m = dcn.DeformConvPack(8, 8, 3, stride=1, padding=1, deformable_groups=2).to(DEV)
+    x = rnd((2, 8, 12, 12), 7).to(DEV)
+    y = m(x)
+    y.square().mean().backward()
+    w = m.weight.detach().clone().requires_grad_()
+    F.conv2d(x, w, None, 1, 1).square().mean().backward()
+    assert float((m.weight.grad - w.grad).abs().max()) <= 2e-5
