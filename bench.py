@@ -72,8 +72,10 @@ def kernel_key(label, cls):
     return "%s:%s" % (cls, fam + (":" + step if step else ""))
 
 
-KERNEL_OF_STEP = {"embed_ln_qkv": "k_embed_qkv2", "proj_mlp_fused": "k_mlp2", "attention": "k_attention_hm / k_attention_win", "embed": "k_gemm_dma", "qkv": "k_gemm_dma",
-                  "proj": "k_gemm_dma", "ffn1": "k_gemm_dma", "ffn2": "k_gemm_dma", "head1": "k_gemm_dma", "head2": "k_gemm_dma"}
+KERNEL_OF_STEP = {"window_block_fused": "k_lvit_window", "embed_ln_qkv": "k_embed_qkv2", "proj_mlp_fused": "k_mlp2",
+                  "attention": "k_attention_hm / k_attention_win", "embed": "k_gemm_dma", "qkv": "k_gemm_dma", "ln1_qkv": "k_gemm_dma (LayerNorm folded)",
+                  "ln2_ffn1": "k_gemm_dma (LayerNorm folded)", "proj": "k_gemm_dma", "ffn1": "k_gemm_dma", "ffn2": "k_gemm_dma", "head1": "k_gemm_dma",
+                  "head2": "k_gemm_dma"}
 
 
 def self_check(net, x, outs, cfg, dtype):
