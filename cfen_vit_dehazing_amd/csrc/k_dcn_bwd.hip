@@ -13,9 +13,9 @@
 //                       all B*Hout*Wout pixels (MFMA operand of pass 5), weight -> per-group [tap*Cg + c][co] (transposed, tap-major)
 //   2. token GEMM       column gradients  gcol[pixel][g][tap*Cg + c] = sum_co grad_out[pixel][g][co] * W[g][co][c][tap]
 //                       (cfen_gemm_impl, exact-fp32 MFMA: the reference's per-image addmm_ of W^T and grad_out, .cpp:332-337)
-//   3. k_dcnb_scatter   one thread per (pixel, tap, deformable group): offsets / mask read once, the four bilinear corners set up once,
-//                       then for every channel of the group: atomic add of corner weight * gcol (* mask) into an NHWC fp32 image
-//                       (col2im), and the running sums for d/d offset_h, d/d offset_w, d/d mask (col2im_coord)
+//   3. k_dcnb_scatter   col2im_coord: one thread per (pixel, tap, deformable group) sums d/d offset_h, d/d offset_w, d/d mask over the
+//                       group's channels;  k_dcnb_col2im: one thread per (pixel, tap, channel), channel fastest, adds corner weight * gcol
+//                       (* mask) into an NHWC fp32 image with atomics (a wave's adds fall into a couple of cache lines)
 //   4. k_dcnb_im2col    the forward's column matrix (masked bilinear samples), channel-major rows over all pixels
 //   5. k_dcnb_weight    grad_W[g][co][k] += scale * sum_pixels grad_out[co][pixel] * column[k][pixel]: exact-fp32 MFMA over 16-pixel
 //                       chunks, a wave owns 16 k x all co, partial sums of a workgroup's pixel range land with fp32 atomics
@@ -120,7 +120,29 @@ CFEN_DEV DcnTap dcnb_tap(const DcnBwd& a, long long b, long long p, int t, int d
   return s;
 }
 
-// pass 3: col2im (grad_input, atomics into NHWC fp32) + col2im_coord (grad_offset, grad_mask)
+// pass 3a: col2im -- grad_input, fp32 atomics into the NHWC image.  One thread per (pixel, tap, CHANNEL), channel fastest: the lanes of a
+// wave add to consecutive addresses of one pixel, i.e. a wave instruction touches a couple of cache lines instead of 64 (with one thread per
+// (pixel, tap) and a channel loop the same number of atomics took 28 ms at (8, 24, 256, 256): L2 atomic throughput is per line, not per lane).
+template <typename T>
+__global__ __launch_bounds__(256) void k_dcnb_col2im(DcnBwd a) {
+  const long long HWo = (long long)a.Ho * a.Wo, n = a.P * a.kk * a.C;
+  for (long long idx = (long long)blockIdx.x * 256 + threadIdx.x; idx < n; idx += (long long)gridDim.x * 256) {
+    const int c = (int)(idx % a.C), t = (int)((idx / a.C) % a.kk);
+    const long long pix = idx / ((long long)a.C * a.kk);
+    const long long b = pix / HWo, p = pix % HWo;
+    const DcnTap s = dcnb_tap<T>(a, b, p, t, c / a.cpdg);
+    if (!s.inside) continue;
+    const int g = c / a.Cg, cl = c - g * a.Cg;
+    const float tg = a.col[pix * ((long long)a.group * a.Kgp) + g * a.Kgp + t * a.Cg + cl] * s.m;
+    const long long base = ((b * a.H + s.hl) * a.W + s.wl) * a.C + c, rowC = (long long)a.W * a.C;
+    if (s.ok0) unsafeAtomicAdd(a.gi + base, (1.f - s.lh) * (1.f - s.lw) * tg);
+    if (s.ok1) unsafeAtomicAdd(a.gi + base + a.C, (1.f - s.lh) * s.lw * tg);
+    if (s.ok2) unsafeAtomicAdd(a.gi + base + rowC, s.lh * (1.f - s.lw) * tg);
+    if (s.ok3) unsafeAtomicAdd(a.gi + base + rowC + a.C, s.lh * s.lw * tg);
+  }
+}
+
+// pass 3b: col2im_coord -- grad_offset, grad_mask: one thread per (pixel, tap, deformable group), a loop over the group's channels
 template <typename T>
 __global__ __launch_bounds__(256) void k_dcnb_scatter(DcnBwd a) {
   const long long HWo = (long long)a.Ho * a.Wo, n = a.P * a.kk * a.dg;
@@ -143,13 +165,6 @@ __global__ __launch_bounds__(256) void k_dcnb_scatter(DcnBwd a) {
         dH += gv * (-(1.f - s.lw) * v0 - s.lw * v1 + (1.f - s.lw) * v2 + s.lw * v3);
         dW += gv * (-(1.f - s.lh) * v0 + (1.f - s.lh) * v1 - s.lh * v2 + s.lh * v3);
         mv += gv * (w0 * v0 + w1 * v1 + w2 * v2 + w3 * v3);
-        if (a.gin) {
-          const float tg = gv * s.m;
-          if (s.ok0) unsafeAtomicAdd(a.gi + base + c, w0 * tg);
-          if (s.ok1) unsafeAtomicAdd(a.gi + base + a.C + c, w1 * tg);
-          if (s.ok2) unsafeAtomicAdd(a.gi + base + rowC + c, w2 * tg);
-          if (s.ok3) unsafeAtomicAdd(a.gi + base + rowC + a.C + c, w3 * tg);
-        }
       }
     }
     if (a.goff) {
@@ -278,9 +293,13 @@ int run_dcn_backward(DcnBwd a, hipStream_t s) {
                               a.col + (size_t)g * a.Kgp, a.group * a.Kgp, (int)a.P, a.Kgp, a.Cogp, 0, s);
       if (rc) return rc;
     }
-    CFEN_LAUNCH(k_dcnb_scatter<T>, dim3(grid_for(a.P * a.kk * a.dg)), dim3(256), 0, s, a);
-    CFEN_CHECK_LAUNCH("deform_conv backward (col2im)");
+    if (a.goff || a.gmask) {
+      CFEN_LAUNCH(k_dcnb_scatter<T>, dim3(grid_for(a.P * a.kk * a.dg)), dim3(256), 0, s, a);
+      CFEN_CHECK_LAUNCH("deform_conv backward (col2im_coord)");
+    }
     if (a.gin) {
+      CFEN_LAUNCH(k_dcnb_col2im<T>, dim3(grid_for(a.P * a.kk * a.C)), dim3(256), 0, s, a);
+      CFEN_CHECK_LAUNCH("deform_conv backward (col2im)");
       CFEN_LAUNCH(k_dcnb_gin_out<T>, dim3(grid_for(n1)), dim3(256), 0, s, a);
       CFEN_CHECK_LAUNCH("deform_conv backward (grad_input)");
     }

@@ -21,6 +21,7 @@ def main():
     ap.add_argument("--dtype", default="fp16", choices=["fp16", "fp32"])
     ap.add_argument("--reps", type=int, default=30)
     ap.add_argument("--check", action="store_true")
+    ap.add_argument("--backward", action="store_true", help="time the backward of each case (all gradients) instead of the forward")
     args = ap.parse_args()
     dt = torch.float16 if args.dtype == "fp16" else torch.float32
     esz = 2 if dt == torch.float16 else 4
@@ -41,6 +42,11 @@ def main():
             for ver in (1, 2):
                 fn = (lambda: dcn.deform_conv(x, off, w, 1, 1, 1, 1, dg)) if ver == 1 else \
                      (lambda: dcn.modulated_deform_conv(x, off, mask, w, bias, 1, 1, 1, 1, dg))
+                if args.backward:
+                    leaves = [t.detach().clone().requires_grad_() for t in ((x, off, w) if ver == 1 else (x, off, mask, w, bias))]
+                    y = dcn.deform_conv(*leaves, 1, 1, 1, 1, dg) if ver == 1 else dcn.modulated_deform_conv(*leaves, 1, 1, 1, 1, dg)
+                    gy = torch.randn(y.shape, generator=g).to(dt).to(dev)
+                    fn = lambda: torch.autograd.grad(y, leaves, gy, retain_graph=True)
                 out = fn()
                 torch.cuda.synchronize()
                 times = []
@@ -54,11 +60,13 @@ def main():
                 ms = times[len(times) // 2]
                 px = B * H * H
                 elems = C * px + (2 if ver == 1 else 3) * dg * 9 * px + C * px + C * C * 9
+                if args.backward:       # reads input, offsets (+ mask), weights, grad_out; writes grad_input, grad_offset (+ grad_mask), grad_weight
+                    elems = 2 * (C * px + (2 if ver == 1 else 3) * dg * 9 * px + C * C * 9) + C * px
                 gbs = elems * esz / ms / 1e6
-                tf = (2.0 * C * C * 9 + 8.0 * C * 9) * px / ms / 1e9
-                rec = {"op": "dcn_v%d" % ver, "shape": [B, C, H, H], "deformable_groups": dg, "dtype": args.dtype, "us": round(ms * 1e3, 1),
+                tf = (2.0 * C * C * 9 + 8.0 * C * 9) * px / ms / 1e9 * (2 if args.backward else 1)
+                rec = {"op": "dcn_v%d%s" % (ver, "_backward" if args.backward else ""), "shape": [B, C, H, H], "deformable_groups": dg, "dtype": args.dtype, "us": round(ms * 1e3, 1),
                        "algorithmic_MB": round(elems * esz / 1e6, 2), "GBps": round(gbs, 1), "hbm_frac": round(gbs / HBM_PEAK, 4), "TFLOPs": round(tf, 2)}
-                if args.check:
+                if args.check and not args.backward:
                     want = dcn_oracle.deform_conv(x[:1].float().cpu(), off[:1].float().cpu(), w.float().cpu(), 1, 1, 1, 1, dg,
                                                   **({} if ver == 1 else {"mask": mask[:1].float().cpu(), "bias": bias.float().cpu()}))
                     rec["max_abs_vs_oracle_image0"] = float((out[:1].float().cpu() - want).abs().max())
