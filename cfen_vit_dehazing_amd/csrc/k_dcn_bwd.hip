@@ -8,15 +8,17 @@
 //   modulated_deform_conv_cuda_backward                              dcn/src/deform_conv_cuda.cpp:566-679
 //
 // Arithmetic is fp32 whatever the tensor type (gradients are sums over up to B*Hout*Wout terms), tensors are NCHW like the reference
-// API, scratch is the caller's `columns` buffer.  Five passes:
-//   1. k_dcnb_prep      layout copies: input -> NHWC fp32, grad_out -> pixel-major rows (GEMM operand) and channel-major rows over
-//                       all B*Hout*Wout pixels (MFMA operand of pass 5), weight -> per-group [tap*Cg + c][co] (transposed, tap-major)
-//   2. token GEMM       column gradients  gcol[pixel][g][tap*Cg + c] = sum_co grad_out[pixel][g][co] * W[g][co][c][tap]
+// API, scratch is the caller's `columns` buffer.  Every kernel maps ADJACENT LANES TO ADJACENT OUTPUT PIXELS and reads / adds to NCHW
+// planes, so for smooth offset fields a wave's gathers and atomic adds fall into a few cache lines (a first version with NHWC copies and
+// a channel loop per thread spent 28 ms at (8, 24, 256, 256): 64 cache lines per wave instruction).  Five passes:
+//   1. k_dcnb_prep      layout copies: grad_out -> pixel-major rows (GEMM operand) and channel-major rows over all B*Hout*Wout pixels
+//                       (MFMA operand of pass 5), weight -> per-group [tap*Cg + c][co] (transposed, tap-major)
+//   2. token GEMM       column gradients, k-major:  gcol[g][tap*Cg + c][pixel] = sum_co W[g][co][c][tap] * grad_out[pixel][g][co]
 //                       (cfen_gemm_impl, exact-fp32 MFMA: the reference's per-image addmm_ of W^T and grad_out, .cpp:332-337)
 //   3. k_dcnb_scatter   col2im_coord: one thread per (pixel, tap, deformable group) sums d/d offset_h, d/d offset_w, d/d mask over the
-//                       group's channels;  k_dcnb_col2im: one thread per (pixel, tap, channel), channel fastest, adds corner weight * gcol
-//                       (* mask) into an NHWC fp32 image with atomics (a wave's adds fall into a couple of cache lines)
-//   4. k_dcnb_im2col    the forward's column matrix (masked bilinear samples), channel-major rows over all pixels
+//                       group's channels;  k_dcnb_col2im: one thread per (pixel, tap, channel) adds corner weight * gcol (* mask) into
+//                       an fp32 NCHW image with atomics (the reference's col2im, .cu:278-328)
+//   4. k_dcnb_im2col    the forward's column matrix (masked bilinear samples), k-major rows over all pixels
 //   5. k_dcnb_weight    grad_W[g][co][k] += scale * sum_pixels grad_out[co][pixel] * column[k][pixel]: exact-fp32 MFMA over 16-pixel
 //                       chunks, a wave owns 16 k x all co, partial sums of a workgroup's pixel range land with fp32 atomics
 // then small epilogue kernels write the NCHW / (Cout, Cg, kh, kw) results in the tensor type.  grad_input / grad_offset / grad_mask
@@ -37,28 +39,27 @@ struct DcnBwd {
   int Cg, Cog, Cogp, kk, Kg, Kgp, cpdg;
   long long P, Pp;          // B*Ho*Wo pixels; row pitch of the channel-major copies (multiple of 16)
   // scratch (fp32)
-  float* xn;                // [B][H][W][C]
-  float* gn;                // [P][group][Cogp]
+  float* gn;                // [Pp][group][Cogp]   (zero rows past P)
   float* gc;                // [Cout][Pp]
   float* wt;                // [group][Kgp][Cogp]
-  float* col;               // pass 2/3: [P][group][Kgp];  pass 4/5: [group][Kg][Pp]
-  float* gi;                // [B][H][W][C]
+  float* col;               // pass 2/3: gcol [group][Kgp][Pp];  pass 4/5: forward columns [group][Kg][Pp]
+  float* gi;                // [B][C][H][W]
   float* gw;                // [group][Cog][Kg]   (k = tap*Cg + c)
 };
 
 inline size_t up256(size_t v) { return (v + 255) / 256 * 256; }
 
-struct DcnBwdLayout { size_t xn, gn, gc, wt, col, gi, gw, total; };
+struct DcnBwdLayout { size_t gn, gc, wt, col, gi, gw, total; };
 DcnBwdLayout dcnb_layout(int B, int C, int H, int W, int Cout, int kk, int Ho, int Wo, int group) {
   const size_t Cg = C / group, Cog = Cout / group, Cogp = (Cog + 3) / 4 * 4, Kg = Cg * kk, Kgp = (Kg + 3) / 4 * 4;
   const size_t P = (size_t)B * Ho * Wo, Pp = (P + 15) / 16 * 16;
   DcnBwdLayout l;
   size_t o = 0;
-  l.xn = o; o += up256((size_t)B * H * W * C * 4);
-  l.gn = o; o += up256(P * group * Cogp * 4);
+  l.gn = o; o += up256(Pp * group * Cogp * 4);
   l.gc = o; o += up256((size_t)Cout * Pp * 4);
   l.wt = o; o += up256((size_t)group * Kgp * Cogp * 4);
-  l.col = o; o += up256(std::max(P * group * Kgp, (size_t)group * Kg * Pp) * 4);
+  l.col = o; o += up256((size_t)group * Kgp * Pp * 4);
+  (void)P; (void)Kg;
   l.gi = o; o += up256((size_t)B * H * W * C * 4);
   l.gw = o; o += up256((size_t)group * Cog * Kg * 4);
   l.total = o;
@@ -67,17 +68,13 @@ DcnBwdLayout dcnb_layout(int B, int C, int H, int W, int Cout, int kk, int Ho, i
 
 template <typename T>
 __global__ __launch_bounds__(256) void k_dcnb_prep(DcnBwd a, long long n1, long long n2, long long n3, long long n4) {
-  const long long HW = (long long)a.H * a.W, HWo = (long long)a.Ho * a.Wo;
+  const long long HWo = (long long)a.Ho * a.Wo;
   for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n1 + n2 + n3 + n4; i += (long long)gridDim.x * 256) {
-    if (i < n1) {                                            // xn[b][p][c] = im[b][c][p]
-      const int c = (int)(i % a.C);
-      const long long bp = i / a.C, b = bp / HW, p = bp % HW;
-      a.xn[i] = (float)((const T*)a.im)[(b * a.C + c) * HW + p];
-    } else if (i < n1 + n2) {                                // gn[pix][g][ol] (zero in the padding lanes ol >= Cog)
+    if (i < n1 + n2) {                                       // gn[pix][g][ol] (zero in the padding lanes ol >= Cog and rows pix >= P)
       const long long j = i - n1;
       const int ol = (int)(j % a.Cogp), g = (int)((j / a.Cogp) % a.group);
       const long long pix = j / ((long long)a.Cogp * a.group), b = pix / HWo, p = pix % HWo;
-      a.gn[j] = ol < a.Cog ? (float)((const T*)a.gout)[(b * a.Cout + g * a.Cog + ol) * HWo + p] : 0.f;
+      a.gn[j] = (ol < a.Cog && pix < a.P) ? (float)((const T*)a.gout)[(b * a.Cout + g * a.Cog + ol) * HWo + p] : 0.f;
     } else if (i < n1 + n2 + n3) {                           // gc[co][pix] (zero in the padding columns pix >= P)
       const long long j = i - n1 - n2, pix = j % a.Pp;
       const int co = (int)(j / a.Pp);
@@ -120,32 +117,30 @@ CFEN_DEV DcnTap dcnb_tap(const DcnBwd& a, long long b, long long p, int t, int d
   return s;
 }
 
-// pass 3a: col2im -- grad_input, fp32 atomics into the NHWC image.  One thread per (pixel, tap, CHANNEL), channel fastest: the lanes of a
-// wave add to consecutive addresses of one pixel, i.e. a wave instruction touches a couple of cache lines instead of 64 (with one thread per
-// (pixel, tap) and a channel loop the same number of atomics took 28 ms at (8, 24, 256, 256): L2 atomic throughput is per line, not per lane).
+// pass 3a: col2im -- grad_input, fp32 atomics into an NCHW image.  One thread per (pixel, tap, channel), pixel fastest.
 template <typename T>
 __global__ __launch_bounds__(256) void k_dcnb_col2im(DcnBwd a) {
-  const long long HWo = (long long)a.Ho * a.Wo, n = a.P * a.kk * a.C;
+  const long long HWo = (long long)a.Ho * a.Wo, HW = (long long)a.H * a.W, n = a.P * a.kk * a.C;
   for (long long idx = (long long)blockIdx.x * 256 + threadIdx.x; idx < n; idx += (long long)gridDim.x * 256) {
-    const int c = (int)(idx % a.C), t = (int)((idx / a.C) % a.kk);
-    const long long pix = idx / ((long long)a.C * a.kk);
+    const long long pix = idx % a.P;
+    const int t = (int)((idx / a.P) % a.kk), c = (int)(idx / (a.P * a.kk));
     const long long b = pix / HWo, p = pix % HWo;
     const DcnTap s = dcnb_tap<T>(a, b, p, t, c / a.cpdg);
     if (!s.inside) continue;
     const int g = c / a.Cg, cl = c - g * a.Cg;
-    const float tg = a.col[pix * ((long long)a.group * a.Kgp) + g * a.Kgp + t * a.Cg + cl] * s.m;
-    const long long base = ((b * a.H + s.hl) * a.W + s.wl) * a.C + c, rowC = (long long)a.W * a.C;
-    if (s.ok0) unsafeAtomicAdd(a.gi + base, (1.f - s.lh) * (1.f - s.lw) * tg);
-    if (s.ok1) unsafeAtomicAdd(a.gi + base + a.C, (1.f - s.lh) * s.lw * tg);
-    if (s.ok2) unsafeAtomicAdd(a.gi + base + rowC, s.lh * (1.f - s.lw) * tg);
-    if (s.ok3) unsafeAtomicAdd(a.gi + base + rowC + a.C, s.lh * s.lw * tg);
+    const float tg = a.col[((long long)g * a.Kgp + t * a.Cg + cl) * a.Pp + pix] * s.m;
+    float* gp = a.gi + (b * a.C + c) * HW + (long long)s.hl * a.W + s.wl;
+    if (s.ok0) unsafeAtomicAdd(gp, (1.f - s.lh) * (1.f - s.lw) * tg);
+    if (s.ok1) unsafeAtomicAdd(gp + 1, (1.f - s.lh) * s.lw * tg);
+    if (s.ok2) unsafeAtomicAdd(gp + a.W, s.lh * (1.f - s.lw) * tg);
+    if (s.ok3) unsafeAtomicAdd(gp + a.W + 1, s.lh * s.lw * tg);
   }
 }
 
 // pass 3b: col2im_coord -- grad_offset, grad_mask: one thread per (pixel, tap, deformable group), a loop over the group's channels
 template <typename T>
 __global__ __launch_bounds__(256) void k_dcnb_scatter(DcnBwd a) {
-  const long long HWo = (long long)a.Ho * a.Wo, n = a.P * a.kk * a.dg;
+  const long long HWo = (long long)a.Ho * a.Wo, HW = (long long)a.H * a.W, n = a.P * a.kk * a.dg;
   for (long long idx = (long long)blockIdx.x * 256 + threadIdx.x; idx < n; idx += (long long)gridDim.x * 256) {
     const long long pix = idx % a.P;
     const int t = (int)((idx / a.P) % a.kk), dgi = (int)(idx / (a.P * a.kk));
@@ -154,14 +149,13 @@ __global__ __launch_bounds__(256) void k_dcnb_scatter(DcnBwd a) {
     float dH = 0.f, dW = 0.f, mv = 0.f;
     if (s.inside) {
       const float w0 = (1.f - s.lh) * (1.f - s.lw), w1 = (1.f - s.lh) * s.lw, w2 = s.lh * (1.f - s.lw), w3 = s.lh * s.lw;
-      const long long base = ((b * a.H + s.hl) * a.W + s.wl) * a.C;     // corner (hl, wl); others + C, + W*C, + (W+1)*C
-      const long long rowC = (long long)a.W * a.C;
-      const float* gcol = a.col + pix * ((long long)a.group * a.Kgp);
+      const long long corner = (long long)s.hl * a.W + s.wl;
       for (int c = dgi * a.cpdg; c < (dgi + 1) * a.cpdg; ++c) {
         const int g = c / a.Cg, cl = c - g * a.Cg;
-        const float gv = gcol[g * a.Kgp + t * a.Cg + cl];
-        const float v0 = s.ok0 ? a.xn[base + c] : 0.f, v1 = s.ok1 ? a.xn[base + a.C + c] : 0.f;
-        const float v2 = s.ok2 ? a.xn[base + rowC + c] : 0.f, v3 = s.ok3 ? a.xn[base + rowC + a.C + c] : 0.f;
+        const float gv = a.col[((long long)g * a.Kgp + t * a.Cg + cl) * a.Pp + pix];
+        const T* ip = (const T*)a.im + (b * a.C + c) * HW + corner;
+        const float v0 = s.ok0 ? (float)ip[0] : 0.f, v1 = s.ok1 ? (float)ip[1] : 0.f;
+        const float v2 = s.ok2 ? (float)ip[a.W] : 0.f, v3 = s.ok3 ? (float)ip[a.W + 1] : 0.f;
         dH += gv * (-(1.f - s.lw) * v0 - s.lw * v1 + (1.f - s.lw) * v2 + s.lw * v3);
         dW += gv * (-(1.f - s.lh) * v0 + (1.f - s.lh) * v1 - s.lh * v2 + s.lh * v3);
         mv += gv * (w0 * v0 + w1 * v1 + w2 * v2 + w3 * v3);
@@ -177,19 +171,15 @@ __global__ __launch_bounds__(256) void k_dcnb_scatter(DcnBwd a) {
 }
 
 template <typename T>
-__global__ __launch_bounds__(256) void k_dcnb_gin_out(DcnBwd a) {     // NHWC fp32 -> NCHW T
-  const long long HW = (long long)a.H * a.W, n = (long long)a.B * a.C * HW;
-  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
-    const long long p = i % HW, bc = i / HW, b = bc / a.C;
-    const int c = (int)(bc % a.C);
-    ((T*)a.gin)[i] = (T)a.gi[(b * HW + p) * a.C + c];
-  }
+__global__ __launch_bounds__(256) void k_dcnb_gin_out(DcnBwd a) {     // fp32 accumulation image -> grad_input (same NCHW layout)
+  const long long n = (long long)a.B * a.C * a.H * a.W;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) ((T*)a.gin)[i] = (T)a.gi[i];
 }
 
-// pass 4: column matrix of the forward, channel-major: col[g][k = t*Cg + cl][pix]  (pix < Pp; zero in the padding columns)
+// pass 4: column matrix of the forward, k-major: col[g][k = t*Cg + cl][pix]  (pix < Pp; zero in the padding columns)
 template <typename T>
 __global__ __launch_bounds__(256) void k_dcnb_im2col(DcnBwd a) {
-  const long long HWo = (long long)a.Ho * a.Wo, n = a.Pp * a.kk * a.dg;
+  const long long HWo = (long long)a.Ho * a.Wo, HW = (long long)a.H * a.W, n = a.Pp * a.kk * a.dg;
   for (long long idx = (long long)blockIdx.x * 256 + threadIdx.x; idx < n; idx += (long long)gridDim.x * 256) {
     const long long pix = idx % a.Pp;
     const int t = (int)((idx / a.Pp) % a.kk), dgi = (int)(idx / (a.Pp * a.kk));
@@ -198,13 +188,14 @@ __global__ __launch_bounds__(256) void k_dcnb_im2col(DcnBwd a) {
     const DcnTap s = dcnb_tap<T>(a, b, p, t, dgi);
     const bool use = live && s.inside;
     const float w0 = (1.f - s.lh) * (1.f - s.lw), w1 = (1.f - s.lh) * s.lw, w2 = s.lh * (1.f - s.lw), w3 = s.lh * s.lw;
-    const long long base = ((b * a.H + s.hl) * a.W + s.wl) * a.C, rowC = (long long)a.W * a.C;
+    const long long corner = (long long)s.hl * a.W + s.wl;
     for (int c = dgi * a.cpdg; c < (dgi + 1) * a.cpdg; ++c) {
       const int g = c / a.Cg, cl = c - g * a.Cg;
       float v = 0.f;
       if (use) {
-        const float v0 = s.ok0 ? a.xn[base + c] : 0.f, v1 = s.ok1 ? a.xn[base + a.C + c] : 0.f;
-        const float v2 = s.ok2 ? a.xn[base + rowC + c] : 0.f, v3 = s.ok3 ? a.xn[base + rowC + a.C + c] : 0.f;
+        const T* ip = (const T*)a.im + (b * a.C + c) * HW + corner;
+        const float v0 = s.ok0 ? (float)ip[0] : 0.f, v1 = s.ok1 ? (float)ip[1] : 0.f;
+        const float v2 = s.ok2 ? (float)ip[a.W] : 0.f, v3 = s.ok3 ? (float)ip[a.W + 1] : 0.f;
         v = (w0 * v0 + w1 * v1 + w2 * v2 + w3 * v3) * s.m;
       }
       a.col[((long long)g * a.Kg + t * a.Cg + cl) * a.Pp + pix] = v;
@@ -282,15 +273,15 @@ unsigned grid_for(long long n) { return (unsigned)std::min<long long>((n + 255) 
 template <typename T>
 int run_dcn_backward(DcnBwd a, hipStream_t s) {
   const bool want_in = a.gin || a.goff || a.gmask, want_par = a.gweight || a.gbias;
-  const long long HW = (long long)a.H * a.W;
-  const long long n1 = (long long)a.B * HW * a.C, n2 = a.P * a.group * a.Cogp, n3 = (long long)a.Cout * a.Pp, n4 = (long long)a.group * a.Kgp * a.Cogp;
+  const long long nin = (long long)a.B * a.C * a.H * a.W;
+  const long long n1 = 0, n2 = a.Pp * a.group * a.Cogp, n3 = (long long)a.Cout * a.Pp, n4 = (long long)a.group * a.Kgp * a.Cogp;
   CFEN_LAUNCH(k_dcnb_prep<T>, dim3(grid_for(n1 + n2 + n3 + n4)), dim3(256), 0, s, a, n1, n2, n3, n4);
   CFEN_CHECK_LAUNCH("deform_conv backward (layout pre-pass)");
   if (want_in) {
-    if (a.gin && hipMemsetAsync(a.gi, 0, (size_t)n1 * 4, s) != hipSuccess) { cfen_set_error("deform_conv backward: memset failed"); return CFEN_ERR_HIP; }
-    for (int g = 0; g < a.group; ++g) {   // gcol[pix][g][:] = gn[pix][g][:] . wt[g]^T
-      int rc = cfen_gemm_impl(0, a.gn + (size_t)g * a.Cogp, a.group * a.Cogp, a.wt + (size_t)g * a.Kgp * a.Cogp, a.Cogp, nullptr, nullptr, 0, nullptr, 0,
-                              a.col + (size_t)g * a.Kgp, a.group * a.Kgp, (int)a.P, a.Kgp, a.Cogp, 0, s);
+    if (a.gin && hipMemsetAsync(a.gi, 0, (size_t)nin * 4, s) != hipSuccess) { cfen_set_error("deform_conv backward: memset failed"); return CFEN_ERR_HIP; }
+    for (int g = 0; g < a.group; ++g) {   // gcol[g][k][pix] = wt[g][k][:] . gn[pix][g][:]   ("tokens" = the Kgp rows of W^T, "features" = pixels)
+      int rc = cfen_gemm_impl(0, a.wt + (size_t)g * a.Kgp * a.Cogp, a.Cogp, a.gn + (size_t)g * a.Cogp, a.group * a.Cogp, nullptr, nullptr, 0, nullptr, 0,
+                              a.col + (size_t)g * a.Kgp * a.Pp, (int)a.Pp, a.Kgp, (int)a.Pp, a.Cogp, 0, s);
       if (rc) return rc;
     }
     if (a.goff || a.gmask) {
@@ -300,7 +291,7 @@ int run_dcn_backward(DcnBwd a, hipStream_t s) {
     if (a.gin) {
       CFEN_LAUNCH(k_dcnb_col2im<T>, dim3(grid_for(a.P * a.kk * a.C)), dim3(256), 0, s, a);
       CFEN_CHECK_LAUNCH("deform_conv backward (col2im)");
-      CFEN_LAUNCH(k_dcnb_gin_out<T>, dim3(grid_for(n1)), dim3(256), 0, s, a);
+      CFEN_LAUNCH(k_dcnb_gin_out<T>, dim3(grid_for(nin)), dim3(256), 0, s, a);
       CFEN_CHECK_LAUNCH("deform_conv backward (grad_input)");
     }
   }
@@ -342,12 +333,12 @@ int dcn_backward(int dtype, DcnBwd a, void* columns, size_t columns_bytes, hipSt
   a.Kg = a.Cg * a.kk; a.Kgp = (a.Kg + 3) / 4 * 4; a.cpdg = a.C / a.dg;
   a.P = (long long)a.B * a.Ho * a.Wo; a.Pp = (a.P + 15) / 16 * 16;
   CFEN_CHECK_ARG(a.Cog <= 16 * DB_MAXOT, "deform_conv backward: more than %d output channels per group", 16 * DB_MAXOT);
-  CFEN_CHECK_ARG(a.P < (1ll << 31) && (long long)a.group * a.Kgp < (1ll << 31), "deform_conv backward: problem too large");
+  CFEN_CHECK_ARG(a.Pp < (1ll << 31) && (long long)a.group * a.Kgp < (1ll << 31), "deform_conv backward: problem too large");
   const DcnBwdLayout l = dcnb_layout(a.B, a.C, a.H, a.W, a.Cout, a.kk, a.Ho, a.Wo, a.group);
   CFEN_CHECK_ARG(columns && cfen_aligned16(columns) && columns_bytes >= l.total,
                  "deform_conv backward: `columns` scratch of at least %zu bytes (cfen_deform_conv_backward_bytes), 16-byte aligned, is required", l.total);
   unsigned char* base = (unsigned char*)columns;
-  a.xn = (float*)(base + l.xn); a.gn = (float*)(base + l.gn); a.gc = (float*)(base + l.gc); a.wt = (float*)(base + l.wt);
+  a.gn = (float*)(base + l.gn); a.gc = (float*)(base + l.gc); a.wt = (float*)(base + l.wt);
   a.col = (float*)(base + l.col); a.gi = (float*)(base + l.gi); a.gw = (float*)(base + l.gw);
   return dtype == 1 ? run_dcn_backward<half_t>(a, s) : run_dcn_backward<float>(a, s);
 }
