@@ -137,6 +137,53 @@ __global__ __launch_bounds__(256) void k_dcnb_col2im(DcnBwd a) {
   }
 }
 
+// pass 3a, LDS-privatised: a workgroup owns a 16 x 16 tile of OUTPUT pixels of one image for CH channels.  Their samples land inside
+// the tile's input footprint grown by a halo of R pixels (offsets beyond R are rare; those adds go straight to global memory), so the
+// adds are LDS atomics (ds_add_f32) into an E x E x CH fp32 tile that is flushed once: 4 * k*k global atomics per (pixel, channel) become
+// ~ E*E / 256 (9x fewer for 3x3, stride 1, R = 6), and zeros are not flushed at all.
+template <typename T>
+__global__ __launch_bounds__(256) void k_dcnb_col2im_lds(DcnBwd a, int E, int R, int CH, int tiles_x) {
+  extern __shared__ float tile[];
+  const long long HWo = (long long)a.Ho * a.Wo, HW = (long long)a.H * a.W;
+  const int tid = threadIdx.x, b = blockIdx.z, c0 = blockIdx.y * CH, nch = min(CH, a.C - c0);
+  const int ho0 = (blockIdx.x / tiles_x) * 16, wo0 = (blockIdx.x % tiles_x) * 16;
+  const int ry0 = ho0 * a.sh - a.ph - R, rx0 = wo0 * a.sw - a.pw - R;
+  for (int i = tid; i < E * E * CH; i += 256) tile[i] = 0.f;
+  __syncthreads();
+  const int ho = ho0 + tid / 16, wo = wo0 + tid % 16;
+  if (ho < a.Ho && wo < a.Wo) {
+    const long long p = (long long)ho * a.Wo + wo, pix = (long long)b * HWo + p;
+    for (int t = 0; t < a.kk; ++t) {
+      int cur = -1;
+      DcnTap s;
+      for (int cl0 = 0; cl0 < nch; ++cl0) {
+        const int c = c0 + cl0, dgi = c / a.cpdg;
+        if (dgi != cur) { s = dcnb_tap<T>(a, b, p, t, dgi); cur = dgi; }
+        if (!s.inside) continue;
+        const int g = c / a.Cg, cl = c - g * a.Cg;
+        const float tg = a.col[((long long)g * a.Kgp + t * a.Cg + cl) * a.Pp + pix] * s.m;
+        const int ly = s.hl - ry0, lx = s.wl - rx0;
+        float* lt = tile + ((long long)cl0 * E + ly) * E + lx;
+        float* gp = a.gi + ((long long)b * a.C + c) * HW + (long long)s.hl * a.W + s.wl;
+        const float w0 = (1.f - s.lh) * (1.f - s.lw) * tg, w1 = (1.f - s.lh) * s.lw * tg, w2 = s.lh * (1.f - s.lw) * tg, w3 = s.lh * s.lw * tg;
+        const bool y0in = ly >= 0 && ly < E, y1in = ly + 1 >= 0 && ly + 1 < E, x0in = lx >= 0 && lx < E, x1in = lx + 1 >= 0 && lx + 1 < E;
+        if (s.ok0) { if (y0in && x0in) atomicAdd(lt, w0); else unsafeAtomicAdd(gp, w0); }
+        if (s.ok1) { if (y0in && x1in) atomicAdd(lt + 1, w1); else unsafeAtomicAdd(gp + 1, w1); }
+        if (s.ok2) { if (y1in && x0in) atomicAdd(lt + E, w2); else unsafeAtomicAdd(gp + a.W, w2); }
+        if (s.ok3) { if (y1in && x1in) atomicAdd(lt + E + 1, w3); else unsafeAtomicAdd(gp + a.W + 1, w3); }
+      }
+    }
+  }
+  __syncthreads();
+  for (int i = tid; i < E * E * nch; i += 256) {
+    const float v = tile[i];
+    if (v == 0.f) continue;
+    const int lx = i % E, ly = (i / E) % E, cl0 = i / (E * E);
+    const int y = ry0 + ly, x = rx0 + lx;
+    if (y >= 0 && y < a.H && x >= 0 && x < a.W) unsafeAtomicAdd(a.gi + ((long long)b * a.C + c0 + cl0) * HW + (long long)y * a.W + x, v);
+  }
+}
+
 // pass 3b: col2im_coord -- grad_offset, grad_mask: one thread per (pixel, tap, deformable group), a loop over the group's channels
 template <typename T>
 __global__ __launch_bounds__(256) void k_dcnb_scatter(DcnBwd a) {
@@ -268,6 +315,11 @@ __global__ __launch_bounds__(256) void k_dcnb_bias(DcnBwd a) {        // grad_bi
   if (threadIdx.x == 0) ((T*)a.gbias)[co] = (T)((float)((T*)a.gbias)[co] + red[0]);
 }
 
+int& cfen_dcn_bwd_lds() {   // 1 (default): LDS-privatised col2im; 0: every add a global atomic (A/B, tests)
+  static int v = 1;
+  return v;
+}
+
 unsigned grid_for(long long n) { return (unsigned)std::min<long long>((n + 255) / 256, 16384); }
 
 template <typename T>
@@ -289,7 +341,17 @@ int run_dcn_backward(DcnBwd a, hipStream_t s) {
       CFEN_CHECK_LAUNCH("deform_conv backward (col2im_coord)");
     }
     if (a.gin) {
-      CFEN_LAUNCH(k_dcnb_col2im<T>, dim3(grid_for(a.P * a.kk * a.C)), dim3(256), 0, s, a);
+      // LDS tile: footprint of 16 output pixels per axis + halo R; CH channels as far as 64 KB go
+      const int foot = 15 * std::max(a.sh, a.sw) + (std::max(a.kh, a.kw) - 1) * std::max(a.dh, a.dw) + 2;
+      int R = foot <= 20 ? (32 - foot) / 2 : 4, E = foot + 2 * R, CH = 8;
+      while (CH > 1 && (size_t)E * E * CH * 4 > 64 * 1024) CH /= 2;
+      const int tiles_x = (a.Wo + 15) / 16, tiles_y = (a.Ho + 15) / 16;
+      if (cfen_dcn_bwd_lds() && (size_t)E * E * CH * 4 <= 64 * 1024 && (a.C + CH - 1) / CH <= 65535 && a.B <= 65535) {
+        CFEN_LAUNCH(k_dcnb_col2im_lds<T>, dim3((unsigned)(tiles_x * tiles_y), (unsigned)((a.C + CH - 1) / CH), (unsigned)a.B), dim3(256),
+                    (size_t)E * E * CH * 4, s, a, E, R, CH, tiles_x);
+      } else {
+        CFEN_LAUNCH(k_dcnb_col2im<T>, dim3(grid_for(a.P * a.kk * a.C)), dim3(256), 0, s, a);
+      }
       CFEN_CHECK_LAUNCH("deform_conv backward (col2im)");
       CFEN_LAUNCH(k_dcnb_gin_out<T>, dim3(grid_for(nin)), dim3(256), 0, s, a);
       CFEN_CHECK_LAUNCH("deform_conv backward (grad_input)");
@@ -346,6 +408,12 @@ int dcn_backward(int dtype, DcnBwd a, void* columns, size_t columns_bytes, hipSt
 }  // namespace
 
 extern "C" {
+
+int cfen_deform_conv_backward_set_lds(int enabled) {   // A/B switch of the LDS-privatised col2im (tests, tools/bench_dcn.py); returns the old value
+  const int old = cfen_dcn_bwd_lds();
+  cfen_dcn_bwd_lds() = enabled != 0;
+  return old;
+}
 
 size_t cfen_deform_conv_backward_bytes(int B, int Cin, int H, int W, int Cout, int kH, int kW, int Hout, int Wout, int group) {
   if (B <= 0 || Cin <= 0 || H <= 0 || W <= 0 || Cout <= 0 || kH <= 0 || kW <= 0 || Hout <= 0 || Wout <= 0 || group <= 0 || Cin % group || Cout % group) return 0;
