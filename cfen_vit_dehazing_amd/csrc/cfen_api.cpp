@@ -175,6 +175,10 @@ int cfen_tune(const char* key, int value) {
     cfen_tune_lvit_window() = value != 0;
     return CFEN_OK;
   }
+  if (!strcmp(key, "net.fold_in_gemm")) {
+    cfen_tune_fold_in_gemm() = value != 0;
+    return CFEN_OK;
+  }
   if (!strcmp(key, "net.attn_head_major")) {
     cfen_tune_attn_head_major() = value != 0;
     return CFEN_OK;

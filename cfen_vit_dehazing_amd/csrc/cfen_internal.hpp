@@ -36,9 +36,10 @@ struct CfenGemmPtrs {
   // One K-step of a 96-feature tile is then ONE contiguous 12 KB run of HBM instead of 96 pieces of 128 bytes a whole row apart --
   // what the few-token GViT GEMMs (weights streamed once from HBM, 0.5 GB per forward) are bound by.  k_gemm_dma with 96-feature tiles only.
   int wtile = 0;
+  void* ymap = nullptr;   // fold: Y goes into this NHWC map (geometry = cfen_gemm_impl_g's `yg`), see GemmArgs::ymap
 };
 int cfen_gemm_impl_g(int dtype, int ng, const CfenGemmPtrs* gp, int ldx, int ldw, int ldr, int period, int ldy, int M, int N, int K, int relu,
-                     const CfenTokGather* tg, hipStream_t s, float* const* splitk_ws, size_t splitk_ws_bytes);
+                     const CfenTokGather* tg, hipStream_t s, float* const* splitk_ws, size_t splitk_ws_bytes, const CfenTokGather* yg = nullptr);
 // tg: geometry only, the maps are gp[g].gmap.  splitk_ws (may be null): one fp32 scratch per problem for split-K partial sums
 int cfen_patchify_impl_g(int dtype, int ng, const void* const* fmap, void* const* tok, int B, int H, int W, int C, int cs, int ws, int p, int pool,
                          int inverse, hipStream_t s);
@@ -94,5 +95,6 @@ int& cfen_tune_ln_fold();               // 1: LN1 / LN2 of the blocks without a 
 int& cfen_tune_fused_front_max_dim();   // k_embed_qkv is used for LViT embedding dims <= this (0 = never) ("net.fused_front_max_dim")
 int& cfen_tune_gemm_splitk();     // 1 (default): K-heavy few-token GEMMs run split-K when the caller provides scratch ("gemm.splitk")
 int& cfen_tune_lvit_window();        // 1 (default): LViT level 1 runs as one k_lvit_window launch per instance group ("net.lvit_window")
+int& cfen_tune_fold_in_gemm();      // 1 (default): the last GEMM of an unfused block folds its tokens into the map itself ("net.fold_in_gemm")
 int& cfen_tune_attn_head_major();   // 1 (default): LViT levels with a fused front half hand qkv to attention head-major ("net.attn_head_major")
 int& cfen_tune_embed_lds();        // k_embed_qkv weights through LDS: bit 0 for D = 96, bit 1 for D = 192 ("embed.lds")

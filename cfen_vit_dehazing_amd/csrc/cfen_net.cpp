@@ -39,6 +39,10 @@ int& cfen_tune_lvit_window() {
   static int v = 1;
   return v;
 }
+int& cfen_tune_fold_in_gemm() {   // 1 (default): mlp_head.3's GEMM stores straight into the NHWC map (fold + Join2x2), no unpatchify launch
+  static int v = 1;
+  return v;
+}
 int& cfen_tune_attn_head_major() {
   static int v = 1;
   return v;
@@ -650,12 +654,26 @@ int cfen_net::run_vit_g(int ng, const VitCall* vc, int scr0) {
     // x = mlp_head(x) + x                                                      (v3:1173)
     step("head1");
     TRYP(K_GEMM, 2 * Md * D * Hd, gemm(cX1, ".head1.w", ".head1.b", nullptr, nullptr, HID, v.hidden, v.D, 1, nullptr));
-    step("head2");
-    TRYP(K_GEMM, 2 * Md * D * Hd, gemm(cHID, ".head2.w", ".head2.b", X1, nullptr, X0, v.D, v.hidden, 0, nullptr));
-    step("fold");
     const void* dst[3];
     for (int g = 0; g < ng; ++g) dst[g] = v.global ? SM[g] : OUT[g];
-    TRYP(K_TOKEN, 0, cfen_patchify_impl_g(dt, ng, dst, X0, B, v.mapH, v.mapH, v.C, v.global ? v.C : bo.cs, v.ws, v.p, 1, 1, stream));
+    if (cfen_tune_fold_in_gemm()) {
+      // x = mlp_head(x) + x, folded: the GEMM's epilogue writes feature (i, j, c) of token m to its pixel of the map   (v3:1173, 1186)
+      step("head2_fold");
+      CfenGemmPtrs gp[3];
+      float* ws[3];
+      for (int g = 0; g < ng; ++g) {
+        gp[g] = CfenGemmPtrs{HID[g], P(nm[g] + ".head2.w"), Pf(nm[g] + ".head2.b"), X1[g], nullptr, X0[g], nullptr, nullptr, v.global && wtile,
+                             const_cast<void*>(dst[g])};
+        ws[g] = (float*)YN[g];
+      }
+      const CfenTokGather yg{nullptr, B, v.mapH, v.mapH, v.C, v.global ? v.C : bo.cs, v.ws, v.p};
+      TRYP(K_GEMM, 2 * Md * D * Hd, cfen_gemm_impl_g(dt, ng, gp, v.hidden, v.hidden, v.D, v.S, v.D, M, v.D, v.hidden, 0, nullptr, stream, ws, scratch_stretch, &yg));
+    } else {
+      step("head2");
+      TRYP(K_GEMM, 2 * Md * D * Hd, gemm(cHID, ".head2.w", ".head2.b", X1, nullptr, X0, v.D, v.hidden, 0, nullptr));
+      step("fold");
+      TRYP(K_TOKEN, 0, cfen_patchify_impl_g(dt, ng, dst, X0, B, v.mapH, v.mapH, v.C, v.global ? v.C : bo.cs, v.ws, v.p, 1, 1, stream));
+    }
   }
   step("upsample4");
   if (v.global) TRYP(K_TOKEN, 0, cfen_upsample4_impl_g(dt, ng, cSM, OUT, B, v.mapH, v.mapH, v.C, v.C, bo.cs, stream));

@@ -56,6 +56,9 @@ template <typename T> struct GemmArgs {
   // token m = (image, window, patch), k = (i, j, c) -> pixel (y + i, x + j), channel c.
   const T* gmap;
   int gH, gW, gcs, gC, gws, gp;
+  // optional fold (v3:1186 F.fold + Join2x2): Y is not a token-major matrix but the NHWC map the tokens tile -- feature n = (i, j, c) of
+  // token m is stored at pixel (y + i, x + j), channel c of `ymap` (same geometry fields; never together with the gather)
+  T* ymap;
   // optional split-K (k_gemm_dma only): blockIdx.y = K slice; partial sums go to `part` [nsplit][M][N] fp32 and
   // k_gemm_splitk_finish adds them in slice order and applies the epilogue -- deterministic, no atomics
   float* part;
@@ -67,17 +70,22 @@ template <typename T> struct GemmArgs {
 };
 
 // pointer to channel 0 of the top-left pixel of token m's patch
-template <typename T> CFEN_DEV const T* gather_pix(const GemmArgs<T>& a, int m) {
+template <typename T> CFEN_DEV size_t gather_pixoff(const GemmArgs<T>& a, int m) {
   const int tw = a.gws / a.gp, S = tw * tw, nwx = a.gW / a.gws, nwy = a.gH / a.gws;
   const int t = m % S, wi = m / S;
   const int wx = wi % nwx, wy = (wi / nwx) % nwy, b = wi / (nwx * nwy);
   const int y = wy * a.gws + (t / tw) * a.gp, x = wx * a.gws + (t % tw) * a.gp;
-  return a.gmap + (((size_t)b * a.gH + y) * a.gW + x) * a.gcs;
+  return (((size_t)b * a.gH + y) * a.gW + x) * a.gcs;
 }
+template <typename T> CFEN_DEV const T* gather_pix(const GemmArgs<T>& a, int m) { return a.gmap + gather_pixoff(a, m); }
 // element offset of feature k = (i, j, c) from that pixel
 template <typename T> CFEN_DEV int gather_off(const GemmArgs<T>& a, int k) {
   const int ij = k / a.gC, c = k - ij * a.gC;
   return ((ij / a.gp) * a.gW + (ij % a.gp)) * a.gcs + c;
+}
+// where Y[m][n .. n+3] goes: the token-major row, or (fold) 4 consecutive channels of one pixel of the map
+template <typename T> CFEN_DEV T* out_ptr(const GemmArgs<T>& a, long long m, int n) {
+  return a.ymap ? a.ymap + gather_pixoff(a, (int)m) + gather_off(a, n) : a.Y + (size_t)m * a.ldy + n;
 }
 
 // Epilogue of the 3 x 4 tile block of one wave: the lane owns Y[m + 16 j][n + 16 i .. +3].  All residual / position
@@ -136,7 +144,7 @@ CFEN_DEV void gemm_epilogue(const GemmArgs<T>& a, floatx4 (&acc)[TN][TM], int n,
 #pragma unroll
           for (int r = 0; r < 4; ++r) v[r] += (float)pv[i][r];
         }
-        store4<T>(a.Y + (size_t)mj * a.ldy + n + 16 * i, v);
+        store4<T>(out_ptr(a, mj, n + 16 * i), v);
       }
     }
     return;
@@ -173,7 +181,7 @@ CFEN_DEV void gemm_epilogue(const GemmArgs<T>& a, floatx4 (&acc)[TN][TM], int n,
 #pragma unroll
         for (int r = 0; r < 4; ++r) v[r] += (float)pv[i][j][r];
       }
-      store4<T>(a.Y + (size_t)mj * a.ldy + n + 16 * i, v);
+      store4<T>(out_ptr(a, mj, n + 16 * i), v);
     }
   }
 }
@@ -436,7 +444,7 @@ __global__ __launch_bounds__(256) void k_gemm_splitk_finish(Grouped<GemmArgs<T>>
     }
     if (a.R) v += load4<T>(a.R + (size_t)m * a.ldr + n);
     if (a.P) v += load4<T>(a.P + (size_t)(m % a.period) * a.N + n);
-    store4<T>(a.Y + (size_t)m * a.ldy + n, v);
+    store4<T>(out_ptr(a, m, n), v);
   }
 }
 
@@ -491,14 +499,21 @@ __global__ __launch_bounds__(256) void k_gemm_skinny(Grouped<GemmArgs<T>> ga) {
   }
   if (a.R) v += load4<T>(a.R + (size_t)m * a.ldr + n);
   if (a.P) v += load4<T>(a.P + (size_t)(m % a.period) * a.N + n);
-  store4<T>(a.Y + (size_t)m * a.ldy + n, v);
+  store4<T>(out_ptr(a, m, n), v);
 }
 
 template <typename T>
 int launch_gemm(int ng, const CfenGemmPtrs* gp, int ldx, int ldw, int ldr, int period, int ldy, int M, int N, int K, int relu, hipStream_t s,
-                const CfenTokGather* tg, float* const* splitk_ws, size_t splitk_ws_bytes) {
+                const CfenTokGather* tg, float* const* splitk_ws, size_t splitk_ws_bytes, const CfenTokGather* yg) {
   constexpr int EPL = Mma<T>::EPL;
   CFEN_CHECK_ARG(ng >= 1 && ng <= CFEN_MAX_GROUPS && gp, "gemm: 1..%d problems per launch", CFEN_MAX_GROUPS);
+  if (yg) {   // Y is folded into an NHWC map (gp[g].ymap): token m = (image, window, patch), feature n = (i, j, c)
+    CFEN_CHECK_ARG(yg->C % 4 == 0 && yg->cs % 4 == 0 && yg->cs >= yg->C && yg->p > 0 && yg->ws % yg->p == 0 && yg->H % yg->ws == 0 && yg->W % yg->ws == 0,
+                   "gemm (fold): bad token geometry");
+    CFEN_CHECK_ARG(N == yg->p * yg->p * yg->C, "gemm (fold): needs N == p*p*C");
+    const int tw = yg->ws / yg->p;
+    CFEN_CHECK_ARG(M == yg->B * (yg->H / yg->ws) * (yg->W / yg->ws) * tw * tw, "gemm (fold): M does not match the map");
+  }
   if (tg) {   // X and R are the patch tokens of an NHWC map (gp[g].gmap)
     CFEN_CHECK_ARG(tg->C % EPL == 0 && tg->cs % EPL == 0 && tg->cs >= tg->C && tg->p > 0 && tg->ws % tg->p == 0 && tg->H % tg->ws == 0 &&
                    tg->W % tg->ws == 0, "gemm (gather): bad token geometry");
@@ -531,6 +546,10 @@ int launch_gemm(int ng, const CfenGemmPtrs* gp, int ldx, int ldw, int ldr, int p
     CFEN_CHECK_ARG(q.wtile == gp[0].wtile, "gemm: grouped problems must share the weight layout");
     if (tg) {
       a.gmap = (const T*)q.gmap; a.gH = tg->H; a.gW = tg->W; a.gcs = tg->cs; a.gC = tg->C; a.gws = tg->ws; a.gp = tg->p;
+    }
+    if (yg) {
+      CFEN_CHECK_ARG(!tg && q.ymap && cfen_aligned16(q.ymap), "gemm (fold): needs an aligned output map and no input gather");
+      a.ymap = (T*)q.ymap; a.gH = yg->H; a.gW = yg->W; a.gcs = yg->cs; a.gC = yg->C; a.gws = yg->ws; a.gp = yg->p;
     }
   }
   const bool lnf = gp[0].lnf_s != nullptr;
@@ -644,9 +663,9 @@ int& cfen_tune_gemm_kernel() {
 }
 
 int cfen_gemm_impl_g(int dtype, int ng, const CfenGemmPtrs* gp, int ldx, int ldw, int ldr, int period, int ldy, int M, int N, int K, int relu,
-                     const CfenTokGather* tg, hipStream_t s, float* const* splitk_ws, size_t splitk_ws_bytes) {
-  if (dtype == 1) return launch_gemm<half_t>(ng, gp, ldx, ldw, ldr, period, ldy, M, N, K, relu, s, tg, splitk_ws, splitk_ws_bytes);
-  if (dtype == 0) return launch_gemm<float>(ng, gp, ldx, ldw, ldr, period, ldy, M, N, K, relu, s, tg, splitk_ws, splitk_ws_bytes);
+                     const CfenTokGather* tg, hipStream_t s, float* const* splitk_ws, size_t splitk_ws_bytes, const CfenTokGather* yg) {
+  if (dtype == 1) return launch_gemm<half_t>(ng, gp, ldx, ldw, ldr, period, ldy, M, N, K, relu, s, tg, splitk_ws, splitk_ws_bytes, yg);
+  if (dtype == 0) return launch_gemm<float>(ng, gp, ldx, ldw, ldr, period, ldy, M, N, K, relu, s, tg, splitk_ws, splitk_ws_bytes, yg);
   cfen_set_error("gemm: unknown dtype %d", dtype);
   return CFEN_ERR_ARG;
 }
@@ -654,7 +673,7 @@ int cfen_gemm_impl_g(int dtype, int ng, const CfenGemmPtrs* gp, int ldx, int ldw
 int cfen_gemm_impl(int dtype, const void* X, int ldx, const void* W, int ldw, const float* bias, const void* R, int ldr,
                    const void* P, int period, void* Y, int ldy, int M, int N, int K, int relu, hipStream_t s) {
   const CfenGemmPtrs q{X, W, bias, R, P, Y, nullptr, nullptr};
-  return cfen_gemm_impl_g(dtype, 1, &q, ldx, ldw, ldr, period, ldy, M, N, K, relu, nullptr, s, nullptr, 0);
+  return cfen_gemm_impl_g(dtype, 1, &q, ldx, ldw, ldr, period, ldy, M, N, K, relu, nullptr, s, nullptr, 0, nullptr);
 }
 
 int cfen_embed_gather_impl(int dtype, const CfenTokGather* tg, const void* W, int ldw, const float* bias, const void* P, int period,
@@ -662,5 +681,5 @@ int cfen_embed_gather_impl(int dtype, const CfenTokGather* tg, const void* W, in
   CFEN_CHECK_ARG(tg != nullptr, "embed_gather: null geometry");
   const int D = tg->p * tg->p * tg->C;
   const CfenGemmPtrs q{nullptr, W, bias, nullptr, P, Y, tg->map, nullptr};
-  return cfen_gemm_impl_g(dtype, 1, &q, D, ldw, 0, period, ldy, M, D, D, 0, tg, s, nullptr, 0);
+  return cfen_gemm_impl_g(dtype, 1, &q, D, ldw, 0, period, ldy, M, D, D, 0, tg, s, nullptr, 0, nullptr);
 }
