@@ -86,7 +86,8 @@ def self_check(net, x, outs, cfg, dtype):
     res = {}
     one = net(x[0:1].clone())
     res["image0_vs_batch1_eager"] = max(float((a[0:1] - b).abs().max()) for a, b in zip(outs, one))
-    fix = os.path.join(ROOT, "tests", "golden", "net_full%d_nf%d_hdr%d.npz" % (cfg.image_size, cfg.n_feats, cfg.hidden_dim_ratio))
+    fix = os.path.join(ROOT, "tests", "golden", "net_%sfull%d_nf%d_hdr%d.npz" % ("" if cfg.variant == "v3" else cfg.variant + "_", cfg.image_size,
+                                                                                 cfg.n_feats, cfg.hidden_dim_ratio))
     if os.path.exists(fix):
         z = np.load(fix)
         n = cfg.image_size
@@ -138,6 +139,8 @@ def main():
     ap.add_argument("--dtype", default="fp16", choices=["fp16", "fp32"])
     ap.add_argument("--hidden-dim-ratio", type=int, default=4)
     ap.add_argument("--load-size", type=int, default=256, help="256 -> 512x512 images")
+    ap.add_argument("--variant", default="v3", choices=["v3", "cfs", "crs", "v5"],
+                    help="generator: v3 = iid_hlgvit_crs_gd4_cfs_v3 (BASELINE's); the siblings are informational runs (cfs / crs: the image edge is --load-size)")
     ap.add_argument("--no-graph", action="store_true", help="launch eagerly instead of replaying a hipGraph")
     ap.add_argument("--gather-dtype", default="auto", choices=["auto", "fp16", "fp32"],
                     help="wire type of the output all-gather (N > 1); auto = the compute dtype")
@@ -166,7 +169,7 @@ def main():
     from cfen_vit_dehazing_amd.manifest import generate_state_dict, synthetic_input
     from cfen_vit_dehazing_amd.parallel import OutputGatherer
 
-    cfg = NetConfig(24, args.hidden_dim_ratio, patch_size=args.load_size // 8, load_size=args.load_size)
+    cfg = NetConfig(24, args.hidden_dim_ratio, patch_size=args.load_size // 8, load_size=args.load_size, variant=args.variant)
     B, n = args.batch, cfg.image_size
     net = dec_ipt(cfg, compute_dtype=args.dtype)
     net.load_state_dict(generate_state_dict(cfg, seed=0), strict=True)
@@ -266,8 +269,8 @@ def main():
             "metric": "images/sec @512x512 n_feats=24", "value": round(ips, 2), "unit": "images/sec", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_step, 3), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f16" if args.dtype == "fp16" else "f32", "data": "synthetic",
-            "config": {"workload": "batch=%d/GPU %dx%d n_feats=24 hidden_dim_ratio=%d %s, weights random-init (seeded generator)"
-                                   % (B, n, n, args.hidden_dim_ratio, args.dtype),
+            "config": {"workload": "batch=%d/GPU %dx%d n_feats=24 hidden_dim_ratio=%d %s%s, weights random-init (seeded generator)"
+                                   % (B, n, n, args.hidden_dim_ratio, args.dtype, "" if args.variant == "v3" else " generator variant " + args.variant),
                        "global_batch": world * B, "parallelism": "dp%d" % world, "graph": graphs is not None,
                        "gather_dtype": (gdt if world > 1 else None),
                        "gflop_per_image": round(flops_img / 1e9, 2)},
