@@ -121,3 +121,23 @@ def test_create_model_errors_and_checkpoint_roundtrip(tmp_path):
     opt.model_G = 'iid_cnn_crs'
     m2 = create_model(opt)
     assert not hasattr(m2, 'netG')                                 # reference: silently undefined -> AttributeError later
+
+
+@pytest.mark.parametrize("model_g,variant,nkeys", [("iid_hlgvit_crs_gd4_cfs_v3", "v3", 958), ("iid_hlgvit_crs_gd4_cfs", "cfs", 934),
+                                                   ("iid_hlgvit_crs_gd4", "crs", 950), ("iid_hlgvit_crs_gd4_cfs_v5", "v5", 1078)])
+def test_model_G_selects_the_generator_variant(tmp_path, model_g, variant, nkeys):
+    """models/model_iid_dehazing.py:50-95: --model_G picks the generator; the four built ones give a module with the reference's state_dict
+    (checkpoint round trip incl. the never-read entries: decoder.*, query_embed, sub/add_mean, crs_gd4's SpatialPyramid)"""
+    opt = parse(tmp_path, ['--loadSize', '64', '--patch_size', '8', '--gpu_ids', '-1', '--model_G', model_g])
+    opt.n_feats, opt.hidden_dim_ratio = 8, 2
+    model = create_model(opt)
+    cfg = model.netG.cfg
+    assert cfg.variant == variant and cfg.image_size == (64 if variant in ("cfs", "crs") else 128)
+    sd = generate_state_dict(cfg, seed=5)
+    assert len(sd) == nkeys
+    torch.save(sd, os.path.join(model.save_dir, 'latest_net_G.pth'))
+    model.setup(opt)
+    back = model.netG.state_dict()
+    assert list(back.keys()) == list(sd.keys())
+    for k in sd:
+        assert torch.equal(back[k], sd[k]), k
