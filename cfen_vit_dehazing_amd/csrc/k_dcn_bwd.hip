@@ -51,37 +51,36 @@ inline size_t up256(size_t v) { return (v + 255) / 256 * 256; }
 
 struct DcnBwdLayout { size_t gn, gc, wt, col, gi, gw, total; };
 DcnBwdLayout dcnb_layout(int B, int C, int H, int W, int Cout, int kk, int Ho, int Wo, int group) {
-  const size_t Cg = C / group, Cog = Cout / group, Cogp = (Cog + 3) / 4 * 4, Kg = Cg * kk, Kgp = (Kg + 3) / 4 * 4;
-  const size_t P = (size_t)B * Ho * Wo, Pp = (P + 15) / 16 * 16;
+  const size_t Cg = C / group, Cog = Cout / group, Cogp = (Cog + 3) / 4 * 4, Kgp = (Cg * kk + 3) / 4 * 4;
+  const size_t Pp = ((size_t)B * Ho * Wo + 15) / 16 * 16;
   DcnBwdLayout l;
   size_t o = 0;
   l.gn = o; o += up256(Pp * group * Cogp * 4);
   l.gc = o; o += up256((size_t)Cout * Pp * 4);
   l.wt = o; o += up256((size_t)group * Kgp * Cogp * 4);
   l.col = o; o += up256((size_t)group * Kgp * Pp * 4);
-  (void)P; (void)Kg;
   l.gi = o; o += up256((size_t)B * H * W * C * 4);
-  l.gw = o; o += up256((size_t)group * Cog * Kg * 4);
+  l.gw = o; o += up256((size_t)group * Cog * Cg * kk * 4);
   l.total = o;
   return l;
 }
 
 template <typename T>
-__global__ __launch_bounds__(256) void k_dcnb_prep(DcnBwd a, long long n1, long long n2, long long n3, long long n4) {
+__global__ __launch_bounds__(256) void k_dcnb_prep(DcnBwd a, long long n2, long long n3, long long n4) {
   const long long HWo = (long long)a.Ho * a.Wo;
-  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n1 + n2 + n3 + n4; i += (long long)gridDim.x * 256) {
-    if (i < n1 + n2) {                                       // gn[pix][g][ol] (zero in the padding lanes ol >= Cog and rows pix >= P)
-      const long long j = i - n1;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n2 + n3 + n4; i += (long long)gridDim.x * 256) {
+    if (i < n2) {                                            // gn[pix][g][ol] (zero in the padding lanes ol >= Cog and rows pix >= P)
+      const long long j = i;
       const int ol = (int)(j % a.Cogp), g = (int)((j / a.Cogp) % a.group);
       const long long pix = j / ((long long)a.Cogp * a.group), b = pix / HWo, p = pix % HWo;
       a.gn[j] = (ol < a.Cog && pix < a.P) ? (float)((const T*)a.gout)[(b * a.Cout + g * a.Cog + ol) * HWo + p] : 0.f;
-    } else if (i < n1 + n2 + n3) {                           // gc[co][pix] (zero in the padding columns pix >= P)
-      const long long j = i - n1 - n2, pix = j % a.Pp;
+    } else if (i < n2 + n3) {                                // gc[co][pix] (zero in the padding columns pix >= P)
+      const long long j = i - n2, pix = j % a.Pp;
       const int co = (int)(j / a.Pp);
       const long long b = pix / HWo, p = pix % HWo;
       a.gc[j] = pix < a.P ? (float)((const T*)a.gout)[(b * a.Cout + co) * HWo + p] : 0.f;
     } else {                                                 // wt[g][k = t*Cg + c][ol] = weight[g*Cog + ol][c][t]
-      const long long j = i - n1 - n2 - n3;
+      const long long j = i - n2 - n3;
       const int ol = (int)(j % a.Cogp), k = (int)((j / a.Cogp) % a.Kgp), g = (int)(j / ((long long)a.Cogp * a.Kgp));
       float v = 0.f;
       if (ol < a.Cog && k < a.Kg) {
@@ -324,10 +323,10 @@ unsigned grid_for(long long n) { return (unsigned)std::min<long long>((n + 255) 
 
 template <typename T>
 int run_dcn_backward(DcnBwd a, hipStream_t s) {
-  const bool want_in = a.gin || a.goff || a.gmask, want_par = a.gweight || a.gbias;
+  const bool want_in = a.gin || a.goff || a.gmask;
   const long long nin = (long long)a.B * a.C * a.H * a.W;
-  const long long n1 = 0, n2 = a.Pp * a.group * a.Cogp, n3 = (long long)a.Cout * a.Pp, n4 = (long long)a.group * a.Kgp * a.Cogp;
-  CFEN_LAUNCH(k_dcnb_prep<T>, dim3(grid_for(n1 + n2 + n3 + n4)), dim3(256), 0, s, a, n1, n2, n3, n4);
+  const long long n2 = a.Pp * a.group * a.Cogp, n3 = (long long)a.Cout * a.Pp, n4 = (long long)a.group * a.Kgp * a.Cogp;
+  CFEN_LAUNCH(k_dcnb_prep<T>, dim3(grid_for(n2 + n3 + n4)), dim3(256), 0, s, a, n2, n3, n4);
   CFEN_CHECK_LAUNCH("deform_conv backward (layout pre-pass)");
   if (want_in) {
     if (a.gin && hipMemsetAsync(a.gi, 0, (size_t)nin * 4, s) != hipSuccess) { cfen_set_error("deform_conv backward: memset failed"); return CFEN_ERR_HIP; }
@@ -375,7 +374,6 @@ int run_dcn_backward(DcnBwd a, hipStream_t s) {
     CFEN_LAUNCH(k_dcnb_bias<T>, dim3((unsigned)a.Cout), dim3(256), 0, s, a);
     CFEN_CHECK_LAUNCH("deform_conv backward (grad_bias)");
   }
-  (void)want_par;
   return CFEN_OK;
 }
 
