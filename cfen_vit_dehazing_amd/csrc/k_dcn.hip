@@ -210,6 +210,55 @@ __global__ __launch_bounds__(256) void k_dcn_nhwc(DcnArgs a) {
 
   for (int k0 = 0; k0 < Kg; k0 += KCH) {
     // ---- column tile: colT[pix][kq .. kq + VE) = VE consecutive channels of one tap, sampled (and modulated) ----
+    if (cpdg % VE == 0) {
+      // Fast path (a channel vector never straddles two deformable groups): the thread's two vectors of this K slice are set up
+      // together and branch-free -- both offset pairs (and masks) are loaded, then all eight corner vectors (coordinates clamped,
+      // validity folded into the four bilinear weights), then the interpolation: two memory round trips per slice instead of four.
+      static_assert(NV == 8, "two vectors per thread and slice");
+      float oh[2], ow[2], mm[2];
+      int cim[2], ti[2], tj[2];
+      bool live[2];
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        const int k = k0 + ((tid >> 6) + 4 * u) * VE;
+        live[u] = pvalid && k < Kg;
+        const int ks = live[u] ? k : 0;
+        const int ij = ks / Cg, c0 = ks - ij * Cg;
+        ti[u] = ij / a.kw; tj[u] = ij - ti[u] * a.kw;
+        cim[u] = g * Cg + c0;
+        const int dgi = cim[u] / cpdg;
+        const size_t pp = pvalid ? (size_t)p : 0;
+        const T* op = off + ((size_t)dgi * 2 * kk + 2 * ij) * HWo + pp;
+        oh[u] = (float)op[0]; ow[u] = (float)op[HWo];
+        mm[u] = msk ? (float)msk[((size_t)dgi * kk + ij) * HWo + pp] : 1.f;
+      }
+      float wgt[2][4];
+      frag q[2][4];
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        const float h_im = (float)(h_in + ti[u] * a.dh) + oh[u], w_im = (float)(w_in + tj[u] * a.dw) + ow[u];
+        const bool inside = live[u] && h_im > -1.f && w_im > -1.f && h_im < (float)a.H && w_im < (float)a.W;   // .cu:226-236
+        const int h_low = (int)floorf(h_im), w_low = (int)floorf(w_im), h_high = h_low + 1, w_high = w_low + 1;   // .cu:83-114
+        const float lh = h_im - h_low, lw = w_im - w_low, hh = 1.f - lh, hw = 1.f - lw;
+        const float sc = inside ? mm[u] : 0.f;
+        wgt[u][0] = (h_low >= 0 && w_low >= 0) ? hh * hw * sc : 0.f;
+        wgt[u][1] = (h_low >= 0 && w_high <= a.W - 1) ? hh * lw * sc : 0.f;
+        wgt[u][2] = (h_high <= a.H - 1 && w_low >= 0) ? lh * hw * sc : 0.f;
+        wgt[u][3] = (h_high <= a.H - 1 && w_high <= a.W - 1) ? lh * lw * sc : 0.f;
+        const int yl = min(max(h_low, 0), a.H - 1), yh = min(max(h_high, 0), a.H - 1), xl = min(max(w_low, 0), a.W - 1), xh = min(max(w_high, 0), a.W - 1);
+        const T* base = imT + cim[u];
+        q[u][0] = load_frag<T>(base + ((size_t)yl * a.W + xl) * a.C); q[u][1] = load_frag<T>(base + ((size_t)yl * a.W + xh) * a.C);
+        q[u][2] = load_frag<T>(base + ((size_t)yh * a.W + xl) * a.C); q[u][3] = load_frag<T>(base + ((size_t)yh * a.W + xh) * a.C);
+      }
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        frag o;
+#pragma unroll
+        for (int e = 0; e < VE; ++e)
+          o[e] = (T)((wgt[u][0] * (float)q[u][0][e] + wgt[u][1] * (float)q[u][1][e] + wgt[u][2] * (float)q[u][2][e] + wgt[u][3] * (float)q[u][3][e]));
+        *reinterpret_cast<frag*>(colT + pix * ROWB + ((tid >> 6) + 4 * u) * 16) = o;
+      }
+    } else
     for (int vq = tid >> 6; vq < NV; vq += 4) {
       const int k = k0 + vq * VE;
       float res[VE];
