@@ -214,6 +214,7 @@ __global__ __launch_bounds__(256) void k_chan_stats(const T* __restrict__ x0, co
 #pragma unroll
   for (int e = 0; e < EPL; ++e) { s[e] = 0.f; q[e] = 0.f; m[e] = -3.0e38f; }
   if (my_p < lanes_per_cv) {
+#pragma unroll 4
     for (int p = p0 + my_p; p < p1; p += lanes_per_cv) {
       size_t off = ((size_t)b * HW + p) * cs + my_cv * EPL;
       float v[EPL];
@@ -252,13 +253,24 @@ __global__ __launch_bounds__(256) void k_instnorm_relu(T* __restrict__ x, const 
                                                        long long nvec_per_img) {
   constexpr int EPL = Vec16<T>::N;
   __shared__ float mean_l[256], rstd_l[256];
+  __shared__ double ps_l[256], pq_l[256];
   const int b = blockIdx.y, tid = threadIdx.x;
+  // every block finishes the statistics itself; the 64 partials of a channel are split over 256 / C threads (each a fixed subset, combined in
+  // a fixed order: deterministic) -- one thread per channel walked them as a chain of 64 dependent round trips, ~8 us in front of the pass
+  const int tpc = max(1, 256 / C), sub = tid / C, cc = tid % C;
+  if (sub < tpc) {
+    double s = 0.0, q = 0.0;
+#pragma unroll 4
+    for (int k = sub; k < ST_CHUNKS; k += tpc) {
+      const float* o = part + (((size_t)b * ST_CHUNKS + k) * 3) * C;
+      s += (double)o[cc]; q += (double)o[C + cc];
+    }
+    ps_l[tid] = s; pq_l[tid] = q;
+  }
+  __syncthreads();
   if (tid < C) {
     double s = 0.0, q = 0.0;
-    for (int k = 0; k < ST_CHUNKS; ++k) {
-      const float* o = part + (((size_t)b * ST_CHUNKS + k) * 3) * C;
-      s += (double)o[tid]; q += (double)o[C + tid];
-    }
+    for (int k = 0; k < tpc; ++k) { s += ps_l[k * C + tid]; q += pq_l[k * C + tid]; }
     double mean = s / HW;
     double var = q / HW - mean * mean;
     if (var < 0.0) var = 0.0;
@@ -267,15 +279,31 @@ __global__ __launch_bounds__(256) void k_instnorm_relu(T* __restrict__ x, const 
   }
   __syncthreads();
   const int cv = C / EPL;
-  for (long long idx = (long long)blockIdx.x * 256 + tid; idx < nvec_per_img; idx += (long long)gridDim.x * 256) {
-    int v = (int)(idx % cv);
-    long long p = idx / cv;
-    T* ptr = x + ((size_t)b * HW + p) * cs + v * EPL;
-    float val[EPL];
-    Vec16<T>::load(ptr, val);
+  // four vectors per thread and pass, loads first: in place the compiler must keep a load behind the store before it, so the plain
+  // grid-stride loop was one memory round trip per vector
+  constexpr int U = 4;
+  const long long stride = (long long)gridDim.x * 256;
+  for (long long idx0 = (long long)blockIdx.x * 256 + tid; idx0 < nvec_per_img; idx0 += U * stride) {
+    typename Mma<T>::frag q[U];
+    T* ptr[U];
+    int vv[U];
 #pragma unroll
-    for (int e = 0; e < EPL; ++e) val[e] = fmaxf((val[e] - mean_l[v * EPL + e]) * rstd_l[v * EPL + e], 0.f);
-    Vec16<T>::store(ptr, val);
+    for (int u = 0; u < U; ++u) {
+      const long long idx = idx0 + u * stride;
+      const bool ok = idx < nvec_per_img;
+      const long long id = ok ? idx : idx0;
+      vv[u] = (int)(id % cv);
+      ptr[u] = ok ? x + ((size_t)b * HW + id / cv) * cs + vv[u] * EPL : nullptr;
+      q[u] = load_frag<T>(x + ((size_t)b * HW + id / cv) * cs + vv[u] * EPL);
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      if (!ptr[u]) continue;
+      float val[EPL];
+#pragma unroll
+      for (int e = 0; e < EPL; ++e) val[e] = fmaxf(((float)q[u][e] - mean_l[vv[u] * EPL + e]) * rstd_l[vv[u] * EPL + e], 0.f);
+      Vec16<T>::store(ptr[u], val);
+    }
   }
 }
 
@@ -287,16 +315,27 @@ __global__ __launch_bounds__(256) void k_cfsm_apply(const T* __restrict__ x0, co
                                                     int HW, int C, int cs, long long nvec_per_img) {
   constexpr int EPL = Vec16<T>::N;
   __shared__ float avg_l[128], max_l[128], hid[4][32], g_l[2][128];
+  __shared__ double ps_l[256];
+  __shared__ float pm_l[256];
   const int b = blockIdx.y, tid = threadIdx.x;
   const int bk = C / 4;
+  const int tpc = max(1, 256 / C), sub = tid / C, cc = tid % C;      // partials of a channel split over 256 / C threads (see k_instnorm_relu)
+  if (sub < tpc) {
+    double s = 0.0;
+    float m = -3.0e38f;
+#pragma unroll 4
+    for (int k = sub; k < ST_CHUNKS; k += tpc) {
+      const float* o = part + (((size_t)b * ST_CHUNKS + k) * 3) * C;
+      s += (double)o[cc];
+      m = fmaxf(m, o[2 * C + cc]);
+    }
+    ps_l[tid] = s; pm_l[tid] = m;
+  }
+  __syncthreads();
   if (tid < C) {
     double s = 0.0;
     float m = -3.0e38f;
-    for (int k = 0; k < ST_CHUNKS; ++k) {
-      const float* o = part + (((size_t)b * ST_CHUNKS + k) * 3) * C;
-      s += (double)o[tid];
-      m = fmaxf(m, o[2 * C + tid]);
-    }
+    for (int k = 0; k < tpc; ++k) { s += ps_l[k * C + tid]; m = fmaxf(m, pm_l[k * C + tid]); }
     avg_l[tid] = (float)(s / HW);
     max_l[tid] = m;
   }
@@ -308,6 +347,7 @@ __global__ __launch_bounds__(256) void k_cfsm_apply(const T* __restrict__ x0, co
     const float* W0 = w + f * per;
     const float* in = (f < 2) ? avg_l : max_l;
     float a = 0.f;
+#pragma unroll 8
     for (int c = 0; c < C; ++c) a += W0[j * C + c] * in[c];
     hid[f][j] = fmaxf(a, 0.f);
   }
@@ -322,17 +362,30 @@ __global__ __launch_bounds__(256) void k_cfsm_apply(const T* __restrict__ x0, co
   }
   __syncthreads();
   const int cv = C / EPL;
-  for (long long idx = (long long)blockIdx.x * 256 + tid; idx < nvec_per_img; idx += (long long)gridDim.x * 256) {
-    int v = (int)(idx % cv);
-    long long p = idx / cv;
-    size_t off = ((size_t)b * HW + p) * cs + v * EPL;
-    float a0[EPL], a1[EPL], a2[EPL];
-    Vec16<T>::load(x0 + off, a0);
-    Vec16<T>::load(x1 + off, a1);
-    Vec16<T>::load(x2 + off, a2);
+  constexpr int U = 2;      // two pixels' vectors per thread and pass: six loads in flight
+  const long long stride = (long long)gridDim.x * 256;
+  for (long long idx0 = (long long)blockIdx.x * 256 + tid; idx0 < nvec_per_img; idx0 += U * stride) {
+    typename Mma<T>::frag q0[U], q1[U], q2[U];
+    size_t off[U];
+    int vv[U];
+    bool ok[U];
 #pragma unroll
-    for (int e = 0; e < EPL; ++e) a0[e] = a0[e] + a1[e] * g_l[0][v * EPL + e] + a2[e] * g_l[1][v * EPL + e];
-    Vec16<T>::store(out + off, a0);
+    for (int u = 0; u < U; ++u) {
+      const long long idx = idx0 + u * stride;
+      ok[u] = idx < nvec_per_img;
+      const long long id = ok[u] ? idx : idx0;
+      vv[u] = (int)(id % cv);
+      off[u] = ((size_t)b * HW + id / cv) * cs + vv[u] * EPL;
+      q0[u] = load_frag<T>(x0 + off[u]); q1[u] = load_frag<T>(x1 + off[u]); q2[u] = load_frag<T>(x2 + off[u]);
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      if (!ok[u]) continue;
+      float a0[EPL];
+#pragma unroll
+      for (int e = 0; e < EPL; ++e) a0[e] = (float)q0[u][e] + (float)q1[u][e] * g_l[0][vv[u] * EPL + e] + (float)q2[u][e] * g_l[1][vv[u] * EPL + e];
+      Vec16<T>::store(out + off[u], a0);
+    }
   }
 }
 
