@@ -431,3 +431,19 @@ def test_v5_reference_init_actnorm_first_window_on_the_device():
     for a, b in zip(outs, net(x)):
         assert torch.equal(a, b)
     print("%s fp32 with device ActNorm init (windowed for the in-LViT layers): outputs max-abs vs reference %.2e" % (name, worst))
+
+
+def test_tile_major_gvit_weights_equal_row_major_to_rounding():
+    """packing.pack_wtile (default, CFEN_WTILE): one K-step of a 96-feature GViT weight tile is one contiguous run; the <= 128-token GEMMs then
+    run on k_gemm_dma instead of k_gemm_skinny (another order of the K sum), so the two layouts agree to rounding, not bitwise"""
+    cfg, batch, z = load_net_fixture("small_nf24_hdr4")
+    sd = generate_state_dict(cfg, seed=0)
+    x = synthetic_input(batch, cfg).to("cuda:0")
+    outs = {}
+    for wt in (True, False):
+        net = dec_ipt(cfg, compute_dtype="fp32")
+        net.wtile = wt
+        net.load_state_dict(sd, strict=True)
+        outs[wt] = [o.clone() for o in net.to("cuda:0")(x)]
+        check_outputs(z, outs[wt], 1e-4)
+    assert max(float((a - b).abs().max()) for a, b in zip(outs[True], outs[False])) <= 2e-5
