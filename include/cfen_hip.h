@@ -259,8 +259,9 @@ int cfen_modulated_deform_conv_forward(int dtype, const void* input, const void*
  * grad_input is summed with fp32 atomics like the reference's col2im (dcn/src/deform_conv_cuda_kernel.cu:322): reproducible up to
  * summation order. */
 size_t cfen_deform_conv_backward_bytes(int B, int Cin, int H, int W, int Cout, int kH, int kW, int Hout, int Wout, int group);
-/* col2im variant switch (process-wide, for A/B runs and tests): 1 (default) accumulates grad_input per 16 x 16 output-pixel tile in LDS and
- * flushes once, 0 sends every add to global memory as the reference does; returns the previous setting */
+/* col2im variant switch (process-wide, for A/B runs and tests): 1 (default) accumulates grad_input per 16 x 16 output-pixel tile in LDS, parks
+ * each tile's footprint in `columns` and sums the overlapping footprints per input pixel in a fixed order; 2 flushes the tiles with global
+ * atomics instead; 0 sends every add to global memory as the reference does; returns the previous setting */
 int cfen_deform_conv_backward_set_lds(int enabled);
 /* deform_conv_backward_input_cuda (dcn/src/deform_conv_cuda.cpp:260-265): W before H, as in the forward */
 int cfen_deform_conv_backward_input(int dtype, const void* input, const void* offset, const void* gradOutput, void* gradInput, void* gradOffset,

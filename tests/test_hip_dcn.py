@@ -158,15 +158,16 @@ def test_deform_conv_pack_trains_one_sgd_step_like_conv2d_at_init():
 
 @pytest.mark.parametrize("off_scale", [1.0, 12.0])
 def test_deform_conv_backward_lds_col2im_equals_global_atomics(off_scale):
-    """grad_input through the LDS-privatised col2im (default) and through plain global atomics, small offsets (all inside the tile halo)
-    and offsets far beyond it (the per-add fallback to global memory), 40 x 36 pixels so that tiles are ragged; both against the oracle"""
+    """grad_input through the LDS-privatised col2im with parked tiles (1, default), with tiles flushed by global atomics (2) and through
+    plain global atomics (0); small offsets (all inside the tile halo) and offsets far beyond it (the per-add fallback to global memory),
+    40 x 36 pixels so that tiles are ragged; all against the oracle"""
     from cfen_vit_dehazing_amd import _lib
     x, w = rnd((2, 12, 40, 36), 1), rnd((12, 12, 3, 3), 2, 0.15)
     off, gy = rnd((2, 36, 40, 36), 3, off_scale), rnd((2, 12, 40, 36), 4)
     want = dcn_oracle.deform_conv_backward(x, off, w, gy, 1, 1, 1, 1, 2)
     lib = _lib.load()
     got = {}
-    for lds in (1, 0):
+    for lds in (1, 2, 0):
         old = lib.cfen_deform_conv_backward_set_lds(lds)
         try:
             xi = x.to(DEV).requires_grad_()
@@ -175,4 +176,5 @@ def test_deform_conv_backward_lds_col2im_equals_global_atomics(off_scale):
         finally:
             lib.cfen_deform_conv_backward_set_lds(old)
         _grad_close(got[lds], want["input"], torch.float32, "grad_input (lds=%d)" % lds)
-    assert float((got[1] - got[0]).abs().max()) <= 1e-4 * max(1.0, float(want["input"].abs().max()))
+    for lds in (1, 2):
+        assert float((got[lds] - got[0]).abs().max()) <= 1e-4 * max(1.0, float(want["input"].abs().max()))

@@ -22,6 +22,7 @@ def main():
     ap.add_argument("--reps", type=int, default=30)
     ap.add_argument("--check", action="store_true")
     ap.add_argument("--backward", action="store_true", help="time the backward of each case (all gradients) instead of the forward")
+    ap.add_argument("--channels", type=int, default=0, help="only the case with this many channels (24, 48 or 96); 0 = all three")
     args = ap.parse_args()
     dt = torch.float16 if args.dtype == "fp16" else torch.float32
     esz = 2 if dt == torch.float16 else 4
@@ -32,6 +33,8 @@ def main():
         import dcn_oracle
     flush = torch.empty(300 * 1024 * 1024, dtype=torch.uint8, device=dev)       # > Infinity Cache: every timed launch starts cold
     for C, H in ((24, 256), (48, 128), (96, 64)):
+        if args.channels and C != args.channels:
+            continue
         for dg in (1, 8):
             g = torch.Generator().manual_seed(C * 10 + dg)
             x = torch.randn(B, C, H, H, generator=g).to(dt).to(dev)

@@ -14,6 +14,7 @@ for w in $what; do
     launches) timeout 600 python3 tools/profile_launches.py 8 fp16 > $out/launches.txt 2>&1; echo "launches rc=$?"; tail -45 $out/launches.txt;;
     dcn) timeout 600 python3 tools/bench_dcn.py --check > $out/dcn.jsonl 2>&1; echo "dcn rc=$?"; cat $out/dcn.jsonl | cut -c1-300;;
     dcnbwd) timeout 600 python3 tools/bench_dcn.py --backward --reps 10 > $out/dcn_bwd.jsonl 2>&1; echo "dcnbwd rc=$?"; cat $out/dcn_bwd.jsonl | cut -c1-300;;
+    dcnbwd_stats) (cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/$out/dcnbwd_stats -- python3 $GRAFT_REPO_ROOT/tools/bench_dcn.py --backward --reps 5 --channels 24 > $GRAFT_REPO_ROOT/$out/dcnbwd_stats.jsonl 2> $GRAFT_REPO_ROOT/$out/dcnbwd_stats.err); echo "dcnbwd_stats rc=$?"; f=$(find $out/dcnbwd_stats -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && head -14 $f | cut -c1-200;;
     stats) (cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/$out/stats -- python3 $GRAFT_REPO_ROOT/bench.py --steps 20 --warmup 3 --no-cpu-baseline --min-seconds 0 > $GRAFT_REPO_ROOT/$out/stats_bench.json 2> $GRAFT_REPO_ROOT/$out/stats.err); echo "stats rc=$?";;
     sq) (cd /tmp && timeout 900 rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT SQ_INSTS_VALU --output-format csv -d $GRAFT_REPO_ROOT/$out/pmc_sq -- python3 $GRAFT_REPO_ROOT/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-graph --min-seconds 0 > $GRAFT_REPO_ROOT/$out/pmc_sq.json 2> $GRAFT_REPO_ROOT/$out/pmc_sq.err); echo "pmc sq rc=$?";;
     probe) /opt/rocm/bin/hipcc --offload-arch=gfx950 -O2 -o /tmp/lds_probe tools/repro/lds_graph_probe.hip > /dev/null 2>&1; timeout 120 /tmp/lds_probe > $out/lds_probe.txt 2>&1; cat $out/lds_probe.txt;;
