@@ -14,24 +14,48 @@
 // pixels per channel across lanes.
 #include "cfen_common.hpp"
 #include "cfen_conv.hpp"
+#include "cfen_internal.hpp"
 
 namespace {
 
-template <typename T, int TN, int TM>
-__global__ __launch_bounds__(256) void k_conv(Grouped<ConvDesc> dg) {
+// bytes per LDS weight row: = 32 (mod 64), the pitch k_mlp2 measured conflict-free for 16-byte fragment reads (row r16, piece h)
+template <typename T>
+__host__ __device__ inline int conv_wl_pitch(int Kpad) {
+  const int row = Kpad * (int)sizeof(T), m = row & 63;
+  return row + (m <= 32 ? 32 - m : 96 - m);
+}
+
+// WL: the phase's whole weight matrix is staged in LDS once per workgroup (NW waves) and the A fragments come from there.  Without it
+// every wave streams all Cout_pad x Kpad weights through the vector cache for its TM x 16 pixels: 83 KB per wave in ds_conv_e03 -- more
+// than the L1 holds, so 2048 waves pull 176 MB out of L2 for a convolution whose maps are 19 MB (ds_conv_e03 36 -> 23 us, the gather-conv
+// class 0.98 -> 0.93 ms).  Tried on top and dropped: K split over the four waves of a workgroup (the chain of dependent round trips is NOT
+// what bounds these kernels: ds_conv_e03 36.7 -> 35.3 us, lgcat_conv_d03 44.6 -> 52.2) and, with the weights in LDS, the pixel vectors
+// fetched branch-free two chunks ahead (small maps +-0, lgcat_conv_d01 99.7 -> 117.5 us).
+template <typename T, int TN, int TM, bool WL = false, int NW = 4>
+__global__ __launch_bounds__(NW * 64) void k_conv(Grouped<ConvDesc> dg) {
   const ConvDesc& d = dg.g[blockIdx.z];
   constexpr int KC = Mma<T>::KC, EPL = Mma<T>::EPL;
   typedef typename Mma<T>::frag frag;
   __shared__ int taps_l[CFEN_MAX_TAPS];
+  extern __shared__ __attribute__((aligned(16))) unsigned char wl[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r16 = lane & 15, h = lane >> 4;
   const int phase = blockIdx.y;
   if (tid < d.ntaps) {
     ConvTap t = d.taps[phase * d.ntaps + tid];
     taps_l[tid] = ((int)(unsigned char)t.src << 16) | ((int)(unsigned char)t.dy << 8) | (int)(unsigned char)t.dx;
   }
+  const int wpitch = conv_wl_pitch<T>(d.Kpad);
+  if (WL) {
+    const int vpr = d.Kpad * (int)sizeof(T) / 16;   // 16-byte pieces per weight row
+    const unsigned char* wsrc = (const unsigned char*)d.weight + (size_t)phase * d.Cout_pad * d.Kpad * sizeof(T);
+    for (int i = tid; i < d.Cout_pad * vpr; i += NW * 64) {
+      const int row = i / vpr, pc = i - row * vpr;
+      *reinterpret_cast<uint4*>(wl + row * wpitch + pc * 16) = *reinterpret_cast<const uint4*>(wsrc + (size_t)i * 16);
+    }
+  }
   __syncthreads();
   const long long total = (long long)d.B * d.Hb * d.Wb;
-  const long long q_wave = ((long long)xcd_chunked_block(blockIdx.x, gridDim.x) * 4 + wave) * (TM * 16);
+  const long long q_wave = ((long long)xcd_chunked_block(blockIdx.x, gridDim.x) * NW + wave) * (TM * 16);
   if (q_wave >= total) return;
 
   int pb[TM], py[TM], px[TM];
@@ -79,7 +103,9 @@ __global__ __launch_bounds__(256) void k_conv(Grouped<ConvDesc> dg) {
     }
     frag af[TN];
 #pragma unroll
-    for (int i = 0; i < TN; ++i) af[i] = load_frag<T>(wbase + (size_t)i * 16 * d.Kpad + kc * KC);
+    for (int i = 0; i < TN; ++i)
+      af[i] = WL ? *reinterpret_cast<const frag*>(wl + (i * 16 + r16) * wpitch + (kc * KC + h * EPL) * (int)sizeof(T))
+                 : load_frag<T>(wbase + (size_t)i * 16 * d.Kpad + kc * KC);
 #pragma unroll
     for (int i = 0; i < TN; ++i)
 #pragma unroll
@@ -135,6 +161,28 @@ int launch_conv_t(int ng, const ConvDesc* dp, hipStream_t s) {
   return CFEN_OK;
 }
 
+template <typename T, int TN, int TM, int NW>
+int launch_conv_wl_t(int ng, const ConvDesc* dp, hipStream_t s) {
+  const ConvDesc& d = dp[0];
+  Grouped<ConvDesc> dg;
+  for (int g = 0; g < CFEN_MAX_GROUPS; ++g) dg.g[g] = dp[g < ng ? g : 0];
+  const long long total = (long long)d.B * d.Hb * d.Wb;
+  const long long per_block = (long long)NW * TM * 16;
+  const size_t smem = (size_t)d.Cout_pad * conv_wl_pitch<T>(d.Kpad);
+  static bool attr_set = false;
+  if (!attr_set) {
+    if (hipFuncSetAttribute((const void*)k_conv<T, TN, TM, true, NW>, hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024) != hipSuccess) {
+      cfen_set_error("conv: cannot reserve LDS for the staged weights");
+      return CFEN_ERR_HIP;
+    }
+    attr_set = true;
+  }
+  dim3 grid(cfen_grid8((total + per_block - 1) / per_block), d.nphase, ng);
+  CFEN_LAUNCH((k_conv<T, TN, TM, true, NW>), grid, dim3(NW * 64), smem, s, dg);
+  CFEN_CHECK_LAUNCH("conv");
+  return CFEN_OK;
+}
+
 template <typename T>
 int check_conv(const ConvDesc& d) {
   constexpr int KC = Mma<T>::KC, EPL = Mma<T>::EPL;
@@ -165,6 +213,17 @@ int check_conv(const ConvDesc& d) {
   return CFEN_OK;
 }
 
+}  // namespace
+int& cfen_tune_conv_wlds() {
+  static int v = 2;
+  return v;
+}
+int& cfen_tune_conv_wlds_maxlog() {   // staged weights only for launches below 2^this pixels
+  static int v = 40;
+  return v;
+}
+namespace {
+
 template <typename T>
 int launch_conv(int ng, const ConvDesc* dp, hipStream_t s) {
   CFEN_CHECK_ARG(ng >= 1 && ng <= CFEN_MAX_GROUPS && dp, "conv: 1..%d problems per launch", CFEN_MAX_GROUPS);
@@ -180,6 +239,24 @@ int launch_conv(int ng, const ConvDesc* dp, hipStream_t s) {
   // latency is the number of waves in flight: shrink TM until the launch has a few thousand waves (tools/profile_launches.py).
   const long long px = (long long)ng * d.B * d.Hb * d.Wb * d.nphase;
   const int shrink = px >= (1 << 20) ? 0 : px >= (1 << 18) ? 1 : 2;   // halve TM once / twice for small maps
+  // weights staged in LDS (conv.wlds: 0 never, 1 where the matrix fits 60 KB with 4-wave workgroups, 2 also up to 150 KB with 8 waves)
+  const int wlm = cfen_tune_conv_wlds();
+  const size_t wbytes = (size_t)d.Cout_pad * conv_wl_pitch<T>(d.Kpad);
+  if (wlm > 0 && wbytes <= 60 * 1024 && px < (1ll << cfen_tune_conv_wlds_maxlog())) {
+    switch (d.Cout_pad / 16) {
+      case 2: return shrink >= 2 ? launch_conv_wl_t<T, 2, 1, 4>(ng, dp, s) : launch_conv_wl_t<T, 2, 2, 4>(ng, dp, s);
+      case 3: return shrink >= 2 ? launch_conv_wl_t<T, 3, 1, 4>(ng, dp, s) : launch_conv_wl_t<T, 3, 2, 4>(ng, dp, s);
+      case 4: return launch_conv_wl_t<T, 4, 1, 4>(ng, dp, s);
+      case 6: return launch_conv_wl_t<T, 6, 1, 4>(ng, dp, s);
+      default: break;
+    }
+  } else if (wlm > 1 && wbytes <= 150 * 1024 && px < (1ll << cfen_tune_conv_wlds_maxlog())) {
+    switch (d.Cout_pad / 16) {
+      case 4: return launch_conv_wl_t<T, 4, 1, 8>(ng, dp, s);
+      case 6: return launch_conv_wl_t<T, 6, 1, 8>(ng, dp, s);
+      default: break;
+    }
+  }
   switch (d.Cout_pad / 16) {
     case 1: return launch_conv_t<T, 1, 2>(ng, dp, s);
     case 2: return shrink >= 2 ? launch_conv_t<T, 2, 1>(ng, dp, s) : launch_conv_t<T, 2, 2>(ng, dp, s);
