@@ -242,16 +242,13 @@ int launch_conv(int ng, const ConvDesc* dp, hipStream_t s) {
   // weights staged in LDS (conv.wlds: 0 never, 1 where the matrix fits 60 KB with 4-wave workgroups, 2 also up to 150 KB with 8 waves)
   const int wlm = cfen_tune_conv_wlds();
   const size_t wbytes = (size_t)d.Cout_pad * conv_wl_pitch<T>(d.Kpad);
-  if (wlm > 0 && wbytes <= 60 * 1024 && px < (1ll << cfen_tune_conv_wlds_maxlog())) {
+  // workgroup shape (MI355X, batch 8, per-launch times): 96 / 64 output channels and weight matrices >= 16 KB run 8 waves per staged copy
+  // (lgcat_conv_d03 41.7 -> 28.0 us, ds_conv_e02 24.6 -> 20.2), the small 1x1 matrices stay on 4-wave workgroups (lgcat_conv_d02 +4 us with 8)
+  if (wlm > 0 && wbytes <= (wlm > 1 ? 150 : 60) * 1024 && px < (1ll << cfen_tune_conv_wlds_maxlog())) {
+    const bool fat = wbytes >= 16 * 1024;
     switch (d.Cout_pad / 16) {
-      case 2: return shrink >= 2 ? launch_conv_wl_t<T, 2, 1, 4>(ng, dp, s) : launch_conv_wl_t<T, 2, 2, 4>(ng, dp, s);
-      case 3: return shrink >= 2 ? launch_conv_wl_t<T, 3, 1, 4>(ng, dp, s) : launch_conv_wl_t<T, 3, 2, 4>(ng, dp, s);
-      case 4: return launch_conv_wl_t<T, 4, 1, 4>(ng, dp, s);
-      case 6: return launch_conv_wl_t<T, 6, 1, 4>(ng, dp, s);
-      default: break;
-    }
-  } else if (wlm > 1 && wbytes <= 150 * 1024 && px < (1ll << cfen_tune_conv_wlds_maxlog())) {
-    switch (d.Cout_pad / 16) {
+      case 2: return fat ? launch_conv_wl_t<T, 2, 2, 8>(ng, dp, s) : shrink >= 2 ? launch_conv_wl_t<T, 2, 1, 4>(ng, dp, s) : launch_conv_wl_t<T, 2, 2, 4>(ng, dp, s);
+      case 3: return fat ? launch_conv_wl_t<T, 3, 2, 8>(ng, dp, s) : shrink >= 2 ? launch_conv_wl_t<T, 3, 1, 4>(ng, dp, s) : launch_conv_wl_t<T, 3, 2, 4>(ng, dp, s);
       case 4: return launch_conv_wl_t<T, 4, 1, 8>(ng, dp, s);
       case 6: return launch_conv_wl_t<T, 6, 1, 8>(ng, dp, s);
       default: break;
