@@ -176,6 +176,7 @@ __global__ __launch_bounds__(256) void k_dcnb_col2im_lds(DcnBwd a, int E, int R,
   const long long p = (long long)ho * a.Wo + wo, pix = (long long)b * HWo + p;
   // ---- pass 0: bound of |mask * column gradient| over the workgroup
   float vmax = 0.f;
+  bool bad = false;
   if (live) {
     for (int t = 0; t < a.kk; ++t) {
       const float m = a.mask ? fabsf((float)((const T*)a.mask)[(((long long)b * a.dg + dgi) * a.kk + t) * HWo + p]) : 1.f;
@@ -186,15 +187,20 @@ __global__ __launch_bounds__(256) void k_dcnb_col2im_lds(DcnBwd a, int E, int R,
         gl[cl0] = a.col[((long long)g * a.Kgp + t * a.Cg + cl) * a.Pp + pix];
       }
 #pragma unroll
-      for (int cl0 = 0; cl0 < DB_CH; ++cl0) gm = fmaxf(gm, fabsf(gl[cl0]));
+      for (int cl0 = 0; cl0 < DB_CH; ++cl0) {
+        gm = fmaxf(gm, fabsf(gl[cl0]));
+        bad |= !(fabsf(gl[cl0]) <= 3.0e38f);               // inf or nan (fmaxf drops a nan)
+      }
+      bad |= !(m <= 3.0e38f);
       vmax = fmaxf(vmax, gm * m);
     }
   }
+  if (bad) vmax = __builtin_inff();
   for (int o = 32; o > 0; o >>= 1) vmax = fmaxf(vmax, __shfl_xor(vmax, o));
   if ((tid & 63) == 0) red[tid >> 6] = vmax;
   __syncthreads();
   vmax = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
-  const bool finite = vmax > 0.f && vmax <= 3.0e38f;          // all-zero gradients: nothing to add; inf / nan: poison the tile below
+  const bool finite = vmax > 0.f && vmax <= 3.0e38f;          // all-zero gradients: nothing to add; a non-finite one: the tile is poisoned below
   const int e = finite ? 48 - __builtin_amdgcn_frexp_expf(vmax) : 0;
   if (live && finite) {
     for (int t = 0; t < a.kk; ++t) {
@@ -234,7 +240,7 @@ __global__ __launch_bounds__(256) void k_dcnb_col2im_lds(DcnBwd a, int E, int R,
     }
   }
   __syncthreads();
-  const float poison = (vmax > 0.f && !finite) || vmax != vmax ? vmax - vmax : 0.f;     // inf - inf = nan; 0 otherwise
+  const float poison = vmax > 3.0e38f ? vmax - vmax : 0.f;     // inf - inf = nan: a non-finite gradient makes the whole tile nan, never a finite number
   if (park) {
     float* dst = a.gt + (((long long)b * gridDim.x + blockIdx.x) * a.C + c0) * (E * E);
     for (int i = tid; i < E * E * nch; i += 256) dst[i] = __builtin_ldexpf((float)(long long)tile[i], -e) + poison;

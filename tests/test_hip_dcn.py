@@ -178,3 +178,29 @@ def test_deform_conv_backward_lds_col2im_equals_global_atomics(off_scale):
         _grad_close(got[lds], want["input"], torch.float32, "grad_input (lds=%d)" % lds)
     for lds in (1, 2):
         assert float((got[lds] - got[0]).abs().max()) <= 1e-4 * max(1.0, float(want["input"].abs().max()))
+
+
+def test_deform_conv_backward_fixed_point_col2im_edge_cases():
+    """k_dcnb_col2im_lds accumulates in 64-bit fixed point scaled by the workgroup's largest contribution: the result must not depend on
+    the magnitude of the gradients (power-of-two scalings are exact, so grad_input scales BITWISE), an all-zero grad_output gives exact zeros,
+    run-to-run results are bit-identical (the adds are order-independent; offsets stay inside the tile halo so no global atomics are
+    involved), and a non-finite grad_output is not laundered into finite numbers."""
+    x, w = rnd((2, 16, 24, 20), 1), rnd((8, 16, 3, 3), 2, 0.1)
+    off, gy = rnd((2, 18, 24, 20), 3, 1.0), rnd((2, 8, 24, 20), 4)
+
+    def grad_in(g):
+        xi = x.to(DEV).requires_grad_()
+        dcn.deform_conv(xi, off.to(DEV), w.to(DEV), 1, 1, 1, 1, 1).backward(g.to(DEV))
+        return xi.grad.cpu()
+
+    base = grad_in(gy)
+    _grad_close(base, dcn_oracle.deform_conv_backward(x, off, w, gy, 1, 1, 1, 1, 1)["input"], torch.float32, "grad_input")
+    assert torch.equal(grad_in(gy), base)                                        # deterministic
+    for k in (-60, -20, 20, 60):
+        assert torch.equal(grad_in(gy * 2.0 ** k), base * 2.0 ** k), "scale 2^%d" % k
+    assert torch.equal(grad_in(torch.zeros_like(gy)), torch.zeros_like(base))
+    for poison in (float("inf"), float("nan")):
+        bad = gy.clone()
+        bad[1, 3, 10, 7] = poison
+        g = grad_in(bad)
+        assert not bool(torch.isfinite(g[1]).all()) and bool(torch.isfinite(g[0]).all())
