@@ -96,7 +96,8 @@ template <typename T, int TM, int TN = 3>
 CFEN_DEV void gemm_lnfold(const GemmArgs<T>& a, floatx4 (&acc)[TN][TM], int n, const float* stats, int mloc) {
 #pragma unroll
   for (int i = 0; i < TN; ++i) {
-    const floatx4 sn = n + 16 * i < a.N ? *reinterpret_cast<const floatx4*>(a.lnf_s + n + 16 * i) : floatx4{0.f, 0.f, 0.f, 0.f};
+    const floatx4 sl = *reinterpret_cast<const floatx4*>(a.lnf_s + (n + 16 * i < a.N ? n + 16 * i : 0));   // unconditional (clamped), see gemm_epilogue
+    const floatx4 sn = n + 16 * i < a.N ? sl : floatx4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int j = 0; j < TM; ++j) {
       const float mean = stats[2 * (mloc + 16 * j)], rstd = stats[2 * (mloc + 16 * j) + 1];
@@ -108,12 +109,22 @@ CFEN_DEV void gemm_lnfold(const GemmArgs<T>& a, floatx4 (&acc)[TN][TM], int n, c
 template <typename T, int TM, int TN = 3>
 CFEN_DEV void gemm_epilogue(const GemmArgs<T>& a, floatx4 (&acc)[TN][TM], int n, int m) {
   typedef typename Mma<T>::out4 out4;
+  // Every load below is UNCONDITIONAL per lane, at an address clamped into the operand, inside wave-uniform `if`s; validity is applied when the
+  // value is used.  `ok ? load : 0` (and a residual taken from one of two sources by a per-lane select) makes hipcc merge the loaded register
+  // with the alternative right after the load: an exec-masked branch and an s_waitcnt vmcnt(0) per load -- the epilogue of the few-token GEMMs
+  // was 6-8 serial memory round trips in a kernel of 7-15 us.
   floatx4 bias[TN];
   bool nok[TN];
+  int nc[TN];
 #pragma unroll
   for (int i = 0; i < TN; ++i) {
     nok[i] = n + 16 * i < a.N;
-    bias[i] = (a.bias && nok[i]) ? *reinterpret_cast<const floatx4*>(a.bias + n + 16 * i) : floatx4{0.f, 0.f, 0.f, 0.f};
+    nc[i] = nok[i] ? n + 16 * i : 0;
+    bias[i] = floatx4{0.f, 0.f, 0.f, 0.f};
+  }
+  if (a.bias) {
+#pragma unroll
+    for (int i = 0; i < TN; ++i) bias[i] = *reinterpret_cast<const floatx4*>(a.bias + nc[i]);
   }
   if constexpr (TN > 3) {
     // big wave tiles (96 accumulator registers): one token column at a time, so only TN residual vectors are live beside the accumulators
@@ -150,24 +161,34 @@ CFEN_DEV void gemm_epilogue(const GemmArgs<T>& a, floatx4 (&acc)[TN][TM], int n,
     return;
   }
   out4 rv[TN][TM], pv[TN][TM];
+  if (a.gmap) {
 #pragma unroll
-  for (int j = 0; j < TM; ++j) {
-    const int mj = m + 16 * j;
+    for (int j = 0; j < TM; ++j) {
+      const T* px = gather_pix(a, min(m + 16 * j, a.M - 1));
 #pragma unroll
-    for (int i = 0; i < TN; ++i) {
-      const bool ok = nok[i] && mj < a.M;
-      if (a.gmap && ok) rv[i][j] = *reinterpret_cast<const out4*>(gather_pix(a, mj) + gather_off(a, n + 16 * i));
-      else if (a.R && ok) rv[i][j] = *reinterpret_cast<const out4*>(a.R + (size_t)mj * a.ldr + n + 16 * i);
-      if (a.P && ok) pv[i][j] = *reinterpret_cast<const out4*>(a.P + (size_t)(mj % a.period) * a.N + n + 16 * i);
+      for (int i = 0; i < TN; ++i) rv[i][j] = *reinterpret_cast<const out4*>(px + gather_off(a, nc[i]));
+    }
+  } else if (a.R) {
+#pragma unroll
+    for (int j = 0; j < TM; ++j) {
+      const T* rp = a.R + (size_t)min(m + 16 * j, a.M - 1) * a.ldr;
+#pragma unroll
+      for (int i = 0; i < TN; ++i) rv[i][j] = *reinterpret_cast<const out4*>(rp + nc[i]);
     }
   }
+  if (a.P) {
 #pragma unroll
-  for (int j = 0; j < TM; ++j) {
-    const int mj = m + 16 * j;
-    if (mj >= a.M) continue;
+    for (int j = 0; j < TM; ++j) {
+      const T* pp = a.P + (size_t)(min(m + 16 * j, a.M - 1) % a.period) * a.N;
+#pragma unroll
+      for (int i = 0; i < TN; ++i) pv[i][j] = *reinterpret_cast<const out4*>(pp + nc[i]);
+    }
+  }
+  // every loaded value is consumed before the first store: a store between two uses makes the next use wait for vmcnt(0), i.e. for the store
+#pragma unroll
+  for (int j = 0; j < TM; ++j)
 #pragma unroll
     for (int i = 0; i < TN; ++i) {
-      if (!nok[i]) continue;
       floatx4 v = acc[i][j] + bias[i];
       if (a.relu) {
 #pragma unroll
@@ -181,8 +202,15 @@ CFEN_DEV void gemm_epilogue(const GemmArgs<T>& a, floatx4 (&acc)[TN][TM], int n,
 #pragma unroll
         for (int r = 0; r < 4; ++r) v[r] += (float)pv[i][j][r];
       }
-      store4<T>(out_ptr(a, mj, n + 16 * i), v);
+      acc[i][j] = v;
     }
+#pragma unroll
+  for (int j = 0; j < TM; ++j) {
+    const int mj = m + 16 * j;
+    if (mj >= a.M) continue;
+#pragma unroll
+    for (int i = 0; i < TN; ++i)
+      if (nok[i]) store4<T>(out_ptr(a, mj, nc[i]), acc[i][j]);
   }
 }
 
