@@ -117,34 +117,93 @@ __global__ __launch_bounds__(NW * 64) void k_conv(Grouped<ConvDesc> dg) {
     }
   }
 
+  // Epilogue in four sweeps -- affine vectors, residual vectors (unconditional loads at the lane's own or, past the end, the last pixel),
+  // arithmetic, stores: written as one loop (load scale, load residual, add, store, next tile) every load was followed by its own
+  // s_waitcnt vmcnt(0), which also waited for the store before it: 12 serial memory round trips per wave behind a K loop of 2-3.
   const int oy_off = d.ph_y[phase], ox_off = d.ph_x[phase];
+  size_t opix[TM];
 #pragma unroll
-  for (int j = 0; j < TM; ++j) {
-    if (!pv[j]) continue;
-    const int oy = py[j] * d.out_stride + oy_off, ox = px[j] * d.out_stride + ox_off;
-    const size_t opix = ((size_t)pb[j] * d.Hout + oy) * d.Wout + ox;
+  for (int j = 0; j < TM; ++j) opix[j] = ((size_t)pb[j] * d.Hout + py[j] * d.out_stride + oy_off) * d.Wout + px[j] * d.out_stride + ox_off;
+  if (d.out_nchw_f32) {   // (rare: the 7x7 tails run on k_conv7_tz) one tile at a time, nothing batched
 #pragma unroll
-    for (int i = 0; i < TN; ++i) {
-      const int n = i * 16 + 4 * h;
-      floatx4 v = acc[i][j] * *reinterpret_cast<const floatx4*>(d.scale + n) + *reinterpret_cast<const floatx4*>(d.shift + n);
-      if (d.act == 1) {
+    for (int j = 0; j < TM; ++j) {
+      if (!pv[j]) continue;
+      const int oy = py[j] * d.out_stride + oy_off, ox = px[j] * d.out_stride + ox_off;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f);
-      } else if (d.act == 2) {
+      for (int i = 0; i < TN; ++i) {
+        const int n = i * 16 + 4 * h;
+        floatx4 v = acc[i][j] * *reinterpret_cast<const floatx4*>(d.scale + n) + *reinterpret_cast<const floatx4*>(d.shift + n);
+        if (d.act == 1) {
 #pragma unroll
-        for (int r = 0; r < 4; ++r) v[r] = tanhf(v[r]);
-      }
-      if (d.out_nchw_f32) {
+          for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f);
+        } else if (d.act == 2) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) v[r] = tanhf(v[r]);
+        }
         float* o = (float*)d.out;
 #pragma unroll
         for (int r = 0; r < 4; ++r)
           if (n + r < d.Cout) o[(((size_t)pb[j] * d.Cout + n + r) * d.Hout + oy) * d.Wout + ox] = v[r];
-      } else if (n < d.cs_out) {
-        if (d.res[0]) v += load4<T>((const T*)d.res[0] + opix * d.cs_res + n);
-        if (d.res[1]) v += load4<T>((const T*)d.res[1] + opix * d.cs_res + n);
-        store4<T>((T*)d.out + opix * d.cs_out + n, v);
       }
     }
+    return;
+  }
+  typedef typename Mma<T>::out4 out4;
+  constexpr int IG = TN <= 3 ? TN : TN % 2 == 0 ? 2 : 1;          // feature tiles per sweep group: bounds the live affine + residual registers
+#pragma unroll
+  for (int i0 = 0; i0 < TN; i0 += IG) {
+    out4 r0[IG][TM], r1[IG][TM];
+    floatx4 gsc[IG], gsf[IG];
+#pragma unroll
+    for (int i = 0; i < IG; ++i) {
+      gsc[i] = *reinterpret_cast<const floatx4*>(d.scale + (i0 + i) * 16 + 4 * h);
+      gsf[i] = *reinterpret_cast<const floatx4*>(d.shift + (i0 + i) * 16 + 4 * h);
+    }
+    int nres[IG];
+#pragma unroll
+    for (int i = 0; i < IG; ++i) nres[i] = (i0 + i) * 16 + 4 * h < d.cs_out ? (i0 + i) * 16 + 4 * h : 0;      // lanes past the channel stride re-read vector 0
+    if (d.res[0]) {
+#pragma unroll
+      for (int j = 0; j < TM; ++j)
+#pragma unroll
+        for (int i = 0; i < IG; ++i) r0[i][j] = *reinterpret_cast<const out4*>((const T*)d.res[0] + opix[j] * d.cs_res + nres[i]);
+    }
+    if (d.res[1]) {
+#pragma unroll
+      for (int j = 0; j < TM; ++j)
+#pragma unroll
+        for (int i = 0; i < IG; ++i) r1[i][j] = *reinterpret_cast<const out4*>((const T*)d.res[1] + opix[j] * d.cs_res + nres[i]);
+    }
+#pragma unroll
+    for (int j = 0; j < TM; ++j)
+#pragma unroll
+      for (int i = 0; i < IG; ++i) {
+        floatx4 v = acc[i0 + i][j] * gsc[i] + gsf[i];
+        if (d.act == 1) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f);
+        } else if (d.act == 2) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) v[r] = tanhf(v[r]);
+        }
+        if (d.res[0]) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) v[r] += (float)r0[i][j][r];
+        }
+        if (d.res[1]) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) v[r] += (float)r1[i][j][r];
+        }
+        acc[i0 + i][j] = v;
+      }
+    __builtin_amdgcn_sched_barrier(0);       // keep the next group's loads out of this one: its registers are what the grouping saves
+  }
+#pragma unroll
+  for (int j = 0; j < TM; ++j) {
+    if (!pv[j]) continue;
+#pragma unroll
+    for (int i = 0; i < TN; ++i)
+      if (i * 16 + 4 * h < d.cs_out) store4<T>((T*)d.out + opix[j] * d.cs_out + i * 16 + 4 * h, acc[i][j]);
   }
 }
 
