@@ -352,7 +352,7 @@ CFEN_DEV void eq_dma16(const void* g, unsigned char* l) {
 template <int ND, int TM, int NW, int RS>
 __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_embed_qkv2(Grouped<CfenEmbedQkvArgs> ga) {
   typedef half_t T;
-  const CfenEmbedQkvArgs& a = ga.g[blockIdx.z];
+  const CfenEmbedQkvArgs a = ga.g[blockIdx.z];
   constexpr int KC = 32, EPL = 8;
   constexpr int D = ND * 16, NCH = ND / 2, RT = RS / 16;
   constexpr int P1 = D * 2 + 32, PP1 = P1 / 16;

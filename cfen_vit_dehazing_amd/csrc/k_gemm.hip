@@ -318,7 +318,7 @@ CFEN_DEV void dma16(const void* g, unsigned char* l) {
 // and the L2 -> LDS traffic per flop halves -- and it is slower on every GEMM of this network, see cfen_tune_gemm_big().
 template <typename T, int TM, int NS, int TN = 3>   // block tile = 32*TN features x 32*TM tokens; a wave owns TN x TM MFMA tiles
 __global__ __launch_bounds__(256, (TN > 3 && NS == 2) ? 2 : 1) void k_gemm_dma(Grouped<GemmArgs<T>> ga) {
-  const GemmArgs<T>& a = ga.g[blockIdx.z];
+  const GemmArgs<T> a = ga.g[blockIdx.z];   // by value: one bulk scalar load into SGPRs instead of a reload of each field where it is used
   constexpr int EPL = Mma<T>::EPL;
   constexpr int BK = G_BKB / (int)sizeof(T);
   constexpr int NCH = BK / Mma<T>::KC;   // 2
@@ -459,7 +459,7 @@ __global__ __launch_bounds__(256, (TN > 3 && NS == 2) ? 2 : 1) void k_gemm_dma(G
 // Second pass of a split-K GEMM: Y = act(sum_s part[s] + bias) + R + P, slices added in index order.
 template <typename T>
 __global__ __launch_bounds__(256) void k_gemm_splitk_finish(Grouped<GemmArgs<T>> ga) {
-  const GemmArgs<T>& a = ga.g[blockIdx.z];
+  const GemmArgs<T> a = ga.g[blockIdx.z];
   const long long nvec = (long long)a.M * (a.N / 4);
   for (long long idx = (long long)blockIdx.x * 256 + threadIdx.x; idx < nvec; idx += (long long)gridDim.x * 256) {
     const int m = (int)(idx / (a.N / 4)), n = (int)(idx % (a.N / 4)) * 4;
@@ -483,7 +483,7 @@ __global__ __launch_bounds__(256) void k_gemm_splitk_finish(Grouped<GemmArgs<T>>
 // in the loop.  Same epilogue as k_gemm_nt.
 template <typename T>
 __global__ __launch_bounds__(256) void k_gemm_skinny(Grouped<GemmArgs<T>> ga) {
-  const GemmArgs<T>& a = ga.g[blockIdx.z];
+  const GemmArgs<T> a = ga.g[blockIdx.z];
   constexpr int EPL = Mma<T>::EPL, KS = 2 * Mma<T>::KC;
   typedef typename Mma<T>::frag frag;
   __shared__ floatx4 red[4][4][64];

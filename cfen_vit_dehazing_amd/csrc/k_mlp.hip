@@ -290,7 +290,7 @@ CFEN_DEV void mlp_dma16(const void* g, unsigned char* l) {
 template <int ND, int TM, int NW, int HCH>
 __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_mlp2(Grouped<MlpArgs> ga) {
   typedef half_t T;
-  const MlpArgs& a = ga.g[blockIdx.z];
+  const MlpArgs a = ga.g[blockIdx.z];
   constexpr int KC = 32, EPL = 8;
   constexpr int NT = NW * 64;
   constexpr int D = ND * 16;
