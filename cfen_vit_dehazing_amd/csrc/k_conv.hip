@@ -31,9 +31,31 @@ __host__ __device__ inline int conv_wl_pitch(int Kpad) {
 // class 0.98 -> 0.93 ms).  Tried on top and dropped: K split over the four waves of a workgroup (the chain of dependent round trips is NOT
 // what bounds these kernels: ds_conv_e03 36.7 -> 35.3 us, lgcat_conv_d03 44.6 -> 52.2) and, with the weights in LDS, the pixel vectors
 // fetched branch-free two chunks ahead (small maps +-0, lgcat_conv_d01 99.7 -> 117.5 us).
+// The scalar fields of a ConvDesc, copied out of the kernel-argument block once (one bulk scalar load): through the reference every use
+// re-read its field (39 s_loads in the 1x1 fuse conv), and `src[tap.src]` -- a per-lane index -- was a VECTOR load of the pointer from the
+// argument block in front of every pixel fetch, i.e. a second memory round trip per K chunk.
+struct ConvK {
+  const void *src0, *src1, *src2, *weight, *res0, *res1;
+  void* out;
+  const float *scale, *shift;
+  int Hin, Win, cs_in, Cin, Kpad, ntaps, in_stride, out_stride, B, Hb, Wb, Hout, Wout, pad_reflect, act, cs_res, cs_out, Cout_pad, Cout, out_nchw_f32;
+  int oy_off, ox_off;
+};
+CFEN_DEV ConvK conv_k(const ConvDesc& r, int phase) {
+  ConvK k;
+  k.src0 = r.src[0]; k.src1 = r.src[1]; k.src2 = r.src[2]; k.weight = r.weight; k.res0 = r.res[0]; k.res1 = r.res[1]; k.out = r.out;
+  k.scale = r.scale; k.shift = r.shift;
+  k.Hin = r.Hin; k.Win = r.Win; k.cs_in = r.cs_in; k.Cin = r.Cin; k.Kpad = r.Kpad; k.ntaps = r.ntaps; k.in_stride = r.in_stride;
+  k.out_stride = r.out_stride; k.B = r.B; k.Hb = r.Hb; k.Wb = r.Wb; k.Hout = r.Hout; k.Wout = r.Wout; k.pad_reflect = r.pad_reflect;
+  k.act = r.act; k.cs_res = r.cs_res; k.cs_out = r.cs_out; k.Cout_pad = r.Cout_pad; k.Cout = r.Cout; k.out_nchw_f32 = r.out_nchw_f32;
+  k.oy_off = r.ph_y[phase]; k.ox_off = r.ph_x[phase];
+  return k;
+}
+
 template <typename T, int TN, int TM, bool WL = false, int NW = 4>
 __global__ __launch_bounds__(NW * 64) void k_conv(Grouped<ConvDesc> dg) {
-  const ConvDesc& d = dg.g[blockIdx.z];
+  const ConvDesc& dref = dg.g[blockIdx.z];
+  const ConvK d = conv_k(dref, blockIdx.y);
   constexpr int KC = Mma<T>::KC, EPL = Mma<T>::EPL;
   typedef typename Mma<T>::frag frag;
   __shared__ int taps_l[CFEN_MAX_TAPS];
@@ -41,7 +63,7 @@ __global__ __launch_bounds__(NW * 64) void k_conv(Grouped<ConvDesc> dg) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r16 = lane & 15, h = lane >> 4;
   const int phase = blockIdx.y;
   if (tid < d.ntaps) {
-    ConvTap t = d.taps[phase * d.ntaps + tid];
+    ConvTap t = dref.taps[phase * d.ntaps + tid];
     taps_l[tid] = ((int)(unsigned char)t.src << 16) | ((int)(unsigned char)t.dy << 8) | (int)(unsigned char)t.dx;
   }
   const int wpitch = conv_wl_pitch<T>(d.Kpad);
@@ -84,7 +106,8 @@ __global__ __launch_bounds__(NW * 64) void k_conv(Grouped<ConvDesc> dg) {
     if (t < d.ntaps) {
       const int tp = taps_l[t];
       const int dy = (int)(signed char)((tp >> 8) & 0xff), dx = (int)(signed char)(tp & 0xff);
-      const T* sp = (const T*)d.src[(tp >> 16) & 3];
+      const int si = (tp >> 16) & 3;
+      const T* sp = (const T*)(si == 0 ? d.src0 : si == 1 ? d.src1 : d.src2);
 #pragma unroll
       for (int j = 0; j < TM; ++j) {
         int iy = py[j] * d.in_stride + dy, ix = px[j] * d.in_stride + dx;
@@ -120,7 +143,7 @@ __global__ __launch_bounds__(NW * 64) void k_conv(Grouped<ConvDesc> dg) {
   // Epilogue in four sweeps -- affine vectors, residual vectors (unconditional loads at the lane's own or, past the end, the last pixel),
   // arithmetic, stores: written as one loop (load scale, load residual, add, store, next tile) every load was followed by its own
   // s_waitcnt vmcnt(0), which also waited for the store before it: 12 serial memory round trips per wave behind a K loop of 2-3.
-  const int oy_off = d.ph_y[phase], ox_off = d.ph_x[phase];
+  const int oy_off = d.oy_off, ox_off = d.ox_off;
   size_t opix[TM];
 #pragma unroll
   for (int j = 0; j < TM; ++j) opix[j] = ((size_t)pb[j] * d.Hout + py[j] * d.out_stride + oy_off) * d.Wout + px[j] * d.out_stride + ox_off;
@@ -162,17 +185,17 @@ __global__ __launch_bounds__(NW * 64) void k_conv(Grouped<ConvDesc> dg) {
     int nres[IG];
 #pragma unroll
     for (int i = 0; i < IG; ++i) nres[i] = (i0 + i) * 16 + 4 * h < d.cs_out ? (i0 + i) * 16 + 4 * h : 0;      // lanes past the channel stride re-read vector 0
-    if (d.res[0]) {
+    if (d.res0) {
 #pragma unroll
       for (int j = 0; j < TM; ++j)
 #pragma unroll
-        for (int i = 0; i < IG; ++i) r0[i][j] = *reinterpret_cast<const out4*>((const T*)d.res[0] + opix[j] * d.cs_res + nres[i]);
+        for (int i = 0; i < IG; ++i) r0[i][j] = *reinterpret_cast<const out4*>((const T*)d.res0 + opix[j] * d.cs_res + nres[i]);
     }
-    if (d.res[1]) {
+    if (d.res1) {
 #pragma unroll
       for (int j = 0; j < TM; ++j)
 #pragma unroll
-        for (int i = 0; i < IG; ++i) r1[i][j] = *reinterpret_cast<const out4*>((const T*)d.res[1] + opix[j] * d.cs_res + nres[i]);
+        for (int i = 0; i < IG; ++i) r1[i][j] = *reinterpret_cast<const out4*>((const T*)d.res1 + opix[j] * d.cs_res + nres[i]);
     }
 #pragma unroll
     for (int j = 0; j < TM; ++j)
@@ -186,11 +209,11 @@ __global__ __launch_bounds__(NW * 64) void k_conv(Grouped<ConvDesc> dg) {
 #pragma unroll
           for (int r = 0; r < 4; ++r) v[r] = tanhf(v[r]);
         }
-        if (d.res[0]) {
+        if (d.res0) {
 #pragma unroll
           for (int r = 0; r < 4; ++r) v[r] += (float)r0[i][j][r];
         }
-        if (d.res[1]) {
+        if (d.res1) {
 #pragma unroll
           for (int r = 0; r < 4; ++r) v[r] += (float)r1[i][j][r];
         }
