@@ -77,3 +77,26 @@ static inline void cfen_desc_convT4(ConvDesc* d, int B, int Hin, int Win, int cs
         }
     }
 }
+
+#if defined(__HIPCC__)
+// The scalar fields of a ConvDesc, copied out of the kernel-argument block once (one bulk scalar load): through the reference every use
+// re-read its field (39 s_loads in the 1x1 fuse conv), and `src[tap.src]` -- a per-lane index -- was a VECTOR load of the pointer from the
+// argument block in front of every pixel fetch, i.e. a second memory round trip per K chunk.
+struct ConvK {
+  const void *src0, *src1, *src2, *weight, *res0, *res1;
+  void* out;
+  const float *scale, *shift;
+  int Hin, Win, cs_in, Cin, Kpad, ntaps, in_stride, out_stride, B, Hb, Wb, Hout, Wout, pad_reflect, act, cs_res, cs_out, Cout_pad, Cout, out_nchw_f32;
+  int oy_off, ox_off;
+};
+__device__ __forceinline__ ConvK conv_k(const ConvDesc& r, int phase) {
+  ConvK k;
+  k.src0 = r.src[0]; k.src1 = r.src[1]; k.src2 = r.src[2]; k.weight = r.weight; k.res0 = r.res[0]; k.res1 = r.res[1]; k.out = r.out;
+  k.scale = r.scale; k.shift = r.shift;
+  k.Hin = r.Hin; k.Win = r.Win; k.cs_in = r.cs_in; k.Cin = r.Cin; k.Kpad = r.Kpad; k.ntaps = r.ntaps; k.in_stride = r.in_stride;
+  k.out_stride = r.out_stride; k.B = r.B; k.Hb = r.Hb; k.Wb = r.Wb; k.Hout = r.Hout; k.Wout = r.Wout; k.pad_reflect = r.pad_reflect;
+  k.act = r.act; k.cs_res = r.cs_res; k.cs_out = r.cs_out; k.Cout_pad = r.Cout_pad; k.Cout = r.Cout; k.out_nchw_f32 = r.out_nchw_f32;
+  k.oy_off = r.ph_y[phase]; k.ox_off = r.ph_x[phase];
+  return k;
+}
+#endif
