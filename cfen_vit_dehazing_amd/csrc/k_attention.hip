@@ -313,14 +313,26 @@ __global__ __launch_bounds__(256) void k_attention_hm(PtrG<const half_t> QKVg, P
   const half_t* Kp = Qp + S * DH;
   const half_t* Vp = Kp + S * DH;
 
-  for (int idx = tid; idx < S * 4; idx += 256) {
-    const int row = idx >> 2, c = idx & 3;
+  // all global loads of the workgroup go out together, unconditionally: the K / V pieces of the staging sweep (piece 3 of a row is padding:
+  // its lane re-reads piece 2 and keeps the constant) and this wave's query fragments.  Written as a loop of `if (c < 3) load; store to LDS`
+  // and a query load at the top of every q iteration, the kernel was 4 + NKT / 4 memory round trips in a row.
+  constexpr int NST = S * 4 / 256, NQ = NKT / 4;
+  static_assert(S * 4 % 256 == 0 && NKT % 4 == 0, "staging sweep / query tiles per wave");
+  half8 kst[NST], vst[NST], qst[NQ];
+#pragma unroll
+  for (int i = 0; i < NST; ++i) {
+    const int idx = tid + i * 256, row = idx >> 2, c = min(idx & 3, 2);
+    kst[i] = load_frag<half_t>(Kp + row * DH + c * 8);
+    vst[i] = load_frag<half_t>(Vp + row * DH + c * 8);
+  }
+#pragma unroll
+  for (int i = 0; i < NQ; ++i) qst[i] = load_frag<half_t>(Qp + ((wave + 4 * i) * 16 + r16) * DH + min(h, 2) * 8);
+#pragma unroll
+  for (int i = 0; i < NST; ++i) {
+    const int idx = tid + i * 256, row = idx >> 2, c = idx & 3;
     half8 kv = Mma<half_t>::zero(), vv = Mma<half_t>::zero();
     vv[0] = (half_t)1.0f;                                      // piece 3 of a V row: feature 24 = 1 (denominator row), 25..31 = 0
-    if (c < 3) {
-      kv = load_frag<half_t>(Kp + row * DH + c * 8);
-      vv = load_frag<half_t>(Vp + row * DH + c * 8);
-    }
+    if (c < 3) { kv = kst[i]; vv = vst[i]; }
     *reinterpret_cast<half8*>(Kl + row * KP + c * 16) = kv;
     *reinterpret_cast<half8*>(Vl + row * VP + c * 16) = vv;
   }
@@ -329,10 +341,10 @@ __global__ __launch_bounds__(256) void k_attention_hm(PtrG<const half_t> QKVg, P
   const float c = scale_log2;
   const int li = lane & 15;
   const unsigned char* vbase = Vl + (4 * h + (li >> 2)) * VP + (li & 3) * 8;   // tr-read: lane 4q+p of a 16-lane group -> row q, columns 4p..4p+3
-#pragma unroll 1
-  for (int qt = wave; qt < NKT; qt += 4) {
-    const int q0 = qt * 16;
-    const half8 qf = h < 3 ? load_frag<half_t>(Qp + (q0 + r16) * DH + h * 8) : Mma<half_t>::zero();
+#pragma unroll
+  for (int qi = 0; qi < NQ; ++qi) {
+    const int q0 = (wave + 4 * qi) * 16;
+    const half8 qf = h < 3 ? qst[qi] : Mma<half_t>::zero();
     floatx4 st[NKT];
 #pragma unroll
     for (int t = 0; t < NKT; ++t)
