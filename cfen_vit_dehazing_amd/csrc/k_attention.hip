@@ -203,16 +203,43 @@ __global__ __launch_bounds__(256) void k_attention_win(PtrG<const T> QKVg, PtrG<
   const T* Kp = Qp + D;
   const T* Vp = Qp + 2 * D;
 
+  // every global load of the workgroup is issued up front and unconditionally (a piece past the head dimension re-reads piece 0 and is
+  // replaced by zeros afterwards): the K pieces, the V pieces and, for the 16-bit type, this wave's query fragments.  As loops of
+  // `cond ? load : 0` followed by the LDS store (and a query load per q iteration) the kernel walked ~10 memory round trips one by one.
   constexpr int NVK = DHPK / EPL, NVV = NDT * 16 / EPL;
-  for (int idx = tid; idx < S * NVK; idx += 256) {
-    int kr = idx / NVK, v = idx - kr * NVK, d = v * EPL;
-    frag val = (d < dh) ? load_frag<T>(Kp + (size_t)kr * ld + d) : Mma<T>::zero();
-    *reinterpret_cast<frag*>(Kl + kr * KROW + v * 16) = val;
+  constexpr int NSK = (S * NVK + 255) / 256, NSV = ((S / 2) * NVV + 255) / 256, NQ = (NKT + 3) / 4;
+  constexpr bool QPRE = sizeof(T) == 2;             // fp32 fragments are twice as many registers: its queries are fetched per iteration
+  frag kst[NSK], v0st[NSV], v1st[NSV], qst[QPRE ? NQ : 1][NCQ];
+#pragma unroll
+  for (int i = 0; i < NSK; ++i) {
+    const int idx = min(tid + i * 256, S * NVK - 1), kr = idx / NVK, d = (idx - kr * NVK) * EPL;
+    kst[i] = load_frag<T>(Kp + (size_t)kr * ld + (d < dh ? d : 0));
   }
-  for (int idx = tid; idx < (S / 2) * NVV; idx += 256) {
-    int kp = idx / NVV, v = idx - kp * NVV, d = v * EPL;
-    frag v0 = (d < dh) ? load_frag<T>(Vp + (size_t)(2 * kp) * ld + d) : Mma<T>::zero();
-    frag v1 = (d < dh) ? load_frag<T>(Vp + (size_t)(2 * kp + 1) * ld + d) : Mma<T>::zero();
+#pragma unroll
+  for (int i = 0; i < NSV; ++i) {
+    const int idx = min(tid + i * 256, (S / 2) * NVV - 1), kp = idx / NVV, d = (idx - kp * NVV) * EPL;
+    v0st[i] = load_frag<T>(Vp + (size_t)(2 * kp) * ld + (d < dh ? d : 0));
+    v1st[i] = load_frag<T>(Vp + (size_t)(2 * kp + 1) * ld + (d < dh ? d : 0));
+  }
+  if constexpr (QPRE) {
+#pragma unroll
+    for (int i = 0; i < NQ; ++i)
+#pragma unroll
+      for (int cc = 0; cc < NCQ; ++cc) {
+        const int d = cc * KC + h * EPL, qrow = min((wave + 4 * i) * 16 + r16, S - 1);
+        qst[i][cc] = load_frag<T>(Qp + (size_t)qrow * ld + (d < dh ? d : 0));
+      }
+  }
+#pragma unroll
+  for (int i = 0; i < NSK; ++i) {
+    const int idx = tid + i * 256, kr = idx / NVK, v = idx - kr * NVK, d = v * EPL;
+    if (idx < S * NVK) *reinterpret_cast<frag*>(Kl + kr * KROW + v * 16) = d < dh ? kst[i] : Mma<T>::zero();
+  }
+#pragma unroll
+  for (int i = 0; i < NSV; ++i) {
+    const int idx = tid + i * 256, kp = idx / NVV, v = idx - kp * NVV, d = v * EPL;
+    if (idx >= (S / 2) * NVV) continue;
+    frag v0 = d < dh ? v0st[i] : Mma<T>::zero(), v1 = d < dh ? v1st[i] : Mma<T>::zero();
     if (ones_row && d == dh / EPL * EPL) {
       v0[dh % EPL] = (T)1.0f;
       v1[dh % EPL] = (T)1.0f;
@@ -222,14 +249,17 @@ __global__ __launch_bounds__(256) void k_attention_win(PtrG<const T> QKVg, PtrG<
   __syncthreads();
 
   const float c = scale_log2;
-#pragma unroll 1
-  for (int qt = wave; qt < NKT; qt += 4) {
+#pragma unroll
+  for (int qi = 0; qi < NQ; ++qi) {
+    const int qt = wave + 4 * qi;
+    if (qt >= NKT) break;
     const int q0 = qt * 16;
     frag qf[NCQ];
 #pragma unroll
     for (int cc = 0; cc < NCQ; ++cc) {
       int d = cc * KC + h * EPL;
-      qf[cc] = (d < dh) ? load_frag<T>(Qp + (size_t)(q0 + r16) * ld + d) : Mma<T>::zero();
+      if constexpr (QPRE) qf[cc] = (d < dh) ? qst[qi][cc] : Mma<T>::zero();
+      else qf[cc] = (d < dh) ? load_frag<T>(Qp + (size_t)(q0 + r16) * ld + d) : Mma<T>::zero();
     }
     floatx4 st[NKT];
 #pragma unroll
