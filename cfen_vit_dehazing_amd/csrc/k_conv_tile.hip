@@ -96,27 +96,32 @@ __global__ __launch_bounds__(256) void k_conv_tile(Grouped<ConvDesc> dg, int nbl
   // ---- epilogue: lane owns output features 4h..4h+3 of pixel (y0 + r, x0 + 16*wave + r16) ----
   const int n = 4 * h, ox = x0 + wave * 16 + r16;
   const floatx4 sc = *reinterpret_cast<const floatx4*>(d.scale + n), sh = *reinterpret_cast<const floatx4*>(d.shift + n);
+  // the descriptor fields of the row loop, read ONCE: through `d` each row re-read them from the argument block after its store (73 s_loads)
+  const int act = d.act, nchw = d.out_nchw_f32, Cout = d.Cout, Hin = d.Hin, Win = d.Win, cs_out = d.cs_out, cs_res = d.cs_res;
+  const void* const res0 = d.res[0];
+  const void* const res1 = d.res[1];
+  void* const outp = d.out;
 #pragma unroll
   for (int r = 0; r < R; ++r) {
     const int oy = y0 + r;
     floatx4 v = acc[r] * sc + sh;
-    if (d.act == 1) {
+    if (act == 1) {
 #pragma unroll
       for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
-    } else if (d.act == 2) {
+    } else if (act == 2) {
 #pragma unroll
       for (int e = 0; e < 4; ++e) v[e] = tanhf(v[e]);
     }
-    if (d.out_nchw_f32) {
-      float* o = (float*)d.out;
+    if (nchw) {
+      float* o = (float*)outp;
 #pragma unroll
       for (int e = 0; e < 4; ++e)
-        if (n + e < d.Cout) o[(((size_t)b * d.Cout + n + e) * d.Hin + oy) * d.Win + ox] = v[e];
-    } else if (n < d.cs_out) {
-      const size_t opix = ((size_t)b * d.Hin + oy) * d.Win + ox;
-      if (d.res[0]) v += load4<T>((const T*)d.res[0] + opix * d.cs_res + n);
-      if (d.res[1]) v += load4<T>((const T*)d.res[1] + opix * d.cs_res + n);
-      store4<T>((T*)d.out + opix * d.cs_out + n, v);
+        if (n + e < Cout) o[(((size_t)b * Cout + n + e) * Hin + oy) * Win + ox] = v[e];
+    } else if (n < cs_out) {
+      const size_t opix = ((size_t)b * Hin + oy) * Win + ox;
+      if (res0) v += load4<T>((const T*)res0 + opix * cs_res + n);
+      if (res1) v += load4<T>((const T*)res1 + opix * cs_res + n);
+      store4<T>((T*)outp + opix * cs_out + n, v);
     }
   }
 }
