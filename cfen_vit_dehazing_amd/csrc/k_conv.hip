@@ -349,22 +349,34 @@ __global__ __launch_bounds__(256) void k_chan_stats(const T* __restrict__ x0, co
 #pragma unroll
   for (int e = 0; e < EPL; ++e) { s[e] = 0.f; q[e] = 0.f; m[e] = -3.0e38f; }
   if (my_p < lanes_per_cv) {
-#pragma unroll 4
-    for (int p = p0 + my_p; p < p1; p += lanes_per_cv) {
-      size_t off = ((size_t)b * HW + p) * cs + my_cv * EPL;
-      float v[EPL];
-      Vec16<T>::load(x0 + off, v);
+    // four pixels per pass, their 4 (or 12) vector loads issued before the first add (clamped to the last pixel past the end of the chunk)
+    typedef typename Mma<T>::frag frag;
+    constexpr int U = 4;
+    for (int pb = p0 + my_p; pb < p1; pb += U * lanes_per_cv) {
+      frag f0[U], f1[U], f2[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const int p = min(pb + u * lanes_per_cv, p1 - 1);
+        f0[u] = load_frag<T>(x0 + ((size_t)b * HW + p) * cs + my_cv * EPL);
+      }
       if (x1) {
-        float u[EPL];
-        Vec16<T>::load(x1 + off, u);
 #pragma unroll
-        for (int e = 0; e < EPL; ++e) v[e] += u[e];
-        Vec16<T>::load(x2 + off, u);
-#pragma unroll
-        for (int e = 0; e < EPL; ++e) v[e] += u[e];
+        for (int u = 0; u < U; ++u) {
+          const int p = min(pb + u * lanes_per_cv, p1 - 1);
+          f1[u] = load_frag<T>(x1 + ((size_t)b * HW + p) * cs + my_cv * EPL);
+          f2[u] = load_frag<T>(x2 + ((size_t)b * HW + p) * cs + my_cv * EPL);
+        }
       }
 #pragma unroll
-      for (int e = 0; e < EPL; ++e) { s[e] += v[e]; q[e] += v[e] * v[e]; m[e] = fmaxf(m[e], v[e]); }
+      for (int u = 0; u < U; ++u) {
+        if (pb + u * lanes_per_cv >= p1) continue;
+#pragma unroll
+        for (int e = 0; e < EPL; ++e) {
+          float v = (float)f0[u][e];
+          if (x1) v = (v + (float)f1[u][e]) + (float)f2[u][e];
+          s[e] += v; q[e] += v * v; m[e] = fmaxf(m[e], v);
+        }
+      }
     }
   }
 #pragma unroll
@@ -492,6 +504,7 @@ __global__ __launch_bounds__(256) void k_cfsm_apply(const T* __restrict__ x0, co
     const float* Wa = w + gsel * per + bk * C;          // fc_avg_cf{1,2}.2
     const float* Wm = w + (2 + gsel) * per + bk * C;    // fc_max_cf{1,2}.2
     float a = 0.f;
+#pragma unroll 4
     for (int j = 0; j < bk; ++j) a += Wa[c * bk + j] * hid[gsel][j] + Wm[c * bk + j] * hid[2 + gsel][j];
     g_l[gsel][c] = 1.f / (1.f + expf(-a));
   }
