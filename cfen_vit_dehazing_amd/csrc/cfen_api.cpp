@@ -138,6 +138,11 @@ int cfen_tune(const char* key, int value) {
     cfen_tune_gemm_big() = value;
     return CFEN_OK;
   }
+  if (!strcmp(key, "conv7.tpw")) {
+    CFEN_CHECK_ARG(value >= 1, "tune: conv7.tpw must be >= 1");
+    cfen_tune_conv7_tpw() = value;
+    return CFEN_OK;
+  }
   if (!strcmp(key, "conv.wlds") || !strcmp(key, "conv.wlds_maxlog")) {
     CFEN_CHECK_ARG(value >= 0, "tune: %s must be >= 0", key);
     (key[9] ? cfen_tune_conv_wlds_maxlog() : cfen_tune_conv_wlds()) = value;

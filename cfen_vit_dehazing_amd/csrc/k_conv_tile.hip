@@ -385,16 +385,30 @@ namespace {
 
 constexpr int Z_RW = 4, Z_ROWS = 4 * Z_RW + 6, Z_WT = 72, Z_RB = Z_WT * 32, Z_NCH = 5, Z_KPAD = 7 * Z_NCH * 32;
 
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_conv7_tz(Grouped<ConvDesc> dg, int nblk) {
+// A workgroup walks `tpw` consecutive tiles: the 35 weight fragments of a lane (35 KB per wave, more than the L1 holds, so every wave of
+// every tile pulled them from L2: 0.86 GB per launch of the three tails) are loaded once per workgroup instead of once per tile.
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_conv7_tz(Grouped<ConvDesc> dg, int nblk, int tpw) {
   const ConvDesc& d = dg.g[blockIdx.z];
   typedef half_t T;
   typedef Mma<T>::frag frag;
   constexpr int NPIECE = Z_ROWS * Z_WT * 2, NIT = (NPIECE + 255) / 256;
   __shared__ __attribute__((aligned(16))) unsigned char lds[Z_ROWS * Z_RB];
 
-  const int blk = (int)xcd_chunked_block(blockIdx.x, gridDim.x);
-  if (blk >= nblk) return;
+  const int blk0 = (int)xcd_chunked_block(blockIdx.x, gridDim.x) * tpw;
+  if (blk0 >= nblk) return;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r16 = lane & 15, h = lane >> 4;
+  frag wf[7][Z_NCH];
+  {
+    const T* wp = (const T*)d.weight + (size_t)r16 * Z_KPAD + h * 8;
+#pragma unroll
+    for (int dy = 0; dy < 7; ++dy)
+#pragma unroll
+      for (int c = 0; c < Z_NCH; ++c) wf[dy][c] = load_frag<T>(wp + (dy * Z_NCH + c) * 32);
+  }
+  for (int it = 0; it < tpw; ++it) {
+  const int blk = blk0 + it;
+  if (blk >= nblk) break;
+  if (it) __syncthreads();                        // every wave is done reading the previous tile's halo
   const int tiles_x = d.Win / 64, tiles_y = d.Hin / (4 * Z_RW);
   const int tx = blk % tiles_x, ty = (blk / tiles_x) % tiles_y, b = blk / (tiles_x * tiles_y);
   const int x0 = tx * 64, y0 = ty * 4 * Z_RW;
@@ -414,14 +428,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
       ok = ok && gy >= 0 && gy < d.Hin && gx >= 0 && gx < d.Win;
     }
     stg[i] = ok ? *reinterpret_cast<const frag*>(src + ((size_t)gy * d.Win + gx) * 32 + q * 16) : Mma<T>::zero();
-  }
-  frag wf[7][Z_NCH];
-  {
-    const T* wp = (const T*)d.weight + (size_t)r16 * Z_KPAD + h * 8;
-#pragma unroll
-    for (int dy = 0; dy < 7; ++dy)
-#pragma unroll
-      for (int c = 0; c < Z_NCH; ++c) wf[dy][c] = load_frag<T>(wp + (dy * Z_NCH + c) * 32);
   }
 #pragma unroll
   for (int i = 0; i < NIT; ++i) {
@@ -467,6 +473,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
       *reinterpret_cast<floatx4*>(o + (size_t)r * d.Win) = v;
     }
   }
+  }   // tiles of this workgroup
 }
 
 }  // namespace
@@ -477,6 +484,10 @@ bool cfen_conv7_tz_supported(int dtype, int k, int stride, int pad, int nsrc, in
          W % 64 == 0;
 }
 int cfen_conv7_tz_kpad() { return Z_KPAD; }
+int& cfen_tune_conv7_tpw() {   // tiles per workgroup of k_conv7_tz ("conv7.tpw")
+  static int v = 4;
+  return v;
+}
 
 int cfen_conv7_tz_impl_g(int dtype, int ng, const ConvDesc* dp, hipStream_t s) {
   CFEN_CHECK_ARG(ng >= 1 && ng <= CFEN_MAX_GROUPS && dp, "conv7 (toeplitz): 1..%d problems per launch", CFEN_MAX_GROUPS);
@@ -492,7 +503,8 @@ int cfen_conv7_tz_impl_g(int dtype, int ng, const ConvDesc* dp, hipStream_t s) {
   }
   for (int g = 0; g < CFEN_MAX_GROUPS; ++g) dg.g[g] = dp[g < ng ? g : 0];
   const long long nblk = (long long)dp[0].B * (dp[0].Hin / (4 * Z_RW)) * (dp[0].Win / 64);
-  CFEN_LAUNCH(k_conv7_tz, dim3(cfen_grid8(nblk), 1, ng), dim3(256), 0, s, dg, (int)nblk);
+  const int tpw = std::max(1, std::min(cfen_tune_conv7_tpw(), (int)(nblk * ng / 1024)));      // at least ~2 workgroups per CU stay in the grid
+  CFEN_LAUNCH(k_conv7_tz, dim3(cfen_grid8((nblk + tpw - 1) / tpw), 1, ng), dim3(256), 0, s, dg, (int)nblk, tpw);
   CFEN_CHECK_LAUNCH("conv7 (toeplitz)");
   return CFEN_OK;
 }
