@@ -138,6 +138,11 @@ int cfen_tune(const char* key, int value) {
     cfen_tune_gemm_big() = value;
     return CFEN_OK;
   }
+  if (!strcmp(key, "convT.tpw")) {
+    CFEN_CHECK_ARG(value >= 1, "tune: convT.tpw must be >= 1");
+    cfen_tune_convT_tpw() = value;
+    return CFEN_OK;
+  }
   if (!strcmp(key, "conv7.tpw")) {
     CFEN_CHECK_ARG(value >= 1, "tune: conv7.tpw must be >= 1");
     cfen_tune_conv7_tpw() = value;

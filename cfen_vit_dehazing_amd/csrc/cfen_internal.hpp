@@ -83,6 +83,7 @@ int cfen_actnorm_init_impl(int dtype, const void* x, float* part, int B, int HW,
 int cfen_cfsm2g_impl(int dtype, const void* x0, const void* x1, const void* x2, void* out, const float* w, float* part, int B, int HW,
                      int C, int cs, hipStream_t s);
 int& cfen_tune_gemm_kernel();   // -1 auto, 0 tiled, 1 skinny (cfen_tune "gemm.kernel")
+int& cfen_tune_convT_tpw();     // "convT.tpw"
 int& cfen_tune_conv7_tpw();     // tiles per workgroup of the Toeplitz 7x7 kernel ("conv7.tpw")
 int& cfen_tune_conv_wlds();     // gather convs stage their weight matrix in LDS: 0 never, 1 matrices up to 60 KB, 2 up to 150 KB ("conv.wlds"; "conv.wlds_maxlog" caps the launch size)
 int& cfen_tune_conv_wlds_maxlog();

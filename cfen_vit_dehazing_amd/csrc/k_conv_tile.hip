@@ -212,7 +212,7 @@ template <int PIXB> CFEN_DEV int convt_swz(int col) {
 }
 
 template <typename T, int PIXB, int TN, int NX, int RY>
-__global__ __launch_bounds__(256) void k_convT_tile(Grouped<ConvDesc> dg, int nblk) {
+__global__ __launch_bounds__(256) void k_convT_tile(Grouped<ConvDesc> dg, int nblk, int tpw) {   // tpw consecutive tiles per workgroup (see k_conv7_tz)
   const ConvDesc& d = dg.g[blockIdx.z];
   constexpr int SZ = (int)sizeof(T), EPL = Mma<T>::EPL, KC = Mma<T>::KC;
   constexpr int CPT = PIXB / 64;                 // chunks per tap
@@ -226,10 +226,29 @@ __global__ __launch_bounds__(256) void k_convT_tile(Grouped<ConvDesc> dg, int nb
   typedef typename Mma<T>::frag frag;
   __shared__ __attribute__((aligned(16))) unsigned char lds[ROWS * RB];
 
-  const int blk = (int)xcd_chunked_block(blockIdx.x, gridDim.x);
-  if (blk >= nblk) return;
+  constexpr bool MT = PIXB == 128;               // multi-tile only in the 128-byte variant (us_conv_d02: 54.7 -> 47.0 us with two tiles); the loop
+                                                 // costs registers: the 192-byte variant drops to one wave per SIMD with it (44 -> 58 us), the
+                                                 // 64-byte one has 4 weight fragments and nothing to amortise
+  const int ntile = MT ? tpw : 1;
+  const int blk0 = (int)xcd_chunked_block(blockIdx.x, gridDim.x) * ntile;
+  if (blk0 >= nblk) return;
   const int tid = threadIdx.x, lane = tid & 63, phase = tid >> 6, r16 = lane & 15, h = lane >> 4;
   const int py = phase >> 1, px = phase & 1;
+  // this wave's phase: weights of its 4 taps
+  frag wf[4][CPT][TN];
+  {
+    const T* wp = (const T*)d.weight + ((size_t)phase * d.Cout_pad + r16) * KPAD + h * EPL;
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+      for (int c = 0; c < CPT; ++c)
+#pragma unroll
+        for (int i = 0; i < TN; ++i) wf[t][c][i] = load_frag<T>(wp + (size_t)i * 16 * KPAD + (t * CPT + c) * KC);
+  }
+  for (int it = 0; it < ntile; ++it) {
+  const int blk = blk0 + it;
+  if (blk >= nblk) break;
+  if (it) __syncthreads();                        // every wave is done reading the previous tile's halo
   const int tiles_x = d.Win / TW, tiles_y = d.Hin / RY;
   const int tx = blk % tiles_x, ty = (blk / tiles_x) % tiles_y, b = blk / (tiles_x * tiles_y);
   const int x0 = tx * TW, y0 = ty * RY;
@@ -244,17 +263,6 @@ __global__ __launch_bounds__(256) void k_convT_tile(Grouped<ConvDesc> dg, int nb
     const int gy = y0 - 1 + row, gx = x0 - 1 + col;
     const bool ok = idx < NPIECE && piece < src_pieces && gy >= 0 && gy < d.Hin && gx >= 0 && gx < d.Win;
     stg[i] = ok ? *reinterpret_cast<const frag*>(src + ((size_t)gy * d.Win + gx) * src_pixb + piece * 16) : Mma<T>::zero();
-  }
-  // this wave's phase: weights of its 4 taps
-  frag wf[4][CPT][TN];
-  {
-    const T* wp = (const T*)d.weight + ((size_t)phase * d.Cout_pad + r16) * KPAD + h * EPL;
-#pragma unroll
-    for (int t = 0; t < 4; ++t)
-#pragma unroll
-      for (int c = 0; c < CPT; ++c)
-#pragma unroll
-        for (int i = 0; i < TN; ++i) wf[t][c][i] = load_frag<T>(wp + (size_t)i * 16 * KPAD + (t * CPT + c) * KC);
   }
 #pragma unroll
   for (int i = 0; i < NIT; ++i) {
@@ -320,6 +328,7 @@ __global__ __launch_bounds__(256) void k_convT_tile(Grouped<ConvDesc> dg, int nb
         store4<T>((T*)d.out + (((size_t)b * Hout + oy) * Wout + ox) * d.cs_out + n, v);
       }
   }
+  }   // tiles of this workgroup
 }
 
 template <typename T, int PIXB, int TN, int NX, int RY>
@@ -328,7 +337,8 @@ int launch_convT_tile(int ng, const ConvDesc* dp, hipStream_t s) {
   Grouped<ConvDesc> dg;
   for (int g = 0; g < CFEN_MAX_GROUPS; ++g) dg.g[g] = dp[g < ng ? g : 0];
   const long long nblk = (long long)d.B * (d.Hin / RY) * (d.Win / (16 * NX));
-  CFEN_LAUNCH((k_convT_tile<T, PIXB, TN, NX, RY>), dim3(cfen_grid8(nblk), 1, ng), dim3(256), 0, s, dg, (int)nblk);
+  const int tpw = PIXB == 128 ? std::max(1, std::min(cfen_tune_convT_tpw(), (int)(nblk * ng / 1024))) : 1;
+  CFEN_LAUNCH((k_convT_tile<T, PIXB, TN, NX, RY>), dim3(cfen_grid8((nblk + tpw - 1) / tpw), 1, ng), dim3(256), 0, s, dg, (int)nblk, tpw);
   CFEN_CHECK_LAUNCH("convT (tile)");
   return CFEN_OK;
 }
@@ -484,6 +494,10 @@ bool cfen_conv7_tz_supported(int dtype, int k, int stride, int pad, int nsrc, in
          W % 64 == 0;
 }
 int cfen_conv7_tz_kpad() { return Z_KPAD; }
+int& cfen_tune_convT_tpw() {   // tiles per workgroup of the 128-byte k_convT_tile variant ("convT.tpw")
+  static int v = 2;
+  return v;
+}
 int& cfen_tune_conv7_tpw() {   // tiles per workgroup of k_conv7_tz ("conv7.tpw")
   static int v = 4;
   return v;
