@@ -504,6 +504,40 @@ def test_conv_transpose(dtype, cin, cout):
         assert float(out[..., cout:].abs().max()) == 0.0
 
 
+def test_multi_tile_workgroups_of_conv7_and_convT_cover_ragged_tile_counts():
+    """k_conv7_tz walks `conv7.tpw` tiles per workgroup and the 128-byte k_convT_tile `convT.tpw` (weights loaded once per workgroup) when the
+    launch has enough tiles; tile counts that do not divide (the last workgroup stops early) must give bitwise the one-tile-per-workgroup result"""
+    dtype, d = torch.float16, dev()
+    try:
+        # conv7: 5 x (1040 / 16) x (576 / 64) = 2925 tiles (odd) -> up to 2 tiles per workgroup (2925 / 1024; the knob value 3 is clamped to 2)
+        x = rnd((5, 12, 1040, 576), 1, dtype)
+        w = rnd((3, 12, 7, 7), 2, dtype, 0.3 / math.sqrt(12 * 49))
+        s, t = packing.affine(rnd((3,), 3, torch.float32, 0.1), cout_pad=16)
+        xn, wz = ops.to_nhwc(x).to(d), packing.pack_conv7_toeplitz(w, dtype)[0].to(d)
+        outs = {}
+        for tpw in (1, 2, 3):
+            ops.tune("conv7.tpw", tpw)
+            outs[tpw] = ops.conv2d(xn, wz, s.to(d), t.to(d), 16, 3, k=7, stride=1, pad=3, reflect=True, act=2, nchw_f32=True, toeplitz=True).cpu()
+        assert torch.equal(outs[1], outs[2]) and torch.equal(outs[1], outs[3])
+        last = slice(4, 5)      # the image the ragged last workgroup writes: against torch (affine = scale 1, shift = bias)
+        want = torch.tanh(F.conv2d(F.pad(x[last].double(), (3, 3, 3, 3), mode="reflect"), w.double(), t[:3].double()))
+        close(outs[2][last], want, tol(dtype, 2))
+        # convT (48 -> 24 channels: the 128-byte variant): 3 x (1028 / 4) x (96 / 32) = 2313 tiles (odd) -> 2 tiles per workgroup
+        cin, cout = 48, 24
+        xt = rnd((3, cin, 1028, 96), 4, dtype)
+        wt = rnd((cin, cout, 4, 4), 5, dtype, 1 / math.sqrt(cin * 4))
+        st, tt = packing.affine(rnd((cout,), 6, torch.float32, 0.1), cout_pad=packing.round_up(cout, 16))
+        xtn, wr = ops.to_nhwc(xt).to(d), packing.pack_convT_weight_rows(wt, packing.cs_of(cin), dtype).to(d)
+        outs = {}
+        for tpw in (1, 2):
+            ops.tune("convT.tpw", tpw)
+            outs[tpw] = ops.conv2d(xtn, wr, st.to(d), tt.to(d), packing.cs_of(cin), cout, transpose=True, act=1, rows_layout=True).cpu()
+        assert torch.equal(outs[1], outs[2])
+    finally:
+        ops.tune("conv7.tpw", 4)
+        ops.tune("convT.tpw", 2)
+
+
 @pytest.mark.parametrize("cin,cout,H,W", [(96, 48, 8, 32), (48, 24, 12, 64), (24, 12, 16, 96)])
 def test_conv_transpose_rows_layout(cin, cout, H, W):
     """LDS-tiled ConvTranspose2d (k_convT_tile, fp16 only): vs torch, vs the gather kernel, and padded channels zero"""
