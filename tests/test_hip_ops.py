@@ -488,6 +488,28 @@ def test_conv_1x1_concat_actnorm_relu_residual(dtype, C):
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
+def test_conv_gather_with_and_without_lds_staged_weights_is_bitwise_equal(dtype):
+    """k_conv reads its weight fragments from an LDS copy staged once per workgroup (default, `conv.wlds` 2: 4- and 8-wave workgroups) or from
+    global memory (0): same MFMAs in the same order, so a strided 3x3 conv (96 output channels: the 8-wave shape) and a two-source 1x1 fuse
+    conv with ActNorm, ReLU and a residual must agree bit for bit"""
+    x = rnd((2, 48, 32, 32), 1, dtype)
+    w3, b3 = rnd((96, 48, 3, 3), 2, dtype, 1 / math.sqrt(48 * 9)), rnd((96,), 3, torch.float32, 0.1)
+    a, b2, res = rnd((2, 24, 32, 32), 4, dtype), rnd((2, 24, 32, 32), 5, dtype), rnd((2, 24, 32, 32), 6, dtype)
+    w1, b1 = rnd((24, 48, 1, 1), 7, dtype, 1 / math.sqrt(48)), rnd((24,), 8, torch.float32, 0.1)
+    anw, anb = rnd((24,), 9, torch.float32, 0.2), rnd((24,), 10, torch.float32, 0.2)
+    outs = {}
+    try:
+        for mode in (2, 1, 0):
+            ops.tune("conv.wlds", mode)
+            outs[mode] = (run_conv(dtype, x, w3, b3, 3, 2, 1, act=1), run_conv(dtype, a, w1, b1, 1, 1, 0, an=(anw, anb), act=1, res=res, x2=b2))
+    finally:
+        ops.tune("conv.wlds", 2)
+    for mode in (1, 0):
+        assert torch.equal(outs[mode][0], outs[2][0]) and torch.equal(outs[mode][1], outs[2][1]), mode
+    close(outs[2][0], torch.relu(F.conv2d(x.double(), w3.double(), b3.double(), stride=2, padding=1)), tol(dtype, 6))
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
 @pytest.mark.parametrize("cin,cout", [(96, 48), (48, 24), (24, 12)])
 def test_conv_transpose(dtype, cin, cout):
     kc = 32 if dtype == torch.float16 else 16
