@@ -40,6 +40,12 @@ class MlpArgsC(ctypes.Structure):
                [(n, ctypes.c_int32) for n in ("mapH", "mapW", "C", "cs", "ws", "p")]
 
 
+class MlpStreamArgsC(ctypes.Structure):
+    _fields_ = [(n, c_void_p) for n in ("x", "y", "fmap", "att", "wp_stream", "ln_gamma", "ln_beta", "wa_stream", "b1a", "b2a", "wb_stream", "b1b", "b2b")] + \
+               [("M", ctypes.c_int64), ("D", ctypes.c_int32), ("H", ctypes.c_int32), ("eps", c_float)] + \
+               [(n, ctypes.c_int32) for n in ("mapH", "mapW", "C", "cs", "ws", "p")]
+
+
 class LvitArgsC(ctypes.Structure):
     _fields_ = [("fmap", c_void_p), ("out", c_void_p)] + [(n, ctypes.c_int32) for n in ("B", "H", "W", "C", "cs_in", "cs_out", "ws", "p")] + \
                [(n, c_void_p) for n in ("we", "be", "pos", "ln1_gamma", "ln1_beta", "wkv", "wq", "wp", "ln2_gamma", "ln2_beta",
@@ -80,6 +86,7 @@ SIGNATURES = {
     "cfen_attention": (_I, [_I, _P, _P, _I, _I, _I, _I, _P]),
     "cfen_attention_head_major": (_I, [_I, _P, _P, _I, _I, _I, _I, _P]),
     "cfen_mlp_block": (_I, [_I, ctypes.POINTER(MlpArgsC), _P]),
+    "cfen_mlp_stream_block": (_I, [_I, ctypes.POINTER(MlpStreamArgsC), _P]),
     "cfen_lvit_window": (_I, [_I, ctypes.POINTER(LvitArgsC), _P]),
     "cfen_patchify": (_I, [_I, _P, _P] + [_I] * 8 + [_P]),
     "cfen_unpatchify": (_I, [_I, _P, _P] + [_I] * 7 + [_P]),

@@ -6,7 +6,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libcfen_hip.so")
-SOURCES = ["k_gemm.hip", "k_attention.hip", "k_tokens.hip", "k_conv.hip", "k_conv_tile.hip", "k_mlp.hip", "k_embed.hip", "k_lvit.hip", "k_dcn.hip", "k_dcn_bwd.hip", "cfen_api.cpp", "cfen_net.cpp"]
+SOURCES = ["k_gemm.hip", "k_attention.hip", "k_tokens.hip", "k_conv.hip", "k_conv_tile.hip", "k_mlp.hip", "k_embed.hip", "k_lvit.hip", "k_stream.hip", "k_dcn.hip", "k_dcn_bwd.hip", "cfen_api.cpp", "cfen_net.cpp"]
 # per-file codegen flags.  k_attention: the softmax is VALU bound -- drop fmaxf's NaN canonicalisation (no NaNs can
 # occur: masked scores are -1e30, not -inf) and let MFMA results land in VGPRs instead of AGPR + v_accvgpr_read.
 EXTRA_FLAGS = {"k_attention.hip": ["-fno-honor-nans", "-mllvm", "-amdgpu-mfma-vgpr-form=1"]}

@@ -68,6 +68,16 @@ int cfen_mlp_block(int dtype, const cfen_mlp_args* a, void* stream) {
   return cfen_mlp_impl(dtype, &m, (hipStream_t)stream);
 }
 
+int cfen_mlp_stream_block(int dtype, const cfen_mlp_stream_args* a, void* stream) {
+  CFEN_CHECK_ARG(a != nullptr, "mlp_stream_block: null args");
+  Mlp3Args m{};
+  m.X = a->x; m.A = a->att; m.Wp = a->wp_stream; m.Y = a->y; m.fmap = a->fmap; m.ln_g = a->ln_gamma; m.ln_b = a->ln_beta;
+  m.Wa = a->wa_stream; m.b1a = a->b1a; m.b2a = a->b2a; m.Wb = a->wb_stream; m.b1b = a->b1b; m.b2b = a->b2b;
+  m.M = a->M; m.D = a->D; m.H = a->H; m.eps = a->eps;
+  m.mapH = a->mapH; m.mapW = a->mapW; m.C = a->C; m.cs = a->cs; m.ws = a->ws; m.p = a->p;
+  return cfen_mlp3_impl_g(dtype, 1, &m, (hipStream_t)stream);
+}
+
 int cfen_lvit_window(int dtype, const cfen_lvit_args* a, void* stream) {
   CFEN_CHECK_ARG(a != nullptr, "lvit_window: null args");
   LvitArgs v{a->fmap, a->out, a->B, a->H, a->W, a->C, a->cs_in, a->cs_out, a->ws, a->p, a->we, a->be, a->pos, a->ln1_gamma, a->ln1_beta,
@@ -196,6 +206,11 @@ int cfen_tune(const char* key, int value) {
   }
   if (!strcmp(key, "net.attn_head_major")) {
     cfen_tune_attn_head_major() = value != 0;
+    return CFEN_OK;
+  }
+  if (!strcmp(key, "net.stream_mlp")) {
+    CFEN_CHECK_ARG(value >= 0 && value <= 2, "tune: net.stream_mlp is 0 (never), 1 (grouped decoder launches) or 2 (always)");
+    cfen_tune_stream_mlp() = value;
     return CFEN_OK;
   }
   if (!strcmp(key, "net.embed_gather")) {

@@ -47,6 +47,10 @@ int& cfen_tune_attn_head_major() {
   static int v = 1;
   return v;
 }
+int& cfen_tune_stream_mlp() {   // k_mlp3 (k_stream.hip) for the D = 384 blocks: 0 never, 1 (default) grouped decoder launches only (a single instance has
+  static int v = 1;             // 64 workgroups of 128 tokens: a quarter of the chip), 2 always
+  return v;
+}
 
 namespace {
 
@@ -74,6 +78,7 @@ struct Vit {
   bool fused_front; // gather+embedding+LN1+qkv run as one k_embed_qkv launch
   bool ln_fold1, ln_fold2;   // LN1 / LN2 ride on the qkv / ffn1 GEMM (k_gemm_dma row statistics + folded weights), no LayerNorm launch
   bool fused_window;// the whole block runs as one k_lvit_window launch (one workgroup per window)
+  bool stream_mlp;  // out_proj + LN2 + FFN + mlp_head + fold can run as one k_mlp3 launch on fragment-stream weights ("<name>.proj.ws" / ".ffn.ws" / ".head.ws")
 };
 struct ConvLayer {
   int kind, k, stride, pad, reflect, nsrc, Cin, Cin_real, Cout, Cout_pad, Kpad, nphase, ntaps, out_edge;
@@ -301,6 +306,7 @@ int cfen_net::build() {
     v.fused_mlp = !v.global && !v.shrink && cfen_mlp_supported(v.D, v.hidden, cfg.dtype);
     v.fused_front = !v.global && !v.shrink && cfen_embed_qkv_supported(v.D);
     v.fused_window = !v.global && v.fused_mlp && v.fused_front && cfen_lvit_window_supported(cfg.dtype, v.D, v.heads, v.S, v.hidden);
+    v.stream_mlp = !v.global && !v.shrink && !v.fused_mlp && v.D == 384 && v.hidden <= 4 * v.D && cfen_mlp3_supported(cfg.dtype, v.D, v.hidden);
     v.ln_fold1 = !v.fused_front && v.Dn == v.D && (v.D * esz) % 128 == 0;
     v.ln_fold2 = !v.fused_mlp && v.Dn == v.D && (v.D * esz) % 128 == 0;
     CFEN_CHECK_ARG(v.Dn % v.heads == 0, "net: %s embedding dim %d not divisible by %d heads", v.name.c_str(), v.Dn, v.heads);
@@ -321,6 +327,9 @@ int cfen_net::build() {
     need(n + ".proj.w", wbytes(v, v.D, v.Da));
     if (v.ln_fold1) { need(n + ".qkv.wl", wbytes(v, 3 * v.Da, v.D)); need(n + ".qkv.s", (size_t)3 * v.Da * 4); need(n + ".qkv.bl", (size_t)3 * v.Da * 4); }
     if (v.ln_fold2) { need(n + ".ffn1.wl", wbytes(v, v.hidden, v.D)); need(n + ".ffn1.s", (size_t)v.hidden * 4); need(n + ".ffn1.bl", (size_t)v.hidden * 4); }
+    if (v.stream_mlp) {
+      need(n + ".proj.ws", (size_t)v.D * v.D * esz); need(n + ".ffn.ws", (size_t)2 * v.D * v.hidden * esz); need(n + ".head.ws", (size_t)2 * v.D * v.hidden * esz);
+    }
     need(n + ".ln2.g", (size_t)v.D * 4); need(n + ".ln2.b", (size_t)v.D * 4);
     const char* wn = v.fused_mlp ? ".wk" : ".w";
     need(n + ".ffn1" + wn, wbytes(v, v.hidden, v.D)); need(n + ".ffn1.b", (size_t)v.hidden * 4);
@@ -616,6 +625,24 @@ int cfen_net::run_vit_g(int ng, const VitCall* vc, int scr0) {
   else
     TRYP(K_ATTN, 4 * Md * v.S * D, cfen_attention_impl_g(dt, ng, cQKV, ATT, B * nwin, v.S, v.heads, v.dh, stream));
   const void* cATT[3] = {ATT[0], ATT[1], ATT[2]};
+  const bool stream_mlp = v.stream_mlp && (cfen_tune_stream_mlp() >= 2 || (cfen_tune_stream_mlp() == 1 && ng == 3));
+  if (stream_mlp) {
+    // LViT level 3: out_proj + residual + LN2 + FFN + mlp_head + fold in one launch on fragment-stream weights (k_stream.hip)
+    Mlp3Args m[3];
+    for (int g = 0; g < ng; ++g) {
+      const std::string& n = nm[g];
+      m[g] = Mlp3Args{};
+      m[g].X = X1[g]; m[g].A = ATT[g]; m[g].Wp = P(n + ".proj.ws"); m[g].Y = nullptr; m[g].fmap = OUT[g];
+      m[g].ln_g = Pf(n + ".ln2.g"); m[g].ln_b = Pf(n + ".ln2.b");
+      m[g].Wa = P(n + ".ffn.ws"); m[g].b1a = Pf(n + ".ffn1.b"); m[g].b2a = Pf(n + ".ffn2.b");
+      m[g].Wb = P(n + ".head.ws"); m[g].b1b = Pf(n + ".head1.b"); m[g].b2b = Pf(n + ".head2.b");
+      m[g].M = M; m[g].D = v.D; m[g].H = v.hidden; m[g].eps = 1e-5f;
+      m[g].mapH = v.mapH; m[g].mapW = v.mapH; m[g].C = v.C; m[g].cs = bo.cs; m[g].ws = v.ws; m[g].p = v.p;
+    }
+    step("proj_mlp_stream");
+    TRYP(K_MLP, 8 * Md * D * Hd + 2 * Md * D * D, cfen_mlp3_impl_g(dt, ng, m, stream));
+    return CFEN_OK;
+  }
   if (!v.fused_mlp) {
     step("proj");
     TRYP(K_GEMM, 2 * Md * D * D, gemm(cATT, ".proj.w", nullptr, X1, nullptr, X1, v.D, v.Da, 0, nullptr));

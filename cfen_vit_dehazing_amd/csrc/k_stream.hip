@@ -1,0 +1,353 @@
+// Token blocks on a FRAGMENT STREAM (round 3): the fused kernels for the embedding dims the register-resident kernels of k_mlp.hip /
+// k_embed.hip could not hold at two waves per SIMD -- D = 384 (LViT level 3, GViT level 1) -- and a spill-free D = 192 variant.
+//
+//   k_mlp3   x (+ Wp att) -> LN2 -> FFN -> +res -> mlp_head -> +res -> fold      (v3:1386-1389, 1173, 1186; replaces proj / ln2_ffn1 / ffn2 /
+//                                                                                head1 / head2_fold = five k_gemm_dma launches and the
+//                                                                                4 D-wide hidden activations they passed through HBM)
+//   k_front3 patch gather -> linear_encoding + res + pos -> X1, LN1 -> qkv (head-major)   (v3:1140-1143, 1166, 1364-1371)
+//
+// What is different from k_mlp2 / k_embed_qkv2:
+//   * ONE wave per SIMD with the whole 512-register file (4 waves a workgroup): the residual stream of 32 tokens x 384 features (or
+//     64 x 192) lives in 192 accumulator registers, its fp16 copy (the B operand) in 96 more -- no spills, and every weight fragment read
+//     from LDS feeds TM = 2 (4) MFMAs instead of 1, which is what an 8-wave / 256-register shape at D = 384 would be limited to.
+//   * the weights are a FRAGMENT STREAM, packed once on the host (packing.pack_stream_*): the 1 KiB A-operand fragments (16 rows x 32 k,
+//     lane l = 16 bytes of row l & 15, k quarter l >> 4) in exactly the order the kernel consumes them.  A "phase" is ND consecutive
+//     fragments = one k-chunk of Wp, one 32-unit slice of W1, or the matching slice of W2; HBM / L2 reads are one linear run per
+//     workgroup, the LDS image is lane-linear (conflict-free ds_read_b128, no padding, no swizzle), and the ring of R phases is filled by
+//     LDS-DMA with a counted vmcnt: R - 2 phases stay in flight across the one raw s_barrier per phase.
+#include <stdlib.h>
+#include <type_traits>
+#include "cfen_common.hpp"
+#include "cfen_internal.hpp"
+#include "cfen_mlp.hpp"
+
+namespace {
+
+template <int I, int N, class F>
+CFEN_DEV void sfor(F&& f) {
+  if constexpr (I < N) {
+    f(std::integral_constant<int, I>{});
+    sfor<I + 1, N>(f);
+  }
+}
+
+// (a __device__ helper, not the builtin inside a lambda: hipcc's host pass drops the stub of a kernel whose lambda calls it)
+CFEN_DEV void st_dma(const void* g, unsigned char* l) {
+  __builtin_amdgcn_global_load_lds(g, (__attribute__((address_space(3))) void*)l, 16, 0, 0);
+}
+
+// wait until at most `younger` phases of DPW LDS-DMAs each are still in flight (younger <= Y)
+template <int DPW, int Y>
+CFEN_DEV void wait_phases(int younger) {
+  if constexpr (Y == 0) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  } else {
+    if (younger >= Y) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(Y * DPW) : "memory");
+    else wait_phases<DPW, Y - 1>(younger);
+  }
+}
+
+CFEN_DEV half8 pack_pair(const floatx4& a, const floatx4& b) {
+  half8 f = {(half_t)a[0], (half_t)a[1], (half_t)a[2], (half_t)a[3], (half_t)b[0], (half_t)b[1], (half_t)b[2], (half_t)b[3]};
+  return f;
+}
+
+// ND = D / 16 feature tiles, TM token tiles of 16 per wave, R ring slots of ND KiB, HB = largest hidden width (bias staging area)
+template <int ND, int TM, int R, int HB>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void k_mlp3(Grouped<Mlp3Args> ga) {
+  typedef half_t T;
+  typedef half8 frag;
+  const Mlp3Args a = ga.g[blockIdx.z];
+  constexpr int NW = 4, D = ND * 16, NCH = ND / 2, SLOT = ND * 1024, DPW = ND / NW, RING = R * SLOT;
+  constexpr int NG = ND / 3;   // fragment groups of 3 per phase
+  static_assert(ND % NW == 0 && NCH % 3 == 0 && R >= 3 && (R - 2) * DPW < 64 && HB % 256 == 0, "ring geometry");
+  static_assert(RING + 2 * HB * 4 <= 160 * 1024, "LDS");
+  __shared__ __attribute__((aligned(1024))) unsigned char lds[RING + 2 * HB * 4];
+
+  const int tid = threadIdx.x, lane = tid & 63, r16 = lane & 15, h = lane >> 4;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const long long tok0 = ((long long)blockIdx.x * NW + wave) * (TM * 16);
+  const int nt = a.H / 32;                      // 32-unit hidden sub-steps per stage
+  const int npp = a.Wp ? NCH : 0;               // projection phases
+  const int NP = npp + 2 * nt * (a.Wb ? 2 : 1);
+
+  auto issue = [&](int q, int slot) {
+    const unsigned char* src = q < npp            ? (const unsigned char*)a.Wp + (size_t)q * SLOT
+                               : q < npp + 2 * nt ? (const unsigned char*)a.Wa + (size_t)(q - npp) * SLOT
+                                                  : (const unsigned char*)a.Wb + (size_t)(q - npp - 2 * nt) * SLOT;
+#pragma unroll
+    for (int k = 0; k < DPW; ++k) {
+      const int f = k * NW + wave;
+      st_dma(src + f * 1024 + lane * 16, lds + slot * SLOT + f * 1024);
+    }
+  };
+  // ---- prologue: hidden biases -> LDS, the first R - 1 phases into the ring, tokens into registers ----
+  {
+    const int pieces = a.H * 4 / 16, nb = (pieces + 63) / 64;
+    for (int blk = wave; blk < nb; blk += NW) {
+      const int pc = min(blk * 64 + lane, pieces - 1);
+      st_dma((const unsigned char*)a.b1a + pc * 16, lds + RING + blk * 1024);
+      if (a.Wb) st_dma((const unsigned char*)a.b1b + pc * 16, lds + RING + HB * 4 + blk * 1024);
+    }
+  }
+#pragma unroll
+  for (int q = 0; q < R - 1; ++q)
+    if (q < NP) issue(q, q);
+
+  floatx4 acc[ND][TM];
+  const T* X = (const T*)a.X;
+#pragma unroll
+  for (int j = 0; j < TM; ++j) {
+    long long t = tok0 + j * 16 + r16;
+    if (t >= a.M) t = a.M - 1;
+    const T* xp = X + t * D + 4 * h;
+#pragma unroll
+    for (int i = 0; i < ND; ++i) acc[i][j] = load4<T>(xp + i * 16);
+  }
+  frag xb[NCH][TM];
+  if (a.Wp) {   // attention output as the projection's B operand (natural k order), borrowed registers
+#pragma unroll
+    for (int j = 0; j < TM; ++j) {
+      long long t = tok0 + j * 16 + r16;
+      if (t >= a.M) t = a.M - 1;
+      const T* ap = (const T*)a.A + t * D + h * 8;
+#pragma unroll
+      for (int c = 0; c < NCH; ++c) xb[c][j] = load_frag<T>(ap + c * 32);
+    }
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // one drain: biases, ring prologue and tokens have landed
+
+  int p = 0, cur = 0, fill = R - 1;
+  // phase p has landed and is visible to every wave; every wave is done with the slot of phase p - 1
+  auto begin = [&]() -> const unsigned char* {
+    wait_phases<DPW, R - 2>(min(R - 2, NP - 1 - p));
+    __builtin_amdgcn_s_barrier();
+    return lds + cur * SLOT;
+  };
+  // ... which phase p + R - 1 may now overwrite (called after the phase's first fragment reads are issued)
+  auto refill = [&]() {
+    if (p + R - 1 < NP) issue(p + R - 1, fill);
+    fill = cur;
+    cur = cur + 1 == R ? 0 : cur + 1;
+    ++p;
+  };
+  const int fo = lane * 16;
+  auto loadg = [&](const unsigned char* s, auto gc, frag (&f)[3]) {
+    constexpr int g = decltype(gc)::value;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) f[k] = *reinterpret_cast<const frag*>(s + (3 * g + k) * 1024 + fo);
+  };
+
+  // ---- x += Wp att (out_proj + residual, v3:1386): phase c = k-chunk c of all ND feature tiles ----
+  if (a.Wp) {
+    sfor<0, NCH>([&](auto cc) {
+      constexpr int c = decltype(cc)::value;
+      const unsigned char* s = begin();
+      frag F[2][3];
+      loadg(s, std::integral_constant<int, 0>{}, F[0]);
+      refill();
+      sfor<0, NG>([&](auto gc) {
+        constexpr int g = decltype(gc)::value;
+        if constexpr (g + 1 < NG) loadg(s, std::integral_constant<int, g + 1>{}, F[(g + 1) & 1]);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int k = 0; k < 3; ++k)
+#pragma unroll
+          for (int j = 0; j < TM; ++j) acc[3 * g + k][j] = Mma<T>::mma(F[g & 1][k], xb[c][j], acc[3 * g + k][j]);
+        __builtin_amdgcn_sched_barrier(0);
+      });
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    });
+  }
+
+  // ---- stage-a input: LayerNorm(x) (or x) as B fragments; residual + output bias go into the accumulators ----
+  if (a.ln_g) {
+#pragma unroll
+    for (int j = 0; j < TM; ++j) {
+      float sm = 0.f;
+#pragma unroll
+      for (int i = 0; i < ND; ++i) sm += acc[i][j][0] + acc[i][j][1] + acc[i][j][2] + acc[i][j][3];
+      sm = col_sum(sm);
+      const float mean = sm * (1.f / D);
+      float q = 0.f;
+#pragma unroll
+      for (int i = 0; i < ND; ++i)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float d = acc[i][j][r] - mean;
+          q += d * d;
+        }
+      q = col_sum(q);
+      const float rstd = rsqrtf(q * (1.f / D) + a.eps);
+#pragma unroll
+      for (int c = 0; c < NCH; ++c) {
+        floatx4 t[2];
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+          const int i = c * 2 + u;
+          const floatx4 g = *reinterpret_cast<const floatx4*>(a.ln_g + i * 16 + 4 * h);
+          const floatx4 b = *reinterpret_cast<const floatx4*>(a.ln_b + i * 16 + 4 * h);
+          t[u] = (acc[i][j] - mean) * rstd * g + b;
+        }
+        xb[c][j] = pack_pair(t[0], t[1]);
+      }
+    }
+  } else {
+#pragma unroll
+    for (int j = 0; j < TM; ++j)
+#pragma unroll
+      for (int c = 0; c < NCH; ++c) xb[c][j] = pack_pair(acc[c * 2][j], acc[c * 2 + 1][j]);
+  }
+#pragma unroll
+  for (int i = 0; i < ND; ++i) {
+    const floatx4 bb = *reinterpret_cast<const floatx4*>(a.b2a + i * 16 + 4 * h);
+#pragma unroll
+    for (int j = 0; j < TM; ++j) acc[i][j] += bb;
+  }
+  // the LayerNorm parameter / bias loads above are ordinary VMEM loads in front of the ring's counted waits: drain them once (the ring
+  // is R - 1 phases ahead, so this costs nothing), from here on only LDS-DMAs are in flight
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+
+  floatx4 hacc[2][TM];
+  auto substep = [&](int t, int stage) {
+    // -- W1 phase: hidden[32 units][tokens] = W1 slice . xb + b1 (fragment f = u * NCH + c) --
+    {
+      const unsigned char* s = begin();
+      frag F[2][3];
+      loadg(s, std::integral_constant<int, 0>{}, F[0]);
+      const unsigned char* bl = lds + RING + stage * (HB * 4) + (t * 32 + 4 * h) * 4;
+      const floatx4 bv0 = *reinterpret_cast<const floatx4*>(bl), bv1 = *reinterpret_cast<const floatx4*>(bl + 64);
+      refill();
+      sfor<0, NG>([&](auto gc) {
+        constexpr int g = decltype(gc)::value, u = (3 * g) / NCH, c0 = (3 * g) % NCH;
+        if constexpr (g + 1 < NG) loadg(s, std::integral_constant<int, g + 1>{}, F[(g + 1) & 1]);
+        __builtin_amdgcn_sched_barrier(0);
+        if constexpr (c0 == 0) {
+#pragma unroll
+          for (int j = 0; j < TM; ++j) hacc[u][j] = u ? bv1 : bv0;
+        }
+#pragma unroll
+        for (int k = 0; k < 3; ++k)
+#pragma unroll
+          for (int j = 0; j < TM; ++j) hacc[u][j] = Mma<T>::mma(F[g & 1][k], xb[c0 + k][j], hacc[u][j]);
+        __builtin_amdgcn_sched_barrier(0);
+      });
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    }
+    // -- W2 phase: y += W2[:, slice] . relu(hidden) (fragment f = feature tile) --
+    {
+      const unsigned char* s = begin();
+      frag F[2][3];
+      loadg(s, std::integral_constant<int, 0>{}, F[0]);
+      refill();
+      frag hb[TM];
+#pragma unroll
+      for (int j = 0; j < TM; ++j) {
+        const half8 v = pack_pair(hacc[0][j], hacc[1][j]);
+        half8 z;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) z[e] = (half_t)0;
+        hb[j] = __builtin_elementwise_max(v, z);
+      }
+      sfor<0, NG>([&](auto gc) {
+        constexpr int g = decltype(gc)::value;
+        if constexpr (g + 1 < NG) loadg(s, std::integral_constant<int, g + 1>{}, F[(g + 1) & 1]);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int k = 0; k < 3; ++k)
+#pragma unroll
+          for (int j = 0; j < TM; ++j) acc[3 * g + k][j] = Mma<T>::mma(F[g & 1][k], hb[j], acc[3 * g + k][j]);
+        __builtin_amdgcn_sched_barrier(0);
+      });
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    }
+  };
+#pragma unroll 1
+  for (int t = 0; t < nt; ++t) substep(t, 0);
+  if (a.Wb) {   // stage b (mlp_head): its input is the stage-a result, which becomes the new residual
+#pragma unroll
+    for (int j = 0; j < TM; ++j)
+#pragma unroll
+      for (int c = 0; c < NCH; ++c) xb[c][j] = pack_pair(acc[c * 2][j], acc[c * 2 + 1][j]);
+    // (b2b is added in the epilogue: a global load here would sit in front of the ring's counted waits)
+#pragma unroll 1
+    for (int t = 0; t < nt; ++t) substep(t, 1);
+  }
+
+  // ---- epilogue: (+ b2b) token-major store, or fold + window join into the NHWC map ----
+#pragma unroll
+  for (int i = 0; i < ND; ++i) {
+    floatx4 bb = floatx4{0.f, 0.f, 0.f, 0.f};
+    if (a.Wb) bb = *reinterpret_cast<const floatx4*>(a.b2b + i * 16 + 4 * h);
+#pragma unroll
+    for (int j = 0; j < TM; ++j) acc[i][j] += bb;
+  }
+#pragma unroll
+  for (int j = 0; j < TM; ++j) {
+    const long long t = tok0 + j * 16 + r16;
+    if (t >= a.M) continue;
+    if (!a.fmap) {
+      T* yp = (T*)a.Y + t * D + 4 * h;
+#pragma unroll
+      for (int i = 0; i < ND; ++i) store4<T>(yp + i * 16, acc[i][j]);
+    } else {
+      const int tw = a.ws / a.p, S = tw * tw;
+      const int nwx = a.mapW / a.ws, nwy = a.mapH / a.ws;
+      const int tt = (int)(t % S);
+      const long long wi = t / S;
+      const int wx = (int)(wi % nwx), wy = (int)((wi / nwx) % nwy);
+      const long long b = wi / ((long long)nwx * nwy);
+      const int y0 = wy * a.ws + (tt / tw) * a.p, x0 = wx * a.ws + (tt % tw) * a.p;
+#pragma unroll
+      for (int i = 0; i < ND; ++i) {
+        const int f = i * 16 + 4 * h;
+        const int ij = f / a.C, c = f - ij * a.C;
+        const int pi = ij / a.p, pj = ij - pi * a.p;
+        T* dst = (T*)a.fmap + ((b * a.mapH + y0 + pi) * a.mapW + x0 + pj) * a.cs + c;
+        store4<T>(dst, acc[i][j]);
+      }
+    }
+  }
+}
+
+template <int ND, int TM, int R, int HB>
+int launch_mlp3(int ng, const Mlp3Args* ap, hipStream_t s) {
+  Grouped<Mlp3Args> ga;
+  for (int g = 0; g < CFEN_MAX_GROUPS; ++g) ga.g[g] = ap[g < ng ? g : 0];
+  CFEN_CHECK_ARG(ap[0].H <= HB, "mlp3: hidden width %d exceeds the %d this variant stages biases for", ap[0].H, HB);
+  const long long per = 4LL * TM * 16, blocks = (ap[0].M + per - 1) / per;
+  CFEN_CHECK_ARG(blocks > 0 && blocks < (1ll << 31), "mlp3: bad grid");
+  CFEN_LAUNCH((k_mlp3<ND, TM, R, HB>), dim3((unsigned)blocks, 1, ng), dim3(256), 0, s, ga);
+  CFEN_CHECK_LAUNCH("mlp3");
+  return CFEN_OK;
+}
+
+}  // namespace
+
+bool cfen_mlp3_supported(int dtype, int D, int H) { return dtype == 1 && (D == 384 || D == 192) && H % 32 == 0 && H > 0 && H <= (D == 384 ? 1536 : 768); }
+
+int cfen_mlp3_impl_g(int dtype, int ng, const Mlp3Args* ap, hipStream_t s) {
+  CFEN_CHECK_ARG(ng >= 1 && ng <= CFEN_MAX_GROUPS && ap, "mlp3: 1..%d problems per launch", CFEN_MAX_GROUPS);
+  CFEN_CHECK_ARG(cfen_mlp3_supported(dtype, ap[0].D, ap[0].H), "mlp3: the fragment-stream MLP runs fp16 at D = 384 (H <= 1536) / D = 192 (H <= 768), H %% 32 == 0; got dtype %d D %d H %d",
+                 dtype, ap[0].D, ap[0].H);
+  for (int g = 0; g < ng; ++g) {
+    const Mlp3Args& a = ap[g];
+    CFEN_CHECK_ARG(a.M > 0 && a.X && a.Wa && a.b1a && a.b2a && (a.Y || a.fmap), "mlp3: null pointer");
+    CFEN_CHECK_ARG((a.Wb == nullptr) == (a.b1b == nullptr) && (a.Wb == nullptr) == (a.b2b == nullptr), "mlp3: incomplete second stage");
+    CFEN_CHECK_ARG((a.ln_g == nullptr) == (a.ln_b == nullptr), "mlp3: LayerNorm needs gamma and beta");
+    CFEN_CHECK_ARG((a.A == nullptr) == (a.Wp == nullptr), "mlp3: projection prologue needs A and Wp");
+    CFEN_CHECK_ARG(cfen_aligned16(a.X) && cfen_aligned16(a.A) && cfen_aligned16(a.Wp) && cfen_aligned16(a.Y) && cfen_aligned16(a.fmap) && cfen_aligned16(a.Wa) &&
+                   cfen_aligned16(a.Wb) && cfen_aligned16(a.b1a) && cfen_aligned16(a.b2a) && cfen_aligned16(a.b1b) && cfen_aligned16(a.b2b) &&
+                   cfen_aligned16(a.ln_g) && cfen_aligned16(a.ln_b), "mlp3: pointers must be 16-byte aligned");
+    if (a.fmap) {
+      CFEN_CHECK_ARG(a.C > 0 && a.C % 4 == 0 && a.cs >= a.C && a.cs % 4 == 0 && a.p > 0 && a.ws % a.p == 0 && a.mapH % a.ws == 0 && a.mapW % a.ws == 0 &&
+                     a.p * a.p * a.C == a.D, "mlp3: bad fold geometry");
+      CFEN_CHECK_ARG(a.M % ((long long)(a.ws / a.p) * (a.ws / a.p)) == 0, "mlp3: token count does not tile the map");
+    }
+    CFEN_CHECK_ARG(a.M == ap[0].M && a.D == ap[0].D && a.H == ap[0].H && (a.Wb == nullptr) == (ap[0].Wb == nullptr) &&
+                   (a.ln_g == nullptr) == (ap[0].ln_g == nullptr) && (a.Wp == nullptr) == (ap[0].Wp == nullptr) && (a.fmap == nullptr) == (ap[0].fmap == nullptr),
+                   "mlp3: grouped problems must have the same shape");
+  }
+  if (ap[0].D == 384) return launch_mlp3<24, 2, 6, 1536>(ng, ap, s);
+  return launch_mlp3<12, 4, 8, 768>(ng, ap, s);
+}

@@ -103,6 +103,33 @@ def mlp_block(x, w1a, b1a, w2a, b2a, ln=None, second=None, fold=None, proj=None)
     return out
 
 
+def mlp_stream_block(x, wa, b1a, b2a, hidden, ln=None, second=None, fold=None, proj=None):
+    """cfen_mlp_stream_block (csrc/k_stream.hip): mlp_block with the matrices as fragment streams.  wa = packing.pack_stream_pair(W1k, W2k);
+    second = (wb, b1b, b2b); proj = (att, packing.pack_stream_sq(Wp)); fold = (B, H, W, C, cs, ws, p)."""
+    from ._lib import MlpStreamArgsC
+    _cuda(x, wa, b1a, b2a)
+    M, D = x.shape
+    a = MlpStreamArgsC(x=x.data_ptr(), wa_stream=wa.data_ptr(), b1a=b1a.data_ptr(), b2a=b2a.data_ptr(), M=M, D=D, H=hidden, eps=1e-5)
+    if proj is not None:
+        _cuda(*proj)
+        a.att, a.wp_stream = proj[0].data_ptr(), proj[1].data_ptr()
+    if ln is not None:
+        _cuda(*ln)
+        a.ln_gamma, a.ln_beta = ln[0].data_ptr(), ln[1].data_ptr()
+    if second is not None:
+        _cuda(*second)
+        a.wb_stream, a.b1b, a.b2b = (t.data_ptr() for t in second)
+    if fold is None:
+        out = torch.empty_like(x)
+        a.y = out.data_ptr()
+    else:
+        B, H, W, C, cs, ws, p = fold
+        out = torch.zeros(B, H, W, cs, dtype=x.dtype, device=x.device)
+        a.fmap, a.mapH, a.mapW, a.C, a.cs, a.ws, a.p = out.data_ptr(), H, W, C, cs, ws, p
+    check(_lib.load().cfen_mlp_stream_block(dtype_code(x.dtype), ctypes.byref(a), current_stream()), "mlp_stream_block")
+    return out
+
+
 def lvit_window(fmap, C, ws, p, packed, name, hidden, cs_out=None, eps=1e-5):
     """whole LViT block (C = 24, p = 2, ws = 32) map -> map in one launch; `packed` = packing.pack_vit + packing.pack_lvit_window entries of `name`"""
     from ._lib import LvitArgsC

@@ -69,7 +69,9 @@ def lvit_q_rows(dh=24):
 
 def window_fusable(g, dtype):
     """mirror of cfen_lvit_window_supported (csrc/k_lvit.hip): LViT level 1 (D = 96, 4 heads of 24, 256-token windows), fp16"""
-    return g.kind == "lvit" and g.shrink == 1 and dtype == torch.float16 and g.dim == 96 and g.heads == 4 and g.seq == 256 and g.hidden % 32 == 0
+    # (cfen_net.cpp builds `fused_window` only on top of the fused MLP and the fused front half: fp16 needs hidden % 64 == 0 there)
+    return (g.kind == "lvit" and g.shrink == 1 and dtype == torch.float16 and g.dim == 96 and g.heads == 4 and g.seq == 256 and g.hidden % 32 == 0
+            and mlp_is_fused(g, dtype) and front_is_fused(g))
 
 
 def pack_lvit_window(sd, g, dtype):
@@ -107,6 +109,36 @@ def pack_wtile(w):
     wp = torch.zeros(n96, k, dtype=w.dtype, device=w.device)
     wp[:n] = w
     return wp.view(n96 // 96, 96, k // bk, bk).permute(0, 2, 1, 3).contiguous().view(-1)
+
+
+def pack_stream_sq(w):
+    """[N][K] (N % 16 == 0, K % 32 == 0, k axis as the kernel wants it) -> fragment stream [K / 32 phases][N / 16 fragments][64 lanes][8]:
+    fragment (c, i) is the 16 x 32 MFMA A operand of feature tile i, k-chunk c in lane order -- lane l holds row i*16 + (l & 15), k = c*32 +
+    (l >> 4)*8 .. +7 (csrc/cfen_common.hpp fragment contract).  One phase of csrc/k_stream.hip = all feature tiles of one k-chunk."""
+    n, k = w.shape
+    assert n % 16 == 0 and k % 32 == 0
+    return w.reshape(n // 16, 16, k // 32, 4, 8).permute(2, 0, 3, 1, 4).contiguous().view(-1)
+
+
+def pack_stream_pair(w1k, w2k):
+    """Linear pair y = W2 relu(W1 x + b1) as ONE fragment stream for csrc/k_stream.hip (k_mlp3): per 32-unit slice t of the hidden dimension
+    a W1 phase -- fragments (u, c): rows t*32 + u*16 + (l & 15) of w1k [H][D], k-chunk c -- then a W2 phase -- fragments i: rows i*16 + (l & 15)
+    of w2k [D][H], k = the slice's 32 hidden units.  Both phases hold D / 16 fragments of 1 KiB.  w1k / w2k carry kperm32 on their k axis."""
+    h, d = w1k.shape
+    assert w2k.shape == (d, h) and h % 32 == 0 and d % 32 == 0
+    nd = d // 16
+    p1 = w1k.reshape(h // 32, 2, 16, d // 32, 4, 8).permute(0, 1, 3, 4, 2, 5).reshape(h // 32, 1, nd, 512)     # [t][u][c][hq][r][e]
+    p2 = w2k.reshape(nd, 16, h // 32, 4, 8).permute(2, 0, 3, 1, 4).reshape(h // 32, 1, nd, 512)               # [t][i][hq][r][e]
+    return torch.cat((p1, p2), 1).contiguous().view(-1)
+
+
+STREAM_MLP_DIMS = (384,)
+
+
+def mlp_is_streamed(g, dtype):
+    """mirror of cfen_net.cpp Vit::stream_mlp: LViT level 3 (D = 384) runs proj + LN2 + FFN + mlp_head + fold as one k_mlp3 launch"""
+    return (g.kind == "lvit" and g.shrink == 1 and dtype == torch.float16 and g.dim in STREAM_MLP_DIMS and g.hidden % 32 == 0
+            and g.hidden <= 4 * g.dim)
 
 
 GVIT_WEIGHT_SUFFIXES = (".embed.w", ".qkv.w", ".qkv.wl", ".proj.w", ".ffn1.w", ".ffn1.wl", ".ffn2.w", ".head1.w", ".head2.w")
@@ -207,10 +239,12 @@ def pack_vit(sd, g, dtype):
     }
     # LayerNorm folded into the following GEMM (csrc/k_gemm.hip: CfenGemmPtrs::lnf_s) wherever the block is not a fused kernel:
     # LN(x) W^T + b = rstd (x (W gamma)^T - mean s) + (W beta + b) with s = row sums of the ROUNDED W gamma (so the mean cancels exactly)
-    if not front_is_fused(g):
+    # (k_gemm_dma stages whole 128-byte K steps: cfen_net.cpp Vit::ln_fold1 / ln_fold2 ask for the folded entries only then)
+    k128 = (g.dim * (2 if dtype == torch.float16 else 4)) % 128 == 0
+    if not front_is_fused(g) and k128:
         out.update(ln_folded(out[n + ".qkv.w"], out[n + ".ln1.g"], out[n + ".ln1.b"], None, n + ".qkv", dtype,
                              sd[e + ".self_attn.in_proj_weight"][:, perm]))
-    if not mlp_is_fused(g, dtype):
+    if not mlp_is_fused(g, dtype) and k128:
         out.update(ln_folded(out[n + ".ffn1.w"], out[n + ".ln2.g"], out[n + ".ln2.b"], out[n + ".ffn1.b"], n + ".ffn1", dtype,
                              sd[e + ".linear1.weight"][:, perm]))
     if front_is_fused(g):
@@ -221,6 +255,12 @@ def pack_vit(sd, g, dtype):
             out[n + "." + nm + ".wk"] = (w[:, kperm32(g.dim)] if dtype == torch.float16 else w).contiguous()
     if window_fusable(g, dtype):
         out.update(pack_lvit_window(sd, g, dtype))
+    if mlp_is_streamed(g, dtype):
+        # k_mlp3 (csrc/k_stream.hip): out_proj, FFN pair and mlp_head pair as fragment streams; the row-major matrices stay for "net.stream_mlp" = 0
+        kd, kh = kperm32(g.dim), kperm32(g.hidden)
+        out[n + ".proj.ws"] = pack_stream_sq(out[n + ".proj.w"])
+        out[n + ".ffn.ws"] = pack_stream_pair(out[n + ".ffn1.w"][:, kd], out[n + ".ffn2.w"][:, kh])
+        out[n + ".head.ws"] = pack_stream_pair(out[n + ".head1.w"][:, kd], out[n + ".head2.w"][:, kh])
     if mlp_is_fused(g, dtype):
         # the fused MLP kernel replaces the four separate GEMMs: same matrices, k axis re-slotted (fp16 only)
         for a, b in (("ffn1", "ffn2"), ("head1", "head2")):

@@ -169,6 +169,23 @@ typedef struct cfen_mlp_args {
   int32_t mapH, mapW, C, cs, ws, p;
 } cfen_mlp_args;
 int cfen_mlp_block(int dtype, const cfen_mlp_args* a, void* stream);
+/* The same block for the embedding dims the register-resident kernel cannot hold at two waves per SIMD (CFEN_F16; D = 384 with H <= 1536: LViT
+ * level 3 / GViT level 1, and D = 192 with H <= 768), one wave per SIMD on the whole register file, weights as FRAGMENT STREAMS
+ * (packing.pack_stream_pair / pack_stream_sq): wa_stream / wb_stream = [H/32][W1 slice, W2 slice][D/16 fragments][1 KiB], a fragment = the
+ * 16 x 32 MFMA A operand in lane order (lane l: 16 bytes of row l & 15, k quarter l >> 4), k axes in packing.kperm32 order;
+ * wp_stream = [D/32][D/16][1 KiB], natural k order.  Same arithmetic as cfen_mlp_block.                (v3:1386-1389, 1173, 1186) */
+typedef struct cfen_mlp_stream_args {
+  const void* x; void* y; void* fmap;
+  const void* att; const void* wp_stream;
+  const float* ln_gamma; const float* ln_beta;
+  const void* wa_stream; const float* b1a; const float* b2a;
+  const void* wb_stream; const float* b1b; const float* b2b;
+  int64_t M;
+  int32_t D, H;
+  float eps;
+  int32_t mapH, mapW, C, cs, ws, p;
+} cfen_mlp_stream_args;
+int cfen_mlp_stream_block(int dtype, const cfen_mlp_stream_args* a, void* stream);
 /* One whole LViT block per workgroup-window (CFEN_F16, C = 24, p = 2, 32-pixel windows: 256 tokens of dim 96, 4 heads of 24):
  * map in -> Crop2x2 + unfold + linear_encoding + pos -> pre-LN MHA -> FFN -> mlp_head -> fold + Join2x2 -> map out, with q / k / v, the
  * attention output and both hidden activations never leaving the chip (K and V of the window live in LDS).  Weight layouts:

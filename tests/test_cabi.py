@@ -42,7 +42,7 @@ def test_argument_errors_do_not_need_a_gpu():
     assert abs(lib.cfen_net_flops_per_image(h) / 1e9 - 120.85) < 0.01           # SURVEY 8d closed form
     assert lib.cfen_net_set_param(h, b"no.such.param", ctypes.c_void_p(16), 4) == -1
     buf = ctypes.create_string_buffer(1 << 16)
-    assert lib.cfen_net_missing_params(h, buf, 1 << 16) == 645   # 24 transformer blocks x 21 + 15 conv layers x 3 ... + 8 LViT blocks with the extra fused-front layouts (2 each) + 4 level-1 LViT blocks x 3 window-kernel layouts + 16 unfused blocks (GViT, LViT-3) x 6 LayerNorm-folded entries
+    assert lib.cfen_net_missing_params(h, buf, 1 << 16) == 657   # (+ 4 level-3 LViT blocks x 3 fragment-stream layouts, round 3) 24 transformer blocks x 21 + 15 conv layers x 3 ... + 8 LViT blocks with the extra fused-front layouts (2 each) + 4 level-1 LViT blocks x 3 window-kernel layouts + 16 unfused blocks (GViT, LViT-3) x 6 LayerNorm-folded entries
     lib.cfen_net_destroy(h)
     for hdr, gf in ((2, 85.07),):
         cfg.hidden_dim_ratio = hdr
@@ -66,23 +66,17 @@ def test_tuning_knobs_validate_without_a_gpu():
         assert lib.cfen_tune(key, val) == 0, key       # (the shipped defaults: the knobs are process-wide)
 
 
-@pytest.mark.parametrize("variant,wtile", [("v3", False), ("v3", True), ("cfs", False), ("crs", False), ("v5", False), ("v5", True)])
-@pytest.mark.parametrize("dtype", ["fp16", "fp32"])
-def test_packed_parameters_are_exactly_what_the_launch_plan_asks_for(variant, wtile, dtype):
-    """packing.pack_state_dict (host) and cfen_net::build (csrc/cfen_net.cpp) must agree on every packed name and byte size, for each of
-    the four generators; set_param only records the pointer, so this runs without a GPU"""
+def _pack_and_register(cfg, dtype, wtile):
     import torch
     from cfen_vit_dehazing_amd import _lib
-    from cfen_vit_dehazing_amd.config import NetConfig
     from cfen_vit_dehazing_amd.hipnet import _VARIANT_CODE
     from cfen_vit_dehazing_amd.manifest import generate_state_dict
     from cfen_vit_dehazing_amd.packing import pack_state_dict
     lib = _lib.load()
-    cfg = NetConfig(24, 4, patch_size=8, load_size=64, variant=variant)
     td = torch.float16 if dtype == "fp16" else torch.float32
     packed = pack_state_dict(generate_state_dict(cfg, seed=0, with_dead=False), cfg, td, wtile=wtile)
-    cc = _lib.NetConfigC(batch=2, n_feats=24, hidden_dim_ratio=4, patch_size=8, load_size=64, num_heads=4, dtype=_lib.dtype_code(td),
-                         reserved=(_VARIANT_CODE[variant] << 8) | (2 if wtile else 0))
+    cc = _lib.NetConfigC(batch=2, n_feats=cfg.n_feats, hidden_dim_ratio=cfg.hidden_dim_ratio, patch_size=cfg.patch_size, load_size=cfg.load_size,
+                         num_heads=cfg.num_heads, dtype=_lib.dtype_code(td), reserved=(_VARIANT_CODE[cfg.variant] << 8) | (2 if wtile else 0))
     h = ctypes.c_void_p()
     assert lib.cfen_net_create(ctypes.byref(h), ctypes.byref(cc)) == 0, lib.cfen_last_error()
     keep = {}
@@ -94,3 +88,22 @@ def test_packed_parameters_are_exactly_what_the_launch_plan_asks_for(variant, wt
     buf = ctypes.create_string_buffer(1 << 16)
     assert lib.cfen_net_missing_params(h, buf, 1 << 16) == 0, buf.value[:400]
     lib.cfen_net_destroy(h)
+
+
+@pytest.mark.parametrize("variant,wtile", [("v3", False), ("v3", True), ("cfs", False), ("crs", False), ("v5", False), ("v5", True)])
+@pytest.mark.parametrize("dtype", ["fp16", "fp32"])
+def test_packed_parameters_are_exactly_what_the_launch_plan_asks_for(variant, wtile, dtype):
+    """packing.pack_state_dict (host) and cfen_net::build (csrc/cfen_net.cpp) must agree on every packed name and byte size, for each of
+    the four generators; set_param only records the pointer, so this runs without a GPU"""
+    from cfen_vit_dehazing_amd.config import NetConfig
+    _pack_and_register(NetConfig(24, 4, patch_size=8, load_size=64, variant=variant), dtype, wtile)
+
+
+@pytest.mark.parametrize("n_feats,hdr,patch,dtype", [(24, 3, 32, "fp16"), (24, 1, 32, "fp16"), (8, 4, 8, "fp16"), (8, 4, 8, "fp32"), (16, 3, 8, "fp16"),
+                                                    (32, 2, 8, "fp16")])
+def test_packed_parameters_match_the_plan_where_the_fused_kernels_do_not_apply(n_feats, hdr, patch, dtype):
+    """the host predicates (packing.window_fusable / mlp_is_fused / front_is_fused / mlp_is_streamed, the LayerNorm fold's 128-byte rule)
+    mirror cfen_net::build also off the benchmarked shape: odd hidden_dim_ratio at the window kernel's geometry (hidden % 64 != 0),
+    embedding dims whose rows are not whole 128-byte K steps (n_feats 8: D = 32, 128), and the D = 384 fragment-stream blocks"""
+    from cfen_vit_dehazing_amd.config import NetConfig
+    _pack_and_register(NetConfig(n_feats, hdr, patch_size=patch, load_size=8 * patch), dtype, True)

@@ -666,6 +666,55 @@ def test_fused_mlp_fold_epilogue(dtype):
     assert torch.equal(fm, want)
 
 
+@pytest.mark.parametrize("D,H,M", [(384, 1536, 300), (384, 768, 128), (384, 96, 31), (192, 768, 520), (192, 384, 256)])
+def test_mlp_stream_block(D, H, M):
+    """k_mlp3 (fragment-stream weights, one wave per SIMD): out_proj prologue + LN + FFN + mlp_head against fp64, every optional part on and off,
+    ragged token counts; the fold epilogue against unpatchify of the token-major result"""
+    dtype = torch.float16
+    d = dev()
+    x, att = rnd((M, D), 1, dtype), rnd((M, D), 2, dtype)
+    wp = rnd((D, D), 3, dtype, D ** -0.5)
+    g, b = 1 + 0.1 * rnd((D,), 4, torch.float32), 0.1 * rnd((D,), 5, torch.float32)
+    w1a, w2a = rnd((H, D), 6, dtype, D ** -0.5), rnd((D, H), 7, dtype, 0.5 * H ** -0.5)
+    w1b, w2b = rnd((H, D), 8, dtype, D ** -0.5), rnd((D, H), 9, dtype, 0.5 * H ** -0.5)
+    b1a, b2a, b1b, b2b = (0.1 * rnd((n,), 10 + i, torch.float32) for i, n in enumerate((H, D, H, D)))
+    kd, kh = packing.kperm32(D), packing.kperm32(H)
+    sa = packing.pack_stream_pair(w1a[:, kd], w2a[:, kh]).to(d)
+    sb = packing.pack_stream_pair(w1b[:, kd], w2b[:, kh]).to(d)
+    sp = packing.pack_stream_sq(wp).to(d)
+    xd = x.double()
+    ffn = lambda v, w1, b1, w2, b2, ln: v + torch.relu((cfen_oracle.layer_norm(v, g.double(), b.double()) if ln else v) @ w1.double().t()
+                                                       + b1.double()) @ w2.double().t() + b2.double()
+    y1 = ffn(xd, w1a, b1a, w2a, b2a, True)
+    close(ops.mlp_stream_block(x.to(d), sa, b1a.to(d), b2a.to(d), H, ln=(g.to(d), b.to(d))), y1, tol(dtype, 6), "stage a")
+    close(ops.mlp_stream_block(x.to(d), sa, b1a.to(d), b2a.to(d), H), ffn(xd, w1a, b1a, w2a, b2a, False), tol(dtype, 6), "no LN")
+    y2 = ffn(y1, w1b, b1b, w2b, b2b, False)
+    two = ops.mlp_stream_block(x.to(d), sa, b1a.to(d), b2a.to(d), H, ln=(g.to(d), b.to(d)), second=(sb, b1b.to(d), b2b.to(d)))
+    close(two, y2, tol(dtype, 10), "both stages")
+    x1 = xd + att.double() @ wp.double().t()
+    full = ffn(ffn(x1, w1a, b1a, w2a, b2a, True), w1b, b1b, w2b, b2b, False)
+    got = ops.mlp_stream_block(x.to(d), sa, b1a.to(d), b2a.to(d), H, ln=(g.to(d), b.to(d)), second=(sb, b1b.to(d), b2b.to(d)), proj=(att.to(d), sp))
+    close(got, full, tol(dtype, 12), "projection prologue + both stages")
+    again = ops.mlp_stream_block(x.to(d), sa, b1a.to(d), b2a.to(d), H, ln=(g.to(d), b.to(d)), second=(sb, b1b.to(d), b2b.to(d)), proj=(att.to(d), sp))
+    assert torch.equal(got, again)
+
+
+def test_mlp_stream_fold_epilogue():
+    # D = 384 = 2*2*96: 8x8 windows of 2x2 patches on a 16x32 map
+    dtype = torch.float16
+    B, C, Hm, Wm, ws, pp, cs = 2, 96, 16, 32, 8, 2, 96
+    D, H = 384, 256
+    M = B * Hm * Wm // 4
+    x = rnd((M, D), 1, dtype)
+    w1, w2 = rnd((H, D), 2, dtype, D ** -0.5), rnd((D, H), 3, dtype, H ** -0.5)
+    b1, b2 = 0.1 * rnd((H,), 4, torch.float32), 0.1 * rnd((D,), 5, torch.float32)
+    d = dev()
+    st = packing.pack_stream_pair(w1[:, packing.kperm32(D)], w2[:, packing.kperm32(H)]).to(d)
+    tok = ops.mlp_stream_block(x.to(d), st, b1.to(d), b2.to(d), H)
+    fm = ops.mlp_stream_block(x.to(d), st, b1.to(d), b2.to(d), H, fold=(B, Hm, Wm, C, cs, ws, pp))
+    assert torch.equal(fm, ops.unpatchify(tok, B, Hm, Wm, C, cs, ws, pp))
+
+
 # ---------------------------------------------------------------------------------------------------
 def _lvit_instance(seed):
     """one LViT level-1 instance (C = 24, D = 96, 4 heads, hidden 384) with the deterministic 'trained' weight distribution"""
