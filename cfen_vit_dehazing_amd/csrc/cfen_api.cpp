@@ -139,7 +139,9 @@ int cfen_tune(const char* key, int value) {
     return CFEN_OK;
   }
   if (!strcmp(key, "gemm.large") || !strcmp(key, "gemm.small")) {
-    CFEN_CHECK_ARG(value % 10 >= 2 && value % 10 <= 5 && value >= 2 && value <= 25, "tune: %s must be tile 2 .. 5 (+10 / +20 for 3 / 4 LDS stages)", key);
+    CFEN_CHECK_ARG(value == 2 || value == 3 || value == 4 || value == 5 || value == 12 || value == 13 || value == 14 || value == 15 || value == 22 || value == 23 ||
+                   value == 24 || value == 25 || value == 34 || value == 45 || value == 65,
+                   "tune: %s must be tile 2 .. 5 (+10 / +20 for 3 / 4 LDS stages; 34 = tile 4 with 5 stages, 45 / 65 = tile 5 with 6 / 8 stages)", key);
     (key[5] == 'l' ? cfen_tune_gemm_large() : cfen_tune_gemm_small()) = value;
     return CFEN_OK;
   }
@@ -170,6 +172,20 @@ int cfen_tune(const char* key, int value) {
   }
   if (!strcmp(key, "embed.lds")) {
     cfen_tune_embed_lds() = value & 7;
+    return CFEN_OK;
+  }
+  if (!strcmp(key, "mlp3.debug")) {
+    cfen_tune_mlp3_debug() = value;
+    return CFEN_OK;
+  }
+  if (!strcmp(key, "gemm.m128")) {
+    CFEN_CHECK_ARG(value == 0 || value == 2 || value == 32 || value == 3 || value == 4 || value == 14 || value == 34, "tune: gemm.m128 is 0 or a k_gemm_dma tile id");
+    cfen_tune_gemm_m128() = value;
+    return CFEN_OK;
+  }
+  if (!strcmp(key, "gemm.splitk_stages")) {
+    CFEN_CHECK_ARG(value == 0 || value == 3, "tune: gemm.splitk_stages is 0 or 3");
+    cfen_tune_gemm_splitk_stages() = value;
     return CFEN_OK;
   }
   if (!strcmp(key, "gemm.splitk")) {

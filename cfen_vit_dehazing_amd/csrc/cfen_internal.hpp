@@ -97,6 +97,9 @@ int& cfen_tune_mlp_small_tiles();   // fused-MLP tiling ("mlp.small_tiles"): 0 2
 int& cfen_tune_skip_classes();    // bit mask of kernel classes NOT launched by the net (marginal-cost timing; outputs invalid) ("net.skip_classes")
 int& cfen_tune_ln_fold();               // 1: LN1 / LN2 of the blocks without a fused kernel ride on the qkv / ffn1 GEMM ("net.ln_fold")
 int& cfen_tune_fused_front_max_dim();   // k_embed_qkv is used for LViT embedding dims <= this (0 = never) ("net.fused_front_max_dim")
+int& cfen_tune_gemm_splitk_stages();   // ring depth of the split-K tile beyond two stages: 0 or 3 ("gemm.splitk_stages")
+int& cfen_tune_mlp3_debug();         // k_mlp3 timing experiments (results invalid): 1 no DMA refills, 2 no MFMAs ("mlp3.debug")
+int& cfen_tune_gemm_m128();          // tile id (+10 per extra stage) for problems of <= 128 tokens, 0 = shape rule ("gemm.m128")
 int& cfen_tune_gemm_splitk();     // 1 (default): K-heavy few-token GEMMs run split-K when the caller provides scratch ("gemm.splitk")
 int& cfen_tune_lvit_window();        // 1 (default): LViT level 1 runs as one k_lvit_window launch per instance group ("net.lvit_window")
 int& cfen_tune_fold_in_gemm();      // 1 (default): the last GEMM of an unfused block folds its tokens into the map itself ("net.fold_in_gemm")

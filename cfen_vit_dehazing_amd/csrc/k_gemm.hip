@@ -313,6 +313,17 @@ CFEN_DEV void dma16(const void* g, unsigned char* l) {
   __builtin_amdgcn_global_load_lds(g, (__attribute__((address_space(3))) void*)l, 16, 0, 0);
 }
 
+// wait until at most `younger` K-steps of LOADS LDS-DMAs each are still in flight (younger <= Y)
+template <int LOADS, int Y>
+CFEN_DEV void gemm_wait_steps(int younger) {
+  if constexpr (Y == 0) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  } else {
+    if (younger >= Y) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(Y * LOADS) : "memory");
+    else gemm_wait_steps<LOADS, Y - 1>(younger);
+  }
+}
+
 // NS LDS stages form a ring: NS - 1 K-steps of DMA are in flight while one is consumed, one barrier per K-step.
 // TN = 6, TM = 4 (192 x 128 block, 96 x 64 per wave): per K-step a wave reads (6 + 4) fragments for 24 MFMAs instead of (3 + 2) for 6
 // and the L2 -> LDS traffic per flop halves -- and it is slower on every GEMM of this network, see cfen_tune_gemm_big().
@@ -326,7 +337,7 @@ __global__ __launch_bounds__(256, (TN > 3 && NS == 2) ? 2 : 1) void k_gemm_dma(G
   constexpr int BM = 32 * TM, ROWS = G_BN + BM, LOADS = ROWS / 32;
   constexpr int STAGE = ROWS * G_BKB;    // 28 KiB at TM = 4
   typedef typename Mma<T>::frag frag;
-  static_assert(NS * STAGE <= 160 * 1024, "LDS");
+  static_assert(NS * STAGE <= 160 * 1024 && (NS - 2) * LOADS < 64, "LDS / vmcnt range");
   __shared__ __attribute__((aligned(1024))) unsigned char lds[NS * STAGE];
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -389,10 +400,9 @@ __global__ __launch_bounds__(256, (TN > 3 && NS == 2) ? 2 : 1) void k_gemm_dma(G
   int buf = 0, fill = NS - 1;   // ring slots: `buf` is consumed at this step, `fill` receives K-step kt + NS - 1
   for (int kt = 0; kt < nk; ++kt) {
     // K-step kt must have landed; the younger K-steps (at most NS - 2 groups of LOADS DMAs) may stay in flight
-    const int younger = min(NS - 2, nk - 1 - kt);
-    if (younger >= 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * LOADS) : "memory");
-    else if (younger == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LOADS) : "memory");
-    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    // (round 3: counted for EVERY ring depth -- the round-2 chain stopped at two K-steps in flight, so rings deeper than four stages
+    // only cost LDS and the "deeper rings do not help" measurement of DESIGN 4.2 never had more than two K-steps in flight)
+    gemm_wait_steps<LOADS, NS - 2>(min(NS - 2, nk - 1 - kt));
     __builtin_amdgcn_s_barrier();   // K-step kt visible to all waves; all waves are done with the slot consumed at kt - 1
     if (kt + NS - 1 < nk) CFEN_GEMM_DMA_ISSUE(kt + NS - 1, fill);
     const unsigned char* st = lds + buf * STAGE;
@@ -603,7 +613,7 @@ int launch_gemm(int ng, const CfenGemmPtrs* gp, int ldx, int ldw, int ldr, int p
     const int nk = K / (G_BKB / (int)sizeof(T));
     nsplit = 8;
     while (nsplit > 1 && (nk % nsplit || (size_t)nsplit * M * N * sizeof(float) > splitk_ws_bytes)) nsplit /= 2;
-    if (nsplit > 1) { kern = 2; stages = 2; }
+    if (nsplit > 1) { kern = 2; stages = 2 + cfen_tune_gemm_splitk_stages(); }
   }
   // many tokens against >= 768 features (LViT-3 / GViT-1 qkv, ffn1, head1): 192 x 128 tiles when they still fill the chip
   const long long tiles_big = (long long)ng * ((N + 191) / 192) * ((M + 127) / 128);
@@ -615,6 +625,11 @@ int launch_gemm(int ng, const CfenGemmPtrs* gp, int ldx, int ldw, int ldr, int p
     const int pick = !k128 ? 0 : (M <= 128 && N <= 2048 && !tg && !lnf) ? 1 : tiles64 >= 1024 ? cfen_tune_gemm_large() : tiles32 <= 512 ? cfen_tune_gemm_small() : 5;
     kern = pick % 10;
     stages = 2 + pick / 10;
+  }
+  // experiment knob: few-token problems (M <= 128) take this tile id (2 = 96 x 128: every weight byte is pulled by ONE workgroup)
+  if (cfen_tune_gemm_m128() > 0 && forced < 0 && nsplit == 1 && M <= 128 && k128 && !tg) {
+    kern = cfen_tune_gemm_m128() % 10;
+    stages = 2 + cfen_tune_gemm_m128() / 10;
   }
   if (gp[0].wtile) {   // tile-major weights: the LDS-DMA kernel with 96-feature tiles (the skinny / register-staged kernels read rows)
     CFEN_CHECK_ARG(k128, "gemm (tile-major weights): needs K * sizeof(T) %% 128 == 0");
@@ -643,6 +658,11 @@ int launch_gemm(int ng, const CfenGemmPtrs* gp, int ldx, int ldw, int ldr, int p
     case 14: case 24: CFEN_LAUNCH((k_gemm_dma<T, 2, 3>), grid, dim3(256), 0, s, ga); break;
     case 5: CFEN_LAUNCH((k_gemm_dma<T, 1, 2>), grid, dim3(256), 0, s, ga); break;
     case 15: CFEN_LAUNCH((k_gemm_dma<T, 1, 3>), grid, dim3(256), 0, s, ga); break;
+    case 25: CFEN_LAUNCH((k_gemm_dma<T, 1, 4>), grid, dim3(256), 0, s, ga); break;
+    case 45: CFEN_LAUNCH((k_gemm_dma<T, 1, 6>), grid, dim3(256), 0, s, ga); break;
+    case 65: CFEN_LAUNCH((k_gemm_dma<T, 1, 8>), grid, dim3(256), 0, s, ga); break;
+    case 34: CFEN_LAUNCH((k_gemm_dma<T, 2, 5>), grid, dim3(256), 0, s, ga); break;
+    case 32: CFEN_LAUNCH((k_gemm_dma<T, 4, 5>), grid, dim3(256), 0, s, ga); break;
     case 6: case 16: case 26: CFEN_LAUNCH((k_gemm_dma<T, 4, 2, 6>), grid, dim3(256), 0, s, ga); break;
     default: CFEN_LAUNCH((k_gemm_dma<T, 1, 4>), grid, dim3(256), 0, s, ga); break;
   }
@@ -675,6 +695,14 @@ int& cfen_tune_gemm_big() {
 }
 int& cfen_tune_gemm_big_min_tiles() {   // the 192 x 128 tile is used when a launch has at least this many of them
   static int v = 256;
+  return v;
+}
+int& cfen_tune_gemm_splitk_stages() {   // extra ring stages of the 96 x 128 split-K tile: 0 (two stages) or 3 (five stages, 140 KB)
+  static int v = 0;
+  return v;
+}
+int& cfen_tune_gemm_m128() {
+  static int v = 0;
   return v;
 }
 int& cfen_tune_gemm_large() {

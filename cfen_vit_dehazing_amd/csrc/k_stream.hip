@@ -47,13 +47,36 @@ CFEN_DEV void wait_phases(int younger) {
   }
 }
 
+// LDS fragment reads and their waits by hand.  hipcc's own waits around a "read the next group, multiply the current one" loop came out as
+// s_waitcnt lgkmcnt(0) right behind the freshly issued reads (every second group waited a full LDS round trip: the kernel ran 137 us with
+// its DMA refills removed against 65 us of MFMA time).  Inline-asm reads are invisible to the compiler's counter, so EVERY LDS read between a
+// phase's barrier and its end goes through these two helpers and the waits are counted here: LDS returns in order, read f is complete once
+// at most (reads issued after f) are outstanding; the "+v" operand keeps the MFMAs that consume the register behind the wait.
+template <int OFF>
+CFEN_DEV void lds_rd(half8& f, unsigned addr) {
+  asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(f) : "v"(addr), "n"(OFF));
+}
+template <int OFF>
+CFEN_DEV void lds_rd(floatx4& f, unsigned addr) {
+  asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(f) : "v"(addr), "n"(OFF));
+}
+template <int N>
+CFEN_DEV void lds_wait(half8& f) {
+  asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(f) : "n"(N));
+}
+template <int N>
+CFEN_DEV void lds_wait(half8& f, floatx4& b0, floatx4& b1) {
+  asm volatile("s_waitcnt lgkmcnt(%3)" : "+v"(f), "+v"(b0), "+v"(b1) : "n"(N));
+}
+
 CFEN_DEV half8 pack_pair(const floatx4& a, const floatx4& b) {
   half8 f = {(half_t)a[0], (half_t)a[1], (half_t)a[2], (half_t)a[3], (half_t)b[0], (half_t)b[1], (half_t)b[2], (half_t)b[3]};
   return f;
 }
 
 // ND = D / 16 feature tiles, TM token tiles of 16 per wave, R ring slots of ND KiB, HB = largest hidden width (bias staging area)
-template <int ND, int TM, int R, int HB>
+// DBG (timing experiments only, results invalid): 1 = no LDS-DMA refills after the prologue, 2 = no MFMAs in the hidden loop
+template <int ND, int TM, int R, int HB, int DBG = 0>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void k_mlp3(Grouped<Mlp3Args> ga) {
   typedef half_t T;
   typedef half8 frag;
@@ -126,37 +149,42 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
   };
   // ... which phase p + R - 1 may now overwrite (called after the phase's first fragment reads are issued)
   auto refill = [&]() {
-    if (p + R - 1 < NP) issue(p + R - 1, fill);
+    if (DBG != 1 && p + R - 1 < NP) issue(p + R - 1, fill);
     fill = cur;
     cur = cur + 1 == R ? 0 : cur + 1;
     ++p;
   };
-  const int fo = lane * 16;
-  auto loadg = [&](const unsigned char* s, auto gc, frag (&f)[3]) {
-    constexpr int g = decltype(gc)::value;
-#pragma unroll
-    for (int k = 0; k < 3; ++k) f[k] = *reinterpret_cast<const frag*>(s + (3 * g + k) * 1024 + fo);
+  // LDS byte addresses (the low 32 bits of a generic pointer into LDS are its LDS offset)
+  const unsigned lbase = (unsigned)(unsigned long long)(__attribute__((address_space(3))) unsigned char*)lds;
+  const unsigned lfrag = lbase + lane * 16;     // + slot * SLOT + fragment * 1024
+  constexpr int PD = 6, NB = 8;                 // fragment reads in flight ahead of the MFMAs / registers of the fragment ring
+  static_assert(PD < NB && PD <= ND, "fragment ring");
+  // one phase: ND fragments, each consumed by body(index, fragment); `pre` runs once the first PD reads are issued (the DMA refill)
+  auto phase = [&](unsigned sa, auto&& pre, auto&& body) {
+    frag F[NB];
+    sfor<0, PD>([&](auto fc) {
+      constexpr int f = decltype(fc)::value;
+      lds_rd<f * 1024>(F[f % NB], sa);
+    });
+    pre();
+    sfor<0, ND>([&](auto fc) {
+      constexpr int f = decltype(fc)::value;
+      if constexpr (f + PD < ND) lds_rd<(f + PD) * 1024>(F[(f + PD) % NB], sa);
+      lds_wait<(f + PD < ND ? PD : ND - 1 - f)>(F[f % NB]);
+      body(fc, F[f % NB]);
+    });
   };
 
   // ---- x += Wp att (out_proj + residual, v3:1386): phase c = k-chunk c of all ND feature tiles ----
   if (a.Wp) {
     sfor<0, NCH>([&](auto cc) {
       constexpr int c = decltype(cc)::value;
-      const unsigned char* s = begin();
-      frag F[2][3];
-      loadg(s, std::integral_constant<int, 0>{}, F[0]);
-      refill();
-      sfor<0, NG>([&](auto gc) {
-        constexpr int g = decltype(gc)::value;
-        if constexpr (g + 1 < NG) loadg(s, std::integral_constant<int, g + 1>{}, F[(g + 1) & 1]);
-        __builtin_amdgcn_sched_barrier(0);
+      begin();
+      phase(lfrag + cur * SLOT, [&]() { refill(); }, [&](auto fc, const frag& fr) {
+        constexpr int f = decltype(fc)::value;
 #pragma unroll
-        for (int k = 0; k < 3; ++k)
-#pragma unroll
-          for (int j = 0; j < TM; ++j) acc[3 * g + k][j] = Mma<T>::mma(F[g & 1][k], xb[c][j], acc[3 * g + k][j]);
-        __builtin_amdgcn_sched_barrier(0);
+        for (int j = 0; j < TM; ++j) acc[f][j] = Mma<T>::mma(fr, xb[c][j], acc[f][j]);
       });
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     });
   }
 
@@ -212,54 +240,47 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
   auto substep = [&](int t, int stage) {
     // -- W1 phase: hidden[32 units][tokens] = W1 slice . xb + b1 (fragment f = u * NCH + c) --
     {
-      const unsigned char* s = begin();
-      frag F[2][3];
-      loadg(s, std::integral_constant<int, 0>{}, F[0]);
-      const unsigned char* bl = lds + RING + stage * (HB * 4) + (t * 32 + 4 * h) * 4;
-      const floatx4 bv0 = *reinterpret_cast<const floatx4*>(bl), bv1 = *reinterpret_cast<const floatx4*>(bl + 64);
-      refill();
-      sfor<0, NG>([&](auto gc) {
-        constexpr int g = decltype(gc)::value, u = (3 * g) / NCH, c0 = (3 * g) % NCH;
-        if constexpr (g + 1 < NG) loadg(s, std::integral_constant<int, g + 1>{}, F[(g + 1) & 1]);
-        __builtin_amdgcn_sched_barrier(0);
-        if constexpr (c0 == 0) {
+      begin();
+      floatx4 bv0, bv1;
+      const unsigned ba = lbase + RING + stage * (HB * 4) + (t * 32 + 4 * h) * 4;
+      lds_rd<0>(bv0, ba);
+      lds_rd<64>(bv1, ba);
+      phase(lfrag + cur * SLOT, [&]() { refill(); }, [&](auto fc, frag& fr) {
+        constexpr int f = decltype(fc)::value, u = f / NCH, c = f % NCH;
+        if constexpr (f == 0) lds_wait<PD>(fr, bv0, bv1);   // (the bias reads are older than every fragment read: landed with fragment 0)
+        if constexpr (c == 0) {
 #pragma unroll
           for (int j = 0; j < TM; ++j) hacc[u][j] = u ? bv1 : bv0;
         }
 #pragma unroll
-        for (int k = 0; k < 3; ++k)
-#pragma unroll
-          for (int j = 0; j < TM; ++j) hacc[u][j] = Mma<T>::mma(F[g & 1][k], xb[c0 + k][j], hacc[u][j]);
-        __builtin_amdgcn_sched_barrier(0);
+        for (int j = 0; j < TM; ++j) {
+          if constexpr (DBG == 2) hacc[u][j][0] += (float)fr[0] * (float)xb[c][j][0];
+          else hacc[u][j] = Mma<T>::mma(fr, xb[c][j], hacc[u][j]);
+        }
       });
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     }
     // -- W2 phase: y += W2[:, slice] . relu(hidden) (fragment f = feature tile) --
     {
-      const unsigned char* s = begin();
-      frag F[2][3];
-      loadg(s, std::integral_constant<int, 0>{}, F[0]);
-      refill();
+      begin();
       frag hb[TM];
+      phase(lfrag + cur * SLOT, [&]() {
+        refill();
 #pragma unroll
-      for (int j = 0; j < TM; ++j) {
-        const half8 v = pack_pair(hacc[0][j], hacc[1][j]);
-        half8 z;
+        for (int j = 0; j < TM; ++j) {
+          const half8 v = pack_pair(hacc[0][j], hacc[1][j]);
+          half8 z;
 #pragma unroll
-        for (int e = 0; e < 8; ++e) z[e] = (half_t)0;
-        hb[j] = __builtin_elementwise_max(v, z);
-      }
-      sfor<0, NG>([&](auto gc) {
-        constexpr int g = decltype(gc)::value;
-        if constexpr (g + 1 < NG) loadg(s, std::integral_constant<int, g + 1>{}, F[(g + 1) & 1]);
-        __builtin_amdgcn_sched_barrier(0);
+          for (int e = 0; e < 8; ++e) z[e] = (half_t)0;
+          hb[j] = __builtin_elementwise_max(v, z);
+        }
+      }, [&](auto fc, const frag& fr) {
+        constexpr int f = decltype(fc)::value;
 #pragma unroll
-        for (int k = 0; k < 3; ++k)
-#pragma unroll
-          for (int j = 0; j < TM; ++j) acc[3 * g + k][j] = Mma<T>::mma(F[g & 1][k], hb[j], acc[3 * g + k][j]);
-        __builtin_amdgcn_sched_barrier(0);
+        for (int j = 0; j < TM; ++j) {
+          if constexpr (DBG == 2) acc[f][j][0] += (float)fr[0] * (float)hb[j][0];
+          else acc[f][j] = Mma<T>::mma(fr, hb[j], acc[f][j]);
+        }
       });
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     }
   };
 #pragma unroll 1
@@ -310,19 +331,24 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
   }
 }
 
-template <int ND, int TM, int R, int HB>
+template <int ND, int TM, int R, int HB, int DBG = 0>
 int launch_mlp3(int ng, const Mlp3Args* ap, hipStream_t s) {
   Grouped<Mlp3Args> ga;
   for (int g = 0; g < CFEN_MAX_GROUPS; ++g) ga.g[g] = ap[g < ng ? g : 0];
   CFEN_CHECK_ARG(ap[0].H <= HB, "mlp3: hidden width %d exceeds the %d this variant stages biases for", ap[0].H, HB);
   const long long per = 4LL * TM * 16, blocks = (ap[0].M + per - 1) / per;
   CFEN_CHECK_ARG(blocks > 0 && blocks < (1ll << 31), "mlp3: bad grid");
-  CFEN_LAUNCH((k_mlp3<ND, TM, R, HB>), dim3((unsigned)blocks, 1, ng), dim3(256), 0, s, ga);
+  CFEN_LAUNCH((k_mlp3<ND, TM, R, HB, DBG>), dim3((unsigned)blocks, 1, ng), dim3(256), 0, s, ga);
   CFEN_CHECK_LAUNCH("mlp3");
   return CFEN_OK;
 }
 
 }  // namespace
+
+int& cfen_tune_mlp3_debug() {
+  static int v = 0;
+  return v;
+}
 
 bool cfen_mlp3_supported(int dtype, int D, int H) { return dtype == 1 && (D == 384 || D == 192) && H % 32 == 0 && H > 0 && H <= (D == 384 ? 1536 : 768); }
 
@@ -348,6 +374,8 @@ int cfen_mlp3_impl_g(int dtype, int ng, const Mlp3Args* ap, hipStream_t s) {
                    (a.ln_g == nullptr) == (ap[0].ln_g == nullptr) && (a.Wp == nullptr) == (ap[0].Wp == nullptr) && (a.fmap == nullptr) == (ap[0].fmap == nullptr),
                    "mlp3: grouped problems must have the same shape");
   }
+  if (ap[0].D == 384 && cfen_tune_mlp3_debug() == 1) return launch_mlp3<24, 2, 6, 1536, 1>(ng, ap, s);
+  if (ap[0].D == 384 && cfen_tune_mlp3_debug() == 2) return launch_mlp3<24, 2, 6, 1536, 2>(ng, ap, s);
   if (ap[0].D == 384) return launch_mlp3<24, 2, 6, 1536>(ng, ap, s);
   return launch_mlp3<12, 4, 8, 768>(ng, ap, s);
 }
