@@ -78,6 +78,7 @@ SIGNATURES = {
     "cfen_net_flops_per_image": (ctypes.c_double, [_P]),
     "cfen_gemm_nt": (_I, [_I, _P, _I, _P, _I, _P, _P, _I, _P, _I, _P, _I, _I, _I, _I, _I, _P]),
     "cfen_gemm_ln": (_I, [_I, _P, _I, _P, _I, _P, _P, _P, _I, _I, _I, _I, _I, ctypes.c_float, _P]),
+    "cfen_gemm_splitk": (_I, [_I, _P, _I, _P, _I, _P, _P, _P, _I, _P, _I, _I, _I, _I, _I, _I, _P, c_size_t, _P]),
     "cfen_embed_gather": (_I, [_I, _P, _I, _I, _I, _I, _I, _I, _I, _P, _I, _P, _P, _I, _P, _I, _P]),
     "cfen_u8hwc_to_nhwc": (_I, [_I, _P, _P, _I, _I, _I, _I, _P]),
     "cfen_tensor2im_u8": (_I, [_P, _P, _I, _I, _I, _P]),

@@ -24,6 +24,30 @@ CfenGraphRecorder*& cfen_recorder() {
   static thread_local CfenGraphRecorder* rec = nullptr;
   return rec;
 }
+// zero `bytes` of device memory on a lane: eagerly, or as a memset node of the graph being built
+int cfen_zero_async(void* p, size_t bytes, hipStream_t s) {
+  CFEN_CHECK_ARG(p && bytes % 4 == 0, "zero_async: bad region");
+  if (CfenGraphRecorder* rec = cfen_recorder()) {
+    hipMemsetParams mp;
+    memset(&mp, 0, sizeof(mp));
+    mp.dst = p; mp.elementSize = 4; mp.width = bytes / 4; mp.height = 1; mp.pitch = bytes; mp.value = 0;
+    std::vector<hipGraphNode_t>& deps = rec->tail[s];
+    hipGraphNode_t node;
+    if (hipGraphAddMemsetNode(&node, rec->graph, deps.empty() ? nullptr : deps.data(), deps.size(), &mp) != hipSuccess) {
+      cfen_set_error("zero_async: hipGraphAddMemsetNode failed");
+      return CFEN_ERR_HIP;
+    }
+    deps.assign(1, node);
+    ++rec->nodes;
+    return CFEN_OK;
+  }
+  if (hipMemsetAsync(p, 0, bytes, s) != hipSuccess) {
+    cfen_set_error("zero_async: hipMemsetAsync failed");
+    return CFEN_ERR_HIP;
+  }
+  return CFEN_OK;
+}
+
 hipError_t& cfen_last_launch() {
   static thread_local hipError_t e = hipSuccess;
   return e;
@@ -45,6 +69,14 @@ int cfen_gemm_ln(int dtype, const void* X, int ldx, const void* Wl, int ldw, con
   CFEN_CHECK_ARG(eps == cfen_gemm_lnf_eps(), "gemm_ln: eps must be %g (the generator's only LayerNorm eps)", (double)cfen_gemm_lnf_eps());
   const CfenGemmPtrs q{X, Wl, bias, nullptr, nullptr, Y, nullptr, s};
   return cfen_gemm_impl_g(dtype, 1, &q, ldx, ldw, 0, 1, ldy, M, N, K, relu, nullptr, (hipStream_t)stream, nullptr, 0);
+}
+
+int cfen_gemm_splitk(int dtype, const void* X, int ldx, const void* W, int ldw, const float* lnf_s, const float* bias, const void* R, int ldr, void* Y,
+                      int ldy, int M, int N, int K, int relu, int nsplit, void* scratch, size_t scratch_bytes, void* stream) {
+  CFEN_CHECK_ARG(nsplit >= 1 && scratch && cfen_aligned16(scratch), "gemm_splitk: needs nsplit >= 1 and an aligned scratch buffer");
+  const CfenGemmPtrs q{X, W, bias, R, nullptr, Y, nullptr, lnf_s};
+  float* ws = (float*)scratch;
+  return cfen_gemm_impl_g(dtype, 1, &q, ldx, ldw, ldr, 1, ldy, M, N, K, relu, nullptr, (hipStream_t)stream, &ws, scratch_bytes, nullptr, nsplit);
 }
 
 int cfen_layernorm(int dtype, const void* X, void* Y, const float* gamma, const float* beta, int M, int D, float eps, void* stream) {

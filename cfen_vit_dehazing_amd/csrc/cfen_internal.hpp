@@ -7,6 +7,7 @@ struct ConvDesc;
 
 int cfen_gemm_impl(int dtype, const void* X, int ldx, const void* W, int ldw, const float* bias, const void* R, int ldr, const void* P,
                    int period, void* Y, int ldy, int M, int N, int K, int relu, hipStream_t s);
+int cfen_zero_async(void* p, size_t bytes, hipStream_t s);   // memset 0 on a lane (eager, or a node of the graph being recorded)
 float& cfen_gemm_lnf_eps();   // LayerNorm eps used by the LN-folded GEMMs (1e-5, the only value the generator uses)
 // Y = tok W^T + bias + tok + P[m % period]  with tok = the patch tokens of an NHWC map, gathered by the GEMM's loader
 // (window partition + unfold + linear_encoding + residual + position add in one launch; v3:1025-1056,1140-1143,1166)
@@ -39,8 +40,12 @@ struct CfenGemmPtrs {
   void* ymap = nullptr;   // fold: Y goes into this NHWC map (geometry = cfen_gemm_impl_g's `yg`), see GemmArgs::ymap
 };
 int cfen_gemm_impl_g(int dtype, int ng, const CfenGemmPtrs* gp, int ldx, int ldw, int ldr, int period, int ldy, int M, int N, int K, int relu,
-                     const CfenTokGather* tg, hipStream_t s, float* const* splitk_ws, size_t splitk_ws_bytes, const CfenTokGather* yg = nullptr);
-// tg: geometry only, the maps are gp[g].gmap.  splitk_ws (may be null): one fp32 scratch per problem for split-K partial sums
+                     const CfenTokGather* tg, hipStream_t s, float* const* splitk_ws, size_t splitk_ws_bytes, const CfenTokGather* yg = nullptr,
+                     int force_nsplit = 0);
+// tg: geometry only, the maps are gp[g].gmap.  splitk_ws (may be null): one scratch per problem for split-K: CFEN_SPLITK_COUNTERS arrival
+// counters (unsigned, ZERO before the first use; every launch leaves them zero) followed by the fp32 partial slabs.
+// force_nsplit: 0 = shape rule, 1 = never split, > 1 = exactly this many K slices (tests)
+constexpr int CFEN_SPLITK_COUNTERS = 1024;
 int cfen_patchify_impl_g(int dtype, int ng, const void* const* fmap, void* const* tok, int B, int H, int W, int C, int cs, int ws, int p, int pool,
                          int inverse, hipStream_t s);
 int cfen_upsample4_impl_g(int dtype, int ng, const void* const* small, void* const* out, int B, int h, int w, int C, int cs_in, int cs_out,

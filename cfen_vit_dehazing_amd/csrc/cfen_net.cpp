@@ -99,7 +99,8 @@ struct cfen_net {
   std::vector<Vit> vits;
   size_t ws_bytes = 0;
   // Token scratch, one set per concurrently running transformer block (LViT / GViT of branch A / B)
-  struct Scratch { size_t x0, x1, yn, qkv, att, hid, small; };
+  struct Scratch { size_t x0, x1, yn, qkv, att, hid, small, splitk; };   // splitk: arrival counters + partial slabs of the split-K GEMMs (GViT sets)
+  static constexpr size_t SPLITK_BYTES = 16u << 20;
   Scratch scr_set[6];
   size_t o_stats_set[3] = {0, 0, 0};
   // ActNorm2d layers whose parameters are still uninitialised (models/actnorm.py:25-37): the next EAGER forward runs the layer
@@ -413,6 +414,7 @@ int cfen_net::build() {
     q.qkv = alloc(3 * md * esz);
     q.hid = alloc(mh * esz);
     q.small = alloc(g ? max_small * esz : 256);
+    q.splitk = g ? alloc(SPLITK_BYTES) : 0;
   }
   for (int k = 0; k < 3; ++k) o_stats_set[k] = alloc(cfen_stats_workspace_bytes(3 * B, 128));   // [0] also serves the 3B-image InstanceNorm
   parallel = (cfg.reserved & 1) == 0;
@@ -541,7 +543,9 @@ int cfen_net::run_vit_g(int ng, const VitCall* vc, int scr0) {
     nm[g] = w.name;
   }
   const void* cHIDp[3] = {HID[0], HID[1], HID[2]};
-  const size_t scratch_stretch = scr_set[scr0].hid - scr_set[scr0].yn;   // bytes from YN to the end of QKV
+  float* SK[3] = {nullptr, nullptr, nullptr};   // split-K scratch of each member (GViT: few tokens against 0.5 GB of weights per forward)
+  if (v.global)
+    for (int g = 0; g < ng; ++g) SK[g] = (float*)at(scr_set[scr0 + 2 * g].splitk);
   const double Md = (double)M * ng, D = v.Dn, Hd = v.hidden;   // algorithmic flops count the real embedding dim
   auto step = [&](const char* what) { if (profiling) label = nm[0] + (ng > 1 ? " (x" + std::to_string(ng) + ")" : "") + ":" + what; };
   // Y = act(X W^T + bias) + R + P for every member; operand arrays are indexed by member
@@ -551,13 +555,7 @@ int cfen_net::run_vit_g(int ng, const VitCall* vc, int scr0) {
     for (int g = 0; g < ng; ++g)
       gp[g] = CfenGemmPtrs{tg ? nullptr : X[g], P(nm[g] + wname), bname ? Pf(nm[g] + bname) : nullptr, R ? R[g] : nullptr,
                            pname ? P(nm[g] + pname) : nullptr, Y[g], tg ? IN[g] : nullptr, nullptr, v.global && wtile};
-    // split-K scratch: the YN | ATT | QKV stretch of the member's scratch set (contiguous, 5 * md elements), free while the
-    // FFN / mlp_head GEMMs run -- the only K-heavy ones
-    float* ws[3] = {nullptr, nullptr, nullptr};
-    const bool ffn = X == (const void* const*)cHIDp;
-    if (ffn)
-      for (int g = 0; g < ng; ++g) ws[g] = (float*)YN[g];
-    return cfen_gemm_impl_g(dt, ng, gp, K, K, N, v.S, N, M, N, K, relu, tg, stream, ffn ? ws : nullptr, ffn ? scratch_stretch : 0);
+    return cfen_gemm_impl_g(dt, ng, gp, K, K, N, v.S, N, M, N, K, relu, tg, stream, v.global ? SK : nullptr, v.global ? SPLITK_BYTES : 0);
   };
   // Y = act(LN(X) W0^T + b0) with the LayerNorm folded: parameters `lname`.wl / .s / .bl (packing.ln_folded)
   auto gemm_ln = [&](const void* const* X, const std::string& lname, void* const* Y, int N, int K, int relu) -> int {
@@ -565,7 +563,7 @@ int cfen_net::run_vit_g(int ng, const VitCall* vc, int scr0) {
     for (int g = 0; g < ng; ++g)
       gp[g] = CfenGemmPtrs{X[g], P(nm[g] + lname + ".wl"), Pf(nm[g] + lname + ".bl"), nullptr, nullptr, Y[g], nullptr, Pf(nm[g] + lname + ".s"),
                            v.global && wtile};
-    return cfen_gemm_impl_g(dt, ng, gp, K, K, N, v.S, N, M, N, K, relu, nullptr, stream, nullptr, 0);
+    return cfen_gemm_impl_g(dt, ng, gp, K, K, N, v.S, N, M, N, K, relu, nullptr, stream, v.global ? SK : nullptr, v.global ? SPLITK_BYTES : 0);
   };
   if (v.fused_window && cfen_tune_lvit_window()) {
     // LViT level 1: one workgroup per window, embed -> attention -> MLP -> fold with q / k / v / attention output on chip (k_lvit.hip)
@@ -687,14 +685,12 @@ int cfen_net::run_vit_g(int ng, const VitCall* vc, int scr0) {
       // x = mlp_head(x) + x, folded: the GEMM's epilogue writes feature (i, j, c) of token m to its pixel of the map   (v3:1173, 1186)
       step("head2_fold");
       CfenGemmPtrs gp[3];
-      float* ws[3];
-      for (int g = 0; g < ng; ++g) {
+      for (int g = 0; g < ng; ++g)
         gp[g] = CfenGemmPtrs{HID[g], P(nm[g] + ".head2.w"), Pf(nm[g] + ".head2.b"), X1[g], nullptr, X0[g], nullptr, nullptr, v.global && wtile,
                              const_cast<void*>(dst[g])};
-        ws[g] = (float*)YN[g];
-      }
       const CfenTokGather yg{nullptr, B, v.mapH, v.mapH, v.C, v.global ? v.C : bo.cs, v.ws, v.p};
-      TRYP(K_GEMM, 2 * Md * D * Hd, cfen_gemm_impl_g(dt, ng, gp, v.hidden, v.hidden, v.D, v.S, v.D, M, v.D, v.hidden, 0, nullptr, stream, ws, scratch_stretch, &yg));
+      TRYP(K_GEMM, 2 * Md * D * Hd, cfen_gemm_impl_g(dt, ng, gp, v.hidden, v.hidden, v.D, v.S, v.D, M, v.D, v.hidden, 0, nullptr, stream,
+                                                    v.global ? SK : nullptr, v.global ? SPLITK_BYTES : 0, &yg));
     } else {
       step("head2");
       TRYP(K_GEMM, 2 * Md * D * Hd, gemm(cHID, ".head2.w", ".head2.b", X1, nullptr, X0, v.D, v.hidden, 0, nullptr));
@@ -841,6 +837,8 @@ int cfen_net::forward(const float* x, float* xr, float* xs, float* xd) {
   const hipStream_t sg = par ? side[NSIDE - 1] : s0;   // only a marker "!= s0": run_level_g draws the real stream
   stream = s0;
   float* stats = (float*)at(o_stats_set[0]);
+  // arrival counters of the split-K GEMMs: every launch leaves them zero, this makes a forward independent of whatever ran (or died) before
+  for (int k = 1; k < 6; k += 2) TRY(cfen_zero_async(at(scr_set[k].splitk), CFEN_SPLITK_COUNTERS * sizeof(unsigned), stream));
   const Buf& bin = bufs.at("input");
   if (input_u8) {
     label = "input:u8hwc_to_nhwc";

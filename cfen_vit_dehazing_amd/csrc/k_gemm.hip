@@ -59,9 +59,11 @@ template <typename T> struct GemmArgs {
   // optional fold (v3:1186 F.fold + Join2x2): Y is not a token-major matrix but the NHWC map the tokens tile -- feature n = (i, j, c) of
   // token m is stored at pixel (y + i, x + j), channel c of `ymap` (same geometry fields; never together with the gather)
   T* ymap;
-  // optional split-K (k_gemm_dma only): blockIdx.y = K slice; partial sums go to `part` [nsplit][M][N] fp32 and
-  // k_gemm_splitk_finish adds them in slice order and applies the epilogue -- deterministic, no atomics
+  // optional split-K (k_gemm_dma only): blockIdx.y = K slice.  Every slice parks its fp32 accumulator tile (and its share of the LayerNorm
+  // row sums) in `part` [tile][slice][vector][thread]; the workgroup whose arrival ticket on cnt[tile] is the last one adds the nsplit
+  // slabs in slice order -- its own included, from memory -- and runs the epilogue: deterministic, no float atomics, no second launch
   float* part;
+  unsigned* cnt;   // one arrival counter per tile, zero between launches (the reducing workgroup puts its tile's back to zero)
   int nsplit;
   // optional LayerNorm fold (k_gemm_dma, nsplit == 1, K = the whole row): see CfenGemmPtrs::lnf_s
   const float* lnf_s;
@@ -433,15 +435,65 @@ __global__ __launch_bounds__(256, (TN > 3 && NS == 2) ? 2 : 1) void k_gemm_dma(G
     buf = buf + 1 == NS ? 0 : buf + 1;
   }
 
-  if (a.nsplit > 1) {   // fp32 partial tile of this K slice
-    float* pp = a.part + (size_t)blockIdx.y * a.M * a.N;
-    const int n = n0 + wn * 16 * TN + 4 * h, m = m0 + wm * 16 * TM + r16;
+  if (a.nsplit > 1) {
+    // In-launch reduction (guide: "Projection GEMM at M = 256", item 2, write-through form): the slab goes out with sc1 (write-through)
+    // 16-byte stores, whole 128-byte lines per wave-instruction -> every wave drains its stores -> workgroup barrier -> lane 0 takes a relaxed
+    // agent-scope ticket (no release fence: a buffer_wbl2 in every one of ~1000 workgroups cost 3x the GEMM itself, measured) -> the last
+    // arriver: agent-scope acquire, drain, barrier, plain loads.  Correct for any placement of a tile's slices over CUs / XCDs; nobody waits
+    // for anybody (no spin), so it cannot hang.
+    constexpr int NV = TN * TM;
+    typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+    const int tile = tm * a.map.gn + tn;
+    const size_t slab = (size_t)(NV * 4 + 2 * TM) * 256;   // floats per (tile, slice): NV accumulator vectors, then (sum, sum of squares) per token tile
+    const __amdgpu_buffer_rsrc_t prs = __builtin_amdgcn_make_buffer_rsrc(a.part, 0, -1, 0x00020000);
+    const unsigned pbase = (unsigned)(((size_t)tile * a.nsplit + blockIdx.y) * slab * 4);   // byte offset of this slice's slab (< 2^32: checked on the host)
 #pragma unroll
-    for (int j = 0; j < TM; ++j)
+    for (int i = 0; i < TN; ++i)
+#pragma unroll
+      for (int j = 0; j < TM; ++j) {
+        const floatx4 v = acc[i][j];
+        const u32x4 bits = {__float_as_uint(v[0]), __float_as_uint(v[1]), __float_as_uint(v[2]), __float_as_uint(v[3])};
+        __builtin_amdgcn_raw_buffer_store_b128(bits, prs, (int)(pbase + ((i * TM + j) * 256 + tid) * 16), 0, 16);   // aux 16 = sc1
+      }
+    if (a.lnf_s) {
+#pragma unroll
+      for (int j = 0; j < TM; ++j) {
+        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(ls[j]), prs, (int)(pbase + (NV * 1024 + (2 * j) * 256 + tid) * 4), 0, 16);
+        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(lq[j]), prs, (int)(pbase + (NV * 1024 + (2 * j + 1) * 256 + tid) * 4), 0, 16);
+      }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    unsigned* flag = reinterpret_cast<unsigned*>(lds);     // the ring is free: every wave is past its last fragment read
+    if (tid == 0) *flag = __hip_atomic_fetch_add(a.cnt + tile, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __syncthreads();
+    if (*flag != (unsigned)(a.nsplit - 1)) return;
+    if (tid == 0) {
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      a.cnt[tile] = 0u;                                    // zero again for the next launch that uses this counter
+    }
+    __syncthreads();
+    const float* p0 = a.part + (size_t)tile * a.nsplit * slab;
+#pragma unroll
+    for (int i = 0; i < TN; ++i)
+#pragma unroll
+      for (int j = 0; j < TM; ++j) acc[i][j] = *reinterpret_cast<const floatx4*>(p0 + ((i * TM + j) * 256 + tid) * 4);
+    if (a.lnf_s) {
+#pragma unroll
+      for (int j = 0; j < TM; ++j) { ls[j] = p0[NV * 1024 + (2 * j) * 256 + tid]; lq[j] = p0[NV * 1024 + (2 * j + 1) * 256 + tid]; }
+    }
+    for (int sl = 1; sl < a.nsplit; ++sl) {
+      const float* ps = p0 + (size_t)sl * slab;
 #pragma unroll
       for (int i = 0; i < TN; ++i)
-        if (m + 16 * j < a.M && n + 16 * i < a.N) *reinterpret_cast<floatx4*>(pp + (size_t)(m + 16 * j) * a.N + n + 16 * i) = acc[i][j];
-    return;
+#pragma unroll
+        for (int j = 0; j < TM; ++j) acc[i][j] += *reinterpret_cast<const floatx4*>(ps + ((i * TM + j) * 256 + tid) * 4);
+      if (a.lnf_s) {
+#pragma unroll
+        for (int j = 0; j < TM; ++j) { ls[j] += ps[NV * 1024 + (2 * j) * 256 + tid]; lq[j] += ps[NV * 1024 + (2 * j + 1) * 256 + tid]; }
+      }
+    }
   }
   if (a.lnf_s) {   // row statistics: reduce the 8 threads of a row (8 consecutive lanes), publish (mean, rstd) per row through LDS
     __builtin_amdgcn_s_barrier();            // every wave is done reading the last stage: the ring is free
@@ -464,26 +516,6 @@ __global__ __launch_bounds__(256, (TN > 3 && NS == 2) ? 2 : 1) void k_gemm_dma(G
   }
   gemm_epilogue<T, TM, TN>(a, acc, n0 + wn * 16 * TN + 4 * h, m0 + wm * 16 * TM + r16);
 #undef CFEN_GEMM_DMA_ISSUE
-}
-
-// Second pass of a split-K GEMM: Y = act(sum_s part[s] + bias) + R + P, slices added in index order.
-template <typename T>
-__global__ __launch_bounds__(256) void k_gemm_splitk_finish(Grouped<GemmArgs<T>> ga) {
-  const GemmArgs<T> a = ga.g[blockIdx.z];
-  const long long nvec = (long long)a.M * (a.N / 4);
-  for (long long idx = (long long)blockIdx.x * 256 + threadIdx.x; idx < nvec; idx += (long long)gridDim.x * 256) {
-    const int m = (int)(idx / (a.N / 4)), n = (int)(idx % (a.N / 4)) * 4;
-    floatx4 v = *reinterpret_cast<const floatx4*>(a.part + (size_t)m * a.N + n);
-    for (int sidx = 1; sidx < a.nsplit; ++sidx) v += *reinterpret_cast<const floatx4*>(a.part + ((size_t)sidx * a.M + m) * a.N + n);
-    if (a.bias) v += *reinterpret_cast<const floatx4*>(a.bias + n);
-    if (a.relu) {
-#pragma unroll
-      for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f);
-    }
-    if (a.R) v += load4<T>(a.R + (size_t)m * a.ldr + n);
-    if (a.P) v += load4<T>(a.P + (size_t)(m % a.period) * a.N + n);
-    store4<T>(out_ptr(a, m, n), v);
-  }
 }
 
 // Small-M variant (GViT: 128..2048 tokens per batch against weight matrices of up to 6144 x 1536): the
@@ -542,7 +574,7 @@ __global__ __launch_bounds__(256) void k_gemm_skinny(Grouped<GemmArgs<T>> ga) {
 
 template <typename T>
 int launch_gemm(int ng, const CfenGemmPtrs* gp, int ldx, int ldw, int ldr, int period, int ldy, int M, int N, int K, int relu, hipStream_t s,
-                const CfenTokGather* tg, float* const* splitk_ws, size_t splitk_ws_bytes, const CfenTokGather* yg) {
+                const CfenTokGather* tg, float* const* splitk_ws, size_t splitk_ws_bytes, const CfenTokGather* yg, int force_nsplit) {
   constexpr int EPL = Mma<T>::EPL;
   CFEN_CHECK_ARG(ng >= 1 && ng <= CFEN_MAX_GROUPS && gp, "gemm: 1..%d problems per launch", CFEN_MAX_GROUPS);
   if (yg) {   // Y is folded into an NHWC map (gp[g].ymap): token m = (image, window, patch), feature n = (i, j, c)
@@ -606,14 +638,30 @@ int launch_gemm(int ng, const CfenGemmPtrs* gp, int ldx, int ldw, int ldr, int p
   const long long tiles64 = (long long)ng * ((N + G_BN - 1) / G_BN) * ((M + 63) / 64);
   const long long tiles32 = (long long)ng * ((N + G_BN - 1) / G_BN) * ((M + 31) / 32);
   int kern = forced < 0 ? -1 : forced % 10, stages = forced < 0 ? 2 : 2 + forced / 10;
-  // K-heavy GEMMs with a handful of tokens (GViT-3 ffn2 / head2: 128 x 1536 x 6144): one 96 x 128 tile per feature block
-  // so the weights are read once, K cut into slices for parallelism, partial sums reduced by a second tiny launch
+  // Few-token GEMMs against big matrices (GViT levels 2 and 3: 128 / 512 tokens, 0.5 GB of weights per forward).  A workgroup's LDS-DMA
+  // stream runs at ~22 GB/s whatever its ring depth (measured, round 3: 96 x 32 and 96 x 128 tiles, 3 to 8 stages), so what sets the time is
+  // the bytes ONE workgroup moves and how many workgroups share the chip: K is cut into slices of >= 4 K-steps until the launch has several
+  // workgroups per CU, 96 x 32 tiles so that a slice's partial tile is 12 KB and the in-launch reduction (k_gemm_dma) stays cheap.
   int nsplit = 1;
-  if (forced < 0 && k128 && splitk_ws && !tg && !lnf && M <= 128 && K >= 4 * N && cfen_tune_gemm_splitk()) {
+  if (force_nsplit > 1 || (force_nsplit == 0 && forced < 0 && k128 && splitk_ws && !tg && M <= 512 && cfen_tune_gemm_splitk())) {
     const int nk = K / (G_BKB / (int)sizeof(T));
-    nsplit = 8;
-    while (nsplit > 1 && (nk % nsplit || (size_t)nsplit * M * N * sizeof(float) > splitk_ws_bytes)) nsplit /= 2;
-    if (nsplit > 1) { kern = 2; stages = 2 + cfen_tune_gemm_splitk_stages(); }
+    const long long base = (long long)ng * ((N + G_BN - 1) / G_BN) * ((M + 31) / 32);
+    if (force_nsplit > 1) {
+      CFEN_CHECK_ARG(k128 && !tg && splitk_ws && nk % force_nsplit == 0, "gemm (split-K): needs K steps (%d) divisible by nsplit (%d), scratch, no gather", nk, force_nsplit);
+      nsplit = force_nsplit;
+    } else {
+      // measured (MI355X, batch 8, GViT-3 at 128 tokens): splitting pays where the unsplit launch leaves CUs idle (embed / proj 64 workgroups:
+      // 17.1 -> 13.8 us, ffn2 / head2 27.1 -> 18.8 us against the round-2 split-K with its second launch) and costs where the launch already
+      // has a workgroup per CU (ffn1 at 256 workgroups cut 4 ways: 17.6 -> 22.0 us: slab traffic, the acquire and the serial tail of the reducer)
+      while (base * nsplit < 256 && nsplit < 8 && nk % (2 * nsplit) == 0 && nk / (2 * nsplit) >= 4 && base * 2 * nsplit <= 512) nsplit *= 2;
+    }
+    const size_t slab = (size_t)(3 * 4 + 2) * 256 * sizeof(float);
+    const long long tiles = (long long)((N + G_BN - 1) / G_BN) * ((M + 31) / 32);
+    if (nsplit > 1 && (tiles > CFEN_SPLITK_COUNTERS || CFEN_SPLITK_COUNTERS * sizeof(unsigned) + (size_t)tiles * nsplit * slab > splitk_ws_bytes)) {
+      CFEN_CHECK_ARG(force_nsplit <= 1, "gemm (split-K): scratch too small (%zu bytes)", splitk_ws_bytes);
+      nsplit = 1;
+    }
+    if (nsplit > 1) { kern = 5; stages = 2 + cfen_tune_gemm_small() / 10; }
   }
   // many tokens against >= 768 features (LViT-3 / GViT-1 qkv, ffn1, head1): 192 x 128 tiles when they still fill the chip
   const long long tiles_big = (long long)ng * ((N + 191) / 192) * ((M + 127) / 128);
@@ -643,8 +691,9 @@ int launch_gemm(int ng, const CfenGemmPtrs* gp, int ldx, int ldw, int ldr, int p
   for (int g = 0; g < ng; ++g) {
     ga.g[g].map = map;
     ga.g[g].nsplit = nsplit;
-    ga.g[g].part = nsplit > 1 ? splitk_ws[g] : nullptr;
     CFEN_CHECK_ARG(nsplit == 1 || (splitk_ws[g] && cfen_aligned16(splitk_ws[g])), "gemm: split-K workspace missing");
+    ga.g[g].cnt = nsplit > 1 ? reinterpret_cast<unsigned*>(splitk_ws[g]) : nullptr;                       // [CFEN_SPLITK_COUNTERS] arrival counters, zero
+    ga.g[g].part = nsplit > 1 ? splitk_ws[g] + CFEN_SPLITK_COUNTERS * sizeof(unsigned) / sizeof(float) : nullptr;   // then the partial slabs
   }
   const long long blocks = 8LL * map.cn * map.cm;
   CFEN_CHECK_ARG(blocks < (1LL << 31), "gemm: problem too large for one launch");
@@ -667,11 +716,6 @@ int launch_gemm(int ng, const CfenGemmPtrs* gp, int ldx, int ldw, int ldr, int p
     default: CFEN_LAUNCH((k_gemm_dma<T, 1, 4>), grid, dim3(256), 0, s, ga); break;
   }
   CFEN_CHECK_LAUNCH("gemm");
-  if (nsplit > 1) {
-    const long long nvec = (long long)M * (N / 4);
-    CFEN_LAUNCH(k_gemm_splitk_finish<T>, dim3((unsigned)((nvec + 255) / 256), 1, (unsigned)ng), dim3(256), 0, s, ga);
-    CFEN_CHECK_LAUNCH("gemm (split-K finish)");
-  }
   return CFEN_OK;
 }
 
@@ -719,9 +763,9 @@ int& cfen_tune_gemm_kernel() {
 }
 
 int cfen_gemm_impl_g(int dtype, int ng, const CfenGemmPtrs* gp, int ldx, int ldw, int ldr, int period, int ldy, int M, int N, int K, int relu,
-                     const CfenTokGather* tg, hipStream_t s, float* const* splitk_ws, size_t splitk_ws_bytes, const CfenTokGather* yg) {
-  if (dtype == 1) return launch_gemm<half_t>(ng, gp, ldx, ldw, ldr, period, ldy, M, N, K, relu, s, tg, splitk_ws, splitk_ws_bytes, yg);
-  if (dtype == 0) return launch_gemm<float>(ng, gp, ldx, ldw, ldr, period, ldy, M, N, K, relu, s, tg, splitk_ws, splitk_ws_bytes, yg);
+                     const CfenTokGather* tg, hipStream_t s, float* const* splitk_ws, size_t splitk_ws_bytes, const CfenTokGather* yg, int force_nsplit) {
+  if (dtype == 1) return launch_gemm<half_t>(ng, gp, ldx, ldw, ldr, period, ldy, M, N, K, relu, s, tg, splitk_ws, splitk_ws_bytes, yg, force_nsplit);
+  if (dtype == 0) return launch_gemm<float>(ng, gp, ldx, ldw, ldr, period, ldy, M, N, K, relu, s, tg, splitk_ws, splitk_ws_bytes, yg, force_nsplit);
   cfen_set_error("gemm: unknown dtype %d", dtype);
   return CFEN_ERR_ARG;
 }

@@ -48,6 +48,21 @@ def gemm_ln(x, wl, s, bias=None, relu=False, eps=1e-5):
     return out
 
 
+def gemm_splitk(x, w, nsplit, bias=None, residual=None, relu=False, lnf_s=None, scratch=None):
+    """cfen_gemm_splitk: act(x @ w.T + bias) + residual (or the LayerNorm-folded form when lnf_s is given) with K cut into nsplit slices and
+    the in-launch reduction; `scratch` (zeroed uint8 buffer) can be passed to check that calls leave its counters zero"""
+    _cuda(x, w, bias, residual, lnf_s, scratch)
+    M, K = x.shape
+    N = w.shape[0]
+    out = torch.empty(M, N, dtype=x.dtype, device=x.device)
+    tiles = ((N + 95) // 96) * ((M + 31) // 32)
+    if scratch is None:
+        scratch = torch.zeros(4096 + tiles * nsplit * 14336, dtype=torch.uint8, device=x.device)
+    check(_lib.load().cfen_gemm_splitk(dtype_code(x.dtype), ptr(x), K, ptr(w), K, ptr(lnf_s), ptr(bias), ptr(residual), N, ptr(out), N, M, N, K,
+                                       int(relu), nsplit, ptr(scratch), scratch.numel(), current_stream()), "gemm_splitk")
+    return out
+
+
 def layernorm(x, gamma, beta, eps=1e-5):
     _cuda(x, gamma, beta)
     out = torch.empty_like(x)

@@ -124,6 +124,13 @@ int cfen_gemm_nt(int dtype, const void* X, int ldx, const void* W, int ldw, cons
  * that have no fused kernel (GViT, LViT level 3).  K * element size must be a multiple of 128 bytes; eps must be 1e-5. */
 int cfen_gemm_ln(int dtype, const void* X, int ldx, const void* Wl, int ldw, const float* s, const float* bias, void* Y, int ldy, int M, int N,
                  int K, int relu, float eps, void* stream);
+/* The same GEMMs with K cut into `nsplit` slices that run as separate workgroups (few tokens against a big matrix: the launch is bound by the
+ * bytes one workgroup streams).  Every slice parks its fp32 partial tile in `scratch`; the workgroup that arrives last on the tile's counter adds
+ * the slices in index order and applies the epilogue -- one launch, deterministic, no float atomics.  lnf_s != NULL: W is the LayerNorm-folded Wl of
+ * cfen_gemm_ln.  scratch: 4096 bytes of arrival counters, which must be ZERO before the first call and are left zero by every call, followed by
+ * ceil(N/96) * ceil(M/32) * nsplit * 14336 bytes of partial slabs.  K * element size / 128 must be divisible by nsplit.   (v3:1364, 1388-1389, 1173) */
+int cfen_gemm_splitk(int dtype, const void* X, int ldx, const void* W, int ldw, const float* lnf_s, const float* bias, const void* R, int ldr, void* Y,
+                      int ldy, int M, int N, int K, int relu, int nsplit, void* scratch, size_t scratch_bytes, void* stream);
 /* LViT token embedding without a token buffer: tok = patchify(fmap) (window partition + unfold, as cfen_patchify with pool 1)
  * is gathered by the GEMM's loader;  Y[m][n] = sum_k tok[m][k] W[n][k] + bias[n] + tok[m][n] + pos[m % period][n],
  * D = p*p*C, W is [D][D] (ldw), Y is [M][D] (ldy).                                        (v3:1140-1143, 1166) */

@@ -99,6 +99,38 @@ def test_gemm_with_layernorm_folded(dtype, M, D, N, relu):
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("M,N,K,nsplit", [(128, 1536, 1536, 4), (128, 1536, 6144, 8), (100, 200, 768, 2), (512, 768, 3072, 8), (33, 96, 256, 2), (16, 4608, 1536, 3)])
+def test_gemm_split_k_in_launch_reduction(dtype, M, N, K, nsplit):
+    """k_gemm_dma with K cut into slices and the last-arriving workgroup of a tile adding the partial tiles in slice order: against fp64,
+    every epilogue (bias / ReLU / residual / folded LayerNorm), bit-reproducible over repeated launches on one scratch buffer, and the arrival
+    counters are back to zero after every call (ragged token / feature tiles included)"""
+    d = dev()
+    x, w = rnd((M, K), 1, dtype), rnd((N, K), 2, dtype, 1 / math.sqrt(K))
+    bias, res = rnd((N,), 3, torch.float32), rnd((M, N), 4, dtype)
+    tiles = ((N + 95) // 96) * ((M + 31) // 32)
+    scratch = torch.zeros(4096 + tiles * nsplit * 14336, dtype=torch.uint8, device=d)
+    ref = x.double() @ w.double().t()
+    got = ops.gemm_splitk(x.to(d), w.to(d), nsplit, scratch=scratch)
+    close(got, ref, tol(dtype, 4), "plain")
+    assert int(scratch[:4096].view(torch.int32).abs().sum()) == 0
+    full = ops.gemm_splitk(x.to(d), w.to(d), nsplit, bias=bias.to(d), residual=res.to(d), relu=True, scratch=scratch)
+    close(full, torch.relu(ref + bias.double()) + res.double(), tol(dtype, 6), "bias + relu + residual")
+    for _ in range(3):
+        assert torch.equal(full, ops.gemm_splitk(x.to(d), w.to(d), nsplit, bias=bias.to(d), residual=res.to(d), relu=True, scratch=scratch))
+    assert int(scratch[:4096].view(torch.int32).abs().sum()) == 0
+    one = ops.gemm_nt(x.to(d), w.to(d), bias=bias.to(d), residual=res.to(d), relu=True)
+    close(full, one, tol(dtype, 6), "split vs unsplit")
+    # LayerNorm folded (packing.ln_folded): each slice sums x and x^2 of its K range, the reducer adds the slices' sums
+    g, b = 1 + 0.1 * rnd((K,), 5, torch.float32), 0.1 * rnd((K,), 6, torch.float32)
+    lf = packing.ln_folded(None, g, b, bias, "q", dtype, w.float())
+    want = cfen_oracle.layer_norm(x.double(), g.double(), b.double()) @ w.double().t() + bias.double()
+    gl = ops.gemm_splitk(x.to(d), lf["q.wl"].to(d), nsplit, bias=lf["q.bl"].to(d), lnf_s=lf["q.s"].to(d), scratch=scratch)
+    close(gl, want, tol(dtype, 12), "LayerNorm folded")
+    assert torch.equal(gl, ops.gemm_splitk(x.to(d), lf["q.wl"].to(d), nsplit, bias=lf["q.bl"].to(d), lnf_s=lf["q.s"].to(d), scratch=scratch))
+    close(gl, ops.gemm_ln(x.to(d), lf["q.wl"].to(d), lf["q.s"].to(d), lf["q.bl"].to(d)), tol(dtype, 8), "folded: split vs unsplit")
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
 @pytest.mark.parametrize("kernel", [6])
 @pytest.mark.parametrize("M,N,K", [(4096, 1536, 384), (300, 1000, 384), (1000, 1152, 1536), (130, 776, 128), (128, 192, 64)])
 def test_gemm_big_tile(dtype, kernel, M, N, K):
