@@ -72,10 +72,64 @@ def kernel_key(label, cls):
     return "%s:%s" % (cls, fam + (":" + step if step else ""))
 
 
-KERNEL_OF_STEP = {"window_block_fused": "k_lvit_window", "embed_ln_qkv": "k_embed_qkv2", "proj_mlp_fused": "k_mlp2",
+KERNEL_OF_STEP = {"window_block_fused": "k_lvit_window", "embed_ln_qkv": "k_embed_qkv2", "proj_mlp_fused": "k_mlp2", "proj_mlp_stream": "k_mlp3",
+                  "front_stream": "k_front3",
                   "attention": "k_attention_hm / k_attention_win", "embed": "k_gemm_dma", "qkv": "k_gemm_dma", "ln1_qkv": "k_gemm_dma (LayerNorm folded)",
                   "ln2_ffn1": "k_gemm_dma (LayerNorm folded)", "proj": "k_gemm_dma", "ffn1": "k_gemm_dma", "ffn2": "k_gemm_dma", "head1": "k_gemm_dma",
                   "head2": "k_gemm_dma"}
+
+
+def symbol_key(label, cls):
+    """per-launch label -> the device kernel that ran it, per block shape (one template instantiation each): every k_gemm_dma step of
+    LViT level 3 is ONE entry here, where kernel_key() lists them as seven"""
+    name, _, step = label.partition(":")
+    name = name.split(" ")[0]
+    if name.startswith(("localvit", "globalvit")):
+        blk = "%s%s" % ("lvit" if name.startswith("local") else "gvit", name.split("_0")[1][0])
+        return "%s @ %s" % (KERNEL_OF_STEP.get(step, step), blk)
+    if cls == "conv":
+        fam = "k_conv7_tz" if name.endswith(".conv7") else "k_conv_tile" if name.startswith(("head.", "tail_")) else \
+              "k_convT_tile" if name.startswith("us_conv") else "k_conv (gather)"
+        return fam
+    return "%s:%s" % (cls, step or name.rstrip("0123456789rsd"))
+
+
+def time_config(cfg, B, dtype, dev, steps, min_seconds, warmup=3):
+    """one extra BASELINE configuration on this GPU: build, capture, replay `steps` forwards per timed region until `min_seconds` are
+    timed; returns the same quantities as the headline run, with its own self_check"""
+    from cfen_vit_dehazing_amd.hipnet import dec_ipt
+    from cfen_vit_dehazing_amd.manifest import generate_state_dict, synthetic_input
+    from cfen_vit_dehazing_amd.parallel import split_slab
+    net = dec_ipt(cfg, compute_dtype=dtype)
+    net.load_state_dict(generate_state_dict(cfg, seed=0), strict=True)
+    net.to(dev)
+    n = cfg.image_size
+    x = synthetic_input(B, cfg, seed0=0).to(dev)
+    slab = torch.empty(7 * B * n * n, dtype=torch.float32, device=dev)
+    net(x, out=slab)
+    torch.cuda.synchronize()
+    gid = net.capture(x, out=slab)[0]
+    for _ in range(warmup):
+        net.replay(gid)
+    reps = []
+    while sum(reps) < min_seconds and len(reps) < 100:
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            net.replay(gid)
+        torch.cuda.synchronize()
+        reps.append(time.perf_counter() - t0)
+    dt = sorted(reps)[len(reps) // 2]
+    fl = net.flops_per_image()
+    ips = B * steps / dt
+    out = {"workload": "batch=%d %dx%d n_feats=24 hidden_dim_ratio=%d %s" % (B, n, n, cfg.hidden_dim_ratio, dtype),
+           "value": round(ips, 2), "unit": "images/sec", "ms_per_step": round(dt / steps * 1e3, 3), "steps": steps, "repetitions": len(reps),
+           "timed_seconds": round(sum(reps), 3), "gflop_per_image": round(fl / 1e9, 2),
+           "whole_forward_tflops": round(ips * fl / 1e12, 2), "whole_forward_frac": round(ips * fl / 1e12 / MFMA_PEAK_TFLOPS[dtype], 5),
+           "self_check": self_check(net, x, split_slab(slab, B, n), cfg, dtype)}
+    del net
+    torch.cuda.empty_cache()
+    return out
 
 
 def self_check(net, x, outs, cfg, dtype):
@@ -145,6 +199,8 @@ def main():
     ap.add_argument("--gather-dtype", default="auto", choices=["auto", "fp16", "fp32"],
                     help="wire type of the output all-gather (N > 1); auto = the compute dtype")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extra-configs", action="store_true",
+                    help="skip the short timed legs of BASELINE configs 4 (batch 4, 1024x1024) and 5 (batch 16, hidden_dim_ratio 2) in the default run")
     ap.add_argument("--cpu-seconds", type=float, default=20.0)
     args = ap.parse_args()
     apply_tuning()
@@ -259,6 +315,14 @@ def main():
         for k in kern.values():
             k["ms"] = round(k["ms"], 4); k["gflop"] = round(k["gflop"], 2)
             k["tflops"] = round(k["gflop"] / k["ms"], 1) if k["gflop"] > 0 and k["ms"] > 0 else None
+        sym = {}
+        for label, cls, fl, ms in mid["launches"]:
+            k = sym.setdefault(symbol_key(label, cls), {"ms": 0.0, "gflop": 0.0, "launches": 0})
+            k["ms"] += ms; k["gflop"] += fl / 1e9; k["launches"] += 1
+        for k in sym.values():
+            k["ms"] = round(k["ms"], 4); k["gflop"] = round(k["gflop"], 2)
+            k["tflops"] = round(k["gflop"] / k["ms"], 1) if k["gflop"] > 0 and k["ms"] > 0 else None
+            k["frac"] = round(k["tflops"] / peak, 5) if k["tflops"] else None
         dom = max((k for k in kern if kern[k]["gflop"] > 0), key=lambda k: kern[k]["ms"])
         ach = kern[dom]["gflop"] / kern[dom]["ms"]                   # GFLOP / ms == TFLOP/s
         dom_launch_ms = kern[dom]["ms"] / kern[dom]["launches"]
@@ -276,7 +340,9 @@ def main():
                        "gflop_per_image": round(flops_img / 1e9, 2)},
             "roofline": {"bound": "mfma", "kernel": "%s [%s]" % (dom, KERNEL_OF_STEP.get(dom.split(":")[-1], "?")),
                          "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s",
-                         "frac": round(ach / peak, 5), "traffic": pmc_traffic(dom),
+                         "frac": round(ach / peak, 5), "traffic": pmc_traffic(dom), "traffic_from_profiles": pmc_traffic(dom),
+                         "traffic_source": "newest committed profiles/r*_pmc_traffic.json (separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of "
+                                           "this command, fetch x2 per the gfx950 guide); a cross-reference, not measured in this run",
                          "launch_ms": round(dom_launch_ms, 4), "launches_per_step": kern[dom]["launches"],
                          "algorithmic_gflop_per_launch": round(kern[dom]["gflop"] / kern[dom]["launches"], 2),
                          "whole_forward_tflops": round(whole, 2), "whole_forward_frac": round(whole / peak, 5)},
@@ -285,7 +351,22 @@ def main():
             "self_check": check,
             "kernel_classes": classes,
             "kernels": dict(sorted(kern.items(), key=lambda kv: -kv[1]["ms"])[:12]),
+            # the same launches grouped by the device kernel that ran them (per block shape = per template instantiation)
+            "by_symbol": dict(sorted(sym.items(), key=lambda kv: -kv[1]["ms"])[:10]),
         }
+        default_run = (B, args.hidden_dim_ratio, args.load_size, args.variant, args.dtype) == (8, 4, 256, "v3", "fp16")
+        if world == 1 and default_run and not args.no_extra_configs:
+            # BASELINE configs 4 and 5 as short legs of the same run, so that their numbers are observed by whoever runs bench.py
+            del net
+            torch.cuda.empty_cache()
+            extra = {}
+            for key, ecfg, eb, esteps in (("config4_batch4_1024x1024", NetConfig(24, 4, patch_size=64, load_size=512), 4, 10),
+                                          ("config5_batch16_hdr2", NetConfig(24, 2, patch_size=32, load_size=256), 16, 20)):
+                try:
+                    extra[key] = time_config(ecfg, eb, args.dtype, dev, esteps, 0.4)
+                except Exception as e:          # a failing extra leg must not cost the headline line
+                    extra[key] = {"error": "%s: %s" % (type(e).__name__, e)}
+            result["extra_configs"] = extra
         if world == 1 and not args.no_cpu_baseline:
             result["cpu_baseline"] = cpu_baseline(cfg, args.cpu_seconds)
         print(json.dumps(result), flush=True)

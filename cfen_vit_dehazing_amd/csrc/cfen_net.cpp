@@ -109,6 +109,7 @@ struct cfen_net {
   // initialises) sees the top-left win x win window of every image only (v5:403-440)
   struct AnPending { const float* ones; const float* conv_bias; float* an_out; int win; };
   std::map<std::string, AnPending> an_pending;
+  bool an_raw_pass = false;
   int input_u8 = 0;                // 1: x is uint8 HWC (B,H,W,3), normalised to [-1,1] by the first launch (data/base_dataset.py:44-46)
   bool cfs = false;                // sibling generators networks_iid_hlgvit_crs_gd4_cfs.py / ..._crs_gd4.py (cfg.reserved bits 8..15 == 1 / 2): the three
                                    // levels run at the image's own resolution -- no ds_conv_e01 / us_conv_d01*, n_feats channels in head and tails
@@ -423,7 +424,7 @@ int cfen_net::build() {
 
 int cfen_net::run_conv_g(int ng, const ConvCall* cc, int act) {
   ConvDesc d[CFEN_MAX_GROUPS];
-  if (!an_pending.empty()) {
+  if (!an_pending.empty() && !an_raw_pass) {
     bool any = false;
     for (int g = 0; g < ng; ++g) any = any || an_pending.count(cc[g].layer);
     if (any && ng > 1) {   // initialise member by member
@@ -437,14 +438,16 @@ int cfen_net::run_conv_g(int ng, const ConvCall* cc, int act) {
       const AnPending ap = an_pending.at(cc[0].layer);
       const ConvLayer& c = convs.at(cc[0].layer);
       const Buf& bo = bufs.at(cc[0].out);
-      an_pending.erase(cc[0].layer);
+      const std::string pending_layer = cc[0].layer;   // forgotten only once the statistics pass has been enqueued (see below)
       // 1. raw layer output x = conv + conv_bias (no activation, no residual) into the layer's own buffer
       Param keep_s = params.at(cc[0].layer + ".scale"), keep_t = params.at(cc[0].layer + ".shift");
       params[cc[0].layer + ".scale"].ptr = ap.ones;
       params[cc[0].layer + ".shift"].ptr = ap.conv_bias;
       ConvCall raw = cc[0];
       raw.res0.clear(); raw.res1.clear();
+      an_raw_pass = true;                 // the raw pass is this same function: it must not start another initialisation of the layer
       int rc = run_conv_g(1, &raw, 0);
+      an_raw_pass = false;
       params[cc[0].layer + ".scale"] = keep_s;
       params[cc[0].layer + ".shift"] = keep_t;
       if (rc) return rc;
@@ -467,6 +470,7 @@ int cfen_net::run_conv_g(int ng, const ConvCall* cc, int act) {
       }
       TRY(cfen_actnorm_init_impl(cfg.dtype, xs, (float*)at(o_stats_set[2]), cfg.batch, hw, c.Cout, bo.cs, c.Cout_pad,
                                  ap.conv_bias, (float*)const_cast<void*>(keep_s.ptr), (float*)const_cast<void*>(keep_t.ptr), ap.an_out, stream));
+      an_pending.erase(pending_layer);   // a failure above leaves the layer pending: the next forward retries instead of running it uninitialised
       // 3. fall through: the layer again, now with its real epilogue
     }
   }

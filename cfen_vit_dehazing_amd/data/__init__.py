@@ -59,6 +59,14 @@ class DECVITDATA(torch.utils.data.Dataset):
         self.root = opt.dataroot
         self.dir_B = os.path.join(opt.dataroot, 'hazy')
         self.B_paths = sorted(make_dataset(self.dir_B))
+        world, rank = getattr(opt, 'dist_world', 1), getattr(opt, 'dist_rank', 0)
+        if world > 1:
+            # one process per GPU (test.py under torch.distributed.run): this rank's contiguous slice of the images the run covers
+            from ..parallel import shard_items
+            if not opt.sb:
+                raise ValueError("multi-process inference needs --sb (the reference samples images randomly without it, dec_vit_data.py:51-58)")
+            limit = min(len(self.B_paths), int(min(opt.max_dataset_size, getattr(opt, 'how_many', float('inf')) * opt.batchSize)))
+            self.B_paths = shard_items(self.B_paths[:limit], world, rank)
         self.B_size = len(self.B_paths)
         self.transform = get_transform(opt)
 
@@ -68,7 +76,10 @@ class DECVITDATA(torch.utils.data.Dataset):
         else:                                   # the reference samples randomly unless --sb (dec_vit_data.py:51-58)
             B_path = self.B_paths[random.randint(0, self.B_size - 1)]
         B = self.transform(Image.open(B_path).convert('RGB'))
-        if B.dtype != torch.uint8 and self.opt.output_nc == 1 and self.opt.which_direction != 'BtoA' or self.opt.input_nc == 1 and self.opt.which_direction == 'BtoA':
+        gray = (self.opt.output_nc == 1 and self.opt.which_direction != 'BtoA') or (self.opt.input_nc == 1 and self.opt.which_direction == 'BtoA')
+        if gray and B.dtype == torch.uint8:
+            raise ValueError("--u8_input hands over the decoded RGB image; single-channel input (--input_nc / --output_nc 1) needs the float path")
+        if gray:
             B = (B[0, ...] * 0.299 + B[1, ...] * 0.587 + B[2, ...] * 0.114).unsqueeze(0)
         return {'B': B, 'B_paths': B_path}
 

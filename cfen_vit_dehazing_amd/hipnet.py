@@ -76,7 +76,20 @@ class dec_ipt(nn.Module):
 
     # ---- parameter management ---------------------------------------------------------------
     def state_dict(self, *args, **kw):
-        """The reference's 958 keys in the reference's order; dead entries come from the loaded checkpoint (zeros otherwise)."""
+        """The reference's 958 keys in the reference's order; dead entries come from the loaded checkpoint (zeros otherwise -- those are
+        read-only stride-0 views without storage: clone before editing in place)."""
+        dest = kw.get("destination", args[0] if len(args) > 0 else None)
+        if dest is not None:
+            # nn.Module.state_dict of a PARENT module (or a caller-supplied destination) ignores what a child returns and keeps `destination`:
+            # put the host-side entries into it as well, so nesting dec_ipt does not drop the 208.6 M never-read parameters from a checkpoint
+            # (they are appended; the reference's key ORDER is only reproduced by the top-level call below)
+            live = super().state_dict(*args, **kw)
+            prefix = kw.get("prefix", args[1] if len(args) > 1 else "")
+            for key, shape, dt in self._manifest:
+                if prefix + key not in live:
+                    t = self._dead.get(key)
+                    live[prefix + key] = t if t is not None else torch.zeros(shape, dtype=dt)
+            return live
         live = super().state_dict(*args, **kw)
         prefix = kw.get("prefix", args[1] if len(args) > 1 else "")
         out = type(live)()
@@ -371,8 +384,9 @@ def define_G(opt, conv=None, compute_dtype=None):
     gpu_ids = getattr(opt, "gpu_ids", [])
     if len(gpu_ids) > 1:
         raise NotImplementedError("--gpu_ids %s: the reference wraps the net in nn.DataParallel (v3:77-83); here multi-GPU is one process "
-                                  "per GPU (cfen_vit_dehazing_amd/parallel.py, `python -m torch.distributed.run --nproc-per-node N ...`) -- "
-                                  "pass one id per process" % (gpu_ids,))
+                                  "per GPU: `python -m torch.distributed.run --nnodes=1 --nproc-per-node %d --master-addr 127.0.0.1 test.py "
+                                  "--sb ...` (every rank takes the GPU of its LOCAL_RANK and its own slice of the images, "
+                                  "cfen_vit_dehazing_amd/parallel.py)" % (gpu_ids, len(gpu_ids)))
     if len(gpu_ids) > 0:
         assert torch.cuda.is_available()
         net.to(gpu_ids[0])

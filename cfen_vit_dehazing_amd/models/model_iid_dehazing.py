@@ -37,5 +37,27 @@ class DECHLGVIT(BaseModel):
         else:
             self._net_in = self.real_B = B
 
+    HALF_GUARD_BAR = 3e-2     # max-abs difference of the fp16 outputs (tanh values in (-1, 1)) from the fp32 path on the first batch
+
+    def setup(self, opt):
+        BaseModel.setup(self, opt)
+        # fp16 range safety of a REAL checkpoint (ActNorm scales, K = 6144 FFN sums) is unknown until its weights are here: with --precision
+        # half the first batch runs through the exact-fp32 path once as well (reference loader: models/base_model.py:114-131)
+        self._half_guard = getattr(opt, 'precision', 'single') == 'half' and not getattr(opt, 'no_half_guard', False)
+
     def forward(self):
+        if getattr(self, '_half_guard', False):
+            self._half_guard = False
+            self.netG.set_compute_dtype('fp32')
+            ref = [t.clone() for t in self.netG(self._net_in)]
+            self.netG.set_compute_dtype('fp16')
+            out = self.netG(self._net_in)
+            worst = max(float((a - b).abs().max()) if bool(torch.isfinite(a).all()) else float('inf') for a, b in zip(out, ref))
+            self.half_guard_max_abs = worst
+            if not worst <= self.HALF_GUARD_BAR:
+                print('warning: --precision half differs from the fp32 path by %.3g max-abs on the first batch (bar %.0e): this checkpoint is not '
+                      'fp16-safe, continuing with --precision single' % (worst, self.HALF_GUARD_BAR))
+                self.netG.set_compute_dtype('fp32')
+                [self.fake_R, self.fake_S, self.fake_A] = ref
+                return
         [self.fake_R, self.fake_S, self.fake_A] = self.netG(self._net_in)

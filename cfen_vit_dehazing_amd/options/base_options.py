@@ -58,6 +58,9 @@ class BaseOptions():
         p.add_argument('--n_feats', type=int, default=32)
         p.add_argument('--precision', type=str, default='single', choices=('single', 'half'),
                        help='HIP compute type: single = fp32 MFMA, half = fp16 storage / fp32 accumulate')
+        p.add_argument('--no_half_guard', action='store_true',
+                       help='(extension) with --precision half the first batch also runs in fp32 once and the model falls back to single when the '
+                            'fp16 outputs differ by more than 3e-2 (range safety of a real checkpoint); this flag skips that check')
         p.add_argument('--u8_input', action='store_true',
                        help='(extension) the dataset hands over uint8 HWC images and ToTensor + Normalize(0.5, 0.5) run on the device '
                             'inside the generator launch plan (12x fewer bytes over PCIe); results are identical')
@@ -85,22 +88,31 @@ class BaseOptions():
             id = int(str_id)
             if id >= 0:
                 opt.gpu_ids.append(id)
+        # one process per GPU: under `python -m torch.distributed.run --nproc-per-node N test.py ...` every rank takes the GPU of its
+        # LOCAL_RANK (whatever --gpu_ids says) and its own slice of the dataset; the reference's counterpart is nn.DataParallel over
+        # --gpu_ids (networks_iid_hlgvit_crs_gd4_cfs_v3.py:77-83)
+        from ..parallel import dist_env
+        opt.dist_rank, opt.dist_world, local = dist_env()
+        if opt.dist_world > 1:
+            opt.gpu_ids = [local]
         if len(opt.gpu_ids) > 0 and torch.cuda.is_available():
             torch.cuda.set_device(opt.gpu_ids[0])
         args = vars(opt)
-        print('------------ Options -------------')
-        for k, v in sorted(args.items()):
-            print('%s: %s' % (str(k), str(v)))
-        print('-------------- End ----------------')
+        if opt.dist_rank == 0:
+            print('------------ Options -------------')
+            for k, v in sorted(args.items()):
+                print('%s: %s' % (str(k), str(v)))
+            print('-------------- End ----------------')
         if opt.suffix:
             suffix = ('_' + opt.suffix.format(**vars(opt))) if opt.suffix != '' else ''
             opt.name = opt.name + suffix
         expr_dir = os.path.join(opt.checkpoints_dir, opt.name)
         util.mkdirs(expr_dir)
-        with open(os.path.join(expr_dir, 'opt.txt'), 'wt') as opt_file:
-            opt_file.write('------------ Options -------------\n')
-            for k, v in sorted(args.items()):
-                opt_file.write('%s: %s\n' % (str(k), str(v)))
-            opt_file.write('-------------- End ----------------\n')
+        if opt.dist_rank == 0:
+            with open(os.path.join(expr_dir, 'opt.txt'), 'wt') as opt_file:
+                opt_file.write('------------ Options -------------\n')
+                for k, v in sorted(args.items()):
+                    opt_file.write('%s: %s\n' % (str(k), str(v)))
+                opt_file.write('-------------- End ----------------\n')
         self.opt = opt
         return self.opt

@@ -27,6 +27,20 @@ def even_shard(total, world, rank):
     return shard_range(total, world, rank)
 
 
+def dist_env():
+    """(rank, world, local_rank) of a process started by `python -m torch.distributed.run` (RANK / WORLD_SIZE / LOCAL_RANK); (0, 1, 0) when
+    started plainly.  Reads the environment only: safe before any GPU call."""
+    import os
+    return int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("LOCAL_RANK", "0"))
+
+
+def shard_items(items, world, rank):
+    """the contiguous slice of a dataset's item list one rank works on (test.py under torch.distributed.run: every rank dehazes its own
+    images and writes its own files, so slices may differ in length by one and no collective is needed)"""
+    lo, hi = shard_range(len(items), world, rank)
+    return items[lo:hi]
+
+
 def split_slab(slab, batch, n):
     """flat [xr | xs | xd] slab of one rank -> views (B,3,n,n), (B,1,n,n), (B,3,n,n)."""
     px = batch * n * n
@@ -50,6 +64,13 @@ class OutputGatherer:
     def __init__(self, world, numel, device, dtype=torch.float32):
         self.world, self.numel, self.dtype = world, numel, dtype
         self.cuda = torch.device(device).type == "cuda"
+        if world > 1 and dist.is_initialized():
+            # every rank must bring the same slab size: all_gather_into_tensor with unequal inputs does not fail, it hangs
+            lohi = torch.tensor([numel, -numel], dtype=torch.int64, device=device)
+            dist.all_reduce(lohi, op=dist.ReduceOp.MAX)
+            if int(lohi[0]) != numel or int(-lohi[1]) != numel:
+                raise ValueError("OutputGatherer: ranks hold slabs of %d .. %d elements; shard the global batch with parallel.even_shard"
+                                 % (int(-lohi[1]), int(lohi[0])))
         self.bufs = [torch.empty(world * numel, dtype=dtype, device=device) for _ in range(2)]
         self.stage = [torch.empty(numel, dtype=dtype, device=device) for _ in range(2)] if dtype != torch.float32 else None
         self.stream = torch.cuda.Stream(device) if self.cuda else None

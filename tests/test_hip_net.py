@@ -266,6 +266,12 @@ def test_fp16_benchmark_configs_graph_replay_vs_reference_vectors(name, batch):
         assert torch.equal(a, b)                                   # replay is bitwise the eager plan
     worst = _fp16_vs_fixture(z, outs, x, 3e-2)
     print("%s B=%d fp16 graph: image 0 max-abs vs reference vectors %.2e" % (name, batch, worst))
+    if name == "full512_nf24_hdr4":
+        # images 0 AND 1 of the batch against the reference's own two-image forward (fixture full512b2: seeds 0 and 1)
+        _, b2, z2 = load_net_fixture("full512b2_nf24_hdr4")
+        assert b2 == 2
+        w2 = check_outputs(z2, [o[0:2] for o in outs], 3e-2)
+        print("   images 0..1 vs the reference's batch-2 vectors: max-abs %.2e" % w2)
     for i in sorted({1, batch // 2, batch - 1}):
         one = net(x[i:i + 1].clone())
         for a, b in zip(outs, one):
@@ -273,6 +279,55 @@ def test_fp16_benchmark_configs_graph_replay_vs_reference_vectors(name, batch):
             assert d <= 1e-2, "image %d differs from its batch-1 forward by %.3e" % (i, d)
     del net
     torch.cuda.empty_cache()
+
+
+def test_fp32_batch2_vs_reference_vectors_of_both_images():
+    """exact-fp32 path, B = 2, 512x512: outputs AND all 58 stages of both images against the reference's batch-2 forward"""
+    cfg, batch, z = load_net_fixture("full512b2_nf24_hdr4")
+    net = make_net(cfg, "fp32")
+    outs = net(synthetic_input(batch, cfg).to("cuda:0"))
+    st = gpu_stages(net, z)
+    for nm, o in zip(("tail_R", "tail_S", "tail_D"), outs):
+        st[nm] = o
+    check_stages(z, st, 3e-4, rel_sum=2e-4)
+    worst = check_outputs(z, outs, 1e-4)
+    print("fp32 B=2 max-abs vs reference vectors %.2e" % worst)
+    del net
+    torch.cuda.empty_cache()
+
+
+def test_half_precision_guard_keeps_safe_weights_and_falls_back_on_unsafe_ones(tmp_path):
+    """--precision half through the model wrapper: the first batch also runs in fp32; seeded weights stay on fp16, a checkpoint whose
+    activations leave the fp16 range (an FFN scaled by 3e4) is caught and the model continues in single precision with fp32-exact outputs"""
+    from cfen_vit_dehazing_amd.models import create_model
+    from cfen_vit_dehazing_amd.options.test_options import TestOptions
+    cfg = NetConfig(24, 4, patch_size=8, load_size=64)
+    sd = generate_state_dict(cfg, seed=0)
+    x = synthetic_input(2, cfg)
+    for tag, scale in (("safe", 1.0), ("unsafe", 3e4)):
+        ck = tmp_path / tag / "half_guard"
+        ck.mkdir(parents=True)
+        sd2 = dict(sd)
+        sd2["localvit_encoder_01.encoder.layers.0.linear1.weight"] = sd["localvit_encoder_01.encoder.layers.0.linear1.weight"] * scale
+        torch.save(sd2, ck / "latest_net_G.pth")
+        opt = TestOptions().parse(['--dataroot', str(tmp_path), '--checkpoints_dir', str(tmp_path / tag), '--name', 'half_guard', '--n_feats', '24',
+                                   '--hidden_dim_ratio', '4', '--patch_size', '8', '--loadSize', '64', '--sb', '--precision', 'half'])
+        model = create_model(opt)
+        model.setup(opt)
+        model.set_input({'B': x, 'B_paths': ['a.png', 'b.png']})
+        model.test(opt)
+        fa = model.get_current_visuals()['fake_A'].clone()
+        assert torch.isfinite(fa).all()
+        if tag == "safe":
+            assert model.half_guard_max_abs <= 3e-2 and model.netG.compute_dtype == torch.float16
+        else:
+            assert not model.half_guard_max_abs <= 3e-2 and model.netG.compute_dtype == torch.float32
+            ref = make_net(cfg, "fp32")
+            ref.load_state_dict(sd2)
+            ref.to("cuda:0")
+            assert torch.equal(fa, ref(x.to("cuda:0"))[2])
+        model.test(opt)            # the second batch runs on whatever the guard settled on, without the double forward
+        assert torch.isfinite(model.get_current_visuals()['fake_A']).all()
 
 
 def test_two_lane_plan_equals_serial_plan_bitwise_full_size():

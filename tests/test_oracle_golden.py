@@ -56,6 +56,13 @@ def test_oracle_full512():
     assert outs[0].shape == (1, 3, 512, 512) and outs[1].shape == (1, 1, 512, 512)
 
 
+@pytest.mark.slow
+def test_oracle_full512_two_images():
+    """the batch-2 fixture (seeds 0 and 1): the oracle against the reference on an image other than the first"""
+    outs = _run("full512b2_nf24_hdr4")
+    assert outs[0].shape == (2, 3, 512, 512)
+
+
 def test_oracle_fp64_agrees_with_fp32():
     cfg, batch, z = load_net_fixture("tiny_nf24_hdr4")
     sd = generate_state_dict(cfg, seed=0, with_dead=False, dtype=torch.float64)

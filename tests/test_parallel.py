@@ -65,11 +65,13 @@ def _gpu_worker(rank, world, port, q):
 
 
 @pytest.mark.gpu
-def test_output_gatherer_cuda_branch_over_rccl():
-    """runs with as many ranks as the box has GPUs (1 on the test box: a single-rank RCCL communicator still drives the whole
-    CUDA branch; 2+ ranks where available)"""
-    world = min(2, torch.cuda.device_count())
-    assert world >= 1
+@pytest.mark.parametrize("world", [1, 2])
+def test_output_gatherer_cuda_branch_over_rccl(world):
+    """world 1: a single-rank RCCL communicator drives the whole CUDA branch (side stream, event hand-off, wire conversion) on the one-GPU
+    test box; world 2: two ranks over xGMI -- skipped with the reason when the box shows fewer than two GPUs, so a run on a multi-GPU
+    node exercises rank ordering across devices"""
+    if torch.cuda.device_count() < world:
+        pytest.skip("needs %d GPUs, this box shows %d" % (world, torch.cuda.device_count()))
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = 29500 + (os.getpid() + 17) % 2000
@@ -132,3 +134,73 @@ def test_two_rank_shard_and_allgather_equals_single_process():
         p.join(300)
         assert p.exitcode == 0
     assert q.get(timeout=5) <= 1e-5
+
+
+def _harness_worker(rank, world, port, root, q):
+    """what `python -m torch.distributed.run --nproc-per-node 2 test.py ...` does before its first GPU call: the options pick the GPU of
+    LOCAL_RANK, the dataset is this rank's contiguous slice"""
+    sys.path.insert(0, ROOT)
+    os.environ.update({"RANK": str(rank), "WORLD_SIZE": str(world), "LOCAL_RANK": str(rank), "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(port)})
+    from cfen_vit_dehazing_amd.options.test_options import TestOptions
+    from cfen_vit_dehazing_amd import data as cdata
+    opt = TestOptions().parse(['--dataroot', os.path.join(root, 'data'), '--checkpoints_dir', os.path.join(root, 'ckpt'), '--name', 'shard_unit',
+                               '--n_feats', '24', '--hidden_dim_ratio', '4', '--sb', '--gpu_ids', '0,1', '--how_many', '6'])
+    assert (opt.dist_rank, opt.dist_world, opt.gpu_ids) == (rank, world, [rank])       # one GPU per process, whatever --gpu_ids said
+    mine = [os.path.basename(p) for b in cdata.CreateDataLoader(opt).load_data() for p in b['B_paths']]
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    everyone = [None] * world
+    dist.all_gather_object(everyone, mine)
+    if rank == 0:
+        q.put(everyone)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_test_py_shards_the_dataset_over_ranks(tmp_path):
+    """world-size-2 gloo run of the harness's sharding: the two ranks' slices are contiguous, disjoint, in order and cover exactly the
+    first --how_many images; the options file is written once"""
+    import numpy as np
+    from PIL import Image
+    hazy = tmp_path / 'data' / 'hazy'
+    hazy.mkdir(parents=True)
+    names = ['img_%04d.png' % i for i in range(7)]
+    for nm in names:
+        Image.fromarray(np.zeros((8, 8, 3), dtype=np.uint8)).save(hazy / nm)
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29500 + (os.getpid() + 911) % 2000
+    procs = [ctx.Process(target=_harness_worker, args=(r, 2, port, str(tmp_path), q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(300)
+        assert p.exitcode == 0
+    a, b = q.get(timeout=5)
+    assert a + b == names[:6] and len(a) == len(b) == 3
+    assert os.path.exists(tmp_path / 'ckpt' / 'shard_unit' / 'opt.txt')
+
+
+def test_gatherer_refuses_unequal_slabs_instead_of_hanging():
+    """two gloo ranks that bring slabs of different sizes: the constructor's size agreement raises on both"""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29500 + (os.getpid() + 1222) % 2000
+    procs = [ctx.Process(target=_unequal_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    assert sorted(q.get(timeout=5) for _ in range(2)) == ["refused", "refused"]
+
+
+def _unequal_worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        OutputGatherer(world, 16 + rank, "cpu")
+        q.put("built")
+    except ValueError:
+        q.put("refused")
+    dist.barrier()
+    dist.destroy_process_group()

@@ -38,6 +38,8 @@ CONFIGS = {
     "small_nf24_hdr4": (NetConfig(24, 4, patch_size=16, load_size=128), 1, False),
     "full512_nf24_hdr4": (NetConfig(24, 4, patch_size=32, load_size=256), 1, False),
     "full512_nf24_hdr2": (NetConfig(24, 2, patch_size=32, load_size=256), 1, False),
+    # two seeded images (seeds 0 and 1): the batched forwards are checked against the reference on an image other than the first as well
+    "full512b2_nf24_hdr4": (NetConfig(24, 4, patch_size=32, load_size=256), 2, False),
     "full1024_nf24_hdr4": (NetConfig(24, 4, patch_size=64, load_size=512), 1, False),
     # weights drawn from what the reference's own define_G / init_weights leaves (v3:49-74, 1330, 1377), ActNorm2d uninitialised:
     # the reference's first forward initialises its 24 ActNorm layers from the batch (models/actnorm.py:25-37); the fixture
@@ -204,7 +206,7 @@ def gen_net(v3, common, name):
     cfg, batch, full = CONFIGS[name]
     print("== %s: reference forward (B=%d, %dx%d)" % (name, batch, cfg.image_size, cfg.image_size), flush=True)
     net, sd, x, outs, stages = run_reference(v3, common, cfg, batch, mode=weight_mode(name))
-    if not name.startswith("refinit"):
+    if not name.startswith("refinit") and "b2_" not in name:
         dump_manifest(net, os.path.join(GOLD, "state_manifest_%s.txt" % name))
     data = {"batch": np.int64(batch), "cfg": np.array([cfg.n_feats, cfg.hidden_dim_ratio, cfg.patch_size, cfg.load_size], np.int64)}
     names = stage_names(cfg.variant)
