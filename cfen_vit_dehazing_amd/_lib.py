@@ -83,6 +83,7 @@ SIGNATURES = {
     "cfen_u8hwc_to_nhwc": (_I, [_I, _P, _P, _I, _I, _I, _I, _P]),
     "cfen_tensor2im_u8": (_I, [_P, _P, _I, _I, _I, _P]),
     "cfen_embed_qkv": (_I, [_I, ctypes.POINTER(EmbedQkvArgsC), _P]),
+    "cfen_embed_qkv_stream": (_I, [_I, ctypes.POINTER(EmbedQkvArgsC), _P]),
     "cfen_layernorm": (_I, [_I, _P, _P, _P, _P, _I, _I, c_float, _P]),
     "cfen_attention": (_I, [_I, _P, _P, _I, _I, _I, _I, _P]),
     "cfen_attention_head_major": (_I, [_I, _P, _P, _I, _I, _I, _I, _P]),

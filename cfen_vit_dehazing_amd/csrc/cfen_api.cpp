@@ -152,6 +152,16 @@ int cfen_embed_qkv(int dtype, const cfen_embed_qkv_args* a, void* stream) {
   return cfen_embed_qkv_impl_g(dtype, 1, &q, (hipStream_t)stream);
 }
 
+int cfen_embed_qkv_stream(int dtype, const cfen_embed_qkv_args* a, void* stream) {
+  CFEN_CHECK_ARG(a != nullptr, "embed_qkv_stream: null args");
+  CFEN_CHECK_ARG(a->B > 0 && a->ws > 0 && a->p > 0 && a->ws % a->p == 0 && a->H > 0 && a->W > 0 && a->H % a->ws == 0 && a->W % a->ws == 0,
+                 "embed_qkv_stream: bad geometry");
+  const int tw = a->ws / a->p;
+  CfenEmbedQkvArgs q{a->fmap, a->B, a->H, a->W, a->C, a->cs, a->ws, a->p, a->we, a->be, a->pos, a->ln_gamma, a->ln_beta, a->wqkv, a->x1, a->qkv,
+                     (long long)a->B * (a->H / a->ws) * (a->W / a->ws) * tw * tw, a->p * a->p * a->C, a->eps, a->head_major_heads};
+  return cfen_front3_impl_g(dtype, 1, &q, (hipStream_t)stream);
+}
+
 int cfen_attention_head_major(int dtype, const void* qkv, void* out, int nseq, int S, int heads, int dh, void* stream) {
   return cfen_attention_hm_impl_g(dtype, 1, &qkv, &out, nseq, S, heads, dh, (hipStream_t)stream);
 }
@@ -254,6 +264,11 @@ int cfen_tune(const char* key, int value) {
   }
   if (!strcmp(key, "net.attn_head_major")) {
     cfen_tune_attn_head_major() = value != 0;
+    return CFEN_OK;
+  }
+  if (!strcmp(key, "net.stream_front")) {
+    CFEN_CHECK_ARG(value >= 0 && value <= 2, "tune: net.stream_front is 0 (never), 1 (grouped decoder launches) or 2 (always)");
+    cfen_tune_stream_front() = value;
     return CFEN_OK;
   }
   if (!strcmp(key, "net.stream_mlp")) {

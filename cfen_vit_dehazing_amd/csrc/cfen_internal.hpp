@@ -26,6 +26,9 @@ struct CfenEmbedQkvArgs {
 };
 bool cfen_embed_qkv_supported(int D);
 int cfen_embed_qkv_impl_g(int dtype, int ng, const CfenEmbedQkvArgs* a, hipStream_t s);
+// the same front half for D = 384 on the fragment-stream ring (k_stream.hip); We / Wqkv are packing.pack_stream_rows streams
+bool cfen_front3_supported(int dtype, int D, long long M);
+int cfen_front3_impl_g(int dtype, int ng, const CfenEmbedQkvArgs* a, hipStream_t s);
 // grouped launches (cfen_common.hpp: CFEN_MAX_GROUPS problems of identical geometry, one launch)
 struct CfenGemmPtrs {
   const void* X; const void* W; const float* bias; const void* R; const void* P; void* Y; const void* gmap;
@@ -109,5 +112,6 @@ int& cfen_tune_gemm_splitk();     // 1 (default): K-heavy few-token GEMMs run sp
 int& cfen_tune_lvit_window();        // 1 (default): LViT level 1 runs as one k_lvit_window launch per instance group ("net.lvit_window")
 int& cfen_tune_fold_in_gemm();      // 1 (default): the last GEMM of an unfused block folds its tokens into the map itself ("net.fold_in_gemm")
 int& cfen_tune_attn_head_major();   // 1 (default): LViT levels with a fused front half hand qkv to attention head-major ("net.attn_head_major")
+int& cfen_tune_stream_front();      // k_front3 for the D = 384 LViT blocks: 0 never, 1 (default) grouped decoder launches, 2 always ("net.stream_front")
 int& cfen_tune_stream_mlp();        // k_mlp3 for the D = 384 LViT blocks: 0 never, 1 (default) grouped decoder launches, 2 always ("net.stream_mlp")
 int& cfen_tune_embed_lds();        // k_embed_qkv weights through LDS: bit 0 for D = 96, bit 1 for D = 192 ("embed.lds")

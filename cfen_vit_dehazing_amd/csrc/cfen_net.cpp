@@ -47,6 +47,10 @@ int& cfen_tune_attn_head_major() {
   static int v = 1;
   return v;
 }
+int& cfen_tune_stream_front() {   // k_front3 for the D = 384 LViT blocks: 0 never, 1 (default) grouped decoder launches, 2 always
+  static int v = 1;
+  return v;
+}
 int& cfen_tune_stream_mlp() {   // k_mlp3 (k_stream.hip) for the D = 384 blocks: 0 never, 1 (default) grouped decoder launches only (a single instance has
   static int v = 1;             // 64 workgroups of 128 tokens: a quarter of the chip), 2 always
   return v;
@@ -330,6 +334,7 @@ int cfen_net::build() {
     if (v.ln_fold1) { need(n + ".qkv.wl", wbytes(v, 3 * v.Da, v.D)); need(n + ".qkv.s", (size_t)3 * v.Da * 4); need(n + ".qkv.bl", (size_t)3 * v.Da * 4); }
     if (v.ln_fold2) { need(n + ".ffn1.wl", wbytes(v, v.hidden, v.D)); need(n + ".ffn1.s", (size_t)v.hidden * 4); need(n + ".ffn1.bl", (size_t)v.hidden * 4); }
     if (v.stream_mlp) {
+      need(n + ".embed.ws", (size_t)v.D * v.D * esz); need(n + ".qkv.ws", (size_t)3 * v.D * v.D * esz);
       need(n + ".proj.ws", (size_t)v.D * v.D * esz); need(n + ".ffn.ws", (size_t)2 * v.D * v.hidden * esz); need(n + ".head.ws", (size_t)2 * v.D * v.hidden * esz);
     }
     need(n + ".ln2.g", (size_t)v.D * 4); need(n + ".ln2.b", (size_t)v.D * 4);
@@ -586,7 +591,18 @@ int cfen_net::run_vit_g(int ng, const VitCall* vc, int scr0) {
   const float* lg[3];
   const float* lb[3];
   bool head_major = false;   // the fused front half writes qkv per (window, head) for k_attention_hm
-  if (v.fused_front && v.D <= cfen_tune_fused_front_max_dim()) {
+  const long long Mll = M;
+  if (v.stream_mlp && cfen_front3_supported(dt, v.D, Mll) && cfen_attention_hm_supported(dt, v.S, v.D / v.heads) &&
+      (cfen_tune_stream_front() >= 2 || (cfen_tune_stream_front() == 1 && ng == 3))) {
+    // LViT level 3: gather + linear_encoding + residual + position + LN1 + qkv in one launch on row-tile weight streams (k_stream.hip)
+    CfenEmbedQkvArgs e[3];
+    head_major = true;
+    for (int g = 0; g < ng; ++g)
+      e[g] = CfenEmbedQkvArgs{IN[g], B, v.mapH, v.mapH, v.C, bi.cs, v.ws, v.p, P(nm[g] + ".embed.ws"), Pf(nm[g] + ".embed.b"), P(nm[g] + ".pos"),
+                              Pf(nm[g] + ".ln1.g"), Pf(nm[g] + ".ln1.b"), P(nm[g] + ".qkv.ws"), X1[g], QKV[g], M, v.D, 1e-5f, v.heads};
+    step("front_stream");
+    TRYP(K_GEMM, 8 * Md * D * D, cfen_front3_impl_g(dt, ng, e, stream));
+  } else if (v.fused_front && v.D <= cfen_tune_fused_front_max_dim()) {
     // LViT levels 1-2: gather + linear_encoding + residual + position + LN1 + qkv in one launch, x -> X1, QKV (k_embed.hip)
     CfenEmbedQkvArgs e[3];
     head_major = cfen_tune_attn_head_major() && cfen_attention_hm_supported(dt, v.S, v.D / v.heads);

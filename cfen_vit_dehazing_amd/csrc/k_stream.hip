@@ -331,6 +331,230 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
   }
 }
 
+// s_waitcnt vmcnt(n) for a wave-uniform run-time n (the instruction takes an immediate): a switch over the 64 encodable values
+#define CFEN_VMCASE(k) case k: asm volatile("s_waitcnt vmcnt(" #k ")" ::: "memory"); break;
+CFEN_DEV void wait_vmcnt_rt(int n) {
+  switch (n < 63 ? n : 63) {
+    CFEN_VMCASE(0) CFEN_VMCASE(1) CFEN_VMCASE(2) CFEN_VMCASE(3) CFEN_VMCASE(4) CFEN_VMCASE(5) CFEN_VMCASE(6) CFEN_VMCASE(7)
+    CFEN_VMCASE(8) CFEN_VMCASE(9) CFEN_VMCASE(10) CFEN_VMCASE(11) CFEN_VMCASE(12) CFEN_VMCASE(13) CFEN_VMCASE(14) CFEN_VMCASE(15)
+    CFEN_VMCASE(16) CFEN_VMCASE(17) CFEN_VMCASE(18) CFEN_VMCASE(19) CFEN_VMCASE(20) CFEN_VMCASE(21) CFEN_VMCASE(22) CFEN_VMCASE(23)
+    CFEN_VMCASE(24) CFEN_VMCASE(25) CFEN_VMCASE(26) CFEN_VMCASE(27) CFEN_VMCASE(28) CFEN_VMCASE(29) CFEN_VMCASE(30) CFEN_VMCASE(31)
+    CFEN_VMCASE(32) CFEN_VMCASE(33) CFEN_VMCASE(34) CFEN_VMCASE(35) CFEN_VMCASE(36) CFEN_VMCASE(37) CFEN_VMCASE(38) CFEN_VMCASE(39)
+    CFEN_VMCASE(40) CFEN_VMCASE(41) CFEN_VMCASE(42) CFEN_VMCASE(43) CFEN_VMCASE(44) CFEN_VMCASE(45) CFEN_VMCASE(46) CFEN_VMCASE(47)
+    CFEN_VMCASE(48) CFEN_VMCASE(49) CFEN_VMCASE(50) CFEN_VMCASE(51) CFEN_VMCASE(52) CFEN_VMCASE(53) CFEN_VMCASE(54) CFEN_VMCASE(55)
+    CFEN_VMCASE(56) CFEN_VMCASE(57) CFEN_VMCASE(58) CFEN_VMCASE(59) CFEN_VMCASE(60) CFEN_VMCASE(61) CFEN_VMCASE(62)
+    default: asm volatile("s_waitcnt vmcnt(63)" ::: "memory"); break;
+  }
+}
+#undef CFEN_VMCASE
+
+// head-major qkv element offset of feature f of [q | k | v] relative to its window's first element, without the token term
+// (k_embed.hip hm_feature_off; head_dim 24 wherever the layout is used)
+template <int D>
+CFEN_DEV int st_hm_feature_off(int f, int S) {
+  const int part = f / D, fd = f - part * D, hd = fd / 24, d = fd - hd * 24;
+  return ((hd * 3 + part) * S) * 24 + d;
+}
+
+// LViT front half on the fragment-stream ring (D = 384): patch gather -> y = W_e x + b_e + x + pos -> X1; qkv = W_qkv LN1(y), written
+// head-major for k_attention_hm (or row-major).  Both matrices are ROW-TILE streams (packing.pack_stream_rows): phase t = output rows
+// t*32 .. +31, fragments (u, c) = row tile u, k-chunk c.  The qkv phases store their tiles from inside the ring loop, so the ring's waits
+// count every vector-memory operation the wave issues (`vm_issued` against the mark taken when a slot's DMA went out).
+template <int ND, int TM, int R>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void k_front3(Grouped<CfenEmbedQkvArgs> ga) {
+  typedef half_t T;
+  typedef half8 frag;
+  const CfenEmbedQkvArgs a = ga.g[blockIdx.z];
+  constexpr int NW = 4, D = ND * 16, NCH = ND / 2, SLOT = ND * 1024, DPW = ND / NW, RING = R * SLOT;
+  constexpr int NE = ND / 2, NQ = 3 * ND / 2, NP = NE + NQ;     // embedding / qkv phases (two 16-row output tiles each)
+  static_assert(ND % NW == 0 && R >= 3 && RING <= 160 * 1024, "ring geometry");
+  __shared__ __attribute__((aligned(1024))) unsigned char lds[RING];
+  const int tid = threadIdx.x, lane = tid & 63, r16 = lane & 15, h = lane >> 4;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const long long tok0 = ((long long)blockIdx.x * NW + wave) * (TM * 16);   // the launcher guarantees M % (NW * TM * 16) == 0
+
+  int vm_issued = 0;              // vector-memory operations this wave has issued since the last full drain
+  int mark[R];                    // vm_issued right after the DMAs of the phase that sits in each slot
+#pragma unroll
+  for (int q = 0; q < R; ++q) mark[q] = 0;
+  auto issue = [&](int q, int slot) {
+    const unsigned char* src = q < NE ? (const unsigned char*)a.We + (size_t)q * SLOT : (const unsigned char*)a.Wqkv + (size_t)(q - NE) * SLOT;
+#pragma unroll
+    for (int k = 0; k < DPW; ++k) {
+      const int f = k * NW + wave;
+      st_dma(src + f * 1024 + lane * 16, lds + slot * SLOT + f * 1024);
+    }
+    vm_issued += DPW;
+#pragma unroll
+    for (int k = 0; k < R; ++k)
+      if (k == slot) mark[k] = vm_issued;
+  };
+#pragma unroll
+  for (int q = 0; q < R - 1; ++q) issue(q, q);
+
+  // ---- gather x^T into accumulator layout ----
+  const int tw = a.ws / a.p, S = tw * tw, nwx = a.W / a.ws, nwy = a.H / a.ws;
+  floatx4 acc[ND][TM];
+  long long tk[TM];
+#pragma unroll
+  for (int j = 0; j < TM; ++j) {
+    const long long t = tok0 + j * 16 + r16;
+    tk[j] = t;
+    const int tt = (int)(t % S);
+    const long long wi = t / S;
+    const int wx = (int)(wi % nwx), wy = (int)((wi / nwx) % nwy);
+    const long long b = wi / ((long long)nwx * nwy);
+    const int y0 = wy * a.ws + (tt / tw) * a.p, x0 = wx * a.ws + (tt % tw) * a.p;
+    const T* pix = (const T*)a.fmap + ((b * a.H + y0) * a.W + x0) * a.cs;
+#pragma unroll
+    for (int i = 0; i < ND; ++i) {
+      const int f = i * 16 + 4 * h;
+      const int ij = f / a.C, c = f - ij * a.C;
+      acc[i][j] = load4<T>(pix + ((ij / a.p) * a.W + (ij % a.p)) * a.cs + c);
+    }
+  }
+  frag xb[NCH][TM];
+#pragma unroll
+  for (int j = 0; j < TM; ++j)
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) xb[c][j] = pack_pair(acc[c * 2][j], acc[c * 2 + 1][j]);
+#pragma unroll
+  for (int i = 0; i < ND; ++i) {
+    const floatx4 bb = *reinterpret_cast<const floatx4*>(a.be + i * 16 + 4 * h);
+#pragma unroll
+    for (int j = 0; j < TM; ++j) acc[i][j] += bb + load4<T>((const T*)a.pos + (size_t)(tk[j] % S) * D + i * 16 + 4 * h);
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // one drain: ring prologue, pixels, position rows
+  vm_issued = 0;
+#pragma unroll
+  for (int q = 0; q < R; ++q) mark[q] = 0;
+
+  int p = 0, cur = 0, fill = R - 1;
+  auto begin = [&]() {
+    int m = 0;
+#pragma unroll
+    for (int k = 0; k < R; ++k)
+      if (k == cur) m = mark[k];
+    wait_vmcnt_rt(vm_issued - m);    // everything issued up to and including this phase's DMAs has completed
+    __builtin_amdgcn_s_barrier();
+  };
+  auto refill = [&]() {
+    if (p + R - 1 < NP) issue(p + R - 1, fill);
+    fill = cur;
+    cur = cur + 1 == R ? 0 : cur + 1;
+    ++p;
+  };
+  const unsigned lbase = (unsigned)(unsigned long long)(__attribute__((address_space(3))) unsigned char*)lds;
+  const unsigned lfrag = lbase + lane * 16;
+  constexpr int PD = 6, NB = 8;
+  auto phase = [&](unsigned sa, auto&& pre, auto&& body) {
+    frag F[NB];
+    sfor<0, PD>([&](auto fc) {
+      constexpr int f = decltype(fc)::value;
+      lds_rd<f * 1024>(F[f % NB], sa);
+    });
+    pre();
+    sfor<0, ND>([&](auto fc) {
+      constexpr int f = decltype(fc)::value;
+      if constexpr (f + PD < ND) lds_rd<(f + PD) * 1024>(F[(f + PD) % NB], sa);
+      lds_wait<(f + PD < ND ? PD : ND - 1 - f)>(F[f % NB]);
+      body(fc, F[f % NB]);
+    });
+  };
+
+  // ---- y = W_e x + (b_e + x + pos): phase q = output tiles 2q, 2q + 1 ----
+  sfor<0, NE>([&](auto qc) {
+    constexpr int q = decltype(qc)::value;
+    begin();
+    phase(lfrag + cur * SLOT, [&]() { refill(); }, [&](auto fc, const frag& fr) {
+      constexpr int f = decltype(fc)::value, u = f / NCH, c = f % NCH;
+#pragma unroll
+      for (int j = 0; j < TM; ++j) acc[2 * q + u][j] = Mma<T>::mma(fr, xb[c][j], acc[2 * q + u][j]);
+    });
+  });
+#pragma unroll
+  for (int j = 0; j < TM; ++j) {
+    T* yp = (T*)a.X1 + tk[j] * D + 4 * h;
+#pragma unroll
+    for (int i = 0; i < ND; ++i) store4<T>(yp + i * 16, acc[i][j]);
+  }
+  // ---- LayerNorm(y) -> B fragments ----
+#pragma unroll
+  for (int j = 0; j < TM; ++j) {
+    float sm = 0.f;
+#pragma unroll
+    for (int i = 0; i < ND; ++i) sm += acc[i][j][0] + acc[i][j][1] + acc[i][j][2] + acc[i][j][3];
+    sm = col_sum(sm);
+    const float mean = sm * (1.f / D);
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < ND; ++i)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float d = acc[i][j][r] - mean;
+        q += d * d;
+      }
+    q = col_sum(q);
+    const float rstd = rsqrtf(q * (1.f / D) + a.eps);
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+      floatx4 t[2];
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        const int i = c * 2 + u;
+        const floatx4 g = *reinterpret_cast<const floatx4*>(a.ln_g + i * 16 + 4 * h);
+        const floatx4 b = *reinterpret_cast<const floatx4*>(a.ln_b + i * 16 + 4 * h);
+        t[u] = (acc[i][j] - mean) * rstd * g + b;
+      }
+      xb[c][j] = pack_pair(t[0], t[1]);
+    }
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // X1 stores, LayerNorm parameters (the ring is R - 1 phases ahead: its DMAs have long landed)
+  vm_issued = 0;
+#pragma unroll
+  for (int q = 0; q < R; ++q) mark[q] = 0;
+  long long qrow[TM];
+#pragma unroll
+  for (int j = 0; j < TM; ++j)
+    qrow[j] = a.hm_heads ? (tk[j] / S) * (3LL * S * D) + (tk[j] % S) * 24 : tk[j] * (3LL * D);
+
+  // ---- qkv = W_qkv LN(y): phase t = output tiles 2t, 2t + 1, each stored as soon as its last k-chunk is in ----
+#pragma unroll 1
+  for (int t = 0; t < NQ; ++t) {
+    begin();
+    floatx4 qa[2][TM];
+    phase(lfrag + cur * SLOT, [&]() { refill(); }, [&](auto fc, const frag& fr) {
+      constexpr int f = decltype(fc)::value, u = f / NCH, c = f % NCH;
+      if constexpr (c == 0) {
+#pragma unroll
+        for (int j = 0; j < TM; ++j) qa[u][j] = floatx4{0.f, 0.f, 0.f, 0.f};
+      }
+#pragma unroll
+      for (int j = 0; j < TM; ++j) qa[u][j] = Mma<T>::mma(fr, xb[c][j], qa[u][j]);
+      if constexpr (c == NCH - 1) {
+        const int fq = (2 * t + u) * 16 + 4 * h;
+        const long long fo = a.hm_heads ? st_hm_feature_off<D>(fq, S) : fq;
+#pragma unroll
+        for (int j = 0; j < TM; ++j) store4<T>((T*)a.QKV + qrow[j] + fo, qa[u][j]);
+        vm_issued += TM;
+      }
+    });
+  }
+}
+
+template <int ND, int TM, int R>
+int launch_front3(int ng, const CfenEmbedQkvArgs* ap, hipStream_t s) {
+  Grouped<CfenEmbedQkvArgs> ga;
+  for (int g = 0; g < CFEN_MAX_GROUPS; ++g) ga.g[g] = ap[g < ng ? g : 0];
+  const long long per = 4LL * TM * 16;
+  CFEN_CHECK_ARG(ap[0].M % per == 0, "front3: token count must be a multiple of %lld", per);
+  const long long blocks = ap[0].M / per;
+  CFEN_CHECK_ARG(blocks > 0 && blocks < (1ll << 31), "front3: bad grid");
+  CFEN_LAUNCH((k_front3<ND, TM, R>), dim3((unsigned)blocks, 1, ng), dim3(256), 0, s, ga);
+  CFEN_CHECK_LAUNCH("front3");
+  return CFEN_OK;
+}
+
 template <int ND, int TM, int R, int HB, int DBG = 0>
 int launch_mlp3(int ng, const Mlp3Args* ap, hipStream_t s) {
   Grouped<Mlp3Args> ga;
@@ -378,4 +602,26 @@ int cfen_mlp3_impl_g(int dtype, int ng, const Mlp3Args* ap, hipStream_t s) {
   if (ap[0].D == 384 && cfen_tune_mlp3_debug() == 2) return launch_mlp3<24, 2, 6, 1536, 2>(ng, ap, s);
   if (ap[0].D == 384) return launch_mlp3<24, 2, 6, 1536>(ng, ap, s);
   return launch_mlp3<12, 4, 8, 768>(ng, ap, s);
+}
+
+bool cfen_front3_supported(int dtype, int D, long long M) { return dtype == 1 && D == 384 && M % 128 == 0; }
+
+// We / Wqkv of the arguments are ROW-TILE fragment streams here (packing.pack_stream_rows), everything else as cfen_embed_qkv_impl_g
+int cfen_front3_impl_g(int dtype, int ng, const CfenEmbedQkvArgs* ap, hipStream_t s) {
+  CFEN_CHECK_ARG(ng >= 1 && ng <= CFEN_MAX_GROUPS && ap, "front3: 1..%d problems per launch", CFEN_MAX_GROUPS);
+  CFEN_CHECK_ARG(cfen_front3_supported(dtype, ap[0].D, ap[0].M), "front3: the fragment-stream front half runs fp16 at D = 384 on whole 128-token workgroups (dtype %d, D %d, M %lld)",
+                 dtype, ap[0].D, ap[0].M);
+  for (int g = 0; g < ng; ++g) {
+    const CfenEmbedQkvArgs& a = ap[g];
+    CFEN_CHECK_ARG(a.fmap && a.We && a.be && a.pos && a.ln_g && a.ln_b && a.Wqkv && a.X1 && a.QKV, "front3: null pointer");
+    CFEN_CHECK_ARG(cfen_aligned16(a.fmap) && cfen_aligned16(a.We) && cfen_aligned16(a.be) && cfen_aligned16(a.pos) && cfen_aligned16(a.ln_g) &&
+                   cfen_aligned16(a.ln_b) && cfen_aligned16(a.Wqkv) && cfen_aligned16(a.X1) && cfen_aligned16(a.QKV), "front3: pointers must be 16-byte aligned");
+    CFEN_CHECK_ARG(a.C > 0 && a.C % 8 == 0 && a.cs % 8 == 0 && a.cs >= a.C && a.p > 0 && a.ws % a.p == 0 && a.H % a.ws == 0 && a.W % a.ws == 0 && a.B > 0,
+                   "front3: bad token geometry");
+    const int tw = a.ws / a.p;
+    CFEN_CHECK_ARG(a.D == a.p * a.p * a.C && a.M == (long long)a.B * (a.H / a.ws) * (a.W / a.ws) * tw * tw, "front3: D / M do not match the map");
+    CFEN_CHECK_ARG(a.D == ap[0].D && a.M == ap[0].M && a.hm_heads == ap[0].hm_heads, "front3: grouped problems must have the same shape");
+    CFEN_CHECK_ARG(a.hm_heads == 0 || a.D == a.hm_heads * 24, "front3: the head-major layout needs head_dim 24");
+  }
+  return launch_front3<24, 2, 6>(ng, ap, s);
 }

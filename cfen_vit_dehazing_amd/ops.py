@@ -183,7 +183,7 @@ def embed_gather(fmap, C, ws, p, w, bias, pos):
     return out
 
 
-def embed_qkv(fmap, C, ws, p, we, be, pos, ln_g, ln_b, wqkv, eps=1e-5, head_major_heads=0):
+def embed_qkv(fmap, C, ws, p, we, be, pos, ln_g, ln_b, wqkv, eps=1e-5, head_major_heads=0, stream_weights=False):
     """fused LViT front half (D = p*p*C in {96,192}); we / wqkv with the k axis in packing.kperm32 order for fp16.
     Returns (x1 [M,D], qkv [M,3D])."""
     from ._lib import EmbedQkvArgsC
@@ -196,7 +196,8 @@ def embed_qkv(fmap, C, ws, p, we, be, pos, ln_g, ln_b, wqkv, eps=1e-5, head_majo
     a = EmbedQkvArgsC(fmap=fmap.data_ptr(), B=B, H=H, W=W, C=C, cs=cs, ws=ws, p=p, we=we.data_ptr(), be=be.data_ptr(), pos=pos.data_ptr(),
                       ln_gamma=ln_g.data_ptr(), ln_beta=ln_b.data_ptr(), wqkv=wqkv.data_ptr(), x1=x1.data_ptr(), qkv=qkv.data_ptr(), eps=eps,
                       head_major_heads=head_major_heads)
-    check(_lib.load().cfen_embed_qkv(dtype_code(fmap.dtype), ctypes.byref(a), current_stream()), "embed_qkv")
+    fn = _lib.load().cfen_embed_qkv_stream if stream_weights else _lib.load().cfen_embed_qkv   # stream_weights: we / wqkv = packing.pack_stream_rows (D = 384)
+    check(fn(dtype_code(fmap.dtype), ctypes.byref(a), current_stream()), "embed_qkv")
     return x1, qkv
 
 

@@ -132,6 +132,14 @@ def pack_stream_pair(w1k, w2k):
     return torch.cat((p1, p2), 1).contiguous().view(-1)
 
 
+def pack_stream_rows(wk):
+    """[N][K] (k axis kperm32'd) -> ROW-TILE fragment stream for csrc/k_stream.hip (k_front3): phase t = output rows t*32 .. +31, fragments
+    (u, c) = 16-row tile u, k-chunk c in lane order; K / 16 fragments of 1 KiB per phase (the W1 phases of pack_stream_pair on their own)."""
+    n, k = wk.shape
+    assert n % 32 == 0 and k % 32 == 0
+    return wk.reshape(n // 32, 2, 16, k // 32, 4, 8).permute(0, 1, 3, 4, 2, 5).contiguous().view(-1)
+
+
 STREAM_MLP_DIMS = (384,)
 
 
@@ -261,6 +269,9 @@ def pack_vit(sd, g, dtype):
         out[n + ".proj.ws"] = pack_stream_sq(out[n + ".proj.w"])
         out[n + ".ffn.ws"] = pack_stream_pair(out[n + ".ffn1.w"][:, kd], out[n + ".ffn2.w"][:, kh])
         out[n + ".head.ws"] = pack_stream_pair(out[n + ".head1.w"][:, kd], out[n + ".head2.w"][:, kh])
+        # k_front3: linear_encoding and in_proj as row-tile streams (the LayerNorm-folded and plain matrices stay for "net.stream_front" = 0)
+        out[n + ".embed.ws"] = pack_stream_rows(out[n + ".embed.w"][:, kd])
+        out[n + ".qkv.ws"] = pack_stream_rows(out[n + ".qkv.w"][:, kd])
     if mlp_is_fused(g, dtype):
         # the fused MLP kernel replaces the four separate GEMMs: same matrices, k axis re-slotted (fp16 only)
         for a, b in (("ffn1", "ffn2"), ("head1", "head2")):

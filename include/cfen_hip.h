@@ -150,6 +150,9 @@ typedef struct cfen_embed_qkv_args {
                                  [(window * heads + head) * 3 + {q, k, v}][S][D / heads] -- the input of cfen_attention_head_major */
 } cfen_embed_qkv_args;
 int cfen_embed_qkv(int dtype, const cfen_embed_qkv_args* a, void* stream);
+/* The same front half for D = 384 (LViT level 3; CFEN_F16, token count a multiple of 128) on the fragment-stream ring of cfen_mlp_stream_block:
+ * `we` / `wqkv` are ROW-TILE fragment streams (packing.pack_stream_rows of the kperm32-slotted matrices): [rows / 32][2 row tiles][D / 32 k-chunks][1 KiB]. */
+int cfen_embed_qkv_stream(int dtype, const cfen_embed_qkv_args* a, void* stream);
 /* LayerNorm over the last dim (eps as given), gamma/beta fp32                       (v3:1370-1371) */
 int cfen_layernorm(int dtype, const void* X, void* Y, const float* gamma, const float* beta, int M, int D, float eps, void* stream);
 /* softmax(QK^T/sqrt(dh))V per (sequence, head); QKV is [nseq*S][3*heads*dh], out [nseq*S][heads*dh]  (v3:1364) */

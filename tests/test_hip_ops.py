@@ -370,6 +370,38 @@ def test_embed_qkv_fused_front(dtype, C, H, W, ws):
     close(qkv, q_u.double(), tol(dtype, 8))
 
 
+@pytest.mark.parametrize("H,W,ws,hm", [(64, 32, 32, True), (32, 64, 16, False)])
+def test_embed_qkv_stream_front_d384(H, W, ws, hm):
+    """k_front3 (row-tile weight streams, one wave per SIMD; C = 96, D = 384, 16 heads of 24) against fp64, row-major and head-major qkv"""
+    dtype = torch.float16
+    d = dev()
+    B, C, p, D, heads = 2, 96, 2, 384, 16
+    S = (ws // p) ** 2
+    fmap = ops.to_nhwc(rnd((B, C, H, W), 1, dtype)).to(d)
+    we, be = rnd((D, D), 2, dtype, D ** -0.5), 0.1 * rnd((D,), 3, torch.float32)
+    pos = rnd((S, D), 4, dtype)
+    g, b = 1 + 0.1 * rnd((D,), 5, torch.float32), 0.1 * rnd((D,), 6, torch.float32)
+    wq = rnd((3 * D, D), 7, dtype, D ** -0.5)
+    tok = ops.patchify(fmap, C, ws, p).double().cpu()
+    M = tok.shape[0]
+    y = tok @ we.double().t() + be.double() + tok + pos.double().repeat(M // S, 1)
+    qkv = cfen_oracle.layer_norm(y, g.double(), b.double()) @ wq.double().t()
+    kd = packing.kperm32(D)
+    x1, got = ops.embed_qkv(fmap, C, ws, p, packing.pack_stream_rows(we[:, kd]).to(d), be.to(d), pos.to(d), g.to(d), b.to(d),
+                            packing.pack_stream_rows(wq[:, kd]).to(d), head_major_heads=heads if hm else 0, stream_weights=True)
+    close(x1, y, tol(dtype, 6), "x1")
+    if hm:
+        want = to_head_major(qkv, M // S, S, heads)
+        close(got.view(-1), want.reshape(-1), tol(dtype, 12), "qkv head-major")
+        att = ops.attention_head_major(got, M // S, S, heads)
+        close(att, attn_ref(qkv, M // S, S, heads), tol(dtype, 12), "attention on the streamed front half's qkv")
+    else:
+        close(got, qkv, tol(dtype, 12), "qkv")
+    again = ops.embed_qkv(fmap, C, ws, p, packing.pack_stream_rows(we[:, kd]).to(d), be.to(d), pos.to(d), g.to(d), b.to(d),
+                          packing.pack_stream_rows(wq[:, kd]).to(d), head_major_heads=heads if hm else 0, stream_weights=True)
+    assert torch.equal(again[0], x1) and torch.equal(again[1], got)
+
+
 # ---------------------------------------------------------------------------------------------------
 def run_conv(dtype, x, w, b, k, stride, pad, reflect=False, an=None, act=0, res=None, nchw=False, x2=None):
     kc = 32 if dtype == torch.float16 else 16
