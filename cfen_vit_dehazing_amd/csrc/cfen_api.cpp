@@ -266,6 +266,10 @@ int cfen_tune(const char* key, int value) {
     cfen_tune_attn_head_major() = value != 0;
     return CFEN_OK;
   }
+  if (!strcmp(key, "net.head_fused")) {
+    cfen_tune_head_fused() = value != 0;
+    return CFEN_OK;
+  }
   if (!strcmp(key, "net.stream_front")) {
     CFEN_CHECK_ARG(value >= 0 && value <= 2, "tune: net.stream_front is 0 (never), 1 (grouped decoder launches) or 2 (always)");
     cfen_tune_stream_front() = value;

@@ -47,6 +47,10 @@ int& cfen_tune_attn_head_major() {
   static int v = 1;
   return v;
 }
+int& cfen_tune_head_fused() {
+  static int v = 1;
+  return v;
+}
 int& cfen_tune_stream_front() {   // k_front3 for the D = 384 LViT blocks: 0 never, 1 (default) grouped decoder launches, 2 always
   static int v = 1;
   return v;
@@ -868,9 +872,24 @@ int cfen_net::forward(const float* x, float* xr, float* xs, float* xd) {
     TRYP(K_TOKEN, 0, cfen_nchw_to_nhwc_impl(dt, x, map_ptr("input"), B, 3, full, full, bin.cs, stream));
   }
   // head: conv5x5 + ResBlock                                                   (v3:123-127,395)
-  TRY(run_conv("head.0.0", "input", nullptr, nullptr, nullptr, 0, "head.conv5", nullptr));
-  TRY(run_conv("head.0.1.body.0", "head.conv5", nullptr, nullptr, nullptr, 1, "head.res_mid", nullptr));
-  TRY(run_conv("head.0.1.body.2", "head.res_mid", nullptr, "head.conv5", nullptr, 0, "head", nullptr));
+  const ConvLayer& h5 = convs.at("head.0.0");
+  if (cfen_tune_head_fused() && h5.tile && convs.at("head.0.1.body.0").tile && convs.at("head.0.1.body.2").tile &&
+      cfen_head_fused_supported(dt, bin.cs, h5.Cout, full, full)) {
+    // one launch, the 5x5 output and the ResBlock's hidden map stay in LDS (k_conv_tile.hip: k_head_fused)
+    label = "head (conv5 + ResBlock fused)";
+    double fl = 0.0;
+    for (const char* l : {"head.0.0", "head.0.1.body.0", "head.0.1.body.2"}) {
+      const ConvLayer& c = convs.at(l);
+      fl += B * 2.0 * c.Cout * (double)c.Cin_real * c.k * c.k * (double)full * full;
+    }
+    TRYP(K_CONV, fl, cfen_head_fused_impl(dt, map_ptr("input"), map_ptr("head"), P("head.0.0.wr"), Pf("head.0.0.scale"), Pf("head.0.0.shift"),
+                                          P("head.0.1.body.0.wr"), Pf("head.0.1.body.0.scale"), Pf("head.0.1.body.0.shift"), P("head.0.1.body.2.wr"),
+                                          Pf("head.0.1.body.2.scale"), Pf("head.0.1.body.2.shift"), B, full, full, stream));
+  } else {
+    TRY(run_conv("head.0.0", "input", nullptr, nullptr, nullptr, 0, "head.conv5", nullptr));
+    TRY(run_conv("head.0.1.body.0", "head.conv5", nullptr, nullptr, nullptr, 1, "head.res_mid", nullptr));
+    TRY(run_conv("head.0.1.body.2", "head.res_mid", nullptr, "head.conv5", nullptr, 0, "head", nullptr));
+  }
   auto down = [&](const std::string& layer, const std::string& in) -> int {   // conv s2 -> IN -> ReLU (v3:292-298)
     TRY(run_conv(layer, in, nullptr, nullptr, nullptr, 0, layer, nullptr));
     const Buf& b = bufs.at(layer);

@@ -522,3 +522,191 @@ int cfen_conv7_tz_impl_g(int dtype, int ng, const ConvDesc* dp, hipStream_t s) {
   CFEN_CHECK_LAUNCH("conv7 (toeplitz)");
   return CFEN_OK;
 }
+
+// ---------------------------------------------------------------------------------------------------------------
+// head = conv5x5 (3 -> 12) + ResBlock (conv3x3, ReLU, conv3x3, + input) of the generator (v3:123-127, 395; common.py:41-62) in ONE launch
+// (round 3).  The three stride-1 convolutions ran at 2.8 - 5.1 TB/s each, i.e. at the HBM rate of their own maps: 33 + 67 MB for the 5x5,
+// 67 + 67 for the first 3x3, 3 x 67 for the second -- 400 MB for a block whose input and output are 100 MB.  Here a workgroup (5 waves)
+// produces a 64 x 8 output tile from an 87 x 16 input halo: the 5x5 output t1 (80 x 12 pixels) and the first 3x3's output t2 (80 x 10)
+// exist only as fp16 tiles in LDS (rounded exactly as the maps the unfused kernels wrote), positions outside the image hold the zero padding
+// the next convolution expects.  Intermediate strips are computed 80 pixels wide so that every column the final 64 need -- zero-weight pad
+// taps included -- is a finite, correct value.  Per-wave structure as k_conv_tile: a 16-pixel column strip, an input-row fragment feeds every
+// (output row, dy) pair, all weight fragments in registers ("rows" layout of the three layers, unchanged).
+namespace {
+
+struct HeadFusedArgs {
+  const void* in; void* out;                      // NHWC fp16: input 8 channels (16-byte pixels), output 16 channels (12 real)
+  const void *w5, *wa, *wb;                       // rows layouts: 5x5 over 16-byte pixels, 3x3 over 32-byte pixels (twice)
+  const float *s5, *t5, *sa, *ta, *sb, *tb;       // (scale, shift) epilogue tables of the three layers
+  int B, H, W;
+};
+
+constexpr int HF_R = 8;                            // output rows per workgroup
+constexpr int HF_WIN = 87, HF_RIN = HF_R + 8;      // input halo: columns x0 - 10 .. x0 + 76, rows y0 - 4 .. y0 + R + 3
+constexpr int HF_WT = 83;                          // t1 / t2 tile columns: x0 - 9 .. x0 + 73 (computed: x0 - 8 .. x0 + 71)
+constexpr int HF_R1 = HF_R + 4, HF_R2 = HF_R + 2;  // t1 rows y0 - 2 .., t2 rows y0 - 1 ..
+constexpr int HF_LDS = HF_RIN * HF_WIN * 16 + (HF_R1 + HF_R2) * HF_WT * 32;
+static_assert(2 * HF_LDS <= 160 * 1024, "two workgroups a CU");
+
+__global__ __launch_bounds__(320) void k_head_fused(HeadFusedArgs a, int nblk) {
+  typedef half_t T;
+  typedef half8 frag;
+  __shared__ __attribute__((aligned(16))) unsigned char lds[HF_LDS];
+  unsigned char* const tin = lds;
+  unsigned char* const t1 = lds + HF_RIN * HF_WIN * 16;
+  unsigned char* const t2 = t1 + HF_R1 * HF_WT * 32;
+  constexpr int RBI = HF_WIN * 16, RBT = HF_WT * 32;
+
+  const int blk = (int)xcd_chunked_block(blockIdx.x, gridDim.x);
+  if (blk >= nblk) return;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r16 = lane & 15, h = lane >> 4;
+  const int tiles_x = a.W / 64, tiles_y = a.H / HF_R;
+  const int tx = blk % tiles_x, ty = (blk / tiles_x) % tiles_y, b = blk / (tiles_x * tiles_y);
+  const int x0 = tx * 64, y0 = ty * HF_R;
+  const unsigned char* src = (const unsigned char*)a.in + (size_t)b * a.H * a.W * 16;
+
+  // ---- stage the input halo (zero outside the image), all loads in flight before the first LDS store ----
+  constexpr int NPIECE = HF_RIN * HF_WIN, NIT = (NPIECE + 319) / 320;
+  frag stg[NIT];
+#pragma unroll
+  for (int i = 0; i < NIT; ++i) {
+    const int idx = tid + i * 320;
+    const int col = idx % HF_WIN, row = idx / HF_WIN;
+    const int gy = y0 - 4 + row, gx = x0 - 10 + col;
+    const bool ok = idx < NPIECE && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W;
+    stg[i] = ok ? *reinterpret_cast<const frag*>(src + ((size_t)gy * a.W + gx) * 16) : Mma<T>::zero();
+  }
+  // the three layers' weights: lane (r16 = output feature, h) keeps its 16 bytes of every chunk
+  frag w5[5][2], wa[3][2], wb[3][2];
+  {
+    const T* p5 = (const T*)a.w5 + (size_t)r16 * (5 * 2 * 32) + h * 8;
+    const T* pa = (const T*)a.wa + (size_t)r16 * (3 * 2 * 32) + h * 8;
+    const T* pb = (const T*)a.wb + (size_t)r16 * (3 * 2 * 32) + h * 8;
+#pragma unroll
+    for (int dy = 0; dy < 5; ++dy)
+#pragma unroll
+      for (int c = 0; c < 2; ++c) w5[dy][c] = load_frag<T>(p5 + (dy * 2 + c) * 32);
+#pragma unroll
+    for (int dy = 0; dy < 3; ++dy)
+#pragma unroll
+      for (int c = 0; c < 2; ++c) {
+        wa[dy][c] = load_frag<T>(pa + (dy * 2 + c) * 32);
+        wb[dy][c] = load_frag<T>(pb + (dy * 2 + c) * 32);
+      }
+  }
+#pragma unroll
+  for (int i = 0; i < NIT; ++i) {
+    const int idx = tid + i * 320;
+    if (idx < NPIECE) *reinterpret_cast<frag*>(tin + idx * 16) = stg[i];
+  }
+  __syncthreads();
+
+  const int n = 4 * h;                               // the lane's 4 output channels of pixel column r16 of its strip
+  const int gcol = x0 - 8 + wave * 16 + r16;         // image column of that pixel in the 80-wide intermediate strips
+  const bool colin = gcol >= 0 && gcol < a.W;
+  // ---- stage A: t1 = conv5x5(input) + bias on rows y0 - 2 .. y0 + R + 1, columns x0 - 8 .. x0 + 71 ----
+  {
+    floatx4 acc[HF_R1];
+#pragma unroll
+    for (int r = 0; r < HF_R1; ++r) acc[r] = floatx4{0.f, 0.f, 0.f, 0.f};
+    const unsigned char* lp = tin + (wave * 16 + r16) * 16 + h * 16;     // input column (gcol - 2) - (x0 - 10) = 16 wave + r16; chunk = 4 taps of 16 B
+#pragma unroll
+    for (int iy = 0; iy < HF_RIN; ++iy)
+#pragma unroll
+      for (int c = 0; c < 2; ++c) {
+        const frag bf = *reinterpret_cast<const frag*>(lp + iy * RBI + c * 64);
+#pragma unroll
+        for (int r = 0; r < HF_R1; ++r) {
+          const int dy = iy - r;
+          if (dy >= 0 && dy < 5) acc[r] = Mma<T>::mma(w5[dy][c], bf, acc[r]);
+        }
+      }
+    const floatx4 sc = *reinterpret_cast<const floatx4*>(a.s5 + n), sh = *reinterpret_cast<const floatx4*>(a.t5 + n);
+#pragma unroll
+    for (int r = 0; r < HF_R1; ++r) {
+      const int gy = y0 - 2 + r;
+      floatx4 v = acc[r] * sc + sh;
+      if (!(colin && gy >= 0 && gy < a.H)) v = floatx4{0.f, 0.f, 0.f, 0.f};   // zero padding of the next convolution
+      const half4 o = {(half_t)v[0], (half_t)v[1], (half_t)v[2], (half_t)v[3]};
+      *reinterpret_cast<half4*>(t1 + r * RBT + (wave * 16 + r16 + 1) * 32 + n * 2) = o;
+    }
+  }
+  __syncthreads();
+  // ---- stage B: t2 = relu(conv3x3(t1) + bias) on rows y0 - 1 .. y0 + R, same 80 columns ----
+  {
+    floatx4 acc[HF_R2];
+#pragma unroll
+    for (int r = 0; r < HF_R2; ++r) acc[r] = floatx4{0.f, 0.f, 0.f, 0.f};
+    const unsigned char* lp = t1 + (wave * 16 + r16) * 32 + h * 16;      // t1 tile column (gcol - 1) - (x0 - 9) = 16 wave + r16; chunk = 2 taps of 32 B
+#pragma unroll
+    for (int iy = 0; iy < HF_R1; ++iy)
+#pragma unroll
+      for (int c = 0; c < 2; ++c) {
+        const frag bf = *reinterpret_cast<const frag*>(lp + iy * RBT + c * 64);
+#pragma unroll
+        for (int r = 0; r < HF_R2; ++r) {
+          const int dy = iy - r;
+          if (dy >= 0 && dy < 3) acc[r] = Mma<T>::mma(wa[dy][c], bf, acc[r]);
+        }
+      }
+    const floatx4 sc = *reinterpret_cast<const floatx4*>(a.sa + n), sh = *reinterpret_cast<const floatx4*>(a.ta + n);
+#pragma unroll
+    for (int r = 0; r < HF_R2; ++r) {
+      const int gy = y0 - 1 + r;
+      floatx4 v = acc[r] * sc + sh;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
+      if (!(colin && gy >= 0 && gy < a.H)) v = floatx4{0.f, 0.f, 0.f, 0.f};
+      const half4 o = {(half_t)v[0], (half_t)v[1], (half_t)v[2], (half_t)v[3]};
+      *reinterpret_cast<half4*>(t2 + r * RBT + (wave * 16 + r16 + 1) * 32 + n * 2) = o;
+    }
+  }
+  __syncthreads();
+  // ---- stage C: out = conv3x3(t2) + bias + t1 on the 64 x R tile (waves 0..3) ----
+  if (wave < 4) {
+    floatx4 acc[HF_R];
+#pragma unroll
+    for (int r = 0; r < HF_R; ++r) acc[r] = floatx4{0.f, 0.f, 0.f, 0.f};
+    const unsigned char* lp = t2 + (wave * 16 + r16 + 8) * 32 + h * 16;  // t2 tile column (x0 + 16 wave + r16 - 1) - (x0 - 9)
+#pragma unroll
+    for (int iy = 0; iy < HF_R2; ++iy)
+#pragma unroll
+      for (int c = 0; c < 2; ++c) {
+        const frag bf = *reinterpret_cast<const frag*>(lp + iy * RBT + c * 64);
+#pragma unroll
+        for (int r = 0; r < HF_R; ++r) {
+          const int dy = iy - r;
+          if (dy >= 0 && dy < 3) acc[r] = Mma<T>::mma(wb[dy][c], bf, acc[r]);
+        }
+      }
+    const floatx4 sc = *reinterpret_cast<const floatx4*>(a.sb + n), sh = *reinterpret_cast<const floatx4*>(a.tb + n);
+    const int ox = x0 + wave * 16 + r16;
+#pragma unroll
+    for (int r = 0; r < HF_R; ++r) {
+      floatx4 v = acc[r] * sc + sh;
+      const half4 res = *reinterpret_cast<const half4*>(t1 + (r + 2) * RBT + (wave * 16 + r16 + 9) * 32 + n * 2);   // t1 at (y0 + r, ox): the ResBlock's input
+#pragma unroll
+      for (int e = 0; e < 4; ++e) v[e] += (float)res[e];
+      store4<T>((T*)a.out + (((size_t)b * a.H + y0 + r) * a.W + ox) * 16 + n, v);
+    }
+  }
+}
+
+}  // namespace
+
+bool cfen_head_fused_supported(int dtype, int cs_in, int C, int H, int W) { return dtype == 1 && cs_in == 8 && C == 12 && H % HF_R == 0 && W % 64 == 0; }
+
+// in: (B, H, W, 8) fp16; out: (B, H, W, 16); weights / tables = the "<layer>.wr" / ".scale" / ".shift" entries of head.0.0, head.0.1.body.0, head.0.1.body.2
+int cfen_head_fused_impl(int dtype, const void* in, void* out, const void* w5, const float* s5, const float* t5, const void* wa, const float* sa,
+                         const float* ta, const void* wb, const float* sb, const float* tb, int B, int H, int W, hipStream_t s) {
+  CFEN_CHECK_ARG(cfen_head_fused_supported(dtype, 8, 12, H, W) && B > 0, "head (fused): fp16, image edges multiples of 8 / 64 (got dtype %d, %d x %d)", dtype, H, W);
+  CFEN_CHECK_ARG(in && out && w5 && wa && wb && s5 && t5 && sa && ta && sb && tb, "head (fused): null pointer");
+  CFEN_CHECK_ARG(cfen_aligned16(in) && cfen_aligned16(out) && cfen_aligned16(w5) && cfen_aligned16(wa) && cfen_aligned16(wb) && cfen_aligned16(s5) &&
+                 cfen_aligned16(t5) && cfen_aligned16(sa) && cfen_aligned16(ta) && cfen_aligned16(sb) && cfen_aligned16(tb), "head (fused): pointers must be 16-byte aligned");
+  const HeadFusedArgs a{in, out, w5, wa, wb, s5, t5, sa, ta, sb, tb, B, H, W};
+  const long long nblk = (long long)B * (H / HF_R) * (W / 64);
+  CFEN_CHECK_ARG(nblk < (1ll << 31), "head (fused): grid too large");
+  CFEN_LAUNCH(k_head_fused, dim3(cfen_grid8(nblk)), dim3(320), 0, s, a, (int)nblk);
+  CFEN_CHECK_LAUNCH("head (fused)");
+  return CFEN_OK;
+}

@@ -69,35 +69,47 @@ CFEN_DEV void lds_wait(half8& f, floatx4& b0, floatx4& b1) {
   asm volatile("s_waitcnt lgkmcnt(%3)" : "+v"(f), "+v"(b0), "+v"(b1) : "n"(N));
 }
 
+// MFMA result -> VALU reader with inline asm in between: hipcc's hazard recognizer does not carry the matrix pipe's write-back latency
+// across an asm statement (found the hard way: k_front3's row-major qkv tiles of the second token tile came out short of their last
+// k-chunk).  Wherever vector code reads an accumulator whose last MFMA sits behind one of this file's asm reads / waits, this pins 12
+// wait states (8-pass MFMA -> VALU read) between them; the sched_barriers keep the MFMAs above and the readers below.
+CFEN_DEV void mfma_results_settle() {
+  __builtin_amdgcn_sched_barrier(0);
+  asm volatile("s_nop 11" ::: "memory");
+  __builtin_amdgcn_sched_barrier(0);
+}
+
 CFEN_DEV half8 pack_pair(const floatx4& a, const floatx4& b) {
   half8 f = {(half_t)a[0], (half_t)a[1], (half_t)a[2], (half_t)a[3], (half_t)b[0], (half_t)b[1], (half_t)b[2], (half_t)b[3]};
   return f;
 }
 
-// ND = D / 16 feature tiles, TM token tiles of 16 per wave, R ring slots of ND KiB, HB = largest hidden width (bias staging area)
+// ND = D / 16 feature tiles, TM token tiles of 16 per wave, R ring slots, HB = largest hidden width (bias staging area).
+// A ring slot holds a DOUBLE phase = 2 ND fragments: the W1 slice AND the W2 slice of one 32-unit hidden sub-step (or two k-chunks of Wp).
+// Measured with single phases (one barrier per ND fragments): 0.63 us a phase whether it held 12 or 24 KiB -- barrier skew, the refill of the
+// fragment pipeline and the DMA issue cost ~0.3 us each time, as much as the 48 MFMAs of the phase; one barrier per sub-step halves that.
 // DBG (timing experiments only, results invalid): 1 = no LDS-DMA refills after the prologue, 2 = no MFMAs in the hidden loop
 template <int ND, int TM, int R, int HB, int DBG = 0>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void k_mlp3(Grouped<Mlp3Args> ga) {
   typedef half_t T;
   typedef half8 frag;
   const Mlp3Args a = ga.g[blockIdx.z];
-  constexpr int NW = 4, D = ND * 16, NCH = ND / 2, SLOT = ND * 1024, DPW = ND / NW, RING = R * SLOT;
-  constexpr int NG = ND / 3;   // fragment groups of 3 per phase
-  static_assert(ND % NW == 0 && NCH % 3 == 0 && R >= 3 && (R - 2) * DPW < 64 && HB % 256 == 0, "ring geometry");
+  constexpr int NW = 4, D = ND * 16, NCH = ND / 2, NF = 2 * ND, SLOT = NF * 1024, DPW = NF / NW, RING = R * SLOT;
+  static_assert(NF % NW == 0 && NCH % 2 == 0 && R >= 3 && (R - 2) * DPW < 64 && HB % 256 == 0, "ring geometry");
   static_assert(RING + 2 * HB * 4 <= 160 * 1024, "LDS");
   __shared__ __attribute__((aligned(1024))) unsigned char lds[RING + 2 * HB * 4];
 
   const int tid = threadIdx.x, lane = tid & 63, r16 = lane & 15, h = lane >> 4;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const long long tok0 = ((long long)blockIdx.x * NW + wave) * (TM * 16);
-  const int nt = a.H / 32;                      // 32-unit hidden sub-steps per stage
-  const int npp = a.Wp ? NCH : 0;               // projection phases
-  const int NP = npp + 2 * nt * (a.Wb ? 2 : 1);
+  const int nt = a.H / 32;                      // 32-unit hidden sub-steps per stage = double phases per stage
+  const int npp = a.Wp ? NCH / 2 : 0;           // projection double phases
+  const int NP = npp + nt * (a.Wb ? 2 : 1);
 
   auto issue = [&](int q, int slot) {
-    const unsigned char* src = q < npp            ? (const unsigned char*)a.Wp + (size_t)q * SLOT
-                               : q < npp + 2 * nt ? (const unsigned char*)a.Wa + (size_t)(q - npp) * SLOT
-                                                  : (const unsigned char*)a.Wb + (size_t)(q - npp - 2 * nt) * SLOT;
+    const unsigned char* src = q < npp        ? (const unsigned char*)a.Wp + (size_t)q * SLOT
+                               : q < npp + nt ? (const unsigned char*)a.Wa + (size_t)(q - npp) * SLOT
+                                              : (const unsigned char*)a.Wb + (size_t)(q - npp - nt) * SLOT;
 #pragma unroll
     for (int k = 0; k < DPW; ++k) {
       const int f = k * NW + wave;
@@ -142,10 +154,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 
   int p = 0, cur = 0, fill = R - 1;
   // phase p has landed and is visible to every wave; every wave is done with the slot of phase p - 1
-  auto begin = [&]() -> const unsigned char* {
+  auto begin = [&]() {
     wait_phases<DPW, R - 2>(min(R - 2, NP - 1 - p));
     __builtin_amdgcn_s_barrier();
-    return lds + cur * SLOT;
   };
   // ... which phase p + R - 1 may now overwrite (called after the phase's first fragment reads are issued)
   auto refill = [&]() {
@@ -157,9 +168,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
   // LDS byte addresses (the low 32 bits of a generic pointer into LDS are its LDS offset)
   const unsigned lbase = (unsigned)(unsigned long long)(__attribute__((address_space(3))) unsigned char*)lds;
   const unsigned lfrag = lbase + lane * 16;     // + slot * SLOT + fragment * 1024
-  constexpr int PD = 6, NB = 8;                 // fragment reads in flight ahead of the MFMAs / registers of the fragment ring
-  static_assert(PD < NB && PD <= ND, "fragment ring");
-  // one phase: ND fragments, each consumed by body(index, fragment); `pre` runs once the first PD reads are issued (the DMA refill)
+  constexpr int PD = TM >= 4 ? 4 : 6, NB = PD + 2;   // fragment reads in flight ahead of the MFMAs (>= 256 MFMA cycles of cover) / registers of the fragment ring
+  static_assert(PD < NB && PD <= NF, "fragment ring");
+  // one double phase: NF fragments, each consumed by body(index, fragment); `pre` runs once the first PD reads are issued (the DMA refill)
   auto phase = [&](unsigned sa, auto&& pre, auto&& body) {
     frag F[NB];
     sfor<0, PD>([&](auto fc) {
@@ -167,28 +178,29 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
       lds_rd<f * 1024>(F[f % NB], sa);
     });
     pre();
-    sfor<0, ND>([&](auto fc) {
+    sfor<0, NF>([&](auto fc) {
       constexpr int f = decltype(fc)::value;
-      if constexpr (f + PD < ND) lds_rd<(f + PD) * 1024>(F[(f + PD) % NB], sa);
-      lds_wait<(f + PD < ND ? PD : ND - 1 - f)>(F[f % NB]);
+      if constexpr (f + PD < NF) lds_rd<(f + PD) * 1024>(F[(f + PD) % NB], sa);
+      lds_wait<(f + PD < NF ? PD : NF - 1 - f)>(F[f % NB]);
       body(fc, F[f % NB]);
     });
   };
 
-  // ---- x += Wp att (out_proj + residual, v3:1386): phase c = k-chunk c of all ND feature tiles ----
+  // ---- x += Wp att (out_proj + residual, v3:1386): double phase q = k-chunks 2q, 2q + 1 of all ND feature tiles ----
   if (a.Wp) {
-    sfor<0, NCH>([&](auto cc) {
-      constexpr int c = decltype(cc)::value;
+    sfor<0, NCH / 2>([&](auto qc) {
+      constexpr int q = decltype(qc)::value;
       begin();
       phase(lfrag + cur * SLOT, [&]() { refill(); }, [&](auto fc, const frag& fr) {
-        constexpr int f = decltype(fc)::value;
+        constexpr int f = decltype(fc)::value, c = 2 * q + f / ND, i = f % ND;
 #pragma unroll
-        for (int j = 0; j < TM; ++j) acc[f][j] = Mma<T>::mma(fr, xb[c][j], acc[f][j]);
+        for (int j = 0; j < TM; ++j) acc[i][j] = Mma<T>::mma(fr, xb[c][j], acc[i][j]);
       });
     });
   }
 
   // ---- stage-a input: LayerNorm(x) (or x) as B fragments; residual + output bias go into the accumulators ----
+  mfma_results_settle();
   if (a.ln_g) {
 #pragma unroll
     for (int j = 0; j < TM; ++j) {
@@ -236,18 +248,21 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
   // is R - 1 phases ahead, so this costs nothing), from here on only LDS-DMAs are in flight
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 
-  floatx4 hacc[2][TM];
+  // one 32-unit hidden sub-step: hidden = W1 slice . xb + b1 (fragments f < ND: f = u * NCH + c), then y += W2[:, slice] . relu(hidden)
+  // (fragments f >= ND: feature tile f - ND)
   auto substep = [&](int t, int stage) {
-    // -- W1 phase: hidden[32 units][tokens] = W1 slice . xb + b1 (fragment f = u * NCH + c) --
-    {
-      begin();
-      floatx4 bv0, bv1;
-      const unsigned ba = lbase + RING + stage * (HB * 4) + (t * 32 + 4 * h) * 4;
-      lds_rd<0>(bv0, ba);
-      lds_rd<64>(bv1, ba);
-      phase(lfrag + cur * SLOT, [&]() { refill(); }, [&](auto fc, frag& fr) {
-        constexpr int f = decltype(fc)::value, u = f / NCH, c = f % NCH;
-        if constexpr (f == 0) lds_wait<PD>(fr, bv0, bv1);   // (the bias reads are older than every fragment read: landed with fragment 0)
+    begin();
+    floatx4 bv0, bv1;
+    const unsigned ba = lbase + RING + stage * (HB * 4) + (t * 32 + 4 * h) * 4;
+    lds_rd<0>(bv0, ba);
+    lds_rd<64>(bv1, ba);
+    floatx4 hacc[2][TM];
+    frag hb[TM];
+    phase(lfrag + cur * SLOT, [&]() { refill(); }, [&](auto fc, frag& fr) {
+      constexpr int f = decltype(fc)::value;
+      if constexpr (f == 0) lds_wait<PD>(fr, bv0, bv1);   // (the bias reads are older than every fragment read: landed with fragment 0)
+      if constexpr (f < ND) {
+        constexpr int u = f / NCH, c = f % NCH;
         if constexpr (c == 0) {
 #pragma unroll
           for (int j = 0; j < TM; ++j) hacc[u][j] = u ? bv1 : bv0;
@@ -257,34 +272,29 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
           if constexpr (DBG == 2) hacc[u][j][0] += (float)fr[0] * (float)xb[c][j][0];
           else hacc[u][j] = Mma<T>::mma(fr, xb[c][j], hacc[u][j]);
         }
-      });
-    }
-    // -- W2 phase: y += W2[:, slice] . relu(hidden) (fragment f = feature tile) --
-    {
-      begin();
-      frag hb[TM];
-      phase(lfrag + cur * SLOT, [&]() {
-        refill();
+      } else {
+        if constexpr (f == ND) {
+          mfma_results_settle();
+#pragma unroll
+          for (int j = 0; j < TM; ++j) {
+            const half8 v = pack_pair(hacc[0][j], hacc[1][j]);
+            half8 z;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) z[e] = (half_t)0;
+            hb[j] = __builtin_elementwise_max(v, z);
+          }
+        }
 #pragma unroll
         for (int j = 0; j < TM; ++j) {
-          const half8 v = pack_pair(hacc[0][j], hacc[1][j]);
-          half8 z;
-#pragma unroll
-          for (int e = 0; e < 8; ++e) z[e] = (half_t)0;
-          hb[j] = __builtin_elementwise_max(v, z);
+          if constexpr (DBG == 2) acc[f - ND][j][0] += (float)fr[0] * (float)hb[j][0];
+          else acc[f - ND][j] = Mma<T>::mma(fr, hb[j], acc[f - ND][j]);
         }
-      }, [&](auto fc, const frag& fr) {
-        constexpr int f = decltype(fc)::value;
-#pragma unroll
-        for (int j = 0; j < TM; ++j) {
-          if constexpr (DBG == 2) acc[f][j][0] += (float)fr[0] * (float)hb[j][0];
-          else acc[f][j] = Mma<T>::mma(fr, hb[j], acc[f][j]);
-        }
-      });
-    }
+      }
+    });
   };
 #pragma unroll 1
   for (int t = 0; t < nt; ++t) substep(t, 0);
+  mfma_results_settle();
   if (a.Wb) {   // stage b (mlp_head): its input is the stage-a result, which becomes the new residual
 #pragma unroll
     for (int j = 0; j < TM; ++j)
@@ -293,6 +303,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     // (b2b is added in the epilogue: a global load here would sit in front of the ring's counted waits)
 #pragma unroll 1
     for (int t = 0; t < nt; ++t) substep(t, 1);
+    mfma_results_settle();
   }
 
   // ---- epilogue: (+ b2b) token-major store, or fold + window join into the NHWC map ----
@@ -365,9 +376,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
   typedef half_t T;
   typedef half8 frag;
   const CfenEmbedQkvArgs a = ga.g[blockIdx.z];
-  constexpr int NW = 4, D = ND * 16, NCH = ND / 2, SLOT = ND * 1024, DPW = ND / NW, RING = R * SLOT;
-  constexpr int NE = ND / 2, NQ = 3 * ND / 2, NP = NE + NQ;     // embedding / qkv phases (two 16-row output tiles each)
-  static_assert(ND % NW == 0 && R >= 3 && RING <= 160 * 1024, "ring geometry");
+  constexpr int NW = 4, D = ND * 16, NCH = ND / 2, NF = 2 * ND, SLOT = NF * 1024, DPW = NF / NW, RING = R * SLOT;
+  constexpr int NE = ND / 4, NQ = 3 * ND / 4, NP = NE + NQ;     // embedding / qkv double phases (four 16-row output tiles each, as k_mlp3)
+  static_assert(NF % NW == 0 && ND % 4 == 0 && R >= 3 && RING <= 160 * 1024, "ring geometry");
   __shared__ __attribute__((aligned(1024))) unsigned char lds[RING];
   const int tid = threadIdx.x, lane = tid & 63, r16 = lane & 15, h = lane >> 4;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -454,24 +465,25 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
       lds_rd<f * 1024>(F[f % NB], sa);
     });
     pre();
-    sfor<0, ND>([&](auto fc) {
+    sfor<0, NF>([&](auto fc) {
       constexpr int f = decltype(fc)::value;
-      if constexpr (f + PD < ND) lds_rd<(f + PD) * 1024>(F[(f + PD) % NB], sa);
-      lds_wait<(f + PD < ND ? PD : ND - 1 - f)>(F[f % NB]);
+      if constexpr (f + PD < NF) lds_rd<(f + PD) * 1024>(F[(f + PD) % NB], sa);
+      lds_wait<(f + PD < NF ? PD : NF - 1 - f)>(F[f % NB]);
       body(fc, F[f % NB]);
     });
   };
 
-  // ---- y = W_e x + (b_e + x + pos): phase q = output tiles 2q, 2q + 1 ----
+  // ---- y = W_e x + (b_e + x + pos): double phase q = output tiles 4q .. 4q + 3 (fragment f: tile f / NCH, k-chunk f % NCH) ----
   sfor<0, NE>([&](auto qc) {
     constexpr int q = decltype(qc)::value;
     begin();
     phase(lfrag + cur * SLOT, [&]() { refill(); }, [&](auto fc, const frag& fr) {
       constexpr int f = decltype(fc)::value, u = f / NCH, c = f % NCH;
 #pragma unroll
-      for (int j = 0; j < TM; ++j) acc[2 * q + u][j] = Mma<T>::mma(fr, xb[c][j], acc[2 * q + u][j]);
+      for (int j = 0; j < TM; ++j) acc[4 * q + u][j] = Mma<T>::mma(fr, xb[c][j], acc[4 * q + u][j]);
     });
   });
+  mfma_results_settle();
 #pragma unroll
   for (int j = 0; j < TM; ++j) {
     T* yp = (T*)a.X1 + tk[j] * D + 4 * h;
@@ -518,24 +530,25 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
   for (int j = 0; j < TM; ++j)
     qrow[j] = a.hm_heads ? (tk[j] / S) * (3LL * S * D) + (tk[j] % S) * 24 : tk[j] * (3LL * D);
 
-  // ---- qkv = W_qkv LN(y): phase t = output tiles 2t, 2t + 1, each stored as soon as its last k-chunk is in ----
+  // ---- qkv = W_qkv LN(y): double phase t = output tiles 4t .. 4t + 3, each stored as soon as its last k-chunk is in ----
 #pragma unroll 1
   for (int t = 0; t < NQ; ++t) {
     begin();
-    floatx4 qa[2][TM];
+    floatx4 qa[TM];
     phase(lfrag + cur * SLOT, [&]() { refill(); }, [&](auto fc, const frag& fr) {
       constexpr int f = decltype(fc)::value, u = f / NCH, c = f % NCH;
       if constexpr (c == 0) {
 #pragma unroll
-        for (int j = 0; j < TM; ++j) qa[u][j] = floatx4{0.f, 0.f, 0.f, 0.f};
+        for (int j = 0; j < TM; ++j) qa[j] = floatx4{0.f, 0.f, 0.f, 0.f};
       }
 #pragma unroll
-      for (int j = 0; j < TM; ++j) qa[u][j] = Mma<T>::mma(fr, xb[c][j], qa[u][j]);
+      for (int j = 0; j < TM; ++j) qa[j] = Mma<T>::mma(fr, xb[c][j], qa[j]);
       if constexpr (c == NCH - 1) {
-        const int fq = (2 * t + u) * 16 + 4 * h;
+        mfma_results_settle();
+        const int fq = (4 * t + u) * 16 + 4 * h;
         const long long fo = a.hm_heads ? st_hm_feature_off<D>(fq, S) : fq;
 #pragma unroll
-        for (int j = 0; j < TM; ++j) store4<T>((T*)a.QKV + qrow[j] + fo, qa[u][j]);
+        for (int j = 0; j < TM; ++j) store4<T>((T*)a.QKV + qrow[j] + fo, qa[j]);
         vm_issued += TM;
       }
     });
@@ -598,10 +611,10 @@ int cfen_mlp3_impl_g(int dtype, int ng, const Mlp3Args* ap, hipStream_t s) {
                    (a.ln_g == nullptr) == (ap[0].ln_g == nullptr) && (a.Wp == nullptr) == (ap[0].Wp == nullptr) && (a.fmap == nullptr) == (ap[0].fmap == nullptr),
                    "mlp3: grouped problems must have the same shape");
   }
-  if (ap[0].D == 384 && cfen_tune_mlp3_debug() == 1) return launch_mlp3<24, 2, 6, 1536, 1>(ng, ap, s);
-  if (ap[0].D == 384 && cfen_tune_mlp3_debug() == 2) return launch_mlp3<24, 2, 6, 1536, 2>(ng, ap, s);
-  if (ap[0].D == 384) return launch_mlp3<24, 2, 6, 1536>(ng, ap, s);
-  return launch_mlp3<12, 4, 8, 768>(ng, ap, s);
+  if (ap[0].D == 384 && cfen_tune_mlp3_debug() == 1) return launch_mlp3<24, 2, 3, 1536, 1>(ng, ap, s);
+  if (ap[0].D == 384 && cfen_tune_mlp3_debug() == 2) return launch_mlp3<24, 2, 3, 1536, 2>(ng, ap, s);
+  if (ap[0].D == 384) return launch_mlp3<24, 2, 3, 1536>(ng, ap, s);
+  return launch_mlp3<12, 4, 6, 768>(ng, ap, s);
 }
 
 bool cfen_front3_supported(int dtype, int D, long long M) { return dtype == 1 && D == 384 && M % 128 == 0; }
@@ -623,5 +636,5 @@ int cfen_front3_impl_g(int dtype, int ng, const CfenEmbedQkvArgs* ap, hipStream_
     CFEN_CHECK_ARG(a.D == ap[0].D && a.M == ap[0].M && a.hm_heads == ap[0].hm_heads, "front3: grouped problems must have the same shape");
     CFEN_CHECK_ARG(a.hm_heads == 0 || a.D == a.hm_heads * 24, "front3: the head-major layout needs head_dim 24");
   }
-  return launch_front3<24, 2, 6>(ng, ap, s);
+  return launch_front3<24, 2, 3>(ng, ap, s);
 }

@@ -330,6 +330,31 @@ def test_half_precision_guard_keeps_safe_weights_and_falls_back_on_unsafe_ones(t
         assert torch.isfinite(model.get_current_visuals()['fake_A']).all()
 
 
+@pytest.mark.parametrize("size", [(8, 64), (32, 256)])
+def test_fused_head_equals_the_three_convolutions_bitwise(size):
+    """k_head_fused (conv5x5 + ResBlock in one launch, both intermediates as fp16 tiles in LDS) against the three k_conv_tile launches it
+    replaces: the `head` stage and the outputs, bit for bit (same MFMA order, same fp16 rounding of the intermediates), at a size with many
+    border tiles and at 512x512"""
+    from cfen_vit_dehazing_amd import ops
+    ps, ls = size
+    cfg = NetConfig(24, 4, patch_size=ps, load_size=ls)
+    x = synthetic_input(2, cfg).to("cuda:0")
+    res = {}
+    try:
+        for k in (1, 0):
+            ops.tune("net.head_fused", k)
+            net = make_net(cfg, "fp16")
+            outs = [o.clone() for o in net(x)]
+            res[k] = (net.stage("head").clone(), outs)
+            del net
+    finally:
+        ops.tune("net.head_fused", 1)
+    assert torch.equal(res[1][0], res[0][0])
+    for a, b in zip(res[1][1], res[0][1]):
+        assert torch.equal(a, b)
+    torch.cuda.empty_cache()
+
+
 def test_two_lane_plan_equals_serial_plan_bitwise_full_size():
     """GViT beside LViT on a second lane must not change a single bit (512x512, B=2, eager and graph)"""
     cfg = NetConfig(24, 4, patch_size=32, load_size=256)

@@ -26,4 +26,6 @@ for w in $what; do
 done
 # keep the merged-back payload small: drop per-process agent info / huge traces beyond the CSVs we fold
 find $out -name "*.db" -delete 2>/dev/null
-du -sh $out
+# gpurun merges at most 64 MiB back: keep the CSV summaries the folding tools read (kernel stats, counter collection), drop traces / agent info / json
+find $out -type f \( -name "*.json" -size +1M -o -name "*.rocpd" -o -name "*.pftrace" -o -name "*kernel_trace.csv" -o -name "*agent_info.csv" -o -name "*_domain_stats.csv" \) -delete 2>/dev/null
+du -sh $out; find $out -type f -size +4M -exec ls -la {} \;
