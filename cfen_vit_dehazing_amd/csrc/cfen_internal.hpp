@@ -76,7 +76,7 @@ int cfen_conv_tile_impl(int dtype, const ConvDesc* d, int k, hipStream_t s);
 bool cfen_head_fused_supported(int dtype, int cs_in, int C, int H, int W);
 int cfen_head_fused_impl(int dtype, const void* in, void* out, const void* w5, const float* s5, const float* t5, const void* wa, const float* sa,
                          const float* ta, const void* wb, const float* sb, const float* tb, int B, int H, int W, hipStream_t s);
-int& cfen_tune_head_fused();        // 1 (default): the head runs as one k_head_fused launch where it applies ("net.head_fused")
+int& cfen_tune_head_fused();        // 1: the head runs as one k_head_fused launch where it applies; 0 (default, faster: see cfen_net.cpp) ("net.head_fused")
 bool cfen_convT_tile_supported(int dtype, int cs_in, int Cout_pad, int Hin, int Win);
 int cfen_convT_tile_kpad(int dtype, int cs_in);
 int cfen_convT_tile_impl(int dtype, const ConvDesc* d, hipStream_t s);

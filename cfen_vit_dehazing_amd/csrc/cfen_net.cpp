@@ -47,9 +47,9 @@ int& cfen_tune_attn_head_major() {
   static int v = 1;
   return v;
 }
-int& cfen_tune_head_fused() {
-  static int v = 1;
-  return v;
+int& cfen_tune_head_fused() {   // 0 (default): three k_conv_tile launches.  MEASURED (MI355X, batch 8): k_head_fused moves 100 MB instead of 400 MB and is
+  static int v = 0;             // SLOWER, 131 us against 108: with 3 input channels padded to 8 and 5 taps to 8 its MFMA work is 5x the algorithmic
+  return v;                     // flops (22 % MFMA-busy, profiles/r03_*), and the unfused kernels already run at the HBM rate of their own maps
 }
 int& cfen_tune_stream_front() {   // k_front3 for the D = 384 LViT blocks: 0 never, 1 (default) grouped decoder launches, 2 always
   static int v = 1;

@@ -248,7 +248,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
   // is R - 1 phases ahead, so this costs nothing), from here on only LDS-DMAs are in flight
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 
-  // one 32-unit hidden sub-step: hidden = W1 slice . xb + b1 (fragments f < ND: f = u * NCH + c), then y += W2[:, slice] . relu(hidden)
+  // one 32-unit hidden sub-step: hidden = W1 slice . xb + b1 (fragments f < ND: f = 2 c + u), then y += W2[:, slice] . relu(hidden)
   // (fragments f >= ND: feature tile f - ND)
   auto substep = [&](int t, int stage) {
     begin();
@@ -262,7 +262,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
       constexpr int f = decltype(fc)::value;
       if constexpr (f == 0) lds_wait<PD>(fr, bv0, bv1);   // (the bias reads are older than every fragment read: landed with fragment 0)
       if constexpr (f < ND) {
-        constexpr int u = f / NCH, c = f % NCH;
+        constexpr int u = f % 2, c = f / 2;      // (c, u) order, u fastest: four independent accumulation chains in rotation
         if constexpr (c == 0) {
 #pragma unroll
           for (int j = 0; j < TM; ++j) hacc[u][j] = u ? bv1 : bv0;
@@ -369,7 +369,7 @@ CFEN_DEV int st_hm_feature_off(int f, int S) {
 
 // LViT front half on the fragment-stream ring (D = 384): patch gather -> y = W_e x + b_e + x + pos -> X1; qkv = W_qkv LN1(y), written
 // head-major for k_attention_hm (or row-major).  Both matrices are ROW-TILE streams (packing.pack_stream_rows): phase t = output rows
-// t*32 .. +31, fragments (u, c) = row tile u, k-chunk c.  The qkv phases store their tiles from inside the ring loop, so the ring's waits
+// t*32 .. +31, fragments (c, u) = k-chunk c, row tile u (u fastest).  The qkv phases store their tiles from inside the ring loop, so the ring's waits
 // count every vector-memory operation the wave issues (`vm_issued` against the mark taken when a slot's DMA went out).
 template <int ND, int TM, int R>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void k_front3(Grouped<CfenEmbedQkvArgs> ga) {
@@ -473,12 +473,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     });
   };
 
-  // ---- y = W_e x + (b_e + x + pos): double phase q = output tiles 4q .. 4q + 3 (fragment f: tile f / NCH, k-chunk f % NCH) ----
+  // ---- y = W_e x + (b_e + x + pos): double phase q = output tiles 4q .. 4q + 3 (two row groups of two tiles) ----
   sfor<0, NE>([&](auto qc) {
     constexpr int q = decltype(qc)::value;
     begin();
     phase(lfrag + cur * SLOT, [&]() { refill(); }, [&](auto fc, const frag& fr) {
-      constexpr int f = decltype(fc)::value, u = f / NCH, c = f % NCH;
+      constexpr int f = decltype(fc)::value, u = 2 * (f / ND) + f % 2, c = (f % ND) / 2;   // row group f / ND, inside it (c, tile) with the tile fastest
 #pragma unroll
       for (int j = 0; j < TM; ++j) acc[4 * q + u][j] = Mma<T>::mma(fr, xb[c][j], acc[4 * q + u][j]);
     });
@@ -534,22 +534,25 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 #pragma unroll 1
   for (int t = 0; t < NQ; ++t) {
     begin();
-    floatx4 qa[TM];
+    floatx4 qa[2][TM];      // the two 16-row tiles of a row group accumulate in rotation (four chains with the two token tiles)
     phase(lfrag + cur * SLOT, [&]() { refill(); }, [&](auto fc, const frag& fr) {
-      constexpr int f = decltype(fc)::value, u = f / NCH, c = f % NCH;
+      constexpr int f = decltype(fc)::value, g2 = f / ND, v = f % 2, c = (f % ND) / 2;
       if constexpr (c == 0) {
 #pragma unroll
-        for (int j = 0; j < TM; ++j) qa[j] = floatx4{0.f, 0.f, 0.f, 0.f};
+        for (int j = 0; j < TM; ++j) qa[v][j] = floatx4{0.f, 0.f, 0.f, 0.f};
       }
 #pragma unroll
-      for (int j = 0; j < TM; ++j) qa[j] = Mma<T>::mma(fr, xb[c][j], qa[j]);
-      if constexpr (c == NCH - 1) {
+      for (int j = 0; j < TM; ++j) qa[v][j] = Mma<T>::mma(fr, xb[c][j], qa[v][j]);
+      if constexpr (c == NCH - 1 && v == 1) {
         mfma_results_settle();
-        const int fq = (4 * t + u) * 16 + 4 * h;
-        const long long fo = a.hm_heads ? st_hm_feature_off<D>(fq, S) : fq;
 #pragma unroll
-        for (int j = 0; j < TM; ++j) store4<T>((T*)a.QKV + qrow[j] + fo, qa[j]);
-        vm_issued += TM;
+        for (int w2 = 0; w2 < 2; ++w2) {
+          const int fq = (4 * t + 2 * g2 + w2) * 16 + 4 * h;
+          const long long fo = a.hm_heads ? st_hm_feature_off<D>(fq, S) : fq;
+#pragma unroll
+          for (int j = 0; j < TM; ++j) store4<T>((T*)a.QKV + qrow[j] + fo, qa[w2][j]);
+        }
+        vm_issued += 2 * TM;
       }
     });
   }

@@ -122,22 +122,25 @@ def pack_stream_sq(w):
 
 def pack_stream_pair(w1k, w2k):
     """Linear pair y = W2 relu(W1 x + b1) as ONE fragment stream for csrc/k_stream.hip (k_mlp3): per 32-unit slice t of the hidden dimension
-    a W1 phase -- fragments (u, c): rows t*32 + u*16 + (l & 15) of w1k [H][D], k-chunk c -- then a W2 phase -- fragments i: rows i*16 + (l & 15)
+    a W1 phase -- fragments (c, u), u fastest: rows t*32 + u*16 + (l & 15) of w1k [H][D], k-chunk c -- then a W2 phase -- fragments i: rows i*16 + (l & 15)
     of w2k [D][H], k = the slice's 32 hidden units.  Both phases hold D / 16 fragments of 1 KiB.  w1k / w2k carry kperm32 on their k axis."""
     h, d = w1k.shape
     assert w2k.shape == (d, h) and h % 32 == 0 and d % 32 == 0
     nd = d // 16
-    p1 = w1k.reshape(h // 32, 2, 16, d // 32, 4, 8).permute(0, 1, 3, 4, 2, 5).reshape(h // 32, 1, nd, 512)     # [t][u][c][hq][r][e]
+    # W1 fragments alternate the slice's two 16-row tiles (c-major, u fastest): four independent accumulation chains (2 tiles x 2 token tiles)
+    # rotate through the MFMA pipe instead of two -- a dependent 16x16x32 MFMA every second issue slot stalls the pipe (35 % issue-stall
+    # cycles in profiles/r03b_sq_wave_states.txt)
+    p1 = w1k.reshape(h // 32, 2, 16, d // 32, 4, 8).permute(0, 3, 1, 4, 2, 5).reshape(h // 32, 1, nd, 512)     # [t][c][u][hq][r][e]
     p2 = w2k.reshape(nd, 16, h // 32, 4, 8).permute(2, 0, 3, 1, 4).reshape(h // 32, 1, nd, 512)               # [t][i][hq][r][e]
     return torch.cat((p1, p2), 1).contiguous().view(-1)
 
 
 def pack_stream_rows(wk):
     """[N][K] (k axis kperm32'd) -> ROW-TILE fragment stream for csrc/k_stream.hip (k_front3): phase t = output rows t*32 .. +31, fragments
-    (u, c) = 16-row tile u, k-chunk c in lane order; K / 16 fragments of 1 KiB per phase (the W1 phases of pack_stream_pair on their own)."""
+    (c, u) = k-chunk c, 16-row tile u (u fastest) in lane order; K / 16 fragments of 1 KiB per phase (the W1 phases of pack_stream_pair on their own)."""
     n, k = wk.shape
     assert n % 32 == 0 and k % 32 == 0
-    return wk.reshape(n // 32, 2, 16, k // 32, 4, 8).permute(0, 1, 3, 4, 2, 5).contiguous().view(-1)
+    return wk.reshape(n // 32, 2, 16, k // 32, 4, 8).permute(0, 3, 1, 4, 2, 5).contiguous().view(-1)     # [t][c][u][hq][r][e]: u fastest, as pack_stream_pair
 
 
 STREAM_MLP_DIMS = (384,)

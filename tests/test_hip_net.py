@@ -348,7 +348,7 @@ def test_fused_head_equals_the_three_convolutions_bitwise(size):
             res[k] = (net.stage("head").clone(), outs)
             del net
     finally:
-        ops.tune("net.head_fused", 1)
+        ops.tune("net.head_fused", 0)
     assert torch.equal(res[1][0], res[0][0])
     for a, b in zip(res[1][1], res[0][1]):
         assert torch.equal(a, b)

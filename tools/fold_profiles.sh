@@ -12,4 +12,6 @@ f=$(find $d/pmc_fetch -name "*counter_collection.csv" 2>/dev/null | head -1)
 w=$(find $d/pmc_write -name "*counter_collection.csv" 2>/dev/null | head -1)
 [ -n "$m" ] && [ -n "$f" ] && [ -n "$w" ] && python3 tools/mfma_summary.py $m $f $w $pre
 q=$(find $d/pmc_sq -name "*counter_collection.csv" 2>/dev/null | head -1); [ -n "$q" ] && python3 tools/sq_summary.py $q > ${pre}_sq_wave_states.txt
+# (round 3: the counter tables are folded on the GPU box by tools/gpu_round.sh -- they exceed what gpurun merges back)
+for f in $d/folded/r_*; do [ -f "$f" ] && cp $f ${pre}_${f##*/r_}; done
 ls -la ${pre}_*

@@ -54,7 +54,7 @@ def short(name):
 
 
 # bench.py kernel key (block kind + level : step) -> the kernel instantiation that runs it, where that is one-to-one
-BENCH_KEY = (("lvit1:window_block_fused", "k_lvit_window<"), ("lvit1:proj_mlp_fused", "k_mlp2<6,"), ("lvit2:proj_mlp_fused", "k_mlp2<12,"),
+BENCH_KEY = (("lvit3:proj_mlp_stream", "k_mlp3<24,"), ("lvit3:front_stream", "k_front3<"), ("lvit1:window_block_fused", "k_lvit_window<"), ("lvit1:proj_mlp_fused", "k_mlp2<6,"), ("lvit2:proj_mlp_fused", "k_mlp2<12,"),
              ("lvit1:embed_ln_qkv", "k_embed_qkv2<6,"), ("lvit2:embed_ln_qkv", "k_embed_qkv2<12,"))
 
 

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Per-launch timing table of one forward (HIP events around every launch, serial): label, class, ms, TFLOP/s.
-Usage: profile_launches.py [batch] [dtype]"""
+Usage: profile_launches.py [batch] [dtype] [load_size] [hidden_dim_ratio]      (load_size 512 = 1024x1024 images, patch_size = load_size / 8)"""
 import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -13,7 +13,9 @@ for kv in filter(None, os.environ.get("CFEN_TUNE", "").split(",")):
     ops.tune(kv.split("=")[0], int(kv.split("=")[1]))
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 8
 dt = sys.argv[2] if len(sys.argv) > 2 else "fp16"
-cfg = NetConfig(24, 4, patch_size=32, load_size=256)
+ls = int(sys.argv[3]) if len(sys.argv) > 3 else 256
+hdr = int(sys.argv[4]) if len(sys.argv) > 4 else 4
+cfg = NetConfig(24, hdr, patch_size=ls // 8, load_size=ls)
 net = dec_ipt(cfg, compute_dtype=dt); net.load_state_dict(generate_state_dict(cfg, seed=0)); net.to("cuda:0")
 x = synthetic_input(B, cfg).to("cuda:0")
 for _ in range(3): net(x)
@@ -25,7 +27,7 @@ for i in range(n):
     ms = sorted(r[i][3] for r in runs)[2]
     rows.append((runs[0][i][0], runs[0][i][1], runs[0][i][2], ms))
 tot = sum(r[3] for r in rows)
-print("%d launches, sum %.3f ms (batch %d, %s)" % (n, tot, B, dt))
+print("%d launches, sum %.3f ms (batch %d, %s, %dx%d, hidden_dim_ratio %d)" % (n, tot, B, dt, cfg.image_size, cfg.image_size, hdr))
 for lab, cls, fl, ms in rows:
     print("%-42s %-9s %8.1f us %8s" % (lab, cls, ms * 1e3, ("%.0f TF" % (fl / ms / 1e9)) if fl else ""))
 # aggregate by step kind
