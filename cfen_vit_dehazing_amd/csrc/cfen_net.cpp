@@ -55,8 +55,8 @@ int& cfen_tune_stream_front() {   // k_front3 for the D = 384 LViT blocks: 0 nev
   static int v = 1;
   return v;
 }
-int& cfen_tune_stream_mlp() {   // k_mlp3 (k_stream.hip) for the D = 384 blocks: 0 never, 1 (default) grouped decoder launches only (a single instance has
-  static int v = 1;             // 64 workgroups of 128 tokens: a quarter of the chip), 2 always
+int& cfen_tune_stream_mlp() {   // k_mlp3 (k_stream.hip) for the D = 384 blocks: 0 never, 1 (default) launches of >= 128 workgroups (at 512 x 512 the grouped
+  static int v = 1;             // decoder launch; a single instance has 64 workgroups of 128 tokens: a quarter of the chip), 2 always
   return v;
 }
 
@@ -597,7 +597,7 @@ int cfen_net::run_vit_g(int ng, const VitCall* vc, int scr0) {
   bool head_major = false;   // the fused front half writes qkv per (window, head) for k_attention_hm
   const long long Mll = M;
   if (v.stream_mlp && cfen_front3_supported(dt, v.D, Mll) && cfen_attention_hm_supported(dt, v.S, v.D / v.heads) &&
-      (cfen_tune_stream_front() >= 2 || (cfen_tune_stream_front() == 1 && ng == 3))) {
+      (cfen_tune_stream_front() >= 2 || (cfen_tune_stream_front() == 1 && (long long)ng * M >= 128LL * 128))) {   // >= 128 workgroups of 128 tokens
     // LViT level 3: gather + linear_encoding + residual + position + LN1 + qkv in one launch on row-tile weight streams (k_stream.hip)
     CfenEmbedQkvArgs e[3];
     head_major = true;
@@ -647,7 +647,7 @@ int cfen_net::run_vit_g(int ng, const VitCall* vc, int scr0) {
   else
     TRYP(K_ATTN, 4 * Md * v.S * D, cfen_attention_impl_g(dt, ng, cQKV, ATT, B * nwin, v.S, v.heads, v.dh, stream));
   const void* cATT[3] = {ATT[0], ATT[1], ATT[2]};
-  const bool stream_mlp = v.stream_mlp && (cfen_tune_stream_mlp() >= 2 || (cfen_tune_stream_mlp() == 1 && ng == 3));
+  const bool stream_mlp = v.stream_mlp && (cfen_tune_stream_mlp() >= 2 || (cfen_tune_stream_mlp() == 1 && (long long)ng * M >= 128LL * 128));
   if (stream_mlp) {
     // LViT level 3: out_proj + residual + LN2 + FFN + mlp_head + fold in one launch on fragment-stream weights (k_stream.hip)
     Mlp3Args m[3];

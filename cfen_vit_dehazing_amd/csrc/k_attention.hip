@@ -427,6 +427,140 @@ __global__ __launch_bounds__(256) void k_attention_hm(PtrG<const half_t> QKVg, P
   }
 }
 
+// The same window attention for the 1024-token windows of the 1024 x 1024 configuration (BASELINE config 4: --loadSize 512 --patch_size 64),
+// round 3.  K and V of one (window, head) still fit a CU -- 1024 rows x 64 bytes each = 128 KB -- so they are staged ONCE and every query of
+// the window reads them from LDS; the generic streaming kernel re-staged K / V per 64-query block through 60 KB of LDS (1.03 GB of HBM
+// traffic per launch, 6.5 % MFMA-busy, 52 % of that configuration's forward: profiles/r03_cfg4_*).  What changes against k_attention_hm:
+//   * 64-byte row pitch (no room for the 96-byte conflict-free pitch): the 16-byte pieces of a K row are XOR-swizzled with (4 - (row >> 2)) & 3
+//     and the two 32-byte halves of a V row are swapped on rows with bit 2 set -- conflict-free ds_read_b128 / ds_read_b64_tr_b16 again;
+//   * the scores of a query against 1024 keys do not fit registers: keys go in blocks of 256 with the running-maximum rescale (the
+//     denominator row of O^T, V feature 24 = 1, is rescaled with the rest);
+//   * a wave works on TWO query tiles at a time, so every K fragment and every transposed V fragment read from LDS feeds two MFMAs;
+//   * 8 waves: two per SIMD.
+template <int NKT, int NKB>
+__global__ __launch_bounds__(512) void k_attention_hm_long(PtrG<const half_t> QKVg, PtrG<half_t> Og, int D, int heads, float scale_log2, int nblk) {
+  constexpr int S = NKT * 16, DH = 24, KP = 64, NW = 8, NT = NW * 64;
+  static_assert(NKT % NKB == 0 && NKB % 2 == 0 && 2 * S * KP <= 160 * 1024 && NKT % (2 * NW) == 0, "geometry");
+  __shared__ __attribute__((aligned(16))) unsigned char lds[2 * S * KP];
+  unsigned char* const Kl = lds;
+  unsigned char* const Vl = lds + S * KP;
+  const half_t* __restrict__ QKV = QKVg.p[blockIdx.z];
+  half_t* __restrict__ O = Og.p[blockIdx.z];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r16 = lane & 15, h = lane >> 4;
+  const int blk = (int)xcd_chunked_block(blockIdx.x, gridDim.x);
+  if (blk >= nblk) return;
+  const int head = blk % heads, seq = blk / heads;
+  const half_t* Qp = QKV + (size_t)blk * 3 * S * DH;
+  const half_t* Kp = Qp + S * DH;
+  const half_t* Vp = Kp + S * DH;
+
+  // ---- stage K and V: 3 data pieces + 1 constant piece per 64-byte row, swizzled ----
+  constexpr int NPC = S * 3 / NT;          // data pieces per thread and matrix (6)
+  static_assert(S * 3 % NT == 0 && S % NT == 0, "staging sweep");
+  half8 kst[NPC], vst[NPC];
+#pragma unroll
+  for (int i = 0; i < NPC; ++i) {
+    const int idx = tid + i * NT;          // piece idx of the contiguous [S][24] block: row idx / 3, piece idx % 3
+    kst[i] = load_frag<half_t>(Kp + idx * 8);
+    vst[i] = load_frag<half_t>(Vp + idx * 8);
+  }
+#pragma unroll
+  for (int i = 0; i < NPC; ++i) {
+    const int idx = tid + i * NT, row = idx / 3, c = idx - row * 3;
+    const int ks = (4 - ((row >> 2) & 3)) & 3;
+    *reinterpret_cast<half8*>(Kl + row * KP + ((c ^ ks) << 4)) = kst[i];
+    // V: piece c of the row = features 8c .. 8c+7; half = c >> 1, swapped on rows with bit 2 set
+    *reinterpret_cast<half8*>(Vl + row * KP + ((((c >> 1) ^ ((row >> 2) & 1)) << 5) | ((c & 1) << 4))) = vst[i];
+  }
+#pragma unroll
+  for (int i = 0; i < S / NT; ++i) {
+    const int row = tid + i * NT;
+    const int ks = (4 - ((row >> 2) & 3)) & 3;
+    half8 one = Mma<half_t>::zero();
+    *reinterpret_cast<half8*>(Kl + row * KP + ((3 ^ ks) << 4)) = one;            // K dims 24..31 = 0
+    one[0] = (half_t)1.0f;                                                           // V feature 24 = 1 (denominator row), 25..31 = 0
+    *reinterpret_cast<half8*>(Vl + row * KP + (((1 ^ ((row >> 2) & 1)) << 5) | 16)) = one;
+  }
+  __syncthreads();
+
+  const float c = scale_log2;
+  const int li = lane & 15;
+  // K fragment of key tile t: row t*16 + r16, piece h -> swizzled by (row >> 2) & 3 = (r16 >> 2) (16 t is a multiple of 16)
+  const unsigned char* kbase = Kl + r16 * KP + ((h ^ ((4 - (r16 >> 2)) & 3)) << 4);
+  // V tr-read: lane 4q+p of a 16-lane group -> key row 4h + q (+ 32 kb, + 16), columns 4p..4p+3 of feature half i; (row >> 2) & 1 = h & 1
+  const unsigned char* vbase = Vl + (4 * h + (li >> 2)) * KP + (li & 3) * 8;
+  const int vsw = (h & 1) << 5;
+  constexpr int QPW = NKT / NW;            // query tiles per wave (8), two at a time
+#pragma unroll 1
+  for (int qi = 0; qi < QPW; qi += 2) {
+    half8 qf[2];
+    int q0[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      q0[j] = (wave + NW * (qi + j)) * 16;
+      qf[j] = load_frag<half_t>(Qp + (q0[j] + r16) * DH + min(h, 2) * 8);
+      if (h == 3) qf[j] = Mma<half_t>::zero();
+    }
+    floatx4 o[2][2];
+    float m[2] = {-1e30f, -1e30f};
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j) o[i][j] = floatx4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll 1
+    for (int kb0 = 0; kb0 < NKT; kb0 += NKB) {
+      floatx4 st[NKB][2];
+#pragma unroll
+      for (int t = 0; t < NKB; ++t) {
+        const half8 kf = *reinterpret_cast<const half8*>(kbase + ((kb0 + t) * 16) * KP);
+#pragma unroll
+        for (int j = 0; j < 2; ++j) st[t][j] = Mma<half_t>::mma(kf, qf[j], floatx4{0.f, 0.f, 0.f, 0.f});
+      }
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        float mx = -1e30f;
+#pragma unroll
+        for (int t = 0; t < NKB; ++t) mx = fmaxf(fmaxf(mx, fmaxf(st[t][j][0], st[t][j][1])), fmaxf(st[t][j][2], st[t][j][3]));
+        mx = fmaxf(col_max(mx), m[j]);
+        const float alpha = __builtin_amdgcn_exp2f((m[j] - mx) * c);     // first block: exp2(-huge) = 0 on zero accumulators
+        m[j] = mx;
+        const float mc = -mx * c;
+#pragma unroll
+        for (int t = 0; t < NKB; ++t)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) st[t][j][r] = __builtin_amdgcn_exp2f(fmaf(st[t][j][r], c, mc));
+#pragma unroll
+        for (int i = 0; i < 2; ++i) o[i][j] *= alpha;
+      }
+#pragma unroll
+      for (int kb = 0; kb < NKB / 2; ++kb) {
+        half8 b[2];
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+          b[j] = half8{(half_t)st[2 * kb][j][0], (half_t)st[2 * kb][j][1], (half_t)st[2 * kb][j][2], (half_t)st[2 * kb][j][3],
+                       (half_t)st[2 * kb + 1][j][0], (half_t)st[2 * kb + 1][j][1], (half_t)st[2 * kb + 1][j][2], (half_t)st[2 * kb + 1][j][3]};
+        const unsigned char* vk = vbase + ((kb0 * 16) + kb * 32) * KP;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+          const half4 lo = lds_read_tr4(vk + ((i << 5) ^ vsw));               // keys +4h .. +3, feature i*16 + (lane & 15)
+          const half4 hi = lds_read_tr4(vk + 16 * KP + ((i << 5) ^ vsw));     // keys +16 + 4h .. +3
+          const half8 a = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+#pragma unroll
+          for (int j = 0; j < 2; ++j) o[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b[j], o[i][j], 0, 0, 0);
+        }
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const float l = col_sum(h == 2 ? o[1][j][0] : 0.f);   // row 24 of O^T = sum of the probabilities (rescaled with the rest)
+      const float inv = 1.f / l;
+      half_t* op = O + ((size_t)seq * S + q0[j] + r16) * D + head * DH + 4 * h;
+      store4<half_t>(op, o[0][j] * inv);
+      if (h < 2) store4<half_t>(op + 16, o[1][j] * inv);
+    }
+  }
+}
+
 template <typename T, int NDT, int NKT>
 int launch_attn_win(int ng, const void* const* qkv, void* const* out, int nseq, int heads, int dh, size_t smem, hipStream_t s) {
   const float scale_log2 = 1.4426950408889634f / sqrtf((float)dh);
@@ -593,10 +727,10 @@ int cfen_attention_impl_g(int dtype, int ng, const void* const* qkv, void* const
   cfen_set_error("attention: unknown dtype %d", dtype);
   return CFEN_ERR_ARG;
 }
-bool cfen_attention_hm_supported(int dtype, int S, int dh) { return dtype == 1 && dh == 24 && (S == 256 || S == 64); }
+bool cfen_attention_hm_supported(int dtype, int S, int dh) { return dtype == 1 && dh == 24 && (S == 1024 || S == 256 || S == 64); }
 
 int cfen_attention_hm_impl_g(int dtype, int ng, const void* const* qkv, void* const* out, int nseq, int S, int heads, int dh, hipStream_t s) {
-  CFEN_CHECK_ARG(cfen_attention_hm_supported(dtype, S, dh), "attention (head-major): fp16, head_dim 24, S in {64, 256} only");
+  CFEN_CHECK_ARG(cfen_attention_hm_supported(dtype, S, dh), "attention (head-major): fp16, head_dim 24, S in {64, 256, 1024} only");
   CFEN_CHECK_ARG(ng >= 1 && ng <= CFEN_MAX_GROUPS && nseq > 0 && heads > 0 && (long long)nseq * heads < (1ll << 31), "attention (head-major): bad problem");
   PtrG<const half_t> qg{};
   PtrG<half_t> og{};
@@ -606,7 +740,9 @@ int cfen_attention_hm_impl_g(int dtype, int ng, const void* const* qkv, void* co
   }
   const float scale_log2 = 1.4426950408889634f / sqrtf((float)dh);
   const dim3 grid(cfen_grid8((long long)nseq * heads), 1, ng);
-  if (S == 256)
+  if (S == 1024)
+    CFEN_LAUNCH((k_attention_hm_long<64, 16>), grid, dim3(512), 0, s, qg, og, heads * dh, heads, scale_log2, nseq * heads);
+  else if (S == 256)
     CFEN_LAUNCH((k_attention_hm<16>), grid, dim3(256), 0, s, qg, og, heads * dh, heads, scale_log2, nseq * heads);
   else
     CFEN_LAUNCH((k_attention_hm<4>), grid, dim3(256), 0, s, qg, og, heads * dh, heads, scale_log2, nseq * heads);

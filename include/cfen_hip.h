@@ -158,7 +158,8 @@ int cfen_layernorm(int dtype, const void* X, void* Y, const float* gamma, const 
 /* softmax(QK^T/sqrt(dh))V per (sequence, head); QKV is [nseq*S][3*heads*dh], out [nseq*S][heads*dh]  (v3:1364) */
 int cfen_attention(int dtype, const void* qkv, void* out, int nseq, int S, int heads, int dh, void* stream);
 /* the same attention reading the head-major qkv layout of cfen_embed_qkv (head_major_heads = heads): the q, k and v of one
- * (sequence, head) are contiguous [S][dh] blocks.  CFEN_F16, dh = 24, S in {64, 256} (every LViT window of the 512x512 configs);
+ * (sequence, head) are contiguous [S][dh] blocks.  CFEN_F16, dh = 24, S in {64, 256} (every LViT window of the 512x512 configs) or 1024 (the
+ * 1024x1024 configuration: K and V of a head stay in LDS, keys in blocks of 256 with the running-maximum rescale);
  * out stays [nseq*S][heads*dh] row-major.                                                                       (v3:1364) */
 int cfen_attention_head_major(int dtype, const void* qkv, void* out, int nseq, int S, int heads, int dh, void* stream);
 /* Fused token MLP block (D in {96,192}; H a multiple of 64 (fp16) / 32 (fp32)):

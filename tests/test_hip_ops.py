@@ -197,13 +197,13 @@ def to_head_major(qkv, nseq, S, heads):
     return qkv.view(nseq, S, 3, heads, dh).permute(0, 3, 2, 1, 4).contiguous().view(-1)
 
 
-@pytest.mark.parametrize("nseq,S,heads", [(3, 256, 4), (5, 256, 8), (2, 64, 4), (9, 64, 16)])
+@pytest.mark.parametrize("nseq,S,heads", [(3, 256, 4), (5, 256, 8), (2, 64, 4), (9, 64, 16), (2, 1024, 4), (3, 1024, 16)])
 def test_attention_head_major_layout(nseq, S, heads):
     qkv = rnd((nseq * S, 3 * heads * 24), 7, torch.float16, 1.5)
     got = ops.attention_head_major(to_head_major(qkv, nseq, S, heads).to(dev()), nseq, S, heads)
     close(got, attn_ref(qkv, nseq, S, heads), tol(torch.float16, 3))
-    # a dominating key late in the sequence (the softmax maximum is not among the first keys)
-    qkv[200 % S, heads * 24:heads * 24 + 24] = qkv[3, :24] * 25
+    # a dominating key late in the sequence (the softmax maximum is not among the first keys; S = 1024: not in the first block of 256 keys)
+    qkv[900 if S > 256 else 200 % S, heads * 24:heads * 24 + 24] = qkv[3, :24] * 25
     got = ops.attention_head_major(to_head_major(qkv, nseq, S, heads).to(dev()), nseq, S, heads)
     close(got, attn_ref(qkv, nseq, S, heads), tol(torch.float16, 3))
 
