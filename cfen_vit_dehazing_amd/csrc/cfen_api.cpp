@@ -266,6 +266,10 @@ int cfen_tune(const char* key, int value) {
     cfen_tune_attn_head_major() = value != 0;
     return CFEN_OK;
   }
+  if (!strcmp(key, "attn.hm_pair")) {
+    cfen_tune_attn_hm_pair() = value != 0;
+    return CFEN_OK;
+  }
   if (!strcmp(key, "net.head_fused")) {
     cfen_tune_head_fused() = value != 0;
     return CFEN_OK;

@@ -455,26 +455,27 @@ __global__ __launch_bounds__(512) void k_attention_hm_long(PtrG<const half_t> QK
   const half_t* Vp = Kp + S * DH;
 
   // ---- stage K and V: 3 data pieces + 1 constant piece per 64-byte row, swizzled ----
-  constexpr int NPC = S * 3 / NT;          // data pieces per thread and matrix (6)
-  static_assert(S * 3 % NT == 0 && S % NT == 0, "staging sweep");
+  constexpr int NPC = (S * 3 + NT - 1) / NT;   // data pieces per thread and matrix (6 at S = 1024)
   half8 kst[NPC], vst[NPC];
 #pragma unroll
   for (int i = 0; i < NPC; ++i) {
-    const int idx = tid + i * NT;          // piece idx of the contiguous [S][24] block: row idx / 3, piece idx % 3
+    const int idx = min(tid + i * NT, S * 3 - 1);   // piece idx of the contiguous [S][24] block: row idx / 3, piece idx % 3
     kst[i] = load_frag<half_t>(Kp + idx * 8);
     vst[i] = load_frag<half_t>(Vp + idx * 8);
   }
 #pragma unroll
   for (int i = 0; i < NPC; ++i) {
     const int idx = tid + i * NT, row = idx / 3, c = idx - row * 3;
+    if (idx >= S * 3) break;
     const int ks = (4 - ((row >> 2) & 3)) & 3;
     *reinterpret_cast<half8*>(Kl + row * KP + ((c ^ ks) << 4)) = kst[i];
     // V: piece c of the row = features 8c .. 8c+7; half = c >> 1, swapped on rows with bit 2 set
     *reinterpret_cast<half8*>(Vl + row * KP + ((((c >> 1) ^ ((row >> 2) & 1)) << 5) | ((c & 1) << 4))) = vst[i];
   }
 #pragma unroll
-  for (int i = 0; i < S / NT; ++i) {
+  for (int i = 0; i < (S + NT - 1) / NT; ++i) {
     const int row = tid + i * NT;
+    if (row >= S) break;
     const int ks = (4 - ((row >> 2) & 3)) & 3;
     half8 one = Mma<half_t>::zero();
     *reinterpret_cast<half8*>(Kl + row * KP + ((3 ^ ks) << 4)) = one;            // K dims 24..31 = 0
@@ -727,6 +728,11 @@ int cfen_attention_impl_g(int dtype, int ng, const void* const* qkv, void* const
   cfen_set_error("attention: unknown dtype %d", dtype);
   return CFEN_ERR_ARG;
 }
+int& cfen_tune_attn_hm_pair() {   // 1: 256-token windows run on k_attention_hm_long<16, 16> (two query tiles per K / V fragment, 8 waves)
+  static int v = 0;
+  return v;
+}
+
 bool cfen_attention_hm_supported(int dtype, int S, int dh) { return dtype == 1 && dh == 24 && (S == 1024 || S == 256 || S == 64); }
 
 int cfen_attention_hm_impl_g(int dtype, int ng, const void* const* qkv, void* const* out, int nseq, int S, int heads, int dh, hipStream_t s) {
@@ -742,6 +748,8 @@ int cfen_attention_hm_impl_g(int dtype, int ng, const void* const* qkv, void* co
   const dim3 grid(cfen_grid8((long long)nseq * heads), 1, ng);
   if (S == 1024)
     CFEN_LAUNCH((k_attention_hm_long<64, 16>), grid, dim3(512), 0, s, qg, og, heads * dh, heads, scale_log2, nseq * heads);
+  else if (S == 256 && cfen_tune_attn_hm_pair())
+    CFEN_LAUNCH((k_attention_hm_long<16, 16>), grid, dim3(512), 0, s, qg, og, heads * dh, heads, scale_log2, nseq * heads);
   else if (S == 256)
     CFEN_LAUNCH((k_attention_hm<16>), grid, dim3(256), 0, s, qg, og, heads * dh, heads, scale_log2, nseq * heads);
   else
