@@ -216,6 +216,11 @@ int cfen_tune(const char* key, int value) {
     cfen_tune_embed_lds() = value & 7;
     return CFEN_OK;
   }
+  if (!strcmp(key, "mlp3.tm192")) {
+    CFEN_CHECK_ARG(value >= 2 && value <= 4, "tune: mlp3.tm192 is 2, 3 or 4");
+    cfen_tune_mlp3_tm192() = value;
+    return CFEN_OK;
+  }
   if (!strcmp(key, "mlp3.debug")) {
     cfen_tune_mlp3_debug() = value;
     return CFEN_OK;
@@ -277,6 +282,10 @@ int cfen_tune(const char* key, int value) {
   if (!strcmp(key, "net.stream_front")) {
     CFEN_CHECK_ARG(value >= 0 && value <= 2, "tune: net.stream_front is 0 (never), 1 (grouped decoder launches) or 2 (always)");
     cfen_tune_stream_front() = value;
+    return CFEN_OK;
+  }
+  if (!strcmp(key, "net.stream_mlp192")) {
+    cfen_tune_stream_mlp192() = value != 0;
     return CFEN_OK;
   }
   if (!strcmp(key, "net.stream_mlp")) {

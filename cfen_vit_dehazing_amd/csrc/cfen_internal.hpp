@@ -111,6 +111,7 @@ int& cfen_tune_skip_classes();    // bit mask of kernel classes NOT launched by 
 int& cfen_tune_ln_fold();               // 1: LN1 / LN2 of the blocks without a fused kernel ride on the qkv / ffn1 GEMM ("net.ln_fold")
 int& cfen_tune_fused_front_max_dim();   // k_embed_qkv is used for LViT embedding dims <= this (0 = never) ("net.fused_front_max_dim")
 int& cfen_tune_gemm_splitk_stages();   // ring depth of the split-K tile beyond two stages: 0 or 3 ("gemm.splitk_stages")
+int& cfen_tune_mlp3_tm192();         // token tiles per wave of k_mlp3 at D = 192: 2, 3 (default) or 4 ("mlp3.tm192")
 int& cfen_tune_mlp3_debug();         // k_mlp3 timing experiments (results invalid): 1 no DMA refills, 2 no MFMAs ("mlp3.debug")
 int& cfen_tune_gemm_m128();          // tile id (+10 per extra stage) for problems of <= 128 tokens, 0 = shape rule ("gemm.m128")
 int& cfen_tune_gemm_splitk();     // 1 (default): K-heavy few-token GEMMs run split-K when the caller provides scratch ("gemm.splitk")
@@ -119,5 +120,6 @@ int& cfen_tune_fold_in_gemm();      // 1 (default): the last GEMM of an unfused 
 int& cfen_tune_attn_head_major();   // 1 (default): LViT levels with a fused front half hand qkv to attention head-major ("net.attn_head_major")
 int& cfen_tune_attn_hm_pair();      // 1: S = 256 head-major attention on the two-query-tile kernel ("attn.hm_pair")
 int& cfen_tune_stream_front();      // k_front3 for the D = 384 LViT blocks: 0 never, 1 (default) grouped decoder launches, 2 always ("net.stream_front")
+int& cfen_tune_stream_mlp192();     // 1: LViT level 2 (D = 192) on k_mlp3 instead of k_mlp2; 0 (default, faster inside the forward: see cfen_net.cpp) ("net.stream_mlp192")
 int& cfen_tune_stream_mlp();        // k_mlp3 for the D = 384 LViT blocks: 0 never, 1 (default) grouped decoder launches, 2 always ("net.stream_mlp")
 int& cfen_tune_embed_lds();        // k_embed_qkv weights through LDS: bit 0 for D = 96, bit 1 for D = 192 ("embed.lds")

@@ -55,6 +55,10 @@ int& cfen_tune_stream_front() {   // k_front3 for the D = 384 LViT blocks: 0 nev
   static int v = 1;
   return v;
 }
+int& cfen_tune_stream_mlp192() {   // 1: LViT level 2 (D = 192) runs its proj + MLP block on k_mlp3<12, 3> instead of k_mlp2.  0 (default): MEASURED -- alone on the chip
+  static int v = 0;                // with cold caches k_mlp3 wins (154-162 us against 181-204 for the grouped decoder launch, tools/bench_mlp3.py), inside the
+  return v;                        // forward it loses (2.92 against 2.90 ms): it takes whole CUs (150 KB of LDS, 512 registers), the GViT lane beside it starves
+}
 int& cfen_tune_stream_mlp() {   // k_mlp3 (k_stream.hip) for the D = 384 blocks: 0 never, 1 (default) launches of >= 128 workgroups (at 512 x 512 the grouped
   static int v = 1;             // decoder launch; a single instance has 64 workgroups of 128 tokens: a quarter of the chip), 2 always
   return v;
@@ -316,7 +320,7 @@ int cfen_net::build() {
     v.fused_mlp = !v.global && !v.shrink && cfen_mlp_supported(v.D, v.hidden, cfg.dtype);
     v.fused_front = !v.global && !v.shrink && cfen_embed_qkv_supported(v.D);
     v.fused_window = !v.global && v.fused_mlp && v.fused_front && cfen_lvit_window_supported(cfg.dtype, v.D, v.heads, v.S, v.hidden);
-    v.stream_mlp = !v.global && !v.shrink && !v.fused_mlp && v.D == 384 && v.hidden <= 4 * v.D && cfen_mlp3_supported(cfg.dtype, v.D, v.hidden);
+    v.stream_mlp = !v.global && !v.shrink && (v.D == 384 ? !v.fused_mlp : v.D == 192) && v.hidden <= 4 * v.D && cfen_mlp3_supported(cfg.dtype, v.D, v.hidden);
     v.ln_fold1 = !v.fused_front && v.Dn == v.D && (v.D * esz) % 128 == 0;
     v.ln_fold2 = !v.fused_mlp && v.Dn == v.D && (v.D * esz) % 128 == 0;
     CFEN_CHECK_ARG(v.Dn % v.heads == 0, "net: %s embedding dim %d not divisible by %d heads", v.name.c_str(), v.Dn, v.heads);
@@ -338,7 +342,7 @@ int cfen_net::build() {
     if (v.ln_fold1) { need(n + ".qkv.wl", wbytes(v, 3 * v.Da, v.D)); need(n + ".qkv.s", (size_t)3 * v.Da * 4); need(n + ".qkv.bl", (size_t)3 * v.Da * 4); }
     if (v.ln_fold2) { need(n + ".ffn1.wl", wbytes(v, v.hidden, v.D)); need(n + ".ffn1.s", (size_t)v.hidden * 4); need(n + ".ffn1.bl", (size_t)v.hidden * 4); }
     if (v.stream_mlp) {
-      need(n + ".embed.ws", (size_t)v.D * v.D * esz); need(n + ".qkv.ws", (size_t)3 * v.D * v.D * esz);
+      if (v.D == 384) { need(n + ".embed.ws", (size_t)v.D * v.D * esz); need(n + ".qkv.ws", (size_t)3 * v.D * v.D * esz); }
       need(n + ".proj.ws", (size_t)v.D * v.D * esz); need(n + ".ffn.ws", (size_t)2 * v.D * v.hidden * esz); need(n + ".head.ws", (size_t)2 * v.D * v.hidden * esz);
     }
     need(n + ".ln2.g", (size_t)v.D * 4); need(n + ".ln2.b", (size_t)v.D * 4);
@@ -647,7 +651,10 @@ int cfen_net::run_vit_g(int ng, const VitCall* vc, int scr0) {
   else
     TRYP(K_ATTN, 4 * Md * v.S * D, cfen_attention_impl_g(dt, ng, cQKV, ATT, B * nwin, v.S, v.heads, v.dh, stream));
   const void* cATT[3] = {ATT[0], ATT[1], ATT[2]};
-  const bool stream_mlp = v.stream_mlp && (cfen_tune_stream_mlp() >= 2 || (cfen_tune_stream_mlp() == 1 && (long long)ng * M >= 128LL * 128));
+  // D = 384: launches of >= 128 workgroups of 128 tokens; D = 192 (LViT level 2): always -- k_mlp3<12, 3> is spill-free and 192-token workgroups
+  // make the grouped decoder launch exactly two rounds (154-162 us against k_mlp2's 181-204, tools/bench_mlp3.py)
+  const bool stream_mlp = v.stream_mlp && (v.D == 192 ? cfen_tune_stream_mlp192() != 0
+                                                      : (cfen_tune_stream_mlp() >= 2 || (cfen_tune_stream_mlp() == 1 && (long long)ng * M >= 128LL * 128)));
   if (stream_mlp) {
     // LViT level 3: out_proj + residual + LN2 + FFN + mlp_head + fold in one launch on fragment-stream weights (k_stream.hip)
     Mlp3Args m[3];

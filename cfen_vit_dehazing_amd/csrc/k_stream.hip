@@ -585,6 +585,10 @@ int launch_mlp3(int ng, const Mlp3Args* ap, hipStream_t s) {
 
 }  // namespace
 
+int& cfen_tune_mlp3_tm192() {   // token tiles per wave of the D = 192 variant: 4 (256 tokens a workgroup), 3 (192: the grouped LViT-2 decoder launch of 3 x 32768
+  static int v = 3;             // tokens is then exactly two rounds of 256 workgroups), 2
+  return v;
+}
 int& cfen_tune_mlp3_debug() {
   static int v = 0;
   return v;
@@ -617,6 +621,8 @@ int cfen_mlp3_impl_g(int dtype, int ng, const Mlp3Args* ap, hipStream_t s) {
   if (ap[0].D == 384 && cfen_tune_mlp3_debug() == 1) return launch_mlp3<24, 2, 3, 1536, 1>(ng, ap, s);
   if (ap[0].D == 384 && cfen_tune_mlp3_debug() == 2) return launch_mlp3<24, 2, 3, 1536, 2>(ng, ap, s);
   if (ap[0].D == 384) return launch_mlp3<24, 2, 3, 1536>(ng, ap, s);
+  if (cfen_tune_mlp3_tm192() == 3) return launch_mlp3<12, 3, 6, 768>(ng, ap, s);
+  if (cfen_tune_mlp3_tm192() == 2) return launch_mlp3<12, 2, 6, 768>(ng, ap, s);
   return launch_mlp3<12, 4, 6, 768>(ng, ap, s);
 }
 

@@ -143,11 +143,11 @@ def pack_stream_rows(wk):
     return wk.reshape(n // 32, 2, 16, k // 32, 4, 8).permute(0, 3, 1, 4, 2, 5).contiguous().view(-1)     # [t][c][u][hq][r][e]: u fastest, as pack_stream_pair
 
 
-STREAM_MLP_DIMS = (384,)
+STREAM_MLP_DIMS = (384, 192)
 
 
 def mlp_is_streamed(g, dtype):
-    """mirror of cfen_net.cpp Vit::stream_mlp: LViT level 3 (D = 384) runs proj + LN2 + FFN + mlp_head + fold as one k_mlp3 launch"""
+    """mirror of cfen_net.cpp Vit::stream_mlp: LViT levels 3 (D = 384) and 2 (D = 192) run proj + LN2 + FFN + mlp_head + fold as one k_mlp3 launch"""
     return (g.kind == "lvit" and g.shrink == 1 and dtype == torch.float16 and g.dim in STREAM_MLP_DIMS and g.hidden % 32 == 0
             and g.hidden <= 4 * g.dim)
 
@@ -272,9 +272,10 @@ def pack_vit(sd, g, dtype):
         out[n + ".proj.ws"] = pack_stream_sq(out[n + ".proj.w"])
         out[n + ".ffn.ws"] = pack_stream_pair(out[n + ".ffn1.w"][:, kd], out[n + ".ffn2.w"][:, kh])
         out[n + ".head.ws"] = pack_stream_pair(out[n + ".head1.w"][:, kd], out[n + ".head2.w"][:, kh])
-        # k_front3: linear_encoding and in_proj as row-tile streams (the LayerNorm-folded and plain matrices stay for "net.stream_front" = 0)
-        out[n + ".embed.ws"] = pack_stream_rows(out[n + ".embed.w"][:, kd])
-        out[n + ".qkv.ws"] = pack_stream_rows(out[n + ".qkv.w"][:, kd])
+        if g.dim == 384:
+            # k_front3: linear_encoding and in_proj as row-tile streams (the LayerNorm-folded and plain matrices stay for "net.stream_front" = 0)
+            out[n + ".embed.ws"] = pack_stream_rows(out[n + ".embed.w"][:, kd])
+            out[n + ".qkv.ws"] = pack_stream_rows(out[n + ".qkv.w"][:, kd])
     if mlp_is_fused(g, dtype):
         # the fused MLP kernel replaces the four separate GEMMs: same matrices, k axis re-slotted (fp16 only)
         for a, b in (("ffn1", "ffn2"), ("head1", "head2")):
