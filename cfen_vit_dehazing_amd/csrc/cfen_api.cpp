@@ -271,6 +271,14 @@ int cfen_tune(const char* key, int value) {
     cfen_tune_attn_head_major() = value != 0;
     return CFEN_OK;
   }
+  if (!strcmp(key, "dcn.tps")) {
+    cfen_tune_dcn_tps() = value;
+    return CFEN_OK;
+  }
+  if (!strcmp(key, "dcn.tile")) {
+    cfen_tune_dcn_tile() = value;
+    return CFEN_OK;
+  }
   if (!strcmp(key, "attn.hm_pair")) {
     cfen_tune_attn_hm_pair() = value != 0;
     return CFEN_OK;

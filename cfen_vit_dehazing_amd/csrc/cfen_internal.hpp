@@ -118,6 +118,8 @@ int& cfen_tune_gemm_splitk();     // 1 (default): K-heavy few-token GEMMs run sp
 int& cfen_tune_lvit_window();        // 1 (default): LViT level 1 runs as one k_lvit_window launch per instance group ("net.lvit_window")
 int& cfen_tune_fold_in_gemm();      // 1 (default): the last GEMM of an unfused block folds its tokens into the map itself ("net.fold_in_gemm")
 int& cfen_tune_attn_head_major();   // 1 (default): LViT levels with a fused front half hand qkv to attention head-major ("net.attn_head_major")
+int& cfen_tune_dcn_tps();           // taps per K slice of k_dcn_lean at most this ("dcn.tps")
+int& cfen_tune_dcn_tile();          // 1: deformable conv forward on k_dcn_tile where its shapes allow ("dcn.tile")
 int& cfen_tune_attn_hm_pair();      // 1: S = 256 head-major attention on the two-query-tile kernel ("attn.hm_pair")
 int& cfen_tune_stream_front();      // k_front3 for the D = 384 LViT blocks: 0 never, 1 (default) grouped decoder launches, 2 always ("net.stream_front")
 int& cfen_tune_stream_mlp192();     // 1: LViT level 2 (D = 192) on k_mlp3 instead of k_mlp2; 0 (default, faster inside the forward: see cfen_net.cpp) ("net.stream_mlp192")

@@ -11,7 +11,11 @@
 // border rules), stages the matching weight slice next to it, and contracts both with MFMA; the
 // column matrix never exists in HBM.  Tensors are NCHW like the reference API.
 #include <algorithm>
+#include <type_traits>
 #include "cfen_common.hpp"
+
+int& cfen_tune_dcn_tile();
+int& cfen_tune_dcn_tps();
 
 namespace {
 struct DcnArgs;
@@ -339,6 +343,402 @@ __global__ __launch_bounds__(256) void k_dcn_nhwc(DcnArgs a) {
   }
 }
 
+// ---- lean path (round 3) -------------------------------------------------------------------------------------------------------
+// What bounds k_dcn_nhwc is instruction issue, not memory (tools/dcn_pmc.sh on (8,24,256,256), dg 1: L1 hit rate 93 %, texture addresser
+// busy 41 %, 181 cycles of L2 latency -- and 1300-3000 VALU + 600 SALU instructions per wave, 65-100 % of the SIMDs' issue slots: 64-bit
+// address arithmetic per load, integer divisions per task, a conversion per channel and corner).  Two intermediate kernels that only
+// shortened the chain of dependent memory round trips (DMA'd weights, offsets up front, gathers two items ahead) or cut the L1 line
+// look-ups by three (the lanes of a pixel side by side) ran in the same 180-190 us as k_dcn_nhwc's 150 + 14.  This kernel is built
+// around the instruction count:
+//   * a lane owns a (pixel, tap, UNIT of 3 channel vectors) task: offsets / mask loaded once, corners set up once (per-axis weights with
+//     the border rules folded in, v_med3 clamps, 24-bit multiplies), 12 gathers; which (tap, unit) a wave works on comes from a table
+//     in LDS (no divisions in the loop), TB tasks in flight per lane;
+//   * every global access is a buffer load: 32-bit byte offset in a VGPR, the tap's plane / the unit's channel offset in an SGPR;
+//   * fp16 is interpolated with packed fp16 FMAs (v_pk_fma_f16: 2 channels per instruction; the reference's half path computes its
+//     bilinear sum in half as well, deform_conv_cuda_kernel.cu:83-114 with scalar_t = at::Half); fp32 stays fp32;
+//   * a K slice is `tps` whole taps (all nine for 24 channels: one gather phase, two barriers per workgroup), every wave contracts its
+//     own 16 pixels with all the weight rows;
+//   * deformable groups narrower than a vector (C/dg = 3, 6, 12: the generator's dg = 8 layers): the task walks the UNIT / CPDG groups of
+//     its unit, each with its own offsets, gathers CPDG channels per corner in ONE load (3 fp16 channels: the 4-byte aligned 8 bytes around
+//     them) and still writes whole 16-byte vectors into the column tile -- k_dcn_nhwc re-gathers a full vector per group.
+typedef _Float16 dcn_h2 __attribute__((ext_vector_type(2)));
+typedef unsigned int dcn_u32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned int dcn_u32x3 __attribute__((ext_vector_type(3)));
+typedef unsigned int dcn_u32x4 __attribute__((ext_vector_type(4)));
+
+CFEN_DEV dcn_h2 dcn_pack_h2(float w) {
+  const _Float16 hw = (_Float16)w;
+  dcn_h2 r = {hw, hw};
+  return r;
+}
+
+// per-axis bilinear weights with the reference's border rules folded in (.cu:83-114, 226-236): the sample counts only for
+// -1 < c < n; its low neighbour only when floor(c) >= 0, its high neighbour only when floor(c) + 1 <= n - 1
+struct DcnAxis { float lo, hi; int il, ih; };
+CFEN_DEV DcnAxis dcn_axis(float c, float n_f, float nm1_f, int nm1) {
+  const float f = floorf(c);
+  const float l = c - f, hh = 1.f - l;
+  const int lowi = (int)f;
+  DcnAxis r;
+  r.lo = (c >= 0.f && c < n_f) ? hh : 0.f;
+  r.hi = (c > -1.f && c < nm1_f) ? l : 0.f;
+  r.il = min(max(lowi, 0), nm1);
+  r.ih = min(max(lowi + 1, 0), nm1);
+  return r;
+}
+
+template <typename T> struct DcnLoad;
+template <> struct DcnLoad<half_t> {
+  static CFEN_DEV float scalar(__amdgpu_buffer_rsrc_t r, int voff, int soff) {
+    const unsigned short u = __builtin_amdgcn_raw_buffer_load_b16(r, voff, soff, 0);
+    _Float16 hv;
+    __builtin_memcpy(&hv, &u, 2);
+    return (float)hv;
+  }
+};
+template <> struct DcnLoad<float> {
+  static CFEN_DEV float scalar(__amdgpu_buffer_rsrc_t r, int voff, int soff) {
+    return __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(r, voff, soff, 0));
+  }
+};
+
+// wg[4] (fp32 corner weights) x four 16-byte corner vectors -> one 16-byte vector of the column tile
+CFEN_DEV half8 dcn_interp(const float (&wg)[4], const dcn_h2 (&wh)[4], const dcn_u32x4 (&q)[4]) {
+  dcn_u32x4 o;
+#pragma unroll
+  for (int d = 0; d < 4; ++d) {
+    dcn_h2 c[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { const unsigned int w = q[k][d]; __builtin_memcpy(&c[k], &w, 4); }
+    const dcn_h2 r = wh[0] * c[0] + wh[1] * c[1] + wh[2] * c[2] + wh[3] * c[3];
+    unsigned int w;
+    __builtin_memcpy(&w, &r, 4);
+    o[d] = w;
+  }
+  half8 out;
+  __builtin_memcpy(&out, &o, 16);
+  (void)wg;
+  return out;
+}
+CFEN_DEV floatx4 dcn_interp(const float (&wg)[4], const float (&)[4], const dcn_u32x4 (&q)[4]) {
+  floatx4 o;
+#pragma unroll
+  for (int d = 0; d < 4; ++d)
+    o[d] = wg[0] * __uint_as_float(q[0][d]) + wg[1] * __uint_as_float(q[1][d]) + wg[2] * __uint_as_float(q[2][d]) + wg[3] * __uint_as_float(q[3][d]);
+  return o;
+}
+
+constexpr int DCN_MAX_TASKS = 256;     // (tap, unit) table entries
+constexpr int DCN_FALLBACK = -100;     // launch_dcn_lean: not this kernel's shape after all
+
+template <typename T, int CPDG, bool MASK, int TB>
+__global__ __launch_bounds__(256) void k_dcn_lean(DcnArgs a, int tps, int pitch) {
+  constexpr int SZ = (int)sizeof(T), VE = 16 / SZ, UNIT = 3 * VE;
+  constexpr bool ONE = CPDG == 0;                       // the unit lies inside one deformable group
+  constexpr int NS = ONE ? 1 : UNIT / CPDG;             // deformable groups a unit walks through
+  constexpr bool HALF = SZ == 2;
+  typedef typename Mma<T>::frag frag;
+  typedef typename std::conditional<HALF, dcn_h2, float>::type wpack;
+  extern __shared__ __attribute__((aligned(16))) unsigned char dcn_smem[];
+  __shared__ unsigned int task_tab[DCN_MAX_TASKS];      // (ti << 24) | (tj << 16) | unit
+  const int tid = threadIdx.x, lane = tid & 63, r16 = lane & 15, h = lane >> 4;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int Cg = a.C / a.group, Cout_g = a.Cout / a.group;
+  const int ncb = (Cout_g + D_CO - 1) / D_CO;
+  const int g = blockIdx.z / ncb, cb = blockIdx.z % ncb;
+  const int b = blockIdx.y;
+  const int HWo = a.Ho * a.Wo;
+  const int kk = a.kh * a.kw;
+  const int Kg = Cg * kk;
+  const int cpdg = a.C / a.dg;
+  const int rows = min(D_CO, Cout_g - cb * D_CO);
+  const int ntile = (rows + 15) / 16;
+  const int units = Cg / UNIT;
+  unsigned char* colT = dcn_smem;
+  unsigned char* Wl = dcn_smem + D_PIX * pitch;
+
+  if (tid < kk * units) {
+    const int ij = tid / units, un = tid - ij * units;
+    const int ti = ij / a.kw, tj = ij - ti * a.kw;
+    task_tab[tid] = ((unsigned)ti << 24) | ((unsigned)tj << 16) | (unsigned)un;
+  }
+
+  const __amdgpu_buffer_rsrc_t im_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<T*>((const T*)a.imT + (size_t)b * a.H * a.W * a.C), 0, -1, 0x00020000);
+  const __amdgpu_buffer_rsrc_t off_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<T*>((const T*)a.offset + (size_t)b * a.dg * 2 * kk * HWo), 0, -1, 0x00020000);
+  const __amdgpu_buffer_rsrc_t msk_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<T*>(MASK ? (const T*)a.mask + (size_t)b * a.dg * kk * HWo : (const T*)a.offset), 0, -1, 0x00020000);
+  const T* wT = (const T*)a.wT + (size_t)(g * Cout_g + cb * D_CO) * Kg;
+
+  const int p = blockIdx.x * D_PIX + lane;
+  const bool pvalid = p < HWo;
+  const int pp = pvalid ? p : 0;
+  const int ho = pp / a.Wo, wo = pp - ho * a.Wo;
+  const float hb = (float)(ho * a.sh - a.ph), wb = (float)(wo * a.sw - a.pw);
+  const int voff_p = pp * SZ;
+  const float H_f = (float)a.H, W_f = (float)a.W, Hm1_f = (float)(a.H - 1), Wm1_f = (float)(a.W - 1);
+  const unsigned rowb = (unsigned)(a.W * a.C * SZ), pixb = (unsigned)(a.C * SZ);      // < 2^24 (launcher)
+  const int plane = HWo * SZ;                                                           // bytes of one offset / mask plane
+
+  floatx4 acc[D_CO / 16];
+#pragma unroll
+  for (int i = 0; i < D_CO / 16; ++i) acc[i] = floatx4{0.f, 0.f, 0.f, 0.f};
+  __syncthreads();                                      // task table
+
+  for (int tap0 = 0; tap0 < kk; tap0 += tps) {
+    const int nt = min(tps, kk - tap0);
+    const int kb = nt * Cg * SZ, kb64 = (kb + 63) & ~63;          // bytes of a slice row with data / as the MFMA loop walks it
+    const int ntask = nt * units, e0 = tap0 * units;
+    // ---- column tile: colT[pixel][tap-in-slice * Cg + c] ----
+    for (int t0 = wave; t0 < ntask; t0 += 4 * TB) {
+      if constexpr (ONE) {
+        float oh[TB], ow[TB], mm[TB], fi[TB], fj[TB];
+        int csoff[TB], dst[TB];
+        bool live[TB];
+#pragma unroll
+        for (int u = 0; u < TB; ++u) {
+          const int t = t0 + 4 * u;
+          live[u] = t < ntask;                                     // wave-uniform
+          const unsigned ent = __builtin_amdgcn_readfirstlane(task_tab[e0 + (live[u] ? t : 0)]);
+          const int ti = ent >> 24, tj = (ent >> 16) & 255, un = ent & 0xffff;
+          const int ij = ti * a.kw + tj, cim = g * Cg + un * UNIT;
+          const int dgi = cim / cpdg;                              // scalar
+          fi[u] = (float)(ti * a.dh); fj[u] = (float)(tj * a.dw);
+          csoff[u] = cim * SZ;
+          dst[u] = ((ij - tap0) * Cg + un * UNIT) * SZ;
+          const int so = (dgi * 2 * kk + 2 * ij) * plane;
+          oh[u] = DcnLoad<T>::scalar(off_rsrc, voff_p, so);
+          ow[u] = DcnLoad<T>::scalar(off_rsrc, voff_p, so + plane);
+          mm[u] = MASK ? DcnLoad<T>::scalar(msk_rsrc, voff_p, (dgi * kk + ij) * plane) : 1.f;
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        float wg[TB][4];
+        wpack wh[TB][4];
+        dcn_u32x4 q[TB][3][4];
+#pragma unroll
+        for (int u = 0; u < TB; ++u) {
+          const DcnAxis ay = dcn_axis(hb + fi[u] + oh[u], H_f, Hm1_f, a.H - 1), ax = dcn_axis(wb + fj[u] + ow[u], W_f, Wm1_f, a.W - 1);
+          const float m = (live[u] && pvalid) ? mm[u] : 0.f;
+          const float xl = ax.lo * m, xh = ax.hi * m;
+          wg[u][0] = ay.lo * xl; wg[u][1] = ay.lo * xh; wg[u][2] = ay.hi * xl; wg[u][3] = ay.hi * xh;
+          const unsigned yl = __umul24(ay.il, rowb), yh = __umul24(ay.ih, rowb), xlb = __umul24(ax.il, pixb), xhb = __umul24(ax.ih, pixb);
+          const int vo[4] = {(int)(yl + xlb), (int)(yl + xhb), (int)(yh + xlb), (int)(yh + xhb)};
+#pragma unroll
+          for (int k = 0; k < 4; ++k)
+#pragma unroll
+            for (int v = 0; v < 3; ++v) q[u][v][k] = __builtin_amdgcn_raw_buffer_load_b128(im_rsrc, vo[k] + v * 16, csoff[u], 0);
+        }
+#pragma unroll
+        for (int u = 0; u < TB; ++u) {
+          asm volatile("" : "+v"(wg[u][0]), "+v"(wg[u][1]), "+v"(wg[u][2]), "+v"(wg[u][3]));   // no interpolation (and its wait) between the gathers
+          if constexpr (HALF) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) wh[u][k] = dcn_pack_h2(wg[u][k]);
+          } else {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) wh[u][k] = wg[u][k];
+          }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int u = 0; u < TB; ++u) {
+          if (!live[u]) continue;
+#pragma unroll
+          for (int v = 0; v < 3; ++v) *reinterpret_cast<frag*>(colT + lane * pitch + dst[u] + v * 16) = dcn_interp(wg[u], wh[u], q[u][v]);
+        }
+      } else {
+        // one task at a time: NS groups x 4 corners are NS * 4 independent gathers already
+        constexpr int SB = CPDG * SZ;                                // bytes of a group's channels at one corner
+        constexpr int LW = SB == 6 ? 2 : SB / 4;                     // dwords per load: 6 bytes -> the aligned 8 around them, 12 -> 3, 24 -> 4 + 2
+        for (int t = t0; t < ntask && t < t0 + 4 * TB; t += 4) {
+          const unsigned ent = __builtin_amdgcn_readfirstlane(task_tab[e0 + t]);
+          const int ti = ent >> 24, tj = (ent >> 16) & 255, un = ent & 0xffff;
+          const int ij = ti * a.kw + tj, cim0 = g * Cg + un * UNIT;
+          const int dg0 = cim0 / CPDG;
+          const float fi = (float)(ti * a.dh), fj = (float)(tj * a.dw);
+          unsigned int res[12];                                        // the unit: 3 vectors of 16 bytes
+          // groups per batch of gathers: all of them (3-channel groups: 32 gathers in flight at 160 registers measured 231 / 308 us on (8,24,256,256)
+          // dg 8, two batches of 16 at 120 registers 243 / 331)
+          constexpr int SEGB = NS;
+#pragma unroll
+          for (int s0 = 0; s0 < NS; s0 += SEGB) {
+            float oh[SEGB], ow[SEGB], mm[SEGB];
+#pragma unroll
+            for (int s = 0; s < SEGB; ++s) {
+              const int so = ((dg0 + s0 + s) * 2 * kk + 2 * ij) * plane;
+              oh[s] = DcnLoad<T>::scalar(off_rsrc, voff_p, so);
+              ow[s] = DcnLoad<T>::scalar(off_rsrc, voff_p, so + plane);
+              mm[s] = MASK ? DcnLoad<T>::scalar(msk_rsrc, voff_p, ((dg0 + s0 + s) * kk + ij) * plane) : 1.f;
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            float wg[SEGB][4];
+            unsigned int raw[SEGB][4][LW == 6 ? 6 : LW];
+#pragma unroll
+            for (int s = 0; s < SEGB; ++s) {
+              const DcnAxis ay = dcn_axis(hb + fi + oh[s], H_f, Hm1_f, a.H - 1), ax = dcn_axis(wb + fj + ow[s], W_f, Wm1_f, a.W - 1);
+              const float m = pvalid ? mm[s] : 0.f;
+              const float xl = ax.lo * m, xh = ax.hi * m;
+              wg[s][0] = ay.lo * xl; wg[s][1] = ay.lo * xh; wg[s][2] = ay.hi * xl; wg[s][3] = ay.hi * xh;
+              const unsigned yl = __umul24(ay.il, rowb), yh = __umul24(ay.ih, rowb), xlb = __umul24(ax.il, pixb), xhb = __umul24(ax.ih, pixb);
+              const int vo[4] = {(int)(yl + xlb), (int)(yl + xhb), (int)(yh + xlb), (int)(yh + xhb)};
+              const int co = ((s0 + s) * CPDG - (SB == 6 ? (s & 1) : 0)) * SZ;          // compile-time after unrolling: folded into the instruction's offset
+#pragma unroll
+              for (int k = 0; k < 4; ++k) {
+                if constexpr (LW == 2) {
+                  const dcn_u32x2 v = __builtin_amdgcn_raw_buffer_load_b64(im_rsrc, vo[k] + co, cim0 * SZ, 0);
+                  raw[s][k][0] = v[0]; raw[s][k][1] = v[1];
+                } else if constexpr (LW == 3) {
+                  const dcn_u32x3 v = __builtin_amdgcn_raw_buffer_load_b96(im_rsrc, vo[k] + co, cim0 * SZ, 0);
+                  raw[s][k][0] = v[0]; raw[s][k][1] = v[1]; raw[s][k][2] = v[2];
+                } else {
+                  static_assert(LW == 6, "3, 6 or 12 channels");
+                  const dcn_u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(im_rsrc, vo[k] + co, cim0 * SZ, 0);
+                  const dcn_u32x2 w = __builtin_amdgcn_raw_buffer_load_b64(im_rsrc, vo[k] + co + 16, cim0 * SZ, 0);
+                  raw[s][k][0] = v[0]; raw[s][k][1] = v[1]; raw[s][k][2] = v[2]; raw[s][k][3] = v[3]; raw[s][k][4] = w[0]; raw[s][k][5] = w[1];
+                }
+              }
+            }
+#pragma unroll
+            for (int s = 0; s < SEGB; ++s) asm volatile("" : "+v"(wg[s][0]), "+v"(wg[s][1]), "+v"(wg[s][2]), "+v"(wg[s][3]));
+            __builtin_amdgcn_sched_barrier(0);
+            if constexpr (HALF) {
+              constexpr int ND = LW == 6 ? 6 : LW;                       // dwords (channel pairs) of a group's load
+              unsigned int part[SEGB][ND];
+#pragma unroll
+              for (int s = 0; s < SEGB; ++s) {
+                dcn_h2 wh[4];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) wh[k] = dcn_pack_h2(wg[s][k]);
+#pragma unroll
+                for (int d = 0; d < ND; ++d) {
+                  dcn_h2 c[4];
+#pragma unroll
+                  for (int k = 0; k < 4; ++k) __builtin_memcpy(&c[k], &raw[s][k][d], 4);
+                  const dcn_h2 r = wh[0] * c[0] + wh[1] * c[1] + wh[2] * c[2] + wh[3] * c[3];
+                  __builtin_memcpy(&part[s][d], &r, 4);
+                }
+              }
+              if constexpr (SB == 6) {
+                // even group: [c0 c1 | c2 x], odd group (loaded one channel early): [x c0 | c1 c2] -> six channels = three pairs
+#pragma unroll
+                for (int s2 = 0; s2 < SEGB / 2; ++s2) {
+                  res[(s0 / 2 + s2) * 3 + 0] = part[2 * s2][0];
+                  res[(s0 / 2 + s2) * 3 + 1] = (part[2 * s2][1] & 0xffffu) | (part[2 * s2 + 1][0] & 0xffff0000u);
+                  res[(s0 / 2 + s2) * 3 + 2] = part[2 * s2 + 1][1];
+                }
+              } else {
+#pragma unroll
+                for (int s = 0; s < SEGB; ++s)
+#pragma unroll
+                  for (int d = 0; d < ND; ++d) res[(s0 + s) * ND + d] = part[s][d];
+              }
+            } else {
+#pragma unroll
+              for (int s = 0; s < SEGB; ++s)
+#pragma unroll
+                for (int e = 0; e < CPDG; ++e)
+                  res[(s0 + s) * CPDG + e] = __float_as_uint(wg[s][0] * __uint_as_float(raw[s][0][e]) + wg[s][1] * __uint_as_float(raw[s][1][e]) +
+                                                      wg[s][2] * __uint_as_float(raw[s][2][e]) + wg[s][3] * __uint_as_float(raw[s][3][e]));
+            }
+            __builtin_amdgcn_sched_barrier(0);
+          }
+          const int dstb = ((ij - tap0) * Cg + un * UNIT) * SZ;
+#pragma unroll
+          for (int v = 0; v < 3; ++v) {
+            const dcn_u32x4 o = {res[v * 4], res[v * 4 + 1], res[v * 4 + 2], res[v * 4 + 3]};
+            *reinterpret_cast<dcn_u32x4*>(colT + lane * pitch + dstb + v * 16) = o;
+          }
+        }
+      }
+    }
+    // ---- weight slice (16-byte pieces of the tap-major copy), zero in the rows past the block's and in the columns [kb, kb64) ----
+    const int npc = kb64 / 16;
+    for (int idx = tid; idx < ntile * 16 * npc; idx += 256) {
+      const int row = idx / npc, pc = idx - row * npc;
+      *reinterpret_cast<frag*>(Wl + row * pitch + pc * 16) =
+          (row < rows && pc * 16 < kb) ? load_frag<T>(wT + (size_t)row * Kg + tap0 * Cg + pc * VE) : Mma<T>::zero();
+    }
+    if (kb64 > kb) {
+      const int nz = (kb64 - kb) / 16;
+      for (int idx = tid; idx < D_PIX * nz; idx += 256) {
+        const int row = idx / nz, pc = idx - row * nz;
+        *reinterpret_cast<frag*>(colT + row * pitch + kb + pc * 16) = Mma<T>::zero();
+      }
+    }
+    __syncthreads();
+    for (int c = 0; c < kb64 / 64; ++c) {
+      const frag bf = *reinterpret_cast<const frag*>(colT + (wave * 16 + r16) * pitch + c * 64 + h * 16);
+#pragma unroll
+      for (int i = 0; i < D_CO / 16; ++i)
+        if (i < ntile) acc[i] = Mma<T>::mma(*reinterpret_cast<const frag*>(Wl + (i * 16 + r16) * pitch + c * 64 + h * 16), bf, acc[i]);
+    }
+    __syncthreads();
+  }
+
+  T* out = (T*)a.out + ((size_t)b * a.Cout + g * Cout_g + cb * D_CO) * HWo;
+  const T* bias = a.bias ? (const T*)a.bias + g * Cout_g + cb * D_CO : nullptr;
+  const int po = blockIdx.x * D_PIX + wave * 16 + r16;
+  if (po < HWo) {
+#pragma unroll
+    for (int i = 0; i < D_CO / 16; ++i) {
+      if (i >= ntile) break;
+      float bv[4];                                  // branch-free loads (a branch per value is a memory round trip per value)
+      const T* bp = bias ? bias : wT;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) bv[r] = (float)bp[min(i * 16 + 4 * h + r, rows - 1)];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int co = i * 16 + 4 * h + r;
+        if (co < rows) out[(size_t)co * HWo + po] = (T)(acc[i][r] + (bias ? bv[r] : 0.f));
+      }
+    }
+  }
+}
+
+// which k_dcn_lean instance serves the problem (0 = none): the unit of 3 channel vectors must tile the group's channels and either lie
+// inside one deformable group or be cut by the groups into equal parts of 3, 6 or 12 channels
+template <typename T>
+int dcn_lean_mode(const DcnArgs& a) {
+  constexpr int SZ = (int)sizeof(T), VE = 16 / SZ, UNIT = 3 * VE;
+  const int Cg = a.C / a.group, cpdg = a.C / a.dg, kk = a.kh * a.kw;
+  if (Cg % UNIT || kk * (Cg / UNIT) > DCN_MAX_TASKS || a.kh > 255 || a.kw > 255) return 0;
+  // 24-bit multiplies for the corner offsets, 32-bit byte offsets into one image / one image's offset planes
+  if ((long long)a.W * a.C * SZ >= (1 << 24) || a.H >= (1 << 24) || (long long)a.H * a.W * a.C * SZ >= (1ll << 31) ||
+      (long long)a.dg * 2 * kk * a.Ho * a.Wo * SZ >= (1ll << 31))
+    return 0;
+  if (cpdg % UNIT == 0) return 1;
+  if (UNIT % cpdg == 0 && (cpdg == 3 || cpdg == 6 || (cpdg == 12 && VE == 8))) return cpdg;
+  return 0;
+}
+
+template <typename T, bool MASK>
+int launch_dcn_lean(const DcnArgs& a, int mode, dim3 grid, hipStream_t s) {
+  constexpr int SZ = (int)sizeof(T);
+  const int Cg = a.C / a.group, Cout_g = a.Cout / a.group, kk = a.kh * a.kw;
+  const int rows16 = (std::min(D_CO, Cout_g) + 15) / 16 * 16;
+  // taps per slice: as many whole taps as fit the LDS budget, then evened out over the slices
+  auto pitch_of = [&](int t) { return ((t * Cg * SZ + 63) & ~63) + 32; };   // 32 (mod 64) bytes: conflict-free 16-byte reads and writes
+  int tmax = 0;
+  for (int t = 1; t <= kk; ++t)
+    if ((size_t)(D_PIX + rows16) * pitch_of(t) <= 60 * 1024) tmax = t;
+  if (!tmax) return DCN_FALLBACK;                      // a one-tap slice does not fit: the caller falls back to k_dcn_nhwc
+  const int nsl = (kk + tmax - 1) / tmax;
+  int tps = (kk + nsl - 1) / nsl;
+  if (cfen_tune_dcn_tps() > 0) tps = std::min(tps, cfen_tune_dcn_tps());
+  const int pitch = pitch_of(tps);
+  const size_t lds = (size_t)(D_PIX + rows16) * pitch;
+  // one task in flight per lane everywhere: 116 registers (four waves per SIMD) beat two or three tasks in flight at 170-250 (measured, section 4.3)
+  switch (mode) {
+    case 1: CFEN_LAUNCH((k_dcn_lean<T, 0, MASK, 1>), grid, dim3(256), lds, s, a, tps, pitch); break;
+    case 3: CFEN_LAUNCH((k_dcn_lean<T, 3, MASK, 1>), grid, dim3(256), lds, s, a, tps, pitch); break;
+    case 6: CFEN_LAUNCH((k_dcn_lean<T, 6, MASK, 1>), grid, dim3(256), lds, s, a, tps, pitch); break;
+    default:
+      if constexpr (SZ == 2) { CFEN_LAUNCH((k_dcn_lean<T, 12, MASK, 1>), grid, dim3(256), lds, s, a, tps, pitch); break; }
+      cfen_set_error("deform_conv: lean mode %d", mode);
+      return CFEN_ERR_ARG;
+  }
+  CFEN_CHECK_LAUNCH("deform_conv (lean)");
+  return CFEN_OK;
+}
+
 int launch_dcn(int dtype, const DcnArgs& a, hipStream_t s) {
   CFEN_CHECK_ARG(a.im && a.offset && a.weight && a.out, "deform_conv: null tensor");
   // shape_check (dcn/src/deform_conv_cuda.cpp:61-149)
@@ -357,6 +757,7 @@ int launch_dcn(int dtype, const DcnArgs& a, hipStream_t s) {
   dim3 grid((unsigned)((HWo + D_PIX - 1) / D_PIX), a.B, a.group * ncb);
   CFEN_CHECK_ARG(grid.y <= 65535 && grid.z <= 65535, "deform_conv: batch / groups too large for one launch");
   if (a.imT && (dtype == 0 || dtype == 1)) {   // fast path: NHWC + tap-major copies in the caller's scratch
+    const int lean_mode = !cfen_tune_dcn_tile() ? 0 : dtype == 1 ? dcn_lean_mode<half_t>(a) : dcn_lean_mode<float>(a);
     const long long HW = (long long)a.H * a.W, nim = (long long)a.B * (a.C / (dtype == 1 ? 8 : 4)) * HW;
     const long long nw = (long long)a.Cout * (a.C / a.group) * a.kh * a.kw;
     const unsigned pg = (unsigned)std::min<long long>((nim + nw + 255) / 256, 8192);
@@ -364,11 +765,13 @@ int launch_dcn(int dtype, const DcnArgs& a, hipStream_t s) {
       CFEN_LAUNCH(k_dcn_prep<half_t>, dim3(pg), dim3(256), 0, s, (const half_t*)a.im, (half_t*)a.imT, (const half_t*)a.weight, (half_t*)a.wT, a.C, HW, nim,
                   a.C / a.group, a.kh * a.kw, nw);
       CFEN_CHECK_LAUNCH("deform_conv (layout pre-pass)");
+      if (lean_mode) { const int rc = a.mask ? launch_dcn_lean<half_t, true>(a, lean_mode, grid, s) : launch_dcn_lean<half_t, false>(a, lean_mode, grid, s); if (rc != DCN_FALLBACK) return rc; }
       CFEN_LAUNCH(k_dcn_nhwc<half_t>, grid, dim3(256), 0, s, a);
     } else {
       CFEN_LAUNCH(k_dcn_prep<float>, dim3(pg), dim3(256), 0, s, (const float*)a.im, (float*)a.imT, (const float*)a.weight, (float*)a.wT, a.C, HW, nim,
                   a.C / a.group, a.kh * a.kw, nw);
       CFEN_CHECK_LAUNCH("deform_conv (layout pre-pass)");
+      if (lean_mode) { const int rc = a.mask ? launch_dcn_lean<float, true>(a, lean_mode, grid, s) : launch_dcn_lean<float, false>(a, lean_mode, grid, s); if (rc != DCN_FALLBACK) return rc; }
       CFEN_LAUNCH(k_dcn_nhwc<float>, grid, dim3(256), 0, s, a);
     }
   } else if (dtype == 1)
@@ -396,6 +799,16 @@ void dcn_use_scratch(int dtype, DcnArgs& a, void* columns, size_t columns_bytes)
 }
 
 }  // namespace
+
+int& cfen_tune_dcn_tile() {   // 1 (default): k_dcn_lean where its shapes allow; 0: k_dcn_nhwc (round 2)
+  static int v = 1;
+  return v;
+}
+
+int& cfen_tune_dcn_tps() {   // taps per K slice of k_dcn_lean at most this (0: as many as fit 60 KB of LDS) ("dcn.tps")
+  static int v = 0;
+  return v;
+}
 
 extern "C" {
 

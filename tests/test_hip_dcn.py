@@ -23,7 +23,11 @@ def tol(dtype):
 @pytest.mark.parametrize("dtype", [torch.float32, torch.float16])
 @pytest.mark.parametrize("B,C,H,Cout,k,stride,pad,dil,groups,dg", [
     (2, 24, 32, 24, 3, 1, 1, 1, 1, 1), (1, 48, 16, 48, 3, 1, 1, 1, 1, 8), (1, 96, 16, 96, 3, 1, 1, 1, 1, 8),
-    (2, 8, 13, 6, 3, 2, 1, 1, 1, 2), (1, 8, 12, 12, 5, 1, 2, 1, 2, 1), (1, 6, 10, 160, 3, 1, 2, 2, 1, 3), (3, 3, 9, 5, 1, 1, 0, 1, 1, 1)])
+    (2, 8, 13, 6, 3, 2, 1, 1, 1, 2), (1, 8, 12, 12, 5, 1, 2, 1, 2, 1), (1, 6, 10, 160, 3, 1, 2, 2, 1, 3), (3, 3, 9, 5, 1, 1, 0, 1, 1, 1),
+    # k_dcn_lean: two conv groups of 24 channels cut into deformable groups of 12, stride / dilation 2 with 40 output rows and groups of 3,
+    # two output-row blocks, a 5x5 kernel (three tap slices, the last one padded), a unit inside a 48-channel deformable group
+    (1, 48, 16, 48, 3, 1, 1, 1, 2, 4), (2, 24, 17, 40, 3, 2, 2, 2, 1, 8), (1, 24, 12, 160, 3, 1, 1, 1, 1, 1), (1, 24, 14, 24, 5, 1, 2, 1, 1, 4),
+    (1, 96, 12, 48, 3, 1, 1, 1, 1, 2)])
 def test_deform_conv_v1_and_v2(dtype, B, C, H, Cout, k, stride, pad, dil, groups, dg):
     x, w = rnd((B, C, H, H + 3), 1), rnd((Cout, C // groups, k, k), 2, (C // groups * k * k) ** -0.5)
     Ho = (H + 2 * pad - (dil * (k - 1) + 1)) // stride + 1
@@ -39,6 +43,25 @@ def test_deform_conv_v1_and_v2(dtype, B, C, H, Cout, k, stride, pad, dil, groups
     want2 = dcn_oracle.deform_conv(xq.float(), oq.float(), wq.float(), stride, pad, dil, groups, dg, mask=mq.float(), bias=bq.float())
     got2 = dcn.modulated_deform_conv(xq.to(DEV), oq.to(DEV), mq.to(DEV), wq.to(DEV), bq.to(DEV), stride, pad, dil, groups, dg)
     assert float((got2.float().cpu() - want2).abs().max()) <= tol(dtype)
+
+
+@pytest.mark.parametrize("C,dg", [(24, 1), (24, 8), (48, 8), (96, 8)])
+def test_lean_kernel_and_round2_kernel_agree(C, dg):
+    """`dcn.tile` 0 runs k_dcn_nhwc (round 2) on the shapes k_dcn_lean serves by default: same sampling rules; the lean kernel interpolates
+    fp16 maps with packed fp16 FMAs (as the reference's half instantiation does), k_dcn_nhwc in fp32 -- equal to fp16 rounding of the samples."""
+    from cfen_vit_dehazing_amd import ops
+    H = 40
+    x, w = rnd((2, C, H, H), 21).half().to(DEV), rnd((C, C, 3, 3), 22, (C * 9) ** -0.5).half().to(DEV)
+    off = rnd((2, dg * 18, H, H), 23, 3.0).half().to(DEV)
+    mask = torch.sigmoid(rnd((2, dg * 9, H, H), 24)).half().to(DEV)
+    bias = rnd((C,), 25).half().to(DEV)
+    try:
+        got = [(dcn.deform_conv(x, off, w, 1, 1, 1, 1, dg), dcn.modulated_deform_conv(x, off, mask, w, bias, 1, 1, 1, 1, dg))
+               for t in (1, 0) if ops.tune("dcn.tile", t) is None]
+    finally:
+        ops.tune("dcn.tile", 1)
+    for a, b in zip(got[0], got[1]):
+        assert float((a.float() - b.float()).abs().max()) <= 8e-3
 
 
 def test_pack_modules_at_init_are_plain_convs():

@@ -22,6 +22,9 @@ def main():
     ap.add_argument("--reps", type=int, default=30)
     ap.add_argument("--check", action="store_true")
     ap.add_argument("--backward", action="store_true", help="time the backward of each case (all gradients) instead of the forward")
+    ap.add_argument("--burst", type=int, default=0, help="also time N back-to-back calls through the C ABI (preallocated output and scratch, no cache eviction, "
+                    "no host synchronisation in between): the rate with the GPU kept busy, reported as us_burst")
+    ap.add_argument("--no-flush", action="store_true", help="do not evict the caches between repetitions (hot numbers)")
     ap.add_argument("--channels", type=int, default=0, help="only the case with this many channels (24, 48 or 96); 0 = all three")
     args = ap.parse_args()
     dt = torch.float16 if args.dtype == "fp16" else torch.float32
@@ -54,7 +57,8 @@ def main():
                 torch.cuda.synchronize()
                 times = []
                 for _ in range(args.reps):
-                    flush.zero_()
+                    if not args.no_flush:
+                        flush.zero_()
                     a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                     a.record(); fn(); b.record()
                     torch.cuda.synchronize()
@@ -69,6 +73,32 @@ def main():
                 tf = (2.0 * C * C * 9 + 8.0 * C * 9) * px / ms / 1e9 * (2 if args.backward else 1)
                 rec = {"op": "dcn_v%d%s" % (ver, "_backward" if args.backward else ""), "shape": [B, C, H, H], "deformable_groups": dg, "dtype": args.dtype, "us": round(ms * 1e3, 1),
                        "algorithmic_MB": round(elems * esz / 1e6, 2), "GBps": round(gbs, 1), "hbm_frac": round(gbs / HBM_PEAK, 4), "TFLOPs": round(tf, 2)}
+                if args.burst and not args.backward:
+                    from cfen_vit_dehazing_amd import _lib
+                    from cfen_vit_dehazing_amd._lib import check, ptr, dtype_code, current_stream
+                    lib = _lib.load()
+                    nb = int(lib.cfen_deform_conv_columns_bytes(dtype_code(dt), B, C, H, H, C, 3, 3, 1))
+                    col = torch.empty(max(nb, 16), dtype=torch.uint8, device=dev)
+                    o2 = torch.empty_like(out)
+                    st = current_stream()
+                    def call():
+                        if ver == 1:
+                            check(lib.cfen_deform_conv_forward(dtype_code(dt), ptr(x), ptr(w), ptr(off), ptr(o2), B, C, H, H, C, 3, 3, 1, 1, 1, 1, 1, 1, 1, dg, B,
+                                                               ptr(col), nb, st), "deform_conv_forward")
+                        else:
+                            check(lib.cfen_modulated_deform_conv_forward(dtype_code(dt), ptr(x), ptr(w), ptr(bias), ptr(off), ptr(mask), ptr(o2), B, C, H, H, C, 3, 3,
+                                                                         1, 1, 1, 1, 1, 1, 1, dg, 1, ptr(col), nb, st), "modulated_deform_conv_forward")
+                    for _ in range(10):
+                        call()
+                    torch.cuda.synchronize()
+                    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    a.record()
+                    for _ in range(args.burst):
+                        call()
+                    b.record()
+                    torch.cuda.synchronize()
+                    rec["us_burst"] = round(a.elapsed_time(b) * 1e3 / args.burst, 1)
+                    rec["burst_equal"] = bool(torch.equal(o2, out))
                 if args.check and not args.backward:
                     want = dcn_oracle.deform_conv(x[:1].float().cpu(), off[:1].float().cpu(), w.float().cpu(), 1, 1, 1, 1, dg,
                                                   **({} if ver == 1 else {"mask": mask[:1].float().cpu(), "bias": bias.float().cpu()}))
