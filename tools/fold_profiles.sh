@@ -15,3 +15,9 @@ q=$(find $d/pmc_sq -name "*counter_collection.csv" 2>/dev/null | head -1); [ -n 
 # (round 3: the counter tables are folded on the GPU box by tools/gpu_round.sh -- they exceed what gpurun merges back)
 for f in $d/folded/r_*; do [ -f "$f" ] && cp $f ${pre}_${f##*/r_}; done
 ls -la ${pre}_*
+for w in cfg4 cfg5; do
+  ks=$(find $d/${w}_stats -name "*kernel_stats.csv" 2>/dev/null | head -1); [ -n "$ks" ] && cp $ks ${pre}_${w}_bench_kernel_stats.csv
+  [ -f $d/${w}_stats_bench.json ] && cp $d/${w}_stats_bench.json ${pre}_${w}_bench_line_under_rocprof.json
+  [ -f $d/${w}_launches.txt ] && grep -v "amdgpu.ids" $d/${w}_launches.txt > ${pre}_${w}_launches.txt
+done
+ks=$(find $d/dcn_stats -name "*kernel_stats.csv" 2>/dev/null | head -1); [ -n "$ks" ] && cp $ks ${pre}_dcn_forward_kernel_stats.csv
