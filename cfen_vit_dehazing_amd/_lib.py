@@ -48,8 +48,8 @@ class MlpStreamArgsC(ctypes.Structure):
 
 class LvitArgsC(ctypes.Structure):
     _fields_ = [("fmap", c_void_p), ("out", c_void_p)] + [(n, ctypes.c_int32) for n in ("B", "H", "W", "C", "cs_in", "cs_out", "ws", "p")] + \
-               [(n, c_void_p) for n in ("we", "be", "pos", "ln1_gamma", "ln1_beta", "wkv", "wq", "wp", "ln2_gamma", "ln2_beta",
-                                        "w1a", "b1a", "w2a", "b2a", "w1b", "b1b", "w2b", "b2b")] + [("hidden", ctypes.c_int32), ("eps", c_float)]
+               [(n, c_void_p) for n in ("w_stream", "be", "pos", "ln1_gamma", "ln1_beta", "ln2_gamma", "ln2_beta", "b1a", "b2a", "b1b", "b2b")] + \
+               [("hidden", ctypes.c_int32), ("eps", c_float)]
 
 
 # every symbol include/cfen_hip.h declares: (restype, argtypes)

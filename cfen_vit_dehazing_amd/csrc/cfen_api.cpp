@@ -112,9 +112,8 @@ int cfen_mlp_stream_block(int dtype, const cfen_mlp_stream_args* a, void* stream
 
 int cfen_lvit_window(int dtype, const cfen_lvit_args* a, void* stream) {
   CFEN_CHECK_ARG(a != nullptr, "lvit_window: null args");
-  LvitArgs v{a->fmap, a->out, a->B, a->H, a->W, a->C, a->cs_in, a->cs_out, a->ws, a->p, a->we, a->be, a->pos, a->ln1_gamma, a->ln1_beta,
-             a->wkv, a->wq, a->wp, a->ln2_gamma, a->ln2_beta, a->w1a, a->b1a, a->w2a, a->b2a, a->w1b, a->b1b, a->w2b, a->b2b, a->hidden, a->eps,
-             1.4426950408889634f / sqrtf(24.f)};
+  LvitArgs v{a->fmap, a->out, a->B, a->H, a->W, a->C, a->cs_in, a->cs_out, a->ws, a->p, a->w_stream, a->be, a->pos, a->ln1_gamma, a->ln1_beta,
+             a->ln2_gamma, a->ln2_beta, a->b1a, a->b2a, a->b1b, a->b2b, a->hidden, a->eps, 1.4426950408889634f / sqrtf(24.f)};
   return cfen_lvit_window_impl_g(dtype, 1, &v, (hipStream_t)stream);
 }
 
@@ -273,6 +272,10 @@ int cfen_tune(const char* key, int value) {
   }
   if (!strcmp(key, "dcn.tps")) {
     cfen_tune_dcn_tps() = value;
+    return CFEN_OK;
+  }
+  if (!strcmp(key, "gemm.nt")) {
+    cfen_tune_gemm_nt() = value;
     return CFEN_OK;
   }
   if (!strcmp(key, "dcn.tile")) {

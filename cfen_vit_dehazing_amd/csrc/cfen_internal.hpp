@@ -114,6 +114,7 @@ int& cfen_tune_gemm_splitk_stages();   // ring depth of the split-K tile beyond 
 int& cfen_tune_mlp3_tm192();         // token tiles per wave of k_mlp3 at D = 192: 2, 3 (default) or 4 ("mlp3.tm192")
 int& cfen_tune_mlp3_debug();         // k_mlp3 timing experiments (results invalid): 1 no DMA refills, 2 no MFMAs ("mlp3.debug")
 int& cfen_tune_gemm_m128();          // tile id (+10 per extra stage) for problems of <= 128 tokens, 0 = shape rule ("gemm.m128")
+int& cfen_tune_gemm_nt();         // weight rows of k_gemm_dma by non-temporal LDS-DMA: 0 / 1 (M <= 512) / 2 ("gemm.nt")
 int& cfen_tune_gemm_splitk();     // 1 (default): K-heavy few-token GEMMs run split-K when the caller provides scratch ("gemm.splitk")
 int& cfen_tune_lvit_window();        // 1 (default): LViT level 1 runs as one k_lvit_window launch per instance group ("net.lvit_window")
 int& cfen_tune_fold_in_gemm();      // 1 (default): the last GEMM of an unfused block folds its tokens into the map itself ("net.fold_in_gemm")

@@ -5,15 +5,14 @@
 struct LvitArgs {
   const void* fmap; void* out;            // NHWC maps (B, H, W), channel strides cs_in / cs_out, C real channels
   int B, H, W, C, cs_in, cs_out, ws, p;   // window edge ws (32), patch p (2): 256 tokens of D = p*p*C = 96 per window
-  const void* We; const float* be; const void* pos;    // linear_encoding [D][D] (k axis kperm32), bias, position table [S][D]
+  const void* Ws;                         // every weight matrix of the block as ONE stream of 1 KiB MFMA A fragments in consumption order
+                                          // (packing.pack_lvit_window): linear_encoding, K / V rows, per head W_q tiles + out_proj slice,
+                                          // linear1 / linear2 and mlp_head in 32-unit hidden slices; k axes kperm32
+  const float* be; const void* pos;       // linear_encoding bias, position table [S][D]
   const float* ln1_g; const float* ln1_b;
-  const void* Wkv;                        // [2D][D]: K rows of all heads, then V rows (natural feature order), k axis kperm32
-  const void* Wq;                         // [heads][32][D]: per head two 16-row tiles laid out so that the accumulator pair packs into
-                                          // natural d order (packing.lvit_q_rows), rows of d >= 24 zero; k axis kperm32
-  const void* Wp;                         // [heads][D][32]: out_proj columns of the head, slot s <- d = kperm32(s), slots of d >= 24 zero
   const float* ln2_g; const float* ln2_b;
-  const void* W1a; const float* b1a; const void* W2a; const float* b2a;   // as MlpArgs (k axis kperm32)
-  const void* W1b; const float* b1b; const void* W2b; const float* b2b;
+  const float* b1a; const float* b2a;     // biases of linear1 / linear2 and of mlp_head (as MlpArgs)
+  const float* b1b; const float* b2b;
   int Hm;                                 // hidden width of both MLPs
   float eps, scale_log2;                  // LayerNorm eps; log2(e) / sqrt(head_dim)
 };

@@ -333,7 +333,8 @@ int cfen_net::build() {
     need(n + ".embed.w", wbytes(v, v.D, v.D)); need(n + ".embed.b", (size_t)v.D * 4);
     if (v.fused_front) { need(n + ".embed.wk", (size_t)v.D * v.D * esz); need(n + ".qkv.wk", (size_t)3 * v.D * v.D * esz); }
     if (v.fused_window) {
-      need(n + ".lw.wkv", (size_t)2 * v.D * v.D * esz); need(n + ".lw.wq", (size_t)v.heads * 32 * v.D * esz); need(n + ".lw.wp", (size_t)v.heads * v.D * 32 * esz);
+      // the window kernel's fragment stream: embedding D x D, K / V 2D x D, per head 32 x D + D x 32, two MLP pairs of 2 x hidden x D
+      need(n + ".lw.ws", ((size_t)3 * v.D * v.D + (size_t)v.heads * 64 * v.D + (size_t)4 * v.hidden * v.D) * esz);
     }
     need(n + ".pos", (size_t)v.S * v.D * esz);
     need(n + ".ln1.g", (size_t)v.D * 4); need(n + ".ln1.b", (size_t)v.D * 4);
@@ -587,10 +588,9 @@ int cfen_net::run_vit_g(int ng, const VitCall* vc, int scr0) {
     LvitArgs w[3];
     for (int g = 0; g < ng; ++g) {
       const std::string& n = nm[g];
-      w[g] = LvitArgs{IN[g], OUT[g], B, v.mapH, v.mapH, v.C, bi.cs, bo.cs, v.ws, v.p, P(n + ".embed.wk"), Pf(n + ".embed.b"), P(n + ".pos"),
-                      Pf(n + ".ln1.g"), Pf(n + ".ln1.b"), P(n + ".lw.wkv"), P(n + ".lw.wq"), P(n + ".lw.wp"), Pf(n + ".ln2.g"), Pf(n + ".ln2.b"),
-                      P(n + ".ffn1.wk"), Pf(n + ".ffn1.b"), P(n + ".ffn2.wk"), Pf(n + ".ffn2.b"), P(n + ".head1.wk"), Pf(n + ".head1.b"),
-                      P(n + ".head2.wk"), Pf(n + ".head2.b"), v.hidden, 1e-5f, 1.4426950408889634f / sqrtf((float)(v.D / v.heads))};
+      w[g] = LvitArgs{IN[g], OUT[g], B, v.mapH, v.mapH, v.C, bi.cs, bo.cs, v.ws, v.p, P(n + ".lw.ws"), Pf(n + ".embed.b"), P(n + ".pos"),
+                      Pf(n + ".ln1.g"), Pf(n + ".ln1.b"), Pf(n + ".ln2.g"), Pf(n + ".ln2.b"), Pf(n + ".ffn1.b"), Pf(n + ".ffn2.b"),
+                      Pf(n + ".head1.b"), Pf(n + ".head2.b"), v.hidden, 1e-5f, 1.4426950408889634f / sqrtf((float)(v.D / v.heads))};
     }
     step("window_block_fused");
     TRYP(K_MLP, 8 * Md * D * D + 4 * Md * v.S * D + 8 * Md * D * Hd + 2 * Md * D * D, cfen_lvit_window_impl_g(dt, ng, w, stream));

@@ -15,6 +15,8 @@
 #include "cfen_common.hpp"
 #include "cfen_internal.hpp"
 
+int& cfen_tune_gemm_nt();
+
 namespace {
 
 // XCD-aware block -> tile map.  Blocks are dealt round-robin to the 8 XCDs (own L2 each); XCD x = block & 7 works on one
@@ -65,6 +67,7 @@ template <typename T> struct GemmArgs {
   float* part;
   unsigned* cnt;   // one arrival counter per tile, zero between launches (the reducing workgroup puts its tile's back to zero)
   int nsplit;
+  int nt;            // weight rows by non-temporal LDS-DMA
   // optional LayerNorm fold (k_gemm_dma, nsplit == 1, K = the whole row): see CfenGemmPtrs::lnf_s
   const float* lnf_s;
   float lnf_eps;
@@ -314,6 +317,10 @@ __global__ __launch_bounds__(256) void k_gemm_nt(Grouped<GemmArgs<T>> ga) {
 CFEN_DEV void dma16(const void* g, unsigned char* l) {
   __builtin_amdgcn_global_load_lds(g, (__attribute__((address_space(3))) void*)l, 16, 0, 0);
 }
+// ... with the non-temporal policy (aux = 2): weight rows that one launch reads once ("gemm.nt")
+CFEN_DEV void dma16_nt(const void* g, unsigned char* l) {
+  __builtin_amdgcn_global_load_lds(g, (__attribute__((address_space(3))) void*)l, 16, 0, 2);
+}
 
 // wait until at most `younger` K-steps of LOADS LDS-DMAs each are still in flight (younger <= Y)
 template <int LOADS, int Y>
@@ -363,9 +370,11 @@ __global__ __launch_bounds__(256, (TN > 3 && NS == 2) ? 2 : 1) void k_gemm_dma(G
     gpc[i] = gx ? piece * EPL : -1;
   }
 #define CFEN_GEMM_DMA_ISSUE(kt_, buf_)                                                                              \
-  _Pragma("unroll") for (int i_ = 0; i_ < LOADS; ++i_)                                                              \
-      dma16(gptr[i_] + (i_ < TN ? (kt_) * wstep : gpc[i_] >= 0 ? gather_off(a, (kt_) * BK + gpc[i_]) : (kt_) * BK),           \
-            lds + (buf_) * STAGE + (i_ * 256 + wave * 64) * 16)
+  _Pragma("unroll") for (int i_ = 0; i_ < LOADS; ++i_) {                                                            \
+    if (i_ < TN && a.nt) dma16_nt(gptr[i_] + (kt_) * wstep, lds + (buf_) * STAGE + (i_ * 256 + wave * 64) * 16);      \
+    else dma16(gptr[i_] + (i_ < TN ? (kt_) * wstep : gpc[i_] >= 0 ? gather_off(a, (kt_) * BK + gpc[i_]) : (kt_) * BK),         \
+               lds + (buf_) * STAGE + (i_ * 256 + wave * 64) * 16);                                                 \
+  }
 
   const int wstep = a.wtile ? G_BN * BK : BK;   // elements from one K-step of a weight row to the next
   floatx4 acc[TN][TM];
@@ -610,6 +619,7 @@ int launch_gemm(int ng, const CfenGemmPtrs* gp, int ldx, int ldw, int ldr, int p
     a.X = (const T*)(tg ? q.gmap : q.X); a.W = (const T*)q.W; a.bias = q.bias; a.R = (const T*)q.R; a.P = (const T*)q.P; a.Y = (T*)q.Y;
     a.M = M; a.N = N; a.K = K; a.ldx = ldx; a.ldw = ldw; a.ldr = ldr; a.ldy = ldy; a.period = period; a.relu = relu;
     a.nsplit = 1;
+    a.nt = 0;
     a.lnf_s = q.lnf_s;
     a.lnf_eps = cfen_gemm_lnf_eps();
     a.wtile = q.wtile;
@@ -691,6 +701,7 @@ int launch_gemm(int ng, const CfenGemmPtrs* gp, int ldx, int ldw, int ldr, int p
   for (int g = 0; g < ng; ++g) {
     ga.g[g].map = map;
     ga.g[g].nsplit = nsplit;
+    ga.g[g].nt = (cfen_tune_gemm_nt() == 2 || (cfen_tune_gemm_nt() == 1 && M <= 512)) ? 1 : 0;
     CFEN_CHECK_ARG(nsplit == 1 || (splitk_ws[g] && cfen_aligned16(splitk_ws[g])), "gemm: split-K workspace missing");
     ga.g[g].cnt = nsplit > 1 ? reinterpret_cast<unsigned*>(splitk_ws[g]) : nullptr;                       // [CFEN_SPLITK_COUNTERS] arrival counters, zero
     ga.g[g].part = nsplit > 1 ? splitk_ws[g] + CFEN_SPLITK_COUNTERS * sizeof(unsigned) / sizeof(float) : nullptr;   // then the partial slabs
@@ -725,6 +736,11 @@ float& cfen_gemm_lnf_eps() {
   static float v = 1e-5f;
   return v;
 }
+int& cfen_tune_gemm_nt() {   // weight rows of k_gemm_dma by non-temporal LDS-DMA: 0 never, 1 few-token GEMMs (M <= 512: GViT levels 2 and 3), 2 always ("gemm.nt")
+  static int v = 0;
+  return v;
+}
+
 int& cfen_tune_gemm_splitk() {
   static int v = 1;
   return v;

@@ -9,8 +9,15 @@
 //
 // A workgroup of 8 waves owns ONE window; wave w owns its tokens 32w .. 32w+31 for the whole chain.  As in k_mlp2 / k_embed_qkv2 the
 // residual stream of a token tile lives in fp32 MFMA accumulators (rows = features, columns = tokens), an accumulator tile pair is the
-// B operand of the next GEMM, and every weight matrix streams through a two-stage LDS ring by LDS-DMA in 32-row chunks (one raw
-// s_barrier per chunk, next chunk in flight, fragment groups of three software-pipelined).  What is new:
+// B operand of the next GEMM, and every weight matrix streams through an LDS ring by LDS-DMA in 32-row chunks (one raw s_barrier per
+// chunk).  Round 3: the weights come as ONE stream of 1 KiB MFMA A fragments in consumption order (packing.pack_lvit_window, as
+// k_stream.hip's format): a chunk is 6 or 12 contiguous KiB, a DMA instruction is a linear 1 KiB copy, fragment reads are lane-linear
+// (conflict-free without row padding), and the 13 KiB stages leave room for THREE of them beside K / V: two chunks in flight.  With the
+// two-stage ring of round 2 an MLP chunk took 0.94 us -- one LDS-DMA issue -> landed latency (MI355X_MICROARCH.md, ldsdma-fill: ~1.1 us)
+// per chunk, 2.5x its MFMA time -- and with two chunks in flight it still takes 0.93 us: the DMA is not what a chunk waits for.  Bound
+// experiment on this kernel (24 images, back to back; barriers / DMA refills / the MLP chunks' MFMAs removed one at a time and together):
+// 435 -> 383 / 360 / 397 us, all three 343 us; 32 hidden units instead of 384: 263 of 385 us -- the embedding, K / V and attention chunks
+// (13 of 37) are two thirds of the kernel: 128 exp2 + ~500 other vector instructions per lane, head and token-tile pair.  What round 2 brought:
 //   * K and V of the whole window (256 keys x 4 heads x 24 dims, fp16) stay in LDS (2 x 56 KB; a kernel node may use the CU's full
 //     160 KB of LDS -- tools/repro/lds_graph_probe.hip).  The K/V chunks of the qkv projection write their tiles there instead of HBM.
 //   * Attention is run as "an MLP whose activation is softmax(Q K^T) V": the chunk of head h carries W_q[h] (32 rows) and the
@@ -62,16 +69,14 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(NW / 4,
   static_assert(NW * TM * 16 == S, "one workgroup = one window");
   constexpr int D = ND * 16, NCH = ND / 2;
   static_assert(D == NH * DH && NCH == 3, "built for D = 96: 4 heads of 24, one fragment group per row tile");
-  constexpr int P1 = D * 2 + 32, PP1 = P1 / 16;            // R1: 32 weight rows of D, pitch 224 B
-  constexpr int P2 = 64 + 32, PP2 = P2 / 16;               // R2: D rows of a 32-wide k slice, pitch 96 B
-  constexpr int N1 = 32 * PP1 / 64, N2 = D * PP2 / 64;     // DMA wave-instructions per region (7, 9)
-  static_assert(32 * PP1 % 64 == 0 && D * PP2 % 64 == 0, "regions must be whole DMA instructions");
-  constexpr int NINS = N1 + N2 + 1, STAGE = NINS * 1024, NI = (NINS + NW - 1) / NW;
+  constexpr int N1 = 2 * NCH, N2 = ND;                     // fragments of a chunk's R1 (32 rows x D: row tile u, k-chunk k -> u * NCH + k) and
+                                                           // R2 (D rows x 32-wide k slice: row tile i) parts, 1 KiB each
+  constexpr int NINS = N1 + N2 + 1, STAGE = NINS * 1024, NI = (NINS + NW - 1) / NW, NS = 3;   // + the MLP chunks' 128 bytes of bias
   constexpr int R2 = N1 * 1024, R3 = (N1 + N2) * 1024;
   constexpr int KVP = NH * DH * 2 + 32;                    // K / V row pitch: 4 heads x 24 dims, 224 B (= 32 mod 64)
   constexpr int KOFF = 0, VOFF = S * KVP, RING = 2 * S * KVP;
-  static_assert(RING + 2 * STAGE <= 160 * 1024, "LDS");
-  __shared__ __attribute__((aligned(1024))) unsigned char lds[RING + 2 * STAGE];
+  static_assert(RING + NS * STAGE <= 160 * 1024, "LDS");
+  __shared__ __attribute__((aligned(1024))) unsigned char lds[RING + NS * STAGE];
   unsigned char* ring = lds + RING;
 
   const int tid = threadIdx.x, lane = tid & 63, r16 = lane & 15, h = lane >> 4;
@@ -80,60 +85,40 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(NW / 4,
   constexpr int NE = D / 32, NKV = 2 * D / 32, NA = NH;    // embedding / K+V / attention chunks
   const int nchunks = NE + NKV + NA + 2 * nhc;
 
-  // ---- DMA plan (as k_mlp2): instruction i of this wave fills block i * NW + wave of the stage ----
-  unsigned off[NI];
-#pragma unroll
-  for (int i = 0; i < NI; ++i) {
-    const int blk = i * NW + wave;
-    if (blk < N1) {
-      const int id = blk * 64 + lane, row = id / PP1, col = min(id % PP1, PP1 - 3);
-      off[i] = (unsigned)(row * D * 2 + col * 16);
-    } else if (blk < N1 + N2) {
-      const int id = (blk - N1) * 64 + lane, row = id / PP2, col = min(id % PP2, PP2 - 3);
-      off[i] = (unsigned)((row << 8) | (col * 16));        // row and byte column of an R2 piece: the row stride depends on the chunk kind
-    } else {
-      off[i] = (unsigned)(min(lane, 7) * 16);
-    }
-  }
-  auto issue = [&](int t, int buf) {
-    const unsigned char* r1 = nullptr;
-    const unsigned char* r2 = nullptr;
-    const unsigned char* r3 = nullptr;
-    unsigned stride2 = 0;
-    if (t < NE) {
-      r1 = (const unsigned char*)a.We + (size_t)t * 32 * D * 2;
-    } else if (t < NE + NKV) {
-      r1 = (const unsigned char*)a.Wkv + (size_t)(t - NE) * 32 * D * 2;
-    } else if (t < NE + NKV + NA) {
-      const int hl = t - NE - NKV;
-      r1 = (const unsigned char*)a.Wq + (size_t)hl * 32 * D * 2;
-      r2 = (const unsigned char*)a.Wp + (size_t)hl * D * 64;
-      stride2 = 64;
-    } else {
-      const int m = t - NE - NKV - NA;
-      const bool sb = m >= nhc;
-      const int hc = sb ? m - nhc : m;
-      r1 = (const unsigned char*)(sb ? a.W1b : a.W1a) + (size_t)hc * 32 * D * 2;
-      r2 = (const unsigned char*)(sb ? a.W2b : a.W2a) + (size_t)hc * 64;
-      r3 = (const unsigned char*)(sb ? a.b1b : a.b1a) + (size_t)hc * 128;
-      stride2 = (unsigned)a.Hm * 2;
-    }
+  // ---- DMA plan: instruction i of this wave copies fragment i * NW + wave of the chunk (the stream is in consumption order) ----
+  // chunk t of the stream: NE embedding + NKV key / value chunks of N1 fragments, then NA attention and 2 * nhc MLP chunks of N1 + N2
+  const unsigned char* const ws = (const unsigned char*)a.Ws;
+  auto nfrag_of = [&](int t) { return t < NE + NKV ? N1 : N1 + N2; };
+  auto issue = [&](int t, int buf) -> int {                  // returns the number of DMA instructions THIS wave issued
+    const int nf = nfrag_of(t);
+    const unsigned char* src = ws + (size_t)(t < NE + NKV ? t * N1 : (NE + NKV) * N1 + (t - NE - NKV) * (N1 + N2)) * 1024 + lane * 16;
+    const int m = t - NE - NKV - NA;                         // MLP chunk index (bias b1 of its 32 hidden units rides behind the fragments)
+    const unsigned char* bsrc = m < 0 ? nullptr : (const unsigned char*)(m >= nhc ? a.b1b : a.b1a) + (size_t)(m >= nhc ? m - nhc : m) * 128 + min(lane, 7) * 16;
+    int n = 0;
 #pragma unroll
     for (int i = 0; i < NI; ++i) {
       const int blk = i * NW + wave;
       unsigned char* dst = ring + buf * STAGE + blk * 1024;
-      if (blk < N1) lv_dma16(r1 + off[i], dst);
-      else if (blk < N1 + N2) { if (r2) lv_dma16(r2 + (off[i] >> 8) * stride2 + (off[i] & 255), dst); }
-      else if (blk < NINS) { if (r3) lv_dma16(r3 + off[i], dst); }
+      if (blk < nf) { lv_dma16(src + blk * 1024, dst); ++n; }
+      else if (blk == N1 + N2 && bsrc) { lv_dma16(bsrc, dst); ++n; }
     }
+    return n;
   };
+  // chunk t is read behind one barrier; chunks t + 1 and t + 2 are in flight behind it (three stages).  The wait leaves this wave's DMAs of
+  // chunk t + 1 outstanding (a stricter wait where other vector loads were issued since: still correct)
+  int inflight = 0;                                          // DMA instructions of this wave for the chunk after the one being waited for
   auto begin_chunk = [&](int t) -> const unsigned char* {
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (inflight >= 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    else if (inflight == 3) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+    else if (inflight == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+    else if (inflight == 1) asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
-    if (t + 1 < nchunks) issue(t + 1, (t + 1) & 1);
-    return ring + (t & 1) * STAGE;
+    inflight = t + 2 < nchunks ? issue(t + 2, (t + 2) % NS) : 0;
+    return ring + (t % NS) * STAGE;
   };
   issue(0, 0);
+  inflight = nchunks > 1 ? issue(1, 1) : 0;
 
   // the 32 pad bytes of every K / V row are read by the last head's padded fragments: they must hold finite values
   for (int r = tid; r < 2 * S; r += NW * 64) {
@@ -175,18 +160,18 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(NW / 4,
     for (int j = 0; j < TM; ++j) acc[i][j] += bb + load4<T>((const T*)a.pos + (size_t)tok[j] * D + i * 16 + 4 * h);
   }
 
-  const int a1 = r16 * P1 + h * 16;            // lane part of an R1 fragment address
-  const int a2 = R2 + r16 * P2 + h * 16;       // ... R2
+  const int a1 = lane * 16;                    // lane part of an R1 fragment address (lane-linear 1 KiB fragments)
+  const int a2 = R2 + lane * 16;               // ... R2
   const int a3 = R3 + 16 * h;                  // ... bias vector
   // R1 fragment group (row tile u of the chunk): NCH = 3 fragments
   auto load_r1 = [&](const unsigned char* buf, int u, frag (&f)[3]) {
 #pragma unroll
-    for (int k = 0; k < 3; ++k) f[k] = *reinterpret_cast<const frag*>(buf + a1 + (u * 16) * P1 + k * 64);
+    for (int k = 0; k < 3; ++k) f[k] = *reinterpret_cast<const frag*>(buf + a1 + (u * NCH + k) * 1024);
   };
   // R2 fragment group: feature-row tiles 3 ig .. 3 ig + 2 of the chunk's 32-wide k slice
   auto load_r2 = [&](const unsigned char* buf, int ig, frag (&f)[3]) {
 #pragma unroll
-    for (int k = 0; k < 3; ++k) f[k] = *reinterpret_cast<const frag*>(buf + a2 + ((ig * 3 + k) * 16) * P2);
+    for (int k = 0; k < 3; ++k) f[k] = *reinterpret_cast<const frag*>(buf + a2 + (ig * 3 + k) * 1024);
   };
   auto layer_norm_to_xb = [&](const float* gamma, const float* beta) {
 #pragma unroll
@@ -441,13 +426,11 @@ int cfen_lvit_window_impl_g(int dtype, int ng, const LvitArgs* ap, hipStream_t s
                    "lvit_window: fp16, C = 24, p = 2, 32-pixel windows (256 tokens of dim 96, 4 heads), hidden %% 32 == 0 only");
     CFEN_CHECK_ARG(a.B > 0 && a.H % a.ws == 0 && a.W % a.ws == 0 && a.cs_in >= a.C && a.cs_out >= a.C && a.cs_in % 4 == 0 && a.cs_out % 4 == 0 && a.C % 4 == 0,
                    "lvit_window: bad map geometry");
-    CFEN_CHECK_ARG(a.fmap && a.out && a.We && a.be && a.pos && a.ln1_g && a.ln1_b && a.Wkv && a.Wq && a.Wp && a.ln2_g && a.ln2_b && a.W1a && a.b1a &&
-                   a.W2a && a.b2a && a.W1b && a.b1b && a.W2b && a.b2b, "lvit_window: null pointer");
-    CFEN_CHECK_ARG(cfen_aligned16(a.fmap) && cfen_aligned16(a.out) && cfen_aligned16(a.We) && cfen_aligned16(a.be) && cfen_aligned16(a.pos) &&
-                   cfen_aligned16(a.ln1_g) && cfen_aligned16(a.ln1_b) && cfen_aligned16(a.Wkv) && cfen_aligned16(a.Wq) && cfen_aligned16(a.Wp) &&
-                   cfen_aligned16(a.ln2_g) && cfen_aligned16(a.ln2_b) && cfen_aligned16(a.W1a) && cfen_aligned16(a.b1a) && cfen_aligned16(a.W2a) &&
-                   cfen_aligned16(a.b2a) && cfen_aligned16(a.W1b) && cfen_aligned16(a.b1b) && cfen_aligned16(a.W2b) && cfen_aligned16(a.b2b),
-                   "lvit_window: pointers must be 16-byte aligned");
+    CFEN_CHECK_ARG(a.fmap && a.out && a.Ws && a.be && a.pos && a.ln1_g && a.ln1_b && a.ln2_g && a.ln2_b && a.b1a && a.b2a && a.b1b && a.b2b,
+                   "lvit_window: null pointer");
+    CFEN_CHECK_ARG(cfen_aligned16(a.fmap) && cfen_aligned16(a.out) && cfen_aligned16(a.Ws) && cfen_aligned16(a.be) && cfen_aligned16(a.pos) &&
+                   cfen_aligned16(a.ln1_g) && cfen_aligned16(a.ln1_b) && cfen_aligned16(a.ln2_g) && cfen_aligned16(a.ln2_b) && cfen_aligned16(a.b1a) &&
+                   cfen_aligned16(a.b2a) && cfen_aligned16(a.b1b) && cfen_aligned16(a.b2b), "lvit_window: pointers must be 16-byte aligned");
     CFEN_CHECK_ARG(a.B == ap[0].B && a.H == ap[0].H && a.W == ap[0].W && a.Hm == ap[0].Hm, "lvit_window: grouped problems must have the same shape");
   }
   const long long blocks = (long long)ap[0].B * (ap[0].H / ap[0].ws) * (ap[0].W / ap[0].ws);

@@ -146,7 +146,7 @@ def mlp_stream_block(x, wa, b1a, b2a, hidden, ln=None, second=None, fold=None, p
 
 
 def lvit_window(fmap, C, ws, p, packed, name, hidden, cs_out=None, eps=1e-5):
-    """whole LViT block (C = 24, p = 2, ws = 32) map -> map in one launch; `packed` = packing.pack_vit + packing.pack_lvit_window entries of `name`"""
+    """whole LViT block (C = 24, p = 2, ws = 32) map -> map in one launch; `packed` = packing.pack_vit entries of `name` + packing.pack_lvit_window's fragment stream (`hidden` = the stream's hidden width)"""
     from ._lib import LvitArgsC
     _cuda(fmap)
     B, H, W, cs = fmap.shape
@@ -154,10 +154,9 @@ def lvit_window(fmap, C, ws, p, packed, name, hidden, cs_out=None, eps=1e-5):
     out = torch.zeros(B, H, W, cs_out, dtype=fmap.dtype, device=fmap.device)
     g = lambda k: packed[name + k].data_ptr()
     a = LvitArgsC(fmap=fmap.data_ptr(), out=out.data_ptr(), B=B, H=H, W=W, C=C, cs_in=cs, cs_out=cs_out, ws=ws, p=p,
-                  we=g(".embed.wk"), be=g(".embed.b"), pos=g(".pos"), ln1_gamma=g(".ln1.g"), ln1_beta=g(".ln1.b"),
-                  wkv=g(".lw.wkv"), wq=g(".lw.wq"), wp=g(".lw.wp"), ln2_gamma=g(".ln2.g"), ln2_beta=g(".ln2.b"),
-                  w1a=g(".ffn1.wk"), b1a=g(".ffn1.b"), w2a=g(".ffn2.wk"), b2a=g(".ffn2.b"),
-                  w1b=g(".head1.wk"), b1b=g(".head1.b"), w2b=g(".head2.wk"), b2b=g(".head2.b"), hidden=hidden, eps=eps)
+                  w_stream=g(".lw.ws"), be=g(".embed.b"), pos=g(".pos"), ln1_gamma=g(".ln1.g"), ln1_beta=g(".ln1.b"),
+                  ln2_gamma=g(".ln2.g"), ln2_beta=g(".ln2.b"), b1a=g(".ffn1.b"), b2a=g(".ffn2.b"), b1b=g(".head1.b"), b2b=g(".head2.b"),
+                  hidden=hidden, eps=eps)
     check(_lib.load().cfen_lvit_window(dtype_code(fmap.dtype), ctypes.byref(a), current_stream()), "lvit_window")
     return out
 

@@ -75,7 +75,7 @@ def window_fusable(g, dtype):
 
 
 def pack_lvit_window(sd, g, dtype):
-    """extra weight layouts of the one-workgroup-per-window LViT kernel: K/V rows, per-head W_q tiles, per-head out_proj slices"""
+    """the weight stream of the one-workgroup-per-window LViT kernel: linear_encoding, K / V rows, per-head W_q tiles + out_proj slices, both MLP pairs"""
     n, D, dh = g.name, g.dim, g.dim // g.heads
     perm = token_perm(g.channels, g.patch)
     kp = kperm32(D)
@@ -95,8 +95,27 @@ def pack_lvit_window(sd, g, dtype):
         for s_, d in enumerate(slot_d.tolist()):
             if d < dh:
                 wp[hd, :, s_] = w_out[:, hd * dh + d]
-    return {n + ".lw.wkv": torch.cat((wk, wv), 0).to(dtype).contiguous(), n + ".lw.wq": wq.to(dtype).contiguous(),
-            n + ".lw.wp": wp.to(dtype).contiguous()}
+    # ONE stream of 1 KiB MFMA A fragments in the order k_lvit_window consumes them (csrc/k_lvit.hip): lane l of a fragment holds row
+    # (l & 15) of its 16-row tile, k elements (l >> 4) * 8 .. + 7 of its 32-wide k-chunk.  A chunk = a 32-row block [32][D] as fragments
+    # (u, k) = (row tile, k-chunk), u major ("R1"), for the attention and MLP chunks followed by a [D][32] block as fragments i = row tile ("R2")
+    def r1(blk):                                                          # [32][D] -> [2 u][D / 32 k][4 hq][16 r][8 e]
+        return blk.reshape(2, 16, D // 32, 4, 8).permute(0, 2, 3, 1, 4).reshape(-1)
+
+    def r2(blk):                                                          # [D][32] -> [D / 16 i][4 hq][16 r][8 e]
+        return blk.reshape(D // 16, 16, 4, 8).permute(0, 2, 1, 3).reshape(-1)
+
+    kd, kh = kperm32(D), kperm32(g.hidden)
+    we = sd[n + ".linear_encoding.weight"][perm][:, perm][:, kd]
+    wkv = torch.cat((wk, wv), 0)
+    parts = [r1(we[32 * c:32 * c + 32]) for c in range(D // 32)] + [r1(wkv[32 * c:32 * c + 32]) for c in range(2 * D // 32)]
+    for hd in range(g.heads):
+        parts += [r1(wq[hd]), r2(wp[hd])]
+    for a1, a2 in ((e + ".linear1.weight", e + ".linear2.weight"), (n + ".mlp_head.0.weight", n + ".mlp_head.3.weight")):
+        w1 = sd[a1][:, perm][:, kd]                                       # [H][D]
+        w2 = sd[a2][perm][:, kh]                                          # [D][H], hidden axis slotted like the accumulator pairs it multiplies
+        for hc in range(g.hidden // 32):
+            parts += [r1(w1[32 * hc:32 * hc + 32]), r2(w2[:, 32 * hc:32 * hc + 32])]
+    return {n + ".lw.ws": torch.cat(parts).to(dtype).contiguous()}
 
 
 def pack_wtile(w):

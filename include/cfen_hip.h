@@ -199,17 +199,16 @@ typedef struct cfen_mlp_stream_args {
 int cfen_mlp_stream_block(int dtype, const cfen_mlp_stream_args* a, void* stream);
 /* One whole LViT block per workgroup-window (CFEN_F16, C = 24, p = 2, 32-pixel windows: 256 tokens of dim 96, 4 heads of 24):
  * map in -> Crop2x2 + unfold + linear_encoding + pos -> pre-LN MHA -> FFN -> mlp_head -> fold + Join2x2 -> map out, with q / k / v, the
- * attention output and both hidden activations never leaving the chip (K and V of the window live in LDS).  Weight layouts:
- * packing.pack_lvit_window.                                                              (v3:1025-1056, 1136-1189, 1382-1390) */
+ * attention output and both hidden activations never leaving the chip (K and V of the window live in LDS).  `w_stream`: every weight
+ * matrix of the block as one stream of 1 KiB MFMA fragments in consumption order, packing.pack_lvit_window.                                                              (v3:1025-1056, 1136-1189, 1382-1390) */
 typedef struct cfen_lvit_args {
   const void* fmap; void* out;
   int32_t B, H, W, C, cs_in, cs_out, ws, p;
-  const void* we; const float* be; const void* pos;
+  const void* w_stream; const float* be; const void* pos;
   const float* ln1_gamma; const float* ln1_beta;
-  const void* wkv; const void* wq; const void* wp;
   const float* ln2_gamma; const float* ln2_beta;
-  const void* w1a; const float* b1a; const void* w2a; const float* b2a;
-  const void* w1b; const float* b1b; const void* w2b; const float* b2b;
+  const float* b1a; const float* b2a;
+  const float* b1b; const float* b2b;
   int32_t hidden;
   float eps;
 } cfen_lvit_args;

@@ -14,9 +14,12 @@ pk.update(packing.pack_lvit_window(sd, g, torch.float16))
 pk = {k: v.to(d).contiguous() for k, v in pk.items()}
 n = g.name
 small = dict(pk)
-for a, b in (("ffn1", "ffn2"), ("head1", "head2")):
-    small[n + "." + a + ".wk"] = pk[n + "." + a + ".wk"][:32].contiguous(); small[n + "." + a + ".b"] = pk[n + "." + a + ".b"][:32].contiguous()
-    small[n + "." + b + ".wk"] = pk[n + "." + b + ".wk"][:, :32].contiguous()
+# hidden 32: the stream's first MLP chunk of either pair (fragments of 512 fp16 elements: 102 before the MLP chunks, 12 per chunk, 12 chunks per pair)
+ws = pk[n + ".lw.ws"]
+pre, chunk = 102 * 512, 12 * 512
+small[n + ".lw.ws"] = torch.cat((ws[:pre + chunk], ws[pre + 12 * chunk:pre + 13 * chunk])).contiguous()
+for a in ("ffn1", "head1"):
+    small[n + "." + a + ".b"] = pk[n + "." + a + ".b"][:32].contiguous()
 flush = torch.empty(320 << 20, dtype=torch.uint8, device=d)
 def timed(f, n=9):
     ts = []
