@@ -431,7 +431,7 @@ CFEN_DEV floatx4 dcn_interp(const float (&wg)[4], const float (&)[4], const dcn_
 constexpr int DCN_MAX_TASKS = 256;     // (tap, unit) table entries
 constexpr int DCN_FALLBACK = -100;     // launch_dcn_lean: not this kernel's shape after all
 
-template <typename T, int CPDG, bool MASK, int TB>
+template <typename T, int CPDG, bool MASK, int TB, int NPAIR>
 __global__ __launch_bounds__(256) void k_dcn_lean(DcnArgs a, int tps, int pitch) {
   constexpr int SZ = (int)sizeof(T), VE = 16 / SZ, UNIT = 3 * VE;
   constexpr bool ONE = CPDG == 0;                       // the unit lies inside one deformable group
@@ -443,6 +443,7 @@ __global__ __launch_bounds__(256) void k_dcn_lean(DcnArgs a, int tps, int pitch)
   __shared__ unsigned int task_tab[DCN_MAX_TASKS];      // (ti << 24) | (tj << 16) | unit
   const int tid = threadIdx.x, lane = tid & 63, r16 = lane & 15, h = lane >> 4;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int nthr = blockDim.x, nwv = nthr >> 6;          // waves of the workgroup (4; 3 measured slower, see the launcher)
   const int Cg = a.C / a.group, Cout_g = a.Cout / a.group;
   const int ncb = (Cout_g + D_CO - 1) / D_CO;
   const int g = blockIdx.z / ncb, cb = blockIdx.z % ncb;
@@ -478,9 +479,10 @@ __global__ __launch_bounds__(256) void k_dcn_lean(DcnArgs a, int tps, int pitch)
   const unsigned rowb = (unsigned)(a.W * a.C * SZ), pixb = (unsigned)(a.C * SZ);      // < 2^24 (launcher)
   const int plane = HWo * SZ;                                                           // bytes of one offset / mask plane
 
-  floatx4 acc[D_CO / 16];
+  // output tiles (row tile i, pixel tile j) = pair i * 4 + j, dealt round-robin to the waves: pair wave + nwv * n is this wave's n-th
+  floatx4 acc[NPAIR];                                 // NPAIR >= ceil(4 * row tiles / waves): 3 serves up to 32 output rows, 11 everything (launcher)
 #pragma unroll
-  for (int i = 0; i < D_CO / 16; ++i) acc[i] = floatx4{0.f, 0.f, 0.f, 0.f};
+  for (int n = 0; n < NPAIR; ++n) acc[n] = floatx4{0.f, 0.f, 0.f, 0.f};
   __syncthreads();                                      // task table
 
   for (int tap0 = 0; tap0 < kk; tap0 += tps) {
@@ -488,14 +490,29 @@ __global__ __launch_bounds__(256) void k_dcn_lean(DcnArgs a, int tps, int pitch)
     const int kb = nt * Cg * SZ, kb64 = (kb + 63) & ~63;          // bytes of a slice row with data / as the MFMA loop walks it
     const int ntask = nt * units, e0 = tap0 * units;
     // ---- column tile: colT[pixel][tap-in-slice * Cg + c] ----
-    for (int t0 = wave; t0 < ntask; t0 += 4 * TB) {
+    // (whole-vector groups, one task in flight) the NEXT task's offsets / mask are loaded before this task's gathers: one memory round trip per
+    // task instead of two
+    float p_oh = 0.f, p_ow = 0.f, p_mm = 1.f;
+    auto load_offsets = [&](int t, float& oh_, float& ow_, float& mm_) {
+      const unsigned ent = __builtin_amdgcn_readfirstlane(task_tab[e0 + t]);
+      const int ti = ent >> 24, tj = (ent >> 16) & 255, un = ent & 0xffff;
+      const int ij = ti * a.kw + tj, dgi = (g * Cg + un * UNIT) / cpdg;
+      const int so = (dgi * 2 * kk + 2 * ij) * plane;
+      oh_ = DcnLoad<T>::scalar(off_rsrc, voff_p, so);
+      ow_ = DcnLoad<T>::scalar(off_rsrc, voff_p, so + plane);
+      mm_ = MASK ? DcnLoad<T>::scalar(msk_rsrc, voff_p, (dgi * kk + ij) * plane) : 1.f;
+    };
+    if constexpr (ONE && TB == 1) {
+      if (wave < ntask) load_offsets(wave, p_oh, p_ow, p_mm);
+    }
+    for (int t0 = wave; t0 < ntask; t0 += nwv * TB) {
       if constexpr (ONE) {
         float oh[TB], ow[TB], mm[TB], fi[TB], fj[TB];
         int csoff[TB], dst[TB];
         bool live[TB];
 #pragma unroll
         for (int u = 0; u < TB; ++u) {
-          const int t = t0 + 4 * u;
+          const int t = t0 + nwv * u;
           live[u] = t < ntask;                                     // wave-uniform
           const unsigned ent = __builtin_amdgcn_readfirstlane(task_tab[e0 + (live[u] ? t : 0)]);
           const int ti = ent >> 24, tj = (ent >> 16) & 255, un = ent & 0xffff;
@@ -504,10 +521,15 @@ __global__ __launch_bounds__(256) void k_dcn_lean(DcnArgs a, int tps, int pitch)
           fi[u] = (float)(ti * a.dh); fj[u] = (float)(tj * a.dw);
           csoff[u] = cim * SZ;
           dst[u] = ((ij - tap0) * Cg + un * UNIT) * SZ;
-          const int so = (dgi * 2 * kk + 2 * ij) * plane;
-          oh[u] = DcnLoad<T>::scalar(off_rsrc, voff_p, so);
-          ow[u] = DcnLoad<T>::scalar(off_rsrc, voff_p, so + plane);
-          mm[u] = MASK ? DcnLoad<T>::scalar(msk_rsrc, voff_p, (dgi * kk + ij) * plane) : 1.f;
+          if constexpr (TB == 1) {
+            oh[u] = p_oh; ow[u] = p_ow; mm[u] = p_mm;
+            if (t0 + nwv < ntask) load_offsets(t0 + nwv, p_oh, p_ow, p_mm);
+          } else {
+            const int so = (dgi * 2 * kk + 2 * ij) * plane;
+            oh[u] = DcnLoad<T>::scalar(off_rsrc, voff_p, so);
+            ow[u] = DcnLoad<T>::scalar(off_rsrc, voff_p, so + plane);
+            mm[u] = MASK ? DcnLoad<T>::scalar(msk_rsrc, voff_p, (dgi * kk + ij) * plane) : 1.f;
+          }
         }
         __builtin_amdgcn_sched_barrier(0);
         float wg[TB][4];
@@ -548,7 +570,7 @@ __global__ __launch_bounds__(256) void k_dcn_lean(DcnArgs a, int tps, int pitch)
         // one task at a time: NS groups x 4 corners are NS * 4 independent gathers already
         constexpr int SB = CPDG * SZ;                                // bytes of a group's channels at one corner
         constexpr int LW = SB == 6 ? 2 : SB / 4;                     // dwords per load: 6 bytes -> the aligned 8 around them, 12 -> 3, 24 -> 4 + 2
-        for (int t = t0; t < ntask && t < t0 + 4 * TB; t += 4) {
+        for (int t = t0; t < ntask && t < t0 + nwv * TB; t += nwv) {
           const unsigned ent = __builtin_amdgcn_readfirstlane(task_tab[e0 + t]);
           const int ti = ent >> 24, tj = (ent >> 16) & 255, un = ent & 0xffff;
           const int ij = ti * a.kw + tj, cim0 = g * Cg + un * UNIT;
@@ -651,44 +673,51 @@ __global__ __launch_bounds__(256) void k_dcn_lean(DcnArgs a, int tps, int pitch)
     }
     // ---- weight slice (16-byte pieces of the tap-major copy), zero in the rows past the block's and in the columns [kb, kb64) ----
     const int npc = kb64 / 16;
-    for (int idx = tid; idx < ntile * 16 * npc; idx += 256) {
+    for (int idx = tid; idx < ntile * 16 * npc; idx += nthr) {
       const int row = idx / npc, pc = idx - row * npc;
       *reinterpret_cast<frag*>(Wl + row * pitch + pc * 16) =
           (row < rows && pc * 16 < kb) ? load_frag<T>(wT + (size_t)row * Kg + tap0 * Cg + pc * VE) : Mma<T>::zero();
     }
     if (kb64 > kb) {
       const int nz = (kb64 - kb) / 16;
-      for (int idx = tid; idx < D_PIX * nz; idx += 256) {
+      for (int idx = tid; idx < D_PIX * nz; idx += nthr) {
         const int row = idx / nz, pc = idx - row * nz;
         *reinterpret_cast<frag*>(colT + row * pitch + kb + pc * 16) = Mma<T>::zero();
       }
     }
     __syncthreads();
+    const int npair = ntile * 4;
     for (int c = 0; c < kb64 / 64; ++c) {
-      const frag bf = *reinterpret_cast<const frag*>(colT + (wave * 16 + r16) * pitch + c * 64 + h * 16);
 #pragma unroll
-      for (int i = 0; i < D_CO / 16; ++i)
-        if (i < ntile) acc[i] = Mma<T>::mma(*reinterpret_cast<const frag*>(Wl + (i * 16 + r16) * pitch + c * 64 + h * 16), bf, acc[i]);
+      for (int n = 0; n < NPAIR; ++n) {
+        const int pr = wave + nwv * n;                     // wave-uniform
+        if (pr < npair) {
+          const int i = pr >> 2, j = pr & 3;
+          acc[n] = Mma<T>::mma(*reinterpret_cast<const frag*>(Wl + (i * 16 + r16) * pitch + c * 64 + h * 16),
+                               *reinterpret_cast<const frag*>(colT + (j * 16 + r16) * pitch + c * 64 + h * 16), acc[n]);
+        }
+      }
     }
     __syncthreads();
   }
 
   T* out = (T*)a.out + ((size_t)b * a.Cout + g * Cout_g + cb * D_CO) * HWo;
   const T* bias = a.bias ? (const T*)a.bias + g * Cout_g + cb * D_CO : nullptr;
-  const int po = blockIdx.x * D_PIX + wave * 16 + r16;
-  if (po < HWo) {
+  const T* bp = bias ? bias : wT;                   // branch-free bias loads (a branch per value is a memory round trip per value)
 #pragma unroll
-    for (int i = 0; i < D_CO / 16; ++i) {
-      if (i >= ntile) break;
-      float bv[4];                                  // branch-free loads (a branch per value is a memory round trip per value)
-      const T* bp = bias ? bias : wT;
+  for (int n = 0; n < NPAIR; ++n) {
+    const int pr = wave + nwv * n;
+    if (pr >= ntile * 4) break;
+    const int i = pr >> 2, j = pr & 3;
+    const int po = blockIdx.x * D_PIX + j * 16 + r16;
+    float bv[4];
 #pragma unroll
-      for (int r = 0; r < 4; ++r) bv[r] = (float)bp[min(i * 16 + 4 * h + r, rows - 1)];
+    for (int r = 0; r < 4; ++r) bv[r] = (float)bp[min(i * 16 + 4 * h + r, rows - 1)];
+    if (po >= HWo) continue;
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int co = i * 16 + 4 * h + r;
-        if (co < rows) out[(size_t)co * HWo + po] = (T)(acc[i][r] + (bias ? bv[r] : 0.f));
-      }
+    for (int r = 0; r < 4; ++r) {
+      const int co = i * 16 + 4 * h + r;
+      if (co < rows) out[(size_t)co * HWo + po] = (T)(acc[n][r] + (bias ? bv[r] : 0.f));
     }
   }
 }
@@ -725,16 +754,23 @@ int launch_dcn_lean(const DcnArgs& a, int mode, dim3 grid, hipStream_t s) {
   if (cfen_tune_dcn_tps() > 0) tps = std::min(tps, cfen_tune_dcn_tps());
   const int pitch = pitch_of(tps);
   const size_t lds = (size_t)(D_PIX + rows16) * pitch;
+  // four waves also where a slice's tasks would divide evenly over three (nine taps of a 24-channel map: 3 + 2 + 2 + 2): 119 us against 132 with
+  // three waves of three tasks -- the fourth wave's latency hiding is worth more than the balance (the kernel takes either: blockDim.x / 64)
+  const dim3 blk(256);
   // one task in flight per lane everywhere: 116 registers (four waves per SIMD) beat two or three tasks in flight at 170-250 (measured, section 4.3)
+  const bool small = rows16 <= 32;                     // <= 8 output tiles: three accumulators per wave (whatever the wave count)
+#define DCN_LEAN(CP) do { if (small) CFEN_LAUNCH((k_dcn_lean<T, CP, MASK, 1, 3>), grid, blk, lds, s, a, tps, pitch); \
+                          else CFEN_LAUNCH((k_dcn_lean<T, CP, MASK, 1, 11>), grid, blk, lds, s, a, tps, pitch); } while (0)
   switch (mode) {
-    case 1: CFEN_LAUNCH((k_dcn_lean<T, 0, MASK, 1>), grid, dim3(256), lds, s, a, tps, pitch); break;
-    case 3: CFEN_LAUNCH((k_dcn_lean<T, 3, MASK, 1>), grid, dim3(256), lds, s, a, tps, pitch); break;
-    case 6: CFEN_LAUNCH((k_dcn_lean<T, 6, MASK, 1>), grid, dim3(256), lds, s, a, tps, pitch); break;
+    case 1: DCN_LEAN(0); break;
+    case 3: DCN_LEAN(3); break;
+    case 6: DCN_LEAN(6); break;
     default:
-      if constexpr (SZ == 2) { CFEN_LAUNCH((k_dcn_lean<T, 12, MASK, 1>), grid, dim3(256), lds, s, a, tps, pitch); break; }
+      if constexpr (SZ == 2) { DCN_LEAN(12); break; }
       cfen_set_error("deform_conv: lean mode %d", mode);
       return CFEN_ERR_ARG;
   }
+#undef DCN_LEAN
   CFEN_CHECK_LAUNCH("deform_conv (lean)");
   return CFEN_OK;
 }
