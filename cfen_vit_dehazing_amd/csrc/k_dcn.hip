@@ -578,7 +578,7 @@ __global__ __launch_bounds__(256) void k_dcn_lean(DcnArgs a, int tps, int pitch)
           const float fi = (float)(ti * a.dh), fj = (float)(tj * a.dw);
           unsigned int res[12];                                        // the unit: 3 vectors of 16 bytes
           // groups per batch of gathers: all of them (3-channel groups: 32 gathers in flight at 160 registers measured 231 / 308 us on (8,24,256,256)
-          // dg 8, two batches of 16 at 120 registers 243 / 331)
+          // dg 8, two batches of 16 at 120 registers 243 / 331; with 28 KB slices 231 / 281 against 246 / 339)
           constexpr int SEGB = NS;
 #pragma unroll
           for (int s0 = 0; s0 < NS; s0 += SEGB) {
@@ -743,11 +743,12 @@ int launch_dcn_lean(const DcnArgs& a, int mode, dim3 grid, hipStream_t s) {
   constexpr int SZ = (int)sizeof(T);
   const int Cg = a.C / a.group, Cout_g = a.Cout / a.group, kk = a.kh * a.kw;
   const int rows16 = (std::min(D_CO, Cout_g) + 15) / 16 * 16;
-  // taps per slice: as many whole taps as fit the LDS budget, then evened out over the slices
+  // taps per slice: as many whole taps as fit the LDS budget, then evened out over the slices.  The budget is occupancy: nine taps of a 24-channel
+  // map in one slice (44 KB: three workgroups per CU) take 121 us, 5 + 4 taps (28 KB: four, the register limit) 107 us, 3 + 3 + 3 114 us
   auto pitch_of = [&](int t) { return ((t * Cg * SZ + 63) & ~63) + 32; };   // 32 (mod 64) bytes: conflict-free 16-byte reads and writes
   int tmax = 0;
   for (int t = 1; t <= kk; ++t)
-    if ((size_t)(D_PIX + rows16) * pitch_of(t) <= 60 * 1024) tmax = t;
+    if ((size_t)(D_PIX + rows16) * pitch_of(t) <= (t == 1 ? 60 : 38) * 1024) tmax = t;   // four workgroups per CU (a one-tap slice may take up to 60 KB)
   if (!tmax) return DCN_FALLBACK;                      // a one-tap slice does not fit: the caller falls back to k_dcn_nhwc
   const int nsl = (kk + tmax - 1) / tmax;
   int tps = (kk + nsl - 1) / nsl;
