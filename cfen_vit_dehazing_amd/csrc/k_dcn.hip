@@ -352,12 +352,15 @@ __global__ __launch_bounds__(256) void k_dcn_nhwc(DcnArgs a) {
 // around the instruction count:
 //   * a lane owns a (pixel, tap, UNIT of 3 channel vectors) task: offsets / mask loaded once, corners set up once (per-axis weights with
 //     the border rules folded in, v_med3 clamps, 24-bit multiplies), 12 gathers; which (tap, unit) a wave works on comes from a table
-//     in LDS (no divisions in the loop), TB tasks in flight per lane;
+//     in LDS (no divisions in the loop); ONE task in flight per lane (TB = 1: 96-108 registers, four waves per SIMD, beat two or three in
+//     flight at 170-250), the next task's offsets loaded before this task's gathers;
 //   * every global access is a buffer load: 32-bit byte offset in a VGPR, the tap's plane / the unit's channel offset in an SGPR;
 //   * fp16 is interpolated with packed fp16 FMAs (v_pk_fma_f16: 2 channels per instruction; the reference's half path computes its
 //     bilinear sum in half as well, deform_conv_cuda_kernel.cu:83-114 with scalar_t = at::Half); fp32 stays fp32;
-//   * a K slice is `tps` whole taps (all nine for 24 channels: one gather phase, two barriers per workgroup), every wave contracts its
-//     own 16 pixels with all the weight rows;
+//   * a K slice is `tps` whole taps sized so that four workgroups fit a CU (24 channels: 5 + 4 taps), the 16 x 16 output tiles are dealt to
+//     the waves as (row tile, pixel tile) pairs;
+//   * occupancy is what moved this kernel after the instruction count: every step above that raised the waves per CU gained, nothing that
+//     only deepened a lane's memory-level parallelism did (DCN forward round 3);
 //   * deformable groups narrower than a vector (C/dg = 3, 6, 12: the generator's dg = 8 layers): the task walks the UNIT / CPDG groups of
 //     its unit, each with its own offsets, gathers CPDG channels per corner in ONE load (3 fp16 channels: the 4-byte aligned 8 bytes around
 //     them) and still writes whole 16-byte vectors into the column tile -- k_dcn_nhwc re-gathers a full vector per group.
