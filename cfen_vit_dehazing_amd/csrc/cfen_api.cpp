@@ -283,7 +283,7 @@ int cfen_tune(const char* key, int value) {
     return CFEN_OK;
   }
   if (!strcmp(key, "attn.hm_pair")) {
-    cfen_tune_attn_hm_pair() = value != 0;
+    cfen_tune_attn_hm_pair() = value;
     return CFEN_OK;
   }
   if (!strcmp(key, "net.head_fused")) {

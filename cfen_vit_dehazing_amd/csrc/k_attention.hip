@@ -437,9 +437,9 @@ __global__ __launch_bounds__(256) void k_attention_hm(PtrG<const half_t> QKVg, P
 //     denominator row of O^T, V feature 24 = 1, is rescaled with the rest);
 //   * a wave works on TWO query tiles at a time, so every K fragment and every transposed V fragment read from LDS feeds two MFMAs;
 //   * 8 waves: two per SIMD.
-template <int NKT, int NKB>
-__global__ __launch_bounds__(512) void k_attention_hm_long(PtrG<const half_t> QKVg, PtrG<half_t> Og, int D, int heads, float scale_log2, int nblk) {
-  constexpr int S = NKT * 16, DH = 24, KP = 64, NW = 8, NT = NW * 64;
+template <int NKT, int NKB, int NW = 8>
+__global__ __launch_bounds__(NW * 64) void k_attention_hm_long(PtrG<const half_t> QKVg, PtrG<half_t> Og, int D, int heads, float scale_log2, int nblk) {
+  constexpr int S = NKT * 16, DH = 24, KP = 64, NT = NW * 64;
   static_assert(NKT % NKB == 0 && NKB % 2 == 0 && 2 * S * KP <= 160 * 1024 && NKT % (2 * NW) == 0, "geometry");
   __shared__ __attribute__((aligned(16))) unsigned char lds[2 * S * KP];
   unsigned char* const Kl = lds;
@@ -728,7 +728,7 @@ int cfen_attention_impl_g(int dtype, int ng, const void* const* qkv, void* const
   cfen_set_error("attention: unknown dtype %d", dtype);
   return CFEN_ERR_ARG;
 }
-int& cfen_tune_attn_hm_pair() {   // 1: 256-token windows run on k_attention_hm_long<16, 16> (two query tiles per K / V fragment, 8 waves)
+int& cfen_tune_attn_hm_pair() {   // 1: 256-token windows run on k_attention_hm_long<16, 16> (two query tiles per K / V fragment, 8 waves); 2: 1024-token windows on 8 waves instead of 16
   static int v = 0;
   return v;
 }
@@ -746,9 +746,14 @@ int cfen_attention_hm_impl_g(int dtype, int ng, const void* const* qkv, void* co
   }
   const float scale_log2 = 1.4426950408889634f / sqrtf((float)dh);
   const dim3 grid(cfen_grid8((long long)nseq * heads), 1, ng);
-  if (S == 1024)
+  // S = 1024: K / V take 128 KB of LDS, one workgroup per CU -- so it has 16 waves of 128 registers (key blocks of 128), not 8 of 208 (blocks of
+  // 256): a wave issues a vector instruction every ~10 cycles, the softmax needs four waves per SIMD; 1024 x 1024 images, batch 4:
+  // 6.29 -> 6.17 ms ("attn.hm_pair" = 2: the 8-wave form)
+  if (S == 1024 && cfen_tune_attn_hm_pair() != 2)
+    CFEN_LAUNCH((k_attention_hm_long<64, 8, 16>), grid, dim3(1024), 0, s, qg, og, heads * dh, heads, scale_log2, nseq * heads);
+  else if (S == 1024)
     CFEN_LAUNCH((k_attention_hm_long<64, 16>), grid, dim3(512), 0, s, qg, og, heads * dh, heads, scale_log2, nseq * heads);
-  else if (S == 256 && cfen_tune_attn_hm_pair())
+  else if (S == 256 && cfen_tune_attn_hm_pair() == 1)
     CFEN_LAUNCH((k_attention_hm_long<16, 16>), grid, dim3(512), 0, s, qg, og, heads * dh, heads, scale_log2, nseq * heads);
   else if (S == 256)
     CFEN_LAUNCH((k_attention_hm<16>), grid, dim3(256), 0, s, qg, og, heads * dh, heads, scale_log2, nseq * heads);
