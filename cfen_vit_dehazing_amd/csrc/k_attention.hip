@@ -754,7 +754,7 @@ int cfen_attention_hm_impl_g(int dtype, int ng, const void* const* qkv, void* co
   else if (S == 1024)
     CFEN_LAUNCH((k_attention_hm_long<64, 16>), grid, dim3(512), 0, s, qg, og, heads * dh, heads, scale_log2, nseq * heads);
   else if (S == 256 && cfen_tune_attn_hm_pair() == 1)
-    CFEN_LAUNCH((k_attention_hm_long<16, 16>), grid, dim3(512), 0, s, qg, og, heads * dh, heads, scale_log2, nseq * heads);
+    CFEN_LAUNCH((k_attention_hm_long<16, 8>), grid, dim3(512), 0, s, qg, og, heads * dh, heads, scale_log2, nseq * heads);
   else if (S == 256)
     CFEN_LAUNCH((k_attention_hm<16>), grid, dim3(256), 0, s, qg, og, heads * dh, heads, scale_log2, nseq * heads);
   else

@@ -206,9 +206,9 @@ def test_attention_head_major_layout(nseq, S, heads):
     qkv[900 if S > 256 else 200 % S, heads * 24:heads * 24 + 24] = qkv[3, :24] * 25
     got = ops.attention_head_major(to_head_major(qkv, nseq, S, heads).to(dev()), nseq, S, heads)
     close(got, attn_ref(qkv, nseq, S, heads), tol(torch.float16, 3))
-    if S == 1024:   # the 8-wave form of the long-window kernel (key blocks of 256) beside the default 16-wave one (blocks of 128)
-        try:
-            ops.tune("attn.hm_pair", 2)
+    if S in (256, 1024):   # S = 1024: the 8-wave form of the long-window kernel (key blocks of 256) beside the default 16-wave one (blocks of 128);
+        try:               # S = 256: the long-window kernel (two query tiles per K / V fragment) instead of k_attention_hm
+            ops.tune("attn.hm_pair", 2 if S == 1024 else 1)
             got8 = ops.attention_head_major(to_head_major(qkv, nseq, S, heads).to(dev()), nseq, S, heads)
         finally:
             ops.tune("attn.hm_pair", 0)
