@@ -7,7 +7,7 @@
 //   norm2 + linear1/ReLU/linear2 + residual, mlp_head + residual       (v3:1387-1389, 1173)
 //   fold + Join2x2                                                     (v3:1176-1186, 1046-1056)
 //
-// A workgroup of 8 waves owns ONE window; wave w owns its tokens 32w .. 32w+31 for the whole chain.  As in k_mlp2 / k_embed_qkv2 the
+// A workgroup of 16 waves (round 3; 8 in round 2) owns ONE window; wave w owns its tokens 16w .. 16w+15 for the whole chain.  As in k_mlp2 / k_embed_qkv2 the
 // residual stream of a token tile lives in fp32 MFMA accumulators (rows = features, columns = tokens), an accumulator tile pair is the
 // B operand of the next GEMM, and every weight matrix streams through an LDS ring by LDS-DMA in 32-row chunks (one raw s_barrier per
 // chunk).  Round 3: the weights come as ONE stream of 1 KiB MFMA A fragments in consumption order (packing.pack_lvit_window, as
@@ -58,8 +58,8 @@ CFEN_DEV half8 lv_pack(floatx4 a, floatx4 b) {
   return f;
 }
 
-// ND = D / 16 (6); NW waves x TM token tiles of 16 = the 256 tokens of one window (8 x 2 at two waves per SIMD, or 4 x 4 with one wave
-// per SIMD and the whole 512-register file); 4 heads of 24
+// ND = D / 16 (6); NW waves x TM token tiles of 16 = the 256 tokens of one window (16 x 1 at four waves per SIMD: the default; 8 x 2 at two;
+// 4 x 4 with one wave per SIMD and the whole 512-register file); 4 heads of 24
 template <int ND, int NW, int TM>
 __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(NW / 4, NW / 4))) void k_lvit_window(Grouped<LvitArgs> ga) {
   typedef half_t T;
@@ -406,8 +406,10 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(NW / 4,
 
 }  // namespace
 
-int& cfen_tune_lvit_shape() {   // 0: 8 waves x 2 token tiles (two waves per SIMD); 1: 4 waves x 4 token tiles (one wave per SIMD, 512 registers)
-  static int v = 0;
+int& cfen_tune_lvit_shape() {   // 2 (default): 16 waves x 1 token tile (four waves per SIMD, 128 registers, no spills: 2.858 -> 2.83 ms -- a wave issues a vector
+                                // instruction every ~10 cycles and two thirds of this kernel are vector-instruction bound); 0: 8 waves x 2 token tiles;
+                                // 1: 4 waves x 4 token tiles (one wave per SIMD, 512 registers)
+  static int v = 2;
   return v;
 }
 
@@ -435,7 +437,9 @@ int cfen_lvit_window_impl_g(int dtype, int ng, const LvitArgs* ap, hipStream_t s
   }
   const long long blocks = (long long)ap[0].B * (ap[0].H / ap[0].ws) * (ap[0].W / ap[0].ws);
   CFEN_CHECK_ARG(blocks > 0 && blocks < (1ll << 31), "lvit_window: bad grid");
-  if (cfen_tune_lvit_shape() == 1)
+  if (cfen_tune_lvit_shape() == 2)
+    CFEN_LAUNCH((k_lvit_window<6, 16, 1>), dim3((unsigned)blocks, 1, ng), dim3(1024), 0, s, ga);
+  else if (cfen_tune_lvit_shape() == 1)
     CFEN_LAUNCH((k_lvit_window<6, 4, 4>), dim3((unsigned)blocks, 1, ng), dim3(256), 0, s, ga);
   else
     CFEN_LAUNCH((k_lvit_window<6, 8, 2>), dim3((unsigned)blocks, 1, ng), dim3(512), 0, s, ga);

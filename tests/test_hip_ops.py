@@ -814,6 +814,14 @@ def test_lvit_window_block_against_oracle_and_unfused_chain(B, H, W):
     fmap = ops.to_nhwc(x).to(d)
     got = ops.from_nhwc(ops.lvit_window(fmap, 24, 32, 2, pk, g.name, g.hidden), 24)
     close(got, want, tol(dt, 12), "fused window block vs fp64")
+    # the three workgroup shapes (16 waves x 1 token tile: the default; 8 x 2; 4 x 4 on 512 registers) do the same arithmetic per token
+    try:
+        for shape in (0, 1):
+            ops.tune("lvit.shape", shape)
+            other = ops.from_nhwc(ops.lvit_window(fmap, 24, 32, 2, pk, g.name, g.hidden), 24)
+            assert torch.equal(other, got), "lvit.shape %d differs from the default shape" % shape
+    finally:
+        ops.tune("lvit.shape", 2)
     # the unfused chain (embed_qkv -> attention -> mlp with projection prologue + fold)
     n = g.name
     x1, qkv = ops.embed_qkv(fmap, 24, 32, 2, pk[n + ".embed.wk"], pk[n + ".embed.b"], pk[n + ".pos"], pk[n + ".ln1.g"], pk[n + ".ln1.b"],
