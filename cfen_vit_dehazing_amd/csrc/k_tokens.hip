@@ -152,9 +152,11 @@ __global__ __launch_bounds__(256) void k_upsample4(PtrG<const T> smallg, PtrG<T>
 #pragma unroll
         for (int e = 0; e < EPL; ++e) row[a][e] = 0.f;
 #pragma unroll
-        for (int bb = 0; bb < 3; ++bb)
+        for (int bb = 0; bb < 3; ++bb) {
+          if (wx[bb] == 0.f) continue;       // compile-time after unrolling: the outer columns / rows have two taps, not three (the compiler may not drop 0 * x)
 #pragma unroll
           for (int e = 0; e < EPL; ++e) row[a][e] += wx[bb] * p[a][bb][e];
+        }
       }
 #pragma unroll
       for (int ry = 0; ry < 4; ++ry) {
@@ -163,9 +165,11 @@ __global__ __launch_bounds__(256) void k_upsample4(PtrG<const T> smallg, PtrG<T>
 #pragma unroll
         for (int e = 0; e < EPL; ++e) acc[e] = 0.f;
 #pragma unroll
-        for (int a = 0; a < 3; ++a)
+        for (int a = 0; a < 3; ++a) {
+          if (wy[a] == 0.f) continue;
 #pragma unroll
           for (int e = 0; e < EPL; ++e) acc[e] += wy[a] * row[a][e];
+        }
         Vec16<T>::store(out + (((size_t)b * H + 4 * ky + ry) * W + 4 * kx + rx) * cs_out + c, acc);
       }
     }
