@@ -125,6 +125,10 @@ __global__ __launch_bounds__(256) void k_unpatchify(PtrG<const T> tokg, PtrG<T> 
 template <typename T>
 __global__ __launch_bounds__(256) void k_upsample4(PtrG<const T> smallg, PtrG<T> outg, int B, int h, int w, int C,
                                                    int cs_in, int cs_out, long long nvec) {
+  // One thread = (input pixel, output column rx of its 4 x 4 block, channel vector), channel vector fastest, then rx: the lanes of a wave
+  // write (4 kx + rx) * cs + c = CONSECUTIVE bytes of an output row (round 2 had a thread write its whole 4 x 4 block: 16-byte pieces 4
+  // pixels apart, a quarter of every line per store instruction; the map writes are what this kernel waits for).  The 3 x 3 neighbourhood is
+  // loaded by the four rx threads of a pixel (same addresses: L1), the arithmetic per output value and its order are unchanged.
   const T* __restrict__ small = smallg.p[blockIdx.z];
   T* __restrict__ out = outg.p[blockIdx.z];
   constexpr int EPL = Vec16<T>::N;
@@ -133,7 +137,9 @@ __global__ __launch_bounds__(256) void k_upsample4(PtrG<const T> smallg, PtrG<T>
   const float w0 = 0.375f, w1 = 0.1875f, w2 = 0.0625f;
   for (long long idx = (long long)blockIdx.x * 256 + threadIdx.x; idx < nvec; idx += (long long)gridDim.x * 256) {
     const int c = (int)(idx % cv) * EPL;
-    const long long pix = idx / cv;
+    const long long t = idx / cv;
+    const int rx = (int)(t & 3);
+    const long long pix = t >> 2;
     const int kx = (int)(pix % w), ky = (int)((pix / w) % h), b = (int)(pix / ((long long)w * h));
     const int xs[3] = {max(kx - 1, 0), kx, min(kx + 1, w - 1)};
     const int ys[3] = {max(ky - 1, 0), ky, min(ky + 1, h - 1)};
@@ -143,35 +149,30 @@ __global__ __launch_bounds__(256) void k_upsample4(PtrG<const T> smallg, PtrG<T>
     for (int a = 0; a < 3; ++a)
 #pragma unroll
       for (int bb = 0; bb < 3; ++bb) Vec16<T>::load(base + ((size_t)ys[a] * w + xs[bb]) * cs_in, p[a][bb]);
+    const float wx[3] = {rx == 0 ? w0 : rx == 1 ? w1 : rx == 2 ? w2 : 0.f, rx == 0 || rx == 3 ? 0.625f : 0.75f, rx == 3 ? w0 : rx == 2 ? w1 : rx == 1 ? w2 : 0.f};
+    float row[3][EPL];     // horizontal pass for output column 4 kx + rx, one row of the neighbourhood at a time
 #pragma unroll
-    for (int rx = 0; rx < 4; ++rx) {
-      const float wx[3] = {rx == 0 ? w0 : rx == 1 ? w1 : rx == 2 ? w2 : 0.f, rx == 0 || rx == 3 ? 0.625f : 0.75f, rx == 3 ? w0 : rx == 2 ? w1 : rx == 1 ? w2 : 0.f};
-      float row[3][EPL];     // horizontal pass for output column 4 kx + rx, one row of the neighbourhood at a time
+    for (int a = 0; a < 3; ++a) {
+#pragma unroll
+      for (int e = 0; e < EPL; ++e) row[a][e] = 0.f;
+#pragma unroll
+      for (int bb = 0; bb < 3; ++bb)
+#pragma unroll
+        for (int e = 0; e < EPL; ++e) row[a][e] += wx[bb] * p[a][bb][e];      // (a zero weight adds +0: the value a two-tap sum has)
+    }
+#pragma unroll
+    for (int ry = 0; ry < 4; ++ry) {
+      const float wy[3] = {ry == 0 ? w0 : ry == 1 ? w1 : ry == 2 ? w2 : 0.f, ry == 0 || ry == 3 ? 0.625f : 0.75f, ry == 3 ? w0 : ry == 2 ? w1 : ry == 1 ? w2 : 0.f};
+      float acc[EPL];
+#pragma unroll
+      for (int e = 0; e < EPL; ++e) acc[e] = 0.f;
 #pragma unroll
       for (int a = 0; a < 3; ++a) {
+        if (wy[a] == 0.f) continue;       // compile-time after unrolling
 #pragma unroll
-        for (int e = 0; e < EPL; ++e) row[a][e] = 0.f;
-#pragma unroll
-        for (int bb = 0; bb < 3; ++bb) {
-          if (wx[bb] == 0.f) continue;       // compile-time after unrolling: the outer columns / rows have two taps, not three (the compiler may not drop 0 * x)
-#pragma unroll
-          for (int e = 0; e < EPL; ++e) row[a][e] += wx[bb] * p[a][bb][e];
-        }
+        for (int e = 0; e < EPL; ++e) acc[e] += wy[a] * row[a][e];
       }
-#pragma unroll
-      for (int ry = 0; ry < 4; ++ry) {
-        const float wy[3] = {ry == 0 ? w0 : ry == 1 ? w1 : ry == 2 ? w2 : 0.f, ry == 0 || ry == 3 ? 0.625f : 0.75f, ry == 3 ? w0 : ry == 2 ? w1 : ry == 1 ? w2 : 0.f};
-        float acc[EPL];
-#pragma unroll
-        for (int e = 0; e < EPL; ++e) acc[e] = 0.f;
-#pragma unroll
-        for (int a = 0; a < 3; ++a) {
-          if (wy[a] == 0.f) continue;
-#pragma unroll
-          for (int e = 0; e < EPL; ++e) acc[e] += wy[a] * row[a][e];
-        }
-        Vec16<T>::store(out + (((size_t)b * H + 4 * ky + ry) * W + 4 * kx + rx) * cs_out + c, acc);
-      }
+      Vec16<T>::store(out + (((size_t)b * H + 4 * ky + ry) * W + 4 * kx + rx) * cs_out + c, acc);
     }
   }
 }
@@ -268,7 +269,7 @@ int run_upsample4(int ng, const void* const* small, void* const* out, int B, int
     CFEN_CHECK_ARG(small[k] && out[k] && cfen_aligned16(small[k]) && cfen_aligned16(out[k]), "upsample4: pointers must be non-null and 16-byte aligned");
     src.p[k] = (const T*)small[k]; dst.p[k] = (T*)out[k];
   }
-  const long long nvec = (long long)B * h * w * (C / EPL);   // one thread per input pixel and channel vector
+  const long long nvec = (long long)B * h * w * 4 * (C / EPL);   // one thread per input pixel, output column of its 4 x 4 block and channel vector
   CFEN_LAUNCH(k_upsample4<T>, dim3(grid_for(nvec), 1, ng), dim3(256), 0, s, src, dst, B, h, w, C, cs_in, cs_out, nvec);
   CFEN_CHECK_LAUNCH("upsample4");
   return CFEN_OK;
