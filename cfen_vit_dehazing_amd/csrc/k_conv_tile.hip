@@ -229,7 +229,11 @@ __global__ __launch_bounds__(256) void k_convT_tile(Grouped<ConvDesc> dg, int nb
   constexpr int NIT = (NPIECE + 255) / 256;
   constexpr int KPAD = 4 * CPT * KC;
   typedef typename Mma<T>::frag frag;
-  __shared__ __attribute__((aligned(16))) unsigned char lds[ROWS * RB];
+  // the halo tile, then (behind a barrier) the output tile: 2 RY rows x 2 TW pixels of at most TN * 16 channels, from where the workgroup stores whole
+  // rows in 16-byte pieces -- a wave's own results are every second pixel of a row (one parity phase), 8 bytes a lane: a quarter to a half of each
+  // line per store instruction
+  constexpr int OUTB = PIXB == 64 ? 2 * RY * 2 * TW * TN * 16 * SZ : 0;     // (the 64-byte-pixel variant only, see the epilogue)
+  __shared__ __attribute__((aligned(16))) unsigned char lds[ROWS * RB > OUTB ? ROWS * RB : OUTB];
 
   constexpr bool MT = PIXB == 128;               // multi-tile only in the 128-byte variant (us_conv_d02: 54.7 -> 47.0 us with two tiles); the loop
                                                  // costs registers: the 192-byte variant drops to one wave per SIMD with it (44 -> 58 us), the
@@ -315,23 +319,55 @@ __global__ __launch_bounds__(256) void k_convT_tile(Grouped<ConvDesc> dg, int nb
   }
 
   const int Hout = 2 * d.Hin, Wout = 2 * d.Win;
-#pragma unroll
-  for (int i = 0; i < TN; ++i) {
-    const int n = i * 16 + 4 * h;
-    if (n >= d.cs_out) continue;
-    const floatx4 sc = *reinterpret_cast<const floatx4*>(d.scale + n), sh = *reinterpret_cast<const floatx4*>(d.shift + n);
-#pragma unroll
-    for (int r = 0; r < RY; ++r)
-#pragma unroll
-      for (int xq = 0; xq < NX; ++xq) {
-        const int oy = 2 * (y0 + r) + py, ox = 2 * (x0 + xq * 16 + r16) + px;
-        floatx4 v = acc[r][xq][i] * sc + sh;
-        if (d.act == 1) {
-#pragma unroll
-          for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
+  if constexpr (PIXB == 64) {
+    const int opx = d.cs_out * SZ, orow = 2 * TW * opx;       // bytes of an output pixel / of a tile row
+    __syncthreads();                                          // every wave is done reading the halo
+  #pragma unroll
+    for (int i = 0; i < TN; ++i) {
+      const int n = i * 16 + 4 * h;
+      if (n >= d.cs_out) continue;
+      const floatx4 sc = *reinterpret_cast<const floatx4*>(d.scale + n), sh = *reinterpret_cast<const floatx4*>(d.shift + n);
+  #pragma unroll
+      for (int r = 0; r < RY; ++r)
+  #pragma unroll
+        for (int xq = 0; xq < NX; ++xq) {
+          floatx4 v = acc[r][xq][i] * sc + sh;
+          if (d.act == 1) {
+  #pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
+          }
+          store4<T>(reinterpret_cast<T*>(lds + (2 * r + py) * orow + (2 * (xq * 16 + r16) + px) * opx) + n, v);
         }
-        store4<T>((T*)d.out + (((size_t)b * Hout + oy) * Wout + ox) * d.cs_out + n, v);
+    }
+    __syncthreads();
+    {
+      const int ppr = orow / 16;                              // 16-byte pieces per tile row
+      unsigned char* gout = (unsigned char*)d.out + (((size_t)b * Hout + 2 * y0) * Wout + 2 * x0) * opx;
+      for (int idx = tid; idx < 2 * RY * ppr; idx += 256) {
+        const int row = idx / ppr, pc = idx - row * ppr;
+        *reinterpret_cast<frag*>(gout + (size_t)row * Wout * opx + pc * 16) = *reinterpret_cast<const frag*>(lds + row * orow + pc * 16);
       }
+    }
+  } else {
+    // (the 128- / 192-byte variants keep the direct stores: staged they measured 46 -> 47.6 and 43 -> 43.1 us, the 64-byte one 85.7 -> 79.6)
+#pragma unroll
+    for (int i = 0; i < TN; ++i) {
+      const int n = i * 16 + 4 * h;
+      if (n >= d.cs_out) continue;
+      const floatx4 sc = *reinterpret_cast<const floatx4*>(d.scale + n), sh = *reinterpret_cast<const floatx4*>(d.shift + n);
+#pragma unroll
+      for (int r = 0; r < RY; ++r)
+#pragma unroll
+        for (int xq = 0; xq < NX; ++xq) {
+          const int oy = 2 * (y0 + r) + py, ox = 2 * (x0 + xq * 16 + r16) + px;
+          floatx4 v = acc[r][xq][i] * sc + sh;
+          if (d.act == 1) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
+          }
+          store4<T>((T*)d.out + (((size_t)b * Hout + oy) * Wout + ox) * d.cs_out + n, v);
+        }
+    }
   }
   }   // tiles of this workgroup
 }
