@@ -52,6 +52,17 @@ class LvitArgsC(ctypes.Structure):
                [("hidden", ctypes.c_int32), ("eps", c_float)]
 
 
+class ChainPhaseC(ctypes.Structure):
+    _fields_ = [(n, c_void_p) for n in ("x", "w_stream", "bias", "lnf_s", "residual", "pos", "y")] + \
+               [(n, ctypes.c_int32) for n in ("ldx", "ldr", "ldy", "period", "N", "K", "relu", "nsplit", "fold")]
+
+
+class ChainArgsC(ctypes.Structure):
+    _fields_ = [("phase", ChainPhaseC * 5), ("nphases", ctypes.c_int32), ("M", ctypes.c_int32)] + \
+               [(n, ctypes.c_int32) for n in ("fold_H", "fold_W", "fold_cs", "fold_C", "fold_p")] + \
+               [("sync_ws", c_void_p), ("sync_ws_bytes", c_size_t)]
+
+
 # every symbol include/cfen_hip.h declares: (restype, argtypes)
 _I = c_int
 _P = c_void_p
@@ -76,9 +87,11 @@ SIGNATURES = {
                                     ctypes.POINTER(ctypes.c_double)]),
     "cfen_net_stage": (_I, [_P, c_char_p, ctypes.POINTER(_P)] + [ctypes.POINTER(ctypes.c_int32)] * 4),
     "cfen_net_flops_per_image": (ctypes.c_double, [_P]),
+    "cfen_net_chain_error_words": (_I, [_P, ctypes.POINTER(_P), _I]),
     "cfen_gemm_nt": (_I, [_I, _P, _I, _P, _I, _P, _P, _I, _P, _I, _P, _I, _I, _I, _I, _I, _P]),
     "cfen_gemm_ln": (_I, [_I, _P, _I, _P, _I, _P, _P, _P, _I, _I, _I, _I, _I, ctypes.c_float, _P]),
     "cfen_gemm_splitk": (_I, [_I, _P, _I, _P, _I, _P, _P, _P, _I, _P, _I, _I, _I, _I, _I, _I, _P, c_size_t, _P]),
+    "cfen_gemm_chain": (_I, [_I, ctypes.POINTER(ChainArgsC), _I, _P]),
     "cfen_embed_gather": (_I, [_I, _P, _I, _I, _I, _I, _I, _I, _I, _P, _I, _P, _P, _I, _P, _I, _P]),
     "cfen_u8hwc_to_nhwc": (_I, [_I, _P, _P, _I, _I, _I, _I, _P]),
     "cfen_tensor2im_u8": (_I, [_P, _P, _I, _I, _I, _P]),

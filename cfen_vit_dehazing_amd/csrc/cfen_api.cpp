@@ -79,6 +79,24 @@ int cfen_gemm_splitk(int dtype, const void* X, int ldx, const void* W, int ldw, 
   return cfen_gemm_impl_g(dtype, 1, &q, ldx, ldw, ldr, 1, ldy, M, N, K, relu, nullptr, (hipStream_t)stream, &ws, scratch_bytes, nullptr, nsplit);
 }
 
+int cfen_gemm_chain(int dtype, const cfen_chain_args* a, int team, void* stream) {
+  CFEN_CHECK_ARG(a && a->sync_ws && a->sync_ws_bytes >= 8192 && cfen_aligned16(a->sync_ws), "gemm_chain: needs >= 8192 aligned bytes of synchronisation words");
+  CFEN_CHECK_ARG(a->nphases >= 1 && a->nphases <= 5, "gemm_chain: 1..5 phases");
+  CfenChainArgs c{};
+  for (int p = 0; p < a->nphases; ++p) {
+    const cfen_chain_phase& q = a->phase[p];
+    c.ph[p] = CfenChainPhase{q.x, q.w_stream, q.bias, q.lnf_s, q.residual, q.pos, q.y, q.ldx, q.ldr, q.ldy, q.period, q.N, q.K, q.relu, q.nsplit, q.fold};
+  }
+  c.nph = a->nphases; c.M = a->M;
+  c.fH = a->fold_H; c.fW = a->fold_W; c.fcs = a->fold_cs; c.fC = a->fold_C; c.fp = a->fold_p;
+  unsigned* w = (unsigned*)a->sync_ws;
+  c.bar = w; c.err = w + 1; c.cnt = w + 1024; c.ncnt = 1024;
+  c.part = (float*)((unsigned char*)a->sync_ws + 8192); c.part_bytes = a->sync_ws_bytes - 8192;
+  int rc = cfen_zero_async(a->sync_ws, 8192, (hipStream_t)stream);   // barrier word, error word, arrival counters
+  if (rc) return rc;
+  return cfen_gvit_chain_impl_g(dtype, 1, &c, team, (hipStream_t)stream);
+}
+
 int cfen_layernorm(int dtype, const void* X, void* Y, const float* gamma, const float* beta, int M, int D, float eps, void* stream) {
   CFEN_CHECK_ARG(gamma && beta, "layernorm: gamma/beta required");
   return cfen_layernorm_impl(dtype, X, Y, gamma, beta, M, D, eps, (hipStream_t)stream);
@@ -234,6 +252,7 @@ int cfen_tune(const char* key, int value) {
     cfen_tune_gemm_splitk_stages() = value;
     return CFEN_OK;
   }
+  if (!strcmp(key, "gemm.splitk_release")) { cfen_tune_gemm_splitk_release() = value != 0; return CFEN_OK; }
   if (!strcmp(key, "gemm.splitk")) {
     cfen_tune_gemm_splitk() = value != 0;
     return CFEN_OK;
@@ -304,6 +323,16 @@ int cfen_tune(const char* key, int value) {
     cfen_tune_stream_mlp() = value;
     return CFEN_OK;
   }
+  if (!strcmp(key, "net.gvit_dummy_wgs")) { cfen_tune_gvit_dummy_wgs() = value; return CFEN_OK; }
+  if (!strcmp(key, "net.gvit_dummy_us")) { cfen_tune_gvit_dummy_us() = value; return CFEN_OK; }
+  if (!strcmp(key, "net.gvit_dummy_stream")) { cfen_tune_gvit_dummy_stream() = value; return CFEN_OK; }
+  if (!strcmp(key, "gvit.team")) {
+    CFEN_CHECK_ARG(value >= 1 && value <= 85, "tune: gvit.team is 1 .. 85 workgroups per block (three blocks share the chip)");
+    cfen_tune_gvit_team() = value;
+    return CFEN_OK;
+  }
+  if (!strcmp(key, "gvit.debug")) { cfen_tune_gvit_debug() = value; return CFEN_OK; }
+  if (!strcmp(key, "net.gvit_chain")) { cfen_tune_gvit_chain() = value != 0; return CFEN_OK; }
   if (!strcmp(key, "net.embed_gather")) {
     cfen_tune_embed_gather() = value != 0;
     return CFEN_OK;

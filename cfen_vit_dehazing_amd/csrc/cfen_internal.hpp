@@ -126,3 +126,29 @@ int& cfen_tune_stream_front();      // k_front3 for the D = 384 LViT blocks: 0 n
 int& cfen_tune_stream_mlp192();     // 1: LViT level 2 (D = 192) on k_mlp3 instead of k_mlp2; 0 (default, faster inside the forward: see cfen_net.cpp) ("net.stream_mlp192")
 int& cfen_tune_stream_mlp();        // k_mlp3 for the D = 384 LViT blocks: 0 never, 1 (default) grouped decoder launches, 2 always ("net.stream_mlp")
 int& cfen_tune_embed_lds();        // k_embed_qkv weights through LDS: bit 0 for D = 96, bit 1 for D = 192 ("embed.lds")
+// what-if probe: a launch that holds `wgs` x `ng` CUs for `usec` microseconds ("net.gvit_dummy_*": CU-time experiments, results invalid)
+int cfen_occupy_impl(int wgs, int ng, int usec, int do_stream, const void* src, size_t src_bytes, void* sink, hipStream_t s);
+int& cfen_tune_gvit_dummy_wgs();
+int& cfen_tune_gvit_dummy_us();
+int& cfen_tune_gvit_dummy_stream();
+// Persistent GEMM chain (k_gvit.hip): up to 5 dependent GEMM phases Y = epi(X W^T) run by ONE launch of `team` workgroups per problem that
+// meet at a grid barrier between phases.  W: fragment streams (packing.pack_stream_tiles).  fp16.
+struct CfenChainPhase {
+  const void* X; const void* W; const float* bias; const float* lnf_s; const void* R; const void* P; void* Y;
+  int ldx, ldr, ldy, period, N, K, relu, nsplit, fold;
+};
+struct CfenChainArgs {
+  CfenChainPhase ph[5];
+  int nph, M;
+  int fH, fW, fcs, fC, fp;     // fold geometry of the phases with fold = 1 (Y = NHWC map of fH x fW pixels, fp x fp patches of fC channels at stride fcs)
+  unsigned* bar;               // grid-barrier counter, ZERO before the launch (one word per launch)
+  unsigned* cnt; int ncnt;     // split-K arrival counters (zero; every launch leaves them zero)
+  float* part; size_t part_bytes;   // split-K slabs
+  unsigned* err;               // set to 1 when a wait gave up (never expected)
+};
+size_t cfen_gvit_chain_part_bytes(int M, int maxN, int max_nsplit);
+int cfen_gvit_chain_impl_g(int dtype, int ng, const CfenChainArgs* ca, int team, hipStream_t s);
+int& cfen_tune_gvit_team();     // workgroups per GViT block of the persistent chain ("gvit.team")
+int& cfen_tune_gvit_chain();    // 1 (default): GViT blocks run their GEMMs as persistent chains where the net holds fragment-stream weights ("net.gvit_chain")
+int& cfen_tune_gvit_debug();    // timing experiments on the chain kernel, results invalid ("gvit.debug")
+int& cfen_tune_gemm_splitk_release();   // A/B: release fence in every split-K slice ("gemm.splitk_release")

@@ -23,6 +23,10 @@ int& cfen_tune_skip_classes() {
   static int v = 0;
   return v;
 }
+int& cfen_tune_gvit_dummy_wgs() { static int v = 0; return v; }
+int& cfen_tune_gvit_dummy_us() { static int v = 100; return v; }
+int& cfen_tune_gvit_dummy_stream() { static int v = 0; return v; }
+int& cfen_tune_gvit_chain() { static int v = 1; return v; }   // only nets built with fragment-stream GViT weights (cfg.reserved bit 2) can use it
 int& cfen_tune_ln_fold() {
   static int v = 1;
   return v;
@@ -90,6 +94,7 @@ struct Vit {
   bool fused_front; // gather+embedding+LN1+qkv run as one k_embed_qkv launch
   bool ln_fold1, ln_fold2;   // LN1 / LN2 ride on the qkv / ffn1 GEMM (k_gemm_dma row statistics + folded weights), no LayerNorm launch
   bool fused_window;// the whole block runs as one k_lvit_window launch (one workgroup per window)
+  bool chain;       // GViT: the GEMMs run as two persistent chains (k_gvit.hip) on fragment-stream weights ("<name>.embed.wf" ... ".head2.wf")
   bool stream_mlp;  // out_proj + LN2 + FFN + mlp_head + fold can run as one k_mlp3 launch on fragment-stream weights ("<name>.proj.ws" / ".ffn.ws" / ".head.ws")
 };
 struct ConvLayer {
@@ -111,7 +116,7 @@ struct cfen_net {
   std::vector<Vit> vits;
   size_t ws_bytes = 0;
   // Token scratch, one set per concurrently running transformer block (LViT / GViT of branch A / B)
-  struct Scratch { size_t x0, x1, yn, qkv, att, hid, small, splitk; };   // splitk: arrival counters + partial slabs of the split-K GEMMs (GViT sets)
+  struct Scratch { size_t x0, x1, yn, qkv, att, hid, small, splitk, sync; };   // sync (GViT sets): grid-barrier words of the persistent chains (one per launch of a forward) + error word   // splitk: arrival counters + partial slabs of the split-K GEMMs (GViT sets)
   static constexpr size_t SPLITK_BYTES = 16u << 20;
   Scratch scr_set[6];
   size_t o_stats_set[3] = {0, 0, 0};
@@ -127,6 +132,9 @@ struct cfen_net {
                                    // levels run at the image's own resolution -- no ds_conv_e01 / us_conv_d01*, n_feats channels in head and tails
   bool crs = false;                // ..._crs_gd4.py (variant 2): D's skip fuse is a 1x1 conv over (D, R, S) upsampled maps instead of CFSM2G (crs:854,889)
   bool v5 = false;                 // ..._cfs_v5.py (variant 3): v3 with every LViT block between conv_shrink / conv_extend
+  bool gvit_stream = false;        // cfg.reserved bit 2: GViT weights are also held as fragment streams (packing.pack_stream_tiles) -> persistent chains
+  int gv_launch = 0;               // persistent-chain launches enqueued so far in this forward (each takes its own barrier word)
+  static constexpr int GV_SYNC_WORDS = 1024, GV_ERR_WORD = 512;
   bool wtile = false;              // cfg.reserved bit 1: GViT weights are packed tile-major (CfenGemmPtrs::wtile, packing.pack_wtile)
   size_t wbytes(const Vit& v, int N, int K) const { return (size_t)(v.global && wtile ? cfen_round_up(N, 96) : N) * K * esz; }
   int full = 0;                    // image edge
@@ -279,6 +287,7 @@ int cfen_net::build() {
   crs = variant == 2;
   v5 = variant == 3;
   wtile = (cfg.reserved & 2) != 0;
+  gvit_stream = (cfg.reserved & 4) != 0 && cfg.dtype == CFEN_F16;
   CFEN_CHECK_ARG(!v5 || nf % cfg.num_heads == 0, "net (v5): shrunk embedding dim (n_feats) not divisible by heads");
   full = cfs ? N : 2 * N;
 
@@ -321,6 +330,7 @@ int cfen_net::build() {
     v.fused_front = !v.global && !v.shrink && cfen_embed_qkv_supported(v.D);
     v.fused_window = !v.global && v.fused_mlp && v.fused_front && cfen_lvit_window_supported(cfg.dtype, v.D, v.heads, v.S, v.hidden);
     v.stream_mlp = !v.global && !v.shrink && (v.D == 384 ? !v.fused_mlp : v.D == 192) && v.hidden <= 4 * v.D && cfen_mlp3_supported(cfg.dtype, v.D, v.hidden);
+    v.chain = v.global && gvit_stream && !v.shrink && v.D % 128 == 0 && v.hidden % 128 == 0;
     v.ln_fold1 = !v.fused_front && v.Dn == v.D && (v.D * esz) % 128 == 0;
     v.ln_fold2 = !v.fused_mlp && v.Dn == v.D && (v.D * esz) % 128 == 0;
     CFEN_CHECK_ARG(v.Dn % v.heads == 0, "net: %s embedding dim %d not divisible by %d heads", v.name.c_str(), v.Dn, v.heads);
@@ -345,6 +355,12 @@ int cfen_net::build() {
     if (v.stream_mlp) {
       if (v.D == 384) { need(n + ".embed.ws", (size_t)v.D * v.D * esz); need(n + ".qkv.ws", (size_t)3 * v.D * v.D * esz); }
       need(n + ".proj.ws", (size_t)v.D * v.D * esz); need(n + ".ffn.ws", (size_t)2 * v.D * v.hidden * esz); need(n + ".head.ws", (size_t)2 * v.D * v.hidden * esz);
+    }
+    if (v.chain) {
+      CFEN_CHECK_ARG(v.ln_fold1 && v.ln_fold2, "net: %s: the persistent chain needs the LayerNorm-folded entries", n.c_str());
+      need(n + ".embed.wf", (size_t)v.D * v.D * esz); need(n + ".qkv.wf", (size_t)3 * v.D * v.D * esz); need(n + ".proj.wf", (size_t)v.D * v.D * esz);
+      need(n + ".ffn1.wf", (size_t)v.hidden * v.D * esz); need(n + ".ffn2.wf", (size_t)v.hidden * v.D * esz);
+      need(n + ".head1.wf", (size_t)v.hidden * v.D * esz); need(n + ".head2.wf", (size_t)v.hidden * v.D * esz);
     }
     need(n + ".ln2.g", (size_t)v.D * 4); need(n + ".ln2.b", (size_t)v.D * 4);
     const char* wn = v.fused_mlp ? ".wk" : ".w";
@@ -430,6 +446,7 @@ int cfen_net::build() {
     q.hid = alloc(mh * esz);
     q.small = alloc(g ? max_small * esz : 256);
     q.splitk = g ? alloc(SPLITK_BYTES) : 0;
+    q.sync = g ? alloc(GV_SYNC_WORDS * sizeof(unsigned)) : 0;
   }
   for (int k = 0; k < 3; ++k) o_stats_set[k] = alloc(cfen_stats_workspace_bytes(3 * B, 128));   // [0] also serves the 3B-image InstanceNorm
   parallel = (cfg.reserved & 1) == 0;
@@ -566,6 +583,10 @@ int cfen_net::run_vit_g(int ng, const VitCall* vc, int scr0) {
     for (int g = 0; g < ng; ++g) SK[g] = (float*)at(scr_set[scr0 + 2 * g].splitk);
   const double Md = (double)M * ng, D = v.Dn, Hd = v.hidden;   // algorithmic flops count the real embedding dim
   auto step = [&](const char* what) { if (profiling) label = nm[0] + (ng > 1 ? " (x" + std::to_string(ng) + ")" : "") + ":" + what; };
+  if (v.global && cfen_tune_gvit_dummy_wgs() > 0) {   // what-if probe: the whole block replaced by a launch that holds CUs (outputs invalid)
+    step("dummy");
+    return cfen_occupy_impl(cfen_tune_gvit_dummy_wgs(), ng, cfen_tune_gvit_dummy_us(), cfen_tune_gvit_dummy_stream(), base, ws_bytes, SK[0], stream);
+  }
   // Y = act(X W^T + bias) + R + P for every member; operand arrays are indexed by member
   auto gemm = [&](const void* const* X, const char* wname, const char* bname, void* const* R, const char* pname, void* const* Y, int N, int K,
                   int relu, const CfenTokGather* tg) -> int {
@@ -583,6 +604,62 @@ int cfen_net::run_vit_g(int ng, const VitCall* vc, int scr0) {
                            v.global && wtile};
     return cfen_gemm_impl_g(dt, ng, gp, K, K, N, v.S, N, M, N, K, relu, nullptr, stream, v.global ? SK : nullptr, v.global ? SPLITK_BYTES : 0);
   };
+  if (v.chain && cfen_tune_gvit_chain()) {
+    // GViT block: pooled patch tokens -> [embed -> qkv] -> attention -> [proj -> ffn1 -> ffn2 -> head1 -> head2 + fold] -> x4 bilinear; the two
+    // bracketed runs are ONE persistent launch each (k_gvit.hip): a team of workgroups per block keeps its CUs over the whole run
+    const int team = std::min(cfen_tune_gvit_team(), 256 / ng);
+    auto nsp = [&](int N, int K) {   // K slices so that the phase has work for most of the team (>= 4 K-steps of 64 per slice)
+      int n = 1;
+      const int units = ((M + 127) / 128) * (N / 128);
+      while (units * n * 2 <= team && n < 8 && (K / 64) % (2 * n) == 0 && K / 64 / (2 * n) >= 4) n *= 2;
+      return n;
+    };
+    auto sync_of = [&](int g, CfenChainArgs& c) {
+      unsigned* w = (unsigned*)at(scr_set[scr0 + 2 * g].sync);
+      CFEN_CHECK_ARG(gv_launch < GV_ERR_WORD, "net: too many persistent-chain launches in one forward");
+      c.bar = w + gv_launch; c.err = w + GV_ERR_WORD;
+      c.cnt = (unsigned*)SK[g]; c.ncnt = CFEN_SPLITK_COUNTERS;
+      c.part = SK[g] + CFEN_SPLITK_COUNTERS * sizeof(unsigned) / sizeof(float); c.part_bytes = SPLITK_BYTES - CFEN_SPLITK_COUNTERS * sizeof(unsigned);
+      return CFEN_OK;
+    };
+    step("patchify");
+    TRYP(K_TOKEN, 0, cfen_patchify_impl_g(dt, ng, IN, X0, B, v.mapH, v.mapH, v.C, bi.cs, v.ws, v.p, 4, 0, stream));
+    CfenChainArgs ca[3];
+    for (int g = 0; g < ng; ++g) {
+      const std::string& n = nm[g];
+      CfenChainArgs& c = ca[g];
+      c = CfenChainArgs{};
+      c.nph = 2; c.M = M;
+      //                      X       W                  bias                 lnf_s              R       P             Y       ldx   ldr   ldy     period N       K    relu nsplit fold
+      c.ph[0] = CfenChainPhase{X0[g], P(n + ".embed.wf"), Pf(n + ".embed.b"), nullptr, X0[g], P(n + ".pos"), X1[g], v.D, v.D, v.D, v.S, v.D, v.D, 0, nsp(v.D, v.D), 0};
+      c.ph[1] = CfenChainPhase{X1[g], P(n + ".qkv.wf"), Pf(n + ".qkv.bl"), Pf(n + ".qkv.s"), nullptr, nullptr, QKV[g], v.D, 0, 3 * v.D, 0, 3 * v.D, v.D, 0, 1, 0};
+      TRY(sync_of(g, c));
+    }
+    ++gv_launch;
+    step("chain_embed_qkv");
+    TRYP(K_GEMM, 8 * Md * D * D, cfen_gvit_chain_impl_g(dt, ng, ca, team, stream));
+    step("attention");
+    TRYP(K_ATTN, 4 * Md * v.S * D, cfen_attention_impl_g(dt, ng, cQKV, ATT, B * nwin, v.S, v.heads, v.dh, stream));
+    for (int g = 0; g < ng; ++g) {
+      const std::string& n = nm[g];
+      CfenChainArgs& c = ca[g];
+      c = CfenChainArgs{};
+      c.nph = 5; c.M = M;
+      c.fH = v.mapH; c.fW = v.mapH; c.fcs = v.C; c.fC = v.C; c.fp = v.p;
+      c.ph[0] = CfenChainPhase{ATT[g], P(n + ".proj.wf"), nullptr, nullptr, X1[g], nullptr, X1[g], v.D, v.D, v.D, 0, v.D, v.D, 0, nsp(v.D, v.D), 0};
+      c.ph[1] = CfenChainPhase{X1[g], P(n + ".ffn1.wf"), Pf(n + ".ffn1.bl"), Pf(n + ".ffn1.s"), nullptr, nullptr, HID[g], v.D, 0, v.hidden, 0, v.hidden, v.D, 1, 1, 0};
+      c.ph[2] = CfenChainPhase{HID[g], P(n + ".ffn2.wf"), Pf(n + ".ffn2.b"), nullptr, X1[g], nullptr, X1[g], v.hidden, v.D, v.D, 0, v.D, v.hidden, 0, nsp(v.D, v.hidden), 0};
+      c.ph[3] = CfenChainPhase{X1[g], P(n + ".head1.wf"), Pf(n + ".head1.b"), nullptr, nullptr, nullptr, HID[g], v.D, 0, v.hidden, 0, v.hidden, v.D, 1, 1, 0};
+      c.ph[4] = CfenChainPhase{HID[g], P(n + ".head2.wf"), Pf(n + ".head2.b"), nullptr, X1[g], nullptr, SM[g], v.hidden, v.D, v.D, 0, v.D, v.hidden, 0, nsp(v.D, v.hidden), 1};
+      TRY(sync_of(g, c));
+    }
+    ++gv_launch;
+    step("chain_proj_mlp_head");
+    TRYP(K_GEMM, 2 * Md * D * D + 8 * Md * D * Hd, cfen_gvit_chain_impl_g(dt, ng, ca, team, stream));
+    step("upsample4");
+    TRYP(K_TOKEN, 0, cfen_upsample4_impl_g(dt, ng, cSM, OUT, B, v.mapH, v.mapH, v.C, v.C, bo.cs, stream));
+    return CFEN_OK;
+  }
   if (v.fused_window && cfen_tune_lvit_window()) {
     // LViT level 1: one workgroup per window, embed -> attention -> MLP -> fold with q / k / v / attention output on chip (k_lvit.hip)
     LvitArgs w[3];
@@ -870,6 +947,9 @@ int cfen_net::forward(const float* x, float* xr, float* xs, float* xd) {
   float* stats = (float*)at(o_stats_set[0]);
   // arrival counters of the split-K GEMMs: every launch leaves them zero, this makes a forward independent of whatever ran (or died) before
   for (int k = 1; k < 6; k += 2) TRY(cfen_zero_async(at(scr_set[k].splitk), CFEN_SPLITK_COUNTERS * sizeof(unsigned), stream));
+  // ... and the grid-barrier words of the persistent GViT chains (the error word behind them is sticky: only cfen_net_chain_errors clears it)
+  for (int k = 1; k < 6; k += 2) TRY(cfen_zero_async(at(scr_set[k].sync), GV_ERR_WORD * sizeof(unsigned), stream));
+  gv_launch = 0;
   const Buf& bin = bufs.at("input");
   if (input_u8) {
     label = "input:u8hwc_to_nhwc";
@@ -1103,6 +1183,16 @@ int cfen_net_stage(const cfen_net* net, const char* name, const void** ptr, int3
   if (cs) *cs = it->second.cs;
   if (H) *H = it->second.H;
   if (W) *W = it->second.W;
+  return CFEN_OK;
+}
+
+int cfen_net_chain_error_words(const cfen_net* net, const void** words, int n) {
+  CFEN_CHECK_ARG(net && words && n >= 3, "net_chain_error_words: needs room for 3 pointers");
+  if (!net->base) {
+    cfen_set_error("net_chain_error_words: no forward has run yet");
+    return CFEN_ERR_STATE;
+  }
+  for (int k = 0; k < 3; ++k) words[k] = (const unsigned*)net->at(net->scr_set[2 * k + 1].sync) + cfen_net::GV_ERR_WORD;
   return CFEN_OK;
 }
 

@@ -16,6 +16,7 @@
 #include "cfen_internal.hpp"
 
 int& cfen_tune_gemm_nt();
+int& cfen_tune_gemm_splitk_release();
 
 namespace {
 
@@ -67,6 +68,7 @@ template <typename T> struct GemmArgs {
   float* part;
   unsigned* cnt;   // one arrival counter per tile, zero between launches (the reducing workgroup puts its tile's back to zero)
   int nsplit;
+  int release;       // split-K: agent-scope release fence in every slice (A/B knob "gemm.splitk_release")
   int nt;            // weight rows by non-temporal LDS-DMA
   // optional LayerNorm fold (k_gemm_dma, nsplit == 1, K = the whole row): see CfenGemmPtrs::lnf_s
   const float* lnf_s;
@@ -472,16 +474,24 @@ __global__ __launch_bounds__(256, (TN > 3 && NS == 2) ? 2 : 1) void k_gemm_dma(G
       }
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    // "gemm.splitk_release" = 1 (A/B knob): the guide's first recipe -- an agent-scope release (buffer_wbl2) in every slice on top of the
+    // write-through stores.  The shipped form (0) relies on what MI355X_MICROARCH.md documents for gfx950: sc1 stores leave the XCD's L2 as
+    // they are issued, so the drain above is the whole publish.  Hardware-specific; measured 57.7 us against 22.0 for a 1024-workgroup launch.
+    if (a.release) {
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
     __syncthreads();
     unsigned* flag = reinterpret_cast<unsigned*>(lds);     // the ring is free: every wave is past its last fragment read
     if (tid == 0) *flag = __hip_atomic_fetch_add(a.cnt + tile, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     __syncthreads();
     if (*flag != (unsigned)(a.nsplit - 1)) return;
-    if (tid == 0) {
-      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      a.cnt[tile] = 0u;                                    // zero again for the next launch that uses this counter
-    }
+    // EVERY wave of the reducing workgroup acquires at agent scope before it touches another slice's slab (round 4): the
+    // invalidate is per CU, so one lane's would do on gfx950 -- but then three waves would read other workgroups' data with no acquire of
+    // their own in program order, a data race in the HIP memory model.  One buffer_inv per wave of ONE workgroup per tile costs nothing measurable.
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (tid == 0) __hip_atomic_store(a.cnt + tile, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // zero again for the next launch that uses this counter
     __syncthreads();
     const float* p0 = a.part + (size_t)tile * a.nsplit * slab;
 #pragma unroll
@@ -667,6 +677,8 @@ int launch_gemm(int ng, const CfenGemmPtrs* gp, int ldx, int ldw, int ldr, int p
     }
     const size_t slab = (size_t)(3 * 4 + 2) * 256 * sizeof(float);
     const long long tiles = (long long)((N + G_BN - 1) / G_BN) * ((M + 31) / 32);
+    // the kernel addresses its slab with a 32-bit byte offset from the scratch base
+    CFEN_CHECK_ARG((unsigned long long)tiles * (unsigned long long)nsplit * slab < (1ull << 32), "gemm (split-K): %lld tiles x %d slices exceed the 4 GiB slab window", tiles, nsplit);
     if (nsplit > 1 && (tiles > CFEN_SPLITK_COUNTERS || CFEN_SPLITK_COUNTERS * sizeof(unsigned) + (size_t)tiles * nsplit * slab > splitk_ws_bytes)) {
       CFEN_CHECK_ARG(force_nsplit <= 1, "gemm (split-K): scratch too small (%zu bytes)", splitk_ws_bytes);
       nsplit = 1;
@@ -701,6 +713,7 @@ int launch_gemm(int ng, const CfenGemmPtrs* gp, int ldx, int ldw, int ldr, int p
   for (int g = 0; g < ng; ++g) {
     ga.g[g].map = map;
     ga.g[g].nsplit = nsplit;
+    ga.g[g].release = cfen_tune_gemm_splitk_release();
     ga.g[g].nt = (cfen_tune_gemm_nt() == 2 || (cfen_tune_gemm_nt() == 1 && M <= 512)) ? 1 : 0;
     CFEN_CHECK_ARG(nsplit == 1 || (splitk_ws[g] && cfen_aligned16(splitk_ws[g])), "gemm: split-K workspace missing");
     ga.g[g].cnt = nsplit > 1 ? reinterpret_cast<unsigned*>(splitk_ws[g]) : nullptr;                       // [CFEN_SPLITK_COUNTERS] arrival counters, zero
@@ -743,6 +756,10 @@ int& cfen_tune_gemm_nt() {   // weight rows of k_gemm_dma by non-temporal LDS-DM
 
 int& cfen_tune_gemm_splitk() {
   static int v = 1;
+  return v;
+}
+int& cfen_tune_gemm_splitk_release() {   // 1: every K slice also runs an agent-scope release fence before its arrival ticket (see the split-K block of k_gemm_dma)
+  static int v = 0;
   return v;
 }
 // 0 (default): off; 6: 192 x 128 tiles, 2-stage ring (80 KB of LDS, two workgroups a CU).  MEASURED (MI355X, B = 8, round 2): the

@@ -275,7 +275,40 @@ int run_upsample4(int ng, const void* const* small, void* const* out, int B, int
   return CFEN_OK;
 }
 
+
+// What-if probe ("net.gvit_dummy_*"): hold `gridDim.x` CUs for `ticks` / 100 us the way a persistent GViT block kernel would (one 512-thread
+// workgroup with 100 KB of LDS per CU), optionally streaming 16-byte loads meanwhile.  Timing experiments only: writes nothing but `sink`.
+__global__ __launch_bounds__(512) void k_occupy(const uint4* __restrict__ src, size_t nvec, unsigned ticks, int do_stream, unsigned* sink) {
+  __shared__ unsigned char lds[100 * 1024];
+  lds[threadIdx.x] = (unsigned char)threadIdx.x;
+  __syncthreads();
+  const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+  unsigned acc = lds[(threadIdx.x * 7) & 1023];
+  size_t i = ((size_t)blockIdx.x * 977 + blockIdx.y * 131) * 512 + threadIdx.x;
+  for (int it = 0; it < (1 << 20); ++it) {
+    if (__builtin_amdgcn_s_memrealtime() - t0 >= ticks) break;
+    if (do_stream) {
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const uint4 v = src[(i + (size_t)u * 512) % nvec];
+        acc += v.x ^ v.y ^ v.z ^ v.w;
+      }
+      i += 8 * 512 * 61;
+    } else {
+      __builtin_amdgcn_s_sleep(32);
+    }
+  }
+  if (acc == 0x12345677u) sink[0] = acc;
+}
+
 }  // namespace
+
+int cfen_occupy_impl(int wgs, int ng, int usec, int do_stream, const void* src, size_t src_bytes, void* sink, hipStream_t s) {
+  CFEN_CHECK_ARG(wgs > 0 && wgs <= 256 && ng >= 1 && ng <= 3 && usec > 0 && usec <= 2000 && src && sink && src_bytes >= (1u << 20), "occupy: bad arguments");
+  CFEN_LAUNCH(k_occupy, dim3(wgs, ng), dim3(512), 0, s, (const uint4*)src, src_bytes / 16, (unsigned)usec * 100u, do_stream, (unsigned*)sink);
+  CFEN_CHECK_LAUNCH("occupy");
+  return CFEN_OK;
+}
 
 // inverse: fmap[] are the maps written from tok[]
 int cfen_patchify_impl_g(int dtype, int ng, const void* const* fmap, void* const* tok, int B, int H, int W, int C, int cs, int ws, int p, int pool,

@@ -73,6 +73,10 @@ class dec_ipt(nn.Module):
         self.serial_plan = bool(os.environ.get("CFEN_SERIAL"))     # single-lane launch plan (debugging / A-B)
         # GViT weights tile-major (packing.pack_wtile; cfen_net_config.reserved bit 1): +1 % measured (3.34 -> 3.30 ms at B = 8); CFEN_WTILE=0 = row-major
         self.wtile = os.environ.get("CFEN_WTILE", "1") != "0"
+        # CFEN_GVIT_CHAIN=1: GViT weights ALSO as MFMA fragment streams (packing.pack_stream_tiles; cfen_net_config.reserved bit 2) and the GEMMs of a
+        # GViT block run as two persistent chains (csrc/k_gvit.hip) instead of eight launches; fp16 only.  OFF by default: measured slower inside the
+        # forward (3.15 against 2.80 ms at B = 8, round 4: grid barriers, split-K seams and write-through stores cost more than the launches they replace)
+        self.gvit_chain = os.environ.get("CFEN_GVIT_CHAIN", "0") != "0"
 
     # ---- parameter management ---------------------------------------------------------------
     def state_dict(self, *args, **kw):
@@ -169,7 +173,8 @@ class dec_ipt(nn.Module):
             self.invalidate()
         if self._packed is None:
             pending = {}
-            packed = pack_state_dict(self._live_state(device), self.cfg, self.compute_dtype, pending=pending, wtile=self.wtile)
+            packed = pack_state_dict(self._live_state(device), self.cfg, self.compute_dtype, pending=pending, wtile=self.wtile,
+                                     gvit_stream=self.gvit_chain)
             self._packed = {k: v.to(device).contiguous() for k, v in packed.items() if not isinstance(v, str)}
             for k, v in packed.items():          # "@other": the same device tensor under a second name (shared modules)
                 if isinstance(v, str):
@@ -190,8 +195,8 @@ class dec_ipt(nn.Module):
         c = self.cfg
         cc = NetConfigC(batch=batch, n_feats=c.n_feats, hidden_dim_ratio=c.hidden_dim_ratio, patch_size=c.patch_size,
                         load_size=c.load_size, num_heads=c.num_heads, dtype=_lib.dtype_code(self.compute_dtype),
-                        reserved=(1 if self.serial_plan else 0) | (2 if self.wtile else 0) | (_VARIANT_CODE[c.variant] << 8))
-        # bit 0: single-stream plan; bit 1: tile-major GViT weights; bits 8..15: variant
+                        reserved=(1 if self.serial_plan else 0) | (2 if self.wtile else 0) | (4 if self.gvit_chain else 0) | (_VARIANT_CODE[c.variant] << 8))
+        # bit 0: single-stream plan; bit 1: tile-major GViT weights; bit 2: GViT fragment streams (persistent chains); bits 8..15: variant
         h = ctypes.c_void_p()
         check(lib.cfen_net_create(ctypes.byref(h), ctypes.byref(cc)), "cfen_net_create")
         for name, t in packed.items():
@@ -204,6 +209,18 @@ class dec_ipt(nn.Module):
         ws = torch.empty(lib.cfen_net_workspace_bytes(h), dtype=torch.uint8, device=device)
         self._nets[key] = (h, ws)
         return self._nets[key]
+
+    def chain_errors(self):
+        """error words of the persistent GViT chains of the net that ran last (csrc/k_gvit.hip): all zero unless a grid-barrier wait gave up
+        (synchronises; for tests and bench.py's self-check, not for the hot path)"""
+        if self._last is None:
+            return [0, 0, 0]
+        h, _ = self._nets[self._last]
+        words = (ctypes.c_void_p * 3)()
+        check(_lib.load().cfen_net_chain_error_words(h, words, 3), "cfen_net_chain_error_words")
+        torch.cuda.synchronize()
+        ws = self._nets[self._last][1]          # the words live in the net's workspace tensor: read them through a view of it
+        return [int(ws[w - ws.data_ptr():w - ws.data_ptr() + 4].view(torch.int32).item()) for w in words]
 
     def _arm_actnorm_init(self, h):
         """Uninitialised ActNorm2d layers are initialised by the next eager forward, from that batch (models/actnorm.py:25-37)."""

@@ -63,6 +63,41 @@ def gemm_splitk(x, w, nsplit, bias=None, residual=None, relu=False, lnf_s=None, 
     return out
 
 
+def gemm_chain(phases, M, team=48, fold=None, sync=None):
+    """cfen_gemm_chain: a list of dependent GEMM phases in one persistent launch.  Every phase is a dict with x [M,K], w [N,K] (row-major; packed
+    to a fragment stream here) or w_stream, y (preallocated output, [M,N] or the NHWC map when fold), and optionally bias, lnf_s, residual, pos,
+    relu, nsplit, fold.  fold = (H, W, cs, C, p) of the map.  Returns the error word (0 = fine)."""
+    from .packing import pack_stream_tiles
+    from ._lib import ChainArgsC
+    a = ChainArgsC()
+    keep = []
+    a.nphases, a.M = len(phases), M
+    maxslab = 0
+    for i, ph in enumerate(phases):
+        x, y = ph["x"], ph["y"]
+        ws = ph.get("w_stream")
+        if ws is None:
+            ws = pack_stream_tiles(ph["w"].contiguous())
+        keep.append(ws)
+        N, K = (ph["w"].shape if "w" in ph else (ph["N"], ph["K"]))
+        _cuda(x, ws, y, ph.get("bias"), ph.get("lnf_s"), ph.get("residual"), ph.get("pos"))
+        q = a.phase[i]
+        q.x, q.w_stream, q.bias, q.lnf_s, q.residual, q.pos, q.y = (ptr(x).value, ptr(ws).value, ptr(ph.get("bias")).value, ptr(ph.get("lnf_s")).value,
+                                                                  ptr(ph.get("residual")).value, ptr(ph.get("pos")).value, ptr(y).value)
+        q.ldx, q.ldr, q.ldy = x.shape[1], N, N
+        q.period = ph["pos"].shape[0] if ph.get("pos") is not None else 0
+        q.N, q.K, q.relu, q.nsplit, q.fold = N, K, int(ph.get("relu", False)), int(ph.get("nsplit", 1)), int(ph.get("fold", False))
+        maxslab = max(maxslab, (N // 128) * q.nsplit)
+    if fold is not None:
+        a.fold_H, a.fold_W, a.fold_cs, a.fold_C, a.fold_p = fold
+    own = sync is None
+    if own:
+        sync = torch.zeros(8192 + ((M + 127) // 128) * maxslab * 65536, dtype=torch.uint8, device=phases[0]["x"].device)
+    a.sync_ws, a.sync_ws_bytes = ptr(sync).value, sync.numel()
+    check(_lib.load().cfen_gemm_chain(dtype_code(phases[0]["x"].dtype), ctypes.byref(a), team, current_stream()), "gemm_chain")
+    return int(sync[:8].view(torch.int32)[1].item()) if own else None     # with a caller-owned `sync` buffer: no read-back (word 1 of it = error)
+
+
 def layernorm(x, gamma, beta, eps=1e-5):
     _cuda(x, gamma, beta)
     out = torch.empty_like(x)

@@ -130,6 +130,20 @@ def pack_wtile(w):
     return wp.view(n96 // 96, 96, k // bk, bk).permute(0, 2, 1, 3).contiguous().view(-1)
 
 
+def pack_stream_tiles(w):
+    """[N][K] (N % 16 == 0, K % 32 == 0) -> fragment stream [N / 16 feature tiles][K / 32 k-chunks][64 lanes][8]: fragment (i, c) is the 16 x 32 MFMA A
+    operand of feature tile i, k-chunk c in lane order (lane l: row i*16 + (l & 15), k = c*32 + (l >> 4)*8 .. +7) -- all k-chunks of a feature tile
+    are ONE contiguous run, which is what a wave of csrc/k_gvit.hip streams."""
+    n, k = w.shape
+    assert n % 16 == 0 and k % 32 == 0
+    return w.reshape(n // 16, 16, k // 32, 4, 8).permute(0, 2, 3, 1, 4).contiguous().view(-1)
+
+
+def gvit_chain_ok(g, dtype):
+    """mirror of cfen_net.cpp Vit::chain: GViT blocks whose GEMMs run as persistent chains (csrc/k_gvit.hip)"""
+    return g.kind == "gvit" and g.shrink == 1 and dtype == torch.float16 and g.dim % 128 == 0 and g.hidden % 128 == 0
+
+
 def pack_stream_sq(w):
     """[N][K] (N % 16 == 0, K % 32 == 0, k axis as the kernel wants it) -> fragment stream [K / 32 phases][N / 16 fragments][64 lanes][8]:
     fragment (c, i) is the 16 x 32 MFMA A operand of feature tile i, k-chunk c in lane order -- lane l holds row i*16 + (l & 15), k = c*32 +
@@ -422,7 +436,7 @@ def _actnorm_ready(sd, prefix):
     return int(sd[prefix + ".initialized"]) == 1
 
 
-def pack_state_dict(sd, cfg: NetConfig, dtype=torch.float16, pending=None, wtile=False):
+def pack_state_dict(sd, cfg: NetConfig, dtype=torch.float16, pending=None, wtile=False, gvit_stream=False):
     """reference state_dict (tensors on any one device) -> packed tensors on the same device.
 
     An ActNorm2d whose `initialized` buffer is 0 holds no parameters yet: the reference fills it from the statistics of its first
@@ -436,6 +450,12 @@ def pack_state_dict(sd, cfg: NetConfig, dtype=torch.float16, pending=None, wtile
     out = {}
     for g in cfg.vit_instances():
         pv = pack_vit(sd, g, dtype)
+        if gvit_stream and gvit_chain_ok(g, dtype):
+            # the persistent chains (csrc/k_gvit.hip) read every matrix as a fragment stream; qkv / ffn1 in their LayerNorm-folded form.  The
+            # row-major / tile-major copies stay: "net.gvit_chain" = 0 runs the launch-per-GEMM plan on them
+            for nm, src in (("embed", ".embed.w"), ("qkv", ".qkv.wl"), ("proj", ".proj.w"), ("ffn1", ".ffn1.wl"), ("ffn2", ".ffn2.w"), ("head1", ".head1.w"),
+                            ("head2", ".head2.w")):
+                pv[g.name + "." + nm + ".wf"] = pack_stream_tiles(pv[g.name + src].contiguous())
         if wtile and g.kind == "gvit":      # the GViT GEMMs stream their weights from HBM once per forward: tile-major (pack_wtile)
             for k in list(pv):
                 if k.endswith(GVIT_WEIGHT_SUFFIXES):

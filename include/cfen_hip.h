@@ -110,6 +110,9 @@ int cfen_net_profile_entry(const cfen_net* net, int index, const char** label, i
 /* device pointer + geometry of a named top-level stage output (SURVEY Appendix D names) inside the
  * workspace of the LAST forward; NHWC, element type = net dtype.                                  */
 int cfen_net_stage(const cfen_net* net, const char* name, const void** ptr, int32_t* C, int32_t* cs, int32_t* H, int32_t* W);
+/* Device addresses of the 3 error words of the persistent GViT chains (csrc/k_gvit.hip): a word becomes 1 if a grid-barrier wait ever gave up
+ * (never expected: the teams fit the chip); outputs of that forward are then invalid.  Valid after the first forward. */
+int cfen_net_chain_error_words(const cfen_net* net, const void** words, int n);
 /* 2*MAC count of one forward per image (SURVEY 8d closed form), for roofline reporting             */
 double cfen_net_flops_per_image(const cfen_net* net);
 
@@ -131,6 +134,26 @@ int cfen_gemm_ln(int dtype, const void* X, int ldx, const void* Wl, int ldw, con
  * ceil(N/96) * ceil(M/32) * nsplit * 14336 bytes of partial slabs.  K * element size / 128 must be divisible by nsplit.   (v3:1364, 1388-1389, 1173) */
 int cfen_gemm_splitk(int dtype, const void* X, int ldx, const void* W, int ldw, const float* lnf_s, const float* bias, const void* R, int ldr, void* Y,
                       int ldy, int M, int N, int K, int relu, int nsplit, void* scratch, size_t scratch_bytes, void* stream);
+/* Persistent GEMM chain (csrc/k_gvit.hip): up to 5 DEPENDENT token GEMMs  y_p = act(x_p W_p^T + bias) + residual + pos[m % period]  (or the
+ * LayerNorm-folded form of cfen_gemm_ln when lnf_s != NULL) run by ONE launch of `team` workgroups (one per CU) that keep their CUs and meet at a
+ * grid barrier between phases -- the nn.Linear chains of a GViT instance: linear_encoding -> in_proj, and out_proj -> linear1 -> linear2 ->
+ * mlp_head.0 -> mlp_head.3 (+ fold) (v3:1143,1166,1364,1386-1389,1173,1186).  CFEN_F16 only.  w_stream: the [N][K] weight as MFMA fragment stream
+ * [N/16][K/32][64 lanes][8 halfs] (packing.pack_stream_tiles); N % 128 == 0, K % 64 == 0; nsplit > 1 cuts K into slices reduced inside the launch
+ * (not with lnf_s).  fold = 1: y is the NHWC map (fold_H x fold_W pixels, channel stride fold_cs) the M tokens tile with fold_p x fold_p patches of
+ * fold_C channels, feature n = (i, j, c).  A phase may read what an earlier phase of the same call wrote.  sync_ws: 8192 bytes of synchronisation
+ * words (the call zeroes the ones it needs; word 1 is set to 1 if a wait ever gave up -- results are then invalid) followed by the split-K slabs:
+ * ceil(M/128) * max(N/128 * nsplit) * 65536 bytes.  team * 1 <= 256: every workgroup must be resident for the grid barrier. */
+typedef struct cfen_chain_phase {
+  const void* x; const void* w_stream; const float* bias; const float* lnf_s; const void* residual; const void* pos; void* y;
+  int32_t ldx, ldr, ldy, period, N, K, relu, nsplit, fold;
+} cfen_chain_phase;
+typedef struct cfen_chain_args {
+  cfen_chain_phase phase[5];
+  int32_t nphases, M;
+  int32_t fold_H, fold_W, fold_cs, fold_C, fold_p;
+  void* sync_ws; size_t sync_ws_bytes;
+} cfen_chain_args;
+int cfen_gemm_chain(int dtype, const cfen_chain_args* a, int team, void* stream);
 /* LViT token embedding without a token buffer: tok = patchify(fmap) (window partition + unfold, as cfen_patchify with pool 1)
  * is gathered by the GEMM's loader;  Y[m][n] = sum_k tok[m][k] W[n][k] + bias[n] + tok[m][n] + pos[m % period][n],
  * D = p*p*C, W is [D][D] (ldw), Y is [M][D] (ldy).                                        (v3:1140-1143, 1166) */

@@ -833,3 +833,114 @@ def test_lvit_window_block_against_oracle_and_unfused_chain(B, H, W):
                           proj=(att, pk[n + ".proj.w"]), fold=(B, H, W, 24, 24, 32, 2))
     close(ops.from_nhwc(chain, 24), want, tol(dt, 12), "unfused chain vs fp64")
     assert float((got.float() - ops.from_nhwc(chain, 24).float()).abs().max()) <= tol(dt, 12)
+
+
+# ---------------------------------------------------------------------------------------------------
+def _chain_ref(x, w, bias=None, lnf=None, residual=None, pos=None, relu=False):
+    """one phase in float64 from the fp16-rounded operands (the kernel stores fp16 between phases: the caller rounds)"""
+    y = x.double() @ w.double().t()
+    if lnf is not None:
+        g, b = lnf
+        y = cfen_oracle.layer_norm(x.double(), g.double(), b.double()) @ w.double().t()
+    if bias is not None:
+        y = y + bias.double()
+    if relu:
+        y = torch.relu(y)
+    if residual is not None:
+        y = y + residual.double()
+    if pos is not None:
+        y = y + pos.double()[torch.arange(x.shape[0]) % pos.shape[0]]
+    return y
+
+
+@pytest.mark.parametrize("M,N,K,nsplit,team", [(128, 1536, 1536, 4, 48), (128, 1536, 6144, 4, 48), (512, 768, 3072, 2, 48), (2048, 384, 1536, 1, 48),
+                                             (16, 128, 64, 1, 3), (100, 256, 512, 2, 5), (256, 1152, 384, 1, 7), (130, 128, 256, 4, 64)])
+def test_gemm_chain_single_phase(M, N, K, nsplit, team):
+    """k_gvit_chain, one phase: every epilogue operand, ragged token counts (clamped rows, skipped stores), split-K with the in-launch
+    reduction, in-place residual; bit-reproducible; against float64"""
+    d = dev()
+    dt = torch.float16
+    x, w = rnd((M, K), 1, dt), rnd((N, K), 2, dt, 1 / math.sqrt(K))
+    bias, res, pos = rnd((N,), 3, torch.float32), rnd((M, N), 4, dt), rnd((16, N), 5, dt)
+    y = torch.full((M, N), float("nan"), dtype=dt, device=d)
+    assert ops.gemm_chain([dict(x=x.to(d), w=w.to(d), y=y, nsplit=nsplit)], M, team) == 0
+    close(y, _chain_ref(x, w), tol(dt, 4), "plain")
+    y2 = torch.empty_like(y)
+    ph = dict(x=x.to(d), w=w.to(d), y=y2, bias=bias.to(d), residual=res.to(d), pos=pos.to(d), relu=True, nsplit=nsplit)
+    assert ops.gemm_chain([ph], M, team) == 0
+    close(y2, _chain_ref(x, w, bias, None, res, pos, True), tol(dt, 8), "bias + relu + residual + pos")
+    y3 = torch.empty_like(y)
+    ph["y"] = y3
+    for _ in range(3):
+        assert ops.gemm_chain([ph], M, team) == 0
+        assert torch.equal(y2, y3)
+    r = res.to(d).clone()     # in-place residual (proj / linear2 of the block)
+    assert ops.gemm_chain([dict(x=x.to(d), w=w.to(d), y=r, residual=r, bias=bias.to(d), nsplit=nsplit)], M, team) == 0
+    close(r, _chain_ref(x, w, bias, None, res), tol(dt, 8), "in-place residual")
+    if nsplit == 1:
+        g, b = 1 + 0.1 * rnd((K,), 6, torch.float32), 0.1 * rnd((K,), 7, torch.float32)
+        lf = packing.ln_folded(None, g, b, bias, "q", dt, w.float())
+        y4 = torch.empty_like(y)
+        assert ops.gemm_chain([dict(x=x.to(d), w=lf["q.wl"].to(d), y=y4, bias=lf["q.bl"].to(d), lnf_s=lf["q.s"].to(d), relu=True)], M, team) == 0
+        close(y4, _chain_ref(x, w, bias, (g, b), relu=True), tol(dt, 12), "LayerNorm folded")
+
+
+@pytest.mark.parametrize("B,S,D,H,heads,team", [(8, 16, 1536, 6144, 16, 48), (8, 64, 768, 3072, 8, 48), (2, 256, 384, 1536, 4, 48), (8, 64, 768, 768, 8, 24),
+                                               (1, 16, 384, 768, 4, 9)])
+def test_gemm_chain_gvit_block(B, S, D, H, heads, team):
+    """the two persistent chains of a GViT instance (embed -> qkv; proj -> ffn1 -> ffn2 -> head1 -> head2 + fold) around the attention operator,
+    against a float64 restatement of v3:1272-1325 / 1359-1390 on the same fp16-rounded parameters; the phases hand their outputs to each other
+    through the grid barrier (in-place x1, shared hidden buffer)"""
+    d, dt = dev(), torch.float16
+    M = B * S
+    C = D // 16
+    tw = int(math.isqrt(S))
+    mapH = 4 * tw
+    sc = lambda k: 1 / math.sqrt(k)
+    x0 = rnd((M, D), 1, dt)
+    we, be, pos = rnd((D, D), 2, dt, sc(D)), rnd((D,), 3, torch.float32, 0.1), rnd((S, D), 4, dt, 0.5)
+    g1, b1, g2, b2 = [(1 if i % 2 == 0 else 0) + 0.1 * rnd((D,), 5 + i, torch.float32) for i in range(4)]
+    wqkv, wp = rnd((3 * D, D), 9, dt, sc(D)), rnd((D, D), 10, dt, sc(D))
+    w1, bb1, w2, bb2 = rnd((H, D), 11, dt, sc(D)), rnd((H,), 12, torch.float32, 0.1), rnd((D, H), 13, dt, sc(H)), rnd((D,), 14, torch.float32, 0.1)
+    w3, bb3, w4, bb4 = rnd((H, D), 15, dt, sc(D)), rnd((H,), 16, torch.float32, 0.1), rnd((D, H), 17, dt, sc(H)), rnd((D,), 18, torch.float32, 0.1)
+    lq = packing.ln_folded(None, g1, b1, None, "q", dt, wqkv.float())
+    lf = packing.ln_folded(None, g2, b2, bb1, "f", dt, w1.float())
+    T = lambda t: t.to(d)
+    x1 = torch.empty(M, D, dtype=dt, device=d)
+    qkv = torch.empty(M, 3 * D, dtype=dt, device=d)
+    hid = torch.empty(M, H, dtype=dt, device=d)
+    sm = torch.zeros(B, mapH, mapH, C, dtype=dt, device=d)
+    x0d = T(x0)
+
+    def nsp(N, K):
+        n, units = 1, ((M + 127) // 128) * (N // 128)
+        while units * n * 2 <= team and n < 8 and (K // 64) % (2 * n) == 0 and K // 64 // (2 * n) >= 4:
+            n *= 2
+        return n
+
+    err = ops.gemm_chain([dict(x=x0d, w=T(we), y=x1, bias=T(be), residual=x0d, pos=T(pos), nsplit=nsp(D, D)),
+                          dict(x=x1, w=T(lq["q.wl"]), y=qkv, bias=T(lq["q.bl"]), lnf_s=T(lq["q.s"]))], M, team)
+    assert err == 0
+    # float64 reference, rounding to fp16 where the kernels store fp16
+    r16 = lambda t: t.to(dt).double()
+    X1 = r16(_chain_ref(x0, we, be, None, x0, pos))
+    close(x1, X1, tol(dt, 8), "embed")
+    QKV = r16(cfen_oracle.layer_norm(X1, g1.double(), b1.double()) @ wqkv.double().t())
+    close(qkv, QKV, tol(dt, 16), "qkv")
+    att = ops.attention(qkv, B, S, heads)
+    q, k, v = [QKV[:, i * D:(i + 1) * D].reshape(B, S, heads, D // heads).permute(0, 2, 1, 3) for i in range(3)]
+    A = r16((torch.softmax(q @ k.transpose(-1, -2) / math.sqrt(D // heads), -1) @ v).permute(0, 2, 1, 3).reshape(M, D))
+    close(att, A, tol(dt, 8), "attention")
+    err = ops.gemm_chain([dict(x=att, w=T(wp), y=x1, residual=x1, nsplit=nsp(D, D)),
+                          dict(x=x1, w=T(lf["f.wl"]), y=hid, bias=T(lf["f.bl"]), lnf_s=T(lf["f.s"]), relu=True),
+                          dict(x=hid, w=T(w2), y=x1, bias=T(bb2), residual=x1, nsplit=nsp(D, H)),
+                          dict(x=x1, w=T(w3), y=hid, bias=T(bb3), relu=True),
+                          dict(x=hid, w=T(w4), y=sm, bias=T(bb4), residual=x1, nsplit=nsp(D, H), fold=True)], M, team, fold=(mapH, mapH, C, C, 4))
+    assert err == 0
+    X2 = r16(att.double().cpu() @ wp.double().t() + X1)
+    HID = r16(torch.relu(cfen_oracle.layer_norm(X2, g2.double(), b2.double()) @ w1.double().t() + bb1.double()))
+    X3 = r16(HID @ w2.double().t() + bb2.double() + X2)
+    HID2 = r16(torch.relu(X3 @ w3.double().t() + bb3.double()))
+    Y = HID2 @ w4.double().t() + bb4.double() + X3          # [M][D], feature (i, j, c)
+    want = Y.reshape(B, tw, tw, 4, 4, C).permute(0, 1, 3, 2, 4, 5).reshape(B, mapH, mapH, C)
+    close(sm, want, tol(dt, 40), "block output (folded map)")
