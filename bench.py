@@ -72,26 +72,17 @@ def kernel_key(label, cls):
     return "%s:%s" % (cls, fam + (":" + step if step else ""))
 
 
-KERNEL_OF_STEP = {"window_block_fused": "k_lvit_window", "embed_ln_qkv": "k_embed_qkv2", "proj_mlp_fused": "k_mlp2", "proj_mlp_stream": "k_mlp3",
-                  "front_stream": "k_front3",
-                  "attention": "k_attention_hm / k_attention_win", "embed": "k_gemm_dma", "qkv": "k_gemm_dma", "ln1_qkv": "k_gemm_dma (LayerNorm folded)",
-                  "ln2_ffn1": "k_gemm_dma (LayerNorm folded)", "proj": "k_gemm_dma", "ffn1": "k_gemm_dma", "ffn2": "k_gemm_dma", "head1": "k_gemm_dma",
-                  "head2": "k_gemm_dma"}
+HBM_PEAK_GBS = 8000.0                                   # same guide: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
 
 
-def symbol_key(label, cls):
-    """per-launch label -> the device kernel that ran it, per block shape (one template instantiation each): every k_gemm_dma step of
-    LViT level 3 is ONE entry here, where kernel_key() lists them as seven"""
-    name, _, step = label.partition(":")
-    name = name.split(" ")[0]
-    if name.startswith(("localvit", "globalvit")):
-        blk = "%s%s" % ("lvit" if name.startswith("local") else "gvit", name.split("_0")[1][0])
-        return "%s @ %s" % (KERNEL_OF_STEP.get(step, step), blk)
-    if cls == "conv":
-        fam = "k_conv7_tz" if name.endswith(".conv7") else "k_conv_tile" if name.startswith(("head.", "tail_")) else \
-              "k_convT_tile" if name.startswith("us_conv") else "k_conv (gather)"
-        return fam
-    return "%s:%s" % (cls, step or name.rstrip("0123456789rsd"))
+def nearer_roof(gflop, gbytes, ms, peak_tflops):
+    """(bound, achieved, peak, unit, frac) of a set of launches: the roof it is nearer to -- MFMA (algorithmic flops / time against the dense peak of
+    the dtype) or HBM (algorithmic bytes / time against 8 TB/s; only launches the net prices in bytes carry them: the weight-streaming token GEMMs)"""
+    f_m = gflop / ms / peak_tflops if ms > 0 else 0.0
+    f_h = gbytes / ms * 1e3 / HBM_PEAK_GBS if ms > 0 else 0.0          # GB / ms * 1e3 = GB/s
+    if f_h > f_m:
+        return "hbm", round(gbytes / ms * 1e3, 1), HBM_PEAK_GBS, "GB/s", round(f_h, 5)
+    return "mfma", round(gflop / ms, 2), peak_tflops, "TFLOP/s", round(f_m, 5)
 
 
 def time_config(cfg, B, dtype, dev, steps, min_seconds, warmup=3):
@@ -124,6 +115,7 @@ def time_config(cfg, B, dtype, dev, steps, min_seconds, warmup=3):
     ips = B * steps / dt
     out = {"workload": "batch=%d %dx%d n_feats=24 hidden_dim_ratio=%d %s" % (B, n, n, cfg.hidden_dim_ratio, dtype),
            "value": round(ips, 2), "unit": "images/sec", "ms_per_step": round(dt / steps * 1e3, 3), "steps": steps, "repetitions": len(reps),
+           "timing_method": "median of the repetitions",
            "timed_seconds": round(sum(reps), 3), "gflop_per_image": round(fl / 1e9, 2),
            "whole_forward_tflops": round(ips * fl / 1e12, 2), "whole_forward_frac": round(ips * fl / 1e12 / MFMA_PEAK_TFLOPS[dtype], 5),
            "self_check": self_check(net, x, split_slab(slab, B, n), cfg, dtype)}
@@ -159,17 +151,31 @@ def self_check(net, x, outs, cfg, dtype):
 
 
 def pmc_traffic(kernel):
-    """HBM bytes per launch of the dominant kernel from the latest committed rocprofv3 PMC summary (tools/pmc_summary.py:
-    separate FETCH_SIZE and WRITE_SIZE passes of this same command, fetch doubled as the gfx950 guide prescribes).
-    A cross-reference to profiles/, not a live measurement: None when the summary has no entry for this kernel."""
+    """HBM bytes per launch of a device kernel from the newest committed rocprofv3 PMC summary (tools/mfma_summary.py: separate FETCH_SIZE and
+    WRITE_SIZE passes of this same command, fetch doubled as the gfx950 guide prescribes).  `kernel` is the launch-site name cfen_net_profile
+    records ("k_gemm_dma<T, 1, 3>"); the summary is keyed by the profiler's symbol ("k_gemm_dma<f16,1,3,3>": element type spelled out,
+    defaulted template arguments included) -- matched on the kernel name and the leading numeric arguments.  A cross-reference to profiles/,
+    not a live measurement: None without a match."""
     import glob
+    import re
     files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic.json")))
     if not files:
         return None
+
+    def parts(name):
+        base, _, args = name.partition("<")
+        nums = [a.strip() for a in args.rstrip(">").split(",") if re.fullmatch(r"\s*-?\d+\s*", a)]
+        return base.strip(), nums
     try:
-        return json.load(open(files[-1]))["bench_kernels"][kernel]["hbm_bytes_per_launch"]
+        table = json.load(open(files[-1]))["kernels"]
     except (KeyError, ValueError, OSError):
         return None
+    base, nums = parts(kernel.split(" + ")[0])
+    for key, val in table.items():
+        kb, kn = parts(key)
+        if kb == base and kn[:len(nums)] == nums:
+            return val.get("hbm_bytes_per_launch")
+    return None
 
 
 def apply_tuning():
@@ -309,26 +315,42 @@ def main():
         # per-KERNEL table from the per-launch records of the median profile: the roofline line names the dominant kernel
         kern = {}
         mid = sorted(profs, key=lambda p: sum(p[n][0] for n in net.KERNEL_CLASSES))[1]
-        for label, cls, fl, ms in mid["launches"]:
+        for label, cls, fl, ms, _kn, _by in mid["launches"]:
             k = kern.setdefault(kernel_key(label, cls), {"ms": 0.0, "gflop": 0.0, "launches": 0})
             k["ms"] += ms; k["gflop"] += fl / 1e9; k["launches"] += 1
         for k in kern.values():
             k["ms"] = round(k["ms"], 4); k["gflop"] = round(k["gflop"], 2)
             k["tflops"] = round(k["gflop"] / k["ms"], 1) if k["gflop"] > 0 and k["ms"] > 0 else None
+        # the same launches grouped by the DEVICE KERNEL that ran them (the template instantiation cfen_net_profile recorded at the launch site:
+        # every k_gemm_dma<T, 1, 3> launch of the forward is ONE entry, whatever block, level or step it served)
         sym = {}
-        for label, cls, fl, ms in mid["launches"]:
-            k = sym.setdefault(symbol_key(label, cls), {"ms": 0.0, "gflop": 0.0, "launches": 0})
-            k["ms"] += ms; k["gflop"] += fl / 1e9; k["launches"] += 1
+        for label, cls, fl, ms, kname, nbytes in mid["launches"]:
+            k = sym.setdefault(kname, {"ms": 0.0, "gflop": 0.0, "gbyte": 0.0, "launches": 0})
+            k["ms"] += ms; k["gflop"] += fl / 1e9; k["gbyte"] += nbytes / 1e9; k["launches"] += 1
         for k in sym.values():
-            k["ms"] = round(k["ms"], 4); k["gflop"] = round(k["gflop"], 2)
-            k["tflops"] = round(k["gflop"] / k["ms"], 1) if k["gflop"] > 0 and k["ms"] > 0 else None
-            k["frac"] = round(k["tflops"] / peak, 5) if k["tflops"] else None
-        dom = max((k for k in kern if kern[k]["gflop"] > 0), key=lambda k: kern[k]["ms"])
-        ach = kern[dom]["gflop"] / kern[dom]["ms"]                   # GFLOP / ms == TFLOP/s
-        dom_launch_ms = kern[dom]["ms"] / kern[dom]["launches"]
+            k["ms"] = round(k["ms"], 4); k["gflop"] = round(k["gflop"], 2); k["gbyte"] = round(k["gbyte"], 4)
+            k["bound"], k["achieved"], _, k["unit"], k["frac"] = nearer_roof(k["gflop"], k["gbyte"], k["ms"], peak)
+        dom = max(sym, key=lambda k: sym[k]["ms"])                   # the device kernel the forward spends most time in
+        d = sym[dom]
+        bound, ach, rpeak, runit, rfrac = nearer_roof(d["gflop"], d["gbyte"], d["ms"], peak)
+        dom_launch_ms = d["ms"] / d["launches"]
         whole = ips / world * flops_img / 1e12
         from cfen_vit_dehazing_amd.parallel import split_slab
         check = self_check(net, x, split_slab(slabs[(args.steps - 1) & 1], B, n), cfg, args.dtype)   # what the last timed step wrote
+        if gather is not None:
+            # the GATHERED buffer of the last timed step, rank by rank: segment r must be rank r's images (synthetic_input seeds r * B ...), so its
+            # first image is checked against a batch-1 eager forward of that image computed here -- an ordering bug of the all-gather /
+            # merge_gathered on real RCCL shows up in the scaling run itself (reference analogue: nn.DataParallel's gather, v3:77-83)
+            from cfen_vit_dehazing_amd.parallel import merge_gathered
+            torch.cuda.synchronize()
+            merged = merge_gathered(gather.bufs[(args.steps - 1) & 1].float(), world, B, n)
+            per_rank = []
+            for r in range(world):
+                xi = synthetic_input(1, cfg, seed0=r * B).to(dev)
+                one = net(xi)
+                per_rank.append(round(max(float((m[r * B:r * B + 1] - o).abs().max()) for m, o in zip(merged, one)), 6))
+            check["gathered_image0_of_rank_vs_batch1_eager"] = per_rank
+            check["ok"] = check["ok"] and all(v <= check["bar"] for v in per_rank)
         result = {
             "metric": "images/sec @512x512 n_feats=24", "value": round(ips, 2), "unit": "images/sec", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_step, 3), "higher_is_better": True,
@@ -338,15 +360,20 @@ def main():
                        "global_batch": world * B, "parallelism": "dp%d" % world, "graph": graphs is not None,
                        "gather_dtype": (gdt if world > 1 else None),
                        "gflop_per_image": round(flops_img / 1e9, 2)},
-            "roofline": {"bound": "mfma", "kernel": "%s [%s]" % (dom, KERNEL_OF_STEP.get(dom.split(":")[-1], "?")),
-                         "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s",
-                         "frac": round(ach / peak, 5), "traffic": pmc_traffic(dom), "traffic_from_profiles": pmc_traffic(dom),
-                         "traffic_source": "newest committed profiles/r*_pmc_traffic.json (separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of "
-                                           "this command, fetch x2 per the gfx950 guide); a cross-reference, not measured in this run",
-                         "launch_ms": round(dom_launch_ms, 4), "launches_per_step": kern[dom]["launches"],
-                         "algorithmic_gflop_per_launch": round(kern[dom]["gflop"] / kern[dom]["launches"], 2),
+            "roofline": {"bound": bound, "kernel": dom, "achieved": ach, "peak": rpeak, "unit": runit, "frac": rfrac,
+                         "traffic": None,
+                         "traffic_from_profiles": pmc_traffic(dom),
+                         "traffic_source": "`traffic` is not measured in this run (null); traffic_from_profiles = HBM bytes per launch of this kernel in the "
+                                           "newest committed profiles/r*_pmc_traffic.json (separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this "
+                                           "command, fetch x2 per the gfx950 guide)",
+                         "launch_ms": round(dom_launch_ms, 4), "launches_per_step": d["launches"],
+                         "algorithmic_gflop_per_launch": round(d["gflop"] / d["launches"], 2),
+                         "algorithmic_gbyte_per_launch": round(d["gbyte"] / d["launches"], 4),
+                         "mfma_frac": round(d["gflop"] / d["ms"] / peak, 5),
+                         "how": "the device kernel with the largest summed launch time in a profiled forward (HIP events on the launch stream around "
+                                "every launch, median of three forwards); achieved = its algorithmic flops or bytes / that time, whichever roof is nearer",
                          "whole_forward_tflops": round(whole, 2), "whole_forward_frac": round(whole / peak, 5)},
-            "timing": {"repetitions": len(reps), "timed_seconds": round(sum(reps), 3), "ms_per_step_min": round(srt[0] / args.steps * 1e3, 3),
+            "timing": {"method": "value = the MEDIAN of the repetitions of the K-step timed region", "repetitions": len(reps), "timed_seconds": round(sum(reps), 3), "ms_per_step_min": round(srt[0] / args.steps * 1e3, 3),
                        "ms_per_step_max": round(srt[-1] / args.steps * 1e3, 3)},
             "self_check": check,
             "kernel_classes": classes,

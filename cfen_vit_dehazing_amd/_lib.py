@@ -85,12 +85,14 @@ SIGNATURES = {
                               ctypes.POINTER(ctypes.c_int32), _I]),
     "cfen_net_profile_entry": (_I, [_P, _I, ctypes.POINTER(c_char_p), ctypes.POINTER(ctypes.c_int32), ctypes.POINTER(ctypes.c_double),
                                     ctypes.POINTER(ctypes.c_double)]),
+    "cfen_net_profile_entry_kernel": (_I, [_P, _I, ctypes.POINTER(c_char_p), ctypes.POINTER(ctypes.c_double)]),
     "cfen_net_stage": (_I, [_P, c_char_p, ctypes.POINTER(_P)] + [ctypes.POINTER(ctypes.c_int32)] * 4),
     "cfen_net_flops_per_image": (ctypes.c_double, [_P]),
     "cfen_net_chain_error_words": (_I, [_P, ctypes.POINTER(_P), _I]),
     "cfen_gemm_nt": (_I, [_I, _P, _I, _P, _I, _P, _P, _I, _P, _I, _P, _I, _I, _I, _I, _I, _P]),
     "cfen_gemm_ln": (_I, [_I, _P, _I, _P, _I, _P, _P, _P, _I, _I, _I, _I, _I, ctypes.c_float, _P]),
     "cfen_gemm_splitk": (_I, [_I, _P, _I, _P, _I, _P, _P, _P, _I, _P, _I, _I, _I, _I, _I, _I, _P, c_size_t, _P]),
+    "cfen_head_conv5": (_I, [_I, _I, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P]),
     "cfen_gemm_chain": (_I, [_I, ctypes.POINTER(ChainArgsC), _I, _P]),
     "cfen_embed_gather": (_I, [_I, _P, _I, _I, _I, _I, _I, _I, _I, _P, _I, _P, _P, _I, _P, _I, _P]),
     "cfen_u8hwc_to_nhwc": (_I, [_I, _P, _P, _I, _I, _I, _I, _P]),

@@ -48,6 +48,11 @@ int cfen_zero_async(void* p, size_t bytes, hipStream_t s) {
   return CFEN_OK;
 }
 
+std::string& cfen_kernel_log() {
+  static thread_local std::string log;
+  return log;
+}
+
 hipError_t& cfen_last_launch() {
   static thread_local hipError_t e = hipSuccess;
   return e;
@@ -77,6 +82,11 @@ int cfen_gemm_splitk(int dtype, const void* X, int ldx, const void* W, int ldw, 
   const CfenGemmPtrs q{X, W, bias, R, nullptr, Y, nullptr, lnf_s};
   float* ws = (float*)scratch;
   return cfen_gemm_impl_g(dtype, 1, &q, ldx, ldw, ldr, 1, ldy, M, N, K, relu, nullptr, (hipStream_t)stream, &ws, scratch_bytes, nullptr, nsplit);
+}
+
+int cfen_head_conv5(int dtype, int in_u8, const void* in, const void* w5, const float* scale, const float* shift, void* out, int B, int H, int W,
+                    int cs_out, int act, void* stream) {
+  return cfen_head5_impl(dtype, in_u8, in, w5, scale, shift, out, B, H, W, cs_out, act, (hipStream_t)stream);
 }
 
 int cfen_gemm_chain(int dtype, const cfen_chain_args* a, int team, void* stream) {
@@ -331,8 +341,9 @@ int cfen_tune(const char* key, int value) {
     cfen_tune_gvit_team() = value;
     return CFEN_OK;
   }
+  if (!strcmp(key, "net.head5")) { cfen_tune_head5() = value != 0; return CFEN_OK; }
   if (!strcmp(key, "gvit.debug")) { cfen_tune_gvit_debug() = value; return CFEN_OK; }
-  if (!strcmp(key, "net.gvit_chain")) { cfen_tune_gvit_chain() = value != 0; return CFEN_OK; }
+  if (!strcmp(key, "net.gvit_chain")) { cfen_tune_gvit_chain() = value; return CFEN_OK; }   // 0 off, 1 every GViT block, 2 the grouped decoder launches only, 3 the encoder blocks only
   if (!strcmp(key, "net.embed_gather")) {
     cfen_tune_embed_gather() = value != 0;
     return CFEN_OK;

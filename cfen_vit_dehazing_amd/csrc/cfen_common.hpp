@@ -214,8 +214,22 @@ static inline hipError_t cfen_launch(void (*kernel)(KArgs...), dim3 grid, dim3 b
   return cfen_add_node(kernel, grid, block, smem, s, packed, std::index_sequence_for<KArgs...>{});
 }
 
+// every launch leaves the kernel's name (the template expression as written at the launch site) in a thread-local log: cfen_net_profile
+// attributes its per-launch times to DEVICE KERNELS with it (bench.py `by_symbol`), not to whatever the host code calls the step
+#include <string>
+std::string& cfen_kernel_log();
+static inline void cfen_log_kernel(const char* name) {
+  std::string& l = cfen_kernel_log();
+  if (l.size() > 400) return;
+  std::string n(name);
+  while (!n.empty() && (n.front() == '(' || n.front() == ' ')) n.erase(n.begin());
+  while (!n.empty() && (n.back() == ')' || n.back() == ' ')) n.pop_back();
+  if (l.find(n) != std::string::npos) return;
+  if (!l.empty()) l += " + ";
+  l += n;
+}
 #define CFEN_LAUNCH(kernel, grid, block, smem, stream, ...) \
-  cfen_last_launch() = cfen_launch(kernel, grid, block, smem, stream, __VA_ARGS__)
+  (cfen_log_kernel(#kernel), cfen_last_launch() = cfen_launch(kernel, grid, block, smem, stream, __VA_ARGS__))
 
 #define CFEN_CHECK_LAUNCH(what)                                                    \
   do {                                                                             \

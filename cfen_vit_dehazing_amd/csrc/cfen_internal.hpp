@@ -152,3 +152,8 @@ int& cfen_tune_gvit_team();     // workgroups per GViT block of the persistent c
 int& cfen_tune_gvit_chain();    // 1 (default): GViT blocks run their GEMMs as persistent chains where the net holds fragment-stream weights ("net.gvit_chain")
 int& cfen_tune_gvit_debug();    // timing experiments on the chain kernel, results invalid ("gvit.debug")
 int& cfen_tune_gemm_splitk_release();   // A/B: release fence in every split-K slice ("gemm.splitk_release")
+// head.0.0 (conv 5x5, 3 -> 12 channels) read straight from the fp32 NCHW input or the uint8 HWC image (k_head5.hip); w5 = packing.pack_head5
+bool cfen_head5_supported(int dtype, int Cout_pad, int cs_out, int H, int W);
+int cfen_head5_impl(int dtype, int in_u8, const void* in, const void* w5, const float* scale, const float* shift, void* out, int B, int H, int W,
+                    int cs_out, int act, hipStream_t s);
+int& cfen_tune_head5();   // 1 (default): the input layout pass and head.0.0 run as one k_head5 launch where it applies ("net.head5")

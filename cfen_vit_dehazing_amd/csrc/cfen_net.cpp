@@ -27,6 +27,7 @@ int& cfen_tune_gvit_dummy_wgs() { static int v = 0; return v; }
 int& cfen_tune_gvit_dummy_us() { static int v = 100; return v; }
 int& cfen_tune_gvit_dummy_stream() { static int v = 0; return v; }
 int& cfen_tune_gvit_chain() { static int v = 1; return v; }   // only nets built with fragment-stream GViT weights (cfg.reserved bit 2) can use it
+int& cfen_tune_head5() { static int v = 1; return v; }
 int& cfen_tune_ln_fold() {
   static int v = 1;
   return v;
@@ -135,6 +136,7 @@ struct cfen_net {
   bool gvit_stream = false;        // cfg.reserved bit 2: GViT weights are also held as fragment streams (packing.pack_stream_tiles) -> persistent chains
   int gv_launch = 0;               // persistent-chain launches enqueued so far in this forward (each takes its own barrier word)
   static constexpr int GV_SYNC_WORDS = 1024, GV_ERR_WORD = 512;
+  bool head5 = false;              // head.0.0 can run on k_head5 (reads the network input itself)
   bool wtile = false;              // cfg.reserved bit 1: GViT weights are packed tile-major (CfenGemmPtrs::wtile, packing.pack_wtile)
   size_t wbytes(const Vit& v, int N, int K) const { return (size_t)(v.global && wtile ? cfen_round_up(N, 96) : N) * K * esz; }
   int full = 0;                    // image edge
@@ -180,18 +182,25 @@ struct cfen_net {
   }
   // optional per-launch timing (cfen_net_profile): one event pair per launch, tagged with a class
   bool profiling = false;
-  struct Rec { int cls; double flops; hipEvent_t a, b; std::string label; double ms; };
+  struct Rec { int cls; double flops; hipEvent_t a, b; std::string label; double ms; std::string kernel; double bytes; };
+  double prof_bytes = 0.0;               // algorithmic bytes of the launch about to be enqueued (weight-streaming GEMMs set it; consumed by prof_begin)
   std::vector<Rec> recs, last_profile;   // last_profile: per-launch detail of the latest cfen_net_profile
   std::string label;                     // what the launches being enqueued belong to (layer / block step)
   int prof_begin(int cls, double flops) {
     if (!profiling) return -1;
-    Rec r; r.cls = cls; r.flops = flops; r.label = label; r.ms = 0;
+    Rec r; r.cls = cls; r.flops = flops; r.label = label; r.ms = 0; r.bytes = prof_bytes;
+    prof_bytes = 0.0;
+    cfen_kernel_log().clear();
     if (hipEventCreate(&r.a) != hipSuccess || hipEventCreate(&r.b) != hipSuccess) return -1;
     (void)hipEventRecord(r.a, stream);
     recs.push_back(r);
     return (int)recs.size() - 1;
   }
-  void prof_end(int id) { if (id >= 0) (void)hipEventRecord(recs[id].b, stream); }
+  void prof_end(int id) {
+    if (id < 0) return;
+    (void)hipEventRecord(recs[id].b, stream);
+    recs[id].kernel = cfen_kernel_log();
+  }
 
   size_t alloc(size_t bytes) {
     size_t off = ws_bytes;
@@ -373,6 +382,8 @@ int cfen_net::build() {
   // ---- convolution layers ----
   const int h = cfs ? nf : nf / 2;
   add_conv("head.0.0", 0, 5, 1, 2, 0, 1, 3, h, full);
+  head5 = cfen_head5_supported(cfg.dtype, convs.at("head.0.0").Cout_pad, cs_of(h), full, full);
+  if (head5) need("head.0.0.w5", (size_t)16 * 160 * esz);   // the 5x5 kernel with 8-byte pixels (k_head5.hip), beside the rows layout the A/B twin reads
   add_conv("head.0.1.body.0", 0, 3, 1, 1, 0, 1, h, h, full);
   add_conv("head.0.1.body.2", 0, 3, 1, 1, 0, 1, h, h, full);
   if (!cfs) add_conv("ds_conv_e01", 0, 3, 2, 1, 0, 1, h, nf, N);
@@ -596,6 +607,8 @@ int cfen_net::run_vit_g(int ng, const VitCall* vc, int scr0) {
                            pname ? P(nm[g] + pname) : nullptr, Y[g], tg ? IN[g] : nullptr, nullptr, v.global && wtile};
     return cfen_gemm_impl_g(dt, ng, gp, K, K, N, v.S, N, M, N, K, relu, tg, stream, v.global ? SK : nullptr, v.global ? SPLITK_BYTES : 0);
   };
+  // algorithmic bytes of a token GEMM launch: weights once + tokens in + tokens out (what a weight-streaming GEMM is priced against)
+  auto gemm_bytes = [&](int N, int K) { prof_bytes = (double)ng * ((double)N * K + (double)M * K + (double)M * N) * esz; };
   // Y = act(LN(X) W0^T + b0) with the LayerNorm folded: parameters `lname`.wl / .s / .bl (packing.ln_folded)
   auto gemm_ln = [&](const void* const* X, const std::string& lname, void* const* Y, int N, int K, int relu) -> int {
     CfenGemmPtrs gp[3];
@@ -604,7 +617,7 @@ int cfen_net::run_vit_g(int ng, const VitCall* vc, int scr0) {
                            v.global && wtile};
     return cfen_gemm_impl_g(dt, ng, gp, K, K, N, v.S, N, M, N, K, relu, nullptr, stream, v.global ? SK : nullptr, v.global ? SPLITK_BYTES : 0);
   };
-  if (v.chain && cfen_tune_gvit_chain()) {
+  if (v.chain && (cfen_tune_gvit_chain() == 1 || (cfen_tune_gvit_chain() == 2 && ng > 1) || (cfen_tune_gvit_chain() == 3 && ng == 1))) {
     // GViT block: pooled patch tokens -> [embed -> qkv] -> attention -> [proj -> ffn1 -> ffn2 -> head1 -> head2 + fold] -> x4 bilinear; the two
     // bracketed runs are ONE persistent launch each (k_gvit.hip): a team of workgroups per block keeps its CUs over the whole run
     const int team = std::min(cfen_tune_gvit_team(), 256 / ng);
@@ -703,6 +716,7 @@ int cfen_net::run_vit_g(int ng, const VitCall* vc, int scr0) {
       TRYP(K_TOKEN, 0, cfen_patchify_impl_g(dt, ng, IN, X0, B, v.mapH, v.mapH, v.C, bi.cs, v.ws, v.p, v.global ? 4 : 1, 0, stream));
       // x = linear_encoding(x) + x + pos                                      (v3:1143,1166)
       step("embed");
+      gemm_bytes(v.D, v.D);
       TRYP(K_GEMM, 2 * Md * D * D, gemm(cX0, ".embed.w", ".embed.b", X0, ".pos", X1, v.D, v.D, 0, nullptr));
     } else {
       // LViT: the window / patch gather rides on the embedding GEMM's loader, no token buffer is written
@@ -713,6 +727,7 @@ int cfen_net::run_vit_g(int ng, const VitCall* vc, int scr0) {
     // src = src + out_proj(MHA(LN1(src)))                                      (v3:1383-1386)
     if (v.ln_fold1 && cfen_tune_ln_fold()) {
       step("ln1_qkv");
+      gemm_bytes(3 * v.Da, v.D);
       TRYP(K_GEMM, 6 * Md * D * D, gemm_ln(cX1, ".qkv", QKV, 3 * v.Da, v.D, 0));
     } else {
       step("ln1");
@@ -751,6 +766,7 @@ int cfen_net::run_vit_g(int ng, const VitCall* vc, int scr0) {
   }
   if (!v.fused_mlp) {
     step("proj");
+    gemm_bytes(v.D, v.Da);
     TRYP(K_GEMM, 2 * Md * D * D, gemm(cATT, ".proj.w", nullptr, X1, nullptr, X1, v.D, v.Da, 0, nullptr));
   }
   if (v.fused_mlp) {
@@ -774,6 +790,7 @@ int cfen_net::run_vit_g(int ng, const VitCall* vc, int scr0) {
     const void* const* cHID = cHIDp;
     if (v.ln_fold2 && cfen_tune_ln_fold()) {
       step("ln2_ffn1");
+      gemm_bytes(v.hidden, v.D);
       TRYP(K_GEMM, 2 * Md * D * Hd, gemm_ln(cX1, ".ffn1", HID, v.hidden, v.D, 1));
     } else {
       step("ln2");
@@ -783,15 +800,18 @@ int cfen_net::run_vit_g(int ng, const VitCall* vc, int scr0) {
       TRYP(K_GEMM, 2 * Md * D * Hd, gemm(cYN, ".ffn1.w", ".ffn1.b", nullptr, nullptr, HID, v.hidden, v.D, 1, nullptr));
     }
     step("ffn2");
+    gemm_bytes(v.D, v.hidden);
     TRYP(K_GEMM, 2 * Md * D * Hd, gemm(cHID, ".ffn2.w", ".ffn2.b", X1, nullptr, X1, v.D, v.hidden, 0, nullptr));
     // x = mlp_head(x) + x                                                      (v3:1173)
     step("head1");
+    gemm_bytes(v.hidden, v.D);
     TRYP(K_GEMM, 2 * Md * D * Hd, gemm(cX1, ".head1.w", ".head1.b", nullptr, nullptr, HID, v.hidden, v.D, 1, nullptr));
     const void* dst[3];
     for (int g = 0; g < ng; ++g) dst[g] = v.global ? SM[g] : OUT[g];
     if (cfen_tune_fold_in_gemm()) {
       // x = mlp_head(x) + x, folded: the GEMM's epilogue writes feature (i, j, c) of token m to its pixel of the map   (v3:1173, 1186)
       step("head2_fold");
+      gemm_bytes(v.D, v.hidden);
       CfenGemmPtrs gp[3];
       for (int g = 0; g < ng; ++g)
         gp[g] = CfenGemmPtrs{HID[g], P(nm[g] + ".head2.w"), Pf(nm[g] + ".head2.b"), X1[g], nullptr, X0[g], nullptr, nullptr, v.global && wtile,
@@ -951,7 +971,15 @@ int cfen_net::forward(const float* x, float* xr, float* xs, float* xd) {
   for (int k = 1; k < 6; k += 2) TRY(cfen_zero_async(at(scr_set[k].sync), GV_ERR_WORD * sizeof(unsigned), stream));
   gv_launch = 0;
   const Buf& bin = bufs.at("input");
-  if (input_u8) {
+  const bool use_head5 = head5 && cfen_tune_head5() && !cfen_tune_head_fused();
+  if (use_head5) {
+    // the input layout pass and head.0.0 in ONE launch: the conv stages its halo straight from the fp32 NCHW tensor / the uint8 HWC image
+    const ConvLayer& c = convs.at("head.0.0");
+    label = "head.0.0 (from the network input)";
+    TRYP(K_CONV, B * 2.0 * c.Cout * (double)c.Cin_real * c.k * c.k * (double)full * full,
+         cfen_head5_impl(dt, input_u8, x, P("head.0.0.w5"), Pf("head.0.0.scale"), Pf("head.0.0.shift"), map_ptr("head.conv5"), B, full, full,
+                         bufs.at("head.conv5").cs, 0, stream));
+  } else if (input_u8) {
     label = "input:u8hwc_to_nhwc";
     TRYP(K_TOKEN, 0, cfen_u8hwc_to_nhwc_impl(dt, (const unsigned char*)x, map_ptr("input"), B, full, full, bin.cs, stream));
   } else {
@@ -973,7 +1001,7 @@ int cfen_net::forward(const float* x, float* xr, float* xs, float* xd) {
                                           P("head.0.1.body.0.wr"), Pf("head.0.1.body.0.scale"), Pf("head.0.1.body.0.shift"), P("head.0.1.body.2.wr"),
                                           Pf("head.0.1.body.2.scale"), Pf("head.0.1.body.2.shift"), B, full, full, stream));
   } else {
-    TRY(run_conv("head.0.0", "input", nullptr, nullptr, nullptr, 0, "head.conv5", nullptr));
+    if (!use_head5) TRY(run_conv("head.0.0", "input", nullptr, nullptr, nullptr, 0, "head.conv5", nullptr));
     TRY(run_conv("head.0.1.body.0", "head.conv5", nullptr, nullptr, nullptr, 1, "head.res_mid", nullptr));
     TRY(run_conv("head.0.1.body.2", "head.res_mid", nullptr, "head.conv5", nullptr, 0, "head", nullptr));
   }
@@ -1167,6 +1195,15 @@ int cfen_net_profile_entry(const cfen_net* net, int index, const char** label, i
   if (kernel_class) *kernel_class = r.cls;
   if (flops) *flops = r.flops;
   if (ms) *ms = r.ms;
+  return CFEN_OK;
+}
+
+int cfen_net_profile_entry_kernel(const cfen_net* net, int index, const char** kernel, double* bytes) {
+  CFEN_CHECK_ARG(net && index >= 0, "net_profile_entry_kernel: bad arguments");
+  if ((size_t)index >= net->last_profile.size()) return CFEN_ERR_STATE;
+  const cfen_net::Rec& r = net->last_profile[(size_t)index];
+  if (kernel) *kernel = r.kernel.c_str();
+  if (bytes) *bytes = r.bytes;
   return CFEN_OK;
 }
 

@@ -290,7 +290,7 @@ __global__ __launch_bounds__(256) void k_attention_win(PtrG<const T> QKVg, PtrG<
     }
     float mx = -1e30f;
 #pragma unroll
-    for (int t = 0; t < NKT; ++t) mx = fmaxf(fmaxf(mx, fmaxf(st[t][0], st[t][1])), fmaxf(st[t][2], st[t][3]));
+    for (int t = 0; t < NKT; ++t) mx = fmaxf(fmaxf(fmaxf(fmaxf(mx, st[t][0]), st[t][1]), st[t][2]), st[t][3]);   // chains of two: v_max3_f32
     mx = col_max(mx);
     const float mc = -mx * c;
     float rs = 0.f;
@@ -399,7 +399,7 @@ __global__ __launch_bounds__(256) void k_attention_hm(PtrG<const half_t> QKVg, P
       st[t] = Mma<half_t>::mma(*reinterpret_cast<const half8*>(Kl + (t * 16 + r16) * KP + h * 16), qf, floatx4{0.f, 0.f, 0.f, 0.f});
     float mx = -1e30f;
 #pragma unroll
-    for (int t = 0; t < NKT; ++t) mx = fmaxf(fmaxf(mx, fmaxf(st[t][0], st[t][1])), fmaxf(st[t][2], st[t][3]));
+    for (int t = 0; t < NKT; ++t) mx = fmaxf(fmaxf(fmaxf(fmaxf(mx, st[t][0]), st[t][1]), st[t][2]), st[t][3]);   // chains of two: v_max3_f32
     mx = col_max(mx);
     const float mc = -mx * c;
 #pragma unroll
@@ -521,7 +521,7 @@ __global__ __launch_bounds__(NW * 64) void k_attention_hm_long(PtrG<const half_t
       for (int j = 0; j < 2; ++j) {
         float mx = -1e30f;
 #pragma unroll
-        for (int t = 0; t < NKB; ++t) mx = fmaxf(fmaxf(mx, fmaxf(st[t][j][0], st[t][j][1])), fmaxf(st[t][j][2], st[t][j][3]));
+        for (int t = 0; t < NKB; ++t) mx = fmaxf(fmaxf(fmaxf(fmaxf(mx, st[t][j][0]), st[t][j][1]), st[t][j][2]), st[t][j][3]);   // v_max3_f32 chains
         mx = fmaxf(col_max(mx), m[j]);
         const float alpha = __builtin_amdgcn_exp2f((m[j] - mx) * c);     // first block: exp2(-huge) = 0 on zero accumulators
         m[j] = mx;

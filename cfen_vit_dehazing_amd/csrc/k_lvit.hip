@@ -60,7 +60,8 @@ CFEN_DEV half8 lv_pack(floatx4 a, floatx4 b) {
 
 // ND = D / 16 (6); NW waves x TM token tiles of 16 = the 256 tokens of one window (16 x 1 at four waves per SIMD: the default; 8 x 2 at two;
 // 4 x 4 with one wave per SIMD and the whole 512-register file); 4 heads of 24
-template <int ND, int NW, int TM>
+template <int ND, int NW, int TM, int SM = 0>   // SM = 0: softmax denominator summed on the vector pipe; 1: on the matrix pipe (round 4; MEASURED SLOWER: 138 / 395 us against
+                                                // 131 / 381 us for 512 / 1536 windows, tools/bench_lvit_window.py -- "lvit.shape" = 3 runs it)
 __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(NW / 4, NW / 4))) void k_lvit_window(Grouped<LvitArgs> ga) {
   typedef half_t T;
   typedef half8 frag;
@@ -254,6 +255,7 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(NW / 4,
 
   // ---- attention, one head per chunk: Q_h = W_q[h] LN1(x) -> softmax(K_h Q_h^T) -> O_h -> x += W_p[:, h] O_h ----
   const float cs = a.scale_log2;
+  const frag ones = {(half_t)1, (half_t)1, (half_t)1, (half_t)1, (half_t)1, (half_t)1, (half_t)1, (half_t)1};
   const int li = lane & 15;
   const int vlane = (4 * h + (li >> 2)) * KVP + (li & 3) * 8;     // tr-read: lane 4q+p of a 16-lane group -> key row q, columns 4p..4p+3
 #pragma unroll 1
@@ -284,24 +286,32 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(NW / 4,
 #pragma unroll
       for (int t = 0; t < S / 16; ++t)
         st[t] = Mma<T>::mma(*reinterpret_cast<const frag*>(Kh + (t * 16) * KVP), qb, floatx4{0.f, 0.f, 0.f, 0.f});
-      float mx = -1e30f;
+      // row maximum: two chains of three-operand maxima (v_max3_f32: half the instructions of a two-operand tree; round 4)
+      float mx = -1e30f, mx2 = -1e30f;
 #pragma unroll
-      for (int t = 0; t < S / 16; ++t) mx = fmaxf(fmaxf(mx, fmaxf(st[t][0], st[t][1])), fmaxf(st[t][2], st[t][3]));
-      mx = col_max(mx);
+      for (int t = 0; t < S / 16; ++t) {
+        mx = fmaxf(fmaxf(mx, st[t][0]), st[t][1]);
+        mx2 = fmaxf(fmaxf(mx2, st[t][2]), st[t][3]);
+      }
+      mx = col_max(fmaxf(mx, mx2));
       const float mc = -mx * cs;
       float rs = 0.f;
 #pragma unroll
       for (int t = 0; t < S / 16; ++t)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          const float pv = __builtin_amdgcn_exp2f(fmaf(st[t][r], cs, mc));
-          st[t][r] = pv;
-          rs += pv;
+          st[t][r] = __builtin_amdgcn_exp2f(fmaf(st[t][r], cs, mc));
+          if constexpr (SM == 0) rs += st[t][r];
         }
+      // SM = 1: the softmax denominator comes off the matrix pipe (idle three quarters of this loop): an all-ones A fragment against the
+      // packed probabilities sums the 32 keys of a block for every query -- 8 MFMAs instead of 64 v_add_f32 and a cross-lane reduction, and
+      // the sum is over the SAME fp16-rounded probabilities the numerator uses
       floatx4 o[2] = {floatx4{0.f, 0.f, 0.f, 0.f}, floatx4{0.f, 0.f, 0.f, 0.f}};
+      floatx4 den = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
       for (int kb = 0; kb < S / 32; ++kb) {
         const frag pb = lv_pack(st[2 * kb], st[2 * kb + 1]);
+        if constexpr (SM == 1) den = __builtin_amdgcn_mfma_f32_16x16x32_f16(ones, pb, den, 0, 0, 0);
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
           const half4 lo = lv_read_tr4(Vh + (kb * 32) * KVP + i * 32);
@@ -310,7 +320,7 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(NW / 4,
           o[i] = __builtin_amdgcn_mfma_f32_16x16x32_f16(va, pb, o[i], 0, 0, 0);
         }
       }
-      const float inv = 1.f / col_sum(rs);
+      const float inv = 1.f / (SM == 1 ? den[0] : col_sum(rs));   // every row of `den` is the column (query) sum
       att[j] = lv_pack(o[0] * inv, o[1] * inv);              // rows d >= 24 of O^T are another head's values: W_p's columns for them are zero
     }
     // x += W_p[:, h] O_h
@@ -439,6 +449,8 @@ int cfen_lvit_window_impl_g(int dtype, int ng, const LvitArgs* ap, hipStream_t s
   CFEN_CHECK_ARG(blocks > 0 && blocks < (1ll << 31), "lvit_window: bad grid");
   if (cfen_tune_lvit_shape() == 2)
     CFEN_LAUNCH((k_lvit_window<6, 16, 1>), dim3((unsigned)blocks, 1, ng), dim3(1024), 0, s, ga);
+  else if (cfen_tune_lvit_shape() == 3)
+    CFEN_LAUNCH((k_lvit_window<6, 16, 1, 1>), dim3((unsigned)blocks, 1, ng), dim3(1024), 0, s, ga);
   else if (cfen_tune_lvit_shape() == 1)
     CFEN_LAUNCH((k_lvit_window<6, 4, 4>), dim3((unsigned)blocks, 1, ng), dim3(256), 0, s, ga);
   else

@@ -65,7 +65,10 @@ class DECVITDATA(torch.utils.data.Dataset):
             from ..parallel import shard_items
             if not opt.sb:
                 raise ValueError("multi-process inference needs --sb (the reference samples images randomly without it, dec_vit_data.py:51-58)")
-            limit = min(len(self.B_paths), int(min(opt.max_dataset_size, getattr(opt, 'how_many', float('inf')) * opt.batchSize)))
+            # (both bounds may be inf -- the default max_dataset_size and options without how_many: int(inf) would raise OverflowError)
+            import math
+            bound = min(opt.max_dataset_size, getattr(opt, 'how_many', float('inf')) * opt.batchSize)
+            limit = len(self.B_paths) if not math.isfinite(bound) else min(len(self.B_paths), int(bound))
             self.B_paths = shard_items(self.B_paths[:limit], world, rank)
         self.B_size = len(self.B_paths)
         self.transform = get_transform(opt)

@@ -317,7 +317,9 @@ class dec_ipt(nn.Module):
             detail, i = [], 0
             lab, cls, f, t = c_char_p_(), ctypes.c_int32(), ctypes.c_double(), ctypes.c_double()
             while lib.cfen_net_profile_entry(h, i, ctypes.byref(lab), ctypes.byref(cls), ctypes.byref(f), ctypes.byref(t)) == 0:
-                detail.append((lab.value.decode(), self.KERNEL_CLASSES[cls.value], f.value, t.value))
+                kn, by = c_char_p_(), ctypes.c_double()
+                lib.cfen_net_profile_entry_kernel(h, i, ctypes.byref(kn), ctypes.byref(by))
+                detail.append((lab.value.decode(), self.KERNEL_CLASSES[cls.value], f.value, t.value, (kn.value or b"?").decode(), by.value))
                 i += 1
             prof["launches"] = detail
         if init_actnorm:

@@ -45,6 +45,50 @@ class DECHLGVIT(BaseModel):
         # half the first batch runs through the exact-fp32 path once as well (reference loader: models/base_model.py:114-131)
         self._half_guard = getattr(opt, 'precision', 'single') == 'half' and not getattr(opt, 'no_half_guard', False)
 
+    def _guard_dir(self):
+        import os
+        o = self.opt
+        d = os.path.join(getattr(o, 'results_dir', './results/'), getattr(o, 'name', 'experiment'), '%s_%s' % (getattr(o, 'phase', 'test'), getattr(o, 'which_epoch', 'latest')))
+        os.makedirs(d, exist_ok=True)
+        return d
+
+    def _agree_on_worst(self, worst, timeout=120.0):
+        import os
+        import time
+        world, rank = getattr(self.opt, 'dist_world', 1), getattr(self.opt, 'dist_rank', 0)
+        if world <= 1:
+            return worst
+        if torch.distributed.is_available() and torch.distributed.is_initialized():
+            t = torch.tensor([worst if worst == worst else float('inf')], dtype=torch.float64, device=self.device)
+            torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+            return float(t.item())
+        d = self._guard_dir()
+        run = os.environ.get('TORCHELASTIC_RUN_ID', 'run')
+        with open(os.path.join(d, '.half_guard_%s_rank%d' % (run, rank)), 'w') as f:
+            f.write(repr(float(worst)))
+        vals, t_end = {}, time.time() + timeout
+        while len(vals) < world and time.time() < t_end:
+            for r in range(world):
+                p = os.path.join(d, '.half_guard_%s_rank%d' % (run, r))
+                if r not in vals and os.path.exists(p):
+                    txt = open(p).read().strip()
+                    if txt:
+                        vals[r] = float(txt)
+            if len(vals) < world:
+                time.sleep(0.05)
+        if len(vals) < world:      # a rank never reported: be safe, everyone who notices falls back
+            return float('inf')
+        return max(vals.values())
+
+    def _record_precision(self, chosen, worst):
+        import os
+        if getattr(self.opt, 'dist_rank', 0) == 0:
+            try:
+                with open(os.path.join(self._guard_dir(), 'precision.txt'), 'w') as f:
+                    f.write('precision: %s\nhalf_guard_max_abs: %r\nbar: %g\n' % (chosen, worst, self.HALF_GUARD_BAR))
+            except OSError as e:          # a read-only results directory must not cost the run
+                print('note: could not record the chosen precision (%s)' % e)
+
     def forward(self):
         if getattr(self, '_half_guard', False):
             self._half_guard = False
@@ -53,7 +97,12 @@ class DECHLGVIT(BaseModel):
             self.netG.set_compute_dtype('fp16')
             out = self.netG(self._net_in)
             worst = max(float((a - b).abs().max()) if bool(torch.isfinite(a).all()) else float('inf') for a, b in zip(out, ref))
+            # one process per GPU (test.py under torch.distributed.run): every rank looks at its OWN first image -- the ranks agree on the worst
+            # of them, so a result set is never silently mixed-precision.  Without a process group (the launcher is used for its environment
+            # only: every rank writes its own files) the decision goes through a file in the results directory.
+            worst = self._agree_on_worst(worst)
             self.half_guard_max_abs = worst
+            self._record_precision('single' if not worst <= self.HALF_GUARD_BAR else 'half', worst)
             if not worst <= self.HALF_GUARD_BAR:
                 print('warning: --precision half differs from the fp32 path by %.3g max-abs on the first batch (bar %.0e): this checkpoint is not '
                       'fp16-safe, continuing with --precision single' % (worst, self.HALF_GUARD_BAR))

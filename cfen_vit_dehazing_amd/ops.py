@@ -63,6 +63,22 @@ def gemm_splitk(x, w, nsplit, bias=None, residual=None, relu=False, lnf_s=None, 
     return out
 
 
+def head_conv5(x, w, bias, act=0):
+    """cfen_head_conv5: conv5x5 (pad 2) of the network input -- (B,3,H,W) fp32 NCHW or (B,H,W,3) uint8 -- to a (B,H,W,16) fp16 NHWC map;
+    w: (Cout <= 16, 3, 5, 5), bias: (Cout,)"""
+    from .packing import pack_head5
+    _cuda(x, w, bias)
+    u8 = x.dtype == torch.uint8
+    B, H, W = (x.shape[0], x.shape[1], x.shape[2]) if u8 else (x.shape[0], x.shape[2], x.shape[3])
+    w5 = pack_head5(w, torch.float16)
+    scale = torch.ones(16, dtype=torch.float32, device=x.device)
+    shift = torch.zeros(16, dtype=torch.float32, device=x.device)
+    shift[:bias.numel()] = bias.float()
+    out = torch.empty(B, H, W, 16, dtype=torch.float16, device=x.device)
+    check(_lib.load().cfen_head_conv5(1, int(u8), ptr(x), ptr(w5), ptr(scale), ptr(shift), ptr(out), B, H, W, 16, act, current_stream()), "head_conv5")
+    return out
+
+
 def gemm_chain(phases, M, team=48, fold=None, sync=None):
     """cfen_gemm_chain: a list of dependent GEMM phases in one persistent launch.  Every phase is a dict with x [M,K], w [N,K] (row-major; packed
     to a fragment stream here) or w_stream, y (preallocated output, [M,N] or the NHWC map when fold), and optionally bias, lnf_s, residual, pos,

@@ -94,6 +94,8 @@ class BaseOptions():
         from ..parallel import dist_env
         opt.dist_rank, opt.dist_world, local = dist_env()
         if opt.dist_world > 1:
+            if opt.gpu_ids != [local]:
+                print('[rank %d] torch.distributed.run: --gpu_ids %s overridden by LOCAL_RANK -> GPU %d' % (opt.dist_rank, opt.gpu_ids, local))
             opt.gpu_ids = [local]
         if len(opt.gpu_ids) > 0 and torch.cuda.is_available():
             torch.cuda.set_device(opt.gpu_ids[0])

@@ -366,6 +366,21 @@ def pack_conv7_toeplitz(w, dtype):
     return wz.reshape(1, 16, 7 * 10 * 16)
 
 
+def head5_supported(dtype, cout, H, W):
+    """mirror of cfen_head5_supported (csrc/k_head5.hip)"""
+    return dtype == torch.float16 and round_up(cout, 16) == 16 and cs_of(cout) == 16 and H % 8 == 0 and W % 64 == 0
+
+
+def pack_head5(w, dtype):
+    """Conv2d weight (Cout <= 16, 3, 5, 5) -> [16][5 dy][8 taps][4 c]: the layout of csrc/k_head5.hip (8-byte pixels: 3 channels + a zero; a kernel row
+    is one 64-byte MFMA chunk of 8 taps, taps 5..7 zero)"""
+    cout, cin, k, _ = w.shape
+    assert cin == 3 and k == 5 and cout <= 16
+    wp = torch.zeros(16, 5, 8, 4, dtype=dtype, device=w.device)
+    wp[:cout, :, :5, :3] = w.permute(0, 2, 3, 1).to(dtype)
+    return wp.reshape(-1)
+
+
 def pack_conv_weight_rows(w, cin_pad, dtype):
     """Conv2d weight (Cout<=16, Cin, k, k) -> [1][16][k*KSP*cin_pad]: tap-major, every kernel row padded with zero
     taps to a whole number of 64-byte chunks (KSP taps)."""
@@ -502,6 +517,8 @@ def pack_state_dict(sd, cfg: NetConfig, dtype=torch.float16, pending=None, wtile
             conv(g.name + ".shrink", g.name + ".conv_shrink.0", g.map_channels, an=g.name + ".conv_shrink.1")
             conv(g.name + ".extend", g.name + ".conv_extend.0", g.channels, an=g.name + ".conv_extend.1")
     conv("head.0.0", "head.0.0", 3, rows=(1, 2))
+    if head5_supported(dtype, sd["head.0.0.weight"].shape[0], full, full):
+        out["head.0.0.w5"] = pack_head5(sd["head.0.0.weight"], dtype)
     conv("head.0.1.body.0", "head.0.1.body.0", h, rows=(1, 1))
     conv("head.0.1.body.2", "head.0.1.body.2", h, rows=(1, 1))
     if not cfs:

@@ -28,10 +28,14 @@ def even_shard(total, world, rank):
 
 
 def dist_env():
-    """(rank, world, local_rank) of a process started by `python -m torch.distributed.run` (RANK / WORLD_SIZE / LOCAL_RANK); (0, 1, 0) when
-    started plainly.  Reads the environment only: safe before any GPU call."""
+    """(rank, world, local_rank) of a process started by `python -m torch.distributed.run`; (0, 1, 0) when started plainly.  The launcher exports
+    RANK, WORLD_SIZE and LOCAL_RANK together (and TORCHELASTIC_RUN_ID): a scheduler that sets only some of them (SLURM / k8s job arrays export
+    WORLD_SIZE or RANK for their own purposes) does NOT switch the sharded mode on.  Reads the environment only: safe before any GPU call."""
     import os
-    return int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("LOCAL_RANK", "0"))
+    env = os.environ
+    if not (all(k in env for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK")) or "TORCHELASTIC_RUN_ID" in env):
+        return 0, 1, 0
+    return int(env.get("RANK", "0")), int(env.get("WORLD_SIZE", "1")), int(env.get("LOCAL_RANK", "0"))
 
 
 def shard_items(items, world, rank):

@@ -107,6 +107,9 @@ int cfen_net_profile(cfen_net* net, const float* x, float* xr, float* xs, float*
  * the net, valid until the next profile), kernel class, algorithmic FLOPs, milliseconds.  Returns CFEN_ERR_STATE past
  * the last entry.                                                                                   */
 int cfen_net_profile_entry(const cfen_net* net, int index, const char** label, int32_t* kernel_class, double* flops, double* ms);
+/* ... and the DEVICE KERNEL(S) that launch ran (the kernel template as instantiated, e.g. "k_gemm_dma<T, 1, 3>"; several joined by " + ") with its
+ * algorithmic bytes where the net prices it against HBM (token GEMMs: weights + tokens in + tokens out; 0 otherwise) */
+int cfen_net_profile_entry_kernel(const cfen_net* net, int index, const char** kernel, double* bytes);
 /* device pointer + geometry of a named top-level stage output (SURVEY Appendix D names) inside the
  * workspace of the LAST forward; NHWC, element type = net dtype.                                  */
 int cfen_net_stage(const cfen_net* net, const char* name, const void** ptr, int32_t* C, int32_t* cs, int32_t* H, int32_t* W);
@@ -134,6 +137,12 @@ int cfen_gemm_ln(int dtype, const void* X, int ldx, const void* Wl, int ldw, con
  * ceil(N/96) * ceil(M/32) * nsplit * 14336 bytes of partial slabs.  K * element size / 128 must be divisible by nsplit.   (v3:1364, 1388-1389, 1173) */
 int cfen_gemm_splitk(int dtype, const void* X, int ldx, const void* W, int ldw, const float* lnf_s, const float* bias, const void* R, int ldr, void* Y,
                       int ldy, int M, int N, int K, int relu, int nsplit, void* scratch, size_t scratch_bytes, void* stream);
+/* head.0.0 read straight from the network input (csrc/k_head5.hip): out = act(conv5x5(in, pad 2) * scale + shift) as a 16-channel-stride NHWC
+ * CFEN_F16 map; in = (B,3,H,W) fp32 NCHW (in_u8 = 0: what model.set_input hands over, models/model_iid_dehazing.py:143) or (B,H,W,3) uint8
+ * (in_u8 = 1: ToTensor + Normalize(0.5, 0.5) folded in, data/base_dataset.py:44-46).  w5: [16][5][8][4] halfs (packing.pack_head5).  H % 8 == 0,
+ * W % 64 == 0.  Replaces cfen_nchw_to_nhwc / cfen_u8hwc_to_nhwc + cfen_conv2d for that layer (v3:123-127, common.py:11-14). */
+int cfen_head_conv5(int dtype, int in_u8, const void* in, const void* w5, const float* scale, const float* shift, void* out, int B, int H, int W,
+                    int cs_out, int act, void* stream);
 /* Persistent GEMM chain (csrc/k_gvit.hip): up to 5 DEPENDENT token GEMMs  y_p = act(x_p W_p^T + bias) + residual + pos[m % period]  (or the
  * LayerNorm-folded form of cfen_gemm_ln when lnf_s != NULL) run by ONE launch of `team` workgroups (one per CU) that keep their CUs and meet at a
  * grid barrier between phases -- the nn.Linear chains of a GViT instance: linear_encoding -> in_proj, and out_proj -> linear1 -> linear2 ->

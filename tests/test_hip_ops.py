@@ -944,3 +944,24 @@ def test_gemm_chain_gvit_block(B, S, D, H, heads, team):
     Y = HID2 @ w4.double().t() + bb4.double() + X3          # [M][D], feature (i, j, c)
     want = Y.reshape(B, tw, tw, 4, 4, C).permute(0, 1, 3, 2, 4, 5).reshape(B, mapH, mapH, C)
     close(sm, want, tol(dt, 40), "block output (folded map)")
+
+
+@pytest.mark.parametrize("u8", [False, True])
+@pytest.mark.parametrize("B,H,W", [(2, 64, 128), (1, 8, 64), (3, 24, 192)])
+def test_head_conv5_from_the_network_input(u8, B, H, W):
+    """k_head5: head.0.0 (5x5, 3 -> 12, zero padding 2, bias) straight from the fp32 NCHW input / the uint8 HWC image (ToTensor + Normalize(0.5, 0.5)
+    folded in) against F.conv2d on the fp16-rounded operands; borders, several tiles, padded channels exactly zero"""
+    d = dev()
+    w, bias = rnd((12, 3, 5, 5), 1, torch.float16, 0.2), rnd((12,), 2, torch.float32)
+    if u8:
+        img = torch.randint(0, 256, (B, H, W, 3), generator=torch.Generator().manual_seed(3), dtype=torch.uint8)
+        x = ((img.float() / 255 - 0.5) / 0.5).permute(0, 3, 1, 2)
+        got = ops.head_conv5(img.to(d), w.to(d), bias.to(d))
+    else:
+        x = torch.rand(B, 3, H, W, generator=torch.Generator().manual_seed(3)) * 2 - 1
+        got = ops.head_conv5(x.to(d).contiguous(), w.to(d), bias.to(d))
+    want = F.conv2d(x.half().double(), w.double(), bias.double(), padding=2).permute(0, 2, 3, 1)
+    close(got[..., :12], want, tol(torch.float16, 4), "conv5 from the input")
+    assert float(got[..., 12:].abs().max()) == 0.0
+    relu = ops.head_conv5((img if u8 else x).to(d).contiguous(), w.to(d), bias.to(d), act=1)
+    close(relu[..., :12], torch.relu(want), tol(torch.float16, 4), "with ReLU")

@@ -46,13 +46,13 @@ for B in (8, 24):
     tc, tf, tg = [], [], []
     for _ in range(7):
         tc.append(timed(chain))
-        ops.tune("lvit.shape", 0); tf.append(timed(fused))
-        ops.tune("lvit.shape", 1); tg.append(timed(fused))
+        ops.tune("lvit.shape", 2); tf.append(timed(fused))
+        ops.tune("lvit.shape", 3); tg.append(timed(fused))
     ops.tune("lvit.shape", 1)
     c = fused(); torch.cuda.synchronize()
     ops.tune("lvit.shape", 0)
     print("B=%d: 4-wave variant vs chain max-abs %.3e" % (B, float((a.float() - c.float()).abs().max())))
     tc.sort(); tf.sort(); tg.sort()
     fl = B * 7.95e9          # 7.95 GFLOP per level-1 instance and image
-    print("B=%d (%d windows): chain %.1f us (incl. torch allocations between its 3 launches), window kernel 8 waves x 2 tiles %.1f us = %.0f TF/s, "
-          "4 waves x 4 tiles %.1f us = %.0f TF/s" % (B, nwin, tc[3], tf[3], fl / tf[3] / 1e6, tg[3], fl / tg[3] / 1e6))
+    print("B=%d (%d windows): chain %.1f us (incl. torch allocations between its 3 launches), window kernel 16 waves, denominator on the vector pipe %.1f us = %.0f TF/s, "
+          "16 waves, denominator by MFMA %.1f us = %.0f TF/s" % (B, nwin, tc[3], tf[3], fl / tf[3] / 1e6, tg[3], fl / tg[3] / 1e6))

@@ -25,17 +25,23 @@ n = len(runs[0])
 rows = []
 for i in range(n):
     ms = sorted(r[i][3] for r in runs)[2]
-    rows.append((runs[0][i][0], runs[0][i][1], runs[0][i][2], ms))
+    rows.append((runs[0][i][0], runs[0][i][1], runs[0][i][2], ms, runs[0][i][4]))
 tot = sum(r[3] for r in rows)
 print("%d launches, sum %.3f ms (batch %d, %s, %dx%d, hidden_dim_ratio %d)" % (n, tot, B, dt, cfg.image_size, cfg.image_size, hdr))
-for lab, cls, fl, ms in rows:
-    print("%-42s %-9s %8.1f us %8s" % (lab, cls, ms * 1e3, ("%.0f TF" % (fl / ms / 1e9)) if fl else ""))
+for lab, cls, fl, ms, kn in rows:
+    print("%-42s %-9s %8.1f us %8s  %s" % (lab, cls, ms * 1e3, ("%.0f TF" % (fl / ms / 1e9)) if fl else "", kn))
 # aggregate by step kind
 agg = {}
-for lab, cls, fl, ms in rows:
+for lab, cls, fl, ms, kn in rows:
     key = (lab.split(":")[1] if ":" in lab else "conv") + (" L%s" % lab.split(":")[0][-2 if lab.split(":")[0][-1] in "rsd" else -1] if ":" in lab and "vit" in lab else "")
     key = ("G " if lab.startswith("global") else "L " if lab.startswith("local") else "") + key
     a = agg.setdefault(key, [0, 0.0, 0.0]); a[0] += 1; a[1] += ms; a[2] += fl
 print("---- by step")
 for k, (c, ms, fl) in sorted(agg.items(), key=lambda kv: -kv[1][1]):
     print("%-28s x%-3d %8.1f us  %5.1f%%  %s" % (k, c, ms * 1e3, 100 * ms / tot, ("%.0f TF" % (fl / ms / 1e9)) if fl else ""))
+print("---- by device kernel")
+byk = {}
+for lab, cls, fl, ms, kn in rows:
+    a = byk.setdefault(kn, [0, 0.0, 0.0]); a[0] += 1; a[1] += ms; a[2] += fl
+for k, (c, ms, fl) in sorted(byk.items(), key=lambda kv: -kv[1][1]):
+    print("%-60s x%-3d %8.1f us  %5.1f%%  %s" % (k, c, ms * 1e3, 100 * ms / tot, ("%.0f TF" % (fl / ms / 1e9)) if fl else ""))
