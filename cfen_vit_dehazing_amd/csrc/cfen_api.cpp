@@ -341,6 +341,9 @@ int cfen_tune(const char* key, int value) {
     cfen_tune_gvit_team() = value;
     return CFEN_OK;
   }
+  if (!strcmp(key, "net.tail_fused")) { cfen_tune_tail_fused() = value != 0; return CFEN_OK; }
+  if (!strcmp(key, "net.keep_stages")) { cfen_tune_keep_stages() = value != 0; return CFEN_OK; }
+  if (!strcmp(key, "net.resblock_fused")) { cfen_tune_resblock_fused() = value != 0; return CFEN_OK; }
   if (!strcmp(key, "net.head5")) { cfen_tune_head5() = value != 0; return CFEN_OK; }
   if (!strcmp(key, "gvit.debug")) { cfen_tune_gvit_debug() = value; return CFEN_OK; }
   if (!strcmp(key, "net.gvit_chain")) { cfen_tune_gvit_chain() = value; return CFEN_OK; }   // 0 off, 1 every GViT block, 2 the grouped decoder launches only, 3 the encoder blocks only

@@ -157,3 +157,20 @@ bool cfen_head5_supported(int dtype, int Cout_pad, int cs_out, int H, int W);
 int cfen_head5_impl(int dtype, int in_u8, const void* in, const void* w5, const float* scale, const float* shift, void* out, int B, int H, int W,
                     int cs_out, int act, hipStream_t s);
 int& cfen_tune_head5();   // 1 (default): the input layout pass and head.0.0 run as one k_head5 launch where it applies ("net.head5")
+// head.0.1 ResBlock (conv3x3 + ReLU + conv3x3 + skip) in one launch, the hidden map in LDS (k_fuse.hip); fp16, 16-channel-stride maps
+bool cfen_resblock_fused_supported(int dtype, int cs, int C, int H, int W);
+int cfen_resblock_fused_impl(int dtype, const void* in, void* out, const void* wa, const float* sa, const float* ta, const void* wb, const float* sb,
+                             const float* tb, int B, int H, int W, hipStream_t s);
+int& cfen_tune_resblock_fused();   // 1 (default): the head's ResBlock runs as one k_resblock_fused launch where it applies ("net.resblock_fused")
+// us_conv_d01* (ConvTranspose 24 -> 12 + ActNorm + ReLU) + the tail's 3x3 in one grouped launch, the map between them in LDS (k_fuse.hip)
+struct CfenUpConv3 {
+  const void* in; int B, Hin, Win, cs_in;                      // (B, Hin, Win, cs_in) fp16 map, cs_in * 2 <= 64 bytes
+  const void* wT; const float* sT; const float* tT; int actT;  // ConvTranspose: "<layer>.wr" [4][16][4 x 32], epilogue table, activation
+  const void* w3; const float* s3; const float* t3; int act3;  // 3x3: "<layer>.wr" [16][3][2][32]
+  void* out;                                                   // (B, 2 Hin, 2 Win, 16) output of the 3x3
+  void* up_out;                                                // optional: the ConvTranspose output map (same shape), written for parity tests
+};
+bool cfen_up_conv3_fused_supported(int dtype, int cs_in, int Cup_pad, int cs_up, int C3_pad, int Hin, int Win);
+int cfen_up_conv3_fused_impl_g(int dtype, int ng, const CfenUpConv3* u, hipStream_t s);
+int& cfen_tune_tail_fused();     // 1 (default): us_conv_d01* + tail conv3 run as one k_up_conv3_fused launch where it applies ("net.tail_fused")
+int& cfen_tune_keep_stages();    // 1: fused launches also store the stage maps they keep on chip (us_conv_d01*), for parity tests ("net.keep_stages"; default 0)

@@ -27,6 +27,9 @@ int& cfen_tune_gvit_dummy_wgs() { static int v = 0; return v; }
 int& cfen_tune_gvit_dummy_us() { static int v = 100; return v; }
 int& cfen_tune_gvit_dummy_stream() { static int v = 0; return v; }
 int& cfen_tune_gvit_chain() { static int v = 1; return v; }   // only nets built with fragment-stream GViT weights (cfg.reserved bit 2) can use it
+int& cfen_tune_tail_fused() { static int v = 1; return v; }
+int& cfen_tune_keep_stages() { static int v = 0; return v; }
+int& cfen_tune_resblock_fused() { static int v = 1; return v; }
 int& cfen_tune_head5() { static int v = 1; return v; }
 int& cfen_tune_ln_fold() {
   static int v = 1;
@@ -136,6 +139,7 @@ struct cfen_net {
   bool gvit_stream = false;        // cfg.reserved bit 2: GViT weights are also held as fragment streams (packing.pack_stream_tiles) -> persistent chains
   int gv_launch = 0;               // persistent-chain launches enqueued so far in this forward (each takes its own barrier word)
   static constexpr int GV_SYNC_WORDS = 1024, GV_ERR_WORD = 512;
+  bool stages_on_chip = false;     // the last forward kept the us_conv_d01* maps in LDS (k_up_conv3_fused without "net.keep_stages"): cfen_net_stage refuses them
   bool head5 = false;              // head.0.0 can run on k_head5 (reads the network input itself)
   bool wtile = false;              // cfg.reserved bit 1: GViT weights are packed tile-major (CfenGemmPtrs::wtile, packing.pack_wtile)
   size_t wbytes(const Vit& v, int N, int K) const { return (size_t)(v.global && wtile ? cfen_round_up(N, 96) : N) * K * esz; }
@@ -882,6 +886,20 @@ int cfen_net::run_level_g(int ng, const char* tags, int l, const std::string* in
 int cfen_net::run_decoder(float* const* outs, hipStream_t sm, hipStream_t sg) {
   const int dt = cfg.dtype, B = cfg.batch;
   static const char* tags = "rsd";
+  bool tail_fused = false;
+  stages_on_chip = false;
+  auto tail_fusable = [&]() {
+    if (cfs || !cfen_tune_tail_fused() || !an_pending.empty() || dt != CFEN_F16) return false;
+    for (int g = 0; g < 3; ++g) {
+      const std::string T = std::string("tail_") + (char)(tags[g] - 32);
+      const ConvLayer& cu = convs.at(std::string("us_conv_d01") + tags[g]);
+      const ConvLayer& cc = convs.at(T + ".conv3");
+      const Buf& bi = bufs.at(std::string("lgcat_conv_d01") + tags[g]);
+      if (!cu.tile || !cc.tile || !cfen_up_conv3_fused_supported(dt, bi.cs, cu.Cout_pad, bufs.at(std::string("us_conv_d01") + tags[g]).cs, cc.Cout_pad, bi.H, bi.W))
+        return false;
+    }
+    return true;
+  };
   auto names = [](const std::string& base, std::string* o) { for (int g = 0; g < 3; ++g) o[g] = base + tags[g]; };
   stream = sm;
   std::string in[3], out[3], up[3];
@@ -933,6 +951,10 @@ int cfen_net::run_decoder(float* const* outs, hipStream_t sm, hipStream_t sg) {
       break;
     }
     names("us_conv_d0" + L, up);
+    if (l == 1 && tail_fusable()) {
+      tail_fused = true;      // us_conv_d01* runs inside the tails' first launch below (k_up_conv3_fused)
+      break;
+    }
     ConvCall c[3];
     for (int g = 0; g < 3; ++g) c[g] = ConvCall{up[g], out[g], "", "", "", up[g], nullptr};
     TRY(run_conv_g(3, c, 1));
@@ -944,7 +966,25 @@ int cfen_net::run_decoder(float* const* outs, hipStream_t sm, hipStream_t sg) {
     c3[g] = ConvCall{T + ".conv3", up[g], "", "", "", T + ".mid", nullptr};
     c7[g] = ConvCall{T + ".conv7", T + ".mid", "", "", "", "", outs[g]};
   }
-  TRY(run_conv_g(3, c3, 1));
+  if (tail_fused) {
+    // ConvTranspose (24 -> 12, ActNorm, ReLU) + the tail's 3x3 in ONE grouped launch: the 12-channel full-resolution map between them stays in LDS
+    CfenUpConv3 u[3];
+    double fl = 0.0;
+    for (int g = 0; g < 3; ++g) {
+      const ConvLayer& cu = convs.at(up[g]);
+      const ConvLayer& cc = convs.at(c3[g].layer);
+      const Buf& bi = bufs.at(out[g]);
+      u[g] = CfenUpConv3{map_ptr(out[g]), B, bi.H, bi.W, bi.cs, P(up[g] + ".wr"), Pf(up[g] + ".scale"), Pf(up[g] + ".shift"), 1,
+                         P(c3[g].layer + ".wr"), Pf(c3[g].layer + ".scale"), Pf(c3[g].layer + ".shift"), 1, map_ptr(c3[g].out),
+                         cfen_tune_keep_stages() ? map_ptr(up[g]) : nullptr};
+      fl += B * (2.0 * cu.Cin_real * cu.Cout * 16.0 * bi.H * bi.W + 2.0 * cc.Cout * (double)cc.Cin_real * 9.0 * 4.0 * bi.H * bi.W);
+    }
+    label = up[0] + " + " + c3[0].layer + " (x3, fused)";
+    TRYP(K_CONV, fl, cfen_up_conv3_fused_impl_g(dt, 3, u, stream));
+    stages_on_chip = !cfen_tune_keep_stages();
+  } else {
+    TRY(run_conv_g(3, c3, 1));
+  }
   return run_conv_g(3, c7, 2);
 }
 
@@ -1002,8 +1042,20 @@ int cfen_net::forward(const float* x, float* xr, float* xs, float* xd) {
                                           Pf("head.0.1.body.2.scale"), Pf("head.0.1.body.2.shift"), B, full, full, stream));
   } else {
     if (!use_head5) TRY(run_conv("head.0.0", "input", nullptr, nullptr, nullptr, 0, "head.conv5", nullptr));
-    TRY(run_conv("head.0.1.body.0", "head.conv5", nullptr, nullptr, nullptr, 1, "head.res_mid", nullptr));
-    TRY(run_conv("head.0.1.body.2", "head.res_mid", nullptr, "head.conv5", nullptr, 0, "head", nullptr));
+    const ConvLayer& ca = convs.at("head.0.1.body.0");
+    const ConvLayer& cb = convs.at("head.0.1.body.2");
+    if (cfen_tune_resblock_fused() && ca.tile && cb.tile && an_pending.empty() &&
+        cfen_resblock_fused_supported(dt, bufs.at("head.conv5").cs, ca.Cout, full, full)) {
+      // ResBlock in one launch: the hidden map (head.res_mid) stays in LDS (k_fuse.hip)
+      label = "head.0.1 (ResBlock fused)";
+      const double fl = B * 2.0 * (double)full * full * 9.0 * ((double)ca.Cout * ca.Cin_real + (double)cb.Cout * cb.Cin_real);
+      TRYP(K_CONV, fl, cfen_resblock_fused_impl(dt, map_ptr("head.conv5"), map_ptr("head"), P("head.0.1.body.0.wr"), Pf("head.0.1.body.0.scale"),
+                                               Pf("head.0.1.body.0.shift"), P("head.0.1.body.2.wr"), Pf("head.0.1.body.2.scale"),
+                                               Pf("head.0.1.body.2.shift"), B, full, full, stream));
+    } else {
+      TRY(run_conv("head.0.1.body.0", "head.conv5", nullptr, nullptr, nullptr, 1, "head.res_mid", nullptr));
+      TRY(run_conv("head.0.1.body.2", "head.res_mid", nullptr, "head.conv5", nullptr, 0, "head", nullptr));
+    }
   }
   auto down = [&](const std::string& layer, const std::string& in) -> int {   // conv s2 -> IN -> ReLU (v3:292-298)
     TRY(run_conv(layer, in, nullptr, nullptr, nullptr, 0, layer, nullptr));
@@ -1213,6 +1265,10 @@ int cfen_net_stage(const cfen_net* net, const char* name, const void** ptr, int3
   CFEN_CHECK_ARG(it != net->bufs.end(), "net_stage: unknown stage '%s'", name);
   if (!net->base) {
     cfen_set_error("net_stage: no forward has run yet");
+    return CFEN_ERR_STATE;
+  }
+  if (net->stages_on_chip && !strncmp(name, "us_conv_d01", 11)) {
+    cfen_set_error("net_stage: '%s' stayed on chip in the last forward (fused into the tail's first launch); cfen_tune(\"net.keep_stages\", 1) stores it", name);
     return CFEN_ERR_STATE;
   }
   *ptr = net->base + it->second.off;

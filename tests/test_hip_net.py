@@ -199,9 +199,14 @@ def test_profile_entries_label_every_launch():
     launches = prof["launches"]
     assert sum(prof[c][2] for c in net.KERNEL_CLASSES) == len(launches) > 50
     labels = [l[0] for l in launches]
-    assert labels[0] == "input:nchw_to_nhwc" and any("(x3)" in l for l in labels) and any(l.startswith("tail_R.conv7") for l in labels)
-    assert all(ms > 0 for _, _, _, ms in launches)
-    assert abs(sum(f for _, _, f, _ in launches) - sum(prof[c][1] for c in net.KERNEL_CLASSES)) < 1e-3 * sum(prof[c][1] for c in net.KERNEL_CLASSES)
+    assert labels[0].startswith("head.0.0") and any("(x3)" in l for l in labels) and any(l.startswith("tail_R.conv7") for l in labels)
+    assert all(l[3] > 0 for l in launches)
+    assert abs(sum(l[2] for l in launches) - sum(prof[c][1] for c in net.KERNEL_CLASSES)) < 1e-3 * sum(prof[c][1] for c in net.KERNEL_CLASSES)
+    # round 4: every record also names the DEVICE KERNEL(S) that ran it (cfen_net_profile_entry_kernel) and, for the token GEMMs, algorithmic bytes
+    kernels = [l[4] for l in launches]
+    assert all(k.startswith("k_") for k in kernels), [k for k in kernels if not k.startswith("k_")]
+    assert kernels[0].startswith("k_head5") and any(k.startswith("k_gemm_dma") for k in kernels) and any("k_conv7_tz" in k for k in kernels)
+    assert all(l[5] >= 0 for l in launches) and any(l[5] > 0 for l in launches if l[4].startswith("k_gemm"))
 
 
 def test_split_k_and_grouping_knobs_do_not_change_results():
@@ -341,6 +346,8 @@ def test_fused_head_equals_the_three_convolutions_bitwise(size):
     x = synthetic_input(2, cfg).to("cuda:0")
     res = {}
     try:
+        ops.tune("net.head5", 0)                 # (round 4's k_head5 sums its products in another order: the three round-3 launches are the twin here)
+        ops.tune("net.resblock_fused", 0)
         for k in (1, 0):
             ops.tune("net.head_fused", k)
             net = make_net(cfg, "fp16")
@@ -349,9 +356,127 @@ def test_fused_head_equals_the_three_convolutions_bitwise(size):
             del net
     finally:
         ops.tune("net.head_fused", 0)
+        ops.tune("net.head5", 1)
+        ops.tune("net.resblock_fused", 1)
     assert torch.equal(res[1][0], res[0][0])
     for a, b in zip(res[1][1], res[0][1]):
         assert torch.equal(a, b)
+    torch.cuda.empty_cache()
+
+
+@pytest.mark.parametrize("size", [(8, 64), (32, 256)])
+def test_head_from_input_and_fused_resblock_against_the_unfused_launches(size):
+    """round 4: k_head5 (input layout pass + conv5x5 in one launch, 8-byte pixels) and k_resblock_fused (hidden map in LDS) against the launches they
+    replace (k_nchw_to_nhwc + three k_conv_tile): the `head` stage and the outputs; every combination of the two knobs, fp32 NCHW and uint8 HWC input"""
+    from cfen_vit_dehazing_amd import ops
+    ps, ls = size
+    cfg = NetConfig(24, 4, patch_size=ps, load_size=ls)
+    x = synthetic_input(2, cfg).to("cuda:0")
+    n = cfg.image_size
+    img = torch.randint(0, 256, (2, n, n, 3), generator=torch.Generator().manual_seed(5), dtype=torch.uint8).to("cuda:0")
+    res = {}
+    try:
+        for h5, rb in ((0, 0), (1, 0), (0, 1), (1, 1)):
+            ops.tune("net.head5", h5)
+            ops.tune("net.resblock_fused", rb)
+            net = make_net(cfg, "fp16")
+            outs = [o.clone() for o in net(x)]
+            head = net.stage("head").clone()
+            outs8 = [o.clone() for o in net(img)]
+            res[(h5, rb)] = (head, outs, outs8)
+            del net
+    finally:
+        ops.tune("net.head5", 1)
+        ops.tune("net.resblock_fused", 1)
+    # the fused ResBlock is bitwise the two launches (same accumulation order, same fp16 rounding of the hidden map) ...
+    for h5 in (0, 1):
+        a, b = res[(h5, 1)], res[(h5, 0)]
+        assert torch.equal(a[0], b[0]), h5
+        for u, v in zip(a[1] + a[2], b[1] + b[2]):
+            assert torch.equal(u, v), h5
+    # ... k_head5 has the same products per output as k_nchw_to_nhwc + k_conv_tile<16, 5> but sums them in chunks of 8 taps instead of 4 + 1:
+    # fp32 reassociation, at most an fp16 ulp on the stored map
+    a, b = res[(1, 1)], res[(0, 0)]
+    assert float((a[0] - b[0]).abs().max()) <= 2e-3 * max(1.0, float(b[0].abs().max()))
+    for u, v in zip(a[1] + a[2], b[1] + b[2]):
+        assert float((u - v).abs().max()) <= 5e-3
+    torch.cuda.empty_cache()
+
+
+@pytest.mark.parametrize("size,batch", [((8, 64), 2), ((32, 256), 2)])
+def test_fused_tail_up_conv3_equals_the_two_launches_bitwise(size, batch):
+    """round 4: k_up_conv3_fused (us_conv_d01* ConvTranspose + ActNorm + ReLU and the tail's 3x3 in one grouped launch, the 12-channel map between
+    them in LDS with its halo recomputed) against k_convT_tile + k_conv_tile: the three outputs bit for bit, and -- with "net.keep_stages" -- the
+    us_conv_d01* stage maps bit for bit; without that knob the stage is refused instead of returning a stale buffer"""
+    from cfen_vit_dehazing_amd import ops
+    from cfen_vit_dehazing_amd._lib import CfenError
+    ps, ls = size
+    cfg = NetConfig(24, 4, patch_size=ps, load_size=ls)
+    x = synthetic_input(batch, cfg).to("cuda:0")
+    res = {}
+    try:
+        for fused, keep in ((0, 0), (1, 1), (1, 0)):
+            ops.tune("net.tail_fused", fused)
+            ops.tune("net.keep_stages", keep)
+            net = make_net(cfg, "fp16")
+            outs = [o.clone() for o in net(x)]
+            if fused and not keep:
+                with pytest.raises(CfenError):
+                    net.stage("us_conv_d01r")
+                st = None
+            else:
+                st = [net.stage("us_conv_d01" + t).clone() for t in "rsd"]
+            gid, gouts = net.capture(x)
+            net.replay(gid)
+            torch.cuda.synchronize()
+            for a, b in zip(gouts, outs):
+                assert torch.equal(a, b)
+            res[(fused, keep)] = (outs, st)
+            del net
+    finally:
+        ops.tune("net.tail_fused", 1)
+        ops.tune("net.keep_stages", 0)
+    for key in ((1, 1), (1, 0)):
+        for a, b in zip(res[key][0], res[(0, 0)][0]):
+            assert torch.equal(a, b), key
+    for a, b in zip(res[(1, 1)][1], res[(0, 0)][1]):
+        assert torch.equal(a, b)
+    torch.cuda.empty_cache()
+
+
+def test_gvit_persistent_chain_plan_agrees_with_the_launch_per_gemm_plan():
+    """csrc/k_gvit.hip inside the net (CFEN_GVIT_CHAIN=1: fragment-stream GViT weights, two persistent launches per block instead of eight GEMM
+    launches): every GViT stage and the outputs against the default plan at B = 8, 512x512, fp16 -- same math, different summation order
+    (128-row units, split-K slices), so fp16-rounding close, not bitwise; the teams' error words stay zero; graph replay = eager, bitwise"""
+    import os
+    from cfen_vit_dehazing_amd import ops
+    cfg = NetConfig(24, 4, patch_size=32, load_size=256)
+    x = synthetic_input(8, cfg).to("cuda:0")
+    base = make_net(cfg, "fp16")
+    want = [o.clone() for o in base(x)]
+    stages = ["globalvit_encoder_01", "globalvit_encoder_02", "globalvit_encoder_03", "globalvit_decoder_03r", "globalvit_decoder_02s", "globalvit_decoder_01d"]
+    wst = {k: base.stage(k).clone() for k in stages}
+    del base
+    os.environ["CFEN_GVIT_CHAIN"] = "1"
+    try:
+        net = make_net(cfg, "fp16")
+    finally:
+        del os.environ["CFEN_GVIT_CHAIN"]
+    assert net.gvit_chain
+    got = [o.clone() for o in net(x)]
+    assert net.chain_errors() == [0, 0, 0]
+    for k in stages:
+        d = float((net.stage(k) - wst[k]).abs().max())
+        assert d <= 3e-2 * max(1.0, float(wst[k].abs().max())), (k, d)
+    for a, b in zip(got, want):
+        assert float((a - b).abs().max()) <= 2e-2
+    gid, gouts = net.capture(x)
+    for _ in range(3):
+        net.replay(gid)
+    torch.cuda.synchronize()
+    for a, b in zip(gouts, got):
+        assert torch.equal(a, b)
+    assert net.chain_errors() == [0, 0, 0]
     torch.cuda.empty_cache()
 
 
