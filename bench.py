@@ -204,6 +204,10 @@ def main():
     ap.add_argument("--no-graph", action="store_true", help="launch eagerly instead of replaying a hipGraph")
     ap.add_argument("--gather-dtype", default="auto", choices=["auto", "fp16", "fp32"],
                     help="wire type of the output all-gather (N > 1); auto = the compute dtype")
+    ap.add_argument("--in-flight", type=int, default=2, choices=[1, 2],
+                    help="forwards in flight: 2 = consecutive steps alternate between two launch plans (own workspace and output slab each, shared "
+                         "weights) on two streams, so the tail of step i overlaps the head of step i + 1; every step is still one whole forward of "
+                         "one batch and all K steps complete inside the timed region")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra-configs", action="store_true",
                     help="skip the short timed legs of BASELINE configs 4 (batch 4, 1024x1024) and 5 (batch 16, hidden_dim_ratio 2) in the default run")
@@ -244,20 +248,37 @@ def main():
     net(x, out=slabs[0])                       # packs weights, builds the plan
     torch.cuda.synchronize()
     graphs = None
+    nfl = args.in_flight
+    lanes = [torch.cuda.Stream(dev) for _ in range(nfl)] if nfl > 1 else None
     if not args.no_graph:
-        graphs = [net.capture(x, out=s)[0] for s in slabs]     # native hipGraph per output slab
+        graphs = []
+        for k, s in enumerate(slabs):          # native hipGraph per output slab (and, with two forwards in flight, per launch-plan replica)
+            net.replica = k % nfl
+            graphs.append(net.capture(x, out=s)[0])
+        net.replica = 0
         torch.cuda.synchronize()
+
+    use_lanes = [lanes is not None]     # the serial leg of the default run flips this: the same graphs, one stream, one forward at a time
 
     def step(i):
         s = slabs[i & 1]
-        if gather is not None:
-            gather.before_write(i & 1)         # the gather of step i-2 must have consumed this slab
-        if graphs is not None:
-            net.replay(graphs[i & 1])
-        else:
-            net(x, out=s)
-        if gather is not None:
-            gather.launch(s, i & 1)            # async all-gather on the communication stream
+        ctx = torch.cuda.stream(lanes[i & 1]) if (lanes is not None and use_lanes[0]) else None
+        if ctx is not None:
+            ctx.__enter__()
+        try:
+            if gather is not None:
+                gather.before_write(i & 1)         # the gather of step i-2 must have consumed this slab
+            if graphs is not None:
+                net.replay(graphs[i & 1])
+            else:
+                net.replica = (i & 1) % nfl
+                net(x, out=s)
+                net.replica = 0
+            if gather is not None:
+                gather.launch(s, i & 1)            # async all-gather on the communication stream
+        finally:
+            if ctx is not None:
+                ctx.__exit__(None, None, None)
 
     def barrier():
         if dist is not None:
@@ -299,6 +320,24 @@ def main():
     dt = srt[len(srt) // 2]
     ms_step = dt / args.steps * 1e3
     ips = world * B * args.steps / dt
+
+    serial = None
+    if nfl > 1:
+        # the same K-step region with ONE forward in flight (same graphs and slabs on the default stream), >= 0.4 s, median: reported beside
+        # the headline so that the gain of overlapping consecutive steps is visible in every run
+        use_lanes[0] = False
+        sreps = [timed_region()]
+        while sum(sreps) < min(0.4, args.min_seconds) and len(sreps) < 50:
+            if dist is not None:
+                flag = torch.tensor([1.0 if sum(sreps) < min(0.4, args.min_seconds) else 0.0], device=dev)
+                dist.all_reduce(flag, op=dist.ReduceOp.MAX)
+                if flag.item() == 0:
+                    break
+            sreps.append(timed_region())
+        use_lanes[0] = True
+        sdt = sorted(sreps)[len(sreps) // 2]
+        serial = {"value": round(world * B * args.steps / sdt, 2), "unit": "images/sec", "ms_per_step": round(sdt / args.steps * 1e3, 3),
+                  "repetitions": len(sreps)}
 
     result = None
     if rank == 0:
@@ -357,7 +396,7 @@ def main():
             "scaling": "weak", "vs_baseline": None, "dtype": "f16" if args.dtype == "fp16" else "f32", "data": "synthetic",
             "config": {"workload": "batch=%d/GPU %dx%d n_feats=24 hidden_dim_ratio=%d %s%s, weights random-init (seeded generator)"
                                    % (B, n, n, args.hidden_dim_ratio, args.dtype, "" if args.variant == "v3" else " generator variant " + args.variant),
-                       "global_batch": world * B, "parallelism": "dp%d" % world, "graph": graphs is not None,
+                       "global_batch": world * B, "parallelism": "dp%d" % world, "graph": graphs is not None, "forwards_in_flight": nfl,
                        "gather_dtype": (gdt if world > 1 else None),
                        "gflop_per_image": round(flops_img / 1e9, 2)},
             "roofline": {"bound": bound, "kernel": dom, "achieved": ach, "peak": rpeak, "unit": runit, "frac": rfrac,
@@ -376,6 +415,11 @@ def main():
             "timing": {"method": "value = the MEDIAN of the repetitions of the K-step timed region", "repetitions": len(reps), "timed_seconds": round(sum(reps), 3), "ms_per_step_min": round(srt[0] / args.steps * 1e3, 3),
                        "ms_per_step_max": round(srt[-1] / args.steps * 1e3, 3)},
             "self_check": check,
+            "pipelining": {"forwards_in_flight": nfl,
+                           "what": "consecutive steps alternate between two launch plans (own workspace and output slab, shared weights) on two streams: the "
+                                   "tail of step i overlaps the head of step i + 1; every step is one whole batch-%d forward, all K steps finish inside the "
+                                   "timed region" % B if nfl > 1 else "one forward at a time",
+                           "one_forward_in_flight": serial},
             "kernel_classes": classes,
             "kernels": dict(sorted(kern.items(), key=lambda kv: -kv[1]["ms"])[:12]),
             # the same launches grouped by the device kernel that ran them (per block shape = per template instantiation)

@@ -71,6 +71,9 @@ class dec_ipt(nn.Module):
         self._graphs = []            # capture() handle -> (net key, native graph id)
         self._last = None
         self.serial_plan = bool(os.environ.get("CFEN_SERIAL"))     # single-lane launch plan (debugging / A-B)
+        # `replica`: which launch plan + workspace the next forward / capture uses.  Replicas share the packed weights; each has its own workspace
+        # (stage buffers, token scratch), so forwards of DIFFERENT replicas may be in flight at once on different streams (bench.py --in-flight 2)
+        self.replica = 0
         # GViT weights tile-major (packing.pack_wtile; cfen_net_config.reserved bit 1): +1 % measured (3.34 -> 3.30 ms at B = 8); CFEN_WTILE=0 = row-major
         self.wtile = os.environ.get("CFEN_WTILE", "1") != "0"
         # CFEN_GVIT_CHAIN=1: GViT weights ALSO as MFMA fragment streams (packing.pack_stream_tiles; cfen_net_config.reserved bit 2) and the GEMMs of a
@@ -188,7 +191,7 @@ class dec_ipt(nn.Module):
 
     def _net_for(self, batch, device, u8=False):
         packed = self._ensure_packed(device)
-        key = (batch, bool(u8), bool(self.serial_plan))
+        key = (batch, bool(u8), bool(self.serial_plan), int(self.replica))
         if key in self._nets:
             return self._nets[key]
         lib = _lib.load()
@@ -324,7 +327,7 @@ class dec_ipt(nn.Module):
             prof["launches"] = detail
         if init_actnorm:
             self._finish_actnorm_init()
-        self._last = (B, bool(u8), bool(self.serial_plan))
+        self._last = (B, bool(u8), bool(self.serial_plan), int(self.replica))
         return [xr, xs, xd]
 
     def set_scale(self, scale_idx):
