@@ -204,9 +204,9 @@ def main():
     ap.add_argument("--no-graph", action="store_true", help="launch eagerly instead of replaying a hipGraph")
     ap.add_argument("--gather-dtype", default="auto", choices=["auto", "fp16", "fp32"],
                     help="wire type of the output all-gather (N > 1); auto = the compute dtype")
-    ap.add_argument("--in-flight", type=int, default=2, choices=[1, 2],
-                    help="forwards in flight: 2 = consecutive steps alternate between two launch plans (own workspace and output slab each, shared "
-                         "weights) on two streams, so the tail of step i overlaps the head of step i + 1; every step is still one whole forward of "
+    ap.add_argument("--in-flight", type=int, default=3, choices=[1, 2, 3, 4],
+                    help="forwards in flight: N > 1 = consecutive steps rotate over N launch plans (own workspace and output slab each, shared "
+                         "weights) on N streams, so the tail of step i overlaps the head of steps i + 1 .. i + N - 1; every step is still one whole forward of "
                          "one batch and all K steps complete inside the timed region")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra-configs", action="store_true",
@@ -241,7 +241,8 @@ def main():
     net.load_state_dict(generate_state_dict(cfg, seed=0), strict=True)
     net.to(dev)
     x = synthetic_input(B, cfg, seed0=rank * B).to(dev)
-    slabs = [torch.empty(7 * B * n * n, dtype=torch.float32, device=dev) for _ in range(2)]
+    nslab = max(2, args.in_flight)
+    slabs = [torch.empty(7 * B * n * n, dtype=torch.float32, device=dev) for _ in range(nslab)]
     gdt = args.dtype if args.gather_dtype == "auto" else args.gather_dtype
     gather = OutputGatherer(world, slabs[0].numel(), dev, torch.float16 if gdt == "fp16" else torch.float32) if world > 1 else None
 
@@ -261,17 +262,18 @@ def main():
     use_lanes = [lanes is not None]     # the serial leg of the default run flips this: the same graphs, one stream, one forward at a time
 
     def step(i):
-        s = slabs[i & 1]
-        ctx = torch.cuda.stream(lanes[i & 1]) if (lanes is not None and use_lanes[0]) else None
+        k = i % nslab
+        s = slabs[k]
+        ctx = torch.cuda.stream(lanes[k % nfl]) if (lanes is not None and use_lanes[0]) else None
         if ctx is not None:
             ctx.__enter__()
         try:
             if gather is not None:
                 gather.before_write(i & 1)         # the gather of step i-2 must have consumed this slab
             if graphs is not None:
-                net.replay(graphs[i & 1])
+                net.replay(graphs[k])
             else:
-                net.replica = (i & 1) % nfl
+                net.replica = k % nfl
                 net(x, out=s)
                 net.replica = 0
             if gather is not None:
@@ -375,7 +377,7 @@ def main():
         dom_launch_ms = d["ms"] / d["launches"]
         whole = ips / world * flops_img / 1e12
         from cfen_vit_dehazing_amd.parallel import split_slab
-        check = self_check(net, x, split_slab(slabs[(args.steps - 1) & 1], B, n), cfg, args.dtype)   # what the last timed step wrote
+        check = self_check(net, x, split_slab(slabs[(args.steps - 1) % nslab], B, n), cfg, args.dtype)   # what the last timed step wrote
         if gather is not None:
             # the GATHERED buffer of the last timed step, rank by rank: segment r must be rank r's images (synthetic_input seeds r * B ...), so its
             # first image is checked against a batch-1 eager forward of that image computed here -- an ordering bug of the all-gather /
@@ -416,9 +418,9 @@ def main():
                        "ms_per_step_max": round(srt[-1] / args.steps * 1e3, 3)},
             "self_check": check,
             "pipelining": {"forwards_in_flight": nfl,
-                           "what": "consecutive steps alternate between two launch plans (own workspace and output slab, shared weights) on two streams: the "
-                                   "tail of step i overlaps the head of step i + 1; every step is one whole batch-%d forward, all K steps finish inside the "
-                                   "timed region" % B if nfl > 1 else "one forward at a time",
+                           "what": "consecutive steps rotate over %d launch plans (own workspace and output slab each, shared weights) on %d streams: the tail "
+                                   "of step i overlaps the head of the next ones; every step is one whole batch-%d forward, all K steps finish inside "
+                                   "the timed region" % (nfl, nfl, B) if nfl > 1 else "one forward at a time",
                            "one_forward_in_flight": serial},
             "kernel_classes": classes,
             "kernels": dict(sorted(kern.items(), key=lambda kv: -kv[1]["ms"])[:12]),

@@ -598,7 +598,7 @@ int cfen_net::run_vit_g(int ng, const VitCall* vc, int scr0) {
     for (int g = 0; g < ng; ++g) SK[g] = (float*)at(scr_set[scr0 + 2 * g].splitk);
   const double Md = (double)M * ng, D = v.Dn, Hd = v.hidden;   // algorithmic flops count the real embedding dim
   auto step = [&](const char* what) { if (profiling) label = nm[0] + (ng > 1 ? " (x" + std::to_string(ng) + ")" : "") + ":" + what; };
-  if (v.global && cfen_tune_gvit_dummy_wgs() > 0) {   // what-if probe: the whole block replaced by a launch that holds CUs (outputs invalid)
+  if (v.global && cfen_tune_gvit_dummy_wgs() != 0) {   // what-if probe: the whole block replaced by a launch that holds CUs (outputs invalid)
     step("dummy");
     return cfen_occupy_impl(cfen_tune_gvit_dummy_wgs(), ng, cfen_tune_gvit_dummy_us(), cfen_tune_gvit_dummy_stream(), base, ws_bytes, SK[0], stream);
   }

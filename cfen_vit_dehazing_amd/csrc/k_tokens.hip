@@ -303,9 +303,26 @@ __global__ __launch_bounds__(512) void k_occupy(const uint4* __restrict__ src, s
 
 }  // namespace
 
+// the same with the footprint of a k_gemm_dma workgroup (256 threads, 36 KB of LDS: four fit a CU, and the dispatcher spreads them over every CU)
+__global__ __launch_bounds__(256) void k_occupy_small(const uint4* __restrict__ src, size_t nvec, unsigned ticks, int do_stream, unsigned* sink) {
+  __shared__ unsigned char lds[36 * 1024];
+  lds[threadIdx.x] = (unsigned char)threadIdx.x;
+  __syncthreads();
+  const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+  unsigned acc = lds[(threadIdx.x * 7) & 1023];
+  for (int it = 0; it < (1 << 20); ++it) {
+    if (__builtin_amdgcn_s_memrealtime() - t0 >= ticks) break;
+    __builtin_amdgcn_s_sleep(32);
+  }
+  if (acc == 0x12345677u) sink[0] = acc;
+}
+
 int cfen_occupy_impl(int wgs, int ng, int usec, int do_stream, const void* src, size_t src_bytes, void* sink, hipStream_t s) {
-  CFEN_CHECK_ARG(wgs > 0 && wgs <= 256 && ng >= 1 && ng <= 3 && usec > 0 && usec <= 2000 && src && sink && src_bytes >= (1u << 20), "occupy: bad arguments");
-  CFEN_LAUNCH(k_occupy, dim3(wgs, ng), dim3(512), 0, s, (const uint4*)src, src_bytes / 16, (unsigned)usec * 100u, do_stream, (unsigned*)sink);
+  CFEN_CHECK_ARG(wgs != 0 && wgs <= 256 && wgs >= -2048 && ng >= 1 && ng <= 3 && usec > 0 && usec <= 2000 && src && sink && src_bytes >= (1u << 20), "occupy: bad arguments");
+  if (wgs < 0)      // negative: that many SMALL workgroups (k_gemm_dma's footprint)
+    CFEN_LAUNCH(k_occupy_small, dim3(-wgs, ng), dim3(256), 0, s, (const uint4*)src, src_bytes / 16, (unsigned)usec * 100u, do_stream, (unsigned*)sink);
+  else
+    CFEN_LAUNCH(k_occupy, dim3(wgs, ng), dim3(512), 0, s, (const uint4*)src, src_bytes / 16, (unsigned)usec * 100u, do_stream, (unsigned*)sink);
   CFEN_CHECK_LAUNCH("occupy");
   return CFEN_OK;
 }
