@@ -85,29 +85,44 @@ def nearer_roof(gflop, gbytes, ms, peak_tflops):
     return "mfma", round(gflop / ms, 2), peak_tflops, "TFLOP/s", round(f_m, 5)
 
 
-def time_config(cfg, B, dtype, dev, steps, min_seconds, warmup=3):
+def time_config(cfg, B, dtype, dev, steps, min_seconds, warmup=3, in_flight=1):
     """one extra BASELINE configuration on this GPU: build, capture, replay `steps` forwards per timed region until `min_seconds` are
-    timed; returns the same quantities as the headline run, with its own self_check"""
+    timed (median repetition); `in_flight` forwards overlap as in the headline run (serial launch plan per forward, one replica workspace,
+    output slab and stream each).  Returns the same quantities as the headline run, with its own self_check."""
     from cfen_vit_dehazing_amd.hipnet import dec_ipt
     from cfen_vit_dehazing_amd.manifest import generate_state_dict, synthetic_input
     from cfen_vit_dehazing_amd.parallel import split_slab
     net = dec_ipt(cfg, compute_dtype=dtype)
     net.load_state_dict(generate_state_dict(cfg, seed=0), strict=True)
     net.to(dev)
+    net.serial_plan = in_flight > 1
     n = cfg.image_size
     x = synthetic_input(B, cfg, seed0=0).to(dev)
-    slab = torch.empty(7 * B * n * n, dtype=torch.float32, device=dev)
-    net(x, out=slab)
+    slabs = [torch.empty(7 * B * n * n, dtype=torch.float32, device=dev) for _ in range(in_flight)]
+    net(x, out=slabs[0])
     torch.cuda.synchronize()
-    gid = net.capture(x, out=slab)[0]
-    for _ in range(warmup):
-        net.replay(gid)
+    gids = []
+    for k in range(in_flight):
+        net.replica = k
+        gids.append(net.capture(x, out=slabs[k])[0])
+    net.replica = 0
+    streams = [torch.cuda.Stream(dev) for _ in range(in_flight)] if in_flight > 1 else [None]
+
+    def run(count):
+        for i in range(count):
+            k = i % in_flight
+            if streams[k] is None:
+                net.replay(gids[k])
+            else:
+                with torch.cuda.stream(streams[k]):
+                    net.replay(gids[k])
+
+    run(warmup * in_flight)
     reps = []
     while sum(reps) < min_seconds and len(reps) < 100:
         torch.cuda.synchronize()
         t0 = time.perf_counter()
-        for _ in range(steps):
-            net.replay(gid)
+        run(steps)
         torch.cuda.synchronize()
         reps.append(time.perf_counter() - t0)
     dt = sorted(reps)[len(reps) // 2]
@@ -115,10 +130,10 @@ def time_config(cfg, B, dtype, dev, steps, min_seconds, warmup=3):
     ips = B * steps / dt
     out = {"workload": "batch=%d %dx%d n_feats=24 hidden_dim_ratio=%d %s" % (B, n, n, cfg.hidden_dim_ratio, dtype),
            "value": round(ips, 2), "unit": "images/sec", "ms_per_step": round(dt / steps * 1e3, 3), "steps": steps, "repetitions": len(reps),
-           "timing_method": "median of the repetitions",
+           "timing_method": "median of the repetitions", "forwards_in_flight": in_flight,
            "timed_seconds": round(sum(reps), 3), "gflop_per_image": round(fl / 1e9, 2),
            "whole_forward_tflops": round(ips * fl / 1e12, 2), "whole_forward_frac": round(ips * fl / 1e12 / MFMA_PEAK_TFLOPS[dtype], 5),
-           "self_check": self_check(net, x, split_slab(slab, B, n), cfg, dtype)}
+           "self_check": self_check(net, x, split_slab(slabs[(steps - 1) % in_flight], B, n), cfg, dtype)}
     del net
     torch.cuda.empty_cache()
     return out
@@ -208,6 +223,10 @@ def main():
                     help="forwards in flight: N > 1 = consecutive steps rotate over N launch plans (own workspace and output slab each, shared "
                          "weights) on N streams, so the tail of step i overlaps the head of steps i + 1 .. i + N - 1; every step is still one whole forward of "
                          "one batch and all K steps complete inside the timed region")
+    ap.add_argument("--lanes", type=int, default=0, choices=[0, 1, 2],
+                    help="launch plan of one forward: 2 = GViT beside LViT on a second graph branch, 1 = one serial chain of launches; 0 (default) = 1 when "
+                         "several forwards are in flight (measured: 2.26 against 2.38 ms per step -- the forwards overlap each other, and a branch in "
+                         "every graph costs ~0.05 ms of cross-queue synchronisation per level), 2 for --in-flight 1")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra-configs", action="store_true",
                     help="skip the short timed legs of BASELINE configs 4 (batch 4, 1024x1024) and 5 (batch 16, hidden_dim_ratio 2) in the default run")
@@ -240,6 +259,9 @@ def main():
     net = dec_ipt(cfg, compute_dtype=args.dtype)
     net.load_state_dict(generate_state_dict(cfg, seed=0), strict=True)
     net.to(dev)
+    lanes_plan = args.lanes or (1 if args.in_flight > 1 else 2)
+    if not os.environ.get("CFEN_SERIAL"):
+        net.serial_plan = lanes_plan == 1
     x = synthetic_input(B, cfg, seed0=rank * B).to(dev)
     nslab = max(2, args.in_flight)
     slabs = [torch.empty(7 * B * n * n, dtype=torch.float32, device=dev) for _ in range(nslab)]
@@ -324,10 +346,18 @@ def main():
     ips = world * B * args.steps / dt
 
     serial = None
-    if nfl > 1:
-        # the same K-step region with ONE forward in flight (same graphs and slabs on the default stream), >= 0.4 s, median: reported beside
-        # the headline so that the gain of overlapping consecutive steps is visible in every run
-        use_lanes[0] = False
+    if nfl > 1 and graphs is not None:
+        # ONE forward in flight, on the launch plan that is best for it (GViT beside LViT on a second graph branch): the same K-step region on the
+        # default stream, >= 0.4 s, median -- reported beside the headline so that what the overlap of consecutive steps buys is visible in every run
+        was_serial = net.serial_plan
+        net.serial_plan, net.replica = False, 0
+        g1 = [net.capture(x, out=slabs[k])[0] for k in range(2)]
+        net.serial_plan = was_serial
+        torch.cuda.synchronize()
+        main_graphs, main_nslab = graphs, nslab
+        graphs, nslab, use_lanes[0] = g1, 2, False
+        for i in range(3):
+            step(i)
         sreps = [timed_region()]
         while sum(sreps) < min(0.4, args.min_seconds) and len(sreps) < 50:
             if dist is not None:
@@ -336,10 +366,17 @@ def main():
                 if flag.item() == 0:
                     break
             sreps.append(timed_region())
-        use_lanes[0] = True
+        graphs, nslab, use_lanes[0] = main_graphs, main_nslab, True
         sdt = sorted(sreps)[len(sreps) // 2]
         serial = {"value": round(world * B * args.steps / sdt, 2), "unit": "images/sec", "ms_per_step": round(sdt / args.steps * 1e3, 3),
-                  "repetitions": len(sreps)}
+                  "repetitions": len(sreps), "lanes_per_forward": 2}
+        # the headline state again: the last step of the main plan wrote slabs[(steps - 1) % nslab]; the serial leg overwrote slabs 0 and 1 with the
+        # same values (same input, same weights), so the self-check below reads what a main-plan step wrote either way -- rerun one to be exact
+        for i in range(args.steps - nslab, args.steps):
+            step(i)
+        if gather is not None:
+            gather.wait_all()
+        torch.cuda.synchronize()
 
     result = None
     if rank == 0:
@@ -398,7 +435,7 @@ def main():
             "scaling": "weak", "vs_baseline": None, "dtype": "f16" if args.dtype == "fp16" else "f32", "data": "synthetic",
             "config": {"workload": "batch=%d/GPU %dx%d n_feats=24 hidden_dim_ratio=%d %s%s, weights random-init (seeded generator)"
                                    % (B, n, n, args.hidden_dim_ratio, args.dtype, "" if args.variant == "v3" else " generator variant " + args.variant),
-                       "global_batch": world * B, "parallelism": "dp%d" % world, "graph": graphs is not None, "forwards_in_flight": nfl,
+                       "global_batch": world * B, "parallelism": "dp%d" % world, "graph": graphs is not None, "forwards_in_flight": nfl, "lanes_per_forward": 1 if net.serial_plan else 2,
                        "gather_dtype": (gdt if world > 1 else None),
                        "gflop_per_image": round(flops_img / 1e9, 2)},
             "roofline": {"bound": bound, "kernel": dom, "achieved": ach, "peak": rpeak, "unit": runit, "frac": rfrac,
@@ -436,7 +473,7 @@ def main():
             for key, ecfg, eb, esteps in (("config4_batch4_1024x1024", NetConfig(24, 4, patch_size=64, load_size=512), 4, 10),
                                           ("config5_batch16_hdr2", NetConfig(24, 2, patch_size=32, load_size=256), 16, 20)):
                 try:
-                    extra[key] = time_config(ecfg, eb, args.dtype, dev, esteps, 0.4)
+                    extra[key] = time_config(ecfg, eb, args.dtype, dev, esteps, 0.4, in_flight=nfl)
                 except Exception as e:          # a failing extra leg must not cost the headline line
                     extra[key] = {"error": "%s: %s" % (type(e).__name__, e)}
             result["extra_configs"] = extra

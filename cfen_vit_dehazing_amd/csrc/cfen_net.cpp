@@ -29,7 +29,7 @@ int& cfen_tune_gvit_dummy_stream() { static int v = 0; return v; }
 int& cfen_tune_gvit_chain() { static int v = 1; return v; }   // only nets built with fragment-stream GViT weights (cfg.reserved bit 2) can use it
 int& cfen_tune_tail_fused() { static int v = 1; return v; }
 int& cfen_tune_keep_stages() { static int v = 0; return v; }
-int& cfen_tune_resblock_fused() { static int v = 1; return v; }
+int& cfen_tune_resblock_fused() { static int v = 0; return v; }   // 0 (default): MEASURED with three forwards in flight 2.44 against 2.48 ms -- the fused kernel (5-wave workgroups, 58 KB of LDS, 154 registers) is 13 us shorter alone and costs more CU-time beside other forwards
 int& cfen_tune_head5() { static int v = 1; return v; }
 int& cfen_tune_ln_fold() {
   static int v = 1;
@@ -59,16 +59,16 @@ int& cfen_tune_head_fused() {   // 0 (default): three k_conv_tile launches.  MEA
   static int v = 0;             // SLOWER, 131 us against 108: with 3 input channels padded to 8 and 5 taps to 8 its MFMA work is 5x the algorithmic
   return v;                     // flops (22 % MFMA-busy, profiles/r03_*), and the unfused kernels already run at the HBM rate of their own maps
 }
-int& cfen_tune_stream_front() {   // k_front3 for the D = 384 LViT blocks: 0 never, 1 (default) grouped decoder launches, 2 always
-  static int v = 1;
+int& cfen_tune_stream_front() {   // k_front3 for the D = 384 LViT blocks: 0 never, 1 grouped decoder launches, 2 (default, round 4) always
+  static int v = 2;             // (with three forwards in flight the single encoder instance on the stream kernels is 0.03 ms better: one whole-CU launch of 64 workgroups instead of 8 GEMM launches)
   return v;
 }
 int& cfen_tune_stream_mlp192() {   // 1: LViT level 2 (D = 192) runs its proj + MLP block on k_mlp3<12, 3> instead of k_mlp2.  0 (default): MEASURED -- alone on the chip
   static int v = 0;                // with cold caches k_mlp3 wins (154-162 us against 181-204 for the grouped decoder launch, tools/bench_mlp3.py), inside the
   return v;                        // forward it loses (2.92 against 2.90 ms): it takes whole CUs (150 KB of LDS, 512 registers), the GViT lane beside it starves
 }
-int& cfen_tune_stream_mlp() {   // k_mlp3 (k_stream.hip) for the D = 384 blocks: 0 never, 1 (default) launches of >= 128 workgroups (at 512 x 512 the grouped
-  static int v = 1;             // decoder launch; a single instance has 64 workgroups of 128 tokens: a quarter of the chip), 2 always
+int& cfen_tune_stream_mlp() {   // k_mlp3 (k_stream.hip) for the D = 384 blocks: 0 never, 1 launches of >= 128 workgroups (at 512 x 512 the grouped
+  static int v = 2;             // decoder launch; a single instance has 64 workgroups of 128 tokens: a quarter of the chip), 2 (default, round 4) always
   return v;
 }
 

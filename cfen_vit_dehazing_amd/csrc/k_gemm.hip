@@ -754,8 +754,8 @@ int& cfen_tune_gemm_nt() {   // weight rows of k_gemm_dma by non-temporal LDS-DM
   return v;
 }
 
-int& cfen_tune_gemm_splitk() {
-  static int v = 1;
+int& cfen_tune_gemm_splitk() {   // 0 (default, round 4): with three forwards in flight the unsplit launches are as fast (2.47 against 2.48 ms) and the default plan
+  static int v = 0;               // no longer depends on the hand-rolled in-launch reduction; 1 = round 3's shape rule
   return v;
 }
 int& cfen_tune_gemm_splitk_release() {   // 1: every K slice also runs an agent-scope release fence before its arrival ticket (see the split-K block of k_gemm_dma)

@@ -4,7 +4,7 @@ out=$1; shift
 : > $out
 for t in "$@"; do
   tt=$t; [ "$t" = "-" ] && tt=""
-  r=$(CFEN_TUNE="$tt" timeout 600 python3 bench.py --no-cpu-baseline --no-extra-configs --min-seconds 0.6 --steps 60 --in-flight ${INFLIGHT:-2} 2>/dev/null | python3 -c "
+  r=$(CFEN_TUNE="$tt" timeout 600 python3 bench.py --no-cpu-baseline --no-extra-configs --min-seconds ${MINSEC:-0.6} --steps 60 --in-flight ${INFLIGHT:-3} 2>/dev/null | python3 -c "
 import sys, json
 for l in sys.stdin:
     if l.startswith('{'):
