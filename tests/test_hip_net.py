@@ -480,6 +480,38 @@ def test_gvit_persistent_chain_plan_agrees_with_the_launch_per_gemm_plan():
     torch.cuda.empty_cache()
 
 
+def test_three_forwards_in_flight_on_replica_plans_match_single_forwards_bitwise():
+    """what bench.py times by default (round 4): consecutive steps rotate over three launch plans -- one serial chain of launches each, own
+    workspace and output slab, shared packed weights -- on three streams, so three forwards are in flight at once.  Every replica gets a DIFFERENT
+    input batch here; after 12 overlapping steps each slab must equal, bit for bit, the eager two-lane forward of its own batch (no cross-talk
+    through a shared scratch buffer, counter or stage map), B = 8, 512x512, fp16"""
+    from cfen_vit_dehazing_amd.parallel import split_slab
+    cfg = NetConfig(24, 4, patch_size=32, load_size=256)
+    net = make_net(cfg, "fp16")
+    n, B = cfg.image_size, 8
+    xs = [synthetic_input(B, cfg, seed0=8 * k).to("cuda:0") for k in range(3)]
+    want = [[o.clone() for o in net(x)] for x in xs]                 # two-lane plan, one forward at a time
+    net.serial_plan = True
+    slabs = [torch.empty(7 * B * n * n, dtype=torch.float32, device="cuda:0") for _ in range(3)]
+    gids = []
+    for k in range(3):
+        net.replica = k
+        gids.append(net.capture(xs[k], out=slabs[k])[0])
+    net.replica = 0
+    for s in slabs:
+        s.fill_(float("nan"))
+    torch.cuda.synchronize()
+    streams = [torch.cuda.Stream("cuda:0") for _ in range(3)]
+    for i in range(12):
+        with torch.cuda.stream(streams[i % 3]):
+            net.replay(gids[i % 3])
+    torch.cuda.synchronize()
+    for k in range(3):
+        for a, b in zip(split_slab(slabs[k], B, n), want[k]):
+            assert torch.equal(a, b), k
+    torch.cuda.empty_cache()
+
+
 def test_two_lane_plan_equals_serial_plan_bitwise_full_size():
     """GViT beside LViT on a second lane must not change a single bit (512x512, B=2, eager and graph)"""
     cfg = NetConfig(24, 4, patch_size=32, load_size=256)
