@@ -27,6 +27,8 @@ int& cfen_tune_gvit_dummy_wgs() { static int v = 0; return v; }
 int& cfen_tune_gvit_dummy_us() { static int v = 100; return v; }
 int& cfen_tune_gvit_dummy_stream() { static int v = 0; return v; }
 int& cfen_tune_gvit_chain() { static int v = 1; return v; }   // only nets built with fragment-stream GViT weights (cfg.reserved bit 2) can use it
+int& cfen_tune_gvit_stream() { static int v = 1; return v; }   // 0 never, 1 (default) in the serial launch plan (several forwards in flight: 2.24 against 2.27 ms), 2 always
+                                                                // (one forward at a time on the two-lane plan it is SLOWER, 2.85 against 2.80 ms: 277 us of latency against 134)
 int& cfen_tune_tail_fused() { static int v = 1; return v; }
 int& cfen_tune_keep_stages() { static int v = 0; return v; }
 int& cfen_tune_resblock_fused() { static int v = 0; return v; }   // 0 (default): MEASURED with three forwards in flight 2.44 against 2.48 ms -- the fused kernel (5-wave workgroups, 58 KB of LDS, 154 registers) is 13 us shorter alone and costs more CU-time beside other forwards
@@ -98,6 +100,7 @@ struct Vit {
   bool fused_front; // gather+embedding+LN1+qkv run as one k_embed_qkv launch
   bool ln_fold1, ln_fold2;   // LN1 / LN2 ride on the qkv / ffn1 GEMM (k_gemm_dma row statistics + folded weights), no LayerNorm launch
   bool fused_window;// the whole block runs as one k_lvit_window launch (one workgroup per window)
+  bool gstream;     // GViT with embedding dim 384: the block runs on the LViT-3 stream kernels (k_front3 / k_mlp3; "<name>.embed.ws" ... ".head.ws")
   bool chain;       // GViT: the GEMMs run as two persistent chains (k_gvit.hip) on fragment-stream weights ("<name>.embed.wf" ... ".head2.wf")
   bool stream_mlp;  // out_proj + LN2 + FFN + mlp_head + fold can run as one k_mlp3 launch on fragment-stream weights ("<name>.proj.ws" / ".ffn.ws" / ".head.ws")
 };
@@ -343,6 +346,8 @@ int cfen_net::build() {
     v.fused_front = !v.global && !v.shrink && cfen_embed_qkv_supported(v.D);
     v.fused_window = !v.global && v.fused_mlp && v.fused_front && cfen_lvit_window_supported(cfg.dtype, v.D, v.heads, v.S, v.hidden);
     v.stream_mlp = !v.global && !v.shrink && (v.D == 384 ? !v.fused_mlp : v.D == 192) && v.hidden <= 4 * v.D && cfen_mlp3_supported(cfg.dtype, v.D, v.hidden);
+    v.gstream = v.global && !v.shrink && cfg.dtype == CFEN_F16 && v.D == 384 && v.hidden <= 4 * v.D && cfen_mlp3_supported(cfg.dtype, v.D, v.hidden) &&
+                v.C % 8 == 0;
     v.chain = v.global && gvit_stream && !v.shrink && v.D % 128 == 0 && v.hidden % 128 == 0;
     v.ln_fold1 = !v.fused_front && v.Dn == v.D && (v.D * esz) % 128 == 0;
     v.ln_fold2 = !v.fused_mlp && v.Dn == v.D && (v.D * esz) % 128 == 0;
@@ -367,6 +372,10 @@ int cfen_net::build() {
     if (v.ln_fold2) { need(n + ".ffn1.wl", wbytes(v, v.hidden, v.D)); need(n + ".ffn1.s", (size_t)v.hidden * 4); need(n + ".ffn1.bl", (size_t)v.hidden * 4); }
     if (v.stream_mlp) {
       if (v.D == 384) { need(n + ".embed.ws", (size_t)v.D * v.D * esz); need(n + ".qkv.ws", (size_t)3 * v.D * v.D * esz); }
+      need(n + ".proj.ws", (size_t)v.D * v.D * esz); need(n + ".ffn.ws", (size_t)2 * v.D * v.hidden * esz); need(n + ".head.ws", (size_t)2 * v.D * v.hidden * esz);
+    }
+    if (v.gstream) {
+      need(n + ".embed.ws", (size_t)v.D * v.D * esz); need(n + ".qkv.ws", (size_t)3 * v.D * v.D * esz);
       need(n + ".proj.ws", (size_t)v.D * v.D * esz); need(n + ".ffn.ws", (size_t)2 * v.D * v.hidden * esz); need(n + ".head.ws", (size_t)2 * v.D * v.hidden * esz);
     }
     if (v.chain) {
@@ -621,6 +630,40 @@ int cfen_net::run_vit_g(int ng, const VitCall* vc, int scr0) {
                            v.global && wtile};
     return cfen_gemm_impl_g(dt, ng, gp, K, K, N, v.S, N, M, N, K, relu, nullptr, stream, v.global ? SK : nullptr, v.global ? SPLITK_BYTES : 0);
   };
+  if (v.gstream && (cfen_tune_gvit_stream() == 2 || (cfen_tune_gvit_stream() == 1 && !(parallel && !profiling))) && cfen_front3_supported(dt, v.D, (long long)M)) {
+    // GViT block of embedding dim 384 (level 1) on the LViT-3 stream kernels: 4 x 4 pooled MAP -> k_front3 (patch gather + linear_encoding + residual +
+    // position + LN1 + in_proj, qkv row-major) -> attention -> k_mlp3 (out_proj + LN2 + FFN + mlp_head + fold into the pooled-size map) -> x4
+    // bilinear: 5 launches instead of 10, and the two stream launches are 16 whole-CU workgroups per block -- 2-3x the latency of the GEMM chain and
+    // a fraction of its CU-time, which is what counts with several forwards in flight
+    const void* PM[3];
+    for (int g = 0; g < ng; ++g) PM[g] = X0[g];          // the token scratch holds the pooled map: B x mapH x mapH x C = M x D elements
+    step("pool4");
+    TRYP(K_TOKEN, 0, cfen_pool4_impl_g(dt, ng, IN, X0, B, v.mapH, v.mapH, v.C, bi.cs, v.C, stream));
+    CfenEmbedQkvArgs e[3];
+    for (int g = 0; g < ng; ++g)
+      e[g] = CfenEmbedQkvArgs{PM[g], B, v.mapH, v.mapH, v.C, v.C, v.ws, v.p, P(nm[g] + ".embed.ws"), Pf(nm[g] + ".embed.b"), P(nm[g] + ".pos"),
+                              Pf(nm[g] + ".ln1.g"), Pf(nm[g] + ".ln1.b"), P(nm[g] + ".qkv.ws"), X1[g], QKV[g], M, v.D, 1e-5f, 0};
+    step("front_stream");
+    TRYP(K_GEMM, 8 * Md * D * D, cfen_front3_impl_g(dt, ng, e, stream));
+    step("attention");
+    TRYP(K_ATTN, 4 * Md * v.S * D, cfen_attention_impl_g(dt, ng, cQKV, ATT, B * nwin, v.S, v.heads, v.dh, stream));
+    Mlp3Args m[3];
+    for (int g = 0; g < ng; ++g) {
+      const std::string& n = nm[g];
+      m[g] = Mlp3Args{};
+      m[g].X = X1[g]; m[g].A = ATT[g]; m[g].Wp = P(n + ".proj.ws"); m[g].Y = nullptr; m[g].fmap = SM[g];
+      m[g].ln_g = Pf(n + ".ln2.g"); m[g].ln_b = Pf(n + ".ln2.b");
+      m[g].Wa = P(n + ".ffn.ws"); m[g].b1a = Pf(n + ".ffn1.b"); m[g].b2a = Pf(n + ".ffn2.b");
+      m[g].Wb = P(n + ".head.ws"); m[g].b1b = Pf(n + ".head1.b"); m[g].b2b = Pf(n + ".head2.b");
+      m[g].M = M; m[g].D = v.D; m[g].H = v.hidden; m[g].eps = 1e-5f;
+      m[g].mapH = v.mapH; m[g].mapW = v.mapH; m[g].C = v.C; m[g].cs = v.C; m[g].ws = v.ws; m[g].p = v.p;
+    }
+    step("proj_mlp_stream");
+    TRYP(K_MLP, 8 * Md * D * Hd + 2 * Md * D * D, cfen_mlp3_impl_g(dt, ng, m, stream));
+    step("upsample4");
+    TRYP(K_TOKEN, 0, cfen_upsample4_impl_g(dt, ng, cSM, OUT, B, v.mapH, v.mapH, v.C, v.C, bo.cs, stream));
+    return CFEN_OK;
+  }
   if (v.chain && (cfen_tune_gvit_chain() == 1 || (cfen_tune_gvit_chain() == 2 && ng > 1) || (cfen_tune_gvit_chain() == 3 && ng == 1))) {
     // GViT block: pooled patch tokens -> [embed -> qkv] -> attention -> [proj -> ffn1 -> ffn2 -> head1 -> head2 + fold] -> x4 bilinear; the two
     // bracketed runs are ONE persistent launch each (k_gvit.hip): a team of workgroups per block keeps its CUs over the whole run

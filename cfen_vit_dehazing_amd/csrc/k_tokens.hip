@@ -276,6 +276,38 @@ int run_upsample4(int ng, const void* const* small, void* const* out, int B, int
 }
 
 
+// GViT's avgpool2(avgpool2(x)) (v3:1274) as a MAP: out[b][y][x][c] = mean of the 4 x 4 block of `in` -- what k_patchify(pool = 4) computes, kept in NHWC
+// so that the fragment-stream front half (k_front3) can gather its 4 x 4 patches from it like an LViT block does from the level's map
+template <typename T>
+__global__ __launch_bounds__(256) void k_pool4(PtrG<const T> ing, PtrG<T> outg, int B, int h, int w, int C, int cs_in, int cs_out, long long nvec) {
+  const T* __restrict__ in = ing.p[blockIdx.z];
+  T* __restrict__ out = outg.p[blockIdx.z];
+  constexpr int EPL = Vec16<T>::N;
+  const int cv = C / EPL;
+  for (long long idx = (long long)blockIdx.x * 256 + threadIdx.x; idx < nvec; idx += (long long)gridDim.x * 256) {
+    const int v = (int)(idx % cv);
+    const long long px = idx / cv;
+    const int x = (int)(px % w), y = (int)((px / w) % h), b = (int)(px / ((long long)w * h));
+    const size_t W4 = (size_t)w * 4;
+    const T* src = in + (((size_t)b * h * 4 + (size_t)y * 4) * W4 + (size_t)x * 4) * cs_in + v * EPL;
+    typename Mma<T>::frag q[16];
+#pragma unroll
+    for (int dy = 0; dy < 4; ++dy)
+#pragma unroll
+      for (int dx = 0; dx < 4; ++dx) q[dy * 4 + dx] = load_frag<T>(src + ((size_t)dy * W4 + dx) * cs_in);
+    float o[EPL];
+#pragma unroll
+    for (int e = 0; e < EPL; ++e) o[e] = 0.f;
+#pragma unroll
+    for (int k = 0; k < 16; ++k)            // the summation order of k_patchify's pooled branch: the two paths produce the same tokens bit for bit
+#pragma unroll
+      for (int e = 0; e < EPL; ++e) o[e] += (float)q[k][e];
+#pragma unroll
+    for (int e = 0; e < EPL; ++e) o[e] *= 1.f / 16.f;
+    Vec16<T>::store(out + (size_t)px * cs_out + v * EPL, o);
+  }
+}
+
 // What-if probe ("net.gvit_dummy_*"): hold `gridDim.x` CUs for `ticks` / 100 us the way a persistent GViT block kernel would (one 512-thread
 // workgroup with 100 KB of LDS per CU), optionally streaming 16-byte loads meanwhile.  Timing experiments only: writes nothing but `sink`.
 __global__ __launch_bounds__(512) void k_occupy(const uint4* __restrict__ src, size_t nvec, unsigned ticks, int do_stream, unsigned* sink) {
@@ -315,6 +347,25 @@ __global__ __launch_bounds__(256) void k_occupy_small(const uint4* __restrict__ 
     __builtin_amdgcn_s_sleep(32);
   }
   if (acc == 0x12345677u) sink[0] = acc;
+}
+
+int cfen_pool4_impl_g(int dtype, int ng, const void* const* in, void* const* out, int B, int h, int w, int C, int cs_in, int cs_out, hipStream_t s) {
+  CFEN_CHECK_ARG(ng >= 1 && ng <= CFEN_MAX_GROUPS && B > 0 && h > 0 && w > 0 && C > 0, "pool4: bad arguments");
+  const int epl = dtype == 1 ? 8 : 4;
+  CFEN_CHECK_ARG((dtype == 0 || dtype == 1) && C % epl == 0 && cs_in % epl == 0 && cs_out % epl == 0 && cs_in >= C && cs_out >= C, "pool4: channels must be multiples of %d", epl);
+  const long long nvec = (long long)B * h * w * (C / epl);
+  for (int k = 0; k < ng; ++k) CFEN_CHECK_ARG(in[k] && out[k] && cfen_aligned16(in[k]) && cfen_aligned16(out[k]), "pool4: null or misaligned pointer");
+  if (dtype == 1) {
+    PtrG<const half_t> a{}; PtrG<half_t> o{};
+    for (int k = 0; k < ng; ++k) { a.p[k] = (const half_t*)in[k]; o.p[k] = (half_t*)out[k]; }
+    CFEN_LAUNCH(k_pool4<half_t>, dim3(grid_for(nvec), 1, ng), dim3(256), 0, s, a, o, B, h, w, C, cs_in, cs_out, nvec);
+  } else {
+    PtrG<const float> a{}; PtrG<float> o{};
+    for (int k = 0; k < ng; ++k) { a.p[k] = (const float*)in[k]; o.p[k] = (float*)out[k]; }
+    CFEN_LAUNCH(k_pool4<float>, dim3(grid_for(nvec), 1, ng), dim3(256), 0, s, a, o, B, h, w, C, cs_in, cs_out, nvec);
+  }
+  CFEN_CHECK_LAUNCH("pool4");
+  return CFEN_OK;
 }
 
 int cfen_occupy_impl(int wgs, int ng, int usec, int do_stream, const void* src, size_t src_bytes, void* sink, hipStream_t s) {

@@ -185,6 +185,12 @@ def mlp_is_streamed(g, dtype):
             and g.hidden <= 4 * g.dim)
 
 
+def gvit_is_streamed(g, dtype):
+    """mirror of cfen_net.cpp Vit::gstream: GViT blocks of embedding dim 384 (level 1) run on the LViT-3 stream kernels (k_front3 / k_mlp3)"""
+    return (g.kind == "gvit" and g.shrink == 1 and dtype == torch.float16 and g.dim == 384 and g.hidden % 32 == 0 and g.hidden <= 4 * g.dim
+            and g.channels % 8 == 0)
+
+
 GVIT_WEIGHT_SUFFIXES = (".embed.w", ".qkv.w", ".qkv.wl", ".proj.w", ".ffn1.w", ".ffn1.wl", ".ffn2.w", ".head1.w", ".head2.w")
 
 
@@ -299,6 +305,15 @@ def pack_vit(sd, g, dtype):
             out[n + "." + nm + ".wk"] = (w[:, kperm32(g.dim)] if dtype == torch.float16 else w).contiguous()
     if window_fusable(g, dtype):
         out.update(pack_lvit_window(sd, g, dtype))
+    if gvit_is_streamed(g, dtype):
+        # the same fragment streams for a GViT block of dim 384 ("net.gvit_stream": pooled map -> k_front3 -> attention -> k_mlp3); the row-major /
+        # tile-major matrices stay for the launch-per-GEMM plan
+        kd, kh = kperm32(g.dim), kperm32(g.hidden)
+        out[n + ".proj.ws"] = pack_stream_sq(out[n + ".proj.w"])
+        out[n + ".ffn.ws"] = pack_stream_pair(out[n + ".ffn1.w"][:, kd], out[n + ".ffn2.w"][:, kh])
+        out[n + ".head.ws"] = pack_stream_pair(out[n + ".head1.w"][:, kd], out[n + ".head2.w"][:, kh])
+        out[n + ".embed.ws"] = pack_stream_rows(out[n + ".embed.w"][:, kd])
+        out[n + ".qkv.ws"] = pack_stream_rows(out[n + ".qkv.w"][:, kd])
     if mlp_is_streamed(g, dtype):
         # k_mlp3 (csrc/k_stream.hip): out_proj, FFN pair and mlp_head pair as fragment streams; the row-major matrices stay for "net.stream_mlp" = 0
         kd, kh = kperm32(g.dim), kperm32(g.hidden)

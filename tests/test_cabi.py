@@ -42,7 +42,7 @@ def test_argument_errors_do_not_need_a_gpu():
     assert abs(lib.cfen_net_flops_per_image(h) / 1e9 - 120.85) < 0.01           # SURVEY 8d closed form
     assert lib.cfen_net_set_param(h, b"no.such.param", ctypes.c_void_p(16), 4) == -1
     buf = ctypes.create_string_buffer(1 << 16)
-    assert lib.cfen_net_missing_params(h, buf, 1 << 16) == 670   # (+ 1: head.0.0.w5, the 8-byte-pixel layout of k_head5, round 4) (+ 4 level-3 LViT blocks x 5 and 4 level-2 blocks x 3 fragment-stream layouts, round 3; the window kernel's three layouts became one stream) 24 transformer blocks x 21 + 15 conv layers x 3 ... + 8 LViT blocks with the extra fused-front layouts (2 each) + 4 level-1 LViT blocks x 1 window-kernel weight stream + 16 unfused blocks (GViT, LViT-3) x 6 LayerNorm-folded entries
+    assert lib.cfen_net_missing_params(h, buf, 1 << 16) == 690   # (+ 1: head.0.0.w5, the 8-byte-pixel layout of k_head5; + 4 level-1 GViT blocks x 5 fragment-stream layouts, round 4) (+ 4 level-3 LViT blocks x 5 and 4 level-2 blocks x 3 fragment-stream layouts, round 3; the window kernel's three layouts became one stream) 24 transformer blocks x 21 + 15 conv layers x 3 ... + 8 LViT blocks with the extra fused-front layouts (2 each) + 4 level-1 LViT blocks x 1 window-kernel weight stream + 16 unfused blocks (GViT, LViT-3) x 6 LayerNorm-folded entries
     lib.cfen_net_destroy(h)
     for hdr, gf in ((2, 85.07),):
         cfg.hidden_dim_ratio = hdr
