@@ -483,15 +483,19 @@ def test_gvit_persistent_chain_plan_agrees_with_the_launch_per_gemm_plan():
 def test_three_forwards_in_flight_on_replica_plans_match_single_forwards_bitwise():
     """what bench.py times by default (round 4): consecutive steps rotate over three launch plans -- one serial chain of launches each, own
     workspace and output slab, shared packed weights -- on three streams, so three forwards are in flight at once.  Every replica gets a DIFFERENT
-    input batch here; after 12 overlapping steps each slab must equal, bit for bit, the eager two-lane forward of its own batch (no cross-talk
+    input batch here; after 12 overlapping steps each slab must equal, bit for bit, the eager one-at-a-time forward of its own batch on the same plan (no cross-talk
     through a shared scratch buffer, counter or stage map), B = 8, 512x512, fp16"""
     from cfen_vit_dehazing_amd.parallel import split_slab
     cfg = NetConfig(24, 4, patch_size=32, load_size=256)
     net = make_net(cfg, "fp16")
     n, B = cfg.image_size, 8
     xs = [synthetic_input(B, cfg, seed0=8 * k).to("cuda:0") for k in range(3)]
-    want = [[o.clone() for o in net(x)] for x in xs]                 # two-lane plan, one forward at a time
+    two_lane = [[o.clone() for o in net(x)] for x in xs]             # two-lane plan, one forward at a time
     net.serial_plan = True
+    want = [[o.clone() for o in net(x)] for x in xs]                 # the serial plan, eagerly, one forward at a time
+    # (the serial plan runs GViT level 1 on the stream kernels: the same math in another summation order -- fp16-rounding close to the two-lane plan)
+    for a, b in zip(sum(want, []), sum(two_lane, [])):
+        assert float((a - b).abs().max()) <= 1e-2
     slabs = [torch.empty(7 * B * n * n, dtype=torch.float32, device="cuda:0") for _ in range(3)]
     gids = []
     for k in range(3):
@@ -513,18 +517,34 @@ def test_three_forwards_in_flight_on_replica_plans_match_single_forwards_bitwise
 
 
 def test_two_lane_plan_equals_serial_plan_bitwise_full_size():
-    """GViT beside LViT on a second lane must not change a single bit (512x512, B=2, eager and graph)"""
+    """GViT beside LViT on a second lane must not change a single bit (512x512, B=2, eager and graph) -- with the same kernels on both plans
+    ("net.gvit_stream" = 0: by default the serial plan runs GViT level 1 on the stream kernels, same math in another summation order, which is
+    checked to fp16 rounding below and bitwise against itself by test_three_forwards_in_flight_...)"""
+    from cfen_vit_dehazing_amd import ops
     cfg = NetConfig(24, 4, patch_size=32, load_size=256)
-    net = make_net(cfg, "fp16")
     x = synthetic_input(2, cfg).to("cuda:0")
-    two = [o.clone() for o in net(x)]
-    gid, gouts = net.capture(x)
-    net.replay(gid)
-    torch.cuda.synchronize()
-    net.serial_plan = True
-    one = [o.clone() for o in net(x)]
-    for a, b, c in zip(two, one, gouts):
-        assert torch.equal(a, b) and torch.equal(a, c)
+    try:
+        ops.tune("net.gvit_stream", 0)
+        net = make_net(cfg, "fp16")
+        two = [o.clone() for o in net(x)]
+        gid, gouts = net.capture(x)
+        net.replay(gid)
+        torch.cuda.synchronize()
+        net.serial_plan = True
+        one = [o.clone() for o in net(x)]
+        for a, b, c in zip(two, one, gouts):
+            assert torch.equal(a, b) and torch.equal(a, c)
+    finally:
+        ops.tune("net.gvit_stream", 1)
+    net2 = make_net(cfg, "fp16")
+    net2.serial_plan = True
+    streamed = [o.clone() for o in net2(x)]
+    st = net2.stage("globalvit_encoder_01")
+    net2.serial_plan = False
+    net2(x)
+    assert float((st - net2.stage("globalvit_encoder_01")).abs().max()) <= 3e-2 * max(1.0, float(st.abs().max()))
+    for a, b in zip(streamed, two):
+        assert float((a - b).abs().max()) <= 1e-2
 
 
 def test_repeated_forwards_are_bit_reproducible_at_benchmark_size():
