@@ -162,6 +162,9 @@ def self_check(net, x, outs, cfg, dtype):
     bar = 3e-2 if dtype == "fp16" else 1e-3
     res["bar"] = bar
     res["ok"] = all(v <= bar for k, v in res.items() if k.startswith("image0"))
+    if getattr(net, "gvit_chain", False):       # the persistent-chain variant: a grid-barrier wait that gave up leaves a mark (csrc/k_gvit.hip)
+        res["chain_error_words"] = net.chain_errors()
+        res["ok"] = res["ok"] and not any(res["chain_error_words"])
     return res
 
 
