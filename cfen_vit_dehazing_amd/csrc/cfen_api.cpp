@@ -262,7 +262,7 @@ int cfen_tune(const char* key, int value) {
     cfen_tune_gemm_splitk_stages() = value;
     return CFEN_OK;
   }
-  if (!strcmp(key, "gemm.splitk_release")) { cfen_tune_gemm_splitk_release() = value != 0; return CFEN_OK; }
+  if (!strcmp(key, "gemm.splitk_release")) { cfen_tune_gemm_splitk_release() = value; return CFEN_OK; }
   if (!strcmp(key, "gemm.splitk")) {
     cfen_tune_gemm_splitk() = value != 0;
     return CFEN_OK;

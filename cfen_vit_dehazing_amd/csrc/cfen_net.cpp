@@ -664,12 +664,14 @@ int cfen_net::run_vit_g(int ng, const VitCall* vc, int scr0) {
     TRYP(K_TOKEN, 0, cfen_upsample4_impl_g(dt, ng, cSM, OUT, B, v.mapH, v.mapH, v.C, v.C, bo.cs, stream));
     return CFEN_OK;
   }
-  if (v.chain && (cfen_tune_gvit_chain() == 1 || (cfen_tune_gvit_chain() == 2 && ng > 1) || (cfen_tune_gvit_chain() == 3 && ng == 1))) {
+  if (v.chain && (cfen_tune_gvit_chain() == 1 || cfen_tune_gvit_chain() == 4 || (cfen_tune_gvit_chain() == 2 && ng > 1) || (cfen_tune_gvit_chain() == 3 && ng == 1))) {
     // GViT block: pooled patch tokens -> [embed -> qkv] -> attention -> [proj -> ffn1 -> ffn2 -> head1 -> head2 + fold] -> x4 bilinear; the two
     // bracketed runs are ONE persistent launch each (k_gvit.hip): a team of workgroups per block keeps its CUs over the whole run
     const int team = std::min(cfen_tune_gvit_team(), 256 / ng);
+    const bool per_gemm = cfen_tune_gvit_chain() == 4;   // every GEMM its own launch of the chain kernel, never split over K: no grid barrier, no split-K seam
     auto nsp = [&](int N, int K) {   // K slices so that the phase has work for most of the team (>= 4 K-steps of 64 per slice)
       int n = 1;
+      if (per_gemm) return n;
       const int units = ((M + 127) / 128) * (N / 128);
       while (units * n * 2 <= team && n < 8 && (K / 64) % (2 * n) == 0 && K / 64 / (2 * n) >= 4) n *= 2;
       return n;
@@ -696,8 +698,28 @@ int cfen_net::run_vit_g(int ng, const VitCall* vc, int scr0) {
       TRY(sync_of(g, c));
     }
     ++gv_launch;
-    step("chain_embed_qkv");
-    TRYP(K_GEMM, 8 * Md * D * D, cfen_gvit_chain_impl_g(dt, ng, ca, team, stream));
+    auto run_chain = [&](const char* what, double fl) -> int {
+      if (!per_gemm) {
+        step(what);
+        TRYP(K_GEMM, fl, cfen_gvit_chain_impl_g(dt, ng, ca, team, stream));
+        return CFEN_OK;
+      }
+      const int nph = ca[0].nph;
+      for (int p = 0; p < nph; ++p) {
+        CfenChainArgs one[3];
+        for (int g = 0; g < ng; ++g) {
+          one[g] = ca[g];
+          one[g].ph[0] = ca[g].ph[p];
+          one[g].nph = 1;
+        }
+        const int units = ((M + 127) / 128) * (one[0].ph[0].N / 128);
+        const std::string lab = std::string(what) + "." + std::to_string(p);
+        step(lab.c_str());
+        TRYP(K_GEMM, fl / nph, cfen_gvit_chain_impl_g(dt, ng, one, std::min(team, units), stream));
+      }
+      return CFEN_OK;
+    };
+    TRY(run_chain("chain_embed_qkv", 8 * Md * D * D));
     step("attention");
     TRYP(K_ATTN, 4 * Md * v.S * D, cfen_attention_impl_g(dt, ng, cQKV, ATT, B * nwin, v.S, v.heads, v.dh, stream));
     for (int g = 0; g < ng; ++g) {
@@ -714,8 +736,7 @@ int cfen_net::run_vit_g(int ng, const VitCall* vc, int scr0) {
       TRY(sync_of(g, c));
     }
     ++gv_launch;
-    step("chain_proj_mlp_head");
-    TRYP(K_GEMM, 2 * Md * D * D + 8 * Md * D * Hd, cfen_gvit_chain_impl_g(dt, ng, ca, team, stream));
+    TRY(run_chain("chain_proj_mlp_head", 2 * Md * D * D + 8 * Md * D * Hd));
     step("upsample4");
     TRYP(K_TOKEN, 0, cfen_upsample4_impl_g(dt, ng, cSM, OUT, B, v.mapH, v.mapH, v.C, v.C, bo.cs, stream));
     return CFEN_OK;

@@ -105,6 +105,7 @@ struct GvArgs {
   unsigned* err;    // raised when a wait gave up
   float eps;
   int dbg;
+  int release;
 };
 
 __global__ __launch_bounds__(512) void k_gvit_chain(Grouped<GvArgs> ga) {
@@ -201,9 +202,14 @@ __global__ __launch_bounds__(512) void k_gvit_chain(Grouped<GvArgs> ga) {
         for (int i = 0; i < 8; ++i) {
           const floatx4 v = acc[i];
           const u32x4 bits = {__float_as_uint(v[0]), __float_as_uint(v[1]), __float_as_uint(v[2]), __float_as_uint(v[3])};
-          __builtin_amdgcn_raw_buffer_store_b128(bits, prs, (int)(pbase + (i * 512 + tid) * 16), 0, 16);   // aux 16 = sc1
+          if (a.release == 2) __builtin_amdgcn_raw_buffer_store_b128(bits, prs, (int)(pbase + (i * 512 + tid) * 16), 0, 0);    // plain stores: the canonical recipe
+          else __builtin_amdgcn_raw_buffer_store_b128(bits, prs, (int)(pbase + (i * 512 + tid) * 16), 0, 16);   // aux 16 = sc1
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (a.release) {   // "gemm.splitk_release" (default 1, round 4): an agent-scope release on top of the write-through stores -- see the note at the host entry
+          __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
         __syncthreads();
         if (tid == 0) *flag = __hip_atomic_fetch_add(a.cnt + tile, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         __syncthreads();
@@ -305,7 +311,7 @@ int cfen_gvit_chain_impl_g(int dtype, int ng, const CfenChainArgs* ca, int team,
     GvArgs& a = ga.g[g];
     CFEN_CHECK_ARG(c.nph >= 1 && c.nph <= GV_MAX_PHASES && c.M >= 1 && c.M == ca[0].M && c.nph == ca[0].nph, "gvit_chain: bad phase count / token count");
     CFEN_CHECK_ARG(c.bar && c.cnt && c.err && cfen_aligned16(c.part), "gvit_chain: synchronisation words missing");
-    a.nph = c.nph; a.M = c.M; a.bar = c.bar; a.cnt = c.cnt; a.part = c.part; a.err = c.err; a.eps = cfen_gemm_lnf_eps(); a.dbg = cfen_tune_gvit_debug();
+    a.nph = c.nph; a.M = c.M; a.bar = c.bar; a.cnt = c.cnt; a.part = c.part; a.err = c.err; a.eps = cfen_gemm_lnf_eps(); a.dbg = cfen_tune_gvit_debug(); a.release = cfen_tune_gemm_splitk_release();
     a.fold = GvFold{c.fH, c.fW, c.fcs, c.fC, c.fp};
     const int tbs = (c.M + 127) / 128;
     for (int p = 0; p < c.nph; ++p) {
