@@ -180,8 +180,14 @@ struct UpConv3Args {
 };
 
 template <int PIXB> CFEN_DEV int uf_swz(int col) { return ((col >> 2) & 1) << 1; }   // k_conv_tile.hip convt_swz<64>
+// Column -> pixel slot of the 3x3's input tile (32-byte pixels).  The ConvTranspose epilogue writes 8 bytes per lane at a pixel stride of 2
+// (one parity phase per wave): ds_write_b64 is banked in groups of 16 lanes over 128 bytes, so at the identity map the 16 lanes of a group fall on
+// two bank pairs -- 8-way, 32 LDS cycles per store against 4 (SQ_LDS_BANK_CONFLICT 1.4x the kernel's conflict-free LDS cycles, round 4).  Swapping
+// the pixel pairs of columns 4..7 (mod 8) brings that to 3-way and keeps every ds_read_b128 of the 3x3 stage conflict-free for its column bases
+// 16 w + 2 c (exhaustive search over per-column XOR flips under the guide's lane groups: no 2-way map with conflict-free reads exists).
+CFEN_DEV int uf_t1col(int col) { return col ^ ((col >> 2) & 1); }
 
-__global__ __launch_bounds__(256) void k_up_conv3_fused(Grouped<UpConv3Args> ga, int nblk) {
+__global__ __launch_bounds__(256, 3) void k_up_conv3_fused(Grouped<UpConv3Args> ga, int nblk) {
   const UpConv3Args& a = ga.g[blockIdx.z];
   typedef half_t T;
   typedef half8 frag;
@@ -250,16 +256,17 @@ __global__ __launch_bounds__(256) void k_up_conv3_fused(Grouped<UpConv3Args> ga,
     }
     const floatx4 sc = *reinterpret_cast<const floatx4*>(a.sT + n), sh = *reinterpret_cast<const floatx4*>(a.tT + n);
     __syncthreads();                                        // every wave is done with the halo: its place becomes the 3x3's input tile
-    if (tid < UF_T1R * 2) *reinterpret_cast<frag*>(t1 + (tid >> 1) * UF_T1B + 66 * 32 + (tid & 1) * 16) = Mma<T>::zero();   // column 66 meets zero weights only
+    if (tid < UF_T1R * 2) *reinterpret_cast<frag*>(t1 + (tid >> 1) * UF_T1B + uf_t1col(66) * 32 + (tid & 1) * 16) = Mma<T>::zero();   // column 66 meets zero weights only
     // column part of the epilogue, once per lane and column tile: the tile column of the lane's output, whether it belongs to the 66-wide tile, and
     // the (scale, shift) pair with the image-border mask folded in (a column outside the image becomes exact zeros: the 3x3's padding)
-    int tcol[UF_NX];
+    int tcol[UF_NX], tpix[UF_NX];
     bool tin[UF_NX];
     floatx4 scx[UF_NX], shx[UF_NX];
 #pragma unroll
     for (int xq = 0; xq < UF_NX; ++xq) {
       tcol[xq] = 2 * (xq * 16 + r16) + px - 1;              // X - (X0 - 1)
       tin[xq] = tcol[xq] >= 0 && tcol[xq] <= 65;
+      tpix[xq] = uf_t1col(tcol[xq] & 127);
       const int X = X0 - 1 + tcol[xq];
       const bool ximg = X >= 0 && X < Wf;
       scx[xq] = ximg ? sc : floatx4{0.f, 0.f, 0.f, 0.f};
@@ -281,7 +288,7 @@ __global__ __launch_bounds__(256) void k_up_conv3_fused(Grouped<UpConv3Args> ga,
         }
         if (!yimg) v = floatx4{0.f, 0.f, 0.f, 0.f};
         const half4 o = {(half_t)v[0], (half_t)v[1], (half_t)v[2], (half_t)v[3]};
-        if (tin[xq]) *reinterpret_cast<half4*>(tw + trow * UF_T1B + tcol[xq] * 32) = o;
+        if (tin[xq]) *reinterpret_cast<half4*>(tw + trow * UF_T1B + tpix[xq] * 32) = o;
         if (a.up_out && tin[xq] && trow >= 1 && trow <= 8 && tcol[xq] >= 1 && tcol[xq] <= 64)
           *reinterpret_cast<half4*>(a.up_out + (((size_t)b * Hf + Y) * Wf + X0 - 1 + tcol[xq]) * 16 + n) = o;
       }
@@ -299,12 +306,15 @@ __global__ __launch_bounds__(256) void k_up_conv3_fused(Grouped<UpConv3Args> ga,
     floatx4 acc[8];
 #pragma unroll
     for (int r = 0; r < 8; ++r) acc[r] = floatx4{0.f, 0.f, 0.f, 0.f};
-    const unsigned char* lp = t1 + (wave * 16 + r16) * 32 + h * 16;
+    // k quarter h of chunk c = 16 bytes of column 16 w + r16 + 2 c + (h >> 1), half h & 1
+    const unsigned char* lp[2];
+#pragma unroll
+    for (int c = 0; c < 2; ++c) lp[c] = t1 + uf_t1col(wave * 16 + r16 + 2 * c + (h >> 1)) * 32 + (h & 1) * 16;
 #pragma unroll
     for (int iy = 0; iy < UF_T1R; ++iy)
 #pragma unroll
       for (int c = 0; c < 2; ++c) {
-        const frag bf = *reinterpret_cast<const frag*>(lp + iy * UF_T1B + c * 64);
+        const frag bf = *reinterpret_cast<const frag*>(lp[c] + iy * UF_T1B);
 #pragma unroll
         for (int r = 0; r < 8; ++r) {
           const int dy = iy - r;
