@@ -21,6 +21,11 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
+# The pipelined run keeps --in-flight forwards on as many streams; the HIP runtime deals a process's streams onto GPU_MAX_HW_QUEUES hardware
+# queues (default 4), and two streams on one queue run one behind the other.  Measured on MI355X (profiles/r04_ab_hw_queues.txt): 4 forwards in
+# flight 2.51 ms / step on 4 queues, 2.10 on 8 (3 in flight: 2.18 either way).  Must be in the environment before the first HIP call.
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+
 import torch
 
 MFMA_PEAK_TFLOPS = {"fp16": 2500.0, "fp32": 157.3}     # /opt/skills/guides/MI355X_MICROARCH.md chip table (dense)
@@ -222,7 +227,7 @@ def main():
     ap.add_argument("--no-graph", action="store_true", help="launch eagerly instead of replaying a hipGraph")
     ap.add_argument("--gather-dtype", default="auto", choices=["auto", "fp16", "fp32"],
                     help="wire type of the output all-gather (N > 1); auto = the compute dtype")
-    ap.add_argument("--in-flight", type=int, default=3, choices=[1, 2, 3, 4],
+    ap.add_argument("--in-flight", type=int, default=4, choices=[1, 2, 3, 4, 5, 6],
                     help="forwards in flight: N > 1 = consecutive steps rotate over N launch plans (own workspace and output slab each, shared "
                          "weights) on N streams, so the tail of step i overlaps the head of steps i + 1 .. i + N - 1; every step is still one whole forward of "
                          "one batch and all K steps complete inside the timed region")
@@ -438,7 +443,7 @@ def main():
             "scaling": "weak", "vs_baseline": None, "dtype": "f16" if args.dtype == "fp16" else "f32", "data": "synthetic",
             "config": {"workload": "batch=%d/GPU %dx%d n_feats=24 hidden_dim_ratio=%d %s%s, weights random-init (seeded generator)"
                                    % (B, n, n, args.hidden_dim_ratio, args.dtype, "" if args.variant == "v3" else " generator variant " + args.variant),
-                       "global_batch": world * B, "parallelism": "dp%d" % world, "graph": graphs is not None, "forwards_in_flight": nfl, "lanes_per_forward": 1 if net.serial_plan else 2,
+                       "global_batch": world * B, "parallelism": "dp%d" % world, "graph": graphs is not None, "forwards_in_flight": nfl, "lanes_per_forward": 1 if net.serial_plan else 2, "hw_queues": int(os.environ.get("GPU_MAX_HW_QUEUES", "4")),
                        "gather_dtype": (gdt if world > 1 else None),
                        "gflop_per_image": round(flops_img / 1e9, 2)},
             "roofline": {"bound": bound, "kernel": dom, "achieved": ach, "peak": rpeak, "unit": runit, "frac": rfrac,
