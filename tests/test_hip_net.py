@@ -131,16 +131,19 @@ def test_wrong_input_size_raises():
         net(torch.zeros(1, 3, 128, 128))                          # CPU tensor: no fallback
 
 
-def test_cli_end_to_end_writes_reference_named_pngs(tmp_path):
+@pytest.mark.parametrize("load_size,nimg,precision,levels", [(64, 3, "single", 1), (256, 1, "single", 1), (256, 1, "half", 6)])
+def test_cli_end_to_end_writes_reference_named_pngs(tmp_path, load_size, nimg, precision, levels):
     """python test.py with the reference's README flags on a synthetic checkpoint: PNGs land where the
-    reference puts them and equal tensor2im(oracle output) up to one grey level."""
+    reference puts them and equal tensor2im(oracle output) up to one grey level (fp16: 6 levels = 0.047 of the [-1, 1] range, the fp16
+    output bar of test_fp16_full512_against_reference_vectors, and 99 % of the pixels within one level).  load_size 256 = the benchmark's
+    512 x 512 images through the CLI, not only through the module."""
     import os
     import subprocess
     import sys
     from PIL import Image
     from cfen_vit_dehazing_amd.util import util
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    cfg = NetConfig(24, 4, patch_size=8, load_size=64)
+    cfg = NetConfig(24, 4, patch_size=load_size // 8, load_size=load_size)   # the reference nests its crops: loadSize = 8 * patch_size
     sd = generate_state_dict(cfg, seed=0)
     name = "iid_hlgvit_crs_gd4_cfs_v3_synthetic"
     os.makedirs(tmp_path / "ckpt" / name)
@@ -148,16 +151,16 @@ def test_cli_end_to_end_writes_reference_named_pngs(tmp_path):
     os.makedirs(tmp_path / "data" / "hazy")
     rs = np.random.RandomState(0)
     imgs = []
-    for i in range(3):
-        a = rs.randint(0, 256, (128, 128, 3), dtype=np.uint8)
+    for i in range(nimg):
+        a = rs.randint(0, 256, (2 * load_size, 2 * load_size, 3), dtype=np.uint8)
         Image.fromarray(a).save(tmp_path / "data" / "hazy" / ("syn_%04d.png" % (i + 1)))
         imgs.append(a)
     cmd = [sys.executable, os.path.join(root, "test.py"), "--dataroot", str(tmp_path / "data"), "--name", name, "--n_feats", "24",
-           "--hidden_dim_ratio", "4", "--sb", "--out_all", "--which_epoch", "32", "--loadSize", "64", "--patch_size", "8",
-           "--checkpoints_dir", str(tmp_path / "ckpt"), "--results_dir", str(tmp_path / "res"), "--precision", "single"]
+           "--hidden_dim_ratio", "4", "--sb", "--out_all", "--which_epoch", "32", "--loadSize", str(load_size), "--patch_size", str(load_size // 8),
+           "--checkpoints_dir", str(tmp_path / "ckpt"), "--results_dir", str(tmp_path / "res"), "--precision", precision]
     subprocess.check_call(cmd, cwd=str(tmp_path))
     out_dir = tmp_path / "res" / name / "test_32" / "images"
-    assert sorted(os.listdir(out_dir)) == ["syn_%04d_fake_A.png" % (i + 1) for i in range(3)]
+    assert sorted(os.listdir(out_dir)) == ["syn_%04d_fake_A.png" % (i + 1) for i in range(nimg)]
     live = {k: v for k, v in sd.items()}
     for i, a in enumerate(imgs):
         x = (torch.from_numpy(a).permute(2, 0, 1).float() / 255 - 0.5) / 0.5
@@ -165,8 +168,8 @@ def test_cli_end_to_end_writes_reference_named_pngs(tmp_path):
             xd = cfen_oracle.forward(live, x[None], cfg.num_heads, cfg.patch_size)[2]
         want = util.tensor2im(xd[0]).astype(np.int32)
         got = np.asarray(Image.open(out_dir / ("syn_%04d_fake_A.png" % (i + 1)))).astype(np.int32)
-        assert got.shape == want.shape and np.abs(got - want).max() <= 1
-        assert (got != want).mean() < 0.01
+        assert got.shape == want.shape and np.abs(got - want).max() <= levels
+        assert (got != want).mean() < 0.01 if levels == 1 else (np.abs(got - want) > 1).mean() < 0.01
 
 
 def test_native_graph_replay_equals_eager():
