@@ -343,6 +343,7 @@ int cfen_tune(const char* key, int value) {
   }
   if (!strcmp(key, "net.gvit_stream")) { cfen_tune_gvit_stream() = value != 0; return CFEN_OK; }
   if (!strcmp(key, "net.tail_fused")) { cfen_tune_tail_fused() = value != 0; return CFEN_OK; }
+  if (!strcmp(key, "net.up_fused")) { cfen_tune_up_fused() = value != 0; return CFEN_OK; }
   if (!strcmp(key, "net.keep_stages")) { cfen_tune_keep_stages() = value != 0; return CFEN_OK; }
   if (!strcmp(key, "net.resblock_fused")) { cfen_tune_resblock_fused() = value != 0; return CFEN_OK; }
   if (!strcmp(key, "net.head5")) { cfen_tune_head5() = value != 0; return CFEN_OK; }

@@ -32,6 +32,9 @@ struct ConvDesc {
   void* out;
   int cs_out, Cout_pad, Cout;
   int out_nchw_f32;
+  // optional (k_conv, 1x1 over a concat, LDS-staged weights): source 1 is GViT's LOW-resolution map [B][up_h][up_w][up_cs], up_h = Hin / 4; the kernel
+  // applies upsam(upsam(.)) (v3:1323, k_upsample4's arithmetic) to the pixels of its workgroup in LDS instead of reading a full-resolution copy
+  int up4, up_h, up_w, up_cs;
 };
 
 static inline int cfen_round_up(int v, int m) { return (v + m - 1) / m * m; }
@@ -88,6 +91,7 @@ struct ConvK {
   const float *scale, *shift;
   int Hin, Win, cs_in, Cin, Kpad, ntaps, in_stride, out_stride, B, Hb, Wb, Hout, Wout, pad_reflect, act, cs_res, cs_out, Cout_pad, Cout, out_nchw_f32;
   int oy_off, ox_off;
+  int up_h, up_w, up_cs;
 };
 __device__ __forceinline__ ConvK conv_k(const ConvDesc& r, int phase) {
   ConvK k;
@@ -97,6 +101,7 @@ __device__ __forceinline__ ConvK conv_k(const ConvDesc& r, int phase) {
   k.out_stride = r.out_stride; k.B = r.B; k.Hb = r.Hb; k.Wb = r.Wb; k.Hout = r.Hout; k.Wout = r.Wout; k.pad_reflect = r.pad_reflect;
   k.act = r.act; k.cs_res = r.cs_res; k.cs_out = r.cs_out; k.Cout_pad = r.Cout_pad; k.Cout = r.Cout; k.out_nchw_f32 = r.out_nchw_f32;
   k.oy_off = r.ph_y[phase]; k.ox_off = r.ph_x[phase];
+  k.up_h = r.up_h; k.up_w = r.up_w; k.up_cs = r.up_cs;
   return k;
 }
 #endif

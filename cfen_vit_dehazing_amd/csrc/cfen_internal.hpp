@@ -81,6 +81,7 @@ bool cfen_convT_tile_supported(int dtype, int cs_in, int Cout_pad, int Hin, int 
 int cfen_convT_tile_kpad(int dtype, int cs_in);
 int cfen_convT_tile_impl(int dtype, const ConvDesc* d, hipStream_t s);
 int cfen_conv_impl_g(int dtype, int ng, const ConvDesc* d, hipStream_t s);
+bool cfen_conv_up4_supported(int dtype, int ng, int B, int H, int W, int Cin, int cs_low, int Cout_pad, int Kpad);
 int cfen_conv_tile_impl_g(int dtype, int ng, const ConvDesc* d, int k, hipStream_t s);
 int cfen_convT_tile_impl_g(int dtype, int ng, const ConvDesc* d, hipStream_t s);
 // 7x7, <= 4 output channels, fp32 NCHW output: Toeplitz-expanded weights [16][7][10 taps][16] (k_conv_tile.hip: k_conv7_tz)
@@ -172,6 +173,9 @@ struct CfenUpConv3 {
 };
 bool cfen_up_conv3_fused_supported(int dtype, int cs_in, int Cup_pad, int cs_up, int C3_pad, int Hin, int Win);
 int cfen_up_conv3_fused_impl_g(int dtype, int ng, const CfenUpConv3* u, hipStream_t s);
+int& cfen_tune_up_fused();       // 1: GViT's x4 bilinear runs inside the level's fuse conv (k_conv UP), no k_upsample4 launch ("net.up_fused").  Default 0: measured
+                                 // 6 launches and 0.35 GB of HBM traffic fewer per forward but 0.7 % SLOWER (the 9-tap interpolation per pixel on the vector
+                                 // pipe in front of a K = 48 .. 192 1x1 costs more than the copy it saves: lgcat_conv_d01 72 -> 110 us for a 19 us launch)
 int& cfen_tune_tail_fused();     // 1 (default): us_conv_d01* + tail conv3 run as one k_up_conv3_fused launch where it applies ("net.tail_fused")
 int& cfen_tune_keep_stages();    // 1: fused launches also store the stage maps they keep on chip (us_conv_d01*), for parity tests ("net.keep_stages"; default 0)
 // out (B, h, w, cs_out) = 4 x 4 mean of in (B, 4h, 4w, cs_in): GViT's avgpool . avgpool as a map (k_tokens.hip: k_pool4)

@@ -9,6 +9,7 @@
 #include <stdlib.h>
 #include <algorithm>
 #include <map>
+#include <set>
 #include <string>
 #include <vector>
 
@@ -30,6 +31,7 @@ int& cfen_tune_gvit_chain() { static int v = 1; return v; }   // only nets built
 int& cfen_tune_gvit_stream() { static int v = 1; return v; }   // 0 never, 1 (default) in the serial launch plan (several forwards in flight: 2.24 against 2.27 ms), 2 always
                                                                 // (one forward at a time on the two-lane plan it is SLOWER, 2.85 against 2.80 ms: 277 us of latency against 134)
 int& cfen_tune_tail_fused() { static int v = 1; return v; }
+int& cfen_tune_up_fused() { static int v = 0; return v; }
 int& cfen_tune_keep_stages() { static int v = 0; return v; }
 int& cfen_tune_resblock_fused() { static int v = 0; return v; }   // 0 (default): MEASURED with three forwards in flight 2.44 against 2.48 ms -- the fused kernel (5-wave workgroups, 58 KB of LDS, 154 registers) is 13 us shorter alone and costs more CU-time beside other forwards
 int& cfen_tune_head5() { static int v = 1; return v; }
@@ -142,6 +144,8 @@ struct cfen_net {
   bool gvit_stream = false;        // cfg.reserved bit 2: GViT weights are also held as fragment streams (packing.pack_stream_tiles) -> persistent chains
   int gv_launch = 0;               // persistent-chain launches enqueued so far in this forward (each takes its own barrier word)
   static constexpr int GV_SYNC_WORDS = 1024, GV_ERR_WORD = 512;
+  std::set<std::string> gvit_low;  // GViT outputs the last forward left at low resolution (x4 bilinear inside the fuse conv, ConvDesc::up4): cfen_net_stage refuses them
+  bool gv_skip_up = false;         // run_vit_g (GViT): leave the block's result in the low-resolution scratch map, no k_upsample4
   bool stages_on_chip = false;     // the last forward kept the us_conv_d01* maps in LDS (k_up_conv3_fused without "net.keep_stages"): cfen_net_stage refuses them
   bool head5 = false;              // head.0.0 can run on k_head5 (reads the network input itself)
   bool wtile = false;              // cfg.reserved bit 1: GViT weights are packed tile-major (CfenGemmPtrs::wtile, packing.pack_wtile)
@@ -252,7 +256,10 @@ struct cfen_net {
 
   int build();
   // one convolution of up to CFEN_MAX_GROUPS same-shaped layers (the R / S / D copies of a decoder layer) as ONE launch
-  struct ConvCall { std::string layer, in0, in1, res0, res1, out; float* nchw_out = nullptr; std::string in2 = ""; };   // "" = absent
+  struct ConvCall {
+    std::string layer, in0, in1, res0, res1, out; float* nchw_out = nullptr; std::string in2 = "";   // "" = absent
+    const void* up_low = nullptr; int up_h = 0, up_w = 0, up_cs = 0;   // in1 is read as x4 of this low-resolution map (ConvDesc::up4)
+  };
   int run_conv_g(int ng, const ConvCall* c, int act);
   int run_conv(const std::string& layer, const std::string& in0, const char* in1, const char* res0, const char* res1, int act,
                const std::string& out, float* nchw_out) {
@@ -544,6 +551,7 @@ int cfen_net::run_conv_g(int ng, const ConvCall* cc, int act) {
     d[g].src[0] = map_ptr(q.in0);
     d[g].src[1] = q.in1.empty() ? nullptr : map_ptr(q.in1);
     d[g].src[2] = q.in2.empty() ? nullptr : map_ptr(q.in2);
+    if (q.up_low) { d[g].src[1] = q.up_low; d[g].up4 = 1; d[g].up_h = q.up_h; d[g].up_w = q.up_w; d[g].up_cs = q.up_cs; }
     CFEN_CHECK_ARG((c.nsrc >= 2) == !q.in1.empty() && (c.nsrc >= 3) == !q.in2.empty(), "net: %s reads %d maps", q.layer.c_str(), c.nsrc);
     d[g].weight = P(q.layer + (c.tz ? ".wz" : c.tile ? ".wr" : ".w")); d[g].Kpad = c.Kpad;
     d[g].scale = Pf(q.layer + ".scale"); d[g].shift = Pf(q.layer + ".shift");
@@ -660,6 +668,7 @@ int cfen_net::run_vit_g(int ng, const VitCall* vc, int scr0) {
     }
     step("proj_mlp_stream");
     TRYP(K_MLP, 8 * Md * D * Hd + 2 * Md * D * D, cfen_mlp3_impl_g(dt, ng, m, stream));
+    if (gv_skip_up) return CFEN_OK;
     step("upsample4");
     TRYP(K_TOKEN, 0, cfen_upsample4_impl_g(dt, ng, cSM, OUT, B, v.mapH, v.mapH, v.C, v.C, bo.cs, stream));
     return CFEN_OK;
@@ -737,6 +746,7 @@ int cfen_net::run_vit_g(int ng, const VitCall* vc, int scr0) {
     }
     ++gv_launch;
     TRY(run_chain("chain_proj_mlp_head", 2 * Md * D * D + 8 * Md * D * Hd));
+    if (gv_skip_up) return CFEN_OK;
     step("upsample4");
     TRYP(K_TOKEN, 0, cfen_upsample4_impl_g(dt, ng, cSM, OUT, B, v.mapH, v.mapH, v.C, v.C, bo.cs, stream));
     return CFEN_OK;
@@ -894,6 +904,7 @@ int cfen_net::run_vit_g(int ng, const VitCall* vc, int scr0) {
       TRYP(K_TOKEN, 0, cfen_patchify_impl_g(dt, ng, dst, X0, B, v.mapH, v.mapH, v.C, v.global ? v.C : bo.cs, v.ws, v.p, 1, 1, stream));
     }
   }
+  if (v.global && gv_skip_up) return CFEN_OK;
   step("upsample4");
   if (v.global) TRYP(K_TOKEN, 0, cfen_upsample4_impl_g(dt, ng, cSM, OUT, B, v.mapH, v.mapH, v.C, v.C, bo.cs, stream));
   return CFEN_OK;
@@ -920,10 +931,30 @@ int cfen_net::run_level_g(int ng, const char* tags, int l, const std::string* in
     fuse[g] = ConvCall{out[g], ln, gn, in[g], extra_res ? extra_res : "", out[g], nullptr};
   }
   // globalvit_encoder_02 has its own hidden size (v3:200), so blocks of one level share launches only within the decoders
+  // x4 bilinear of the GViT result inside the fuse conv (k_conv UP): the block leaves its low-resolution map in the scratch set, no k_upsample4 launch
+  // and no full-resolution copy.  Not while an ActNorm of the level is still uninitialised (its raw pass reads the stored map) or stages are asked for.
+  {
+    const Vit& g0 = *gv[0].v;
+    const ConvLayer& fc = convs.at(out[0]);
+    const Buf& bo = bufs.at(out[0]);
+    const bool up = cfen_tune_up_fused() && !cfen_tune_keep_stages() && an_pending.empty() && cfg.dtype == CFEN_F16 && !g0.shrink && !lv[0].v->shrink &&
+                    fc.kind == 0 && fc.k == 1 && fc.nsrc == 2 && !fc.tile && fc.Cin == g0.C && bo.H == 4 * g0.mapH && bo.W == 4 * g0.mapH &&
+                    cfen_conv_up4_supported(cfg.dtype, ng, cfg.batch, bo.H, bo.W, fc.Cin, g0.C, fc.Cout_pad, fc.Kpad);
+    if (up) {
+      for (int g = 0; g < ng; ++g) {
+        fuse[g].up_low = at(scr_set[1 + 2 * g].small);
+        fuse[g].up_h = g0.mapH; fuse[g].up_w = g0.mapH; fuse[g].up_cs = g0.C;
+      }
+      for (int g = 0; g < ng; ++g) gvit_low.insert(gv[g].out);
+    }
+    gv_skip_up = up;
+  }
   hipStream_t lane_g = sg == sm ? sm : fresh_side();
   TRY(order(sm, lane_g));
   stream = lane_g;
-  TRY(run_vit_g(ng, gv, 1));
+  int rcg = run_vit_g(ng, gv, 1);
+  gv_skip_up = false;
+  TRY(rcg);
   stream = sm;
   if (lv[0].v->shrink) {
     // v5:1139,1190: x = conv_shrink(x) ... x = conv_extend(x); both are per-pixel, so they run on the whole map around the windowed block
@@ -1064,6 +1095,7 @@ int cfen_net::forward(const float* x, float* xr, float* xs, float* xd) {
       }
   }
   ev_next = 0;
+  gvit_low.clear();
   side_next = 0;
   // two lanes: the caller's stream (CNN + LViT) and a side stream per level for GViT (drawn fresh per fork)
   const hipStream_t sg = par ? side[NSIDE - 1] : s0;   // only a marker "!= s0": run_level_g draws the real stream
@@ -1329,6 +1361,10 @@ int cfen_net_stage(const cfen_net* net, const char* name, const void** ptr, int3
   CFEN_CHECK_ARG(it != net->bufs.end(), "net_stage: unknown stage '%s'", name);
   if (!net->base) {
     cfen_set_error("net_stage: no forward has run yet");
+    return CFEN_ERR_STATE;
+  }
+  if (net->gvit_low.count(name)) {
+    cfen_set_error("net_stage: '%s' was never stored at full resolution in the last forward (its x4 upsampling ran inside the fuse conv); cfen_tune(\"net.keep_stages\", 1) stores it", name);
     return CFEN_ERR_STATE;
   }
   if (net->stages_on_chip && !strncmp(name, "us_conv_d01", 11)) {

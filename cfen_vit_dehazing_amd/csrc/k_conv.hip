@@ -31,7 +31,15 @@ __host__ __device__ inline int conv_wl_pitch(int Kpad) {
 // class 0.98 -> 0.93 ms).  Tried on top and dropped: K split over the four waves of a workgroup (the chain of dependent round trips is NOT
 // what bounds these kernels: ds_conv_e03 36.7 -> 35.3 us, lgcat_conv_d03 44.6 -> 52.2) and, with the weights in LDS, the pixel vectors
 // fetched branch-free two chunks ahead (small maps +-0, lgcat_conv_d01 99.7 -> 117.5 us).
-template <typename T, int TN, int TM, bool WL = false, int NW = 4>
+// UP (with WL): source 1 is GViT's low-resolution map (ConvDesc::up4).  The workgroup's NW * TM * 16 pixels are a run inside one row, or whole rows
+// of one 4-row group (host-checked), so their x4 bilinear values come from 3 low-resolution rows x (run / 4 + 2) columns: those are staged (edges
+// clamped, as k_upsample4 clamps its indices), every (pixel, channel vector) is interpolated with k_upsample4's arithmetic -- horizontal pass per
+// neighbourhood row, then the vertical one, fp32, rounded once to T -- into an LDS tile, and the K loop takes source 1 from that tile: the
+// full-resolution copy of the GViT output (written by k_upsample4, read back here: 2 x 0.18 GB per forward) and six launches are gone.
+template <typename T>
+__host__ __device__ inline int conv_up_pitch(int Cg) { return ((Cg / Mma<T>::EPL) | 1) * 16; }   // bytes per pixel of the tile: an odd number of 16-byte slots (conflict-free column reads)
+
+template <typename T, int TN, int TM, bool WL = false, int NW = 4, bool UP = false>
 __global__ __launch_bounds__(NW * 64) void k_conv(Grouped<ConvDesc> dg) {
   const ConvDesc& dref = dg.g[blockIdx.z];
   const ConvK d = conv_k(dref, blockIdx.y);
@@ -54,8 +62,86 @@ __global__ __launch_bounds__(NW * 64) void k_conv(Grouped<ConvDesc> dg) {
       *reinterpret_cast<uint4*>(wl + row * wpitch + pc * 16) = *reinterpret_cast<const uint4*>(wsrc + (size_t)i * 16);
     }
   }
-  __syncthreads();
   const long long total = (long long)d.B * d.Hb * d.Wb;
+  const unsigned char* upt = nullptr;
+  int up_pitch = 0;
+  // UP: the source-0 vectors of the lane's pixels are requested BEFORE the interpolation prologue (its two barriers and LDS passes would otherwise sit
+  // in front of the first global load of the K loop: lgcat_conv_d01 72 -> 87 us measured with the loads behind it).  A 1x1 over two maps: the lane's
+  // k slot of chunk kc is channel c of source t = 0 / 1 (t >= 2: zero padding), no halo, no taps table.
+  constexpr int UP_MAXCH = 6;
+  frag upre[UP ? UP_MAXCH : 1][TM];
+  if constexpr (UP) {
+    const long long qw = ((long long)xcd_chunked_block(blockIdx.x, gridDim.x) * NW + wave) * (TM * 16);
+    int t0 = (h * EPL) / d.Cin, c0 = h * EPL - t0 * d.Cin;
+#pragma unroll
+    for (int kc = 0; kc < UP_MAXCH; ++kc) {
+      if (kc * KC < d.Kpad) {
+#pragma unroll
+        for (int j = 0; j < TM; ++j) {
+          long long q = qw + j * 16 + r16;
+          if (q >= total) q = total - 1;
+          upre[kc][j] = t0 == 0 ? load_frag<T>((const T*)d.src0 + (size_t)q * d.cs_in + c0) : Mma<T>::zero();
+        }
+        c0 += KC;
+        while (c0 >= d.Cin) { c0 -= d.Cin; ++t0; }
+      }
+    }
+  }
+  if constexpr (UP) {
+    static_assert(WL, "the upsampling variant stages its weights");
+    constexpr int P = NW * TM * 16;
+    const int cvg = d.Cin / EPL;
+    up_pitch = conv_up_pitch<T>(d.Cin);
+    const int Pw = P < d.Wb ? P : d.Wb, lowW = Pw / 4 + 2;
+    unsigned char* lowt = wl + (d.Cout_pad * wpitch + 15) / 16 * 16;
+    unsigned char* upw = lowt + 3 * lowW * cvg * 16;
+    upt = upw;
+    const long long q0 = (long long)xcd_chunked_block(blockIdx.x, gridDim.x) * P;
+    if (q0 < total) {       // (total is a multiple of P: a workgroup is whole or absent)
+      const int x0 = (int)(q0 % d.Wb), y0 = (int)((q0 / d.Wb) % d.Hb), b = (int)(q0 / ((long long)d.Wb * d.Hb));
+      const int kx0 = x0 >> 2, ky = y0 >> 2;
+      const T* low = (const T*)d.src1 + (size_t)b * d.up_h * d.up_w * d.up_cs;
+      for (int i = tid; i < 3 * lowW * cvg; i += NW * 64) {
+        const int v = i % cvg, j = (i / cvg) % lowW, a = i / (cvg * lowW);
+        const int yy = min(max(ky - 1 + a, 0), d.up_h - 1), xx = min(max(kx0 - 1 + j, 0), d.up_w - 1);
+        *reinterpret_cast<frag*>(lowt + (size_t)i * 16) = load_frag<T>(low + ((size_t)yy * d.up_w + xx) * d.up_cs + v * EPL);
+      }
+      __syncthreads();
+      const float w0 = 0.375f, w1 = 0.1875f, w2 = 0.0625f;
+      for (int i = tid; i < P * cvg; i += NW * 64) {
+#pragma clang fp contract(off)      // separate multiplies and adds here and in k_upsample4: the two plans agree bit for bit
+        const int v = i % cvg, pl = i / cvg;
+        const int x = x0 + (P <= d.Wb ? pl : pl % d.Wb), y = y0 + (P <= d.Wb ? 0 : pl / d.Wb);
+        const int rx = x & 3, ry = y & 3, jl = (x >> 2) - kx0;       // staged column 0 = low-resolution column kx0 - 1: the left neighbour of kx sits at jl
+        const float wx[3] = {rx == 0 ? w0 : rx == 1 ? w1 : rx == 2 ? w2 : 0.f, rx == 0 || rx == 3 ? 0.625f : 0.75f, rx == 3 ? w0 : rx == 2 ? w1 : rx == 1 ? w2 : 0.f};
+        const float wy[3] = {ry == 0 ? w0 : ry == 1 ? w1 : ry == 2 ? w2 : 0.f, ry == 0 || ry == 3 ? 0.625f : 0.75f, ry == 3 ? w0 : ry == 2 ? w1 : ry == 1 ? w2 : 0.f};
+        float acc[EPL];
+#pragma unroll
+        for (int e = 0; e < EPL; ++e) acc[e] = 0.f;
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+          float row[EPL];
+#pragma unroll
+          for (int e = 0; e < EPL; ++e) row[e] = 0.f;
+#pragma unroll
+          for (int bb = 0; bb < 3; ++bb) {
+            const frag pv = *reinterpret_cast<const frag*>(lowt + ((size_t)(a * lowW + jl + bb) * cvg + v) * 16);
+#pragma unroll
+            for (int e = 0; e < EPL; ++e) row[e] += wx[bb] * (float)pv[e];
+          }
+          if (wy[a] != 0.f) {     // k_upsample4 leaves a zero-weight row out of the vertical sum
+#pragma unroll
+            for (int e = 0; e < EPL; ++e) acc[e] += wy[a] * row[e];
+          }
+        }
+        frag o;
+#pragma unroll
+        for (int e = 0; e < EPL; ++e) o[e] = (T)acc[e];
+        *reinterpret_cast<frag*>(upw + (size_t)pl * up_pitch + v * 16) = o;
+      }
+    }
+  }
+  __syncthreads();
   const long long q_wave = ((long long)xcd_chunked_block(blockIdx.x, gridDim.x) * NW + wave) * (TM * 16);
   if (q_wave >= total) return;
 
@@ -80,6 +166,26 @@ __global__ __launch_bounds__(NW * 64) void k_conv(Grouped<ConvDesc> dg) {
   int t = (h * EPL) / d.Cin;
   int c = h * EPL - t * d.Cin;
   const int nch = d.Kpad / KC;
+  if constexpr (UP) {
+#pragma unroll
+    for (int kc = 0; kc < UP_MAXCH; ++kc) {
+      if (kc < nch) {
+        frag bf[TM];
+#pragma unroll
+        for (int j = 0; j < TM; ++j)
+          bf[j] = t == 1 ? *reinterpret_cast<const frag*>(upt + (size_t)((wave * TM + j) * 16 + r16) * up_pitch + c * (int)sizeof(T)) : upre[kc][j];
+        frag af[TN];
+#pragma unroll
+        for (int i = 0; i < TN; ++i) af[i] = *reinterpret_cast<const frag*>(wl + (i * 16 + r16) * wpitch + (kc * KC + h * EPL) * (int)sizeof(T));
+#pragma unroll
+        for (int i = 0; i < TN; ++i)
+#pragma unroll
+          for (int j = 0; j < TM; ++j) acc[i][j] = Mma<T>::mma(af[i], bf[j], acc[i][j]);
+        c += KC;
+        while (c >= d.Cin) { c -= d.Cin; ++t; }
+      }
+    }
+  } else
   for (int kc = 0; kc < nch; ++kc) {
     frag bf[TM];
     if (t < d.ntaps) {
@@ -222,24 +328,41 @@ int launch_conv_t(int ng, const ConvDesc* dp, hipStream_t s) {
   return CFEN_OK;
 }
 
-template <typename T, int TN, int TM, int NW>
+template <typename T, int NW, int TM>
+bool conv_up4_geometry_ok(const ConvDesc& d) {
+  constexpr int P = NW * TM * 16;
+  const long long total = (long long)d.B * d.Hb * d.Wb;
+  const bool run = d.Wb % P == 0, rows = P % d.Wb == 0 && P / d.Wb <= 4 && 4 % (P / d.Wb) == 0 && d.Hb % (P / d.Wb) == 0;
+  return total % P == 0 && (run || rows) && d.Wb % 4 == 0 && d.Hb % 4 == 0 && d.up_h * 4 == d.Hb && d.up_w * 4 == d.Wb && d.Cin % Mma<T>::EPL == 0 &&
+         d.up_cs % Mma<T>::EPL == 0 && d.Cin <= d.up_cs;
+}
+
+template <typename T, int TN, int TM, int NW, bool UP = false>
 int launch_conv_wl_t(int ng, const ConvDesc* dp, hipStream_t s) {
   const ConvDesc& d = dp[0];
   Grouped<ConvDesc> dg;
   for (int g = 0; g < CFEN_MAX_GROUPS; ++g) dg.g[g] = dp[g < ng ? g : 0];
   const long long total = (long long)d.B * d.Hb * d.Wb;
   const long long per_block = (long long)NW * TM * 16;
-  const size_t smem = (size_t)d.Cout_pad * conv_wl_pitch<T>(d.Kpad);
+  size_t smem = (size_t)d.Cout_pad * conv_wl_pitch<T>(d.Kpad);
+  if (UP) {
+    CFEN_CHECK_ARG(d.Kpad <= 6 * Mma<T>::KC, "conv (x4 source): at most %d input channels per map", 3 * Mma<T>::KC);
+    CFEN_CHECK_ARG((conv_up4_geometry_ok<T, NW, TM>(d)), "conv (x4 source): %d x %d map / %d x %d low-resolution map do not tile into runs of %d pixels", d.Hb, d.Wb,
+                   d.up_h, d.up_w, NW * TM * 16);
+    const int P = NW * TM * 16, Pw = P < d.Wb ? P : d.Wb;
+    smem = (smem + 15) / 16 * 16 + (size_t)3 * (Pw / 4 + 2) * (d.Cin / Mma<T>::EPL) * 16 + (size_t)P * conv_up_pitch<T>(d.Cin);
+    CFEN_CHECK_ARG(smem <= 152 * 1024, "conv (x4 source): %zu bytes of LDS", smem);
+  }
   static bool attr_set = false;
   if (!attr_set) {
-    if (hipFuncSetAttribute((const void*)k_conv<T, TN, TM, true, NW>, hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024) != hipSuccess) {
+    if (hipFuncSetAttribute((const void*)k_conv<T, TN, TM, true, NW, UP>, hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024) != hipSuccess) {
       cfen_set_error("conv: cannot reserve LDS for the staged weights");
       return CFEN_ERR_HIP;
     }
     attr_set = true;
   }
   dim3 grid(cfen_grid8((total + per_block - 1) / per_block), d.nphase, ng);
-  CFEN_LAUNCH((k_conv<T, TN, TM, true, NW>), grid, dim3(NW * 64), smem, s, dg);
+  CFEN_LAUNCH((k_conv<T, TN, TM, true, NW, UP>), grid, dim3(NW * 64), smem, s, dg);
   CFEN_CHECK_LAUNCH("conv");
   return CFEN_OK;
 }
@@ -303,6 +426,25 @@ int launch_conv(int ng, const ConvDesc* dp, hipStream_t s) {
   // weights staged in LDS (conv.wlds: 0 never, 1 where the matrix fits 60 KB with 4-wave workgroups, 2 also up to 150 KB with 8 waves)
   const int wlm = cfen_tune_conv_wlds();
   const size_t wbytes = (size_t)d.Cout_pad * conv_wl_pitch<T>(d.Kpad);
+  if (d.up4) {   // 1x1 over [LViT map ; x4 of GViT's low-resolution map]: the staged-weight shapes below, source 1 interpolated in LDS
+    if constexpr (sizeof(T) == 2) {
+      for (int g = 0; g < ng; ++g)
+        CFEN_CHECK_ARG(dp[g].up4 && dp[g].ntaps == 2 && dp[g].nphase == 1 && dp[g].in_stride == 1 && dp[g].taps[0].src == 0 && dp[g].taps[1].src == 1 &&
+                       dp[g].taps[0].dy == 0 && dp[g].taps[0].dx == 0 && dp[g].taps[1].dy == 0 && dp[g].taps[1].dx == 0 && dp[g].up_h == d.up_h &&
+                       dp[g].up_w == d.up_w && dp[g].up_cs == d.up_cs && dp[g].Cin == d.Cin,
+                       "conv (x4 source): needs a 1x1 convolution over two maps, the same geometry in every grouped problem");
+      const bool fat = wbytes >= 16 * 1024;
+      switch (d.Cout_pad / 16) {
+        case 2: return fat ? launch_conv_wl_t<T, 2, 2, 8, true>(ng, dp, s) : shrink >= 2 ? launch_conv_wl_t<T, 2, 1, 4, true>(ng, dp, s) : launch_conv_wl_t<T, 2, 2, 4, true>(ng, dp, s);
+        case 3: return fat ? launch_conv_wl_t<T, 3, 2, 8, true>(ng, dp, s) : shrink >= 2 ? launch_conv_wl_t<T, 3, 1, 4, true>(ng, dp, s) : launch_conv_wl_t<T, 3, 2, 4, true>(ng, dp, s);
+        case 4: return launch_conv_wl_t<T, 4, 1, 8, true>(ng, dp, s);
+        case 6: return launch_conv_wl_t<T, 6, 1, 8, true>(ng, dp, s);
+        default: break;
+      }
+    }
+    cfen_set_error("conv (x4 source): fp16 and 32 / 48 / 64 / 96 output channels only");
+    return CFEN_ERR_ARG;
+  }
   // workgroup shape (MI355X, batch 8, per-launch times): 96 / 64 output channels and weight matrices >= 16 KB run 8 waves per staged copy
   // (lgcat_conv_d03 41.7 -> 28.0 us, ds_conv_e02 24.6 -> 20.2), the small 1x1 matrices stay on 4-wave workgroups (lgcat_conv_d02 +4 us with 8)
   if (wlm > 0 && wbytes <= (wlm > 1 ? 150 : 60) * 1024 && px < (1ll << cfen_tune_conv_wlds_maxlog())) {
@@ -595,6 +737,23 @@ int cfen_conv_impl_g(int dtype, int ng, const ConvDesc* d, hipStream_t s) {
   return CFEN_ERR_ARG;
 }
 int cfen_conv_impl(int dtype, const ConvDesc* d, hipStream_t s) { return cfen_conv_impl_g(dtype, 1, d, s); }
+
+// can a grouped 1x1 fuse conv over [map ; x4 of a low-resolution map] run with ConvDesc::up4?  Mirrors launch_conv's choice of workgroup shape.
+bool cfen_conv_up4_supported(int dtype, int ng, int B, int H, int W, int Cin, int cs_low, int Cout_pad, int Kpad) {
+  if (dtype != 1 || H % 4 || W % 4) return false;
+  ConvDesc d;
+  memset(&d, 0, sizeof(d));
+  d.B = B; d.Hb = H; d.Wb = W; d.up_h = H / 4; d.up_w = W / 4; d.up_cs = cs_low; d.Cin = Cin;
+  const long long px = (long long)ng * B * H * W;
+  const int shrink = px >= (1 << 20) ? 0 : px >= (1 << 18) ? 1 : 2;
+  const bool fat = (size_t)Cout_pad * conv_wl_pitch<half_t>(Kpad) >= 16 * 1024;
+  if (Kpad > 6 * 32) return false;
+  switch (Cout_pad / 16) {
+    case 2: case 3: return fat ? conv_up4_geometry_ok<half_t, 8, 2>(d) : shrink >= 2 ? conv_up4_geometry_ok<half_t, 4, 1>(d) : conv_up4_geometry_ok<half_t, 4, 2>(d);
+    case 4: case 6: return conv_up4_geometry_ok<half_t, 8, 1>(d);
+    default: return false;
+  }
+}
 
 int cfen_instnorm_relu_impl(int dtype, void* x, float* part, int B, int HW, int C, int cs, float eps, hipStream_t s) {
   int rc = dtype == 1 ? run_stats<half_t>(x, nullptr, nullptr, part, B, HW, C, cs, s)

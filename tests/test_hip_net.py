@@ -447,6 +447,49 @@ def test_fused_tail_up_conv3_equals_the_two_launches_bitwise(size, batch):
     torch.cuda.empty_cache()
 
 
+@pytest.mark.parametrize("size,batch", [(64, 2), (256, 8)])
+def test_gvit_upsampling_inside_the_fuse_conv_equals_the_upsample_launch(size, batch):
+    """"net.up_fused" (default 0: measured slower): GViT's upsam(upsam(x)) (v3:1323) runs inside the level's 1x1 fuse conv (k_conv UP: the workgroup's pixels are
+    interpolated from the low-resolution map in LDS with k_upsample4's arithmetic) instead of k_upsample4 writing a full-resolution copy -- the
+    three outputs and every lgcat stage against the plan with the launch, bit for bit; graph replay = eager; the GViT stages, which are then
+    never stored, are refused by net.stage; the profile has no upsample4 entry left"""
+    from cfen_vit_dehazing_amd import ops
+    from cfen_vit_dehazing_amd._lib import CfenError
+    cfg = NetConfig(24, 4, patch_size=size // 8, load_size=size)
+    x = synthetic_input(batch, cfg).to("cuda:0")
+    names = ["lgcat_conv_e01", "lgcat_conv_e02", "lgcat_conv_e03", "lgcat_conv_d03r", "lgcat_conv_d02s", "lgcat_conv_d01d"]
+    res = {}
+    try:
+        for fused in (0, 1):
+            ops.tune("net.up_fused", fused)
+            net = make_net(cfg, "fp16")
+            net(x)                                   # first forward initialises nothing here (trained ActNorm), second is the measured plan
+            outs = [o.clone() for o in net(x)]
+            st = {k: net.stage(k).clone() for k in names}
+            if fused:
+                with pytest.raises(CfenError):
+                    net.stage("globalvit_encoder_01")
+                ups = [l[0] for l in net.profile(x)["launches"] if "upsample4" in l[0]]
+                # (the 16 x 16 level-3 maps of the 128 x 128 case do not tile into the kernel's pixel runs: that level keeps its launch)
+                assert not ups if size == 256 else all("_03" in u for u in ups) and len(ups) == 2
+            else:
+                net.stage("globalvit_encoder_01")
+            gid, gouts = net.capture(x)
+            net.replay(gid)
+            torch.cuda.synchronize()
+            for a, b in zip(gouts, outs):
+                assert torch.equal(a, b)
+            res[fused] = (outs, st)
+            del net
+    finally:
+        ops.tune("net.up_fused", 0)
+    for k in names:
+        assert torch.equal(res[0][1][k], res[1][1][k]), k
+    for a, b in zip(res[0][0], res[1][0]):
+        assert torch.equal(a, b)
+    torch.cuda.empty_cache()
+
+
 def test_gvit_persistent_chain_plan_agrees_with_the_launch_per_gemm_plan():
     """csrc/k_gvit.hip inside the net (CFEN_GVIT_CHAIN=1: fragment-stream GViT weights, two persistent launches per block instead of eight GEMM
     launches): every GViT stage and the outputs against the default plan at B = 8, 512x512, fp16 -- same math, different summation order
@@ -455,22 +498,26 @@ def test_gvit_persistent_chain_plan_agrees_with_the_launch_per_gemm_plan():
     from cfen_vit_dehazing_amd import ops
     cfg = NetConfig(24, 4, patch_size=32, load_size=256)
     x = synthetic_input(8, cfg).to("cuda:0")
-    base = make_net(cfg, "fp16")
-    want = [o.clone() for o in base(x)]
     stages = ["globalvit_encoder_01", "globalvit_encoder_02", "globalvit_encoder_03", "globalvit_decoder_03r", "globalvit_decoder_02s", "globalvit_decoder_01d"]
-    wst = {k: base.stage(k).clone() for k in stages}
-    del base
-    os.environ["CFEN_GVIT_CHAIN"] = "1"
+    ops.tune("net.keep_stages", 1)          # the GViT maps are stored at full resolution (default: x4 bilinear inside the fuse convs)
     try:
-        net = make_net(cfg, "fp16")
+        base = make_net(cfg, "fp16")
+        want = [o.clone() for o in base(x)]
+        wst = {k: base.stage(k).clone() for k in stages}
+        del base
+        os.environ["CFEN_GVIT_CHAIN"] = "1"
+        try:
+            net = make_net(cfg, "fp16")
+        finally:
+            del os.environ["CFEN_GVIT_CHAIN"]
+        assert net.gvit_chain
+        got = [o.clone() for o in net(x)]
+        assert net.chain_errors() == [0, 0, 0]
+        for k in stages:
+            d = float((net.stage(k) - wst[k]).abs().max())
+            assert d <= 3e-2 * max(1.0, float(wst[k].abs().max())), (k, d)
     finally:
-        del os.environ["CFEN_GVIT_CHAIN"]
-    assert net.gvit_chain
-    got = [o.clone() for o in net(x)]
-    assert net.chain_errors() == [0, 0, 0]
-    for k in stages:
-        d = float((net.stage(k) - wst[k]).abs().max())
-        assert d <= 3e-2 * max(1.0, float(wst[k].abs().max())), (k, d)
+        ops.tune("net.keep_stages", 0)
     for a, b in zip(got, want):
         assert float((a - b).abs().max()) <= 2e-2
     gid, gouts = net.capture(x)
@@ -539,13 +586,17 @@ def test_two_lane_plan_equals_serial_plan_bitwise_full_size():
             assert torch.equal(a, b) and torch.equal(a, c)
     finally:
         ops.tune("net.gvit_stream", 1)
-    net2 = make_net(cfg, "fp16")
-    net2.serial_plan = True
-    streamed = [o.clone() for o in net2(x)]
-    st = net2.stage("globalvit_encoder_01")
-    net2.serial_plan = False
-    net2(x)
-    assert float((st - net2.stage("globalvit_encoder_01")).abs().max()) <= 3e-2 * max(1.0, float(st.abs().max()))
+    try:
+        ops.tune("net.keep_stages", 1)
+        net2 = make_net(cfg, "fp16")
+        net2.serial_plan = True
+        streamed = [o.clone() for o in net2(x)]
+        st = net2.stage("globalvit_encoder_01").clone()
+        net2.serial_plan = False
+        net2(x)
+        assert float((st - net2.stage("globalvit_encoder_01")).abs().max()) <= 3e-2 * max(1.0, float(st.abs().max()))
+    finally:
+        ops.tune("net.keep_stages", 0)
     for a, b in zip(streamed, two):
         assert float((a - b).abs().max()) <= 1e-2
 
