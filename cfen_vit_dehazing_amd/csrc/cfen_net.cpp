@@ -136,6 +136,7 @@ struct cfen_net {
   struct AnPending { const float* ones; const float* conv_bias; float* an_out; int win; };
   std::map<std::string, AnPending> an_pending;
   bool an_raw_pass = false;
+  int output_u8 = 0;               // 1: xr / xs / xd are uint8 HWC (B,H,W,3) = util.tensor2im of the fp32 results, written by the tails' 7x7 launch (k_conv7_tz)
   int input_u8 = 0;                // 1: x is uint8 HWC (B,H,W,3), normalised to [-1,1] by the first launch (data/base_dataset.py:44-46)
   bool cfs = false;                // sibling generators networks_iid_hlgvit_crs_gd4_cfs.py / ..._crs_gd4.py (cfg.reserved bits 8..15 == 1 / 2): the three
                                    // levels run at the image's own resolution -- no ds_conv_e01 / us_conv_d01*, n_feats channels in head and tails
@@ -558,7 +559,8 @@ int cfen_net::run_conv_g(int ng, const ConvCall* cc, int act) {
     d[g].act = act;
     d[g].Cout = c.Cout; d[g].Cout_pad = c.Cout_pad;
     if (q.nchw_out) {
-      d[g].out = q.nchw_out; d[g].out_nchw_f32 = 1; d[g].cs_out = c.Cout_pad;
+      d[g].out = q.nchw_out; d[g].out_nchw_f32 = (output_u8 && c.tz) ? 2 : 1; d[g].cs_out = c.Cout_pad;
+      CFEN_CHECK_ARG(!output_u8 || c.tz, "net: uint8 outputs need the Toeplitz 7x7 tail kernel, %s does not run on it", q.layer.c_str());
     } else {
       const Buf& bo = bufs.at(q.out);
       CFEN_CHECK_ARG(bo.H == d[g].Hout && bo.W == d[g].Wout, "net: %s output geometry mismatch", q.layer.c_str());
@@ -1223,6 +1225,18 @@ int cfen_net_actnorm_pending_count(const cfen_net* net) { return net ? (int)net-
 int cfen_net_set_input_u8(cfen_net* net, int enabled) {
   CFEN_CHECK_ARG(net != nullptr, "set_input_u8: null net");
   net->input_u8 = enabled ? 1 : 0;
+  return CFEN_OK;
+}
+
+int cfen_net_set_output_u8(cfen_net* net, int enabled) {
+  CFEN_CHECK_ARG(net != nullptr, "set_output_u8: null net");
+  if (enabled)
+    for (const char* t : {"tail_R.conv7", "tail_S.conv7", "tail_D.conv7"}) {
+      auto it = net->convs.find(t);
+      CFEN_CHECK_ARG(it != net->convs.end() && it->second.tz && (it->second.Cout == 1 || it->second.Cout == 3),
+                     "set_output_u8: %s does not run on the Toeplitz 7x7 kernel at this geometry (fp16, image edge a multiple of 64): take fp32 outputs and cfen_tensor2im_u8", t);
+    }
+  net->output_u8 = enabled ? 1 : 0;
   return CFEN_OK;
 }
 

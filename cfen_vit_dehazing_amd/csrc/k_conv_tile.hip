@@ -508,7 +508,37 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   }
 
   // lane (j = r16, h): channel co = h, output pixels x0 + 4j .. +3 of row y0 + 4*wave + r
-  if (h < d.Cout) {
+  if (d.out_nchw_f32 == 2) {
+    // uint8 HWC x 3 output = util.tensor2im of the fp32 result (util/util.py:12-24: (x + 1) / 2 * 255 in fp32, truncating cast, no clamp, a 1-channel
+    // map tiled to 3; k_tensor2im_u8's arithmetic) written by the tail itself: the lanes h = 0, 1, 2 of a column hold R, G, B of the same 4 pixels,
+    // lane h = 0 collects their bytes (two cross-lane reads) and stores the 12 bytes of its 4 pixels -- 16 lanes = 192 consecutive bytes of a row
+    const float sc = d.scale[h], sh = d.shift[h];       // (h = 3 reads a padding entry of the [16] table; its bytes are never stored)
+    unsigned char* o = (unsigned char*)d.out + (((size_t)b * d.Hin + y0 + wave * Z_RW) * d.Win + x0 + 4 * r16) * 3;
+#pragma unroll
+    for (int r = 0; r < Z_RW; ++r) {
+      floatx4 v = acc[r] * sc + sh;
+      if (d.act == 1) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
+      } else if (d.act == 2) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = tanhf(v[e]);
+      }
+      unsigned w = 0;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) w |= (unsigned)(unsigned char)(int)((v[e] + 1.f) / 2.0f * 255.0f) << (8 * e);
+      const unsigned wg = d.Cout >= 3 ? (unsigned)__shfl((int)w, r16 + 16, 64) : w;     // all 64 lanes take part in the exchange
+      const unsigned wb = d.Cout >= 3 ? (unsigned)__shfl((int)w, r16 + 32, 64) : w;
+      if (h == 0) {
+        // bytes R0 G0 B0 R1 | G1 B1 R2 G2 | B2 R3 G3 B3
+        const unsigned o0 = (w & 0xffu) | ((wg & 0xffu) << 8) | ((wb & 0xffu) << 16) | ((w & 0xff00u) << 16);
+        const unsigned o1 = ((wg >> 8) & 0xffu) | (((wb >> 8) & 0xffu) << 8) | (((w >> 16) & 0xffu) << 16) | (((wg >> 16) & 0xffu) << 24);
+        const unsigned o2 = ((wb >> 16) & 0xffu) | (((w >> 24) & 0xffu) << 8) | (((wg >> 24) & 0xffu) << 16) | (((wb >> 24) & 0xffu) << 24);
+        unsigned* op = reinterpret_cast<unsigned*>(o + (size_t)r * d.Win * 3);
+        op[0] = o0; op[1] = o1; op[2] = o2;
+      }
+    }
+  } else if (h < d.Cout) {
     const float sc = d.scale[h], sh = d.shift[h];
     float* o = (float*)d.out + (((size_t)b * d.Cout + h) * d.Hin + y0 + wave * Z_RW) * d.Win + x0 + 4 * r16;
 #pragma unroll
@@ -531,7 +561,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 
 // geometry of the Toeplitz 7x7 kernel (mirrored by packing.conv_uses_toeplitz7)
 bool cfen_conv7_tz_supported(int dtype, int k, int stride, int pad, int nsrc, int cs_in, int Cout, int out_nchw_f32, int H, int W) {
-  return dtype == 1 && k == 7 && stride == 1 && pad == 3 && nsrc == 1 && cs_in == 16 && Cout >= 1 && Cout <= 4 && out_nchw_f32 && H % (4 * Z_RW) == 0 &&
+  return dtype == 1 && k == 7 && stride == 1 && pad == 3 && nsrc == 1 && cs_in == 16 && Cout >= 1 && Cout <= 4 && out_nchw_f32 && (out_nchw_f32 != 2 || Cout == 1 || Cout == 3) &&
+         H % (4 * Z_RW) == 0 &&
          W % 64 == 0;
 }
 int cfen_conv7_tz_kpad() { return Z_KPAD; }

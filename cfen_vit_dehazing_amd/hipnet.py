@@ -66,7 +66,8 @@ class dec_ipt(nn.Module):
         self._packed = None          # {name: device tensor}
         self._packed_dev = None
         self._an_pending = {}        # packed layer name -> (ActNorm key prefix, conv bias, an_out): uninitialised ActNorm2d layers
-        self._nets = {}              # (batch, input kind) -> (handle, workspace tensor)
+        self._nets = {}              # (batch, input kind, plan, replica, output kind) -> (handle, workspace tensor)
+        self._native_u8 = {}         # same key -> the net writes uint8 outputs itself
         self._graph_keep = []
         self._graphs = []            # capture() handle -> (net key, native graph id)
         self._last = None
@@ -74,6 +75,9 @@ class dec_ipt(nn.Module):
         # `replica`: which launch plan + workspace the next forward / capture uses.  Replicas share the packed weights; each has its own workspace
         # (stage buffers, token scratch), so forwards of DIFFERENT replicas may be in flight at once on different streams (bench.py --in-flight 2)
         self.replica = 0
+        # `output_u8`: forward() returns three uint8 (B,H,W,3) tensors = util.tensor2im of the fp32 results (test.py --out_all saves exactly those),
+        # written by the tails' last launch where the geometry allows (cfen_net_set_output_u8), else by cfen_tensor2im_u8 passes on the device
+        self.output_u8 = False
         # GViT weights tile-major (packing.pack_wtile; cfen_net_config.reserved bit 1): +1 % measured (3.34 -> 3.30 ms at B = 8); CFEN_WTILE=0 = row-major
         self.wtile = os.environ.get("CFEN_WTILE", "1") != "0"
         # CFEN_GVIT_CHAIN=1: GViT weights ALSO as MFMA fragment streams (packing.pack_stream_tiles; cfen_net_config.reserved bit 2) and the GEMMs of a
@@ -150,6 +154,7 @@ class dec_ipt(nn.Module):
         for h, _ in self._nets.values():
             lib.cfen_net_destroy(h)
         self._nets = {}
+        self._native_u8 = {}
         self._graph_keep = []        # captured graphs died with their nets
         self._graphs = []
         self._last = None
@@ -191,7 +196,7 @@ class dec_ipt(nn.Module):
 
     def _net_for(self, batch, device, u8=False):
         packed = self._ensure_packed(device)
-        key = (batch, bool(u8), bool(self.serial_plan), int(self.replica))
+        key = (batch, bool(u8), bool(self.serial_plan), int(self.replica), bool(self.output_u8))
         if self.gvit_chain and (self.replica > 0 or self.serial_plan) and not os.environ.get("CFEN_GVIT_CHAIN_UNSAFE"):
             # MEASURED (round 4, bench.py --lanes 1 --in-flight 2 with CFEN_GVIT_CHAIN=1): the persistent-chain variant gives wrong outputs when two forwards
             # on serial launch plans overlap (no barrier wait gave up, error words 0; correct one forward at a time and on two-lane plans) -- cause not
@@ -214,8 +219,10 @@ class dec_ipt(nn.Module):
             raise CfenError("packed parameters missing: " + buf.value.decode())
         if u8:
             check(lib.cfen_net_set_input_u8(h, 1), "cfen_net_set_input_u8")
+        native_u8 = bool(self.output_u8) and lib.cfen_net_set_output_u8(h, 1) == 0      # refused (fp32 net, small images): fp32 outputs + tensor2im_u8 passes
         ws = torch.empty(lib.cfen_net_workspace_bytes(h), dtype=torch.uint8, device=device)
         self._nets[key] = (h, ws)
+        self._native_u8[key] = native_u8
         return self._nets[key]
 
     def chain_errors(self):
@@ -300,13 +307,21 @@ class dec_ipt(nn.Module):
                 raise CfenError("ActNorm2d layers are uninitialised: run one plain forward (it initialises them from its batch, "
                                 "models/actnorm.py:25-37) before capture() / profile()")
             self._arm_actnorm_init(h)
-        if out is None:
-            out = torch.empty(7 * B * n * n, dtype=torch.float32, device=x.device)
-        elif out.dtype != torch.float32 or out.numel() != 7 * B * n * n or not out.is_contiguous() or out.device != x.device:
-            raise ValueError("out must be a contiguous float32 buffer of 7*B*H*W elements on the input's device")
         px = B * n * n
-        flat = out.view(-1)
-        xr, xs, xd = flat[:3 * px].view(B, 3, n, n), flat[3 * px:4 * px].view(B, 1, n, n), flat[4 * px:].view(B, 3, n, n)
+        key = (B, bool(u8), bool(self.serial_plan), int(self.replica), bool(self.output_u8))
+        native_u8 = self._native_u8[key]
+        if self.output_u8 and out is not None:
+            raise ValueError("output_u8 allocates its own (B,H,W,3) uint8 outputs: no `out` slab")
+        if native_u8:
+            flat = torch.empty(9 * px, dtype=torch.uint8, device=x.device)
+            xr, xs, xd = (flat[k * 3 * px:(k + 1) * 3 * px].view(B, n, n, 3) for k in range(3))
+        else:
+            if out is None:
+                out = torch.empty(7 * px, dtype=torch.float32, device=x.device)
+            elif out.dtype != torch.float32 or out.numel() != 7 * px or not out.is_contiguous() or out.device != x.device:
+                raise ValueError("out must be a contiguous float32 buffer of 7*B*H*W elements on the input's device")
+            flat = out.view(-1)
+            xr, xs, xd = flat[:3 * px].view(B, 3, n, n), flat[3 * px:4 * px].view(B, 1, n, n), flat[4 * px:].view(B, 3, n, n)
         lib = _lib.load()
         if capture:
             gid = ctypes.c_int32()
@@ -332,7 +347,10 @@ class dec_ipt(nn.Module):
             prof["launches"] = detail
         if init_actnorm:
             self._finish_actnorm_init()
-        self._last = (B, bool(u8), bool(self.serial_plan), int(self.replica))
+        self._last = key
+        if self.output_u8 and not native_u8:
+            from . import ops
+            return [torch.stack([ops.tensor2im_u8(t[b].contiguous()) for b in range(B)]) for t in (xr, xs, xd)]
         return [xr, xs, xd]
 
     def set_scale(self, scale_idx):

@@ -44,6 +44,9 @@ class DECHLGVIT(BaseModel):
         # fp16 range safety of a REAL checkpoint (ActNorm scales, K = 6144 FFN sums) is unknown until its weights are here: with --precision
         # half the first batch runs through the exact-fp32 path once as well (reference loader: models/base_model.py:114-131)
         self._half_guard = getattr(opt, 'precision', 'single') == 'half' and not getattr(opt, 'no_half_guard', False)
+        # test.py only turns the outputs into PNGs (util.tensor2im, util/util.py:12-24): the generator writes those bytes itself -- (B,H,W,3) uint8
+        # from the tails' last launch where the geometry allows, a device pass elsewhere (hipnet.dec_ipt.output_u8) -- instead of fp32 planes
+        self._u8_out = not getattr(opt, 'isTrain', False) and getattr(opt, 'phase', 'test') == 'test' and hasattr(self.netG, 'output_u8')
 
     def _guard_dir(self):
         import os
@@ -92,6 +95,7 @@ class DECHLGVIT(BaseModel):
     def forward(self):
         if getattr(self, '_half_guard', False):
             self._half_guard = False
+            self.netG.output_u8 = False                   # the guard compares the float outputs
             self.netG.set_compute_dtype('fp32')
             ref = [t.clone() for t in self.netG(self._net_in)]
             self.netG.set_compute_dtype('fp16')
@@ -109,4 +113,6 @@ class DECHLGVIT(BaseModel):
                 self.netG.set_compute_dtype('fp32')
                 [self.fake_R, self.fake_S, self.fake_A] = ref
                 return
+        if getattr(self, '_u8_out', False):
+            self.netG.output_u8 = True
         [self.fake_R, self.fake_S, self.fake_A] = self.netG(self._net_in)

@@ -13,6 +13,8 @@ def tensor2im(input_image, imtype=np.uint8):
     if not isinstance(input_image, torch.Tensor):
         return input_image
     t = input_image.data
+    if t.dtype == torch.uint8 and t.dim() == 3 and t.shape[-1] == 3 and imtype == np.uint8:
+        return t.cpu().numpy()      # already an image: the generator wrote tensor2im's bytes itself (hipnet.dec_ipt.output_u8)
     if t.is_cuda and t.dim() == 3 and imtype == np.uint8:
         # the same arithmetic on the device (csrc/k_tokens.hip: k_tensor2im_u8): H*W*3 bytes cross PCIe instead of fp32 planes
         from .. import ops

@@ -86,6 +86,12 @@ int cfen_net_actnorm_pending_count(const cfen_net* net);
  * (B,H,W,3) as decoded from the image file, normalised (v/255 - 0.5)/0.5 on the device by the plan's first launch
  * (ToTensor + Normalize(0.5, 0.5), data/base_dataset.py:44-46).  Pass the uint8 pointer through the `x` argument.            */
 int cfen_net_set_input_u8(cfen_net* net, int enabled);
+/* Output format of cfen_net_forward / _graph_capture / _profile: 0 (default) xr / xs / xd are fp32 NCHW; 1: each of the three is uint8 HWC
+ * (B,H,W,3) -- util.tensor2im of the fp32 result ((x + 1) / 2 * 255 in fp32, truncating cast, no clamp, the 1-channel xs tiled to 3;
+ * util/util.py:12-24), written by the tails' last launch instead of a cfen_tensor2im_u8 pass over fp32 planes.  Pass the uint8 pointers through
+ * the xr / xs / xd arguments (16-byte aligned).  CFEN_ERR_ARG when the tails do not run on the Toeplitz 7x7 kernel (fp32 nets, image edges that are
+ * not multiples of 64): take fp32 outputs and cfen_tensor2im_u8 there.                                                                          */
+int cfen_net_set_output_u8(cfen_net* net, int enabled);
 /* names still missing, written as a ';'-separated list into buf; returns the count                */
 int cfen_net_missing_params(const cfen_net* net, char* buf, size_t buflen);
 /* x: (B,3,H,W) fp32 NCHW in [-1,1];  xr: (B,3,H,W), xs: (B,1,H,W), xd: (B,3,H,W) fp32 NCHW        */

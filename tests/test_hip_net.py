@@ -683,6 +683,39 @@ def test_uint8_input_equals_host_normalised_input():
         assert torch.equal(p, q)
 
 
+@pytest.mark.parametrize("load_size,batch,dtype", [(256, 2, "fp16"), (64, 3, "fp16"), (64, 2, "fp32")])
+def test_uint8_outputs_written_by_the_tail_equal_tensor2im_of_the_float_outputs(load_size, batch, dtype):
+    """dec_ipt.output_u8 / cfen_net_set_output_u8: the three outputs as (B,H,W,3) uint8 images, byte for byte util.tensor2im of the float outputs
+    (util/util.py:12-24 -- (x + 1) / 2 * 255, truncating cast, xs tiled to 3 channels; tests/golden/harness.npz pins that arithmetic).  fp16 nets
+    write them from the 7x7 tails' epilogue (k_conv7_tz), fp32 nets take the cfen_tensor2im_u8 pass; eager = graph replay."""
+    from cfen_vit_dehazing_amd import ops
+    from cfen_vit_dehazing_amd.util import util
+    cfg = NetConfig(24, 4, patch_size=load_size // 8, load_size=load_size)
+    net = make_net(cfg, dtype)
+    x = synthetic_input(batch, cfg).to("cuda:0")
+    want = [o.clone() for o in net(x)]
+    net.output_u8 = True
+    got = [o.clone() for o in net(x)]
+    assert all(net._native_u8[k] == (dtype == "fp16") for k in net._native_u8 if k[4])
+    n = cfg.image_size
+    for g, w in zip(got, want):
+        assert g.dtype == torch.uint8 and tuple(g.shape) == (batch, n, n, 3)
+        for b in range(batch):
+            assert torch.equal(g[b], ops.tensor2im_u8(w[b].contiguous()))
+    assert np.array_equal(util.tensor2im(got[2][0]), util.tensor2im(want[2][0]))       # what test.py saves
+    if dtype == "fp16":
+        gid, gouts = net.capture(x)
+        net.replay(gid)
+        torch.cuda.synchronize()
+        for a, b in zip(gouts, got):
+            assert torch.equal(a, b)
+    with pytest.raises(ValueError):
+        net(x, out=torch.empty(7 * batch * n * n, device="cuda:0"))
+    net.output_u8 = False
+    for a, b in zip(net(x), want):
+        assert torch.equal(a, b)
+
+
 # ---- sibling generators --model_G iid_hlgvit_crs_gd4_cfs / iid_hlgvit_crs_gd4 / iid_hlgvit_crs_gd4_cfs_v5 (models/networks_iid_hlgvit_crs_gd4_cfs.py,
 # ..._crs_gd4.py, ..._cfs_v5.py): same kernels, other launch plans ---------
 
