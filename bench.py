@@ -227,8 +227,8 @@ def main():
     ap.add_argument("--no-graph", action="store_true", help="launch eagerly instead of replaying a hipGraph")
     ap.add_argument("--gather-dtype", default="auto", choices=["auto", "fp16", "fp32"],
                     help="wire type of the output all-gather (N > 1); auto = the compute dtype")
-    ap.add_argument("--in-flight", type=int, default=4, choices=[1, 2, 3, 4, 5, 6],
-                    help="forwards in flight: N > 1 = consecutive steps rotate over N launch plans (own workspace and output slab each, shared "
+    ap.add_argument("--in-flight", type=int, default=0, choices=[0, 1, 2, 3, 4, 5, 6],
+                    help="forwards in flight (0 = default: 4 on one GPU, 3 per rank when an all-gather stream runs beside them): N > 1 = consecutive steps rotate over N launch plans (own workspace and output slab each, shared "
                          "weights) on N streams, so the tail of step i overlaps the head of steps i + 1 .. i + N - 1; every step is still one whole forward of "
                          "one batch and all K steps complete inside the timed region")
     ap.add_argument("--lanes", type=int, default=0, choices=[0, 1, 2],
@@ -249,6 +249,10 @@ def main():
         if world == 1 and args.gpus > 1:
             raise SystemExit("--gpus %d needs torch.distributed.run with --nproc-per-node %d" % (args.gpus, args.gpus))
         raise SystemExit("WORLD_SIZE=%d does not match --gpus %d" % (world, args.gpus))
+    if args.in_flight == 0:
+        # one hardware queue per concurrently busy stream is what the card runs well: 4 forward lanes on one GPU, 3 beside the communication stream of
+        # the sharded run (measured with a stand-in for it, CFEN_BENCH_FAKE_COMM_CYCLES: 4 lanes + 1 busy queue 2.52 ms / step, 3 + 1 2.25; profiles/r04_ab_hw_queues.txt)
+        args.in_flight = 4 if world == 1 else 3
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     dist = None
@@ -289,6 +293,9 @@ def main():
         net.replica = 0
         torch.cuda.synchronize()
 
+    fake_comm = [int(os.environ.get("CFEN_BENCH_FAKE_COMM_CYCLES", "0")), None]
+    if fake_comm[0]:
+        fake_comm[1] = torch.cuda.Stream(dev)
     use_lanes = [lanes is not None]     # the serial leg of the default run flips this: the same graphs, one stream, one forward at a time
 
     def step(i):
@@ -308,6 +315,12 @@ def main():
                 net.replica = 0
             if gather is not None:
                 gather.launch(s, i & 1)            # async all-gather on the communication stream
+            elif fake_comm[0]:
+                # what-if probe (CFEN_BENCH_FAKE_COMM_CYCLES=n, results are not a benchmark line): a one-workgroup kernel of n cycles per step on its own
+                # stream behind the forward -- the footprint of an always-busy communication queue beside the --in-flight lanes on ONE GPU
+                fake_comm[1].wait_stream(torch.cuda.current_stream())
+                with torch.cuda.stream(fake_comm[1]):
+                    torch.cuda._sleep(fake_comm[0])
         finally:
             if ctx is not None:
                 ctx.__exit__(None, None, None)
