@@ -25,8 +25,10 @@ CfenGraphRecorder*& cfen_recorder() {
   return rec;
 }
 // zero `bytes` of device memory on a lane: eagerly, or as a memset node of the graph being built
+int& cfen_tune_zero_memset() { static int v = 0; return v; }   // 1: round 3's form (hipMemsetAsync / a memset node of the recorded plan), for A/B ("net.zero_memset")
 int cfen_zero_async(void* p, size_t bytes, hipStream_t s) {
   CFEN_CHECK_ARG(p && bytes % 4 == 0, "zero_async: bad region");
+  if (!cfen_tune_zero_memset()) return cfen_zero_words_impl(p, bytes / 4, s);   // a kernel (node): ordered like every other launch of the plan
   if (CfenGraphRecorder* rec = cfen_recorder()) {
     hipMemsetParams mp;
     memset(&mp, 0, sizeof(mp));
@@ -344,6 +346,7 @@ int cfen_tune(const char* key, int value) {
   if (!strcmp(key, "net.gvit_stream")) { cfen_tune_gvit_stream() = value != 0; return CFEN_OK; }
   if (!strcmp(key, "net.tail_fused")) { cfen_tune_tail_fused() = value != 0; return CFEN_OK; }
   if (!strcmp(key, "net.up_fused")) { cfen_tune_up_fused() = value != 0; return CFEN_OK; }
+  if (!strcmp(key, "net.zero_memset")) { cfen_tune_zero_memset() = value != 0; return CFEN_OK; }
   if (!strcmp(key, "net.keep_stages")) { cfen_tune_keep_stages() = value != 0; return CFEN_OK; }
   if (!strcmp(key, "net.resblock_fused")) { cfen_tune_resblock_fused() = value != 0; return CFEN_OK; }
   if (!strcmp(key, "net.head5")) { cfen_tune_head5() = value != 0; return CFEN_OK; }

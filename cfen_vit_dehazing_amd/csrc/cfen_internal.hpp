@@ -7,6 +7,8 @@ struct ConvDesc;
 
 int cfen_gemm_impl(int dtype, const void* X, int ldx, const void* W, int ldw, const float* bias, const void* R, int ldr, const void* P,
                    int period, void* Y, int ldy, int M, int N, int K, int relu, hipStream_t s);
+int cfen_zero_words_impl(void* p, size_t nwords, hipStream_t s);   // k_tokens.hip
+int& cfen_tune_zero_memset();
 int cfen_zero_async(void* p, size_t bytes, hipStream_t s);   // memset 0 on a lane (eager, or a node of the graph being recorded)
 float& cfen_gemm_lnf_eps();   // LayerNorm eps used by the LN-folded GEMMs (1e-5, the only value the generator uses)
 // Y = tok W^T + bias + tok + P[m % period]  with tok = the patch tokens of an NHWC map, gathered by the GEMM's loader

@@ -268,6 +268,18 @@ struct cfen_net {
     return run_conv_g(1, &c, act);
   }
   struct VitCall { const Vit* v; std::string in, out; };
+  // first use of a workspace: its synchronisation words (split-K arrival counters, barrier and error words of the chains) start at zero
+  const void* primed_base = nullptr;
+  int prime_workspace() {
+    if (base == primed_base) return CFEN_OK;
+    for (int k = 1; k < 6; k += 2)
+      if (hipMemset(at(scr_set[k].splitk), 0, CFEN_SPLITK_COUNTERS * sizeof(unsigned)) != hipSuccess || hipMemset(at(scr_set[k].sync), 0, GV_SYNC_WORDS * sizeof(unsigned)) != hipSuccess) {
+        cfen_set_error("net: cannot zero the synchronisation words of the workspace");
+        return CFEN_ERR_HIP;
+      }
+    primed_base = base;
+    return CFEN_OK;
+  }
   int run_vit_g(int ng, const VitCall* c, int scr0);   // group member g uses scratch set scr0 + 2 g
   int run_level_g(int ng, const char* tags, int l, const std::string* in, const char* extra_res, const std::string* out, hipStream_t sm,
                   hipStream_t sg);
@@ -1103,10 +1115,14 @@ int cfen_net::forward(const float* x, float* xr, float* xs, float* xd) {
   const hipStream_t sg = par ? side[NSIDE - 1] : s0;   // only a marker "!= s0": run_level_g draws the real stream
   stream = s0;
   float* stats = (float*)at(o_stats_set[0]);
-  // arrival counters of the split-K GEMMs: every launch leaves them zero, this makes a forward independent of whatever ran (or died) before
-  for (int k = 1; k < 6; k += 2) TRY(cfen_zero_async(at(scr_set[k].splitk), CFEN_SPLITK_COUNTERS * sizeof(unsigned), stream));
+  // arrival counters of the split-K GEMMs: every launch leaves them zero, this makes a forward independent of whatever ran (or died) before -- where
+  // the plan has such launches ("gemm.splitk", the persistent chains); the default plan has none and gets no zeroing launch (prime_workspace zeroed them once)
+  const bool chains = gvit_stream && cfen_tune_gvit_chain() != 0;
+  if (cfen_tune_gemm_splitk() || chains)
+    for (int k = 1; k < 6; k += 2) TRY(cfen_zero_async(at(scr_set[k].splitk), CFEN_SPLITK_COUNTERS * sizeof(unsigned), stream));
   // ... and the grid-barrier words of the persistent GViT chains (the error word behind them is sticky: only cfen_net_chain_errors clears it)
-  for (int k = 1; k < 6; k += 2) TRY(cfen_zero_async(at(scr_set[k].sync), GV_ERR_WORD * sizeof(unsigned), stream));
+  if (chains)
+    for (int k = 1; k < 6; k += 2) TRY(cfen_zero_async(at(scr_set[k].sync), GV_ERR_WORD * sizeof(unsigned), stream));
   gv_launch = 0;
   const Buf& bin = bufs.at("input");
   const bool use_head5 = head5 && cfen_tune_head5() && !cfen_tune_head_fused();
@@ -1273,6 +1289,7 @@ int cfen_net_forward(cfen_net* net, const float* x, float* xr, float* xs, float*
     }
   net->base = (unsigned char*)workspace;
   net->stream = (hipStream_t)stream;
+  TRY(net->prime_workspace());
   return net->forward(x, xr, xs, xd);
 }
 
@@ -1298,6 +1315,7 @@ int cfen_net_graph_capture(cfen_net* net, const float* x, float* xr, float* xs, 
   }
   net->base = (unsigned char*)workspace;
   net->stream = (hipStream_t)(uintptr_t)16;          // lane key of the main lane; nothing is launched on it
+  if (int prc = net->prime_workspace()) { (void)hipGraphDestroy(rec.graph); return prc; }
   cfen_recorder() = &rec;
   int rc = net->forward(x, xr, xs, xd);
   cfen_recorder() = nullptr;

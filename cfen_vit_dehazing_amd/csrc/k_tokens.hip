@@ -404,6 +404,17 @@ int cfen_upsample4_impl(int dtype, const void* small, void* out, int B, int h, i
   return cfen_upsample4_impl_g(dtype, 1, &small, &out, B, h, w, C, cs_in, cs_out, s);
 }
 
+// Zero a few KB of synchronisation words (arrival counters, barrier words) as a KERNEL: inside a recorded launch plan this is a kernel node like
+// its neighbours (see cfen_zero_async in cfen_api.cpp for why it is not a memset node).
+__global__ __launch_bounds__(256) void k_zero_words(unsigned* __restrict__ p, long long n) {
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) p[i] = 0u;
+}
+int cfen_zero_words_impl(void* p, size_t nwords, hipStream_t s) {
+  CFEN_LAUNCH(k_zero_words, dim3(grid_for((long long)nwords)), dim3(256), 0, s, (unsigned*)p, (long long)nwords);
+  CFEN_CHECK_LAUNCH("zero_words");
+  return CFEN_OK;
+}
+
 int cfen_tensor2im_u8_impl(const float* in, unsigned char* out, int C, int H, int W, hipStream_t s) {
   CFEN_CHECK_ARG(in && out && (C == 1 || C == 3) && H > 0 && W > 0, "tensor2im_u8: needs a (1|3,H,W) fp32 tensor");
   const long long npix = (long long)H * W;

@@ -197,11 +197,6 @@ class dec_ipt(nn.Module):
     def _net_for(self, batch, device, u8=False):
         packed = self._ensure_packed(device)
         key = (batch, bool(u8), bool(self.serial_plan), int(self.replica), bool(self.output_u8))
-        if self.gvit_chain and (self.replica > 0 or self.serial_plan) and not os.environ.get("CFEN_GVIT_CHAIN_UNSAFE"):
-            # MEASURED (round 4, bench.py --lanes 1 --in-flight 2 with CFEN_GVIT_CHAIN=1): the persistent-chain variant gives wrong outputs when two forwards
-            # on serial launch plans overlap (no barrier wait gave up, error words 0; correct one forward at a time and on two-lane plans) -- cause not
-            # found, so the variant is confined to what it was validated for
-            raise CfenError("CFEN_GVIT_CHAIN=1 (persistent GViT chains, a tested variant) is validated for ONE forward in flight on the two-lane plan only")
         if key in self._nets:
             return self._nets[key]
         lib = _lib.load()

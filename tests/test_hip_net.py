@@ -530,14 +530,36 @@ def test_gvit_persistent_chain_plan_agrees_with_the_launch_per_gemm_plan():
     torch.cuda.empty_cache()
 
 
-def test_three_forwards_in_flight_on_replica_plans_match_single_forwards_bitwise():
+@pytest.mark.parametrize("splitk", [0, 1, 2])
+def test_three_forwards_in_flight_on_replica_plans_match_single_forwards_bitwise(splitk):
     """what bench.py times by default (round 4): consecutive steps rotate over three launch plans -- one serial chain of launches each, own
     workspace and output slab, shared packed weights -- on three streams, so three forwards are in flight at once.  Every replica gets a DIFFERENT
     input batch here; after 12 overlapping steps each slab must equal, bit for bit, the eager one-at-a-time forward of its own batch on the same plan (no cross-talk
-    through a shared scratch buffer, counter or stage map), B = 8, 512x512, fp16"""
+    through a shared scratch buffer, counter or stage map), B = 8, 512x512, fp16.
+    splitk = 1: the same with "gemm.splitk" on -- the few-token GViT GEMMs reduce their K slices inside the launch through arrival counters, which the plan
+    zeroes at the head of every forward.  As a MEMSET NODE of the recorded plan that zeroing was not ordered against the kernel nodes around it once several
+    graphs were in flight (outputs off by 0.17; round 4 hunted this in the seam's memory ordering); it is a kernel node now ("net.zero_memset" = 1 is the old form).
+    splitk = 2: the persistent GViT chains (CFEN_GVIT_CHAIN=1: grid barriers + split-K seams inside one launch), which failed the same way for
+    the same reason; their error words must stay zero."""
+    import os
+    from cfen_vit_dehazing_amd import ops
     from cfen_vit_dehazing_amd.parallel import split_slab
     cfg = NetConfig(24, 4, patch_size=32, load_size=256)
-    net = make_net(cfg, "fp16")
+    ops.tune("gemm.splitk", int(splitk == 1))
+    if splitk == 2:
+        os.environ["CFEN_GVIT_CHAIN"] = "1"
+    try:
+        net = make_net(cfg, "fp16")
+        assert bool(net.gvit_chain) == (splitk == 2)
+        _three_in_flight(net, cfg, split_slab)
+        if splitk == 2:
+            assert net.chain_errors() == [0, 0, 0]
+    finally:
+        os.environ.pop("CFEN_GVIT_CHAIN", None)
+        ops.tune("gemm.splitk", 0)
+
+
+def _three_in_flight(net, cfg, split_slab):
     n, B = cfg.image_size, 8
     xs = [synthetic_input(B, cfg, seed0=8 * k).to("cuda:0") for k in range(3)]
     two_lane = [[o.clone() for o in net(x)] for x in xs]             # two-lane plan, one forward at a time
