@@ -25,7 +25,12 @@ CfenGraphRecorder*& cfen_recorder() {
   return rec;
 }
 // zero `bytes` of device memory on a lane: eagerly, or as a memset node of the graph being built
-int& cfen_tune_zero_memset() { static int v = 0; return v; }   // 1: round 3's form (hipMemsetAsync / a memset node of the recorded plan), for A/B ("net.zero_memset")
+// Zeroing of synchronisation words (split-K arrival counters, the chains' barrier words) in front of the launches that use them.
+// MEASURED (round 4, MI355X, ROCm 7.2): as a hipGraph MEMSET node -- dependencies recorded like every kernel node's -- the zeroing is NOT ordered against its
+// neighbouring kernel nodes once several instantiated graphs are in flight on different streams: counters were cleared in the middle of a launch that was
+// counting arrivals (outputs off by 0.07 .. 0.2, no wait gave up), one graph at a time it is fine.  As a kernel node it is ordered.  "net.zero_memset" = 1 is the
+// old form, kept for the A/B (tests/test_hip_net.py::test_three_forwards_in_flight...; profiles/r04_ab_zero_memset.txt).
+int& cfen_tune_zero_memset() { static int v = 0; return v; }
 int cfen_zero_async(void* p, size_t bytes, hipStream_t s) {
   CFEN_CHECK_ARG(p && bytes % 4 == 0, "zero_async: bad region");
   if (!cfen_tune_zero_memset()) return cfen_zero_words_impl(p, bytes / 4, s);   // a kernel (node): ordered like every other launch of the plan

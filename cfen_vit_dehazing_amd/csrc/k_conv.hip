@@ -33,8 +33,8 @@ __host__ __device__ inline int conv_wl_pitch(int Kpad) {
 // fetched branch-free two chunks ahead (small maps +-0, lgcat_conv_d01 99.7 -> 117.5 us).
 // UP (with WL): source 1 is GViT's low-resolution map (ConvDesc::up4).  The workgroup's NW * TM * 16 pixels are a run inside one row, or whole rows
 // of one 4-row group (host-checked), so their x4 bilinear values come from 3 low-resolution rows x (run / 4 + 2) columns: those are staged (edges
-// clamped, as k_upsample4 clamps its indices), every (pixel, channel vector) is interpolated with k_upsample4's arithmetic -- horizontal pass per
-// neighbourhood row, then the vertical one, fp32, rounded once to T -- into an LDS tile, and the K loop takes source 1 from that tile: the
+// clamped, as k_upsample4 clamps its indices), every (pixel, channel vector) is interpolated like k_upsample4 does it -- horizontal pass per
+// neighbourhood row, then the vertical one, fp32, rounded once to T (the compiler contracts the two kernels' sums differently: last-bit differences) -- into an LDS tile, and the K loop takes source 1 from that tile: the
 // full-resolution copy of the GViT output (written by k_upsample4, read back here: 2 x 0.18 GB per forward) and six launches are gone.
 template <typename T>
 __host__ __device__ inline int conv_up_pitch(int Cg) { return ((Cg / Mma<T>::EPL) | 1) * 16; }   // bytes per pixel of the tile: an odd number of 16-byte slots (conflict-free column reads)
@@ -109,7 +109,6 @@ __global__ __launch_bounds__(NW * 64) void k_conv(Grouped<ConvDesc> dg) {
       __syncthreads();
       const float w0 = 0.375f, w1 = 0.1875f, w2 = 0.0625f;
       for (int i = tid; i < P * cvg; i += NW * 64) {
-#pragma clang fp contract(off)      // separate multiplies and adds here and in k_upsample4: the two plans agree bit for bit
         const int v = i % cvg, pl = i / cvg;
         const int x = x0 + (P <= d.Wb ? pl : pl % d.Wb), y = y0 + (P <= d.Wb ? 0 : pl / d.Wb);
         const int rx = x & 3, ry = y & 3, jl = (x >> 2) - kx0;       // staged column 0 = low-resolution column kx0 - 1: the left neighbour of kx sits at jl

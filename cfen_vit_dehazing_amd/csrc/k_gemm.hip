@@ -754,14 +754,14 @@ int& cfen_tune_gemm_nt() {   // weight rows of k_gemm_dma by non-temporal LDS-DM
   return v;
 }
 
-int& cfen_tune_gemm_splitk() {   // 0 (default, round 4): with three forwards in flight the unsplit launches are as fast (2.47 against 2.48 ms) and the default plan
-  static int v = 0;               // no longer depends on the hand-rolled in-launch reduction; 1 = round 3's shape rule
+int& cfen_tune_gemm_splitk() {   // 0 (default, round 4): with several forwards in flight the unsplit launches are faster (2.13 against 2.16 ms per step, and 2.80 with
+  static int v = 0;               // the release fence below: a split launch is more workgroups, and CU-time is what a forward costs there); 1 = round 3's shape rule
   return v;
 }
-int& cfen_tune_gemm_splitk_release() {   // 1 (default, round 4): every K slice runs an agent-scope release fence before its arrival ticket.  MEASURED: without it
-  static int v = 1;                       // (write-through slab stores + a vmcnt drain only, round 3's form, the guide's "measured, not an architectural guarantee"
-  return v;                               // row) the same protocol in k_gvit_chain summed STALE slabs once two forwards were in flight (0.2 max-abs, no wait gave
-}                                         // up): the ticket can overtake the slab stores in the fabric under load.  0 = that form, for A/B timing only
+int& cfen_tune_gemm_splitk_release() {   // 1 (default): every K slice runs an agent-scope release fence before its arrival ticket -- the memory model's recipe;
+  static int v = 1;                       // 0 = round 3's publish (write-through slab stores + a vmcnt drain, the guide's "measured, not an architectural guarantee" row):
+  return v;                               // also right in every test here, 57.7 -> 22.0 us on a 1024-workgroup launch.  (Round 4 blamed this seam for wrong outputs with two
+}                                         // forwards in flight; the cause was the counters' zeroing as a graph MEMSET node, cfen_api.cpp: cfen_zero_async.)
 // 0 (default): off; 6: 192 x 128 tiles, 2-stage ring (80 KB of LDS, two workgroups a CU).  MEASURED (MI355X, B = 8, round 2): the
 // LViT-3 / GViT-1 qkv, ffn1, head1 GEMMs are 5 - 25 % SLOWER on it (ln1_qkv x3 60 -> 76 us, ln2_ffn1 x3 75 -> 80 us; a 3-stage
 // one-workgroup-a-CU variant 104 / 119 us): with K = 384 a tile is 6 dependent K-steps, the kernel is bound by the latency of that

@@ -136,7 +136,6 @@ __global__ __launch_bounds__(256) void k_upsample4(PtrG<const T> smallg, PtrG<T>
   const int H = 4 * h, W = 4 * w;
   const float w0 = 0.375f, w1 = 0.1875f, w2 = 0.0625f;
   for (long long idx = (long long)blockIdx.x * 256 + threadIdx.x; idx < nvec; idx += (long long)gridDim.x * 256) {
-#pragma clang fp contract(off)      // separate multiplies and adds: k_conv's in-LDS copy of this interpolation (ConvDesc::up4) gives the same bits
     const int c = (int)(idx % cv) * EPL;
     const long long t = idx / cv;
     const int rx = (int)(t & 3);

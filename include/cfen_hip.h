@@ -39,7 +39,7 @@ const char* cfen_last_error(void);
  *                  96 x 128 / 96 / 64 / 32 (features x tokens) tile (1..5 need K * element size to be a multiple of 128 bytes)
  *   "embed.lds": bit 2 (default 6): the LDS-DMA-ring front half k_embed_qkv2; else k_embed_qkv stages its weights through LDS for D = 96 (bit 0) / D = 192 (bit 1)
  *   "gemm.splitk": 0 (default, round 4) / 1: K-heavy few-token GEMMs inside the net run split-K with the in-launch reduction (scratch from the workspace).
- *                  MEASURED WRONG (0.07 max-abs) when several forwards of replica launch plans are in flight: one forward at a time only
+ *                  (off by default because the unsplit launches are faster with several forwards in flight; bitwise right there too)
  *   "mlp.small_tiles": fused-MLP kernel variant: 0..4 the register-staged k_mlp tilings, >= 10 (default 10) the LDS-DMA k_mlp2 (tens digit:
  *                  D = 96 variant, ones digit: D = 192 variant, see k_mlp.hip);  "net.fused_front_max_dim": largest LViT embedding dim that uses k_embed_qkv
  *   "net.skip_classes": bit mask of kernel classes the net does NOT launch (what-if timing only, outputs invalid)

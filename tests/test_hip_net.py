@@ -451,7 +451,7 @@ def test_fused_tail_up_conv3_equals_the_two_launches_bitwise(size, batch):
 def test_gvit_upsampling_inside_the_fuse_conv_equals_the_upsample_launch(size, batch):
     """"net.up_fused" (default 0: measured slower): GViT's upsam(upsam(x)) (v3:1323) runs inside the level's 1x1 fuse conv (k_conv UP: the workgroup's pixels are
     interpolated from the low-resolution map in LDS with k_upsample4's arithmetic) instead of k_upsample4 writing a full-resolution copy -- the
-    three outputs and every lgcat stage against the plan with the launch, bit for bit; graph replay = eager; the GViT stages, which are then
+    three outputs and every lgcat stage against the plan with the launch (fp16-rounding close); graph replay = eager, bitwise; the GViT stages, which are then
     never stored, are refused by net.stage; the profile has no upsample4 entry left"""
     from cfen_vit_dehazing_amd import ops
     from cfen_vit_dehazing_amd._lib import CfenError
@@ -483,10 +483,13 @@ def test_gvit_upsampling_inside_the_fuse_conv_equals_the_upsample_launch(size, b
             del net
     finally:
         ops.tune("net.up_fused", 0)
+    # the same interpolation in two kernels: fp32 sums the compiler contracts differently, then one rounding to fp16 -- last-bit differences of the GViT half of
+    # the fuse conv's input (forcing separate multiplies and adds in both made the plans bitwise equal and k_upsample4 20 % slower: not worth it for a variant)
     for k in names:
-        assert torch.equal(res[0][1][k], res[1][1][k]), k
+        a, b = res[0][1][k], res[1][1][k]
+        assert float((a - b).abs().max()) <= 4e-3 * max(1.0, float(a.abs().max())), k
     for a, b in zip(res[0][0], res[1][0]):
-        assert torch.equal(a, b)
+        assert float((a - b).abs().max()) <= 2e-3
     torch.cuda.empty_cache()
 
 
