@@ -130,6 +130,37 @@ def test_gemm_split_k_in_launch_reduction(dtype, M, N, K, nsplit):
     close(gl, ops.gemm_ln(x.to(d), lf["q.wl"].to(d), lf["q.s"].to(d), lf["q.bl"].to(d)), tol(dtype, 8), "folded: split vs unsplit")
 
 
+@pytest.mark.parametrize("release", [1, 0])
+def test_gemm_split_k_is_bit_reproducible_with_concurrent_lanes(release):
+    """the in-launch split-K reduction under concurrency -- two streams run the GViT-3 shapes (own operands, own scratch) 150 times each while a third
+    stream keeps the memory system busy; every result must equal the first one bit for bit and the arrival counters must end at zero.  release = 1: the agent-scope
+    release fence in every slice (default, the memory model's recipe); 0: round 3's write-through stores + drain."""
+    d = dev()
+    ops.tune("gemm.splitk_release", release)
+    try:
+        lanes = []
+        for k, (M, N, K, nsplit) in enumerate([(128, 1536, 6144, 8), (128, 1536, 1536, 4)]):
+            x, w = rnd((M, K), 10 + k, torch.float16).to(d), rnd((N, K), 20 + k, torch.float16, 1 / math.sqrt(K)).to(d)
+            tiles = ((N + 95) // 96) * ((M + 31) // 32)
+            scratch = torch.zeros(4096 + tiles * nsplit * 14336, dtype=torch.uint8, device=d)
+            first = ops.gemm_splitk(x, w, nsplit, scratch=scratch).clone()
+            lanes.append((x, w, nsplit, scratch, first, torch.cuda.Stream(d), torch.zeros((), dtype=torch.int64, device=d)))
+        noise_s, big = torch.cuda.Stream(d), torch.empty(64 << 20, dtype=torch.float32, device=d)
+        torch.cuda.synchronize()
+        for it in range(150):
+            for x, w, nsplit, scratch, first, s, bad in lanes:
+                with torch.cuda.stream(s):
+                    bad += (ops.gemm_splitk(x, w, nsplit, scratch=scratch) != first).sum()
+            with torch.cuda.stream(noise_s):
+                big.mul_(1.0001)
+        torch.cuda.synchronize()
+        for x, w, nsplit, scratch, first, s, bad in lanes:
+            assert int(bad) == 0
+            assert int(scratch[:4096].view(torch.int32).abs().sum()) == 0
+    finally:
+        ops.tune("gemm.splitk_release", 1)
+
+
 @pytest.mark.parametrize("dtype", DTYPES)
 @pytest.mark.parametrize("kernel", [6])
 @pytest.mark.parametrize("M,N,K", [(4096, 1536, 384), (300, 1000, 384), (1000, 1152, 1536), (130, 776, 128), (128, 192, 64)])
