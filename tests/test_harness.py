@@ -28,6 +28,9 @@ def test_tensor2im_matches_reference_vectors(golden_dir):
     kat = np.load(golden_dir + "/ops_kat.npz")
     assert np.array_equal(util.tensor2im(torch.from_numpy(kat["t2i/x"])), kat["t2i/y"])      # truncation, 1-channel tiling
     assert np.array_equal(util.tensor2im(torch.from_numpy(kat["t2i/x3"])), kat["t2i/y3"])
+    # an image the generator already wrote as tensor2im's bytes (dec_ipt.output_u8: (H,W,3) uint8) passes through unchanged
+    img = torch.from_numpy(kat["t2i/y3"].copy())
+    assert img.dtype == torch.uint8 and np.array_equal(util.tensor2im(img), kat["t2i/y3"])
 
 
 def test_options_defaults_and_readme_command(tmp_path):
