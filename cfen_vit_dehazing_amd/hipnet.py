@@ -71,7 +71,14 @@ class dec_ipt(nn.Module):
         self._graph_keep = []
         self._graphs = []            # capture() handle -> (net key, native graph id)
         self._last = None
-        self.serial_plan = bool(os.environ.get("CFEN_SERIAL"))     # single-lane launch plan (debugging / A-B)
+        # single-lane launch plan: what several forwards in flight want (bench.py), and what ONE forward wants when the process runs with more than the
+        # default 4 hardware queues -- measured: the two-lane plan's forks / joins then cross queues, 4.49 ms per forward against 2.75 on <= 4 queues; the serial
+        # plan is 3.44 either way (profiles/r04_ab_hw_queues.txt)
+        try:
+            many_queues = int(os.environ.get("GPU_MAX_HW_QUEUES", "4")) > 4
+        except ValueError:
+            many_queues = False
+        self.serial_plan = bool(os.environ.get("CFEN_SERIAL")) or many_queues
         # `replica`: which launch plan + workspace the next forward / capture uses.  Replicas share the packed weights; each has its own workspace
         # (stage buffers, token scratch), so forwards of DIFFERENT replicas may be in flight at once on different streams (bench.py --in-flight 2)
         self.replica = 0
