@@ -7,7 +7,11 @@
         bench.py --gpus N --steps K --warmup W
 
 A step = one forward of one batch of synthetic hazy tensors already resident in HBM, through
-libcfen_hip.so (replayed from a hipGraph).  With N > 1 every rank runs its own 8 images (weak scaling,
+libcfen_hip.so (replayed from a hipGraph).  Consecutive steps rotate over --in-flight launch plans (own workspace
+and output slab, shared weights) on as many streams, so several forwards are in flight at once (default: 4 on one
+GPU, 3 per rank beside the all-gather stream; one hardware queue per stream: GPU_MAX_HW_QUEUES=8 is exported below);
+all K steps complete inside the timed region, and the same line reports ONE forward at a time as well
+(pipelining.one_forward_in_flight).  With N > 1 every rank runs its own 8 images (weak scaling,
 weights replicated) and the per-rank output slab is all-gathered with RCCL; the gather of step i
 overlaps the forward of step i+1 on a side stream and the last one is waited for inside the timed region.
 Rank 0 prints ONE JSON line.
