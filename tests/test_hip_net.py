@@ -18,9 +18,23 @@ from helpers import load_net_fixture, check_outputs, check_stages, weight_mode
 pytestmark = pytest.mark.gpu
 
 
+_SD_CACHE = {}
+
+
+def cached_state_dict(cfg, seed=0, mode="trained"):
+    """generate_state_dict is deterministic and takes 4 s at 512 x 512 (it also draws the 0.2 G never-read parameters of a real checkpoint): the last few are kept
+    (tests only read them -- load_state_dict copies)"""
+    key = (repr(cfg), seed, mode)
+    if key not in _SD_CACHE:
+        if len(_SD_CACHE) >= 3:
+            _SD_CACHE.pop(next(iter(_SD_CACHE)))
+        _SD_CACHE[key] = generate_state_dict(cfg, seed=seed, mode=mode)
+    return _SD_CACHE[key]
+
+
 def make_net(cfg, dtype, seed=0, mode="trained", sd=None):
     net = dec_ipt(cfg, compute_dtype=dtype)
-    net.load_state_dict(sd if sd is not None else generate_state_dict(cfg, seed=seed, mode=mode), strict=True)
+    net.load_state_dict(sd if sd is not None else cached_state_dict(cfg, seed=seed, mode=mode), strict=True)
     return net.to("cuda:0")
 
 
