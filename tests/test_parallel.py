@@ -136,6 +136,42 @@ def test_two_rank_shard_and_allgather_equals_single_process():
     assert q.get(timeout=5) <= 1e-5
 
 
+def _rotation_worker(rank, world, port, q):
+    """bench.py's step loop of the sharded run on CPU tensors: `nslab` = 3 output slabs rotate (three forwards in flight per rank), the gather slot is step & 1"""
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    B, n, nslab, steps = 2, 8, 3, 7
+    slabs = [torch.empty(7 * B * n * n) for _ in range(nslab)]
+    g = OutputGatherer(world, slabs[0].numel(), "cpu", torch.float16)
+    for i in range(steps):
+        s = slabs[i % nslab]
+        g.before_write(i & 1)
+        s.copy_(torch.arange(s.numel(), dtype=torch.float32) % 31 / 64 + rank / 4 + i / 128)      # what step i of this rank "computed" (fp16-exact values)
+        g.launch(s, i & 1)
+    g.wait_all()
+    merged = merge_gathered(g.bufs[(steps - 1) & 1].float(), world, B, n)
+    want = [torch.arange(slabs[0].numel(), dtype=torch.float32) % 31 / 64 + r / 4 + (steps - 1) / 128 for r in range(world)]
+    ok = all(torch.equal(torch.cat([split_slab(want[r], B, n)[k] for r in range(world)], 0), merged[k]) for k in range(3))
+    if rank == 0:
+        q.put(bool(ok))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_slab_rotation_of_the_sharded_bench_loop_gathers_the_last_step():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 31500 + os.getpid() % 2000
+    procs = [ctx.Process(target=_rotation_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    assert q.get(timeout=5) is True
+
+
 def _harness_worker(rank, world, port, root, q):
     """what `python -m torch.distributed.run --nproc-per-node 2 test.py ...` does before its first GPU call: the options pick the GPU of
     LOCAL_RANK, the dataset is this rank's contiguous slice"""
