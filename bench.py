@@ -149,28 +149,37 @@ def time_config(cfg, B, dtype, dev, steps, min_seconds, warmup=3, in_flight=1):
 
 
 def self_check(net, x, outs, cfg, dtype):
-    """The benchmarked computation is validated where it is timed: image 0 of the LAST graph replay against (a) its own batch-1
-    eager forward and (b) the reference vectors of tests/golden (made by importing the reference, tools/gen_golden.py) when
-    the configuration has a fixture.  Returns max-abs differences."""
+    """The benchmarked computation is validated where it is timed: the slab the LAST graph replay wrote against (a) image 0's own batch-1
+    eager forward and (b) the reference vectors of tests/golden (made by importing the reference, tools/gen_golden.py): EVERY image of the batch
+    where the configuration has a fixture of that batch (the headline: net_full512b8_*, seeds 0 .. 7 = synthetic_input's), image 0 otherwise.
+    Returns max-abs differences."""
     import numpy as np
     res = {}
     one = net(x[0:1].clone())
     res["image0_vs_batch1_eager"] = max(float((a[0:1] - b).abs().max()) for a, b in zip(outs, one))
-    fix = os.path.join(ROOT, "tests", "golden", "net_%sfull%d_nf%d_hdr%d.npz" % ("" if cfg.variant == "v3" else cfg.variant + "_", cfg.image_size,
-                                                                                 cfg.n_feats, cfg.hidden_dim_ratio))
+    stem = "%sfull%d" % ("" if cfg.variant == "v3" else cfg.variant + "_", cfg.image_size)
+    tail = "_nf%d_hdr%d.npz" % (cfg.n_feats, cfg.hidden_dim_ratio)
+    B = int(outs[0].shape[0])
+    fix_b = os.path.join(ROOT, "tests", "golden", "net_%sb%d%s" % (stem, B, tail))
+    fix_1 = os.path.join(ROOT, "tests", "golden", "net_%s%s" % (stem, tail))
+    fix, nimg = (fix_b, B) if os.path.exists(fix_b) else (fix_1, 1)
     if os.path.exists(fix):
         z = np.load(fix)
         n = cfg.image_size
         c0 = n // 2 - 32
-        worst = 0.0
+        per_image = [0.0] * nimg
         for nm, o in zip(("xr", "xs", "xd"), outs):
-            o0 = o[0:1].float().cpu()
-            worst = max(worst, float((o0[:, :, c0:c0 + 64, c0:c0 + 64] - torch.from_numpy(z["crop/" + nm])).abs().max()),
-                        float((o0[:, :, 3::8, 5::8] - torch.from_numpy(z["strided/" + nm])).abs().max()))
-        res["image0_vs_reference_vectors"] = worst
-    bar = 3e-2 if dtype == "fp16" else 1e-3
+            oc = o[0:nimg].float().cpu()
+            d1 = (oc[:, :, c0:c0 + 64, c0:c0 + 64] - torch.from_numpy(z["crop/" + nm])).abs().flatten(1).max(1).values
+            d2 = (oc[:, :, 3::8, 5::8] - torch.from_numpy(z["strided/" + nm])).abs().flatten(1).max(1).values
+            per_image = [max(p, float(a), float(b)) for p, a, b in zip(per_image, d1, d2)]
+        res["image0_vs_reference_vectors"] = per_image[0]
+        if nimg > 1:
+            res["images_vs_reference_vectors"] = [round(v, 7) for v in per_image]
+            res["images_checked_against_reference"] = nimg
+    bar = 5e-3 if dtype == "fp16" else 1e-3
     res["bar"] = bar
-    res["ok"] = all(v <= bar for k, v in res.items() if k.startswith("image0"))
+    res["ok"] = all(v <= bar for k, v in res.items() if k.startswith("image0")) and all(v <= bar for v in res.get("images_vs_reference_vectors", []))
     if getattr(net, "gvit_chain", False):       # the persistent-chain variant: a grid-barrier wait that gave up leaves a mark (csrc/k_gvit.hip)
         res["chain_error_words"] = net.chain_errors()
         res["ok"] = res["ok"] and not any(res["chain_error_words"])
@@ -282,7 +291,7 @@ def main():
     nslab = max(2, args.in_flight)
     slabs = [torch.empty(7 * B * n * n, dtype=torch.float32, device=dev) for _ in range(nslab)]
     gdt = args.dtype if args.gather_dtype == "auto" else args.gather_dtype
-    gather = OutputGatherer(world, slabs[0].numel(), dev, torch.float16 if gdt == "fp16" else torch.float32) if world > 1 else None
+    gather = OutputGatherer(world, slabs[0].numel(), dev, torch.float16 if gdt == "fp16" else torch.float32, slots=nslab) if world > 1 else None
 
     net(x, out=slabs[0])                       # packs weights, builds the plan
     torch.cuda.synchronize()
@@ -310,7 +319,7 @@ def main():
             ctx.__enter__()
         try:
             if gather is not None:
-                gather.before_write(i & 1)         # the gather of step i-2 must have consumed this slab
+                gather.before_write(k)             # slot = slab: the gather of step i - nslab, the last reader of THIS slab, must be done with it
             if graphs is not None:
                 net.replay(graphs[k])
             else:
@@ -318,7 +327,7 @@ def main():
                 net(x, out=s)
                 net.replica = 0
             if gather is not None:
-                gather.launch(s, i & 1)            # async all-gather on the communication stream
+                gather.launch(s, k)                # async all-gather on the communication stream
             elif fake_comm[0]:
                 # what-if probe (CFEN_BENCH_FAKE_COMM_CYCLES=n, results are not a benchmark line): a one-workgroup kernel of n cycles per step on its own
                 # stream behind the forward -- the footprint of an always-busy communication queue beside the --in-flight lanes on ONE GPU
@@ -446,7 +455,7 @@ def main():
             # merge_gathered on real RCCL shows up in the scaling run itself (reference analogue: nn.DataParallel's gather, v3:77-83)
             from cfen_vit_dehazing_amd.parallel import merge_gathered
             torch.cuda.synchronize()
-            merged = merge_gathered(gather.bufs[(args.steps - 1) & 1].float(), world, B, n)
+            merged = merge_gathered(gather.bufs[(args.steps - 1) % nslab].float(), world, B, n)
             per_rank = []
             for r in range(world):
                 xi = synthetic_input(1, cfg, seed0=r * B).to(dev)
@@ -491,14 +500,55 @@ def main():
         }
         default_run = (B, args.hidden_dim_ratio, args.load_size, args.variant, args.dtype) == (8, 4, 256, "v3", "fp16")
         if world == 1 and default_run and not args.no_extra_configs:
-            # BASELINE configs 4 and 5 as short legs of the same run, so that their numbers are observed by whoever runs bench.py
+            extra = {}
+            # what the sharded run's communication queue costs a rank, measured instead of modelled: the N = 1 code path WITH the gatherer (a world-1
+            # RCCL communicator, 3 forward lanes + the communication stream, exactly the per-rank configuration of --gpus N) against the same 3 lanes
+            # without it, same graphs, same box, back to back
+            if graphs is not None and nfl >= 3:
+                try:
+                    import socket
+                    import torch.distributed as dist1
+                    with socket.socket() as sk:
+                        sk.bind(("127.0.0.1", 0))
+                        port = sk.getsockname()[1]
+                    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+                    os.environ.setdefault("MASTER_PORT", str(port))
+                    dist1.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+                    main_state = (nslab, nfl, gather)
+                    nslab, nfl = 3, 3
+                    legs = {}
+                    for tag in ("three_lanes_no_gather", "three_lanes_with_gather"):
+                        gather = OutputGatherer(1, slabs[0].numel(), dev, torch.float16 if gdt == "fp16" else torch.float32, slots=nslab) \
+                            if tag.endswith("with_gather") else None
+                        for i in range(6):
+                            step(i)
+                        if gather is not None:
+                            gather.wait_all()
+                        lr = [timed_region()]
+                        while sum(lr) < min(0.4, args.min_seconds) and len(lr) < 50:
+                            lr.append(timed_region())
+                        ldt = sorted(lr)[len(lr) // 2]
+                        legs[tag] = {"value": round(B * args.steps / ldt, 2), "unit": "images/sec", "ms_per_step": round(ldt / args.steps * 1e3, 3), "repetitions": len(lr)}
+                    legs["ms_per_step_added_by_the_gather_queue"] = round(legs["three_lanes_with_gather"]["ms_per_step"] - legs["three_lanes_no_gather"]["ms_per_step"], 3)
+                    torch.cuda.synchronize()
+                    last = (args.steps - 1) % nslab
+                    legs["gathered_equals_slab"] = bool(torch.equal(gather.bufs[last], slabs[last].to(gather.bufs[last].dtype)))
+                    legs["what"] = ("per-rank configuration of the sharded run on ONE GPU: 3 forwards in flight + RCCL all_gather_into_tensor of the %s output slab on "
+                                    "the communication stream (world-1 communicator), one gather slot per slab" % gdt)
+                    nslab, nfl, gather = main_state
+                    dist1.destroy_process_group()
+                    extra["gather_overhead_1gpu"] = legs
+                except Exception as e:          # a failing extra leg must not cost the headline line
+                    extra["gather_overhead_1gpu"] = {"error": "%s: %s" % (type(e).__name__, e)}
+            # BASELINE configs 4 and 5, and the exact-fp32 path (the one that meets north_star's 1e-3 max-abs criterion) at the headline batch, as short
+            # legs of the same run, so that their numbers are observed by whoever runs bench.py
             del net
             torch.cuda.empty_cache()
-            extra = {}
-            for key, ecfg, eb, esteps in (("config4_batch4_1024x1024", NetConfig(24, 4, patch_size=64, load_size=512), 4, 10),
-                                          ("config5_batch16_hdr2", NetConfig(24, 2, patch_size=32, load_size=256), 16, 20)):
+            for key, ecfg, eb, esteps, edt in (("config4_batch4_1024x1024", NetConfig(24, 4, patch_size=64, load_size=512), 4, 10, args.dtype),
+                                               ("config5_batch16_hdr2", NetConfig(24, 2, patch_size=32, load_size=256), 16, 20, args.dtype),
+                                               ("fp32_batch8", NetConfig(24, 4, patch_size=32, load_size=256), 8, 8, "fp32")):
                 try:
-                    extra[key] = time_config(ecfg, eb, args.dtype, dev, esteps, 0.4, in_flight=nfl)
+                    extra[key] = time_config(ecfg, eb, edt, dev, esteps, 0.4, in_flight=nfl)
                 except Exception as e:          # a failing extra leg must not cost the headline line
                     extra[key] = {"error": "%s: %s" % (type(e).__name__, e)}
             result["extra_configs"] = extra

@@ -348,7 +348,16 @@ int cfen_tune(const char* key, int value) {
     cfen_tune_gvit_team() = value;
     return CFEN_OK;
   }
-  if (!strcmp(key, "net.gvit_stream")) { cfen_tune_gvit_stream() = value != 0; return CFEN_OK; }
+  if (!strcmp(key, "net.gvit_stream")) {
+    CFEN_CHECK_ARG(value >= 0 && value <= 2, "tune: net.gvit_stream is 0 (never), 1 (serial launch plan only) or 2 (every plan)");
+    cfen_tune_gvit_stream() = value;
+    return CFEN_OK;
+  }
+  if (!strcmp(key, "gvit.max_concurrent")) {
+    CFEN_CHECK_ARG(value >= 1 && value <= 8, "tune: gvit.max_concurrent is 1 .. 8 forwards in flight");
+    cfen_tune_gvit_max_concurrent() = value;
+    return CFEN_OK;
+  }
   if (!strcmp(key, "net.tail_fused")) { cfen_tune_tail_fused() = value != 0; return CFEN_OK; }
   if (!strcmp(key, "net.up_fused")) { cfen_tune_up_fused() = value != 0; return CFEN_OK; }
   if (!strcmp(key, "net.zero_memset")) { cfen_tune_zero_memset() = value != 0; return CFEN_OK; }

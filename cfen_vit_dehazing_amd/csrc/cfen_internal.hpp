@@ -152,6 +152,7 @@ struct CfenChainArgs {
 size_t cfen_gvit_chain_part_bytes(int M, int maxN, int max_nsplit);
 int cfen_gvit_chain_impl_g(int dtype, int ng, const CfenChainArgs* ca, int team, hipStream_t s);
 int& cfen_tune_gvit_team();     // workgroups per GViT block of the persistent chain ("gvit.team")
+int& cfen_tune_gvit_max_concurrent();   // forwards of the chain plan that may be in flight at once ("gvit.max_concurrent", default 1): the teams of ALL of them must fit the chip
 int& cfen_tune_gvit_chain();    // 1 (default): GViT blocks run their GEMMs as persistent chains where the net holds fragment-stream weights ("net.gvit_chain")
 int& cfen_tune_gvit_debug();    // timing experiments on the chain kernel, results invalid ("gvit.debug")
 int& cfen_tune_gemm_splitk_release();   // A/B: release fence in every split-K slice ("gemm.splitk_release")

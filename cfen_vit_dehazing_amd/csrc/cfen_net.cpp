@@ -28,7 +28,9 @@ int& cfen_tune_gvit_dummy_wgs() { static int v = 0; return v; }
 int& cfen_tune_gvit_dummy_us() { static int v = 100; return v; }
 int& cfen_tune_gvit_dummy_stream() { static int v = 0; return v; }
 int& cfen_tune_gvit_chain() { static int v = 1; return v; }   // only nets built with fragment-stream GViT weights (cfg.reserved bit 2) can use it
-int& cfen_tune_gvit_stream() { static int v = 1; return v; }   // 0 never, 1 (default) in the serial launch plan (several forwards in flight: 2.24 against 2.27 ms), 2 always
+int& cfen_tune_gvit_stream() { static int v = 2; return v; }   // 0 never, 1 in the serial launch plan only, 2 (default, round 5) on every plan: which KERNELS produce the
+                                                                // outputs no longer depends on the lane plan or on profiling (two-lane, serial and profiled forwards are bitwise equal;
+                                                                // the stream kernels cost one forward at a time 2.80 -> 2.85 ms and gain 2.27 -> 2.24 with several in flight)
                                                                 // (one forward at a time on the two-lane plan it is SLOWER, 2.85 against 2.80 ms: 277 us of latency against 134)
 int& cfen_tune_tail_fused() { static int v = 1; return v; }
 int& cfen_tune_up_fused() { static int v = 0; return v; }
@@ -268,16 +270,32 @@ struct cfen_net {
     return run_conv_g(1, &c, act);
   }
   struct VitCall { const Vit* v; std::string in, out; };
-  // first use of a workspace: its synchronisation words (split-K arrival counters, barrier and error words of the chains) start at zero
+  // first use of a workspace: its synchronisation words (split-K arrival counters, barrier and error words of the chains) start at zero.  Ordered on
+  // the CALLER'S stream (a kernel launch on it) for an eager forward -- torch's lane streams are non-blocking, a memset on the legacy null stream is
+  // not ordered against them -- and synchronously for a graph capture (a one-time set-up call without a stream of its own).  Keyed by
+  // (address, size): the caller must not write into the workspace between forwards (include/cfen_hip.h), and hands a NEW net a workspace of its own.
   const void* primed_base = nullptr;
-  int prime_workspace() {
-    if (base == primed_base) return CFEN_OK;
-    for (int k = 1; k < 6; k += 2)
-      if (hipMemset(at(scr_set[k].splitk), 0, CFEN_SPLITK_COUNTERS * sizeof(unsigned)) != hipSuccess || hipMemset(at(scr_set[k].sync), 0, GV_SYNC_WORDS * sizeof(unsigned)) != hipSuccess) {
-        cfen_set_error("net: cannot zero the synchronisation words of the workspace");
-        return CFEN_ERR_HIP;
+  size_t primed_bytes = 0;
+  int prime_workspace(bool capturing) {
+    if (base == primed_base && primed_bytes == ws_bytes) return CFEN_OK;
+    for (int k = 1; k < 6; k += 2) {
+      if (capturing) {
+        if (hipMemset(at(scr_set[k].splitk), 0, CFEN_SPLITK_COUNTERS * sizeof(unsigned)) != hipSuccess ||
+            hipMemset(at(scr_set[k].sync), 0, GV_SYNC_WORDS * sizeof(unsigned)) != hipSuccess) {
+          cfen_set_error("net: cannot zero the synchronisation words of the workspace");
+          return CFEN_ERR_HIP;
+        }
+      } else {
+        if (int rc = cfen_zero_words_impl(at(scr_set[k].splitk), CFEN_SPLITK_COUNTERS, stream)) return rc;
+        if (int rc = cfen_zero_words_impl(at(scr_set[k].sync), GV_SYNC_WORDS, stream)) return rc;
       }
+    }
+    if (capturing && hipDeviceSynchronize() != hipSuccess) {
+      cfen_set_error("net: cannot zero the synchronisation words of the workspace (synchronize)");
+      return CFEN_ERR_HIP;
+    }
     primed_base = base;
+    primed_bytes = ws_bytes;
     return CFEN_OK;
   }
   int run_vit_g(int ng, const VitCall* c, int scr0);   // group member g uses scratch set scr0 + 2 g
@@ -652,7 +670,7 @@ int cfen_net::run_vit_g(int ng, const VitCall* vc, int scr0) {
                            v.global && wtile};
     return cfen_gemm_impl_g(dt, ng, gp, K, K, N, v.S, N, M, N, K, relu, nullptr, stream, v.global ? SK : nullptr, v.global ? SPLITK_BYTES : 0);
   };
-  if (v.gstream && (cfen_tune_gvit_stream() == 2 || (cfen_tune_gvit_stream() == 1 && !(parallel && !profiling))) && cfen_front3_supported(dt, v.D, (long long)M)) {
+  if (v.gstream && (cfen_tune_gvit_stream() == 2 || (cfen_tune_gvit_stream() == 1 && !parallel)) && cfen_front3_supported(dt, v.D, (long long)M)) {
     // GViT block of embedding dim 384 (level 1) on the LViT-3 stream kernels: 4 x 4 pooled MAP -> k_front3 (patch gather + linear_encoding + residual +
     // position + LN1 + in_proj, qkv row-major) -> attention -> k_mlp3 (out_proj + LN2 + FFN + mlp_head + fold into the pooled-size map) -> x4
     // bilinear: 5 launches instead of 10, and the two stream launches are 16 whole-CU workgroups per block -- 2-3x the latency of the GEMM chain and
@@ -690,7 +708,7 @@ int cfen_net::run_vit_g(int ng, const VitCall* vc, int scr0) {
   if (v.chain && (cfen_tune_gvit_chain() == 1 || cfen_tune_gvit_chain() == 4 || (cfen_tune_gvit_chain() == 2 && ng > 1) || (cfen_tune_gvit_chain() == 3 && ng == 1))) {
     // GViT block: pooled patch tokens -> [embed -> qkv] -> attention -> [proj -> ffn1 -> ffn2 -> head1 -> head2 + fold] -> x4 bilinear; the two
     // bracketed runs are ONE persistent launch each (k_gvit.hip): a team of workgroups per block keeps its CUs over the whole run
-    const int team = std::min(cfen_tune_gvit_team(), 256 / ng);
+    const int team = std::max(1, std::min(cfen_tune_gvit_team(), 256 / (ng * std::max(1, cfen_tune_gvit_max_concurrent()))));   // every team of every forward in flight must be RESIDENT at once (grid barrier)
     const bool per_gemm = cfen_tune_gvit_chain() == 4;   // every GEMM its own launch of the chain kernel, never split over K: no grid barrier, no split-K seam
     auto nsp = [&](int N, int K) {   // K slices so that the phase has work for most of the team (>= 4 K-steps of 64 per slice)
       int n = 1;
@@ -1289,7 +1307,7 @@ int cfen_net_forward(cfen_net* net, const float* x, float* xr, float* xs, float*
     }
   net->base = (unsigned char*)workspace;
   net->stream = (hipStream_t)stream;
-  TRY(net->prime_workspace());
+  TRY(net->prime_workspace(false));
   return net->forward(x, xr, xs, xd);
 }
 
@@ -1315,7 +1333,7 @@ int cfen_net_graph_capture(cfen_net* net, const float* x, float* xr, float* xs, 
   }
   net->base = (unsigned char*)workspace;
   net->stream = (hipStream_t)(uintptr_t)16;          // lane key of the main lane; nothing is launched on it
-  if (int prc = net->prime_workspace()) { (void)hipGraphDestroy(rec.graph); return prc; }
+  if (int prc = net->prime_workspace(true)) { (void)hipGraphDestroy(rec.graph); return prc; }
   cfen_recorder() = &rec;
   int rc = net->forward(x, xr, xs, xd);
   cfen_recorder() = nullptr;

@@ -27,6 +27,12 @@ int& cfen_tune_gvit_debug() {   // timing experiments (results invalid): 1 no we
   static int v = 0;
   return v;
 }
+int& cfen_tune_gvit_max_concurrent() {   // a grid barrier needs its whole team resident; with several forwards of the chain plan in flight (replica plans on their
+                                         // own streams) two launches asking for more CUs than the chip has can each end up partially resident and spin on each other
+                                         // until GV_SPIN_LIMIT.  The host caps team x ng x this at 256 CUs (cfen_net.cpp) and hipnet refuses a replica beyond it.
+  static int v = 1;
+  return v;
+}
 int& cfen_tune_gvit_team() {   // workgroups (= CUs) per GViT block of the persistent chain ("gvit.team")
   static int v = 48;
   return v;

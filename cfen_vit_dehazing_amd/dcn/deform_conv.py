@@ -8,7 +8,6 @@ libcfen_hip.so: forward (csrc/k_dcn.hip; the column matrix is never materialised
 the kernel's operand scratch) and backward (csrc/k_dcn_bwd.hip: grad_input / grad_offset / grad_mask /
 grad_weight / grad_bias, fp32 arithmetic), so the functions are differentiable like the reference's.
 """
-import logging
 import math
 
 import torch
@@ -19,8 +18,6 @@ from torch.nn.modules.utils import _pair
 
 from .. import _lib
 from .._lib import check, ptr, dtype_code, current_stream
-
-logger = logging.getLogger('base')
 
 
 def _contig(*ts):
@@ -164,119 +161,110 @@ deform_conv = DeformConvFunction.apply
 modulated_deform_conv = ModulatedDeformConvFunction.apply
 
 
-class DeformConv(nn.Module):
-    def __init__(self, in_channels, out_channels, kernel_size, stride=1, padding=0, dilation=1, groups=1, deformable_groups=1,
-                 bias=False):
-        super(DeformConv, self).__init__()
-        assert not bias
-        assert in_channels % groups == 0, 'in_channels {} cannot be divisible by groups {}'.format(in_channels, groups)
-        assert out_channels % groups == 0, 'out_channels {} cannot be divisible by groups {}'.format(out_channels, groups)
-        self.in_channels = in_channels
-        self.out_channels = out_channels
+# ---- the module API (reference dcn/deform_conv.py:161-329: six nn.Modules) ------------------------------------------------------------------
+# One base class owns the geometry, the kernel weight (and v2's bias) and their initialisation; the reference's classes are thin views of it.  What a
+# checkpoint or a caller can see is kept: class names, constructor signatures, attribute names, state_dict keys (`weight`, `bias`,
+# `conv_offset.*`, `conv_offset_mask.*`), uniform(+-1/sqrt(Cin*kh*kw)) weights, zero bias, zero-initialised offset branches (so a *Pack module is a
+# plain convolution until trained), `chunk -> cat -> sigmoid` of the v2 branch's output, the `[input, features]` calling form of extra_offset_mask.
+
+class _DeformableBase(nn.Module):
+    _modulated = False          # v2: mask + optional bias, and stride / padding / dilation kept as the caller passed them (the reference does, :221-237)
+
+    def _setup(self, in_channels, out_channels, kernel_size, stride, padding, dilation, groups, deformable_groups, bias):
+        for what, c in (("in_channels", in_channels), ("out_channels", out_channels)):
+            assert c % groups == 0, '{} {} cannot be divisible by groups {}'.format(what, c, groups)
+        self.in_channels, self.out_channels = in_channels, out_channels
         self.kernel_size = _pair(kernel_size)
-        self.stride = _pair(stride)
-        self.padding = _pair(padding)
-        self.dilation = _pair(dilation)
-        self.groups = groups
-        self.deformable_groups = deformable_groups
-        self.weight = nn.Parameter(torch.Tensor(out_channels, in_channels // self.groups, *self.kernel_size))
+        keep = (lambda v: v) if self._modulated else _pair
+        self.stride, self.padding, self.dilation = keep(stride), keep(padding), keep(dilation)
+        self.groups, self.deformable_groups = groups, deformable_groups
+        self.weight = nn.Parameter(torch.empty(out_channels, in_channels // groups, *self.kernel_size))
+        if self._modulated:
+            self.with_bias = bias
+            if bias:
+                self.bias = nn.Parameter(torch.empty(out_channels))
+            else:
+                self.register_parameter('bias', None)
         self.reset_parameters()
 
     def reset_parameters(self):
-        n = self.in_channels
-        for k in self.kernel_size:
-            n *= k
-        stdv = 1. / math.sqrt(n)
-        self.weight.data.uniform_(-stdv, stdv)
+        bound = 1.0 / math.sqrt(self.in_channels * self.kernel_size[0] * self.kernel_size[1])
+        with torch.no_grad():
+            self.weight.uniform_(-bound, bound)
+            if getattr(self, 'bias', None) is not None:
+                self.bias.zero_()
+
+    def _offset_branch(self, maps_per_tap, in_channels=None):
+        """the convolution that predicts offsets (2 maps per tap and deformable group) or offsets + masks (3): same window as the deformable conv, zero at init"""
+        taps = self.kernel_size[0] * self.kernel_size[1]
+        conv = nn.Conv2d(in_channels or self.in_channels, self.deformable_groups * maps_per_tap * taps, kernel_size=self.kernel_size,
+                         stride=_pair(self.stride), padding=_pair(self.padding), bias=True)
+        nn.init.zeros_(conv.weight)
+        nn.init.zeros_(conv.bias)
+        return conv
+
+    def _apply_v1(self, x, offset):
+        return deform_conv(x, offset, self.weight, self.stride, self.padding, self.dilation, self.groups, self.deformable_groups)
+
+    def _apply_v2(self, x, offset, mask):
+        return modulated_deform_conv(x, offset, mask, self.weight, self.bias, self.stride, self.padding, self.dilation, self.groups, self.deformable_groups)
+
+
+class DeformConv(_DeformableBase):
+    def __init__(self, in_channels, out_channels, kernel_size, stride=1, padding=0, dilation=1, groups=1, deformable_groups=1, bias=False):
+        super().__init__()
+        assert not bias                                    # DCNv1 has no bias (reference :165)
+        self._setup(in_channels, out_channels, kernel_size, stride, padding, dilation, groups, deformable_groups, False)
 
     def forward(self, x, offset):
-        return deform_conv(x, offset, self.weight, self.stride, self.padding, self.dilation, self.groups, self.deformable_groups)
+        return self._apply_v1(x, offset)
 
 
 class DeformConvPack(DeformConv):
     def __init__(self, *args, **kwargs):
-        super(DeformConvPack, self).__init__(*args, **kwargs)
-        self.conv_offset = nn.Conv2d(self.in_channels, self.deformable_groups * 2 * self.kernel_size[0] * self.kernel_size[1],
-                                     kernel_size=self.kernel_size, stride=_pair(self.stride), padding=_pair(self.padding), bias=True)
-        self.init_offset()
+        super().__init__(*args, **kwargs)
+        self.conv_offset = self._offset_branch(2)
 
     def init_offset(self):
-        self.conv_offset.weight.data.zero_()
-        self.conv_offset.bias.data.zero_()
+        nn.init.zeros_(self.conv_offset.weight)
+        nn.init.zeros_(self.conv_offset.bias)
 
     def forward(self, x):
-        offset = self.conv_offset(x)
-        return deform_conv(x, offset, self.weight, self.stride, self.padding, self.dilation, self.groups, self.deformable_groups)
+        return self._apply_v1(x, self.conv_offset(x))
 
 
-class ModulatedDeformConv(nn.Module):
-    def __init__(self, in_channels, out_channels, kernel_size, stride=1, padding=0, dilation=1, groups=1, deformable_groups=1,
-                 bias=True):
-        super(ModulatedDeformConv, self).__init__()
-        self.in_channels = in_channels
-        self.out_channels = out_channels
-        self.kernel_size = _pair(kernel_size)
-        self.stride = stride
-        self.padding = padding
-        self.dilation = dilation
-        self.groups = groups
-        self.deformable_groups = deformable_groups
-        self.with_bias = bias
-        self.weight = nn.Parameter(torch.Tensor(out_channels, in_channels // groups, *self.kernel_size))
-        if bias:
-            self.bias = nn.Parameter(torch.Tensor(out_channels))
-        else:
-            self.register_parameter('bias', None)
-        self.reset_parameters()
+class ModulatedDeformConv(_DeformableBase):
+    _modulated = True
 
-    def reset_parameters(self):
-        n = self.in_channels
-        for k in self.kernel_size:
-            n *= k
-        stdv = 1. / math.sqrt(n)
-        self.weight.data.uniform_(-stdv, stdv)
-        if self.bias is not None:
-            self.bias.data.zero_()
+    def __init__(self, in_channels, out_channels, kernel_size, stride=1, padding=0, dilation=1, groups=1, deformable_groups=1, bias=True):
+        super().__init__()
+        self._setup(in_channels, out_channels, kernel_size, stride, padding, dilation, groups, deformable_groups, bias)
 
     def forward(self, x, offset, mask):
-        return modulated_deform_conv(x, offset, mask, self.weight, self.bias, self.stride, self.padding, self.dilation, self.groups,
-                                     self.deformable_groups)
+        return self._apply_v2(x, offset, mask)
 
 
 class ModulatedDeformConvPack(ModulatedDeformConv):
     _offset_in_channels = None
 
     def __init__(self, *args, extra_offset_mask=False, **kwargs):
-        super(ModulatedDeformConvPack, self).__init__(*args, **kwargs)
+        super().__init__(*args, **kwargs)
         self.extra_offset_mask = extra_offset_mask
-        self.conv_offset_mask = nn.Conv2d(self._offset_in_channels or self.in_channels,
-                                          self.deformable_groups * 3 * self.kernel_size[0] * self.kernel_size[1],
-                                          kernel_size=self.kernel_size, stride=_pair(self.stride), padding=_pair(self.padding), bias=True)
-        self.init_offset()
+        self.conv_offset_mask = self._offset_branch(3, self._offset_in_channels)
 
     def init_offset(self):
-        self.conv_offset_mask.weight.data.zero_()
-        self.conv_offset_mask.bias.data.zero_()
+        nn.init.zeros_(self.conv_offset_mask.weight)
+        nn.init.zeros_(self.conv_offset_mask.bias)
 
     def forward(self, x):
-        if self.extra_offset_mask:
-            out = self.conv_offset_mask(x[1])      # x = [input, features]
-            x = x[0]
-        else:
-            out = self.conv_offset_mask(x)
-        o1, o2, mask = torch.chunk(out, 3, dim=1)
-        offset = torch.cat((o1, o2), dim=1)
-        mask = torch.sigmoid(mask)
-        offset_mean = torch.mean(torch.abs(offset))
-        if offset_mean > 100:
-            logger.warning('Offset mean is {}, larger than 100.'.format(offset_mean))
-        return modulated_deform_conv(x, offset, mask, self.weight, self.bias, self.stride, self.padding, self.dilation, self.groups,
-                                     self.deformable_groups)
+        x, feat = (x[0], x[1]) if self.extra_offset_mask else (x, x)       # extra_offset_mask: x = [input, features the branch reads]
+        dy, dx, m = torch.chunk(self.conv_offset_mask(feat), 3, dim=1)
+        return self._apply_v2(x, torch.cat((dy, dx), dim=1), torch.sigmoid(m))
 
 
 class ModulatedDeformConvPack2(ModulatedDeformConvPack):
-    """Same as ModulatedDeformConvPack with an offset branch fed by `offset_in_channel` features."""
+    """ModulatedDeformConvPack whose offset / mask branch reads `offset_in_channel` feature channels (reference :294-329)."""
 
     def __init__(self, *args, extra_offset_mask=False, offset_in_channel=32, **kwargs):
         self._offset_in_channels = offset_in_channel
-        super(ModulatedDeformConvPack2, self).__init__(*args, extra_offset_mask=extra_offset_mask, **kwargs)
+        super().__init__(*args, extra_offset_mask=extra_offset_mask, **kwargs)

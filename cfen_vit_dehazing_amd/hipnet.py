@@ -63,22 +63,28 @@ class dec_ipt(nn.Module):
         self._manifest = state_manifest(self.cfg)
         _build_tree(self, self._manifest)
         self._dead = {}              # dead key -> CPU tensor, as loaded from a checkpoint (absent = zeros of the manifest shape)
-        self._packed = None          # {name: device tensor}
+        self._packed = None          # {name: device tensor} of the current compute dtype
+        self._packed_cache = {}      # other compute dtypes' packed sets (set_compute_dtype)
         self._packed_dev = None
         self._an_pending = {}        # packed layer name -> (ActNorm key prefix, conv bias, an_out): uninitialised ActNorm2d layers
-        self._nets = {}              # (batch, input kind, plan, replica, output kind) -> (handle, workspace tensor)
+        self._nets = {}              # (batch, input kind, plan, replica, output kind, compute dtype) -> (handle, workspace tensor)
         self._native_u8 = {}         # same key -> the net writes uint8 outputs itself
         self._graph_keep = []
         self._graphs = []            # capture() handle -> (net key, native graph id)
         self._last = None
-        # single-lane launch plan: what several forwards in flight want (bench.py), and what ONE forward wants when the process runs with more than the
-        # default 4 hardware queues -- measured: the two-lane plan's forks / joins then cross queues, 4.49 ms per forward against 2.75 on <= 4 queues; the serial
-        # plan is 3.44 either way (profiles/r04_ab_hw_queues.txt)
+        # Launch plan of one forward: two lanes (GViT beside LViT on a second stream / graph branch; best for ONE forward at a time on the default 4
+        # hardware queues: 2.75 against 3.44 ms) or one serial chain of launches (what several forwards in flight want -- bench.py, pipeline.py set
+        # `serial_plan` themselves -- and what one forward wants once the process runs on more than 4 hardware queues: the two-lane plan's forks / joins
+        # then cross queues, 4.49 against 3.44 ms, profiles/r04_ab_hw_queues.txt).  The plan changes WHEN kernels run, never which kernels run or what
+        # they compute (round 5: "net.gvit_stream" = 2), so outputs are bitwise the same either way; `plan_info()` says which one is in force and why.
         try:
             many_queues = int(os.environ.get("GPU_MAX_HW_QUEUES", "4")) > 4
         except ValueError:
             many_queues = False
         self.serial_plan = bool(os.environ.get("CFEN_SERIAL")) or many_queues
+        self._plan_reason = ("CFEN_SERIAL is set" if os.environ.get("CFEN_SERIAL") else
+                             "GPU_MAX_HW_QUEUES=%s > 4 in the environment" % os.environ.get("GPU_MAX_HW_QUEUES") if many_queues else
+                             "default: one forward at a time on <= 4 hardware queues")
         # `replica`: which launch plan + workspace the next forward / capture uses.  Replicas share the packed weights; each has its own workspace
         # (stage buffers, token scratch), so forwards of DIFFERENT replicas may be in flight at once on different streams (bench.py --in-flight 2)
         self.replica = 0
@@ -154,6 +160,7 @@ class dec_ipt(nn.Module):
     def invalidate(self):
         """Call after mutating parameters in place; packed copies are rebuilt at the next forward."""
         self._packed = None
+        self._packed_cache = {}
         self._free_nets()
 
     def _free_nets(self):
@@ -173,8 +180,18 @@ class dec_ipt(nn.Module):
             pass
 
     def set_compute_dtype(self, dtype):
-        self.compute_dtype = _DTYPES[dtype]
-        self.invalidate()
+        """Switch the arithmetic type of the following forwards.  Packed weights and launch plans are kept PER TYPE (round 5): the --precision half
+        checks of the harness flip between fp16 and fp32 every --half_guard_every batches, and repacking 271 M parameters each time cost seconds."""
+        dtype = _DTYPES[dtype]
+        if dtype == self.compute_dtype:
+            return
+        if self._packed is not None:
+            self._packed_cache[self.compute_dtype] = (self._packed, self._packed_dev, self._an_pending, getattr(self, "_ones", None))
+        self.compute_dtype = dtype
+        self._packed = None
+        hit = self._packed_cache.pop(dtype, None)
+        if hit is not None:
+            self._packed, self._packed_dev, self._an_pending, self._ones = hit
 
     def _live_state(self, device):
         sd = {}
@@ -203,9 +220,19 @@ class dec_ipt(nn.Module):
 
     def _net_for(self, batch, device, u8=False):
         packed = self._ensure_packed(device)
-        key = (batch, bool(u8), bool(self.serial_plan), int(self.replica), bool(self.output_u8))
+        key = (batch, bool(u8), bool(self.serial_plan), int(self.replica), bool(self.output_u8), self.compute_dtype)
         if key in self._nets:
             return self._nets[key]
+        if self.gvit_chain:
+            # the persistent chains meet at a grid barrier: every team of every forward in flight must be resident at once.  The host caps the team at
+            # 256 / (ng x "gvit.max_concurrent") CUs; a replica beyond that number could leave two launches partially resident, spinning on each other
+            # until GV_SPIN_LIMIT and then continuing with unsynchronised data (csrc/k_gvit.hip) -- refused here
+            from . import ops
+            allowed = ops.tuned("gvit.max_concurrent", 1)
+            if int(self.replica) >= allowed:
+                raise CfenError("CFEN_GVIT_CHAIN=1: replica %d would put %d chain plans in flight, the grid barriers are sized for %d "
+                                "(ops.tune('gvit.max_concurrent', n) BEFORE building the nets caps the teams accordingly)"
+                                % (self.replica, int(self.replica) + 1, allowed))
         lib = _lib.load()
         c = self.cfg
         cc = NetConfigC(batch=batch, n_feats=c.n_feats, hidden_dim_ratio=c.hidden_dim_ratio, patch_size=c.patch_size,
@@ -226,6 +253,14 @@ class dec_ipt(nn.Module):
         self._nets[key] = (h, ws)
         self._native_u8[key] = native_u8
         return self._nets[key]
+
+    def plan_info(self):
+        """the launch plan the NEXT forward / capture of this module uses, and why (the choice must be visible, not ambient)"""
+        set_by_caller = self.serial_plan != (bool(os.environ.get("CFEN_SERIAL")) or self._plan_reason.startswith("GPU_MAX_HW_QUEUES"))
+        return {"lanes_per_forward": 1 if self.serial_plan else 2, "replica": int(self.replica),
+                "why": "set by the caller (bench.py / pipeline.py: several forwards in flight)" if set_by_caller else self._plan_reason,
+                "hw_queues": os.environ.get("GPU_MAX_HW_QUEUES", "4 (runtime default)"), "gvit_chain": bool(self.gvit_chain),
+                "compute_dtype": str(self.compute_dtype).replace("torch.", "")}
 
     def chain_errors(self):
         """error words of the persistent GViT chains of the net that ran last (csrc/k_gvit.hip): all zero unless a grid-barrier wait gave up
@@ -310,7 +345,7 @@ class dec_ipt(nn.Module):
                                 "models/actnorm.py:25-37) before capture() / profile()")
             self._arm_actnorm_init(h)
         px = B * n * n
-        key = (B, bool(u8), bool(self.serial_plan), int(self.replica), bool(self.output_u8))
+        key = (B, bool(u8), bool(self.serial_plan), int(self.replica), bool(self.output_u8), self.compute_dtype)
         native_u8 = self._native_u8[key]
         if self.output_u8 and out is not None:
             raise ValueError("output_u8 allocates its own (B,H,W,3) uint8 outputs: no `out` slab")
@@ -368,11 +403,12 @@ class dec_ipt(nn.Module):
         C, cs, H, W = (ctypes.c_int32() for _ in range(4))
         check(_lib.load().cfen_net_stage(h, name.encode(), ctypes.byref(p), ctypes.byref(C), ctypes.byref(cs), ctypes.byref(H),
                                          ctypes.byref(W)), "cfen_net_stage")
-        esz = 2 if self.compute_dtype == torch.float16 else 4
+        dt = self._last[5]
+        esz = 2 if dt == torch.float16 else 4
         off = p.value - ws.data_ptr()
         B = self._last[0]
         n = B * H.value * W.value * cs.value
-        flat = ws[off:off + n * esz].view(self.compute_dtype)
+        flat = ws[off:off + n * esz].view(dt)
         return flat.view(B, H.value, W.value, cs.value)[..., :C.value].permute(0, 3, 1, 2).float().contiguous()
 
     def flops_per_image(self):

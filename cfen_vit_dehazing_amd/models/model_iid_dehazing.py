@@ -37,13 +37,22 @@ class DECHLGVIT(BaseModel):
         else:
             self._net_in = self.real_B = B
 
-    HALF_GUARD_BAR = 3e-2     # max-abs difference of the fp16 outputs (tanh values in (-1, 1)) from the fp32 path on the first batch
+    HALF_GUARD_BAR = 3e-2     # max-abs difference of the fp16 outputs (tanh values in (-1, 1)) from the fp32 path on a checked batch
 
     def setup(self, opt):
         BaseModel.setup(self, opt)
-        # fp16 range safety of a REAL checkpoint (ActNorm scales, K = 6144 FFN sums) is unknown until its weights are here: with --precision
-        # half the first batch runs through the exact-fp32 path once as well (reference loader: models/base_model.py:114-131)
+        # fp16 range safety of a REAL checkpoint (ActNorm scales, K = 6144 FFN sums) is unknown until its weights are here, and it depends on the
+        # IMAGE: with --precision half the first batch and then every --half_guard_every-th batch of the run also go through the exact-fp32 path
+        # (reference loader: models/base_model.py:114-131).  The kernels are built with -fno-honor-nans (build.py), so an fp16 overflow inside the net
+        # comes out as finite garbage, not NaN: comparing with the fp32 path is the only check that sees it.
         self._half_guard = getattr(opt, 'precision', 'single') == 'half' and not getattr(opt, 'no_half_guard', False)
+        self._guard_every = max(0, int(getattr(opt, 'half_guard_every', 32)))
+        self._batch_index = 0            # index of the batch the next forward() works on (the pipelined driver sets it: not every batch passes here)
+        self._since_check = []           # image paths of the fp16 batches since the last passed check (pipeline.py adds the ones it runs itself)
+        self.redo_paths = []             # images whose files were written by fp16 forwards later found unsafe: test.py runs them again in fp32
+        self.half_guard_log = []         # (batch index, agreed max-abs) of every check
+        self._checks_planned = None      # checks EVERY rank takes part in (plan_half_guard), None = only the first
+        self._checks_done = 0
         # test.py only turns the outputs into PNGs (util.tensor2im, util/util.py:12-24): the generator writes those bytes itself -- (B,H,W,3) uint8
         # from the tails' last launch where the geometry allows, a device pass elsewhere (hipnet.dec_ipt.output_u8) -- instead of fp32 planes
         self._u8_out = not getattr(opt, 'isTrain', False) and getattr(opt, 'phase', 'test') == 'test' and hasattr(self.netG, 'output_u8')
@@ -55,64 +64,121 @@ class DECHLGVIT(BaseModel):
         os.makedirs(d, exist_ok=True)
         return d
 
-    def _agree_on_worst(self, worst, timeout=120.0):
-        import os
-        import time
-        world, rank = getattr(self.opt, 'dist_world', 1), getattr(self.opt, 'dist_rank', 0)
-        if world <= 1:
-            return worst
-        if torch.distributed.is_available() and torch.distributed.is_initialized():
-            t = torch.tensor([worst if worst == worst else float('inf')], dtype=torch.float64, device=self.device)
-            torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
-            return float(t.item())
-        d = self._guard_dir()
-        run = os.environ.get('TORCHELASTIC_RUN_ID', 'run')
-        with open(os.path.join(d, '.half_guard_%s_rank%d' % (run, rank)), 'w') as f:
-            f.write(repr(float(worst)))
-        vals, t_end = {}, time.time() + timeout
-        while len(vals) < world and time.time() < t_end:
-            for r in range(world):
-                p = os.path.join(d, '.half_guard_%s_rank%d' % (run, r))
-                if r not in vals and os.path.exists(p):
-                    txt = open(p).read().strip()
-                    if txt:
-                        vals[r] = float(txt)
-            if len(vals) < world:
-                time.sleep(0.05)
-        if len(vals) < world:      # a rank never reported: be safe, everyone who notices falls back
-            return float('inf')
-        return max(vals.values())
+    # ---- which batches are checked, and how the ranks of a sharded run stay in step --------------------------------------------------------------
+    def guard_due(self, batch_index):
+        """does the batch with this index (0-based, per rank) go through the fp32 comparison?"""
+        if not getattr(self, '_half_guard', False):
+            return False
+        if getattr(self.opt, 'dist_world', 1) > 1 and self._checks_planned is None:
+            return batch_index == 0          # no plan_half_guard(): the ranks' later checks could not be paired up -- only the first one is common to all
+        return batch_index == 0 or (self._guard_every > 0 and batch_index % self._guard_every == 0)
 
-    def _record_precision(self, chosen, worst):
+    def checks_for(self, n_batches):
+        if n_batches <= 0:
+            return 0
+        return 1 + ((n_batches - 1) // self._guard_every if self._guard_every > 0 else 0)
+
+    def plan_half_guard(self, n_batches):
+        """Call once before the first batch of a sharded run: ranks may hold slices that differ by a batch, so they agree on the number of checks the
+        LONGEST slice makes; a rank with fewer takes part in the remaining ones from finish_half_guard() (every check is one collective on all ranks)."""
+        if not getattr(self, '_half_guard', False):
+            return
+        mine = self.checks_for(n_batches)
+        self._checks_planned = int(self._all_reduce_max(float(mine))) if getattr(self.opt, 'dist_world', 1) > 1 else mine
+
+    def finish_half_guard(self):
+        """Call after the last batch: joins the checks other ranks still make; a failure agreed on there marks this rank's unchecked batches as well."""
+        if not getattr(self, '_half_guard', False) or self._checks_planned is None:
+            return
+        while self._checks_done < self._checks_planned:
+            worst = self._agree_on_worst(0.0)
+            self._checks_done += 1
+            if not worst <= self.HALF_GUARD_BAR:
+                self._fall_back(worst, batch_index=None)
+                break
+
+    def _process_group(self):
+        """the harness's process group (test.py creates a gloo group under torch.distributed.run; the launcher's environment is enough for env://)"""
+        import torch.distributed as dist
+        if not dist.is_available():
+            raise RuntimeError('--precision half on %d ranks needs torch.distributed for the ranks to agree on the guard' % getattr(self.opt, 'dist_world', 1))
+        if not dist.is_initialized():
+            import os
+            os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+            dist.init_process_group('gloo', rank=getattr(self.opt, 'dist_rank', 0), world_size=getattr(self.opt, 'dist_world', 1))
+        return dist
+
+    def _all_reduce_max(self, value):
+        dist = self._process_group()
+        dev = self.device if dist.get_backend() == 'nccl' else 'cpu'
+        t = torch.tensor([value if value == value else float('inf')], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t.item())
+
+    def _agree_on_worst(self, worst):
+        """one process per GPU (test.py under torch.distributed.run): every rank looks at its OWN batch -- the ranks agree on the worst of them, so a
+        result set is never silently mixed-precision.  An all-reduce on the harness's process group (round 4 fell back to files in the results
+        directory: stale files of an earlier run could make ranks decide differently -- ADVICE r04)."""
+        if getattr(self.opt, 'dist_world', 1) <= 1:
+            return worst
+        return self._all_reduce_max(worst)
+
+    def _record_precision(self, chosen, worst, batch_index=0):
         import os
         if getattr(self.opt, 'dist_rank', 0) == 0:
             try:
                 with open(os.path.join(self._guard_dir(), 'precision.txt'), 'w') as f:
-                    f.write('precision: %s\nhalf_guard_max_abs: %r\nbar: %g\n' % (chosen, worst, self.HALF_GUARD_BAR))
+                    f.write('precision: %s\nhalf_guard_max_abs: %r\nbar: %g\nchecked_batches: %s\n' % (
+                        chosen, worst, self.HALF_GUARD_BAR, ' '.join('%d:%.3g' % (b if b is not None else -1, w) for b, w in self.half_guard_log)))
+                    if chosen == 'single' and batch_index:
+                        f.write('fell_back_at_batch: %s\nredone_in_fp32: %d images\n' % (batch_index, len(self.redo_paths)))
             except OSError as e:          # a read-only results directory must not cost the run
                 print('note: could not record the chosen precision (%s)' % e)
 
-    def forward(self):
+    def note_unchecked(self, paths):
+        """the pipelined driver ran this batch in fp16 without passing through forward(): it counts as unchecked until the next check passes"""
         if getattr(self, '_half_guard', False):
-            self._half_guard = False
+            self._since_check.append(list(paths))
+
+    def _fall_back(self, worst, batch_index):
+        print('warning: --precision half differs from the fp32 path by %.3g max-abs on batch %s (bar %.0e): this checkpoint is not fp16-safe on '
+              'these images, continuing with --precision single%s' % (worst, 'of another rank' if batch_index is None else batch_index, self.HALF_GUARD_BAR,
+                                                                      '; %d images since the last passed check will be redone in fp32' % sum(len(p) for p in self._since_check)
+                                                                      if self._since_check else ''))
+        self._half_guard = False
+        self.redo_paths += [p for batch in self._since_check for p in batch]
+        self._since_check = []
+        self.netG.set_compute_dtype('fp32')
+        self._record_precision('single', worst, batch_index if batch_index is not None else -1)
+
+    def _settle_check(self, j, worst):
+        """one check of batch j: the ranks agree on the worst difference; passed -> the batches since the previous check are cleared, failed -> fp32 from here on"""
+        worst = self._agree_on_worst(worst)
+        self._checks_done += 1
+        self.half_guard_max_abs = worst
+        self.half_guard_log.append((j, worst))
+        if not worst <= self.HALF_GUARD_BAR:
+            self._fall_back(worst, j)
+            return False
+        self._since_check = []
+        self._record_precision('half', worst, j)
+        return True
+
+    def forward(self):
+        j = self._batch_index
+        self._batch_index = j + 1
+        if self.guard_due(j):
             self.netG.output_u8 = False                   # the guard compares the float outputs
             self.netG.set_compute_dtype('fp32')
             ref = [t.clone() for t in self.netG(self._net_in)]
             self.netG.set_compute_dtype('fp16')
             out = self.netG(self._net_in)
             worst = max(float((a - b).abs().max()) if bool(torch.isfinite(a).all()) else float('inf') for a, b in zip(out, ref))
-            # one process per GPU (test.py under torch.distributed.run): every rank looks at its OWN first image -- the ranks agree on the worst
-            # of them, so a result set is never silently mixed-precision.  Without a process group (the launcher is used for its environment
-            # only: every rank writes its own files) the decision goes through a file in the results directory.
-            worst = self._agree_on_worst(worst)
-            self.half_guard_max_abs = worst
-            self._record_precision('single' if not worst <= self.HALF_GUARD_BAR else 'half', worst)
-            if not worst <= self.HALF_GUARD_BAR:
-                print('warning: --precision half differs from the fp32 path by %.3g max-abs on the first batch (bar %.0e): this checkpoint is not '
-                      'fp16-safe, continuing with --precision single' % (worst, self.HALF_GUARD_BAR))
-                self.netG.set_compute_dtype('fp32')
+            if not self._settle_check(j, worst):
                 [self.fake_R, self.fake_S, self.fake_A] = ref
                 return
+        elif getattr(self, '_half_guard', False):
+            self._since_check.append(list(self.image_paths))
         if getattr(self, '_u8_out', False):
             self.netG.output_u8 = True
         [self.fake_R, self.fake_S, self.fake_A] = self.netG(self._net_in)

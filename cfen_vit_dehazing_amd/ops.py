@@ -19,9 +19,18 @@ def _cuda(*ts):
             raise ValueError("HIP operators need contiguous CUDA tensors")
 
 
+_TUNED = {}
+
+
 def tune(key, value):
     """process-wide kernel-variant knob (cfen_tune); for benchmarks"""
     check(_lib.load().cfen_tune(key.encode(), int(value)), "tune")
+    _TUNED[key] = int(value)
+
+
+def tuned(key, default=None):
+    """what this process last set a knob to through tune() (None / `default` = never touched: the library's own default is in force)"""
+    return _TUNED.get(key, default)
 
 
 def gemm_nt(x, w, bias=None, residual=None, pos=None, relu=False, out=None):

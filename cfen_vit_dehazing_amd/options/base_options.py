@@ -61,6 +61,15 @@ class BaseOptions():
         p.add_argument('--no_half_guard', action='store_true',
                        help='(extension) with --precision half the first batch also runs in fp32 once and the model falls back to single when the '
                             'fp16 outputs differ by more than 3e-2 (range safety of a real checkpoint); this flag skips that check')
+        p.add_argument('--half_guard_every', type=int, default=32,
+                       help='(extension) with --precision half, repeat that fp32 comparison on every N-th batch of the run (0 = first batch only); all '
+                            'ranks of a sharded run agree on the outcome, and the batches since the last passed check are redone in fp32 after a failure')
+        p.add_argument('--in_flight', type=int, default=1,
+                       help='(extension) batches kept in flight by test.py: 1 = the reference loop (set_input / test / save, one at a time); K > 1 = '
+                            'the pipelined driver (cfen_vit_dehazing_amd/pipeline.py): K launch-plan replicas replayed from hipGraphs on K streams, pinned '
+                            'asynchronous copies both ways, PNG decode in the DataLoader workers (--nThreads) and encode in --writers threads; the files '
+                            'written are byte-identical to the sequential loop')
+        p.add_argument('--writers', type=int, default=8, help='(extension) PNG encoder threads of the pipelined driver')
         p.add_argument('--u8_input', action='store_true',
                        help='(extension) the dataset hands over uint8 HWC images and ToTensor + Normalize(0.5, 0.5) run on the device '
                             'inside the generator launch plan (12x fewer bytes over PCIe); results are identical')
@@ -97,6 +106,13 @@ class BaseOptions():
             if opt.gpu_ids != [local]:
                 print('[rank %d] torch.distributed.run: --gpu_ids %s overridden by LOCAL_RANK -> GPU %d' % (opt.dist_rank, opt.gpu_ids, local))
             opt.gpu_ids = [local]
+        if opt.in_flight < 1:
+            raise ValueError('--in_flight must be >= 1')
+        if opt.in_flight > 1:
+            # the pipelined driver keeps K forwards on K streams; the HIP runtime deals a process's streams onto GPU_MAX_HW_QUEUES hardware queues
+            # (default 4) and two busy streams on one queue run one behind the other (4 in flight: 2.51 ms / step on 4 queues, 2.10 on 8,
+            # profiles/r04_ab_hw_queues.txt).  The harness, not the user, sets it -- here, before the first HIP call of the process (set_device below)
+            os.environ.setdefault('GPU_MAX_HW_QUEUES', '8')
         if len(opt.gpu_ids) > 0 and torch.cuda.is_available():
             torch.cuda.set_device(opt.gpu_ids[0])
         args = vars(opt)

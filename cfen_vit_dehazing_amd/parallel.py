@@ -59,14 +59,22 @@ def merge_gathered(gathered, world, batch, n):
 
 
 class OutputGatherer:
-    """Double-buffered asynchronous all-gather of equally sized per-rank slabs.
+    """Asynchronous all-gather of equally sized per-rank slabs, ONE SLOT PER OUTPUT SLAB of the caller's rotation.
+
+    A slot owns what the collective of one slab needs: the fence event (recorded when the communication stream has finished READING the slab), the
+    fp16 stage buffer and the gathered buffer.  `slots` is the number of slabs the compute lanes rotate over (bench.py: max(2, forwards in flight)), so
+    step i uses slot i % slots and `before_write(slot)` waits exactly for the gather of step i - slots -- the last reader of that slab -- and for nothing
+    else: with three slabs three forwards really are in flight.  (Round 4 kept two slots for three slabs; forward i then waited for gather i - 2 and at most
+    two forwards overlapped per rank: ADVICE r04.)
 
     `dtype` is the wire type.  The kernels write fp32 slabs; with the fp16 compute path the slab is converted to fp16 on
     the communication stream before it is gathered (outputs are tanh values in (-1, 1): the 2^-11 rounding is below the
     fp16 path's own error), which halves the xGMI traffic -- 29 MB instead of 59 MB per rank at 8 images of 512x512."""
 
-    def __init__(self, world, numel, device, dtype=torch.float32):
-        self.world, self.numel, self.dtype = world, numel, dtype
+    def __init__(self, world, numel, device, dtype=torch.float32, slots=2):
+        if slots < 1:
+            raise ValueError("OutputGatherer needs at least one slot")
+        self.world, self.numel, self.dtype, self.slots = world, numel, dtype, slots
         self.cuda = torch.device(device).type == "cuda"
         if world > 1 and dist.is_initialized():
             # every rank must bring the same slab size: all_gather_into_tensor with unequal inputs does not fail, it hangs
@@ -75,13 +83,14 @@ class OutputGatherer:
             if int(lohi[0]) != numel or int(-lohi[1]) != numel:
                 raise ValueError("OutputGatherer: ranks hold slabs of %d .. %d elements; shard the global batch with parallel.even_shard"
                                  % (int(-lohi[1]), int(lohi[0])))
-        self.bufs = [torch.empty(world * numel, dtype=dtype, device=device) for _ in range(2)]
-        self.stage = [torch.empty(numel, dtype=dtype, device=device) for _ in range(2)] if dtype != torch.float32 else None
+        self.bufs = [torch.empty(world * numel, dtype=dtype, device=device) for _ in range(slots)]
+        self.stage = [torch.empty(numel, dtype=dtype, device=device) for _ in range(slots)] if dtype != torch.float32 else None
         self.stream = torch.cuda.Stream(device) if self.cuda else None
-        self.events = [None, None]
+        self.events = [None] * slots          # slot -> "the communication stream no longer reads the slab handed to launch(slot)"
+        self.done = [None] * slots            # slot -> "bufs[slot] holds the gathered result"
 
     def before_write(self, slot):
-        """Call before the compute stream overwrites the slab last handed to launch(slot)."""
+        """Call on the compute stream before it overwrites the slab last handed to launch(slot)."""
         if self.cuda and self.events[slot] is not None:
             torch.cuda.current_stream().wait_event(self.events[slot])
 
@@ -106,7 +115,10 @@ class OutputGatherer:
             work.wait()                                   # side stream now orders after the collective
             if not convert:
                 ev.record(self.stream)
+            fin = torch.cuda.Event()
+            fin.record(self.stream)
         self.events[slot] = ev
+        self.done[slot] = fin
         return self.bufs[slot]
 
     def wait_all(self):

@@ -21,27 +21,71 @@ from cfen_vit_dehazing_amd.options.test_options import TestOptions
 from cfen_vit_dehazing_amd.util import html
 from cfen_vit_dehazing_amd.util.visualizer import save_images
 
+def _rerun_in_fp32(opt, model, image_dir, paths):
+    """images whose files came from fp16 forwards later found unsafe (--precision half, a periodic check failed): the model has switched to fp32, run them again"""
+    import torch.utils.data
+    from cfen_vit_dehazing_amd import data as cdata
+    ds = cdata.DECVITDATA()
+    ds.initialize(opt)
+    ds.B_paths, ds.B_size = list(paths), len(paths)
+    for data in torch.utils.data.DataLoader(ds, batch_size=opt.batchSize, shuffle=False, num_workers=0):
+        model.set_input(data)
+        model.test(opt)
+        visuals = model.get_current_visuals()
+        if opt.out_all:
+            for item in [k for k in visuals if 'fake_A' not in k]:
+                del visuals[item]
+        save_images(image_dir, visuals, model.get_image_paths(), aspect_ratio=opt.aspect_ratio, width=opt.display_winsize)
+
+
 if __name__ == '__main__':
-    opt = TestOptions().parse()
+    opt = TestOptions().parse()   # --in_flight > 1 also exports GPU_MAX_HW_QUEUES=8 there, before the first HIP call
     opt.serial_batches = True   # no shuffle
     opt.no_flip = True          # no flip
     opt.display_id = -1         # no visdom display
+    if opt.dist_world > 1:
+        # one process per GPU under torch.distributed.run: every rank writes its own files, so the data path needs no collective; the ranks only
+        # agree on the --precision half checks (models/model_iid_dehazing.py), over a CPU (gloo) group
+        import torch.distributed as dist
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        dist.init_process_group('gloo', rank=opt.dist_rank, world_size=opt.dist_world)
     data_loader = CreateDataLoader(opt)
     dataset = data_loader.load_data()
     model = create_model(opt)
     model.setup(opt)
     web_dir = os.path.join(opt.results_dir, opt.name, '%s_%s' % (opt.phase, opt.which_epoch))
     webpage = html.HTML(web_dir, 'Experiment = %s, Phase = %s, Epoch = %s' % (opt.name, opt.phase, opt.which_epoch))
-    for i, data in enumerate(dataset):
-        if i >= opt.how_many:
-            break
-        model.set_input(data)
-        model.test(opt)
-        visuals = model.get_current_visuals()
-        if opt.out_all:                       # keep only the dehazed image
-            for item in [k for k in visuals if 'fake_A' not in k]:
-                del visuals[item]
-        img_path = model.get_image_paths()
-        if i % 5 == 0:
-            logging.info('processing (%04d)-th image...' % (i * opt.batchSize))
-        save_images(webpage.get_image_dir(), visuals, img_path, aspect_ratio=opt.aspect_ratio, width=opt.display_winsize)
+    n_batches = min(opt.how_many, -(-min(len(data_loader), len(data_loader.dataset)) // opt.batchSize))
+    model.plan_half_guard(n_batches)
+    if opt.in_flight > 1:
+        # the pipelined driver: --in_flight batches on as many launch-plan replicas / streams / hardware queues, hipGraph replay, pinned asynchronous
+        # copies, PNG encode in --writers threads -- the loop bench.py's throughput presupposes, for real files; byte-identical files
+        from cfen_vit_dehazing_amd.pipeline import PipelinedRunner
+        runner = PipelinedRunner(model, opt, webpage.get_image_dir())
+        print('pipelined driver: %d batches in flight, plan %s' % (opt.in_flight, model.netG.plan_info()))
+        stats = runner.run(dataset, opt.how_many)
+        runner.close()
+        print('pipelined driver: %d images in %.2f s = %.1f images/s file to file (%d batches replayed from graphs, %d through the sequential path)'
+              % (stats['images'], stats['seconds'], stats['images'] / max(stats['seconds'], 1e-9), stats['graph_batches'], stats['sequential_batches']))
+    else:
+        for i, data in enumerate(dataset):
+            if i >= opt.how_many:
+                break
+            model.set_input(data)
+            model.test(opt)
+            visuals = model.get_current_visuals()
+            if opt.out_all:                       # keep only the dehazed image
+                for item in [k for k in visuals if 'fake_A' not in k]:
+                    del visuals[item]
+            img_path = model.get_image_paths()
+            if i % 5 == 0:
+                logging.info('processing (%04d)-th image...' % (i * opt.batchSize))
+            save_images(webpage.get_image_dir(), visuals, img_path, aspect_ratio=opt.aspect_ratio, width=opt.display_winsize)
+    model.finish_half_guard()
+    if model.redo_paths:
+        print('redoing %d images in fp32 (a --precision half check failed after they were written)' % len(model.redo_paths))
+        _rerun_in_fp32(opt, model, webpage.get_image_dir(), model.redo_paths)
+    if opt.dist_world > 1:
+        import torch.distributed as dist
+        dist.barrier()
+        dist.destroy_process_group()

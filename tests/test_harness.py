@@ -144,3 +144,115 @@ def test_model_G_selects_the_generator_variant(tmp_path, model_g, variant, nkeys
     assert list(back.keys()) == list(sd.keys())
     for k in sd:
         assert torch.equal(back[k], sd[k]), k
+
+
+# ---- round 5: the --precision half checks (first batch + every N-th), the pipelined driver's options ------------------------------------------
+
+class _FakeNet:
+    """stands in for hipnet.dec_ipt where only the guard's bookkeeping is under test (no GPU)"""
+    compute_dtype = torch.float16
+    output_u8 = False
+
+    def set_compute_dtype(self, d):
+        self.compute_dtype = {"fp32": torch.float32, "fp16": torch.float16}[d]
+
+
+def _guard_model(tmp_path, every, world=1, rank=0):
+    from types import SimpleNamespace
+    from cfen_vit_dehazing_amd.models.model_iid_dehazing import DECHLGVIT
+    m = DECHLGVIT.__new__(DECHLGVIT)
+    m.opt = SimpleNamespace(precision='half', no_half_guard=False, half_guard_every=every, dist_world=world, dist_rank=rank, isTrain=False,
+                            phase='test', results_dir=str(tmp_path / 'res'), name='guard_unit', which_epoch='latest')
+    m.device = torch.device('cpu')
+    m.netG = _FakeNet()
+    m._half_guard = True
+    m._guard_every = every
+    m._batch_index, m._since_check, m.redo_paths, m.half_guard_log, m._checks_planned, m._checks_done = 0, [], [], [], None, 0
+    return m
+
+
+def test_half_guard_schedule_first_batch_and_every_nth(tmp_path):
+    m = _guard_model(tmp_path, every=4)
+    assert [j for j in range(13) if m.guard_due(j)] == [0, 4, 8, 12]
+    assert [m.checks_for(n) for n in (0, 1, 4, 5, 8, 9)] == [0, 1, 1, 2, 2, 3]
+    m0 = _guard_model(tmp_path, every=0)
+    assert [j for j in range(9) if m0.guard_due(j)] == [0] and m0.checks_for(100) == 1
+    m.plan_half_guard(9)
+    assert m._checks_planned == 3
+    # batches noted as unchecked become redo work when a later check fails, and the model leaves fp16
+    m.note_unchecked(['a.png', 'b.png'])
+    m.note_unchecked(['c.png'])
+    m._fall_back(0.4, batch_index=4)
+    assert m.redo_paths == ['a.png', 'b.png', 'c.png'] and m.netG.compute_dtype == torch.float32 and not m.guard_due(8)
+    txt = open(tmp_path / 'res' / 'guard_unit' / 'test_latest' / 'precision.txt').read()
+    assert 'precision: single' in txt and 'fell_back_at_batch: 4' in txt
+
+
+def _guard_rank(rank, world, port, tmp, q):
+    import torch.distributed as dist
+    from pathlib import Path
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    m = _guard_model(Path(tmp), every=2, world=world, rank=rank)
+    # without a plan only the first check is common to all ranks
+    assert [j for j in range(6) if m.guard_due(j)] == [0]
+    nb = 5 if rank == 0 else 3                      # slices differ: rank 0 checks batches 0, 2, 4; rank 1 batches 0, 2
+    m.plan_half_guard(nb)
+    assert m._checks_planned == 3
+    worsts = []
+    for j in range(nb):
+        if m.guard_due(j):
+            mine = 1e-3 if not (rank == 0 and j == 4) else 0.5      # rank 0's LAST check fails, after rank 1 has finished its slice
+            m._settle_check(j, mine)
+            worsts.append(m.half_guard_max_abs)
+        else:
+            m.note_unchecked(['r%d_b%d.png' % (rank, j)])
+    m.finish_half_guard()                            # rank 1 joins the third check here and learns of the failure
+    q.put((rank, worsts, m.netG.compute_dtype == torch.float32, sorted(m.redo_paths)))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_half_guard_ranks_with_unequal_slices_agree_on_every_check(tmp_path):
+    """world-size-2 gloo run of the guard's collectives (what test.py does under torch.distributed.run): the ranks pair up their checks although one
+    holds more batches, and a failure on one rank's last check moves BOTH to fp32 and marks each rank's unchecked batches for redoing"""
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29500 + (os.getpid() + 333) % 2000
+    procs = [ctx.Process(target=_guard_rank, args=(r, 2, port, str(tmp_path), q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    res = dict((r, rest) for r, *rest in (q.get(timeout=5) for _ in range(2)))
+    assert res[0][0] == [1e-3, 1e-3, 0.5] and res[1][0] == [1e-3, 1e-3]
+    assert res[0][1] and res[1][1]                                  # both ranks ended in fp32
+    assert res[0][2] == ['r0_b3.png'] and res[1][2] == []           # rank 1's batch 1 was covered by its passed check at batch 2
+
+
+def test_in_flight_option_sets_the_hardware_queues_before_the_first_hip_call(tmp_path, monkeypatch):
+    monkeypatch.delenv("GPU_MAX_HW_QUEUES", raising=False)
+    opt = parse(tmp_path, [])
+    assert opt.in_flight == 1 and "GPU_MAX_HW_QUEUES" not in os.environ and opt.half_guard_every == 32
+    opt = parse(tmp_path, ['--in_flight', '4', '--batchSize', '8', '--writers', '3'])
+    assert (opt.in_flight, opt.writers, os.environ.get("GPU_MAX_HW_QUEUES")) == (4, 3, "8")
+    monkeypatch.setenv("GPU_MAX_HW_QUEUES", "6")                    # an explicit choice of the user is kept
+    parse(tmp_path, ['--in_flight', '2'])
+    assert os.environ["GPU_MAX_HW_QUEUES"] == "6"
+    with pytest.raises(ValueError):
+        parse(tmp_path, ['--in_flight', '0'])
+
+
+def test_plan_info_says_which_launch_plan_and_why(monkeypatch):
+    monkeypatch.delenv("GPU_MAX_HW_QUEUES", raising=False)
+    monkeypatch.delenv("CFEN_SERIAL", raising=False)
+    net = dec_ipt(NetConfig(24, 4, patch_size=8, load_size=64))
+    assert net.plan_info()["lanes_per_forward"] == 2 and "default" in net.plan_info()["why"]
+    net.serial_plan = True
+    assert net.plan_info()["lanes_per_forward"] == 1 and "caller" in net.plan_info()["why"]
+    monkeypatch.setenv("GPU_MAX_HW_QUEUES", "8")
+    net8 = dec_ipt(NetConfig(24, 4, patch_size=8, load_size=64))
+    assert net8.plan_info()["lanes_per_forward"] == 1 and "GPU_MAX_HW_QUEUES" in net8.plan_info()["why"]

@@ -17,6 +17,10 @@ from helpers import load_net_fixture, check_outputs, check_stages, weight_mode
 
 pytestmark = pytest.mark.gpu
 
+# max-abs bar of the fp16 path on outputs in (-1, 1) with the seeded weights: measured 8.7e-4 .. 9.9e-4 at 512 x 512 in every record of rounds 1-4; the bar sits
+# 5x above that (it was 3e-2: a kernel regression costing a factor 10 in accuracy passed every gate -- VERDICT r04)
+FP16_BAR = 5e-3
+
 
 _SD_CACHE = {}
 
@@ -110,14 +114,14 @@ def test_fp16_psnr_ssim_against_oracle(name):
     for dp, ds, p, mx in _psnr_ssim_delta(ref, got, x):
         print("%s fp16: dPSNR %.4f dB, dSSIM %.2e, PSNR(fp16 vs ref) %.1f dB, max-abs %.2e" % (name, dp, ds, p, mx))
         assert dp <= 0.01 and ds <= 1e-4
-        assert p >= 50.0 and mx <= 3e-2
+        assert p >= 50.0 and mx <= FP16_BAR
 
 
 def test_fp16_full512_against_reference_vectors():
     cfg, batch, z = load_net_fixture("full512_nf24_hdr4")
     net = make_net(cfg, "fp16")
     outs = net(synthetic_input(batch, cfg).to("cuda:0"))
-    worst = check_outputs(z, outs, 3e-2)
+    worst = check_outputs(z, outs, FP16_BAR)
     print("full512 fp16 outputs max-abs vs reference %.2e" % worst)
     for nm, o in zip(("xr", "xs", "xd"), outs):
         stat = z["stat/" + nm]
@@ -286,19 +290,33 @@ def test_fp16_benchmark_configs_graph_replay_vs_reference_vectors(name, batch):
     torch.cuda.synchronize()
     for a, b in zip(eager, outs):
         assert torch.equal(a, b)                                   # replay is bitwise the eager plan
-    worst = _fp16_vs_fixture(z, outs, x, 3e-2)
+    worst = _fp16_vs_fixture(z, outs, x, FP16_BAR)
     print("%s B=%d fp16 graph: image 0 max-abs vs reference vectors %.2e" % (name, batch, worst))
     if name == "full512_nf24_hdr4":
-        # images 0 AND 1 of the batch against the reference's own two-image forward (fixture full512b2: seeds 0 and 1)
-        _, b2, z2 = load_net_fixture("full512b2_nf24_hdr4")
-        assert b2 == 2
-        w2 = check_outputs(z2, [o[0:2] for o in outs], 3e-2)
-        print("   images 0..1 vs the reference's batch-2 vectors: max-abs %.2e" % w2)
+        # EVERY image of the benchmarked batch against the reference's own batch-8 forward (fixture full512b8: seeds 0 .. 7): max-abs on the crop and
+        # strided samples of all eight, whole-image PSNR / SSIM of all 24 output planes against the input within 0.01 dB / 1e-4 of the reference's,
+        # and the 256 x 256 centre crop of image 0
+        _, b8, z8 = load_net_fixture("full512b8_nf24_hdr4")
+        assert b8 == batch == 8
+        w8 = check_outputs(z8, outs, FP16_BAR)
+        xc = x.float().cpu()
+        worst_dp = worst_ds = 0.0
+        for nm, o in zip(("xr", "xs", "xd"), outs):
+            oc = o.float().cpu()
+            for b in range(batch):
+                t = xc[b:b + 1, :oc.shape[1]]
+                worst_dp = max(worst_dp, abs(cfen_oracle.psnr(oc[b:b + 1], t) - float(z8["full_psnr/" + nm][b])))
+                worst_ds = max(worst_ds, abs(cfen_oracle.ssim(oc[b:b + 1], t) - float(z8["full_ssim/" + nm][b])))
+            n = oc.shape[-1]
+            d = float((oc[0:1, :, n // 2 - 128:n // 2 + 128, n // 2 - 128:n // 2 + 128] - torch.from_numpy(z8["crop256/" + nm])).abs().max())
+            assert d <= FP16_BAR, "%s: 256 x 256 crop of image 0 differs by %.3e" % (nm, d)
+        print("   images 0..7 vs the reference's batch-8 vectors: max-abs %.2e; whole-image dPSNR %.4f dB, dSSIM %.2e" % (w8, worst_dp, worst_ds))
+        assert worst_dp <= 0.01 and worst_ds <= 1e-4
     for i in sorted({1, batch // 2, batch - 1}):
         one = net(x[i:i + 1].clone())
         for a, b in zip(outs, one):
             d = float((a[i:i + 1] - b).abs().max())
-            assert d <= 1e-2, "image %d differs from its batch-1 forward by %.3e" % (i, d)
+            assert d <= FP16_BAR, "image %d differs from its batch-1 forward by %.3e" % (i, d)
     del net
     torch.cuda.empty_cache()
 
@@ -568,23 +586,33 @@ def test_three_forwards_in_flight_on_replica_plans_match_single_forwards_bitwise
     try:
         net = make_net(cfg, "fp16")
         assert bool(net.gvit_chain) == (splitk == 2)
+        if splitk == 2:
+            # the chains' grid barriers need every team of every forward in flight resident at once: without the cap a second replica is refused
+            net.replica = 1
+            with pytest.raises(Exception, match="gvit.max_concurrent"):
+                net(synthetic_input(8, cfg).to("cuda:0"))
+            net.replica = 0
+            ops.tune("gvit.max_concurrent", 3)
         _three_in_flight(net, cfg, split_slab)
         if splitk == 2:
             assert net.chain_errors() == [0, 0, 0]
     finally:
         os.environ.pop("CFEN_GVIT_CHAIN", None)
         ops.tune("gemm.splitk", 0)
+        ops.tune("gvit.max_concurrent", 1)
 
 
 def _three_in_flight(net, cfg, split_slab):
     n, B = cfg.image_size, 8
     xs = [synthetic_input(B, cfg, seed0=8 * k).to("cuda:0") for k in range(3)]
     two_lane = [[o.clone() for o in net(x)] for x in xs]             # two-lane plan, one forward at a time
+    assert net.plan_info()["lanes_per_forward"] == 2
     net.serial_plan = True
+    assert net.plan_info()["lanes_per_forward"] == 1 and "caller" in net.plan_info()["why"]
     want = [[o.clone() for o in net(x)] for x in xs]                 # the serial plan, eagerly, one forward at a time
-    # (the serial plan runs GViT level 1 on the stream kernels: the same math in another summation order -- fp16-rounding close to the two-lane plan)
+    # the lane plan changes when kernels run, not which kernels run ("net.gvit_stream" = 2 since round 5): bit for bit the two-lane results
     for a, b in zip(sum(want, []), sum(two_lane, [])):
-        assert float((a - b).abs().max()) <= 1e-2
+        assert torch.equal(a, b)
     slabs = [torch.empty(7 * B * n * n, dtype=torch.float32, device="cuda:0") for _ in range(3)]
     gids = []
     for k in range(3):
@@ -606,38 +634,40 @@ def _three_in_flight(net, cfg, split_slab):
 
 
 def test_two_lane_plan_equals_serial_plan_bitwise_full_size():
-    """GViT beside LViT on a second lane must not change a single bit (512x512, B=2, eager and graph) -- with the same kernels on both plans
-    ("net.gvit_stream" = 0: by default the serial plan runs GViT level 1 on the stream kernels, same math in another summation order, which is
-    checked to fp16 rounding below and bitwise against itself by test_three_forwards_in_flight_...)"""
+    """GViT beside LViT on a second lane must not change a single bit (512x512, B=2, eager, graph and PROFILED forwards), with GViT level 1 on the
+    launch-per-GEMM chain ("net.gvit_stream" = 0) and on the stream kernels (2, the default on every plan since round 5); the two kernel families
+    are the same math in another summation order and agree to fp16 rounding"""
     from cfen_vit_dehazing_amd import ops
     cfg = NetConfig(24, 4, patch_size=32, load_size=256)
     x = synthetic_input(2, cfg).to("cuda:0")
+    res = {}
     try:
-        ops.tune("net.gvit_stream", 0)
-        net = make_net(cfg, "fp16")
-        two = [o.clone() for o in net(x)]
-        gid, gouts = net.capture(x)
-        net.replay(gid)
-        torch.cuda.synchronize()
-        net.serial_plan = True
-        one = [o.clone() for o in net(x)]
-        for a, b, c in zip(two, one, gouts):
-            assert torch.equal(a, b) and torch.equal(a, c)
+        for mode in (0, 2):
+            ops.tune("net.gvit_stream", mode)
+            ops.tune("net.keep_stages", 1)
+            net = make_net(cfg, "fp16")
+            net.serial_plan = False
+            two = [o.clone() for o in net(x)]
+            gid, gouts = net.capture(x)
+            net.replay(gid)
+            torch.cuda.synchronize()
+            prof = net.profile(x)                                  # the profiled forward replays the same launches serially: same kernels, same bits
+            names = [l[4] for l in prof["launches"] if l[0].startswith("globalvit_encoder_01")]
+            assert any("k_mlp3" in k for k in names) == (mode == 2), names
+            net.serial_plan = True
+            one = [o.clone() for o in net(x)]
+            st = net.stage("globalvit_encoder_01").clone()
+            for a, b, c in zip(two, one, gouts):
+                assert torch.equal(a, b) and torch.equal(a, c)
+            res[mode] = (two, st)
+            del net
     finally:
-        ops.tune("net.gvit_stream", 1)
-    try:
-        ops.tune("net.keep_stages", 1)
-        net2 = make_net(cfg, "fp16")
-        net2.serial_plan = True
-        streamed = [o.clone() for o in net2(x)]
-        st = net2.stage("globalvit_encoder_01").clone()
-        net2.serial_plan = False
-        net2(x)
-        assert float((st - net2.stage("globalvit_encoder_01")).abs().max()) <= 3e-2 * max(1.0, float(st.abs().max()))
-    finally:
+        ops.tune("net.gvit_stream", 2)
         ops.tune("net.keep_stages", 0)
-    for a, b in zip(streamed, two):
-        assert float((a - b).abs().max()) <= 1e-2
+    st0, st2 = res[0][1], res[2][1]
+    assert float((st0 - st2).abs().max()) <= 3e-2 * max(1.0, float(st0.abs().max()))
+    for a, b in zip(res[0][0], res[2][0]):
+        assert float((a - b).abs().max()) <= FP16_BAR
 
 
 def test_repeated_forwards_are_bit_reproducible_at_benchmark_size():
@@ -785,7 +815,7 @@ def test_sibling_variants_fp32_all_stages_and_fp16(name):
     check_stages(z, st, 3e-4, rel_sum=2e-4)
     wo = check_outputs(z, outs, 1e-4)
     net16 = make_net(cfg, "fp16")
-    w16 = check_outputs(z, net16(x), 3e-2)
+    w16 = check_outputs(z, net16(x), FP16_BAR)
     gid, gouts = net16.capture(x)
     net16.replay(gid)
     torch.cuda.synchronize()
@@ -830,3 +860,106 @@ def test_tile_major_gvit_weights_equal_row_major_to_rounding():
         outs[wt] = [o.clone() for o in net.to("cuda:0")(x)]
         check_outputs(z, outs[wt], 1e-4)
     assert max(float((a - b).abs().max()) for a, b in zip(outs[True], outs[False])) <= 2e-5
+
+
+# ---- round 5: the pipelined inference driver (test.py --in_flight K) and the periodic --precision half checks -----------------------------------
+
+def _cli_fixture(tmp_path, load_size, nimg, name="iid_hlgvit_crs_gd4_cfs_v3_pipe"):
+    import os
+    from PIL import Image
+    cfg = NetConfig(24, 4, patch_size=load_size // 8, load_size=load_size)
+    os.makedirs(tmp_path / "ckpt" / name)
+    torch.save(cached_state_dict(cfg), tmp_path / "ckpt" / name / "32_net_G.pth")
+    os.makedirs(tmp_path / "data" / "hazy")
+    rs = np.random.RandomState(5)
+    n = 2 * load_size
+    yy, xx = np.mgrid[0:n, 0:n].astype(np.float32) / n
+    for i in range(nimg):
+        # smooth colour fields + a little noise: compressible like a photograph (pure noise makes the PNG encoder the whole test)
+        base = np.stack([np.sin(6.0 * (xx * (i % 5 + 1) + yy)) * 90 + 128, np.cos(5.0 * (yy * (i % 3 + 1) - xx)) * 80 + 120, (xx + yy) * 100 + 20 + 4 * i], -1)
+        a = np.clip(base + rs.randn(n, n, 3) * 3.0, 0, 255).astype(np.uint8)
+        Image.fromarray(a).save(tmp_path / "data" / "hazy" / ("syn_%04d.png" % (i + 1)))
+    return cfg, name
+
+
+def _run_cli(tmp_path, name, load_size, res, extra):
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cmd = [sys.executable, os.path.join(root, "test.py"), "--dataroot", str(tmp_path / "data"), "--name", name, "--n_feats", "24",
+           "--hidden_dim_ratio", "4", "--sb", "--which_epoch", "32", "--loadSize", str(load_size), "--patch_size", str(load_size // 8),
+           "--checkpoints_dir", str(tmp_path / "ckpt"), "--results_dir", str(tmp_path / res)] + list(extra)
+    env = dict(os.environ)
+    env.pop("GPU_MAX_HW_QUEUES", None)            # the harness chooses it
+    out = subprocess.run(cmd, cwd=str(tmp_path), env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    assert out.returncode == 0, out.stdout[-3000:]
+    return out.stdout, tmp_path / res / name / "test_32" / "images"
+
+
+@pytest.mark.parametrize("load_size,nimg,flags", [
+    (256, 26, ["--precision", "half", "--u8_input", "--out_all", "--batchSize", "4", "--half_guard_every", "4", "--nThreads", "2"]),   # the benchmarked geometry: uint8 in,
+    # tensor2im bytes out of the tails' last launch, a ragged last batch, --precision half checks on batches 0 and 4
+    (64, 24, ["--precision", "single", "--batchSize", "5"]),                                                                           # fp32 plans, float input, all four visuals
+])
+def test_pipelined_cli_writes_the_same_pngs(tmp_path, load_size, nimg, flags):
+    """`test.py --in_flight 3` (replica launch plans replayed from hipGraphs on three streams, pinned asynchronous copies, writer threads) against the
+    sequential loop of the same command line: every PNG byte for byte, on >= 24 images"""
+    import os
+    cfg, name = _cli_fixture(tmp_path, load_size, nimg)
+    seq_log, seq_dir = _run_cli(tmp_path, name, load_size, "res_seq", flags)
+    pipe_log, pipe_dir = _run_cli(tmp_path, name, load_size, "res_pipe", flags + ["--in_flight", "3", "--writers", "4"])
+    assert "pipelined driver" in pipe_log and "'lanes_per_forward': 1" in pipe_log, pipe_log[-2000:]
+    labels = ["fake_A"] if "--out_all" in flags else ["fake_A", "fake_R", "fake_S", "real_B"]
+    want = sorted("syn_%04d_%s.png" % (i + 1, lab) for i in range(nimg) for lab in labels)
+    assert sorted(os.listdir(seq_dir)) == want and sorted(os.listdir(pipe_dir)) == want
+    for f in want:
+        assert open(seq_dir / f, "rb").read() == open(pipe_dir / f, "rb").read(), f
+    if "half" in flags:
+        assert "precision: half" in open(tmp_path / "res_pipe" / name / "test_32" / "precision.txt").read()
+        assert "checked_batches: 0:" in open(tmp_path / "res_pipe" / name / "test_32" / "precision.txt").read()
+
+
+def test_half_guard_catches_an_overflow_that_starts_on_a_later_batch(tmp_path):
+    """--precision half with --half_guard_every 3: batches 0 .. 2 are fine, then the checkpoint's activations leave the fp16 range (stand-in for 'image 57
+    overflows': an FFN scaled by 3e4 behind the model's back).  With -fno-honor-nans kernels that is finite garbage, not NaN -- the check of batch 3 sees
+    it, the model continues in fp32, and the two unchecked batches before it are queued for redoing"""
+    from cfen_vit_dehazing_amd.models import create_model
+    from cfen_vit_dehazing_amd.options.test_options import TestOptions
+    cfg = NetConfig(24, 4, patch_size=8, load_size=64)
+    sd = cached_state_dict(cfg)
+    ck = tmp_path / "ck" / "late_overflow"
+    ck.mkdir(parents=True)
+    torch.save(sd, ck / "latest_net_G.pth")
+    opt = TestOptions().parse(['--dataroot', str(tmp_path), '--checkpoints_dir', str(tmp_path / "ck"), '--name', 'late_overflow', '--n_feats', '24',
+                               '--hidden_dim_ratio', '4', '--patch_size', '8', '--loadSize', '64', '--sb', '--precision', 'half', '--half_guard_every', '3',
+                               '--results_dir', str(tmp_path / "res")])
+    model = create_model(opt)
+    model.setup(opt)
+    model.plan_half_guard(6)
+    key = "localvit_encoder_01.encoder.layers.0.linear1.weight"
+    for j in range(5):
+        if j == 3:
+            with torch.no_grad():
+                dict(model.netG.named_parameters())[key].mul_(3e4)
+            model.netG.invalidate()
+        x = synthetic_input(2, cfg, seed0=2 * j)
+        model.set_input({'B': x, 'B_paths': ['b%d_0.png' % j, 'b%d_1.png' % j]})
+        model.test(opt)
+        fa = model.get_current_visuals()['fake_A']
+        assert torch.isfinite(fa.float()).all()
+        if j < 3:
+            assert model.netG.compute_dtype == torch.float16 and model.redo_paths == []
+        else:
+            assert model.netG.compute_dtype == torch.float32
+        if j == 3:
+            batch3_fake_A = fa.float().clone()
+    assert [b for b, _ in model.half_guard_log] == [0, 3] and model.half_guard_log[0][1] <= 3e-2 and not model.half_guard_log[1][1] <= 3e-2
+    assert model.redo_paths == ['b1_0.png', 'b1_1.png', 'b2_0.png', 'b2_1.png']
+    # batch 3 itself came out of the fp32 path: equal to a plain fp32 net on the same (scaled) weights
+    sd2 = dict(sd)
+    sd2[key] = sd[key] * 3e4
+    ref = make_net(cfg, "fp32", sd=sd2)
+    assert torch.equal(batch3_fake_A, ref(synthetic_input(2, cfg, seed0=6).to("cuda:0"))[2])
+    txt = open(tmp_path / "res" / "late_overflow" / "test_latest" / "precision.txt").read()
+    assert "precision: single" in txt and "fell_back_at_batch: 3" in txt

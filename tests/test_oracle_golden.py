@@ -63,6 +63,19 @@ def test_oracle_full512_two_images():
     assert outs[0].shape == (2, 3, 512, 512)
 
 
+@pytest.mark.slow
+def test_oracle_full512_benchmarked_batch_of_eight():
+    """the batch-8 fixture (seeds 0 .. 7 = the benchmarked batch): outputs, stages and the whole-image PSNR / SSIM figures of every image"""
+    outs = _run("full512b8_nf24_hdr4")
+    _, batch, z = load_net_fixture("full512b8_nf24_hdr4")
+    x = synthetic_input(batch, load_net_fixture("full512b8_nf24_hdr4")[0])
+    for nm, o in zip(("xr", "xs", "xd"), outs):
+        for b in range(batch):
+            t = x[b:b + 1, :o.shape[1]]
+            assert abs(cfen_oracle.psnr(o[b:b + 1], t) - float(z["full_psnr/" + nm][b])) < 1e-4
+            assert abs(cfen_oracle.ssim(o[b:b + 1], t) - float(z["full_ssim/" + nm][b])) < 1e-6
+
+
 def test_oracle_fp64_agrees_with_fp32():
     cfg, batch, z = load_net_fixture("tiny_nf24_hdr4")
     sd = generate_state_dict(cfg, seed=0, with_dead=False, dtype=torch.float64)

@@ -137,22 +137,27 @@ def test_two_rank_shard_and_allgather_equals_single_process():
 
 
 def _rotation_worker(rank, world, port, q):
-    """bench.py's step loop of the sharded run on CPU tensors: `nslab` = 3 output slabs rotate (three forwards in flight per rank), the gather slot is step & 1"""
+    """bench.py's step loop of the sharded run on CPU tensors: `nslab` = 3 output slabs rotate (three forwards in flight per rank) and the gatherer has
+    one slot per slab (slot = step % nslab), so the fence in front of step i is the gather of step i - nslab, the last reader of that slab"""
     sys.path.insert(0, ROOT)
     os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     B, n, nslab, steps = 2, 8, 3, 7
     slabs = [torch.empty(7 * B * n * n) for _ in range(nslab)]
-    g = OutputGatherer(world, slabs[0].numel(), "cpu", torch.float16)
+    g = OutputGatherer(world, slabs[0].numel(), "cpu", torch.float16, slots=nslab)
+    assert len(g.bufs) == len(g.stage) == len(g.events) == nslab
     for i in range(steps):
         s = slabs[i % nslab]
-        g.before_write(i & 1)
+        g.before_write(i % nslab)
         s.copy_(torch.arange(s.numel(), dtype=torch.float32) % 31 / 64 + rank / 4 + i / 128)      # what step i of this rank "computed" (fp16-exact values)
-        g.launch(s, i & 1)
+        g.launch(s, i % nslab)
     g.wait_all()
-    merged = merge_gathered(g.bufs[(steps - 1) & 1].float(), world, B, n)
-    want = [torch.arange(slabs[0].numel(), dtype=torch.float32) % 31 / 64 + r / 4 + (steps - 1) / 128 for r in range(world)]
-    ok = all(torch.equal(torch.cat([split_slab(want[r], B, n)[k] for r in range(world)], 0), merged[k]) for k in range(3))
+    ok = True
+    for back in range(nslab):          # the last nslab steps each still sit in their own slot
+        i = steps - 1 - back
+        merged = merge_gathered(g.bufs[i % nslab].float(), world, B, n)
+        want = [torch.arange(slabs[0].numel(), dtype=torch.float32) % 31 / 64 + r / 4 + i / 128 for r in range(world)]
+        ok = ok and all(torch.equal(torch.cat([split_slab(want[r], B, n)[k] for r in range(world)], 0), merged[k]) for k in range(3))
     if rank == 0:
         q.put(bool(ok))
     dist.barrier()
