@@ -533,8 +533,9 @@ def main():
                     torch.cuda.synchronize()
                     last = (args.steps - 1) % nslab
                     legs["gathered_equals_slab"] = bool(torch.equal(gather.bufs[last], slabs[last].to(gather.bufs[last].dtype)))
-                    legs["what"] = ("per-rank configuration of the sharded run on ONE GPU: 3 forwards in flight + RCCL all_gather_into_tensor of the %s output slab on "
-                                    "the communication stream (world-1 communicator), one gather slot per slab" % gdt)
+                    legs["what"] = ("per-rank configuration of the sharded run on ONE GPU: 3 forwards in flight, each followed on its own lane by the wire conversion and an "
+                                    "asynchronous RCCL all_gather_into_tensor of the %s output slab (world-1 communicator, torch's internal collective stream is the "
+                                    "fourth busy queue), one gather slot per slab" % gdt)
                     nslab, nfl, gather = main_state
                     dist1.destroy_process_group()
                     extra["gather_overhead_1gpu"] = legs

@@ -349,6 +349,10 @@ class dec_ipt(nn.Module):
         native_u8 = self._native_u8[key]
         if self.output_u8 and out is not None:
             raise ValueError("output_u8 allocates its own (B,H,W,3) uint8 outputs: no `out` slab")
+        if capture and self.output_u8 and not native_u8:
+            raise CfenError("capture() with output_u8 needs a net that writes the uint8 images itself (fp16, full-size tails); this one converts its "
+                            "float outputs with separate passes AFTER the forward, which a replayed graph would not run -- capture with output_u8 = "
+                            "False and convert after the replay (pipeline.py does)")
         if native_u8:
             flat = torch.empty(9 * px, dtype=torch.uint8, device=x.device)
             xr, xs, xd = (flat[k * 3 * px:(k + 1) * 3 * px].view(B, n, n, 3) for k in range(3))
@@ -410,6 +414,10 @@ class dec_ipt(nn.Module):
         n = B * H.value * W.value * cs.value
         flat = ws[off:off + n * esz].view(dt)
         return flat.view(B, H.value, W.value, cs.value)[..., :C.value].permute(0, 3, 1, 2).float().contiguous()
+
+    def writes_u8_natively(self):
+        """did the net of the last forward write the uint8 images itself (tensor2im in the tails' last launch)?"""
+        return self._last is not None and bool(self._native_u8.get(self._last, False))
 
     def flops_per_image(self):
         if not self._nets:

@@ -61,15 +61,20 @@ def merge_gathered(gathered, world, batch, n):
 class OutputGatherer:
     """Asynchronous all-gather of equally sized per-rank slabs, ONE SLOT PER OUTPUT SLAB of the caller's rotation.
 
-    A slot owns what the collective of one slab needs: the fence event (recorded when the communication stream has finished READING the slab), the
-    fp16 stage buffer and the gathered buffer.  `slots` is the number of slabs the compute lanes rotate over (bench.py: max(2, forwards in flight)), so
-    step i uses slot i % slots and `before_write(slot)` waits exactly for the gather of step i - slots -- the last reader of that slab -- and for nothing
-    else: with three slabs three forwards really are in flight.  (Round 4 kept two slots for three slabs; forward i then waited for gather i - 2 and at most
-    two forwards overlapped per rank: ADVICE r04.)
+    A slot owns what the collective of one slab needs: the fp16 stage buffer, the gathered buffer and the handle of the collective that last used them.
+    `slots` is the number of slabs the compute lanes rotate over (bench.py: max(2, forwards in flight)), so step i uses slot i % slots and the only
+    thing step i ever waits for is the gather of step i - slots, the last user of that slot -- with three slabs three forwards really are in flight.
+    (Round 4 kept two slots for three slabs; forward i then waited for gather i - 2 and at most two forwards overlapped per rank: ADVICE r04.)
 
-    `dtype` is the wire type.  The kernels write fp32 slabs; with the fp16 compute path the slab is converted to fp16 on
-    the communication stream before it is gathered (outputs are tanh values in (-1, 1): the 2^-11 rounding is below the
-    fp16 path's own error), which halves the xGMI traffic -- 29 MB instead of 59 MB per rank at 8 images of 512x512."""
+    No communication stream of its own (round 5): `launch` is called in the LANE's stream context right behind the forward.  The wire-type conversion
+    runs on the lane (30 us, stream-ordered behind the forward, so the slab is free for the lane's next forward without any fence) and the collective is
+    handed to torch.distributed asynchronously: ProcessGroupNCCL runs it on its own internal stream behind an event of the lane.  Busy hardware queues
+    per rank = the lanes + that one stream.  Measured on one MI355X with a world-1 RCCL communicator (bench.py extra_configs.gather_overhead_1gpu): a
+    separate communication stream in front of torch's internal one -- five busy queues -- cost 0.72 ms per step (2.21 -> 2.93 ms with three lanes).
+
+    `dtype` is the wire type.  The kernels write fp32 slabs; with the fp16 compute path the slab is converted to fp16 before it is gathered (outputs
+    are tanh values in (-1, 1): the 2^-11 rounding is below the fp16 path's own error), which halves the xGMI traffic -- 29 MB instead of 59 MB per
+    rank at 8 images of 512x512."""
 
     def __init__(self, world, numel, device, dtype=torch.float32, slots=2):
         if slots < 1:
@@ -85,16 +90,22 @@ class OutputGatherer:
                                  % (int(-lohi[1]), int(lohi[0])))
         self.bufs = [torch.empty(world * numel, dtype=dtype, device=device) for _ in range(slots)]
         self.stage = [torch.empty(numel, dtype=dtype, device=device) for _ in range(slots)] if dtype != torch.float32 else None
-        self.stream = torch.cuda.Stream(device) if self.cuda else None
-        self.events = [None] * slots          # slot -> "the communication stream no longer reads the slab handed to launch(slot)"
-        self.done = [None] * slots            # slot -> "bufs[slot] holds the gathered result"
+        self.work = [None] * slots            # slot -> handle of the collective that last read stage[slot] / the slab and wrote bufs[slot]
+
+    def _settle(self, slot):
+        """the current stream waits (on the device, not the host) until the collective that last used `slot` is done with its buffers"""
+        if self.cuda and self.work[slot] is not None:
+            self.work[slot].wait()
+            self.work[slot] = None
 
     def before_write(self, slot):
-        """Call on the compute stream before it overwrites the slab last handed to launch(slot)."""
-        if self.cuda and self.events[slot] is not None:
-            torch.cuda.current_stream().wait_event(self.events[slot])
+        """Call on the lane's stream before the forward overwrites the slab last handed to launch(slot).  With a converting gatherer the slab was
+        released by a copy on this same lane (nothing to wait for); an fp32 wire reads the slab itself."""
+        if self.stage is None:
+            self._settle(slot)
 
     def launch(self, slab, slot):
+        """Call on the lane's stream right behind the forward that wrote `slab`.  Returns the gathered buffer (valid after wait_all / the next _settle)."""
         if slab.numel() != self.numel:
             raise ValueError("slab has %d elements, the gatherer was built for %d per rank (every rank must hand over the same size)"
                              % (slab.numel(), self.numel))
@@ -103,24 +114,12 @@ class OutputGatherer:
             src = self.stage[slot].copy_(slab) if convert else slab
             dist.all_gather_into_tensor(self.bufs[slot], src)
             return self.bufs[slot]
-        self.stream.wait_stream(torch.cuda.current_stream())
-        with torch.cuda.stream(self.stream):
-            ev = torch.cuda.Event()
-            if convert:
-                src = self.stage[slot].copy_(slab)        # the slab is free again as soon as this copy is done
-                ev.record(self.stream)
-            else:
-                src = slab
-            work = dist.all_gather_into_tensor(self.bufs[slot], src, async_op=True)
-            work.wait()                                   # side stream now orders after the collective
-            if not convert:
-                ev.record(self.stream)
-            fin = torch.cuda.Event()
-            fin.record(self.stream)
-        self.events[slot] = ev
-        self.done[slot] = fin
+        self._settle(slot)                                # stage[slot] / bufs[slot] are free again
+        src = self.stage[slot].copy_(slab) if convert else slab
+        self.work[slot] = dist.all_gather_into_tensor(self.bufs[slot], src, async_op=True)
         return self.bufs[slot]
 
     def wait_all(self):
-        if self.cuda:
-            torch.cuda.current_stream().wait_stream(self.stream)
+        """the current stream waits for every collective still out"""
+        for slot in range(self.slots):
+            self._settle(slot)

@@ -76,6 +76,10 @@ class PipelinedRunner:
         s.x_dev.copy_(batch)
         with torch.cuda.stream(s.stream):
             self.net(s.x_dev)                                  # builds this replica's plan (and packs the weights the first time)
+            if self.net.output_u8 and not self.net.writes_u8_natively():
+                # (fp32 plans, small images) the uint8 images are separate passes behind the forward: the graph holds the forward and writes float
+                # outputs, _visual_u8 runs those passes behind every replay
+                self.net.output_u8 = False
             s.gid, s.outs = self.net.capture(s.x_dev)
         s.stream.synchronize()
         self.net.replica = 0

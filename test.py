@@ -68,9 +68,12 @@ if __name__ == '__main__':
         print('pipelined driver: %d images in %.2f s = %.1f images/s file to file (%d batches replayed from graphs, %d through the sequential path)'
               % (stats['images'], stats['seconds'], stats['images'] / max(stats['seconds'], 1e-9), stats['graph_batches'], stats['sequential_batches']))
     else:
+        import time
+        t_loop, n_img = time.perf_counter(), 0
         for i, data in enumerate(dataset):
             if i >= opt.how_many:
                 break
+            n_img += len(data['B_paths'])
             model.set_input(data)
             model.test(opt)
             visuals = model.get_current_visuals()
@@ -81,6 +84,8 @@ if __name__ == '__main__':
             if i % 5 == 0:
                 logging.info('processing (%04d)-th image...' % (i * opt.batchSize))
             save_images(webpage.get_image_dir(), visuals, img_path, aspect_ratio=opt.aspect_ratio, width=opt.display_winsize)
+        t_loop = time.perf_counter() - t_loop
+        print('sequential loop: %d images in %.2f s = %.1f images/s file to file' % (n_img, t_loop, n_img / max(t_loop, 1e-9)))
     model.finish_half_guard()
     if model.redo_paths:
         print('redoing %d images in fp32 (a --precision half check failed after they were written)' % len(model.redo_paths))

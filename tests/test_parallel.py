@@ -45,19 +45,29 @@ def _gpu_worker(rank, world, port, q):
     slabs = [(torch.rand(7 * B * n * n, generator=g) * 2 - 1) for _ in range(world)]     # every rank can rebuild all slabs
     mine = slabs[rank].to(dev)
     worst = 0.0
+    lanes = [torch.cuda.Stream(dev) for _ in range(3)]
     for wire in (torch.float32, torch.float16):
-        og = OutputGatherer(world, mine.numel(), dev, wire)
-        for it in range(3):                                       # double buffering: slots alternate, the slab is rewritten in between
-            slot = it & 1
-            og.before_write(slot)
-            mine.copy_(slabs[rank].to(dev) * (1.0 + 0.0 * it))
-            out = og.launch(mine, slot)
-        og.wait_all()
+        # bench.py's rotation: three slabs on three lane streams, one gather slot per slab, launch() in the lane's context right behind the "forward"
+        # (here: a rewrite of the slab with values that depend on the step, so a gather that read a slab or a stage too late or too early is seen)
+        og = OutputGatherer(world, mine.numel(), dev, wire, slots=3)
+        mines = [torch.empty_like(mine) for _ in range(3)]
+        steps = 8
+        for it in range(steps):
+            slot = it % 3
+            with torch.cuda.stream(lanes[slot]):
+                og.before_write(slot)
+                mines[slot].copy_(slabs[rank].to(dev) * (1.0 - it / 16.0))     # exact in fp16 and fp32: a power-of-two step
+                og.launch(mines[slot], slot)
+        for s in lanes:
+            with torch.cuda.stream(s):
+                og.wait_all()
         torch.cuda.synchronize()
-        want = torch.cat(slabs).to(dev)
-        err = float((out.float() - want).abs().max())
-        assert out.dtype == wire and err <= (0.0 if wire == torch.float32 else 2.0 ** -11), (wire, err)
-        worst = max(worst, err)
+        for it in range(steps - 3, steps):
+            out = og.bufs[it % 3]
+            want = torch.cat(slabs).to(dev) * (1.0 - it / 16.0)
+            err = float((out.float() - want).abs().max())
+            assert out.dtype == wire and err <= (0.0 if wire == torch.float32 else 2.0 ** -11), (wire, it, err)
+            worst = max(worst, err)
     if rank == 0:
         q.put(worst)
     dist.barrier()
@@ -145,7 +155,7 @@ def _rotation_worker(rank, world, port, q):
     B, n, nslab, steps = 2, 8, 3, 7
     slabs = [torch.empty(7 * B * n * n) for _ in range(nslab)]
     g = OutputGatherer(world, slabs[0].numel(), "cpu", torch.float16, slots=nslab)
-    assert len(g.bufs) == len(g.stage) == len(g.events) == nslab
+    assert len(g.bufs) == len(g.stage) == len(g.work) == nslab
     for i in range(steps):
         s = slabs[i % nslab]
         g.before_write(i % nslab)
