@@ -40,16 +40,25 @@ def to_u8_hwc(img):
     return torch.from_numpy(np.asarray(img, dtype=np.uint8).copy())
 
 
+class _ResizeShortSide:
+    """--resize_or_crop resize_only / scale_width: the short side becomes --loadSize (a picklable callable: the loader's workers are started by a
+    fork server, not forked from the GPU process -- CustomDatasetDataLoader)"""
+
+    def __init__(self, load_size):
+        self.load_size = load_size
+
+    def __call__(self, img):
+        w, h = img.size
+        s = self.load_size / min(w, h)
+        return to_normalized_tensor(img.resize((max(1, round(w * s)), max(1, round(h * s))), Image.BICUBIC))
+
+
 def get_transform(opt):
     mode = opt.resize_or_crop
     if mode in ('resize', 'none'):
         return to_u8_hwc if getattr(opt, 'u8_input', False) else to_normalized_tensor
     if mode in ('resize_only', 'scale_width'):
-        def f(img):
-            w, h = img.size
-            s = opt.loadSize / min(w, h)
-            return to_normalized_tensor(img.resize((max(1, round(w * s)), max(1, round(h * s))), Image.BICUBIC))
-        return f
+        return _ResizeShortSide(opt.loadSize)
     raise NotImplementedError("--resize_or_crop %s uses random crops (training only)" % mode)
 
 
@@ -110,8 +119,26 @@ class CustomDatasetDataLoader():
     def initialize(self, opt):
         self.opt = opt
         self.dataset = CreateDataset(opt)
+        workers = int(opt.nThreads)
+        # How the worker processes come to be matters on MI355X / ROCm 7.2: forking a process that already holds its GPU working set (packed weights,
+        # workspaces, pinned buffers) stalled the GPU for 10-16 s at the first launch afterwards (the fork write-protects the parent's pinned /
+        # registered pages and the driver re-validates the process's buffers): test.py --nThreads 4 ran at 6.5 images/s against 35 with --nThreads 0,
+        # and the first batch of a pipelined run waited 14 s (profiles/r05_cli_throughput.json).  So the harness forks EARLY: test.py calls
+        # start_workers() right after the options are parsed, before the model exists (the reference creates the loader first too, test.py:24-26, but
+        # its workers only start at the first iteration).  CFEN_LOADER_CONTEXT=forkserver|spawn starts fresh worker processes instead (the main
+        # script must then be importable: `if __name__ == '__main__'`).
+        ctx = os.environ.get('CFEN_LOADER_CONTEXT', 'fork') if workers > 0 else None
         self.dataloader = torch.utils.data.DataLoader(self.dataset, batch_size=opt.batchSize, shuffle=not opt.sb,
-                                                      num_workers=int(opt.nThreads))
+                                                      num_workers=workers, multiprocessing_context=ctx,
+                                                      pin_memory=bool(workers > 0 and getattr(opt, 'in_flight', 1) > 1 and torch.cuda.is_available()))
+        # (pin_memory: the pipelined driver copies every batch H2D asynchronously; torch's pin thread stages it off the main thread)
+        self._started = None
+
+    def start_workers(self):
+        """fork the worker processes NOW (they begin decoding the first batches); the next iteration over the loader uses them"""
+        if int(self.opt.nThreads) > 0 and self._started is None:
+            self._started = iter(self.dataloader)
+        return self
 
     def load_data(self):
         return self
@@ -120,7 +147,8 @@ class CustomDatasetDataLoader():
         return min(len(self.dataset), self.opt.max_dataset_size)
 
     def __iter__(self):
-        for i, data in enumerate(self.dataloader):
+        it, self._started = (self._started, None) if getattr(self, '_started', None) is not None else (iter(self.dataloader), None)
+        for i, data in enumerate(it):
             if i * self.opt.batchSize >= self.opt.max_dataset_size:
                 break
             yield data

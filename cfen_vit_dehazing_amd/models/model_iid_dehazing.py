@@ -27,7 +27,15 @@ class DECHLGVIT(BaseModel):
         # any other --model_G leaves netG undefined, as the reference's if/elif chain does (-> AttributeError)
 
     def set_input(self, input):
-        B = input['B'].to(self.device)                      # hazy image, H2D copy
+        B = input['B']
+        if not B.is_cuda and self.device.type == 'cuda':
+            # H2D through a pinned staging buffer the model keeps per batch shape (allocated by warm_up, before the DataLoader forks its workers).
+            # Measured on MI355X / ROCm 7.2: once forked workers exist, a copy from PAGEABLE host memory (the worker's shared-memory batch, or a plain
+            # clone of it) to the device took ~8 s per 6 MB batch -- 6.5 images/s for the whole sequential loop with --nThreads 4 against 35 with
+            # --nThreads 0 (profiles/r05_cli_throughput.json); from pinned memory it is the PCIe time
+            B = self._staged(B).to(self.device, non_blocking=True)
+        else:
+            B = B.to(self.device)
         self.image_paths = input['B_paths']
         if B.dtype == torch.uint8:
             # --u8_input: (B,H,W,3) uint8 goes to the generator as it is (normalised by the plan's first launch);
@@ -36,6 +44,18 @@ class DECHLGVIT(BaseModel):
             self.real_B = (B.permute(0, 3, 1, 2).float() / 255.0 - 0.5) / 0.5
         else:
             self._net_in = self.real_B = B
+
+    def _staged(self, B):
+        pins = self.__dict__.setdefault('_pins', {})
+        key = (tuple(B.shape), B.dtype)
+        if key not in pins:
+            if len(pins) >= 4:
+                pins.clear()
+            pins[key] = torch.empty(B.shape, dtype=B.dtype).pin_memory()
+        if torch.cuda.is_available():
+            torch.cuda.current_stream().synchronize()       # the previous batch's copy out of this buffer has completed
+        pins[key].copy_(B)
+        return pins[key]
 
     HALF_GUARD_BAR = 3e-2     # max-abs difference of the fp16 outputs (tanh values in (-1, 1)) from the fp32 path on a checked batch
 
@@ -150,6 +170,31 @@ class DECHLGVIT(BaseModel):
         self._since_check = []
         self.netG.set_compute_dtype('fp32')
         self._record_precision('single', worst, batch_index if batch_index is not None else -1)
+
+    def warm_up(self, batch_size, u8_input=False):
+        """Build everything the run will need -- packed weights, launch plans and workspaces of every compute type in play -- on a dummy batch, BEFORE the
+        DataLoader forks its workers: device allocations made while forked children hold the process's GPU mappings took seconds each on MI355X / ROCm 7.2
+        (the first --precision half check of a pipelined run with 16 workers: 18 s against < 1 s; profiles/r05_cli_throughput.json).  No guard state changes."""
+        if not self.actnorm_ready():
+            return False           # the first REAL batch must initialise those layers (models/actnorm.py:25-37), not a dummy
+        n = self.netG.cfg.image_size
+        shape = (batch_size, n, n, 3) if u8_input else (batch_size, 3, n, n)
+        x = self._staged(torch.zeros(shape, dtype=torch.uint8 if u8_input else torch.float32)).to(self.device)
+        with torch.no_grad():
+            if getattr(self, '_half_guard', False):
+                self.netG.output_u8 = False
+                self.netG.set_compute_dtype('fp32')
+                self.netG(x)
+                self.netG.set_compute_dtype('fp16')
+                self.netG(x)
+            if getattr(self, '_u8_out', False):
+                self.netG.output_u8 = True
+            self.netG(x)
+        torch.cuda.synchronize()
+        return True
+
+    def actnorm_ready(self):
+        return all(int(b) != 0 for k, b in self.netG.named_buffers() if k.endswith('initialized'))
 
     def _settle_check(self, j, worst):
         """one check of batch j: the ranks agree on the worst difference; passed -> the batches since the previous check are cleared, failed -> fp32 from here on"""

@@ -50,23 +50,36 @@ if __name__ == '__main__':
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         dist.init_process_group('gloo', rank=opt.dist_rank, world_size=opt.dist_world)
     data_loader = CreateDataLoader(opt)
+    data_loader.start_workers()          # fork the --nThreads decode workers BEFORE the process holds its GPU working set (data/__init__.py)
     dataset = data_loader.load_data()
     model = create_model(opt)
     model.setup(opt)
     web_dir = os.path.join(opt.results_dir, opt.name, '%s_%s' % (opt.phase, opt.which_epoch))
     webpage = html.HTML(web_dir, 'Experiment = %s, Phase = %s, Epoch = %s' % (opt.name, opt.phase, opt.which_epoch))
-    n_batches = min(opt.how_many, -(-min(len(data_loader), len(data_loader.dataset)) // opt.batchSize))
+    n_images = min(len(data_loader), len(data_loader.dataset))
+    n_batches = min(opt.how_many, -(-n_images // opt.batchSize))
     model.plan_half_guard(n_batches)
+    runner = None
+    if opt.in_flight > 1:
+        from cfen_vit_dehazing_amd.pipeline import PipelinedRunner
+        runner = PipelinedRunner(model, opt, webpage.get_image_dir())          # switches the generator to the serial launch plan: before anything is built
+    if n_images > 0 and hasattr(model, 'warm_up'):
+        model.warm_up(min(opt.batchSize, n_images), getattr(opt, 'u8_input', False))      # every allocation of the run before the DataLoader forks its workers
     if opt.in_flight > 1:
         # the pipelined driver: --in_flight batches on as many launch-plan replicas / streams / hardware queues, hipGraph replay, pinned asynchronous
         # copies, PNG encode in --writers threads -- the loop bench.py's throughput presupposes, for real files; byte-identical files
-        from cfen_vit_dehazing_amd.pipeline import PipelinedRunner
-        runner = PipelinedRunner(model, opt, webpage.get_image_dir())
         print('pipelined driver: %d batches in flight, plan %s' % (opt.in_flight, model.netG.plan_info()))
+        if n_images > 0 and model.actnorm_ready():
+            n = model.netG.cfg.image_size
+            sizes = [min(opt.batchSize, n_images)] + ([n_images % opt.batchSize] if n_images > opt.batchSize and n_images % opt.batchSize and n_batches * opt.batchSize >= n_images else [])
+            u8 = getattr(opt, 'u8_input', False)
+            runner.warm_up([(b, n, n, 3) if u8 else (b, 3, n, n) for b in sizes], torch.uint8 if u8 else torch.float32)
         stats = runner.run(dataset, opt.how_many)
         runner.close()
         print('pipelined driver: %d images in %.2f s = %.1f images/s file to file (%d batches replayed from graphs, %d through the sequential path)'
               % (stats['images'], stats['seconds'], stats['images'] / max(stats['seconds'], 1e-9), stats['graph_batches'], stats['sequential_batches']))
+        print('pipelined driver: main-thread seconds %s' % stats['main_thread_seconds'])
+        print('pipelined driver: sequential-path seconds %s' % stats.get('sequential_seconds'))
     else:
         import time
         t_loop, n_img = time.perf_counter(), 0

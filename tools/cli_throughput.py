@@ -30,74 +30,81 @@ from PIL import Image
 from cfen_vit_dehazing_amd.config import NetConfig
 from cfen_vit_dehazing_amd.manifest import generate_state_dict
 
-n_images = int(sys.argv[1]) if len(sys.argv) > 1 else 256
-out_path = sys.argv[2] if len(sys.argv) > 2 else None
-ncpu = os.cpu_count() or 8
-threads = int(os.environ.get("CLI_THREADS", min(16, max(2, ncpu // 2))))
-writers = int(os.environ.get("CLI_WRITERS", min(32, max(4, ncpu // 2))))
-tmp = tempfile.mkdtemp(prefix="cfen_cli_")
-try:
-    cfg = NetConfig(24, 4, patch_size=32, load_size=256)
-    name = "iid_hlgvit_crs_gd4_cfs_v3_cli"
-    os.makedirs(os.path.join(tmp, "ckpt", name))
-    torch.save(generate_state_dict(cfg, seed=0), os.path.join(tmp, "ckpt", name, "32_net_G.pth"))
-    hazy = os.path.join(tmp, "data", "hazy")
-    os.makedirs(hazy)
-    rs = np.random.RandomState(1)
-    n = 512
-    yy, xx = np.mgrid[0:n, 0:n].astype(np.float32) / n
-    for i in range(n_images):
-        base = np.stack([np.sin(6.0 * (xx * (i % 5 + 1) + yy)) * 90 + 128, np.cos(5.0 * (yy * (i % 3 + 1) - xx)) * 80 + 120, (xx + yy) * 100 + 20 + (i % 50)], -1)
-        Image.fromarray(np.clip(base + rs.randn(n, n, 3) * 6.0, 0, 255).astype(np.uint8)).save(os.path.join(hazy, "syn_%05d.png" % i))
-    res = {"images": n_images, "image": "512x512", "host_logical_cores": ncpu, "decode_workers": threads, "writer_threads": writers}
+def main():
+    n_images = int(sys.argv[1]) if len(sys.argv) > 1 else 256
+    out_path = sys.argv[2] if len(sys.argv) > 2 else None
+    ncpu = os.cpu_count() or 8
+    threads = int(os.environ.get("CLI_THREADS", min(16, max(2, ncpu // 2))))
+    writers = int(os.environ.get("CLI_WRITERS", min(32, max(4, ncpu // 2))))
+    tmp = tempfile.mkdtemp(prefix="cfen_cli_")
+    try:
+        cfg = NetConfig(24, 4, patch_size=32, load_size=256)
+        name = "iid_hlgvit_crs_gd4_cfs_v3_cli"
+        os.makedirs(os.path.join(tmp, "ckpt", name))
+        torch.save(generate_state_dict(cfg, seed=0), os.path.join(tmp, "ckpt", name, "32_net_G.pth"))
+        hazy = os.path.join(tmp, "data", "hazy")
+        os.makedirs(hazy)
+        rs = np.random.RandomState(1)
+        n = 512
+        yy, xx = np.mgrid[0:n, 0:n].astype(np.float32) / n
+        for i in range(n_images):
+            base = np.stack([np.sin(6.0 * (xx * (i % 5 + 1) + yy)) * 90 + 128, np.cos(5.0 * (yy * (i % 3 + 1) - xx)) * 80 + 120, (xx + yy) * 100 + 20 + (i % 50)], -1)
+            Image.fromarray(np.clip(base + rs.randn(n, n, 3) * 6.0, 0, 255).astype(np.uint8)).save(os.path.join(hazy, "syn_%05d.png" % i))
+        res = {"images": n_images, "image": "512x512", "host_logical_cores": ncpu, "decode_workers": threads, "writer_threads": writers}
 
-    # ---- component rates --------------------------------------------------------------------------------------------------------------------
-    from cfen_vit_dehazing_amd.options.test_options import TestOptions
-    from cfen_vit_dehazing_amd import data as cdata
-    common = ["--dataroot", os.path.join(tmp, "data"), "--name", name, "--n_feats", "24", "--hidden_dim_ratio", "4", "--sb", "--out_all", "--which_epoch", "32",
-              "--checkpoints_dir", os.path.join(tmp, "ckpt"), "--precision", "half", "--u8_input", "--batchSize", "8"]
-    opt = TestOptions().parse(common + ["--nThreads", str(threads), "--gpu_ids", "-1"])
-    t0 = time.perf_counter()
-    cnt = sum(len(b["B_paths"]) for b in cdata.CreateDataLoader(opt).load_data())
-    res["decode_only_images_per_s"] = round(cnt / (time.perf_counter() - t0), 1)
-    from concurrent.futures import ThreadPoolExecutor
-    imgs = [np.asarray(Image.open(os.path.join(hazy, "syn_%05d.png" % i)).convert("RGB")) for i in range(min(64, n_images))]
-    os.makedirs(os.path.join(tmp, "enc"))
-    with ThreadPoolExecutor(writers) as ex:
+        # ---- component rates --------------------------------------------------------------------------------------------------------------------
+        from cfen_vit_dehazing_amd.options.test_options import TestOptions
+        from cfen_vit_dehazing_amd import data as cdata
+        common = ["--dataroot", os.path.join(tmp, "data"), "--name", name, "--n_feats", "24", "--hidden_dim_ratio", "4", "--sb", "--out_all", "--which_epoch", "32",
+                  "--checkpoints_dir", os.path.join(tmp, "ckpt"), "--precision", "half", "--u8_input", "--batchSize", "8"]
+        opt = TestOptions().parse(common + ["--nThreads", str(threads), "--gpu_ids", "-1"])
         t0 = time.perf_counter()
-        list(ex.map(lambda k: Image.fromarray(imgs[k % len(imgs)]).save(os.path.join(tmp, "enc", "e_%05d.png" % k)), range(n_images)))
-        res["encode_only_images_per_s"] = round(n_images / (time.perf_counter() - t0), 1)
-    t0 = time.perf_counter()
-    for k in range(min(32, n_images)):
-        Image.fromarray(imgs[k % len(imgs)]).save(os.path.join(tmp, "enc", "s_%05d.png" % k))
-    res["encode_one_thread_images_per_s"] = round(min(32, n_images) / (time.perf_counter() - t0), 1)
+        cnt = sum(len(b["B_paths"]) for b in cdata.CreateDataLoader(opt).load_data())
+        res["decode_only_images_per_s"] = round(cnt / (time.perf_counter() - t0), 1)
+        from concurrent.futures import ThreadPoolExecutor
+        imgs = [np.asarray(Image.open(os.path.join(hazy, "syn_%05d.png" % i)).convert("RGB")) for i in range(min(64, n_images))]
+        os.makedirs(os.path.join(tmp, "enc"))
+        with ThreadPoolExecutor(writers) as ex:
+            t0 = time.perf_counter()
+            list(ex.map(lambda k: Image.fromarray(imgs[k % len(imgs)]).save(os.path.join(tmp, "enc", "e_%05d.png" % k)), range(n_images)))
+            res["encode_only_images_per_s"] = round(n_images / (time.perf_counter() - t0), 1)
+        t0 = time.perf_counter()
+        for k in range(min(32, n_images)):
+            Image.fromarray(imgs[k % len(imgs)]).save(os.path.join(tmp, "enc", "s_%05d.png" % k))
+        res["encode_one_thread_images_per_s"] = round(min(32, n_images) / (time.perf_counter() - t0), 1)
 
-    # ---- the two CLI runs -------------------------------------------------------------------------------------------------------------------
-    env = dict(os.environ)
-    env.pop("GPU_MAX_HW_QUEUES", None)
-    for tag, extra in (("sequential", ["--nThreads", "0"]), ("pipelined", ["--in_flight", "4", "--nThreads", str(threads), "--writers", str(writers)])):
-        t0 = time.perf_counter()
-        p = subprocess.run([sys.executable, os.path.join(ROOT, "test.py")] + common + ["--results_dir", os.path.join(tmp, "res_" + tag)] + extra,
-                           cwd=tmp, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
-        wall = time.perf_counter() - t0
-        if p.returncode != 0:
-            res[tag] = {"error": p.stdout[-1500:]}
-            continue
-        m = re.search(r"(\d+) images in ([0-9.]+) s = ([0-9.]+) images/s file to file", p.stdout)
-        res[tag] = {"images_per_s_file_to_file": float(m.group(3)) if m else None, "loop_seconds": float(m.group(2)) if m else None,
-                    "process_wall_seconds_incl_checkpoint_load": round(wall, 2), "flags": " ".join(extra)}
-    a, b = (os.path.join(tmp, "res_" + t, name, "test_32", "images") for t in ("sequential", "pipelined"))
-    if os.path.isdir(a) and os.path.isdir(b):
-        fa, fb = sorted(os.listdir(a)), sorted(os.listdir(b))
-        res["files_written"] = len(fb)
-        res["byte_identical"] = fa == fb and all(open(os.path.join(a, f), "rb").read() == open(os.path.join(b, f), "rb").read() for f in fa)
-    pipe = res.get("pipelined", {}).get("images_per_s_file_to_file")
-    if pipe:
-        res["bound"] = ("PNG encode (%.0f images/s on %d writer threads) and decode (%.0f images/s on %d workers) on the host cores bound the file-to-file rate; "
-                        "the GPU alone replays these batches at bench.py's headline rate" % (res["encode_only_images_per_s"], writers, res["decode_only_images_per_s"], threads))
-    print(json.dumps(res))
-    if out_path:
-        with open(out_path, "w") as f:
-            json.dump(res, f, indent=1)
-finally:
-    shutil.rmtree(tmp, ignore_errors=True)
+        # ---- the two CLI runs -------------------------------------------------------------------------------------------------------------------
+        env = dict(os.environ)
+        env.pop("GPU_MAX_HW_QUEUES", None)
+        for tag, extra in (("sequential", ["--nThreads", "0"]), ("pipelined", ["--in_flight", "4", "--nThreads", str(threads), "--writers", str(writers)])):
+            t0 = time.perf_counter()
+            p = subprocess.run([sys.executable, os.path.join(ROOT, "test.py")] + common + ["--results_dir", os.path.join(tmp, "res_" + tag)] + extra,
+                               cwd=tmp, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+            wall = time.perf_counter() - t0
+            if p.returncode != 0:
+                res[tag] = {"error": p.stdout[-1500:]}
+                continue
+            m = re.search(r"(\d+) images in ([0-9.]+) s = ([0-9.]+) images/s file to file", p.stdout)
+            mt = re.search(r"main-thread seconds (\{.*\})", p.stdout)
+            res[tag] = {"images_per_s_file_to_file": float(m.group(3)) if m else None, "loop_seconds": float(m.group(2)) if m else None,
+                        "main_thread_seconds": json.loads(mt.group(1).replace("'", '"')) if mt else None,
+                        "process_wall_seconds_incl_checkpoint_load": round(wall, 2), "flags": " ".join(extra)}
+        a, b = (os.path.join(tmp, "res_" + t, name, "test_32", "images") for t in ("sequential", "pipelined"))
+        if os.path.isdir(a) and os.path.isdir(b):
+            fa, fb = sorted(os.listdir(a)), sorted(os.listdir(b))
+            res["files_written"] = len(fb)
+            res["byte_identical"] = fa == fb and all(open(os.path.join(a, f), "rb").read() == open(os.path.join(b, f), "rb").read() for f in fa)
+        pipe = res.get("pipelined", {}).get("images_per_s_file_to_file")
+        if pipe:
+            res["bound"] = ("PNG encode (%.0f images/s on %d writer threads) and decode (%.0f images/s on %d workers) on the host cores bound the file-to-file rate; "
+                            "the GPU alone replays these batches at bench.py's headline rate" % (res["encode_only_images_per_s"], writers, res["decode_only_images_per_s"], threads))
+        print(json.dumps(res))
+        if out_path:
+            with open(out_path, "w") as f:
+                json.dump(res, f, indent=1)
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+
+
+if __name__ == '__main__':
+    main()
