@@ -96,9 +96,10 @@ def main():
             res["byte_identical"] = fa == fb and all(open(os.path.join(a, f), "rb").read() == open(os.path.join(b, f), "rb").read() for f in fa)
         pipe = res.get("pipelined", {}).get("images_per_s_file_to_file")
         if pipe:
-            res["bound"] = ("PNG encode (%.0f images/s on %d writer threads) and decode (%.0f images/s on %d workers) on the host cores bound the file-to-file rate; "
-                            "the GPU alone replays these batches at bench.py's headline rate" % (res["encode_only_images_per_s"], writers, res["decode_only_images_per_s"], threads))
-        print(json.dumps(res))
+            res["bound"] = ("I/O bound, on the host: PNG encode (%.0f images/s on %d writer threads) and decode (%.0f images/s on %d workers) bound the file-to-file rate "
+                        "(the pipelined loop's clock starts at its first batch: the workers, forked before the model is built, have decoded ahead while the checkpoint "
+                        "loaded); the GPU alone replays these batches at bench.py's headline rate" % (res["encode_only_images_per_s"], writers, res["decode_only_images_per_s"], threads))
+    print(json.dumps(res))
         if out_path:
             with open(out_path, "w") as f:
                 json.dump(res, f, indent=1)
