@@ -97,9 +97,9 @@ def main():
         pipe = res.get("pipelined", {}).get("images_per_s_file_to_file")
         if pipe:
             res["bound"] = ("I/O bound, on the host: PNG encode (%.0f images/s on %d writer threads) and decode (%.0f images/s on %d workers) bound the file-to-file rate "
-                        "(the pipelined loop's clock starts at its first batch: the workers, forked before the model is built, have decoded ahead while the checkpoint "
+                            "(the pipelined loop's clock starts at its first batch: the workers, forked before the model is built, have decoded ahead while the checkpoint "
                         "loaded); the GPU alone replays these batches at bench.py's headline rate" % (res["encode_only_images_per_s"], writers, res["decode_only_images_per_s"], threads))
-    print(json.dumps(res))
+        print(json.dumps(res))
         if out_path:
             with open(out_path, "w") as f:
                 json.dump(res, f, indent=1)
