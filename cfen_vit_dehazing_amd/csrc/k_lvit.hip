@@ -53,6 +53,42 @@ CFEN_DEV half4 lv_read_tr4(const unsigned char* p) {
   return o;
 }
 
+// ---- hand-issued LDS reads with counted waits (round 5; the k_stream.hip idiom) ----
+// hipcc schedules the attention loops as "ds_read -> s_waitcnt lgkmcnt(0) -> MFMA -> s_nop 6 -> v_max3" per key tile through ONE fragment register
+// set: every one of the 16 K fragments and of the 16 V fragment pairs per head and token tile exposed a whole LDS round trip (disassembly of
+// k_lvit_window<6,16,1,0>, profiles/r05_lvit_window_disasm.txt).  Here the K fragment of key tile t is read INTO THE REGISTERS OF THE SCORE TILE IT
+// PRODUCES (an MFMA may overwrite its own A operand), so up to LV_KPD reads are in flight at no register cost; LDS returns in order, so "fragment t
+// has landed" = at most (reads issued after t) outstanding.
+template <int OFF>
+CFEN_DEV void lv_rd128(floatx4& f, unsigned addr) {
+  asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(f) : "v"(addr), "n"(OFF));
+}
+typedef unsigned int lv_u32x2 __attribute__((ext_vector_type(2)));
+template <int OFF>
+CFEN_DEV void lv_rd_tr64(lv_u32x2& f, unsigned addr) {
+  asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(f) : "v"(addr), "n"(OFF));
+}
+template <int N>
+CFEN_DEV void lv_wait(floatx4& f) {
+  asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(f) : "n"(N));
+}
+template <int N>
+CFEN_DEV void lv_wait2(lv_u32x2& a, lv_u32x2& b) {
+  asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(a), "+v"(b) : "n"(N));
+}
+// MFMA result -> VALU reader with inline asm in between: the hazard recognizer does not carry the matrix pipe's write-back latency across an asm
+// statement (k_stream.hip: mfma_results_settle)
+CFEN_DEV void lv_settle() {
+  __builtin_amdgcn_sched_barrier(0);
+  asm volatile("s_nop 11" ::: "memory");
+  __builtin_amdgcn_sched_barrier(0);
+}
+CFEN_DEV half8 lv_as_half8(floatx4 v) {
+  half8 o;
+  __builtin_memcpy(&o, &v, 16);
+  return o;
+}
+
 CFEN_DEV half8 lv_pack(floatx4 a, floatx4 b) {
   half8 f = {(half_t)a[0], (half_t)a[1], (half_t)a[2], (half_t)a[3], (half_t)b[0], (half_t)b[1], (half_t)b[2], (half_t)b[3]};
   return f;
@@ -61,7 +97,8 @@ CFEN_DEV half8 lv_pack(floatx4 a, floatx4 b) {
 // ND = D / 16 (6); NW waves x TM token tiles of 16 = the 256 tokens of one window (16 x 1 at four waves per SIMD: the default; 8 x 2 at two;
 // 4 x 4 with one wave per SIMD and the whole 512-register file); 4 heads of 24
 template <int ND, int NW, int TM, int SM = 0>   // SM = 0: softmax denominator summed on the vector pipe; 1: on the matrix pipe (round 4; MEASURED SLOWER: 138 / 395 us against
-                                                // 131 / 381 us for 512 / 1536 windows, tools/bench_lvit_window.py -- "lvit.shape" = 3 runs it)
+                                                // 131 / 381 us for 512 / 1536 windows, tools/bench_lvit_window.py -- "lvit.shape" = 3 runs it); 2 (round 5): as 0 with the K / V
+                                                // fragment reads of the attention loops issued by hand, LV_KPD / one key block ahead of the MFMAs ("lvit.shape" = 4)
 __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(NW / 4, NW / 4))) void k_lvit_window(Grouped<LvitArgs> ga) {
   typedef half_t T;
   typedef half8 frag;
@@ -258,6 +295,7 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(NW / 4,
   const frag ones = {(half_t)1, (half_t)1, (half_t)1, (half_t)1, (half_t)1, (half_t)1, (half_t)1, (half_t)1};
   const int li = lane & 15;
   const int vlane = (4 * h + (li >> 2)) * KVP + (li & 3) * 8;     // tr-read: lane 4q+p of a 16-lane group -> key row q, columns 4p..4p+3
+  const unsigned lbase = (unsigned)(unsigned long long)(__attribute__((address_space(3))) unsigned char*)lds;   // LDS byte address of the array (asm reads)
 #pragma unroll 1
   for (int hl = 0; hl < NA; ++hl) {
     const unsigned char* buf = begin_chunk(NE + NKV + hl);     // the first of these barriers also publishes every wave's K / V tiles
@@ -283,9 +321,24 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(NW / 4,
     for (int j = 0; j < TM; ++j) {
       const frag qb = lv_pack(hq[0][j], hq[1][j]);           // Q_h^T for 16 queries: k slot 8h'+e holds d = 8h'+e (host row layout), d >= 24 zero
       floatx4 st[S / 16];
+      if constexpr (SM == 2) {
+        // S^T = K_h Q_h^T with LV_KPD fragment reads in flight: fragment t lands in st[t]'s own registers and the MFMA overwrites it with the scores
+        constexpr int NT = S / 16, KPD = 8;
+        const unsigned ka = lbase + (unsigned)(KOFF + hl * (DH * 2) + r16 * KVP + h * 16);
+        __builtin_amdgcn_sched_barrier(0);
+        lv_static_for<0, KPD>([&](auto tc) { lv_rd128<decltype(tc)::value * 16 * KVP>(st[decltype(tc)::value], ka); });
+        lv_static_for<0, NT>([&](auto tc) {
+          constexpr int t = decltype(tc)::value;
+          if constexpr (t + KPD < NT) lv_rd128<(t + KPD) * 16 * KVP>(st[t + KPD], ka);
+          lv_wait<(t + KPD < NT ? KPD : NT - 1 - t)>(st[t]);
+          st[t] = Mma<T>::mma(lv_as_half8(st[t]), qb, floatx4{0.f, 0.f, 0.f, 0.f});
+        });
+        lv_settle();
+      } else {
 #pragma unroll
       for (int t = 0; t < S / 16; ++t)
         st[t] = Mma<T>::mma(*reinterpret_cast<const frag*>(Kh + (t * 16) * KVP), qb, floatx4{0.f, 0.f, 0.f, 0.f});
+      }
       // row maximum: two chains of three-operand maxima (v_max3_f32: half the instructions of a two-operand tree; round 4)
       float mx = -1e30f, mx2 = -1e30f;
 #pragma unroll
@@ -301,25 +354,70 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(NW / 4,
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           st[t][r] = __builtin_amdgcn_exp2f(fmaf(st[t][r], cs, mc));
-          if constexpr (SM == 0) rs += st[t][r];
+          if constexpr (SM != 1) rs += st[t][r];
         }
       // SM = 1: the softmax denominator comes off the matrix pipe (idle three quarters of this loop): an all-ones A fragment against the
       // packed probabilities sums the 32 keys of a block for every query -- 8 MFMAs instead of 64 v_add_f32 and a cross-lane reduction, and
       // the sum is over the SAME fp16-rounded probabilities the numerator uses
       floatx4 o[2] = {floatx4{0.f, 0.f, 0.f, 0.f}, floatx4{0.f, 0.f, 0.f, 0.f}};
       floatx4 den = {0.f, 0.f, 0.f, 0.f};
+      if constexpr (SM == 2) {
+        // O^T = V_h^T P^T: the probabilities are packed first (64 score registers -> 32), then the four transposed 8-byte reads of key block kb + 1 are
+        // in flight while block kb multiplies
+        constexpr int NB = S / 32;
+        frag pb[NB];
 #pragma unroll
-      for (int kb = 0; kb < S / 32; ++kb) {
-        const frag pb = lv_pack(st[2 * kb], st[2 * kb + 1]);
-        if constexpr (SM == 1) den = __builtin_amdgcn_mfma_f32_16x16x32_f16(ones, pb, den, 0, 0, 0);
+        for (int kb = 0; kb < NB; ++kb) pb[kb] = lv_pack(st[2 * kb], st[2 * kb + 1]);
+        const unsigned va = lbase + (unsigned)(VOFF + hl * (DH * 2) + vlane);
+        lv_u32x2 V[2][4];                                       // [ring slot][i * 2 + {lo, hi}]
+        auto rd_block = [&](auto kc, lv_u32x2 (&v)[4]) {
+          constexpr int kb = decltype(kc)::value;
+          lv_rd_tr64<(kb * 32) * KVP>(v[0], va);
+          lv_rd_tr64<(kb * 32 + 16) * KVP>(v[1], va);
+          lv_rd_tr64<(kb * 32) * KVP + 32>(v[2], va);
+          lv_rd_tr64<(kb * 32 + 16) * KVP + 32>(v[3], va);
+        };
+        __builtin_amdgcn_sched_barrier(0);
+        rd_block(std::integral_constant<int, 0>{}, V[0]);
+        lv_static_for<0, NB>([&](auto kc) {
+          constexpr int kb = decltype(kc)::value;
+          if constexpr (kb + 1 < NB) rd_block(std::integral_constant<int, kb + 1>{}, V[(kb + 1) & 1]);
+          lv_u32x2 (&v)[4] = V[kb & 1];
+          lv_wait2<(kb + 1 < NB ? 6 : 2)>(v[0], v[1]);
+          {
+            frag f;
+            const lv_u32x2 lo = v[0], hi = v[1];
+            __builtin_memcpy(&f, &lo, 8);
+            __builtin_memcpy(reinterpret_cast<unsigned char*>(&f) + 8, &hi, 8);
+            o[0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(f, pb[kb], o[0], 0, 0, 0);
+          }
+          lv_wait2<(kb + 1 < NB ? 4 : 0)>(v[2], v[3]);
+          {
+            frag f;
+            const lv_u32x2 lo = v[2], hi = v[3];
+            __builtin_memcpy(&f, &lo, 8);
+            __builtin_memcpy(reinterpret_cast<unsigned char*>(&f) + 8, &hi, 8);
+            o[1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(f, pb[kb], o[1], 0, 0, 0);
+          }
+        });
+        lv_settle();
+      } else {
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
-          const half4 lo = lv_read_tr4(Vh + (kb * 32) * KVP + i * 32);
-          const half4 hi = lv_read_tr4(Vh + (kb * 32 + 16) * KVP + i * 32);
-          const frag va = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-          o[i] = __builtin_amdgcn_mfma_f32_16x16x32_f16(va, pb, o[i], 0, 0, 0);
+        for (int kb = 0; kb < S / 32; ++kb) {
+          const frag pb = lv_pack(st[2 * kb], st[2 * kb + 1]);
+          if constexpr (SM == 1) den = __builtin_amdgcn_mfma_f32_16x16x32_f16(ones, pb, den, 0, 0, 0);
+#pragma unroll
+          for (int i = 0; i < 2; ++i) {
+            const half4 lo = lv_read_tr4(Vh + (kb * 32) * KVP + i * 32);
+            const half4 hi = lv_read_tr4(Vh + (kb * 32 + 16) * KVP + i * 32);
+            const frag va = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+            o[i] = __builtin_amdgcn_mfma_f32_16x16x32_f16(va, pb, o[i], 0, 0, 0);
+          }
         }
       }
+      // (round 5, measured and reverted: the V region's base kept opaque in a register so that all 32 transposed reads are base + immediate -- 29 -> 3
+      // v_add_u32 per head -- and v_rcp_f32 instead of the IEEE division -- 10 -> 1 instructions: 330 -> 314 vector instructions per head and token
+      // tile, 357.6 against 355.5 us for 1536 windows: no gain; the kernel is not bound by its vector-instruction count alone)
       const float inv = 1.f / (SM == 1 ? den[0] : col_sum(rs));   // every row of `den` is the column (query) sum
       att[j] = lv_pack(o[0] * inv, o[1] * inv);              // rows d >= 24 of O^T are another head's values: W_p's columns for them are zero
     }
@@ -451,6 +549,10 @@ int cfen_lvit_window_impl_g(int dtype, int ng, const LvitArgs* ap, hipStream_t s
     CFEN_LAUNCH((k_lvit_window<6, 16, 1>), dim3((unsigned)blocks, 1, ng), dim3(1024), 0, s, ga);
   else if (cfen_tune_lvit_shape() == 3)
     CFEN_LAUNCH((k_lvit_window<6, 16, 1, 1>), dim3((unsigned)blocks, 1, ng), dim3(1024), 0, s, ga);
+  else if (cfen_tune_lvit_shape() == 4)
+    CFEN_LAUNCH((k_lvit_window<6, 16, 1, 2>), dim3((unsigned)blocks, 1, ng), dim3(1024), 0, s, ga);
+  else if (cfen_tune_lvit_shape() == 5)
+    CFEN_LAUNCH((k_lvit_window<6, 8, 2, 2>), dim3((unsigned)blocks, 1, ng), dim3(512), 0, s, ga);
   else if (cfen_tune_lvit_shape() == 1)
     CFEN_LAUNCH((k_lvit_window<6, 4, 4>), dim3((unsigned)blocks, 1, ng), dim3(256), 0, s, ga);
   else

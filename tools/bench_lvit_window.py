@@ -43,16 +43,26 @@ for B in (8, 24):
     a, b = chain(), fused()
     torch.cuda.synchronize()
     print("B=%d: fused vs chain max-abs %.3e" % (B, float((a.float() - b.float()).abs().max())))
-    tc, tf, tg = [], [], []
+    tc, tf, tg, th, t5, t0 = [], [], [], [], [], []
+    ops.tune("lvit.shape", 4)
+    p4 = fused(); torch.cuda.synchronize()
+    ops.tune("lvit.shape", 2)
+    print("B=%d: hand-pipelined attention reads (lvit.shape 4) bitwise equal to shape 2: %s" % (B, bool(torch.equal(p4, fused()))))
     for _ in range(7):
         tc.append(timed(chain))
         ops.tune("lvit.shape", 2); tf.append(timed(fused))
         ops.tune("lvit.shape", 3); tg.append(timed(fused))
+        ops.tune("lvit.shape", 4); th.append(timed(fused))
+        ops.tune("lvit.shape", 5); t5.append(timed(fused))
+        ops.tune("lvit.shape", 0); t0.append(timed(fused))
     ops.tune("lvit.shape", 1)
     c = fused(); torch.cuda.synchronize()
     ops.tune("lvit.shape", 0)
     print("B=%d: 4-wave variant vs chain max-abs %.3e" % (B, float((a.float() - c.float()).abs().max())))
-    tc.sort(); tf.sort(); tg.sort()
+    tc.sort(); tf.sort(); tg.sort(); th.sort(); t5.sort(); t0.sort()
+    print("B=%d (%d windows): 8 waves x 2 token tiles: compiler-scheduled reads (lvit.shape 0) %.1f us, hand-issued (lvit.shape 5) %.1f us" % (B, nwin, t0[3], t5[3]))
+    print("B=%d (%d windows): lvit.shape 2 (compiler-scheduled LDS reads) %.1f us, lvit.shape 4 (hand-issued, 8 K fragments / one V block ahead) %.1f us = %.0f TF/s"
+          % (B, nwin, tf[3], th[3], B * 7.95e9 / th[3] / 1e6))
     fl = B * 7.95e9          # 7.95 GFLOP per level-1 instance and image
     print("B=%d (%d windows): chain %.1f us (incl. torch allocations between its 3 launches), window kernel 16 waves, denominator on the vector pipe %.1f us = %.0f TF/s, "
           "16 waves, denominator by MFMA %.1f us = %.0f TF/s" % (B, nwin, tc[3], tf[3], fl / tf[3] / 1e6, tg[3], fl / tg[3] / 1e6))
