@@ -170,8 +170,8 @@ def self_check(net, x, outs, cfg, dtype):
         per_image = [0.0] * nimg
         for nm, o in zip(("xr", "xs", "xd"), outs):
             oc = o[0:nimg].float().cpu()
-            d1 = (oc[:, :, c0:c0 + 64, c0:c0 + 64] - torch.from_numpy(z["crop/" + nm])).abs().flatten(1).max(1).values
             d2 = (oc[:, :, 3::8, 5::8] - torch.from_numpy(z["strided/" + nm])).abs().flatten(1).max(1).values
+            d1 = (oc[:, :, c0:c0 + 64, c0:c0 + 64] - torch.from_numpy(z["crop/" + nm])).abs().flatten(1).max(1).values if ("crop/" + nm) in z else d2
             per_image = [max(p, float(a), float(b)) for p, a, b in zip(per_image, d1, d2)]
         res["image0_vs_reference_vectors"] = per_image[0]
         if nimg > 1:

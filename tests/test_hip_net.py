@@ -312,6 +312,22 @@ def test_fp16_benchmark_configs_graph_replay_vs_reference_vectors(name, batch):
             assert d <= FP16_BAR, "%s: 256 x 256 crop of image 0 differs by %.3e" % (nm, d)
         print("   images 0..7 vs the reference's batch-8 vectors: max-abs %.2e; whole-image dPSNR %.4f dB, dSSIM %.2e" % (w8, worst_dp, worst_ds))
         assert worst_dp <= 0.01 and worst_ds <= 1e-4
+    else:
+        # configs 5 and 4: every image of the batch against the reference's own forward of that batch (fixtures full512b16_nf24_hdr2 / full1024b4_nf24_hdr4:
+        # strided samples of all images + whole-image PSNR / SSIM against the input)
+        _, bb, zb = load_net_fixture(name.replace("full512", "full512b16").replace("full1024", "full1024b4"))
+        assert bb == batch
+        wb = check_outputs(zb, outs, FP16_BAR)
+        xc = x.float().cpu()
+        worst_dp = worst_ds = 0.0
+        for nm, o in zip(("xr", "xs", "xd"), outs):
+            oc = o.float().cpu()
+            for b in range(batch):
+                t = xc[b:b + 1, :oc.shape[1]]
+                worst_dp = max(worst_dp, abs(cfen_oracle.psnr(oc[b:b + 1], t) - float(zb["full_psnr/" + nm][b])))
+                worst_ds = max(worst_ds, abs(cfen_oracle.ssim(oc[b:b + 1], t) - float(zb["full_ssim/" + nm][b])))
+        print("   all %d images vs the reference's batch vectors: max-abs %.2e; whole-image dPSNR %.4f dB, dSSIM %.2e" % (batch, wb, worst_dp, worst_ds))
+        assert worst_dp <= 0.01 and worst_ds <= 1e-4
     for i in sorted({1, batch // 2, batch - 1}):
         one = net(x[i:i + 1].clone())
         for a, b in zip(outs, one):

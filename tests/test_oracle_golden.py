@@ -76,6 +76,13 @@ def test_oracle_full512_benchmarked_batch_of_eight():
             assert abs(cfen_oracle.ssim(o[b:b + 1], t) - float(z["full_ssim/" + nm][b])) < 1e-6
 
 
+@pytest.mark.slow
+@pytest.mark.parametrize("name", ["full512b16_nf24_hdr2", "full1024b4_nf24_hdr4"])
+def test_oracle_other_benchmarked_batches(name):
+    """BASELINE configs 5 (batch 16, hidden_dim_ratio 2) and 4 (batch 4, 1024 x 1024): the oracle against the reference's forward of the whole batch"""
+    _run(name)
+
+
 def test_oracle_fp64_agrees_with_fp32():
     cfg, batch, z = load_net_fixture("tiny_nf24_hdr4")
     sd = generate_state_dict(cfg, seed=0, with_dead=False, dtype=torch.float64)

@@ -44,6 +44,9 @@ CONFIGS = {
     # output of every image against its input (the parity tests' common target), and a 256 x 256 crop of image 0
     "full512b8_nf24_hdr4": (NetConfig(24, 4, patch_size=32, load_size=256), 8, False),
     "full1024_nf24_hdr4": (NetConfig(24, 4, patch_size=64, load_size=512), 1, False),
+    # the other two benchmarked batches (BASELINE configs 5 and 4: seeds 0 .. 15 / 0 .. 3): strided samples + whole-image PSNR / SSIM of every image
+    "full512b16_nf24_hdr2": (NetConfig(24, 2, patch_size=32, load_size=256), 16, False),
+    "full1024b4_nf24_hdr4": (NetConfig(24, 4, patch_size=64, load_size=512), 4, False),
     # weights drawn from what the reference's own define_G / init_weights leaves (v3:49-74, 1330, 1377), ActNorm2d uninitialised:
     # the reference's first forward initialises its 24 ActNorm layers from the batch (models/actnorm.py:25-37); the fixture
     # holds those parameters next to the outputs of that same forward
@@ -209,7 +212,8 @@ def gen_net(v3, common, name):
     cfg, batch, full = CONFIGS[name]
     print("== %s: reference forward (B=%d, %dx%d)" % (name, batch, cfg.image_size, cfg.image_size), flush=True)
     net, sd, x, outs, stages = run_reference(v3, common, cfg, batch, mode=weight_mode(name))
-    if not name.startswith("refinit") and "b2_" not in name and "b8_" not in name:
+    batch_fixture = any(t in name for t in ("b2_", "b4_", "b8_", "b16_"))
+    if not name.startswith("refinit") and not batch_fixture:
         dump_manifest(net, os.path.join(GOLD, "state_manifest_%s.txt" % name))
     data = {"batch": np.int64(batch), "cfg": np.array([cfg.n_feats, cfg.hidden_dim_ratio, cfg.patch_size, cfg.load_size], np.int64)}
     names = stage_names(cfg.variant)
@@ -228,16 +232,18 @@ def gen_net(v3, common, name):
         else:
             n = o.shape[-1]
             c0 = n // 2 - 32
-            data["crop/" + nm] = o[:, :, c0:c0 + 64, c0:c0 + 64].numpy().copy()
+            if not ("b4_" in name or "b16_" in name):
+                data["crop/" + nm] = o[:, :, c0:c0 + 64, c0:c0 + 64].numpy().copy()
             data["strided/" + nm] = o[:, :, 3::8, 5::8].numpy().copy()
-            if "b8_" in name:
+            if "b8_" in name or "b4_" in name or "b16_" in name:
                 # whole-image quality figures of the REFERENCE outputs against the common target (the input image), per image: the fp16 path's
                 # PSNR / SSIM must sit within 0.01 dB / 1e-4 of these (north_star), over the full 512 x 512 frame
                 sys.path.insert(0, os.path.join(ROOT, "oracle"))
                 import cfen_oracle
                 data["full_psnr/" + nm] = np.array([cfen_oracle.psnr(o[b:b + 1], x[b:b + 1, :o.shape[1]]) for b in range(batch)], np.float64)
                 data["full_ssim/" + nm] = np.array([cfen_oracle.ssim(o[b:b + 1], x[b:b + 1, :o.shape[1]]) for b in range(batch)], np.float64)
-                data["crop256/" + nm] = o[0:1, :, n // 2 - 128:n // 2 + 128, n // 2 - 128:n // 2 + 128].numpy().copy()
+                if "b8_" in name:
+                    data["crop256/" + nm] = o[0:1, :, n // 2 - 128:n // 2 + 128, n // 2 - 128:n // 2 + 128].numpy().copy()
     if name.startswith("refinit"):
         # the ActNorm parameters the reference's first forward computed (and its `initialized` flags, now 1)
         after = net.state_dict()
