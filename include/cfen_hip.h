@@ -47,7 +47,13 @@ const char* cfen_last_error(void);
  *   "net.ln_fold": 1 (default) LN1 / LN2 of GViT and LViT level 3 are folded into the qkv / ffn1 GEMMs (cfen_gemm_ln), 0 separate LayerNorm launches
  *   "net.embed_gather": 1 (default) the LViT embedding GEMM gathers its patch tokens from the map, 0 separate patchify launch
  *                  (read when a forward is enqueued or a graph is built)
- *   "gemm.large" / "gemm.small": the k_gemm_dma tile (2..5) the shape rule uses for problems with >= / < 1024 tiles of 96 x 64 */
+ *   "gemm.large" / "gemm.small": the k_gemm_dma tile (2..5) the shape rule uses for problems with >= / < 1024 tiles of 96 x 64
+ *   "net.gvit_stream": GViT level 1 (embedding dim 384) on the LViT-3 stream kernels: 0 never, 1 in the single-lane plan only, 2 (default, round 5) on every
+ *                  plan -- which kernels produce the outputs does not depend on the launch plan or on profiling
+ *   "gvit.max_concurrent": 1 (default) .. 8: forwards of the persistent-chain plan ("net.gvit_chain") that may be in flight at once; the teams of all of them
+ *                  must be resident together (grid barriers), so the host caps a team at 256 / (groups x this) CUs
+ *   "lvit.shape": k_lvit_window's workgroup shape / schedule: 2 (default) 16 waves x 1 token tile, 0 8 x 2, 1 4 x 4, 3 denominator by MFMA, 4 / 5 the 16 x 1 / 8 x 2
+ *                  shapes with hand-issued K / V fragment reads (round 5: bitwise equal, not faster) */
 int cfen_tune(const char* key, int value);
 
 /* ---- whole generator: replaces define_G (v3:93-100) + dec_ipt.forward (v3:392-1020) ------------- */
@@ -68,7 +74,10 @@ typedef struct cfen_net_config {
 
 int cfen_net_create(cfen_net** out, const cfen_net_config* cfg);
 void cfen_net_destroy(cfen_net* net);
-/* bytes of device scratch the caller must pass to cfen_net_forward (256-byte aligned) */
+/* bytes of device scratch the caller must pass to cfen_net_forward (256-byte aligned).  The workspace belongs to ONE net: the first forward on a
+ * (workspace address, size) pair zeroes its synchronisation words with a launch on the caller's stream, graph capture zeroes them synchronously; the
+ * caller must not write into the workspace between forwards, and hands a new net a workspace of its own (stage maps of the last forward live there:
+ * cfen_net_stage). */
 size_t cfen_net_workspace_bytes(const cfen_net* net);
 /* register one packed parameter (layout: cfen_vit_dehazing_amd/packing.py); the pointer must stay
  * valid for the life of the net.  `nbytes` is checked against what the layer needs.               */
