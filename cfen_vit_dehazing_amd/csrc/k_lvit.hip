@@ -341,6 +341,8 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(NW / 4,
       }
       // row maximum: two chains of three-operand maxima (v_max3_f32: half the instructions of a two-operand tree; round 4)
       float mx = -1e30f, mx2 = -1e30f;
+      float rs = 0.f;
+      if constexpr (SM < 8) {
 #pragma unroll
       for (int t = 0; t < S / 16; ++t) {
         mx = fmaxf(fmaxf(mx, st[t][0]), st[t][1]);
@@ -348,7 +350,6 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(NW / 4,
       }
       mx = col_max(fmaxf(mx, mx2));
       const float mc = -mx * cs;
-      float rs = 0.f;
 #pragma unroll
       for (int t = 0; t < S / 16; ++t)
 #pragma unroll
@@ -356,6 +357,21 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(NW / 4,
           st[t][r] = __builtin_amdgcn_exp2f(fmaf(st[t][r], cs, mc));
           if constexpr (SM != 1) rs += st[t][r];
         }
+      } else {
+        // TIMING EXPERIMENT ONLY ("lvit.shape" 8 / 9, results invalid): SM = 8 drops the softmax's exp / sum (keeps the max), SM = 9 drops the whole
+        // softmax -- the raw scores go to the PV product.  What the kernel's time does when 60 % / 75 % of the attention loop's vector instructions
+        // disappear says whether it is bound by them (profiles/r05_lvit_window_disasm.txt)
+        if constexpr (SM == 8) {
+#pragma unroll
+          for (int t = 0; t < S / 16; ++t) {
+            mx = fmaxf(fmaxf(mx, st[t][0]), st[t][1]);
+            mx2 = fmaxf(fmaxf(mx2, st[t][2]), st[t][3]);
+          }
+          rs = col_max(fmaxf(mx, mx2)) + 2.f;
+        } else {
+          rs = 1.f;
+        }
+      }
       // SM = 1: the softmax denominator comes off the matrix pipe (idle three quarters of this loop): an all-ones A fragment against the
       // packed probabilities sums the 32 keys of a block for every query -- 8 MFMAs instead of 64 v_add_f32 and a cross-lane reduction, and
       // the sum is over the SAME fp16-rounded probabilities the numerator uses
@@ -553,6 +569,10 @@ int cfen_lvit_window_impl_g(int dtype, int ng, const LvitArgs* ap, hipStream_t s
     CFEN_LAUNCH((k_lvit_window<6, 16, 1, 2>), dim3((unsigned)blocks, 1, ng), dim3(1024), 0, s, ga);
   else if (cfen_tune_lvit_shape() == 5)
     CFEN_LAUNCH((k_lvit_window<6, 8, 2, 2>), dim3((unsigned)blocks, 1, ng), dim3(512), 0, s, ga);
+  else if (cfen_tune_lvit_shape() == 8)
+    CFEN_LAUNCH((k_lvit_window<6, 16, 1, 8>), dim3((unsigned)blocks, 1, ng), dim3(1024), 0, s, ga);
+  else if (cfen_tune_lvit_shape() == 9)
+    CFEN_LAUNCH((k_lvit_window<6, 16, 1, 9>), dim3((unsigned)blocks, 1, ng), dim3(1024), 0, s, ga);
   else if (cfen_tune_lvit_shape() == 1)
     CFEN_LAUNCH((k_lvit_window<6, 4, 4>), dim3((unsigned)blocks, 1, ng), dim3(256), 0, s, ga);
   else
