@@ -295,6 +295,14 @@ def main():
 
     net(x, out=slabs[0])                       # packs weights, builds the plan
     torch.cuda.synchronize()
+    # what-if probe (CFEN_BENCH_DUMMY_STREAMS=n, not a benchmark setting): n extra streams are created and touched before the graphs are built, so that the
+    # hardware queues the runtime hands to the two-lane graph's branch streams are already shared -- the difference between `--in-flight 1` on 8 queues
+    # (4.49 ms) and the one-forward leg of the default run, which holds four lane streams (2.75 ms): profiles/r05_ab_hw_queue_placement.txt
+    dummies = [torch.cuda.Stream(dev) for _ in range(int(os.environ.get("CFEN_BENCH_DUMMY_STREAMS", "0")))]
+    for ds in dummies:
+        with torch.cuda.stream(ds):
+            torch.zeros(16, device=dev).add_(1)
+    torch.cuda.synchronize()
     graphs = None
     nfl = args.in_flight
     lanes = [torch.cuda.Stream(dev) for _ in range(nfl)] if nfl > 1 else None
