@@ -250,8 +250,13 @@ int cfen_tune(const char* key, int value) {
     cfen_tune_embed_lds() = value & 7;
     return CFEN_OK;
   }
+  if (!strcmp(key, "embed.stages")) {
+    CFEN_CHECK_ARG(value >= 2 && value <= 5, "tune: embed.stages is 2 .. 5 ring stages of k_embed_qkv2 (D = 192)");
+    cfen_tune_embed_stages() = value;
+    return CFEN_OK;
+  }
   if (!strcmp(key, "mlp3.tm192")) {
-    CFEN_CHECK_ARG(value >= 2 && value <= 4, "tune: mlp3.tm192 is 2, 3 or 4");
+    CFEN_CHECK_ARG((value >= 2 && value <= 4) || value == 22 || value == 24, "tune: mlp3.tm192 is 2, 3 or 4 token tiles a wave (one workgroup a CU), 22 / 24 = 2 tiles at 256 registers on a 3- / 4-slot ring");
     cfen_tune_mlp3_tm192() = value;
     return CFEN_OK;
   }

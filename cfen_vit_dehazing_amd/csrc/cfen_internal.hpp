@@ -183,4 +183,5 @@ int& cfen_tune_tail_fused();     // 1 (default): us_conv_d01* + tail conv3 run a
 int& cfen_tune_keep_stages();    // 1: fused launches also store the stage maps they keep on chip (us_conv_d01*), for parity tests ("net.keep_stages"; default 0)
 // out (B, h, w, cs_out) = 4 x 4 mean of in (B, 4h, 4w, cs_in): GViT's avgpool . avgpool as a map (k_tokens.hip: k_pool4)
 int cfen_pool4_impl_g(int dtype, int ng, const void* const* in, void* const* out, int B, int h, int w, int C, int cs_in, int cs_out, hipStream_t s);
+int& cfen_tune_embed_stages();   // LDS-DMA ring stages of k_embed_qkv2 at D = 192 ("embed.stages": 2 .. 5, default 4)
 int& cfen_tune_gvit_stream();   // 1 (default): GViT blocks of embedding dim 384 run on the LViT-3 stream kernels (k_front3 / k_mlp3): 5 launches a block ("net.gvit_stream")

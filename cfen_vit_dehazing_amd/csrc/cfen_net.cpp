@@ -69,10 +69,10 @@ int& cfen_tune_stream_front() {   // k_front3 for the D = 384 LViT blocks: 0 nev
   static int v = 2;             // (with three forwards in flight the single encoder instance on the stream kernels is 0.03 ms better: one whole-CU launch of 64 workgroups instead of 8 GEMM launches)
   return v;
 }
-int& cfen_tune_stream_mlp192() {   // 1: LViT level 2 (D = 192) runs its proj + MLP block on k_mlp3<12, 3> instead of k_mlp2.  0 (default): MEASURED -- alone on the chip
-  static int v = 0;                // with cold caches k_mlp3 wins (154-162 us against 181-204 for the grouped decoder launch, tools/bench_mlp3.py), inside the
-  return v;                        // forward it loses (2.92 against 2.90 ms): it takes whole CUs (150 KB of LDS, 512 registers), the GViT lane beside it starves
-}
+int& cfen_tune_stream_mlp192() {   // LViT level 2 (D = 192) proj + MLP block: 1 (default, round 5) on k_mlp3 (fragment-stream weights, three-slot ring; mlp3.tm192 = 22: TWO 78 KB
+  static int v = 1;                // workgroups a CU at 256 registers -- k_mlp2's occupancy without its two-stage ring, whose chunk period is one LDS-DMA issue -> landed
+  return v;                        // latency: encoder 79.7 -> 56.4 us, grouped decoder launch 168.4 -> 128.2 us (961 TF), 2.148 -> 2.121 ms per step with four forwards in
+}                                  // flight, profiles/r05_ab_stream_mlp192_two_wgs_per_cu.txt); 0: k_mlp2.  (k_mlp3<12, 3> on one 150 KB workgroup a CU, rounds 3-4: equal to k_mlp2.)
 int& cfen_tune_stream_mlp() {   // k_mlp3 (k_stream.hip) for the D = 384 blocks: 0 never, 1 launches of >= 128 workgroups (at 512 x 512 the grouped
   static int v = 2;             // decoder launch; a single instance has 64 workgroups of 128 tokens: a quarter of the chip), 2 (default, round 4) always
   return v;

@@ -349,7 +349,23 @@ CFEN_DEV void eq_dma16(const void* g, unsigned char* l) {
   __builtin_amdgcn_global_load_lds(g, (__attribute__((address_space(3))) void*)l, 16, 0, 0);
 }
 
-template <int ND, int TM, int NW, int RS>
+// s_waitcnt vmcnt(n) for a wave-uniform run-time n <= 31 (the instruction takes an immediate)
+#define CFEN_EQ_VMCASE(k) case k: asm volatile("s_waitcnt vmcnt(" #k ")" ::: "memory"); break;
+CFEN_DEV void eq_wait_vmcnt(int n) {
+  switch (n) {
+    CFEN_EQ_VMCASE(0) CFEN_EQ_VMCASE(1) CFEN_EQ_VMCASE(2) CFEN_EQ_VMCASE(3) CFEN_EQ_VMCASE(4) CFEN_EQ_VMCASE(5) CFEN_EQ_VMCASE(6) CFEN_EQ_VMCASE(7)
+    CFEN_EQ_VMCASE(8) CFEN_EQ_VMCASE(9) CFEN_EQ_VMCASE(10) CFEN_EQ_VMCASE(11) CFEN_EQ_VMCASE(12) CFEN_EQ_VMCASE(13) CFEN_EQ_VMCASE(14) CFEN_EQ_VMCASE(15)
+    CFEN_EQ_VMCASE(16) CFEN_EQ_VMCASE(17) CFEN_EQ_VMCASE(18) CFEN_EQ_VMCASE(19) CFEN_EQ_VMCASE(20) CFEN_EQ_VMCASE(21) CFEN_EQ_VMCASE(22) CFEN_EQ_VMCASE(23)
+    CFEN_EQ_VMCASE(24) CFEN_EQ_VMCASE(25) CFEN_EQ_VMCASE(26) CFEN_EQ_VMCASE(27) CFEN_EQ_VMCASE(28) CFEN_EQ_VMCASE(29) CFEN_EQ_VMCASE(30) CFEN_EQ_VMCASE(31)
+    default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;      // (never taken for the shapes below; a full drain is always correct)
+  }
+}
+#undef CFEN_EQ_VMCASE
+
+// NS (round 5): ring stages.  With NS = 2 (rounds 2-4) the DMA of chunk c + 1 went out at the head of chunk c, whose 24 MFMAs per wave are over in ~400 cycles:
+// every chunk waited a whole LDS-DMA issue -> landed latency (~1.1 us), 24 chunks a workgroup.  NS - 1 chunks are in flight now; the landing wait is a COUNTED
+// vmcnt that leaves the younger chunks' DMAs (and, in the qkv loop, the tile stores issued since) outstanding.
+template <int ND, int TM, int NW, int RS, int NS = 2>
 __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_embed_qkv2(Grouped<CfenEmbedQkvArgs> ga) {
   typedef half_t T;
   const CfenEmbedQkvArgs a = ga.g[blockIdx.z];
@@ -363,8 +379,10 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(2, 2)))
   constexpr int GPT = NCH / 3;                        // fragment groups per row tile
   constexpr int NG = RT * GPT;                        // ... per chunk
   static_assert(RS % 16 == 0 && RS * PP1 % 64 == 0 && D % RS == 0 && NCH % 3 == 0, "chunk geometry");
+  constexpr int NC = NEC + NQC, PF = NS - 1;          // chunks; chunks in flight beyond the one being multiplied
+  static_assert(NS >= 2 && NS * STAGE <= 80 * 1024 && PF <= NEC && (PF - 1) * NI + PF * RT * TM <= 31, "ring geometry");
   typedef half8 frag;
-  __shared__ __attribute__((aligned(1024))) unsigned char lds[2 * STAGE];
+  __shared__ __attribute__((aligned(1024))) unsigned char lds[NS * STAGE];
   const int tid = threadIdx.x, lane = tid & 63, r16 = lane & 15, h = lane >> 4;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const long long tok0 = ((long long)blockIdx.x * NW + wave) * (TM * 16);   // the launcher guarantees M % (NW * TM * 16) == 0
@@ -383,7 +401,9 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(2, 2)))
       if (blk < NINS) eq_dma16(W + off[i], lds + buf * STAGE + blk * 1024);
     }
   };
-  issue(0, 0);
+#pragma unroll
+  for (int c = 0; c < PF; ++c) issue(c, c);
+  const int nd = (NINS - wave + NW - 1) / NW;         // DMA instructions THIS wave issues per chunk (wave-uniform)
 
   // ---- gather x^T into accumulator layout ----
   const int tw = a.ws / a.p, S = tw * tw, nwx = a.W / a.ws, nwy = a.H / a.ws;
@@ -431,10 +451,13 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(2, 2)))
   // ---- y = W_e x + (b_e + x + pos): embedding chunks (accumulator indices are compile-time) ----
   eq_static_for<0, NEC>([&](auto cc) {
     constexpr int c = decltype(cc)::value;
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    // chunk c has landed once at most the DMAs of the chunks issued after it are outstanding (chunk 0: the token gathers and bias / position loads of the
+    // prologue sit behind the ring's first DMAs -- one full drain)
+    if constexpr (c == 0 || NS == 2) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    else eq_wait_vmcnt((PF - 1 < NC - 1 - c ? PF - 1 : NC - 1 - c) * nd);
     __builtin_amdgcn_s_barrier();
-    issue(c + 1, (c + 1) & 1);                           // NEC < NEC + NQC: there is always a next chunk
-    const unsigned char* buf = lds + (c & 1) * STAGE;
+    if constexpr (c + PF < NC) issue(c + PF, (c + PF) % NS);      // into the slot of chunk c - 1, which every wave has left
+    const unsigned char* buf = lds + (c % NS) * STAGE;
     frag F[2][3];
     load_g(buf, std::integral_constant<int, 0>{}, F[0]);
     eq_static_for<0, NG>([&](auto gc) {
@@ -497,11 +520,13 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(2, 2)))
     const int c = NEC + cq;
     // chunk c has landed when at most the RT * TM tile stores issued after its DMA are still outstanding (first qkv chunk: the X1
     // stores and LayerNorm parameter loads sit behind the DMA too -- drain)
+    // (with NS stages: behind the DMA of chunk c come the tile stores of PF chunks and the DMAs of the up to PF - 1 younger chunks)
     if (cq == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(RT * TM) : "memory");
+    else if constexpr (NS == 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(RT * TM) : "memory");
+    else eq_wait_vmcnt((PF - 1 < NC - 1 - c ? PF - 1 : NC - 1 - c) * nd + (cq < PF ? cq : PF) * RT * TM);
     __builtin_amdgcn_s_barrier();
-    if (cq + 1 < NQC) issue(c + 1, (c + 1) & 1);
-    const unsigned char* buf = lds + (c & 1) * STAGE;
+    if (c + PF < NC) issue(c + PF, (c + PF) % NS);
+    const unsigned char* buf = lds + (c % NS) * STAGE;
     frag F[2][3];
     floatx4 q[TM];
     load_g(buf, std::integral_constant<int, 0>{}, F[0]);
@@ -529,7 +554,7 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(2, 2)))
   }
 }
 
-template <int ND, int TM, int NW, int RS>
+template <int ND, int TM, int NW, int RS, int NS = 2>
 int launch_embed_qkv2(int ng, const CfenEmbedQkvArgs* ap, hipStream_t s) {
   Grouped<CfenEmbedQkvArgs> ga;
   for (int g = 0; g < CFEN_MAX_GROUPS; ++g) ga.g[g] = ap[g < ng ? g : 0];
@@ -537,7 +562,7 @@ int launch_embed_qkv2(int ng, const CfenEmbedQkvArgs* ap, hipStream_t s) {
   CFEN_CHECK_ARG(ap[0].M % per == 0, "embed_qkv2: token count must be a multiple of %lld", per);
   const long long blocks = ap[0].M / per;
   CFEN_CHECK_ARG(blocks > 0 && blocks < (1ll << 31), "embed_qkv: bad grid");
-  CFEN_LAUNCH((k_embed_qkv2<ND, TM, NW, RS>), dim3((unsigned)blocks, 1, ng), dim3(NW * 64), 0, s, ga);
+  CFEN_LAUNCH((k_embed_qkv2<ND, TM, NW, RS, NS>), dim3((unsigned)blocks, 1, ng), dim3(NW * 64), 0, s, ga);
   CFEN_CHECK_LAUNCH("embed_qkv");
   return CFEN_OK;
 }
@@ -586,7 +611,11 @@ int run_embed_qkv(int ng, const CfenEmbedQkvArgs* ap, hipStream_t s) {
   if constexpr (sizeof(T) == 2) {   // the fp32 stages would not fit 64 KB of LDS
     if (lds & 4) {   // LDS-DMA ring + pipelined fragment groups (k_embed_qkv2); needs whole workgroups of tokens
       if (ap[0].D == 96 && ap[0].M % 256 == 0) return launch_embed_qkv2<6, 4, 4, 32>(ng, ap, s);
-      if (ap[0].D == 192 && ap[0].M % 128 == 0) return launch_embed_qkv2<12, 2, 4, 32>(ng, ap, s);
+      if (ap[0].D == 192 && ap[0].M % 128 == 0) {
+        const int ns = cfen_tune_embed_stages();
+        return ns == 2 ? launch_embed_qkv2<12, 2, 4, 32, 2>(ng, ap, s) : ns == 3 ? launch_embed_qkv2<12, 2, 4, 32, 3>(ng, ap, s)
+             : ns == 5 ? launch_embed_qkv2<12, 2, 4, 32, 5>(ng, ap, s) : launch_embed_qkv2<12, 2, 4, 32, 4>(ng, ap, s);
+      }
     }
     if (ap[0].D == 96 && (lds & 1)) return launch_embed_qkv_lds<T, 6, 4, 6>(ng, ap, s);
     if (ap[0].D == 192 && (lds & 2)) return launch_embed_qkv_lds<T, 12, 2, 4>(ng, ap, s);
@@ -601,6 +630,11 @@ int run_embed_qkv(int ng, const CfenEmbedQkvArgs* ap, hipStream_t s) {
 }
 
 }  // namespace
+
+int& cfen_tune_embed_stages() {   // ring stages of k_embed_qkv2 at D = 192 ("embed.stages"): 2 (rounds 2-4), 3, 4 (default, round 5), 5
+  static int v = 4;
+  return v;
+}
 
 int& cfen_tune_embed_lds() {
   static int v = 6;

@@ -89,8 +89,10 @@ CFEN_DEV half8 pack_pair(const floatx4& a, const floatx4& b) {
 // Measured with single phases (one barrier per ND fragments): 0.63 us a phase whether it held 12 or 24 KiB -- barrier skew, the refill of the
 // fragment pipeline and the DMA issue cost ~0.3 us each time, as much as the 48 MFMAs of the phase; one barrier per sub-step halves that.
 // DBG (timing experiments only, results invalid): 1 = no LDS-DMA refills after the prologue, 2 = no MFMAs in the hidden loop
-template <int ND, int TM, int R, int HB, int DBG = 0>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void k_mlp3(Grouped<Mlp3Args> ga) {
+// WPE (round 5): waves per SIMD the kernel is compiled for.  1 = the whole 512-register file for one wave per SIMD (one workgroup a CU); 2 = 256 registers,
+// so that TWO workgroups of a short ring (R = 3 slots of 24 KiB at D = 192: 78 KB) share a CU -- k_mlp2's occupancy on k_mlp3's fragment-stream ring.
+template <int ND, int TM, int R, int HB, int DBG = 0, int WPE = 1>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) void k_mlp3(Grouped<Mlp3Args> ga) {
   typedef half_t T;
   typedef half8 frag;
   const Mlp3Args a = ga.g[blockIdx.z];
@@ -571,22 +573,22 @@ int launch_front3(int ng, const CfenEmbedQkvArgs* ap, hipStream_t s) {
   return CFEN_OK;
 }
 
-template <int ND, int TM, int R, int HB, int DBG = 0>
+template <int ND, int TM, int R, int HB, int DBG = 0, int WPE = 1>
 int launch_mlp3(int ng, const Mlp3Args* ap, hipStream_t s) {
   Grouped<Mlp3Args> ga;
   for (int g = 0; g < CFEN_MAX_GROUPS; ++g) ga.g[g] = ap[g < ng ? g : 0];
   CFEN_CHECK_ARG(ap[0].H <= HB, "mlp3: hidden width %d exceeds the %d this variant stages biases for", ap[0].H, HB);
   const long long per = 4LL * TM * 16, blocks = (ap[0].M + per - 1) / per;
   CFEN_CHECK_ARG(blocks > 0 && blocks < (1ll << 31), "mlp3: bad grid");
-  CFEN_LAUNCH((k_mlp3<ND, TM, R, HB, DBG>), dim3((unsigned)blocks, 1, ng), dim3(256), 0, s, ga);
+  CFEN_LAUNCH((k_mlp3<ND, TM, R, HB, DBG, WPE>), dim3((unsigned)blocks, 1, ng), dim3(256), 0, s, ga);
   CFEN_CHECK_LAUNCH("mlp3");
   return CFEN_OK;
 }
 
 }  // namespace
 
-int& cfen_tune_mlp3_tm192() {   // token tiles per wave of the D = 192 variant: 4 (256 tokens a workgroup), 3 (192: the grouped LViT-2 decoder launch of 3 x 32768
-  static int v = 3;             // tokens is then exactly two rounds of 256 workgroups), 2
+int& cfen_tune_mlp3_tm192() {   // the D = 192 variant: 22 (default, round 5) = 2 token tiles a wave at 256 registers on a three-slot ring, two 78 KB workgroups a CU; 24 = the same
+  static int v = 22;            // on four slots (one workgroup a CU); 4 / 3 / 2 token tiles a wave on the six-slot ring of one 150 KB workgroup a CU (512 registers)
   return v;
 }
 int& cfen_tune_mlp3_debug() {
@@ -621,6 +623,8 @@ int cfen_mlp3_impl_g(int dtype, int ng, const Mlp3Args* ap, hipStream_t s) {
   if (ap[0].D == 384 && cfen_tune_mlp3_debug() == 1) return launch_mlp3<24, 2, 3, 1536, 1>(ng, ap, s);
   if (ap[0].D == 384 && cfen_tune_mlp3_debug() == 2) return launch_mlp3<24, 2, 3, 1536, 2>(ng, ap, s);
   if (ap[0].D == 384) return launch_mlp3<24, 2, 3, 1536>(ng, ap, s);
+  if (cfen_tune_mlp3_tm192() == 22) return launch_mlp3<12, 2, 3, 768, 0, 2>(ng, ap, s);   // two 78 KB workgroups a CU, three-slot ring (round 5 A/B)
+  if (cfen_tune_mlp3_tm192() == 24) return launch_mlp3<12, 2, 4, 768, 0, 2>(ng, ap, s);   // one 102 KB workgroup a CU at 256 registers, four slots
   if (cfen_tune_mlp3_tm192() == 3) return launch_mlp3<12, 3, 6, 768>(ng, ap, s);
   if (cfen_tune_mlp3_tm192() == 2) return launch_mlp3<12, 2, 6, 768>(ng, ap, s);
   return launch_mlp3<12, 4, 6, 768>(ng, ap, s);

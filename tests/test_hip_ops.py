@@ -383,6 +383,23 @@ def test_embed_qkv_fused_front(dtype, C, H, W, ws):
         ops.tune("embed.lds", 6)
     assert torch.equal(res[0][0], res[1][0]) and torch.equal(res[0][1], res[1][1])
     assert torch.equal(res[0][0], res[2][0]) and torch.equal(res[0][1], res[2][1])
+    if dtype == torch.float16 and D == 192:
+        # the ring depth of k_embed_qkv2 (round 5: 4 stages by default, counted vmcnt waits that leave the younger chunks' DMAs and the tile stores outstanding)
+        try:
+            ops.tune("embed.lds", 4)
+            for ns in (2, 3, 5):
+                ops.tune("embed.stages", ns)
+                for hm in (0, D // 24):
+                    a_, b_ = ops.embed_qkv(fmap, C, ws, p, we[:, perm].contiguous().to(d), be.to(d), pos.to(d), g.to(d), b.to(d), wq[:, perm].contiguous().to(d),
+                                           head_major_heads=hm)
+                    ops.tune("embed.stages", 4)
+                    c_, d_ = ops.embed_qkv(fmap, C, ws, p, we[:, perm].contiguous().to(d), be.to(d), pos.to(d), g.to(d), b.to(d), wq[:, perm].contiguous().to(d),
+                                           head_major_heads=hm)
+                    ops.tune("embed.stages", ns)
+                    assert torch.equal(a_, c_) and torch.equal(b_, d_), "embed.stages %d differs from 4" % ns
+        finally:
+            ops.tune("embed.stages", 4)
+            ops.tune("embed.lds", 6)
     x1, qkv = res[1]
     # head-major store (input layout of cfen_attention_head_major): the same values, laid out per (window, head)
     heads = D // 24
@@ -799,6 +816,19 @@ def test_mlp_stream_block(D, H, M):
     close(got, full, tol(dtype, 12), "projection prologue + both stages")
     again = ops.mlp_stream_block(x.to(d), sa, b1a.to(d), b2a.to(d), H, ln=(g.to(d), b.to(d)), second=(sb, b1b.to(d), b2b.to(d)), proj=(att.to(d), sp))
     assert torch.equal(got, again)
+    if D == 192:
+        # the workgroup shapes of the D = 192 variant (default 22: two 78 KB workgroups a CU on a three-slot ring, 256 registers; 24: four slots; 2 / 3 / 4 token
+        # tiles a wave on the six-slot ring of one workgroup a CU) do the same arithmetic per token in the same order
+        try:
+            for tm in (24, 3, 4, 2):
+                ops.tune("mlp3.tm192", tm)
+                other = ops.mlp_stream_block(x.to(d), sa, b1a.to(d), b2a.to(d), H, ln=(g.to(d), b.to(d)), second=(sb, b1b.to(d), b2b.to(d)), proj=(att.to(d), sp))
+                if tm == 2:     # (the two-tile shape on 512 registers: hipcc contracts one epilogue product differently -- 1 fp16 ulp on a handful of elements)
+                    assert float((got.float() - other.float()).abs().max()) <= 2e-3
+                else:
+                    assert torch.equal(got, other), "mlp3.tm192 = %d differs from the default shape" % tm
+        finally:
+            ops.tune("mlp3.tm192", 22)
 
 
 def test_mlp_stream_fold_epilogue():

@@ -36,11 +36,11 @@ def run(D, M, hdr=4):
     t3 = timeit(lambda: ops.mlp_stream_block(x, sa, b1, b2, H, ln=(g, b), second=(sb, b1, b2), proj=(att, sp)))
     out = {"D": D, "M": M, "H": H, "k_mlp3_us": round(t3, 1), "k_mlp3_TF": round(fl / t3 / 1e6, 1)}
     if D == 192:
-        for tm in (2, 3, 4):
+        for tm in (2, 3, 4, 22, 24):
             ops.tune("mlp3.tm192", tm)
             tt = timeit(lambda: ops.mlp_stream_block(x, sa, b1, b2, H, ln=(g, b), second=(sb, b1, b2), proj=(att, sp)))
             out["k_mlp3_tm%d_us" % tm] = round(tt, 1)
-        ops.tune("mlp3.tm192", 3)
+        ops.tune("mlp3.tm192", 22)
     if D in (96, 192):
         w = lambda a_, k_: a_[:, k_].contiguous()
         t2 = timeit(lambda: ops.mlp_block(x, w(w1a, kd), b1, w(w2a, kh), b2, ln=(g, b), second=(w(w1b, kd), b1, w(w2b, kh), b2), proj=(att, wp)))
