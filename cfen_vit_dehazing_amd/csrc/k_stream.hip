@@ -91,12 +91,14 @@ CFEN_DEV half8 pack_pair(const floatx4& a, const floatx4& b) {
 // DBG (timing experiments only, results invalid): 1 = no LDS-DMA refills after the prologue, 2 = no MFMAs in the hidden loop
 // WPE (round 5): waves per SIMD the kernel is compiled for.  1 = the whole 512-register file for one wave per SIMD (one workgroup a CU); 2 = 256 registers,
 // so that TWO workgroups of a short ring (R = 3 slots of 24 KiB at D = 192: 78 KB) share a CU -- k_mlp2's occupancy on k_mlp3's fragment-stream ring.
-template <int ND, int TM, int R, int HB, int DBG = 0, int WPE = 1>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) void k_mlp3(Grouped<Mlp3Args> ga) {
+// NW (round 5): waves per workgroup.  4 = one per SIMD; 8 with TM = 1 and WPE = 2 = the same 128 tokens a workgroup on two waves per SIMD (each covers the
+// other's DMA issue and waits) at twice the LDS fragment reads per token -- the D = 384 A/B of this round.
+template <int ND, int TM, int R, int HB, int DBG = 0, int WPE = 1, int NW = 4>
+__global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) void k_mlp3(Grouped<Mlp3Args> ga) {
   typedef half_t T;
   typedef half8 frag;
   const Mlp3Args a = ga.g[blockIdx.z];
-  constexpr int NW = 4, D = ND * 16, NCH = ND / 2, NF = 2 * ND, SLOT = NF * 1024, DPW = NF / NW, RING = R * SLOT;
+  constexpr int D = ND * 16, NCH = ND / 2, NF = 2 * ND, SLOT = NF * 1024, DPW = NF / NW, RING = R * SLOT;
   static_assert(NF % NW == 0 && NCH % 2 == 0 && R >= 3 && (R - 2) * DPW < 64 && HB % 256 == 0, "ring geometry");
   static_assert(RING + 2 * HB * 4 <= 160 * 1024, "LDS");
   __shared__ __attribute__((aligned(1024))) unsigned char lds[RING + 2 * HB * 4];
@@ -573,14 +575,14 @@ int launch_front3(int ng, const CfenEmbedQkvArgs* ap, hipStream_t s) {
   return CFEN_OK;
 }
 
-template <int ND, int TM, int R, int HB, int DBG = 0, int WPE = 1>
+template <int ND, int TM, int R, int HB, int DBG = 0, int WPE = 1, int NW = 4>
 int launch_mlp3(int ng, const Mlp3Args* ap, hipStream_t s) {
   Grouped<Mlp3Args> ga;
   for (int g = 0; g < CFEN_MAX_GROUPS; ++g) ga.g[g] = ap[g < ng ? g : 0];
   CFEN_CHECK_ARG(ap[0].H <= HB, "mlp3: hidden width %d exceeds the %d this variant stages biases for", ap[0].H, HB);
-  const long long per = 4LL * TM * 16, blocks = (ap[0].M + per - 1) / per;
+  const long long per = (long long)NW * TM * 16, blocks = (ap[0].M + per - 1) / per;
   CFEN_CHECK_ARG(blocks > 0 && blocks < (1ll << 31), "mlp3: bad grid");
-  CFEN_LAUNCH((k_mlp3<ND, TM, R, HB, DBG, WPE>), dim3((unsigned)blocks, 1, ng), dim3(256), 0, s, ga);
+  CFEN_LAUNCH((k_mlp3<ND, TM, R, HB, DBG, WPE, NW>), dim3((unsigned)blocks, 1, ng), dim3(NW * 64), 0, s, ga);
   CFEN_CHECK_LAUNCH("mlp3");
   return CFEN_OK;
 }
@@ -622,6 +624,7 @@ int cfen_mlp3_impl_g(int dtype, int ng, const Mlp3Args* ap, hipStream_t s) {
   }
   if (ap[0].D == 384 && cfen_tune_mlp3_debug() == 1) return launch_mlp3<24, 2, 3, 1536, 1>(ng, ap, s);
   if (ap[0].D == 384 && cfen_tune_mlp3_debug() == 2) return launch_mlp3<24, 2, 3, 1536, 2>(ng, ap, s);
+  if (ap[0].D == 384 && cfen_tune_mlp3_debug() == 8) return launch_mlp3<24, 1, 3, 1536, 0, 2, 8>(ng, ap, s);   // round-5 A/B: 8 waves x 1 tile, two waves per SIMD
   if (ap[0].D == 384) return launch_mlp3<24, 2, 3, 1536>(ng, ap, s);
   if (cfen_tune_mlp3_tm192() == 22) return launch_mlp3<12, 2, 3, 768, 0, 2>(ng, ap, s);   // two 78 KB workgroups a CU, three-slot ring (round 5 A/B)
   if (cfen_tune_mlp3_tm192() == 24) return launch_mlp3<12, 2, 4, 768, 0, 2>(ng, ap, s);   // one 102 KB workgroup a CU at 256 registers, four slots
