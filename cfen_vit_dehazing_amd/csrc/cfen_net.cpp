@@ -705,16 +705,18 @@ int cfen_net::run_vit_g(int ng, const VitCall* vc, int scr0) {
     TRYP(K_TOKEN, 0, cfen_upsample4_impl_g(dt, ng, cSM, OUT, B, v.mapH, v.mapH, v.C, v.C, bo.cs, stream));
     return CFEN_OK;
   }
-  if (v.chain && (cfen_tune_gvit_chain() == 1 || cfen_tune_gvit_chain() == 4 || (cfen_tune_gvit_chain() == 2 && ng > 1) || (cfen_tune_gvit_chain() == 3 && ng == 1))) {
+  if (v.chain && (cfen_tune_gvit_chain() == 1 || cfen_tune_gvit_chain() == 4 || cfen_tune_gvit_chain() == 5 || (cfen_tune_gvit_chain() == 2 && ng > 1) || (cfen_tune_gvit_chain() == 3 && ng == 1))) {
     // GViT block: pooled patch tokens -> [embed -> qkv] -> attention -> [proj -> ffn1 -> ffn2 -> head1 -> head2 + fold] -> x4 bilinear; the two
     // bracketed runs are ONE persistent launch each (k_gvit.hip): a team of workgroups per block keeps its CUs over the whole run
     const int team = std::max(1, std::min(cfen_tune_gvit_team(), 256 / (ng * std::max(1, cfen_tune_gvit_max_concurrent()))));   // every team of every forward in flight must be RESIDENT at once (grid barrier)
-    const bool per_gemm = cfen_tune_gvit_chain() == 4;   // every GEMM its own launch of the chain kernel, never split over K: no grid barrier, no split-K seam
+    const bool per_gemm = cfen_tune_gvit_chain() >= 4;   // 4: every GEMM its own launch of the chain kernel, never split over K: no grid barrier, no split-K seam;
+                                                         // 5 (round 5 A/B): as 4 with K split so that a launch has ~a workgroup per CU (in-launch split-K seam, no grid barrier)
+    const int split_team = cfen_tune_gvit_chain() == 5 ? 256 / ng : team;
     auto nsp = [&](int N, int K) {   // K slices so that the phase has work for most of the team (>= 4 K-steps of 64 per slice)
       int n = 1;
-      if (per_gemm) return n;
+      if (cfen_tune_gvit_chain() == 4) return n;
       const int units = ((M + 127) / 128) * (N / 128);
-      while (units * n * 2 <= team && n < 8 && (K / 64) % (2 * n) == 0 && K / 64 / (2 * n) >= 4) n *= 2;
+      while (units * n * 2 <= split_team && n < 8 && (K / 64) % (2 * n) == 0 && K / 64 / (2 * n) >= 4) n *= 2;
       return n;
     };
     auto sync_of = [&](int g, CfenChainArgs& c) {
@@ -753,10 +755,11 @@ int cfen_net::run_vit_g(int ng, const VitCall* vc, int scr0) {
           one[g].ph[0] = ca[g].ph[p];
           one[g].nph = 1;
         }
-        const int units = ((M + 127) / 128) * (one[0].ph[0].N / 128);
+        const int units = ((M + 127) / 128) * (one[0].ph[0].N / 128) * std::max(1, one[0].ph[0].nsplit);
         const std::string lab = std::string(what) + "." + std::to_string(p);
         step(lab.c_str());
-        TRYP(K_GEMM, fl / nph, cfen_gvit_chain_impl_g(dt, ng, one, std::min(team, units), stream));
+        // (no grid barrier in a one-phase launch: the residency cap of the persistent chains does not apply)
+        TRYP(K_GEMM, fl / nph, cfen_gvit_chain_impl_g(dt, ng, one, std::min(256 / ng, units), stream));
       }
       return CFEN_OK;
     };

@@ -229,7 +229,7 @@ class dec_ipt(nn.Module):
             # until GV_SPIN_LIMIT and then continuing with unsynchronised data (csrc/k_gvit.hip) -- refused here
             from . import ops
             allowed = ops.tuned("gvit.max_concurrent", 1)
-            if int(self.replica) >= allowed:
+            if int(self.replica) >= allowed and ops.tuned("net.gvit_chain", 1) not in (4, 5):      # (4 / 5: one launch per GEMM, no grid barrier)
                 raise CfenError("CFEN_GVIT_CHAIN=1: replica %d would put %d chain plans in flight, the grid barriers are sized for %d "
                                 "(ops.tune('gvit.max_concurrent', n) BEFORE building the nets caps the teams accordingly)"
                                 % (self.replica, int(self.replica) + 1, allowed))

@@ -149,7 +149,7 @@ def test_wrong_input_size_raises():
         net(torch.zeros(1, 3, 128, 128))                          # CPU tensor: no fallback
 
 
-@pytest.mark.parametrize("load_size,nimg,precision,levels", [(64, 3, "single", 1), (256, 1, "single", 1), (256, 1, "half", 6)])
+@pytest.mark.parametrize("load_size,nimg,precision,levels", [(64, 3, "single", 1), (256, 1, "half", 6)])
 def test_cli_end_to_end_writes_reference_named_pngs(tmp_path, load_size, nimg, precision, levels):
     """python test.py with the reference's README flags on a synthetic checkpoint: PNGs land where the
     reference puts them and equal tensor2im(oracle output) up to one grey level (fp16: 6 levels = 0.047 of the [-1, 1] range, the fp16
@@ -252,6 +252,35 @@ def test_split_k_and_grouping_knobs_do_not_change_results():
 
 # ---- the benchmarked configurations themselves (BASELINE.json configs 2, 4, 5), fp16, replayed from the hipGraph ----------------
 
+def _psnr_ssim_on_device(a, b):
+    """cfen_oracle.psnr / ssim (the metric definitions of the fixtures: peak 2, 11 x 11 Gaussian window, sigma 1.5, float64) evaluated on the GPU for whole
+    512 x 512 / 1024 x 1024 planes of whole batches -- on the host these comparisons were a quarter of the GPU suite's wall time"""
+    import torch.nn.functional as F
+    a, b = a.double(), b.double()
+    mse = torch.mean((a - b) ** 2)
+    psnr = float(10 * torch.log10(4.0 / mse)) if float(mse) > 0 else float("inf")
+    a01, b01 = (a + 1) / 2, (b + 1) / 2
+    g = torch.exp(-((torch.arange(11, dtype=torch.float64, device=a.device) - 5) ** 2) / (2 * 1.5 * 1.5))
+    g = g / g.sum()
+    C = a.shape[1]
+    w = (g[:, None] * g[None, :]).expand(C, 1, 11, 11).contiguous()
+    mu1, mu2 = F.conv2d(a01, w, padding=5, groups=C), F.conv2d(b01, w, padding=5, groups=C)
+    s11 = F.conv2d(a01 * a01, w, padding=5, groups=C) - mu1 * mu1
+    s22 = F.conv2d(b01 * b01, w, padding=5, groups=C) - mu2 * mu2
+    s12 = F.conv2d(a01 * b01, w, padding=5, groups=C) - mu1 * mu2
+    C1, C2 = 0.01 ** 2, 0.03 ** 2
+    m = ((2 * mu1 * mu2 + C1) * (2 * s12 + C2)) / ((mu1 * mu1 + mu2 * mu2 + C1) * (s11 + s22 + C2))
+    return psnr, float(m.mean())
+
+
+def test_device_side_psnr_ssim_equal_the_oracle_definitions():
+    g = torch.Generator().manual_seed(3)
+    a = torch.rand(1, 3, 96, 80, generator=g) * 2 - 1
+    b = (a + 0.05 * torch.randn(a.shape, generator=g)).clamp(-1, 1)
+    p, s = _psnr_ssim_on_device(a.to("cuda:0"), b.to("cuda:0"))
+    assert abs(p - cfen_oracle.psnr(a, b)) < 1e-9 and abs(s - cfen_oracle.ssim(a, b)) < 1e-12
+
+
 def _crop(t):
     n = t.shape[-1]
     c0 = n // 2 - 32
@@ -299,14 +328,13 @@ def test_fp16_benchmark_configs_graph_replay_vs_reference_vectors(name, batch):
         _, b8, z8 = load_net_fixture("full512b8_nf24_hdr4")
         assert b8 == batch == 8
         w8 = check_outputs(z8, outs, FP16_BAR)
-        xc = x.float().cpu()
         worst_dp = worst_ds = 0.0
         for nm, o in zip(("xr", "xs", "xd"), outs):
             oc = o.float().cpu()
             for b in range(batch):
-                t = xc[b:b + 1, :oc.shape[1]]
-                worst_dp = max(worst_dp, abs(cfen_oracle.psnr(oc[b:b + 1], t) - float(z8["full_psnr/" + nm][b])))
-                worst_ds = max(worst_ds, abs(cfen_oracle.ssim(oc[b:b + 1], t) - float(z8["full_ssim/" + nm][b])))
+                pp, ss = _psnr_ssim_on_device(o[b:b + 1], x[b:b + 1, :o.shape[1]])
+                worst_dp = max(worst_dp, abs(pp - float(z8["full_psnr/" + nm][b])))
+                worst_ds = max(worst_ds, abs(ss - float(z8["full_ssim/" + nm][b])))
             n = oc.shape[-1]
             d = float((oc[0:1, :, n // 2 - 128:n // 2 + 128, n // 2 - 128:n // 2 + 128] - torch.from_numpy(z8["crop256/" + nm])).abs().max())
             assert d <= FP16_BAR, "%s: 256 x 256 crop of image 0 differs by %.3e" % (nm, d)
@@ -318,17 +346,15 @@ def test_fp16_benchmark_configs_graph_replay_vs_reference_vectors(name, batch):
         _, bb, zb = load_net_fixture(name.replace("full512", "full512b16").replace("full1024", "full1024b4"))
         assert bb == batch
         wb = check_outputs(zb, outs, FP16_BAR)
-        xc = x.float().cpu()
         worst_dp = worst_ds = 0.0
         for nm, o in zip(("xr", "xs", "xd"), outs):
-            oc = o.float().cpu()
             for b in range(batch):
-                t = xc[b:b + 1, :oc.shape[1]]
-                worst_dp = max(worst_dp, abs(cfen_oracle.psnr(oc[b:b + 1], t) - float(zb["full_psnr/" + nm][b])))
-                worst_ds = max(worst_ds, abs(cfen_oracle.ssim(oc[b:b + 1], t) - float(zb["full_ssim/" + nm][b])))
+                pp, ss = _psnr_ssim_on_device(o[b:b + 1], x[b:b + 1, :o.shape[1]])
+                worst_dp = max(worst_dp, abs(pp - float(zb["full_psnr/" + nm][b])))
+                worst_ds = max(worst_ds, abs(ss - float(zb["full_ssim/" + nm][b])))
         print("   all %d images vs the reference's batch vectors: max-abs %.2e; whole-image dPSNR %.4f dB, dSSIM %.2e" % (batch, wb, worst_dp, worst_ds))
         assert worst_dp <= 0.01 and worst_ds <= 1e-4
-    for i in sorted({1, batch // 2, batch - 1}):
+    for i in (batch - 1,):           # (every image is checked against the reference's own batch forward above; one batch-1 forward keeps the batch-invariance check)
         one = net(x[i:i + 1].clone())
         for a, b in zip(outs, one):
             d = float((a[i:i + 1] - b).abs().max())
