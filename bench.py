@@ -12,8 +12,8 @@ and output slab, shared weights) on as many streams, so several forwards are in 
 GPU, 3 per rank beside the all-gather stream; one hardware queue per stream: GPU_MAX_HW_QUEUES=8 is exported below);
 all K steps complete inside the timed region, and the same line reports ONE forward at a time as well
 (pipelining.one_forward_in_flight).  With N > 1 every rank runs its own 8 images (weak scaling,
-weights replicated) and the per-rank output slab is all-gathered with RCCL; the gather of step i
-overlaps the forward of step i+1 on a side stream and the last one is waited for inside the timed region.
+weights replicated) and the per-rank output slab is all-gathered with RCCL; the gather of step i is launched from
+the lane that ran step i and overlaps the forwards of the other lanes; the last ones are waited for inside the timed region.
 Rank 0 prints ONE JSON line.
 """
 import argparse
@@ -335,7 +335,7 @@ def main():
                 net(x, out=s)
                 net.replica = 0
             if gather is not None:
-                gather.launch(s, k)                # async all-gather on the communication stream
+                gather.launch(s, k)                # wire conversion on this lane, then the all-gather handed to torch asynchronously (parallel.OutputGatherer)
             elif fake_comm[0]:
                 # what-if probe (CFEN_BENCH_FAKE_COMM_CYCLES=n, results are not a benchmark line): a one-workgroup kernel of n cycles per step on its own
                 # stream behind the forward -- the footprint of an always-busy communication queue beside the --in-flight lanes on ONE GPU
