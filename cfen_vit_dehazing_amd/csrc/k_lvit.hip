@@ -96,7 +96,9 @@ CFEN_DEV half8 lv_pack(floatx4 a, floatx4 b) {
 
 // ND = D / 16 (6); NW waves x TM token tiles of 16 = the 256 tokens of one window (16 x 1 at four waves per SIMD: the default; 8 x 2 at two;
 // 4 x 4 with one wave per SIMD and the whole 512-register file); 4 heads of 24
-template <int ND, int NW, int TM, int SM = 0>   // SM = 0: softmax denominator summed on the vector pipe; 1: on the matrix pipe (round 4; MEASURED SLOWER: 138 / 395 us against
+// FR (round 5): 1 = the embedding and K / V matrices stream in chunks of 64 rows (12 fragments: what a stage holds for the MLP chunks anyway) instead of 32 --
+// 5 barrier-separated chunks in front of the attention instead of 9, each with 12 MFMAs per wave instead of 6; same fragment stream, same arithmetic, same bits.
+template <int ND, int NW, int TM, int SM = 0, int FR = 0>   // SM = 0: softmax denominator summed on the vector pipe; 1: on the matrix pipe (round 4; MEASURED SLOWER: 138 / 395 us against
                                                 // 131 / 381 us for 512 / 1536 windows, tools/bench_lvit_window.py -- "lvit.shape" = 3 runs it); 2 (round 5): as 0 with the K / V
                                                 // fragment reads of the attention loops issued by hand, LV_KPD / one key block ahead of the MFMAs ("lvit.shape" = 4)
 __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(NW / 4, NW / 4))) void k_lvit_window(Grouped<LvitArgs> ga) {
@@ -120,16 +122,22 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(NW / 4,
   const int tid = threadIdx.x, lane = tid & 63, r16 = lane & 15, h = lane >> 4;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int nhc = a.Hm / 32;
-  constexpr int NE = D / 32, NKV = 2 * D / 32, NA = NH;    // embedding / K+V / attention chunks
+  constexpr int NE = FR ? 2 : D / 32, NKV = FR ? D / 32 : 2 * D / 32, NA = NH;    // embedding / K+V / attention chunks (FR: 64 + 32 rows, then 3 x 64)
+  constexpr int NFRONT = (D / 32 + 2 * D / 32) * N1;       // fragments in front of the attention chunks (either chunking)
   const int nchunks = NE + NKV + NA + 2 * nhc;
 
   // ---- DMA plan: instruction i of this wave copies fragment i * NW + wave of the chunk (the stream is in consumption order) ----
   // chunk t of the stream: NE embedding + NKV key / value chunks of N1 fragments, then NA attention and 2 * nhc MLP chunks of N1 + N2
   const unsigned char* const ws = (const unsigned char*)a.Ws;
-  auto nfrag_of = [&](int t) { return t < NE + NKV ? N1 : N1 + N2; };
+  auto nfrag_of = [&](int t) { return FR ? (t == 1 ? N1 : N1 + N2) : (t < NE + NKV ? N1 : N1 + N2); };
+  auto fstart_of = [&](int t) {                              // first fragment of chunk t in the stream
+    if (t >= NE + NKV) return NFRONT + (t - NE - NKV) * (N1 + N2);
+    if (!FR) return t * N1;
+    return t == 0 ? 0 : t == 1 ? 2 * N1 : 3 * N1 + (t - 2) * 2 * N1;
+  };
   auto issue = [&](int t, int buf) -> int {                  // returns the number of DMA instructions THIS wave issued
     const int nf = nfrag_of(t);
-    const unsigned char* src = ws + (size_t)(t < NE + NKV ? t * N1 : (NE + NKV) * N1 + (t - NE - NKV) * (N1 + N2)) * 1024 + lane * 16;
+    const unsigned char* src = ws + (size_t)fstart_of(t) * 1024 + lane * 16;
     const int m = t - NE - NKV - NA;                         // MLP chunk index (bias b1 of its 32 hidden units rides behind the fragments)
     const unsigned char* bsrc = m < 0 ? nullptr : (const unsigned char*)(m >= nhc ? a.b1b : a.b1a) + (size_t)(m >= nhc ? m - nhc : m) * 128 + min(lane, 7) * 16;
     int n = 0;
@@ -248,16 +256,21 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(NW / 4,
   lv_static_for<0, NE>([&](auto cc) {
     constexpr int c = decltype(cc)::value;
     const unsigned char* buf = begin_chunk(c);
-    frag F[2][3];
-    load_r1(buf, 0, F[0]);
-    load_r1(buf, 1, F[1]);
-    __builtin_amdgcn_sched_barrier(0);
+    constexpr int NP = FR ? (c == 0 ? 2 : 1) : 1;             // pairs of 16-row tiles in this chunk
+    constexpr int T0 = FR ? (c == 0 ? 0 : 4) : c * 2;         // first accumulator (feature) tile of the chunk
+    lv_static_for<0, NP>([&](auto pc) {
+      constexpr int pr = decltype(pc)::value;
+      frag F[2][3];
+      load_r1(buf, 2 * pr, F[0]);
+      load_r1(buf, 2 * pr + 1, F[1]);
+      __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-    for (int u = 0; u < 2; ++u)
+      for (int u = 0; u < 2; ++u)
 #pragma unroll
-      for (int k = 0; k < 3; ++k)
+        for (int k = 0; k < 3; ++k)
 #pragma unroll
-        for (int j = 0; j < TM; ++j) acc[c * 2 + u][j] = Mma<T>::mma(F[u][k], xb[k][j], acc[c * 2 + u][j]);
+          for (int j = 0; j < TM; ++j) acc[T0 + 2 * pr + u][j] = Mma<T>::mma(F[u][k], xb[k][j], acc[T0 + 2 * pr + u][j]);
+    });
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   });
   layer_norm_to_xb(a.ln1_g, a.ln1_b);        // acc keeps x1 (the residual stream); xb = LN1(x1)
@@ -266,25 +279,29 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(NW / 4,
 #pragma unroll 1
   for (int c = 0; c < NKV; ++c) {
     const unsigned char* buf = begin_chunk(NE + c);
-    frag F[2][3];
-    load_r1(buf, 0, F[0]);
-    load_r1(buf, 1, F[1]);
-    __builtin_amdgcn_sched_barrier(0);
+    constexpr int NP = FR ? 2 : 1;                           // pairs of 16-row tiles per chunk
 #pragma unroll
-    for (int u = 0; u < 2; ++u) {
-      floatx4 q[TM];
+    for (int pr = 0; pr < NP; ++pr) {
+      frag F[2][3];
+      load_r1(buf, 2 * pr, F[0]);
+      load_r1(buf, 2 * pr + 1, F[1]);
+      __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-      for (int j = 0; j < TM; ++j) q[j] = floatx4{0.f, 0.f, 0.f, 0.f};
+      for (int u = 0; u < 2; ++u) {
+        floatx4 q[TM];
 #pragma unroll
-      for (int k = 0; k < 3; ++k)
+        for (int j = 0; j < TM; ++j) q[j] = floatx4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int j = 0; j < TM; ++j) q[j] = Mma<T>::mma(F[u][k], xb[k][j], q[j]);
-      const int t = c * 2 + u;                           // feature tile 0..11: K tiles 0..5, V tiles 0..5
-      unsigned char* base = lds + (t < ND ? KOFF : VOFF) + (t < ND ? t : t - ND) * 32 + 8 * h;
+        for (int k = 0; k < 3; ++k)
 #pragma unroll
-      for (int j = 0; j < TM; ++j) {
-        const half4 v = {(half_t)q[j][0], (half_t)q[j][1], (half_t)q[j][2], (half_t)q[j][3]};
-        *reinterpret_cast<half4*>(base + tok[j] * KVP) = v;
+          for (int j = 0; j < TM; ++j) q[j] = Mma<T>::mma(F[u][k], xb[k][j], q[j]);
+        const int t = (c * NP + pr) * 2 + u;               // feature tile 0..11: K tiles 0..5, V tiles 0..5
+        unsigned char* base = lds + (t < ND ? KOFF : VOFF) + (t < ND ? t : t - ND) * 32 + 8 * h;
+#pragma unroll
+        for (int j = 0; j < TM; ++j) {
+          const half4 v = {(half_t)q[j][0], (half_t)q[j][1], (half_t)q[j][2], (half_t)q[j][3]};
+          *reinterpret_cast<half4*>(base + tok[j] * KVP) = v;
+        }
       }
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -569,6 +586,8 @@ int cfen_lvit_window_impl_g(int dtype, int ng, const LvitArgs* ap, hipStream_t s
     CFEN_LAUNCH((k_lvit_window<6, 16, 1, 2>), dim3((unsigned)blocks, 1, ng), dim3(1024), 0, s, ga);
   else if (cfen_tune_lvit_shape() == 5)
     CFEN_LAUNCH((k_lvit_window<6, 8, 2, 2>), dim3((unsigned)blocks, 1, ng), dim3(512), 0, s, ga);
+  else if (cfen_tune_lvit_shape() == 6)
+    CFEN_LAUNCH((k_lvit_window<6, 16, 1, 0, 1>), dim3((unsigned)blocks, 1, ng), dim3(1024), 0, s, ga);
   else if (cfen_tune_lvit_shape() == 8)
     CFEN_LAUNCH((k_lvit_window<6, 16, 1, 8>), dim3((unsigned)blocks, 1, ng), dim3(1024), 0, s, ga);
   else if (cfen_tune_lvit_shape() == 9)

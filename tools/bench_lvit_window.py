@@ -43,7 +43,7 @@ for B in (8, 24):
     a, b = chain(), fused()
     torch.cuda.synchronize()
     print("B=%d: fused vs chain max-abs %.3e" % (B, float((a.float() - b.float()).abs().max())))
-    tc, tf, tg, th, t5, t0, t8, t9 = [], [], [], [], [], [], [], []
+    tc, tf, tg, th, t5, t0, t8, t9, t6 = [], [], [], [], [], [], [], [], []
     ops.tune("lvit.shape", 4)
     p4 = fused(); torch.cuda.synchronize()
     ops.tune("lvit.shape", 2)
@@ -57,11 +57,14 @@ for B in (8, 24):
         ops.tune("lvit.shape", 0); t0.append(timed(fused))
         ops.tune("lvit.shape", 8); t8.append(timed(fused))
         ops.tune("lvit.shape", 9); t9.append(timed(fused))
+        ops.tune("lvit.shape", 6); t6.append(timed(fused))
     ops.tune("lvit.shape", 1)
     c = fused(); torch.cuda.synchronize()
     ops.tune("lvit.shape", 0)
     print("B=%d: 4-wave variant vs chain max-abs %.3e" % (B, float((a.float() - c.float()).abs().max())))
-    tc.sort(); tf.sort(); tg.sort(); th.sort(); t5.sort(); t0.sort(); t8.sort(); t9.sort()
+    tc.sort(); tf.sort(); tg.sort(); th.sort(); t5.sort(); t0.sort(); t8.sort(); t9.sort(); t6.sort()
+    ops.tune("lvit.shape", 6); p6 = fused(); torch.cuda.synchronize(); ops.tune("lvit.shape", 2)
+    print("B=%d (%d windows): 64-row front chunks (lvit.shape 6) %.1f us against %.1f us, bitwise equal: %s" % (B, nwin, t6[3], tf[3], bool(torch.equal(p6, fused()))))
     print("B=%d (%d windows): timing experiments, results invalid: without the softmax's exp / sum (lvit.shape 8) %.1f us, without the whole softmax (lvit.shape 9) %.1f us" % (B, nwin, t8[3], t9[3]))
     print("B=%d (%d windows): 8 waves x 2 token tiles: compiler-scheduled reads (lvit.shape 0) %.1f us, hand-issued (lvit.shape 5) %.1f us" % (B, nwin, t0[3], t5[3]))
     print("B=%d (%d windows): lvit.shape 2 (compiler-scheduled LDS reads) %.1f us, lvit.shape 4 (hand-issued, 8 K fragments / one V block ahead) %.1f us = %.0f TF/s"
