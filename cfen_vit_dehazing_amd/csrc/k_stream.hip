@@ -93,7 +93,7 @@ CFEN_DEV half8 pack_pair(const floatx4& a, const floatx4& b) {
 // so that TWO workgroups of a short ring (R = 3 slots of 24 KiB at D = 192: 78 KB) share a CU -- k_mlp2's occupancy on k_mlp3's fragment-stream ring.
 // NW (round 5): waves per workgroup.  4 = one per SIMD; 8 with TM = 1 and WPE = 2 = the same 128 tokens a workgroup on two waves per SIMD (each covers the
 // other's DMA issue and waits) at twice the LDS fragment reads per token -- the D = 384 A/B of this round.
-template <int ND, int TM, int R, int HB, int DBG = 0, int WPE = 1, int NW = 4>
+template <int ND, int TM, int R, int HB, int DBG = 0, int WPE = 1, int NW = 4, int PDX = 0>
 __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) void k_mlp3(Grouped<Mlp3Args> ga) {
   typedef half_t T;
   typedef half8 frag;
@@ -172,7 +172,7 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(WPE, WP
   // LDS byte addresses (the low 32 bits of a generic pointer into LDS are its LDS offset)
   const unsigned lbase = (unsigned)(unsigned long long)(__attribute__((address_space(3))) unsigned char*)lds;
   const unsigned lfrag = lbase + lane * 16;     // + slot * SLOT + fragment * 1024
-  constexpr int PD = TM >= 4 ? 4 : 6, NB = PD + 2;   // fragment reads in flight ahead of the MFMAs (>= 256 MFMA cycles of cover) / registers of the fragment ring
+  constexpr int PD = PDX ? PDX : (TM >= 4 ? 4 : 6), NB = PD + 2;   // fragment reads in flight ahead of the MFMAs (>= 256 MFMA cycles of cover) / registers of the fragment ring
   static_assert(PD < NB && PD <= NF, "fragment ring");
   // one double phase: NF fragments, each consumed by body(index, fragment); `pre` runs once the first PD reads are issued (the DMA refill)
   auto phase = [&](unsigned sa, auto&& pre, auto&& body) {
@@ -575,14 +575,14 @@ int launch_front3(int ng, const CfenEmbedQkvArgs* ap, hipStream_t s) {
   return CFEN_OK;
 }
 
-template <int ND, int TM, int R, int HB, int DBG = 0, int WPE = 1, int NW = 4>
+template <int ND, int TM, int R, int HB, int DBG = 0, int WPE = 1, int NW = 4, int PDX = 0>
 int launch_mlp3(int ng, const Mlp3Args* ap, hipStream_t s) {
   Grouped<Mlp3Args> ga;
   for (int g = 0; g < CFEN_MAX_GROUPS; ++g) ga.g[g] = ap[g < ng ? g : 0];
   CFEN_CHECK_ARG(ap[0].H <= HB, "mlp3: hidden width %d exceeds the %d this variant stages biases for", ap[0].H, HB);
   const long long per = (long long)NW * TM * 16, blocks = (ap[0].M + per - 1) / per;
   CFEN_CHECK_ARG(blocks > 0 && blocks < (1ll << 31), "mlp3: bad grid");
-  CFEN_LAUNCH((k_mlp3<ND, TM, R, HB, DBG, WPE, NW>), dim3((unsigned)blocks, 1, ng), dim3(NW * 64), 0, s, ga);
+  CFEN_LAUNCH((k_mlp3<ND, TM, R, HB, DBG, WPE, NW, PDX>), dim3((unsigned)blocks, 1, ng), dim3(NW * 64), 0, s, ga);
   CFEN_CHECK_LAUNCH("mlp3");
   return CFEN_OK;
 }
@@ -627,6 +627,11 @@ int cfen_mlp3_impl_g(int dtype, int ng, const Mlp3Args* ap, hipStream_t s) {
   if (ap[0].D == 384 && cfen_tune_mlp3_debug() == 8) return launch_mlp3<24, 1, 3, 1536, 0, 2, 8>(ng, ap, s);   // round-5 A/B: 8 waves x 1 tile, two waves per SIMD
   if (ap[0].D == 384) return launch_mlp3<24, 2, 3, 1536>(ng, ap, s);
   if (cfen_tune_mlp3_tm192() == 22) return launch_mlp3<12, 2, 3, 768, 0, 2>(ng, ap, s);   // two 78 KB workgroups a CU, three-slot ring (round 5 A/B)
+  if (cfen_tune_mlp3_tm192() == 28) return launch_mlp3<12, 2, 3, 768, 0, 2, 8>(ng, ap, s);        // ONE 8-wave workgroup a CU (two waves per SIMD) sharing one three-slot ring: 256 tokens per weight byte streamed
+  if (cfen_tune_mlp3_tm192() == 29) return launch_mlp3<12, 2, 6, 768, 0, 2, 8>(ng, ap, s);        // ... on six slots
+  if (cfen_tune_mlp3_tm192() == 222) return launch_mlp3<12, 2, 3, 768, 0, 2, 4, 3>(ng, ap, s);    // ... with 3 / 10 / 12 fragment reads in flight instead of 6
+  if (cfen_tune_mlp3_tm192() == 122) return launch_mlp3<12, 2, 3, 768, 0, 2, 4, 10>(ng, ap, s);
+  if (cfen_tune_mlp3_tm192() == 322) return launch_mlp3<12, 2, 3, 768, 0, 2, 4, 12>(ng, ap, s);
   if (cfen_tune_mlp3_tm192() == 24) return launch_mlp3<12, 2, 4, 768, 0, 2>(ng, ap, s);   // one 102 KB workgroup a CU at 256 registers, four slots
   if (cfen_tune_mlp3_tm192() == 3) return launch_mlp3<12, 3, 6, 768>(ng, ap, s);
   if (cfen_tune_mlp3_tm192() == 2) return launch_mlp3<12, 2, 6, 768>(ng, ap, s);

@@ -52,8 +52,11 @@ const char* cfen_last_error(void);
  *                  plan -- which kernels produce the outputs does not depend on the launch plan or on profiling
  *   "gvit.max_concurrent": 1 (default) .. 8: forwards of the persistent-chain plan ("net.gvit_chain") that may be in flight at once; the teams of all of them
  *                  must be resident together (grid barriers), so the host caps a team at 256 / (groups x this) CUs
+ *   "net.stream_mlp192" (default 1) / "mlp3.tm192" (default 22): LViT level 2's proj + MLP block on k_mlp3: 22 = two 4-wave 78 KB workgroups a CU on a three-slot ring
+ *                  (256 registers); 24 four slots; 28 / 29 one 8-wave workgroup a CU; 2 / 3 / 4 token tiles a wave on one 150 KB workgroup a CU; net.stream_mlp192 = 0: k_mlp2
+ *   "embed.stages": 2 .. 5 ring stages of k_embed_qkv2 at D = 192 (default 4)
  *   "lvit.shape": k_lvit_window's workgroup shape / schedule: 2 (default) 16 waves x 1 token tile, 0 8 x 2, 1 4 x 4, 3 denominator by MFMA, 4 / 5 the 16 x 1 / 8 x 2
- *                  shapes with hand-issued K / V fragment reads (round 5: bitwise equal, not faster) */
+ *                  shapes with hand-issued K / V fragment reads, 6 64-row front chunks (round 5: bitwise equal, not faster); 8 / 9 timing experiments without the softmax (results invalid) */
 int cfen_tune(const char* key, int value);
 
 /* ---- whole generator: replaces define_G (v3:93-100) + dec_ipt.forward (v3:392-1020) ------------- */
