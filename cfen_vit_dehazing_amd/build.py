@@ -6,7 +6,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libcfen_hip.so")
-SOURCES = ["k_gemm.hip", "k_attention.hip", "k_tokens.hip", "k_conv.hip", "k_conv_tile.hip", "k_mlp.hip", "k_embed.hip", "k_lvit.hip", "k_stream.hip", "k_gvit.hip", "k_head5.hip", "k_fuse.hip", "k_dcn.hip", "k_dcn_bwd.hip", "cfen_api.cpp", "cfen_net.cpp"]
+SOURCES = ["k_gemm.hip", "k_attention.hip", "k_tokens.hip", "k_conv.hip", "k_conv_tile.hip", "k_mlp.hip", "k_embed.hip", "k_lvit.hip", "k_stream.hip", "k_gvit.hip", "k_head5.hip", "k_fuse.hip", "k_tail.hip", "k_dcn.hip", "k_dcn_bwd.hip", "cfen_api.cpp", "cfen_net.cpp"]
 # per-file codegen flags.  k_attention: the softmax is VALU bound -- drop fmaxf's NaN canonicalisation (no NaNs can
 # occur: masked scores are -1e30, not -inf) and let MFMA results land in VGPRs instead of AGPR + v_accvgpr_read.
 EXTRA_FLAGS = {"k_attention.hip": ["-fno-honor-nans", "-mllvm", "-amdgpu-mfma-vgpr-form=1"],
@@ -14,7 +14,7 @@ EXTRA_FLAGS = {"k_attention.hip": ["-fno-honor-nans", "-mllvm", "-amdgpu-mfma-vg
                # 136 of the 812 vector instructions per head and wave of k_lvit_window's attention loop, and sits in front of every ReLU
                # of the conv / GEMM epilogues
                "k_lvit.hip": ["-fno-honor-nans"], "k_mlp.hip": ["-fno-honor-nans"], "k_conv_tile.hip": ["-fno-honor-nans"],
-               "k_conv.hip": ["-fno-honor-nans"], "k_gemm.hip": ["-fno-honor-nans"], "k_gvit.hip": ["-fno-honor-nans"], "k_head5.hip": ["-fno-honor-nans"], "k_fuse.hip": ["-fno-honor-nans"]}
+               "k_conv.hip": ["-fno-honor-nans"], "k_gemm.hip": ["-fno-honor-nans"], "k_gvit.hip": ["-fno-honor-nans"], "k_head5.hip": ["-fno-honor-nans"], "k_fuse.hip": ["-fno-honor-nans"], "k_tail.hip": ["-fno-honor-nans"]}
 # every file: no packed-fp32 VALU code (v_pk_fma_f32 / v_pk_mul_f32 / v_pk_add_f32).  WHY, honestly: round 1 attributed a run-to-run
 # nondeterminism of the two-lane plan to these instructions ("wrong high lane beside another kernel's MFMA waves").  Round 2 tested that
 # claim (tools/repro_pk_fma.py, profiles/r02_pk_fma_repro.json): a stand-alone v_pk_fma_f32 / v_pk_mul_f32 kernel beside an MFMA kernel

@@ -214,11 +214,11 @@ int cfen_tune(const char* key, int value) {
     cfen_tune_gemm_kernel() = value;
     return CFEN_OK;
   }
-  if (!strcmp(key, "gemm.large") || !strcmp(key, "gemm.small")) {
+  if (!strcmp(key, "gemm.large") || !strcmp(key, "gemm.small") || !strcmp(key, "gemm.mid")) {
     CFEN_CHECK_ARG(value == 2 || value == 3 || value == 4 || value == 5 || value == 12 || value == 13 || value == 14 || value == 15 || value == 22 || value == 23 ||
-                   value == 24 || value == 25 || value == 34 || value == 45 || value == 65,
+                   value == 24 || value == 25 || value == 32 || value == 34 || value == 45 || value == 65,
                    "tune: %s must be tile 2 .. 5 (+10 / +20 for 3 / 4 LDS stages; 34 = tile 4 with 5 stages, 45 / 65 = tile 5 with 6 / 8 stages)", key);
-    (key[5] == 'l' ? cfen_tune_gemm_large() : cfen_tune_gemm_small()) = value;
+    (key[5] == 'l' ? cfen_tune_gemm_large() : key[5] == 'm' ? cfen_tune_gemm_mid() : cfen_tune_gemm_small()) = value;
     return CFEN_OK;
   }
   if (!strcmp(key, "gemm.big")) {
@@ -347,6 +347,10 @@ int cfen_tune(const char* key, int value) {
   }
   if (!strcmp(key, "net.gvit_dummy_wgs")) { cfen_tune_gvit_dummy_wgs() = value; return CFEN_OK; }
   if (!strcmp(key, "net.gvit_dummy_us")) { cfen_tune_gvit_dummy_us() = value; return CFEN_OK; }
+  if (!strcmp(key, "net.skip_from")) { cfen_tune_skip_from() = value; return CFEN_OK; }
+  if (!strcmp(key, "net.skip_to")) { cfen_tune_skip_to() = value; return CFEN_OK; }
+  if (!strcmp(key, "net.extra_launches")) { cfen_tune_extra_launches() = value; return CFEN_OK; }
+  if (!strcmp(key, "net.gvit_dummy_levels")) { cfen_tune_gvit_dummy_levels() = value; return CFEN_OK; }
   if (!strcmp(key, "net.gvit_dummy_stream")) { cfen_tune_gvit_dummy_stream() = value; return CFEN_OK; }
   if (!strcmp(key, "gvit.team")) {
     CFEN_CHECK_ARG(value >= 1 && value <= 85, "tune: gvit.team is 1 .. 85 workgroups per block (three blocks share the chip)");
@@ -363,7 +367,9 @@ int cfen_tune(const char* key, int value) {
     cfen_tune_gvit_max_concurrent() = value;
     return CFEN_OK;
   }
-  if (!strcmp(key, "net.tail_fused")) { cfen_tune_tail_fused() = value != 0; return CFEN_OK; }
+  if (!strcmp(key, "net.tail_fused")) { CFEN_CHECK_ARG(value >= 0 && value <= 2, "tune: net.tail_fused is 0, 1 (ConvTranspose + 3x3) or 2 (+ the 7x7)"); cfen_tune_tail_fused() = value; return CFEN_OK; }
+  if (!strcmp(key, "tail.debug")) { cfen_tune_tail_debug() = value; return CFEN_OK; }
+  if (!strcmp(key, "tail.segments")) { CFEN_CHECK_ARG(value >= 1 && value <= 64, "tune: tail.segments is 1 .. 64"); cfen_tune_tail_segments() = value; return CFEN_OK; }
   if (!strcmp(key, "net.up_fused")) { cfen_tune_up_fused() = value != 0; return CFEN_OK; }
   if (!strcmp(key, "net.zero_memset")) { cfen_tune_zero_memset() = value != 0; return CFEN_OK; }
   if (!strcmp(key, "net.keep_stages")) { cfen_tune_keep_stages() = value != 0; return CFEN_OK; }

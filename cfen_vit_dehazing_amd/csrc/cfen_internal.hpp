@@ -106,7 +106,8 @@ int& cfen_tune_conv_wlds_maxlog();
 int& cfen_tune_gemm_big();      // 192 x 128 tile for many-token GEMMs with N >= 768: 0 off (default: it is slower), 6 on ("gemm.big")
 int& cfen_tune_gemm_big_min_tiles();   // ... when the launch has at least this many such tiles ("gemm.big_min_tiles")
 int& cfen_tune_gemm_large();    // k_gemm_dma tile id (2..5) for problems with >= 1024 tiles of 96 x 64 ("gemm.large")
-int& cfen_tune_gemm_small();    // ... and for smaller ones ("gemm.small")
+int& cfen_tune_gemm_small();
+int& cfen_tune_gemm_mid();    // ... and for smaller ones ("gemm.small")
 int& cfen_tune_embed_gather();  // 1 (default): LViT embedding gathers its tokens from the map; 0: separate k_patchify ("net.embed_gather")
 int& cfen_tune_mlp_small_tiles();   // fused-MLP tiling ("mlp.small_tiles"): 0 256/128 tokens per 4-wave WG at 1 wave/SIMD, 1 half-size token tiles at
                                     // 2 waves/SIMD, 2 as 1 but TM = 2 for D = 192 (register-capped), 3 (default) 8-wave WGs: half the weight re-streaming
@@ -134,6 +135,10 @@ int cfen_occupy_impl(int wgs, int ng, int usec, int do_stream, const void* src, 
 int& cfen_tune_gvit_dummy_wgs();
 int& cfen_tune_gvit_dummy_us();
 int& cfen_tune_gvit_dummy_stream();
+int& cfen_tune_gvit_dummy_levels();
+int& cfen_tune_extra_launches();
+int& cfen_tune_skip_from();
+int& cfen_tune_skip_to();
 // Persistent GEMM chain (k_gvit.hip): up to 5 dependent GEMM phases Y = epi(X W^T) run by ONE launch of `team` workgroups per problem that
 // meet at a grid barrier between phases.  W: fragment streams (packing.pack_stream_tiles).  fp16.
 struct CfenChainPhase {
@@ -176,6 +181,12 @@ struct CfenUpConv3 {
 };
 bool cfen_up_conv3_fused_supported(int dtype, int cs_in, int Cup_pad, int cs_up, int C3_pad, int Hin, int Win);
 int cfen_up_conv3_fused_impl_g(int dtype, int ng, const CfenUpConv3* u, hipStream_t s);
+// the whole tail in one launch: ConvTranspose + 3x3 + reflect-pad 7x7 + tanh, both intermediate maps in LDS (k_tail.hip); d7 = the 7x7's descriptor as for cfen_conv7_tz_impl_g
+struct ConvDesc;
+bool cfen_tail_fused_supported(int dtype, int cs_in, int Cup_pad, int cs_up, int C3_pad, int Hin, int Win, int Cout7, int out_mode);
+int cfen_tail_fused_impl_g(int dtype, int ng, const CfenUpConv3* u, const ConvDesc* d7, hipStream_t s);
+int& cfen_tune_tail_debug();     // timing experiments of k_tail_fused ("tail.debug", results invalid)
+int& cfen_tune_tail_segments();  // vertical segments per 64-column strip of k_tail_fused ("tail.segments", default 4)
 int& cfen_tune_up_fused();       // 1: GViT's x4 bilinear runs inside the level's fuse conv (k_conv UP), no k_upsample4 launch ("net.up_fused").  Default 0: measured
                                  // 6 launches and 0.35 GB of HBM traffic fewer per forward but 0.7 % SLOWER (the 9-tap interpolation per pixel on the vector
                                  // pipe in front of a K = 48 .. 192 1x1 costs more than the copy it saves: lgcat_conv_d01 72 -> 110 us for a 19 us launch)

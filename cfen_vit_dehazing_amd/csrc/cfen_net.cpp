@@ -27,6 +27,10 @@ int& cfen_tune_skip_classes() {
 int& cfen_tune_gvit_dummy_wgs() { static int v = 0; return v; }
 int& cfen_tune_gvit_dummy_us() { static int v = 100; return v; }
 int& cfen_tune_gvit_dummy_stream() { static int v = 0; return v; }
+int& cfen_tune_skip_from() { static int v = -1; return v; }   // what-if probe: the launches number skip_from .. skip_to of a forward are not launched (outputs invalid)
+int& cfen_tune_skip_to() { static int v = -1; return v; }
+int& cfen_tune_extra_launches() { static int v = 0; return v; }   // what-if probe: that many one-workgroup 1 us launches in front of every ViT block (what a launch costs a chain)
+int& cfen_tune_gvit_dummy_levels() { static int v = 0; return v; }   // 1: the what-if probe replaces only the blocks that run as a launch per GEMM (levels 2-3)
 int& cfen_tune_gvit_chain() { static int v = 1; return v; }   // only nets built with fragment-stream GViT weights (cfg.reserved bit 2) can use it
 int& cfen_tune_gvit_stream() { static int v = 2; return v; }   // 0 never, 1 in the serial launch plan only, 2 (default, round 5) on every plan: which KERNELS produce the
                                                                 // outputs no longer depends on the lane plan or on profiling (two-lane, serial and profiled forwards are bitwise equal;
@@ -154,6 +158,7 @@ struct cfen_net {
   bool wtile = false;              // cfg.reserved bit 1: GViT weights are packed tile-major (CfenGemmPtrs::wtile, packing.pack_wtile)
   size_t wbytes(const Vit& v, int N, int K) const { return (size_t)(v.global && wtile ? cfen_round_up(N, 96) : N) * K * esz; }
   int full = 0;                    // image edge
+  int launch_idx = 0;              // launches of this forward so far ("net.skip_from" / "net.skip_to")
   int blk_kind = 0;                // 0 CNN, 1 GViT block, 2 LViT block (selects bits 8.. / 16.. of "net.skip_classes")
   unsigned char* base = nullptr;   // workspace of the current / last forward
   hipStream_t stream = nullptr;    // stream of the lane being enqueued
@@ -315,6 +320,7 @@ struct cfen_net {
 #define TRYP(cls, flops, expr)            \
   do {                                    \
     if (cfen_tune_skip_classes() & ((1 << (cls)) | (1 << ((cls) + 8 * blk_kind)))) break; /* what-if timing: outputs are garbage */ \
+    { const int li__ = launch_idx++; if (li__ >= cfen_tune_skip_from() && li__ <= cfen_tune_skip_to()) break; } \
     int id__ = prof_begin(cls, flops);    \
     int rc__ = (expr);                    \
     prof_end(id__);                       \
@@ -647,7 +653,11 @@ int cfen_net::run_vit_g(int ng, const VitCall* vc, int scr0) {
     for (int g = 0; g < ng; ++g) SK[g] = (float*)at(scr_set[scr0 + 2 * g].splitk);
   const double Md = (double)M * ng, D = v.Dn, Hd = v.hidden;   // algorithmic flops count the real embedding dim
   auto step = [&](const char* what) { if (profiling) label = nm[0] + (ng > 1 ? " (x" + std::to_string(ng) + ")" : "") + ":" + what; };
-  if (v.global && cfen_tune_gvit_dummy_wgs() != 0) {   // what-if probe: the whole block replaced by a launch that holds CUs (outputs invalid)
+  for (int i = 0; i < cfen_tune_extra_launches(); ++i) {
+    step("extra_launch");
+    TRY(cfen_occupy_impl(-1, 1, 1, 0, base, ws_bytes, X0[0], stream));
+  }
+  if (v.global && cfen_tune_gvit_dummy_wgs() != 0 && (cfen_tune_gvit_dummy_levels() == 0 || (!v.gstream && (cfen_tune_gvit_dummy_levels() == 1 || (cfen_tune_gvit_dummy_levels() == 2) == (v.D >= 1536))))) {   // levels: 1 = 2 and 3, 2 = level 3 only, 3 = level 2 only   // what-if probe: the whole block replaced by a launch that holds CUs (outputs invalid)
     step("dummy");
     return cfen_occupy_impl(cfen_tune_gvit_dummy_wgs(), ng, cfen_tune_gvit_dummy_us(), cfen_tune_gvit_dummy_stream(), base, ws_bytes, SK[0], stream);
   }
@@ -1109,6 +1119,31 @@ int cfen_net::run_decoder(float* const* outs, hipStream_t sm, hipStream_t sg) {
                          cfen_tune_keep_stages() ? map_ptr(up[g]) : nullptr};
       fl += B * (2.0 * cu.Cin_real * cu.Cout * 16.0 * bi.H * bi.W + 2.0 * cc.Cout * (double)cc.Cin_real * 9.0 * 4.0 * bi.H * bi.W);
     }
+    // "net.tail_fused" = 2 (round 5): the reflect-pad 7x7 + tanh rides along too (k_tail.hip: a workgroup walks down a 64-column strip, both intermediate
+    // maps in LDS) -- unless the stage maps are asked for
+    bool whole = cfen_tune_tail_fused() == 2 && !cfen_tune_keep_stages();
+    ConvDesc d7[3];
+    for (int g = 0; g < 3 && whole; ++g) {
+      const ConvLayer& z = convs.at(c7[g].layer);
+      const Buf& bm = bufs.at(c7[g].in0);
+      const int mode = output_u8 ? 2 : 1;
+      whole = z.tz && z.kind == 0 && z.k == 7 && z.reflect && outs[g] &&
+              cfen_tail_fused_supported(dt, bufs.at(out[g]).cs, convs.at(up[g]).Cout_pad, bufs.at(up[g]).cs, convs.at(c3[g].layer).Cout_pad, bufs.at(out[g]).H,
+                                        bufs.at(out[g]).W, z.Cout, mode) && bm.cs == 16;
+      if (!whole) break;
+      cfen_desc_conv(&d7[g], B, bm.H, bm.W, bm.cs, z.Cin, z.k, z.stride, z.pad, z.reflect, z.nsrc);
+      d7[g].weight = P(c7[g].layer + ".wz"); d7[g].Kpad = z.Kpad;
+      d7[g].scale = Pf(c7[g].layer + ".scale"); d7[g].shift = Pf(c7[g].layer + ".shift");
+      d7[g].act = 2; d7[g].Cout = z.Cout; d7[g].Cout_pad = z.Cout_pad;
+      d7[g].out = outs[g]; d7[g].out_nchw_f32 = mode; d7[g].cs_out = z.Cout_pad;
+      fl += B * 2.0 * z.Cout * (double)z.Cin_real * 49.0 * bm.H * bm.W;
+    }
+    if (whole) {
+      label = up[0] + " + " + c3[0].layer + " + " + c7[0].layer + " (x3, fused)";
+      TRYP(K_CONV, fl, cfen_tail_fused_impl_g(dt, 3, u, d7, stream));
+      stages_on_chip = true;
+      return CFEN_OK;
+    }
     label = up[0] + " + " + c3[0].layer + " (x3, fused)";
     TRYP(K_CONV, fl, cfen_up_conv3_fused_impl_g(dt, 3, u, stream));
     stages_on_chip = !cfen_tune_keep_stages();
@@ -1145,6 +1180,7 @@ int cfen_net::forward(const float* x, float* xr, float* xs, float* xd) {
   if (chains)
     for (int k = 1; k < 6; k += 2) TRY(cfen_zero_async(at(scr_set[k].sync), GV_ERR_WORD * sizeof(unsigned), stream));
   gv_launch = 0;
+  launch_idx = 0;
   const Buf& bin = bufs.at("input");
   const bool use_head5 = head5 && cfen_tune_head5() && !cfen_tune_head_fused();
   if (use_head5) {

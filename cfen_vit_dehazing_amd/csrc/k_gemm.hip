@@ -17,6 +17,7 @@
 
 int& cfen_tune_gemm_nt();
 int& cfen_tune_gemm_splitk_release();
+int& cfen_tune_gemm_mid();
 
 namespace {
 
@@ -692,7 +693,7 @@ int launch_gemm(int ng, const CfenGemmPtrs* gp, int ldx, int ldw, int ldr, int p
     stages = 2 + cfen_tune_gemm_big() / 10;
   }
   if (kern < 0) {
-    const int pick = !k128 ? 0 : (M <= 128 && N <= 2048 && !tg && !lnf) ? 1 : tiles64 >= 1024 ? cfen_tune_gemm_large() : tiles32 <= 512 ? cfen_tune_gemm_small() : 5;
+    const int pick = !k128 ? 0 : (M <= 128 && N <= 2048 && !tg && !lnf) ? 1 : tiles64 >= 1024 ? cfen_tune_gemm_large() : tiles32 <= 512 ? cfen_tune_gemm_small() : cfen_tune_gemm_mid();
     kern = pick % 10;
     stages = 2 + pick / 10;
   }
@@ -785,6 +786,10 @@ int& cfen_tune_gemm_m128() {
 int& cfen_tune_gemm_large() {
   static int v = 4;
   return v;
+}
+int& cfen_tune_gemm_mid() {   // more than 512 tiles of 96 x 32 and fewer than 1024 of 96 x 64 (the grouped GViT-2 decoder GEMMs, 3 x 512 tokens): kernel id as "gemm.small".
+  static int v = 2;            // Round 5, four forwards in flight, same box: 96 x 128 tiles (2) 2.059 / 2.060 ms per step, 96 x 64 (4) 2.094, 96 x 96 (3) 2.106, 96 x 32 on
+  return v;                    // 2 / 3 stages (5 / 15: rounds 2-4) 2.075-2.078 / 2.136 (profiles/r05_ab_gvit2_decoder_gemm_tiles.txt): a quarter of the weight bytes through the DMA path
 }
 int& cfen_tune_gemm_small() {
   static int v = 15;   // 96 x 32 tiles, 3-stage ring: the few-token GViT GEMMs are latency bound (one K-step per memory round trip with 2 stages)
