@@ -186,11 +186,11 @@ struct ConvDesc;
 bool cfen_tail_fused_supported(int dtype, int cs_in, int Cup_pad, int cs_up, int C3_pad, int Hin, int Win, int Cout7, int out_mode);
 int cfen_tail_fused_impl_g(int dtype, int ng, const CfenUpConv3* u, const ConvDesc* d7, hipStream_t s);
 int& cfen_tune_tail_debug();     // timing experiments of k_tail_fused ("tail.debug", results invalid)
-int& cfen_tune_tail_segments();  // vertical segments per 64-column strip of k_tail_fused ("tail.segments", default 4)
+int& cfen_tune_tail_segments();  // vertical segments per 64-column strip of k_tail_fused ("tail.segments", default 2)
 int& cfen_tune_up_fused();       // 1: GViT's x4 bilinear runs inside the level's fuse conv (k_conv UP), no k_upsample4 launch ("net.up_fused").  Default 0: measured
                                  // 6 launches and 0.35 GB of HBM traffic fewer per forward but 0.7 % SLOWER (the 9-tap interpolation per pixel on the vector
                                  // pipe in front of a K = 48 .. 192 1x1 costs more than the copy it saves: lgcat_conv_d01 72 -> 110 us for a 19 us launch)
-int& cfen_tune_tail_fused();     // 1 (default): us_conv_d01* + tail conv3 run as one k_up_conv3_fused launch where it applies ("net.tail_fused")
+int& cfen_tune_tail_fused();     // "net.tail_fused": 2 (default) the whole tail as one k_tail_fused launch, 1 us_conv_d01* + tail conv3 as one k_up_conv3_fused launch, 0 three launches
 int& cfen_tune_keep_stages();    // 1: fused launches also store the stage maps they keep on chip (us_conv_d01*), for parity tests ("net.keep_stages"; default 0)
 // out (B, h, w, cs_out) = 4 x 4 mean of in (B, 4h, 4w, cs_in): GViT's avgpool . avgpool as a map (k_tokens.hip: k_pool4)
 int cfen_pool4_impl_g(int dtype, int ng, const void* const* in, void* const* out, int B, int h, int w, int C, int cs_in, int cs_out, hipStream_t s);

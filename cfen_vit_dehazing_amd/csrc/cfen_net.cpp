@@ -36,7 +36,7 @@ int& cfen_tune_gvit_stream() { static int v = 2; return v; }   // 0 never, 1 in 
                                                                 // outputs no longer depends on the lane plan or on profiling (two-lane, serial and profiled forwards are bitwise equal;
                                                                 // the stream kernels cost one forward at a time 2.80 -> 2.85 ms and gain 2.27 -> 2.24 with several in flight)
                                                                 // (one forward at a time on the two-lane plan it is SLOWER, 2.85 against 2.80 ms: 277 us of latency against 134)
-int& cfen_tune_tail_fused() { static int v = 1; return v; }
+int& cfen_tune_tail_fused() { static int v = 2; return v; }   // 0 three launches, 1 ConvTranspose + 3x3 fused (round 4), 2 (default, round 5) the whole tail in one launch (k_tail.hip)
 int& cfen_tune_up_fused() { static int v = 0; return v; }
 int& cfen_tune_keep_stages() { static int v = 0; return v; }
 int& cfen_tune_resblock_fused() { static int v = 0; return v; }   // 0 (default): MEASURED with three forwards in flight 2.44 against 2.48 ms -- the fused kernel (5-wave workgroups, 58 KB of LDS, 154 registers) is 13 us shorter alone and costs more CU-time beside other forwards
@@ -153,6 +153,7 @@ struct cfen_net {
   static constexpr int GV_SYNC_WORDS = 1024, GV_ERR_WORD = 512;
   std::set<std::string> gvit_low;  // GViT outputs the last forward left at low resolution (x4 bilinear inside the fuse conv, ConvDesc::up4): cfen_net_stage refuses them
   bool gv_skip_up = false;         // run_vit_g (GViT): leave the block's result in the low-resolution scratch map, no k_upsample4
+  bool tail_whole = false;         // ... and the tails' 3x3 outputs too (k_tail_fused)
   bool stages_on_chip = false;     // the last forward kept the us_conv_d01* maps in LDS (k_up_conv3_fused without "net.keep_stages"): cfen_net_stage refuses them
   bool head5 = false;              // head.0.0 can run on k_head5 (reads the network input itself)
   bool wtile = false;              // cfg.reserved bit 1: GViT weights are packed tile-major (CfenGemmPtrs::wtile, packing.pack_wtile)
@@ -1028,6 +1029,7 @@ int cfen_net::run_decoder(float* const* outs, hipStream_t sm, hipStream_t sg) {
   static const char* tags = "rsd";
   bool tail_fused = false;
   stages_on_chip = false;
+  tail_whole = false;
   auto tail_fusable = [&]() {
     if (cfs || !cfen_tune_tail_fused() || !an_pending.empty() || dt != CFEN_F16) return false;
     for (int g = 0; g < 3; ++g) {
@@ -1142,6 +1144,7 @@ int cfen_net::run_decoder(float* const* outs, hipStream_t sm, hipStream_t sg) {
       label = up[0] + " + " + c3[0].layer + " + " + c7[0].layer + " (x3, fused)";
       TRYP(K_CONV, fl, cfen_tail_fused_impl_g(dt, 3, u, d7, stream));
       stages_on_chip = true;
+      tail_whole = true;
       return CFEN_OK;
     }
     label = up[0] + " + " + c3[0].layer + " (x3, fused)";
@@ -1456,7 +1459,7 @@ int cfen_net_stage(const cfen_net* net, const char* name, const void** ptr, int3
     cfen_set_error("net_stage: '%s' was never stored at full resolution in the last forward (its x4 upsampling ran inside the fuse conv); cfen_tune(\"net.keep_stages\", 1) stores it", name);
     return CFEN_ERR_STATE;
   }
-  if (net->stages_on_chip && !strncmp(name, "us_conv_d01", 11)) {
+  if (net->stages_on_chip && (!strncmp(name, "us_conv_d01", 11) || (net->tail_whole && !strncmp(name, "tail_", 5)))) {
     cfen_set_error("net_stage: '%s' stayed on chip in the last forward (fused into the tail's first launch); cfen_tune(\"net.keep_stages\", 1) stores it", name);
     return CFEN_ERR_STATE;
   }

@@ -11,21 +11,22 @@
 //   A  ConvTranspose rows 8j+4 .. 8j+11, columns X0-4 .. X0+71   (k_up_conv3_fused's stage: one parity phase per wave) from 6 staged base rows -> t1
 //   B  3x3 rows 8j+3 .. 8j+10, columns X0-3 .. X0+68 from t1 (its last two rows of band j-1 are carried over)           -> t2, a ring of 16 rows
 //   C  7x7 + tanh rows 8j .. 8j+7 from t2 rows 8j-3 .. 8j+10 (reflected at the image border by row / by mirrored stores of stage B) -> output
-// The 35 Toeplitz fragments of the 7x7 (k_conv_tile.hip: k_conv7_tz) are 140 registers a lane, the other stages need ~130: one wave cannot hold both (a
-// 4-wave version spilled 157 registers), so the workgroup has ROLES -- waves 0..3 stage the input and run A and B, waves 4..7 run C one band behind, a producer
-// and a consumer wave on every SIMD.  LDS (one workgroup a CU): staged input 6 x 50 x 64 B, t1 a ring of 16 rows x 84 x 32 B (no carry copy), t2 a ring of
-// 24 rows x 72 x 32 B (stage B of band j never touches what stage C of band j-1 reads) = 114.8 KB; two barriers per band.
+// Three wave groups work on three different bands at once, one barrier per band: in step j waves 0..3 run A of band j, waves 4..7 run B of band j-1, waves
+// 8..11 run C of band j-2 (their 35 Toeplitz fragments are 140 registers a lane: the reason for the roles -- a 4-wave version that did everything spilled 157
+// registers), and the eight waves 0..7 finish band j-3 (scale, tanh, store: one row each) from the accumulators the C waves parked in LDS.  Every SIMD holds
+// one wave of each group, so one group's MFMAs run under another's epilogue arithmetic.  LDS (one workgroup a CU): staged input 2 x 6 x 50 x 64 B, t1 a ring
+// of 20 rows x 84 x 32 B, t2 a ring of 22 rows x 72 x 32 B, parked accumulators 2 x 8 KB = 155.5 KB.
 #include "cfen_common.hpp"
 #include "cfen_internal.hpp"
 #include "cfen_conv.hpp"
 
 namespace {
 
-constexpr int TF_INROWS = 6, TF_INW = 50, TF_INS = 40, TF_INB = TF_INW * 64;   // staged base rows 4j+1 .. 4j+6, base columns xb0-3 .. (40 staged, 50 addressed)
-constexpr int TF_T1W = 84, TF_T1B = TF_T1W * 32, TF_T1R = 16, TF_T1KEEP = 76;  // t1 columns X0-4 .., kept while < 76 (stage B's zero-weight fourth tap must read finite values)
-constexpr int TF_ZW = 72, TF_ZB = TF_ZW * 32, TF_ZNCH = 5, TF_ZKPAD = 7 * TF_ZNCH * 32, TF_T2R = 24;
-constexpr int TF_ZBUF = 8 * 4 * 16 * 16;                                           // the 7x7's raw accumulators of a band: [row 8][channel 4][pixel quad 16] fp32 x 4
-constexpr int TF_LDS = TF_INROWS * TF_INB + TF_T1R * TF_T1B + TF_T2R * TF_ZB + TF_ZBUF;
+constexpr int TF_INROWS = 6, TF_INW = 50, TF_INS = 40, TF_INB = TF_INW * 64, TF_INBUF = TF_INROWS * TF_INB;   // staged base rows 4j+1 .. 4j+6, base columns xb0-3 .. (40 staged, 50 addressed)
+constexpr int TF_T1W = 84, TF_T1B = TF_T1W * 32, TF_T1R = 20, TF_T1KEEP = 76;  // t1 columns X0-4 .., kept while < 76 (stage B's zero-weight fourth tap must read finite values)
+constexpr int TF_ZW = 72, TF_ZB = TF_ZW * 32, TF_ZNCH = 5, TF_ZKPAD = 7 * TF_ZNCH * 32, TF_T2R = 22;
+constexpr int TF_ZBUF = 8 * 4 * 16 * 16;                                       // the 7x7's raw accumulators of a band: [row 8][channel 4][pixel quad 16] fp32 x 4
+constexpr int TF_LDS = 2 * TF_INBUF + TF_T1R * TF_T1B + TF_T2R * TF_ZB + 2 * TF_ZBUF;
 static_assert(TF_LDS <= 160 * 1024, "one workgroup a CU");
 
 struct TailArgs {
@@ -38,7 +39,8 @@ struct TailArgs {
 CFEN_DEV int tf_swz(int col) { return ((col >> 2) & 1) << 1; }            // k_fuse.hip uf_swz<64>
 CFEN_DEV int tf_t1col(int col) { return col ^ ((col >> 2) & 1); }         // k_fuse.hip uf_t1col
 CFEN_DEV int tf_zpiece(int P, int q) { const int slot = 2 * P + q; return (slot & ~7) | ((slot & 7) ^ ((P >> 2) & 6)); }   // k_conv7_tz's halo swizzle
-CFEN_DEV int tf_t2slot(int y) { return (y + 4 * TF_T2R) % TF_T2R; }       // y >= -4 * 24
+CFEN_DEV int tf_t1slot(int y) { return (y + 8 * TF_T1R) % TF_T1R; }       // y >= -160
+CFEN_DEV int tf_t2slot(int y) { return (y + 8 * TF_T2R) % TF_T2R; }
 
 __global__ __launch_bounds__(768) void k_tail_fused(Grouped<TailArgs> ga, int nblk, int segb, int dbg) {
   const TailArgs& a = ga.g[blockIdx.z];
@@ -46,7 +48,7 @@ __global__ __launch_bounds__(768) void k_tail_fused(Grouped<TailArgs> ga, int nb
   typedef half8 frag;
   extern __shared__ __attribute__((aligned(16))) unsigned char tf_lds[];
   unsigned char* const inl = tf_lds;
-  unsigned char* const t1 = tf_lds + TF_INROWS * TF_INB;
+  unsigned char* const t1 = tf_lds + 2 * TF_INBUF;
   unsigned char* const t2 = t1 + TF_T1R * TF_T1B;
   unsigned char* const zbuf = t2 + TF_T2R * TF_ZB;
 
@@ -60,28 +62,11 @@ __global__ __launch_bounds__(768) void k_tail_fused(Grouped<TailArgs> ga, int nb
   // scalars of the argument block the band loop uses: read once (behind a barrier the compiler re-reads them from the kernel arguments, an s_load + lgkmcnt(0) per use)
   const int actT = a.actT, act3 = a.act3, act7 = a.act7, Cout = a.Cout, out_mode = a.out_mode, Hin = a.Hin, Win = a.Win;
   void* const outp = a.out;
+  auto band_live = [&](int j) { return j >= k0 - 2 && j < k1 && 8 * j + 11 >= 0 && 8 * j + 4 < Hf; };   // ConvTranspose rows 8j+4 .. 8j+11 are wanted and meet the image
+  const int jend = k1 + 2;                             // the last step finishes band k1 - 1
 
   if (wave < 8) {
-    // ============================ producer waves: stage the input, ConvTranspose (A), 3x3 (B) ============================
-    // A: wave = (parity phase, half): output rows 2 hf, 2 hf + 1 of the phase's four, all three column tiles.  B: wave = (row pair, half): rows 2 br, 2 br + 1
-    // of the band, column tiles {0, 1, 2} / {3, 4}.
-    const int ph = wave & 3, py = ph >> 1, px = ph & 1, hf = wave >> 2, br = wave & 3, ct0 = hf ? 3 : 0;
-    const bool third = hf == 0;                        // wave-uniform: this wave has a third column tile in stage B
-    frag wf[4], wb[3][2];
-    {
-      const T* wp = a.wT + ((size_t)ph * 16 + r16) * 128 + h * 8;
-#pragma unroll
-      for (int t = 0; t < 4; ++t) wf[t] = load_frag<T>(wp + t * 32);
-      const T* pb = a.w3 + (size_t)r16 * (3 * 2 * 32) + h * 8;
-#pragma unroll
-      for (int dy = 0; dy < 3; ++dy)
-#pragma unroll
-        for (int c = 0; c < 2; ++c) wb[dy][c] = load_frag<T>(pb + (dy * 2 + c) * 32);
-    }
-    const floatx4 scT = *reinterpret_cast<const floatx4*>(a.sT + n), shT = *reinterpret_cast<const floatx4*>(a.tT + n);
-    const floatx4 sc3 = *reinterpret_cast<const floatx4*>(a.s3 + n), sh3 = *reinterpret_cast<const floatx4*>(a.t3 + n);
-    const float sc7 = a.s7[h], sh7 = a.t7[h];            // (h = 3 may read a padding entry of the [16] table; its results are never stored)
-    // staging: the 6 rows x 40 columns x 4 pieces of 16 bytes are dealt over the 512 producer threads, two pieces (rows) each
+    // ---- staging (waves 0..7): the 6 rows x 40 columns x 4 pieces of 16 bytes of a band are dealt over 512 threads, two pieces each ----
     const int src_pixb = a.cs_in * 2, src_pieces = src_pixb / 16;
     const unsigned char* src = (const unsigned char*)a.in + (size_t)b * a.Hin * a.Win * src_pixb;
     int s_row[2], s_off[2], s_dst[2];
@@ -95,37 +80,6 @@ __global__ __launch_bounds__(768) void k_tail_fused(Grouped<TailArgs> ga, int nb
       s_off[k] = min(max(sgx, 0), a.Win - 1) * src_pixb + min(spiece, src_pieces - 1) * 16;
       s_dst[k] = (s_use[k] ? row : 0) * TF_INB + scol * 64 + ((spiece ^ tf_swz(scol)) << 4);
     }
-    // stage A: LDS offset of the (tap column, column tile) fragment; epilogue: t1 column of (xq, lane) = 32 xq + 2 r16 + px = X - (X0 - 4)
-    int a_ld[2][3], a_pix[3];
-    bool a_keep[3], a_ximg[3];
-#pragma unroll
-    for (int xq = 0; xq < 3; ++xq) {
-#pragma unroll
-      for (int txx = 0; txx < 2; ++txx) {
-        const int col = xq * 16 + r16 + px + 1 - txx;
-        a_ld[txx][xq] = col * 64 + ((h ^ tf_swz(col)) << 4);
-      }
-      const int idx = 32 * xq + 2 * r16 + px, X = X0 - 4 + idx;
-      a_keep[xq] = idx < TF_T1KEEP;
-      a_pix[xq] = tf_t1col(idx) * 32 + n * 2;
-      a_ximg[xq] = X >= 0 && X < Wf;                   // a column outside the image is the 3x3's zero padding
-    }
-    // stage B: column tile ct0 + i of the lane = t2 pixel P = 16 ct + r16 = X - (X0 - 3); the reflected copy of a padding column of the 7x7 is stored by its source's owner
-    int b_ld[2][3], b_off[3], b_moff[3];
-    bool b_keep[3], b_mir[3];
-#pragma unroll
-    for (int i = 0; i < 3; ++i) {
-      const int ct = ct0 + i, P = 16 * ct + r16, X = X0 - 3 + P;
-#pragma unroll
-      for (int c = 0; c < 2; ++c) b_ld[c][i] = tf_t1col((16 * ct + r16 + 2 * c + (h >> 1)) & 127) * 32 + (h & 1) * 16;
-      b_keep[i] = ct < 5 && P < TF_ZW && X >= 0 && X < Wf;
-      b_off[i] = (tf_zpiece(P & 127, h >> 1) << 4) + (h & 1) * 8;
-      const int Xm = (X >= 1 && X <= 3) ? -X : (X >= Wf - 4 && X <= Wf - 2) ? 2 * (Wf - 1) - X : -100000;
-      const int Pm = Xm - (X0 - 3);
-      b_mir[i] = b_keep[i] && Pm >= 0 && Pm < TF_ZW;
-      b_moff[i] = (tf_zpiece(Pm & 127, h >> 1) << 4) + (h & 1) * 8;
-    }
-    auto band_live = [&](int j) { return j < k1 && 8 * j + 11 >= 0 && 8 * j + 4 < Hf; };   // ConvTranspose rows 8j+4 .. 8j+11 meet the image
     frag stg[2];
     auto fetch = [&](int j) {
 #pragma unroll
@@ -135,135 +89,194 @@ __global__ __launch_bounds__(768) void k_tail_fused(Grouped<TailArgs> ga, int nb
         stg[k] = (s_ok[k] && gy >= 0 && gy < Hin) ? v : Mma<T>::zero();
       }
     };
-    if (band_live(k0 - 2)) fetch(k0 - 2);
-    for (int j = k0 - 2; j <= k1 + 1; ++j) {
-      const bool a_live = band_live(j);                // wave-uniform
-      if (a_live) {
+    auto stage = [&](int j) {                          // band j's input into buffer j & 1
 #pragma unroll
-        for (int k = 0; k < 2; ++k)
-          if (s_use[k]) *reinterpret_cast<frag*>(inl + s_dst[k]) = stg[k];
+      for (int k = 0; k < 2; ++k)
+        if (s_use[k]) *reinterpret_cast<frag*>(inl + (j & 1) * TF_INBUF + s_dst[k]) = stg[k];
+    };
+    const float sc7 = a.s7[h], sh7 = a.t7[h];            // (h = 3 may read a padding entry of the [16] table; its results are never stored)
+    // finish band e (waves 0..7 = its rows): scale, tanh, store -- k_conv7_tz's epilogue on the accumulators the C waves parked
+    auto finish = [&](int e) {
+      const int y = 8 * e + wave;
+      floatx4 v = *reinterpret_cast<const floatx4*>(zbuf + (e & 1) * TF_ZBUF + ((wave * 4 + h) * 16 + r16) * 16) * sc7 + sh7;
+      if (act7 == 1) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) v[q] = fmaxf(v[q], 0.f);
+      } else if (act7 == 2 && !(dbg & 8)) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) v[q] = tanhf(v[q]);
       }
-      __syncthreads();                                 // (A) the staged input of band j is in LDS; stage B of band j-1 is complete
-      if (j - 2 >= k0 && !(dbg & 16)) {
-        // epilogue of the 7x7 of band j-2 (its accumulators were parked by the consumer waves before this barrier): wave = row of the band, lane (r16, h) =
-        // channel h of pixels X0 + 4 r16 .. + 3 -- k_conv7_tz's epilogue
-        const int y = 8 * (j - 2) + wave;
-        floatx4 v = *reinterpret_cast<const floatx4*>(zbuf + ((wave * 4 + h) * 16 + r16) * 16) * sc7 + sh7;
-        if (act7 == 1) {
+      if (out_mode == 2) {
+        unsigned wr = 0;
 #pragma unroll
-          for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
-        } else if (act7 == 2 && !(dbg & 8)) {
-#pragma unroll
-          for (int e = 0; e < 4; ++e) v[e] = tanhf(v[e]);
+        for (int q = 0; q < 4; ++q) wr |= (unsigned)(unsigned char)(int)((v[q] + 1.f) / 2.0f * 255.0f) << (8 * q);
+        const unsigned wg = Cout >= 3 ? (unsigned)__shfl((int)wr, r16 + 16, 64) : wr;     // all 64 lanes take part in the exchange
+        const unsigned wbl = Cout >= 3 ? (unsigned)__shfl((int)wr, r16 + 32, 64) : wr;
+        if (h == 0) {
+          // bytes R0 G0 B0 R1 | G1 B1 R2 G2 | B2 R3 G3 B3
+          const unsigned o0 = (wr & 0xffu) | ((wg & 0xffu) << 8) | ((wbl & 0xffu) << 16) | ((wr & 0xff00u) << 16);
+          const unsigned o1 = ((wg >> 8) & 0xffu) | (((wbl >> 8) & 0xffu) << 8) | (((wr >> 16) & 0xffu) << 16) | (((wg >> 16) & 0xffu) << 24);
+          const unsigned o2 = ((wbl >> 16) & 0xffu) | (((wr >> 24) & 0xffu) << 8) | (((wg >> 24) & 0xffu) << 16) | (((wbl >> 24) & 0xffu) << 24);
+          unsigned* op = reinterpret_cast<unsigned*>((unsigned char*)outp + (((size_t)b * Hf + y) * Wf + X0 + 4 * r16) * 3);
+          op[0] = o0; op[1] = o1; op[2] = o2;
         }
-        if (out_mode == 2) {
-          unsigned wr = 0;
-#pragma unroll
-          for (int e = 0; e < 4; ++e) wr |= (unsigned)(unsigned char)(int)((v[e] + 1.f) / 2.0f * 255.0f) << (8 * e);
-          const unsigned wg = Cout >= 3 ? (unsigned)__shfl((int)wr, r16 + 16, 64) : wr;     // all 64 lanes take part in the exchange
-          const unsigned wbl = Cout >= 3 ? (unsigned)__shfl((int)wr, r16 + 32, 64) : wr;
-          if (h == 0) {
-            // bytes R0 G0 B0 R1 | G1 B1 R2 G2 | B2 R3 G3 B3
-            const unsigned o0 = (wr & 0xffu) | ((wg & 0xffu) << 8) | ((wbl & 0xffu) << 16) | ((wr & 0xff00u) << 16);
-            const unsigned o1 = ((wg >> 8) & 0xffu) | (((wbl >> 8) & 0xffu) << 8) | (((wr >> 16) & 0xffu) << 16) | (((wg >> 16) & 0xffu) << 24);
-            const unsigned o2 = ((wbl >> 16) & 0xffu) | (((wr >> 24) & 0xffu) << 8) | (((wg >> 24) & 0xffu) << 16) | (((wbl >> 24) & 0xffu) << 24);
-            unsigned* op = reinterpret_cast<unsigned*>((unsigned char*)outp + (((size_t)b * Hf + y) * Wf + X0 + 4 * r16) * 3);
-            op[0] = o0; op[1] = o1; op[2] = o2;
-          }
-        } else if (h < Cout) {
-          *reinterpret_cast<floatx4*>((float*)outp + (((size_t)b * Cout + h) * Hf + y) * Wf + X0 + 4 * r16) = v;
-        }
+      } else if (h < Cout) {
+        *reinterpret_cast<floatx4*>((float*)outp + (((size_t)b * Cout + h) * Hf + y) * Wf + X0 + 4 * r16) = v;
       }
-      if (j < k1) {
-        floatx4 acc[2][3];
+    };
+    if (band_live(k0 - 2)) { fetch(k0 - 2); stage(k0 - 2); }
+
+    if (wave < 4) {
+      // ============================ waves 0..3: ConvTranspose (A) of band j, one parity phase per wave ============================
+      const int py = wave >> 1, px = wave & 1;
+      frag wf[4];
+      {
+        const T* wp = a.wT + ((size_t)wave * 16 + r16) * 128 + h * 8;
 #pragma unroll
-        for (int r = 0; r < 2; ++r)
+        for (int t = 0; t < 4; ++t) wf[t] = load_frag<T>(wp + t * 32);
+      }
+      const floatx4 scT = *reinterpret_cast<const floatx4*>(a.sT + n), shT = *reinterpret_cast<const floatx4*>(a.tT + n);
+      // LDS offset of the (tap column, column tile) fragment; epilogue: t1 column of (xq, lane) = 32 xq + 2 r16 + px = X - (X0 - 4)
+      int a_ld[2][3], a_pix[3];
+      bool a_keep[3], a_ximg[3];
 #pragma unroll
-          for (int xq = 0; xq < 3; ++xq) acc[r][xq] = floatx4{0.f, 0.f, 0.f, 0.f};
-        if (a_live && !(dbg & 1)) {
-          const unsigned char* lp = inl + (1 + py + 2 * hf) * TF_INB;
+      for (int xq = 0; xq < 3; ++xq) {
 #pragma unroll
-          for (int q = -1; q < 2; ++q) {
+        for (int txx = 0; txx < 2; ++txx) {
+          const int col = xq * 16 + r16 + px + 1 - txx;
+          a_ld[txx][xq] = col * 64 + ((h ^ tf_swz(col)) << 4);
+        }
+        const int idx = 32 * xq + 2 * r16 + px, X = X0 - 4 + idx;
+        a_keep[xq] = idx < TF_T1KEEP;
+        a_pix[xq] = tf_t1col(idx) * 32 + n * 2;
+        a_ximg[xq] = X >= 0 && X < Wf;                 // a column outside the image is the 3x3's zero padding
+      }
+      for (int j = k0 - 2; j <= jend; ++j) {
+        __syncthreads();
+        const bool a_live = band_live(j);              // wave-uniform
+        if (band_live(j + 1) && !(dbg & 32)) fetch(j + 1);
+        if (j < k1) {
+          floatx4 acc[4][3];
 #pragma unroll
-            for (int txx = 0; txx < 2; ++txx) {
+          for (int r = 0; r < 4; ++r)
 #pragma unroll
-              for (int xq = 0; xq < 3; ++xq) {
-                const frag bf = *reinterpret_cast<const frag*>(lp + q * TF_INB + a_ld[txx][xq]);
-                if (q >= 0) acc[q][xq] = Mma<T>::mma(wf[txx], bf, acc[q][xq]);
-                if (q + 1 < 2) acc[q + 1][xq] = Mma<T>::mma(wf[2 + txx], bf, acc[q + 1][xq]);
+            for (int xq = 0; xq < 3; ++xq) acc[r][xq] = floatx4{0.f, 0.f, 0.f, 0.f};
+          if (a_live && !(dbg & 1)) {
+            const unsigned char* lp = inl + (j & 1) * TF_INBUF + (1 + py) * TF_INB;
+#pragma unroll
+            for (int q = -1; q < 4; ++q) {
+#pragma unroll
+              for (int txx = 0; txx < 2; ++txx) {
+#pragma unroll
+                for (int xq = 0; xq < 3; ++xq) {
+                  const frag bf = *reinterpret_cast<const frag*>(lp + q * TF_INB + a_ld[txx][xq]);
+                  if (q >= 0) acc[q][xq] = Mma<T>::mma(wf[txx], bf, acc[q][xq]);
+                  if (q + 1 < 4) acc[q + 1][xq] = Mma<T>::mma(wf[2 + txx], bf, acc[q + 1][xq]);
+                }
               }
             }
           }
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int Y = 8 * j + 4 + 2 * r + py;      // wave-uniform
+            const bool yimg = a_live && Y >= 0 && Y < Hf;
+            unsigned char* const row = t1 + tf_t1slot(Y) * TF_T1B;
+#pragma unroll
+            for (int xq = 0; xq < 3; ++xq) {
+              floatx4 v = floatx4{0.f, 0.f, 0.f, 0.f};
+              if (yimg) {
+                v = acc[r][xq] * scT + shT;
+                if (actT == 1) {
+#pragma unroll
+                  for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
+                }
+              }
+              half4 o = {(half_t)v[0], (half_t)v[1], (half_t)v[2], (half_t)v[3]};
+              if (!a_ximg[xq]) o = half4{(half_t)0, (half_t)0, (half_t)0, (half_t)0};   // (two selects on the packed result)
+              if (a_keep[xq]) *reinterpret_cast<half4*>(row + a_pix[xq]) = o;
+            }
+          }
         }
+        if (j - 3 >= k0 && j - 3 < k1 && !(dbg & 16)) finish(j - 3);
+        if (band_live(j + 1)) stage(j + 1);
+      }
+    } else {
+      // ============================ waves 4..7: 3x3 (B) of band j-1: rows 2w, 2w+1 of the band, five 16-column tiles ============================
+      const int w = wave - 4;
+      frag wb[3][2];
+      {
+        const T* pb = a.w3 + (size_t)r16 * (3 * 2 * 32) + h * 8;
 #pragma unroll
-        for (int r = 0; r < 2; ++r) {
-          const int Y = 8 * j + 4 + 2 * (2 * hf + r) + py;   // wave-uniform
-          const bool yimg = a_live && Y >= 0 && Y < Hf;
-          unsigned char* const row = t1 + ((Y + 4 * TF_T1R) & (TF_T1R - 1)) * TF_T1B;
+        for (int dy = 0; dy < 3; ++dy)
 #pragma unroll
-          for (int xq = 0; xq < 3; ++xq) {
-            floatx4 v = floatx4{0.f, 0.f, 0.f, 0.f};
-            if (yimg) {
-              v = acc[r][xq] * scT + shT;
-              if (actT == 1) {
+          for (int c = 0; c < 2; ++c) wb[dy][c] = load_frag<T>(pb + (dy * 2 + c) * 32);
+      }
+      const floatx4 sc3 = *reinterpret_cast<const floatx4*>(a.s3 + n), sh3 = *reinterpret_cast<const floatx4*>(a.t3 + n);
+      // column tile ct of the lane = t2 pixel P = 16 ct + r16 = X - (X0 - 3); the reflected copy of a padding column of the 7x7 is stored by its source's owner
+      int b_ld[2][5], b_off[5], b_moff[5];
+      bool b_keep[5], b_mir[5];
+#pragma unroll
+      for (int ct = 0; ct < 5; ++ct) {
+        const int P = 16 * ct + r16, X = X0 - 3 + P;
+#pragma unroll
+        for (int c = 0; c < 2; ++c) b_ld[c][ct] = tf_t1col(16 * ct + r16 + 2 * c + (h >> 1)) * 32 + (h & 1) * 16;
+        b_keep[ct] = P < TF_ZW && X >= 0 && X < Wf;
+        b_off[ct] = (tf_zpiece(P & 127, h >> 1) << 4) + (h & 1) * 8;
+        const int Xm = (X >= 1 && X <= 3) ? -X : (X >= Wf - 4 && X <= Wf - 2) ? 2 * (Wf - 1) - X : -100000;
+        const int Pm = Xm - (X0 - 3);
+        b_mir[ct] = b_keep[ct] && Pm >= 0 && Pm < TF_ZW;
+        b_moff[ct] = (tf_zpiece(Pm & 127, h >> 1) << 4) + (h & 1) * 8;
+      }
+      for (int j = k0 - 2; j <= jend; ++j) {
+        __syncthreads();
+        const int bj = j - 1;
+        if (band_live(j + 1) && !(dbg & 32)) fetch(j + 1);
+        if (bj >= k0 - 1 && bj < k1) {
+          floatx4 bc[2][5];
+#pragma unroll
+          for (int r = 0; r < 2; ++r)
+#pragma unroll
+            for (int ct = 0; ct < 5; ++ct) bc[r][ct] = floatx4{0.f, 0.f, 0.f, 0.f};
+          if (!(dbg & 2))
+#pragma unroll
+          for (int iy = 0; iy < 4; ++iy) {
+            const unsigned char* lp = t1 + tf_t1slot(8 * bj + 2 + 2 * w + iy) * TF_T1B;
+#pragma unroll
+            for (int c = 0; c < 2; ++c)
+#pragma unroll
+              for (int ct = 0; ct < 5; ++ct) {
+                const frag bf = *reinterpret_cast<const frag*>(lp + b_ld[c][ct]);
+#pragma unroll
+                for (int r = 0; r < 2; ++r) {
+                  const int dy = iy - r;
+                  if (dy >= 0 && dy < 3) bc[r][ct] = Mma<T>::mma(wb[dy][c], bf, bc[r][ct]);
+                }
+              }
+          }
+#pragma unroll
+          for (int r = 0; r < 2; ++r) {
+            const int y = 8 * bj + 3 + 2 * w + r;      // wave-uniform
+            if (y < 0 || y >= Hf) continue;            // the 7x7 reads reflected rows instead
+            unsigned char* const row = t2 + tf_t2slot(y) * TF_ZB;
+#pragma unroll
+            for (int ct = 0; ct < 5; ++ct) {
+              floatx4 v = bc[r][ct] * sc3 + sh3;
+              if (act3 == 1) {
 #pragma unroll
                 for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
               }
+              const half4 o = {(half_t)v[0], (half_t)v[1], (half_t)v[2], (half_t)v[3]};
+              if (b_keep[ct]) *reinterpret_cast<half4*>(row + b_off[ct]) = o;
+              if (b_mir[ct]) *reinterpret_cast<half4*>(row + b_moff[ct]) = o;
             }
-            half4 o = {(half_t)v[0], (half_t)v[1], (half_t)v[2], (half_t)v[3]};
-            if (!a_ximg[xq]) o = half4{(half_t)0, (half_t)0, (half_t)0, (half_t)0};   // (two selects on the packed result)
-            if (a_keep[xq]) *reinterpret_cast<half4*>(row + a_pix[xq]) = o;
           }
         }
-      }
-      __syncthreads();                                 // (B) t1 band j is complete
-      if (band_live(j + 1) && !(dbg & 32)) fetch(j + 1);              // in flight behind stage B
-      if (j < k1 && j >= k0 - 1) {
-        // 3x3 rows 8j+3 .. 8j+10: rows 2 br, 2 br + 1 of the band, this wave's column tiles
-        floatx4 bc[2][3];
-#pragma unroll
-        for (int r = 0; r < 2; ++r)
-#pragma unroll
-          for (int i = 0; i < 3; ++i) bc[r][i] = floatx4{0.f, 0.f, 0.f, 0.f};
-        if (!(dbg & 2))
-#pragma unroll
-        for (int iy = 0; iy < 4; ++iy) {
-          const unsigned char* lp = t1 + ((8 * j + 2 + 2 * br + iy + 4 * TF_T1R) & (TF_T1R - 1)) * TF_T1B;
-#pragma unroll
-          for (int c = 0; c < 2; ++c)
-#pragma unroll
-            for (int i = 0; i < 3; ++i) {
-              if (i == 2 && !third) continue;
-              const frag bf = *reinterpret_cast<const frag*>(lp + b_ld[c][i]);
-#pragma unroll
-              for (int r = 0; r < 2; ++r) {
-                const int dy = iy - r;
-                if (dy >= 0 && dy < 3) bc[r][i] = Mma<T>::mma(wb[dy][c], bf, bc[r][i]);
-              }
-            }
-        }
-#pragma unroll
-        for (int r = 0; r < 2; ++r) {
-          const int y = 8 * j + 3 + 2 * br + r;        // wave-uniform
-          if (y < 0 || y >= Hf) continue;              // the 7x7 reads reflected rows instead
-          unsigned char* const row = t2 + tf_t2slot(y) * TF_ZB;
-#pragma unroll
-          for (int i = 0; i < 3; ++i) {
-            if (i == 2 && !third) continue;
-            floatx4 v = bc[r][i] * sc3 + sh3;
-            if (act3 == 1) {
-#pragma unroll
-              for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
-            }
-            const half4 o = {(half_t)v[0], (half_t)v[1], (half_t)v[2], (half_t)v[3]};
-            if (b_keep[i]) *reinterpret_cast<half4*>(row + b_off[i]) = o;
-            if (b_mir[i]) *reinterpret_cast<half4*>(row + b_moff[i]) = o;
-          }
-        }
+        if (j - 3 >= k0 && j - 3 < k1 && !(dbg & 16)) finish(j - 3);
+        if (band_live(j + 1)) stage(j + 1);
       }
     }
   } else {
-    // ============================ consumer waves: 7x7 + tanh of band j-1 (C), one band behind the producers ============================
+    // ============================ waves 8..11: 7x7 (C) of band j-2: rows 2w, 2w+1, accumulators parked in LDS for the finishing waves ============================
     const int w = wave - 8;
     frag w7[7][TF_ZNCH];
     {
@@ -273,39 +286,32 @@ __global__ __launch_bounds__(768) void k_tail_fused(Grouped<TailArgs> ga, int nb
 #pragma unroll
         for (int c = 0; c < TF_ZNCH; ++c) w7[dy][c] = load_frag<T>(pz + (dy * TF_ZNCH + c) * 32);
     }
-    for (int j = k0 - 2; j <= k1 + 1; ++j) {
-      const int cj = j - 1;
-      const bool live = cj >= k0 && cj < k1;           // wave-uniform
+    for (int j = k0 - 2; j <= jend; ++j) {
+      __syncthreads();
+      const int cj = j - 2;
+      if (cj < k0 || cj >= k1) continue;               // wave-uniform
       floatx4 zc[2] = {floatx4{0.f, 0.f, 0.f, 0.f}, floatx4{0.f, 0.f, 0.f, 0.f}};
-      __syncthreads();                                 // (A) t2 bands cj-1, cj are complete; the producers' epilogue may read band cj-1's accumulators
+      if (!(dbg & 4)) {
 #pragma unroll
-      for (int half = 0; half < 2; ++half) {
-        if (live && !(dbg & 4)) {
+        for (int iy = 0; iy < 8; ++iy) {
+          int yy = 8 * cj + 2 * w + iy - 3;
+          yy = yy < 0 ? -yy : (yy >= Hf ? 2 * Hf - 2 - yy : yy);       // ReflectionPad2d(3)
+          const unsigned char* lp = t2 + tf_t2slot(yy) * TF_ZB;
 #pragma unroll
-          for (int i4 = 0; i4 < 4; ++i4) {
-            const int iy = 4 * half + i4;
-            int yy = 8 * cj + 2 * w + iy - 3;
-            yy = yy < 0 ? -yy : (yy >= Hf ? 2 * Hf - 2 - yy : yy);     // ReflectionPad2d(3)
-            const unsigned char* lp = t2 + tf_t2slot(yy) * TF_ZB;
+          for (int c = 0; c < TF_ZNCH; ++c) {
+            const int G = r16 + (c >> 1);
+            const frag bf = *reinterpret_cast<const frag*>(lp + ((8 * G + ((4 * (c & 1) + h) ^ (G & 6))) << 4));
 #pragma unroll
-            for (int c = 0; c < TF_ZNCH; ++c) {
-              const int G = r16 + (c >> 1);
-              const frag bf = *reinterpret_cast<const frag*>(lp + ((8 * G + ((4 * (c & 1) + h) ^ (G & 6))) << 4));
-#pragma unroll
-              for (int r = 0; r < 2; ++r) {
-                const int dy = iy - r;
-                if (dy >= 0 && dy < 7) zc[r] = Mma<T>::mma(w7[dy][c], bf, zc[r]);
-              }
+            for (int r = 0; r < 2; ++r) {
+              const int dy = iy - r;
+              if (dy >= 0 && dy < 7) zc[r] = Mma<T>::mma(w7[dy][c], bf, zc[r]);
             }
           }
         }
-        if (half == 0) __syncthreads();                // (B) the producers are done reading the previous band's accumulators
       }
-      // lane (r16, h): channel h, output pixels X0 + 4 r16 .. + 3 of rows 8 cj + 2 w + r -> zbuf[row][h][r16]; the producer wave of that row finishes it
-      if (live) {
+      // lane (r16, h): channel h, output pixels X0 + 4 r16 .. + 3 of rows 8 cj + 2 w + r -> zbuf[cj & 1][row][h][r16]
 #pragma unroll
-        for (int r = 0; r < 2; ++r) *reinterpret_cast<floatx4*>(zbuf + (((2 * w + r) * 4 + h) * 16 + r16) * 16) = zc[r];
-      }
+      for (int r = 0; r < 2; ++r) *reinterpret_cast<floatx4*>(zbuf + (cj & 1) * TF_ZBUF + (((2 * w + r) * 4 + h) * 16 + r16) * 16) = zc[r];
     }
   }
 }
@@ -316,8 +322,8 @@ int& cfen_tune_tail_debug() {   // timing experiments (results invalid): 1 no Co
   static int v = 0;
   return v;
 }
-int& cfen_tune_tail_segments() {   // vertical segments a strip is cut into ("tail.segments"): more workgroups against 2 + 1 warm-up bands per segment
-  static int v = 4;
+int& cfen_tune_tail_segments() {   // vertical segments a strip is cut into ("tail.segments"): more workgroups against 5 fill / drain steps per segment.  Measured, batch 8:
+  static int v = 2;                // alone 4 segments are fastest (202 us against 235 for 2); with four forwards in flight 2 segments (2.022-2.030 ms per step against 2.043-2.048)
   return v;
 }
 

@@ -20,7 +20,7 @@ pytestmark = pytest.mark.gpu
 # max-abs bar of the fp16 path on outputs in (-1, 1) with the seeded weights: measured 8.7e-4 .. 9.9e-4 at 512 x 512 in every record of rounds 1-4; the bar sits
 # 5x above that (it was 3e-2: a kernel regression costing a factor 10 in accuracy passed every gate -- VERDICT r04)
 FP16_BAR = 5e-3
-TAIL_FUSED_DEFAULT = 1   # "net.tail_fused" of the shipped library (restored by tests that change it)
+TAIL_FUSED_DEFAULT = 2   # "net.tail_fused" of the shipped library (restored by tests that change it)
 
 
 _SD_CACHE = {}
@@ -221,13 +221,13 @@ def test_profile_entries_label_every_launch():
     launches = prof["launches"]
     assert sum(prof[c][2] for c in net.KERNEL_CLASSES) == len(launches) > 50
     labels = [l[0] for l in launches]
-    assert labels[0].startswith("head.0.0") and any("(x3)" in l for l in labels) and any(l.startswith("tail_R.conv7") for l in labels)
+    assert labels[0].startswith("head.0.0") and any("(x3)" in l for l in labels) and any("tail_R.conv7" in l for l in labels)
     assert all(l[3] > 0 for l in launches)
     assert abs(sum(l[2] for l in launches) - sum(prof[c][1] for c in net.KERNEL_CLASSES)) < 1e-3 * sum(prof[c][1] for c in net.KERNEL_CLASSES)
     # round 4: every record also names the DEVICE KERNEL(S) that ran it (cfen_net_profile_entry_kernel) and, for the token GEMMs, algorithmic bytes
     kernels = [l[4] for l in launches]
     assert all(k.startswith("k_") for k in kernels), [k for k in kernels if not k.startswith("k_")]
-    assert kernels[0].startswith("k_head5") and any(k.startswith("k_gemm_dma") for k in kernels) and any("k_conv7_tz" in k for k in kernels)
+    assert kernels[0].startswith("k_head5") and any(k.startswith("k_gemm_dma") for k in kernels) and any("k_tail_fused" in k or "k_conv7_tz" in k for k in kernels)
     assert all(l[5] >= 0 for l in launches) and any(l[5] > 0 for l in launches if l[4].startswith("k_gemm"))
 
 
@@ -246,7 +246,7 @@ def test_split_k_and_grouping_knobs_do_not_change_results():
             assert all(torch.equal(p, q) for p, q in zip(a, b))
             outs[k] = a
     finally:
-        ops.tune("gemm.splitk", 1)
+        ops.tune("gemm.splitk", 0)          # the shipped default (round 4)
     for p, q in zip(outs[0], outs[1]):
         assert float((p - q).abs().max()) < 5e-3
 
@@ -520,7 +520,7 @@ def test_fused_tail_equals_the_separate_launches_bitwise(size, batch):
     finally:
         ops.tune("net.tail_fused", TAIL_FUSED_DEFAULT)
         ops.tune("net.keep_stages", 0)
-        ops.tune("tail.segments", 4)
+        ops.tune("tail.segments", 2)
     ref = res[(0, 0, 4)]
     for key, got in res.items():
         for a, b in zip(got[0], ref[0]):
