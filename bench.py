@@ -225,6 +225,11 @@ def apply_tuning():
 
 
 def main():
+    # stdout carries exactly ONE line, the result: whatever libraries print there while the run lasts (RCCL's version banner when a communicator comes up)
+    # is sent to stderr; the JSON line goes to the saved descriptor at the end
+    sys.stdout.flush()
+    result_fd = os.dup(1)
+    os.dup2(2, 1)
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=100)
@@ -563,7 +568,8 @@ def main():
             result["extra_configs"] = extra
         if world == 1 and not args.no_cpu_baseline:
             result["cpu_baseline"] = cpu_baseline(cfg, args.cpu_seconds)
-        print(json.dumps(result), flush=True)
+        sys.stdout.flush()
+        os.write(result_fd, (json.dumps(result) + "\n").encode())
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
