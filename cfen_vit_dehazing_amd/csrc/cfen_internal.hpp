@@ -186,7 +186,7 @@ struct ConvDesc;
 bool cfen_tail_fused_supported(int dtype, int cs_in, int Cup_pad, int cs_up, int C3_pad, int Hin, int Win, int Cout7, int out_mode);
 int cfen_tail_fused_impl_g(int dtype, int ng, const CfenUpConv3* u, const ConvDesc* d7, hipStream_t s);
 int& cfen_tune_tail_debug();     // timing experiments of k_tail_fused ("tail.debug", results invalid)
-int& cfen_tune_tail_segments();  // vertical segments per 64-column strip of k_tail_fused ("tail.segments", default 2)
+int& cfen_tune_tail_segments();  // vertical segments per 64-column strip of k_tail_fused ("tail.segments", default 1)
 int& cfen_tune_up_fused();       // 1: GViT's x4 bilinear runs inside the level's fuse conv (k_conv UP), no k_upsample4 launch ("net.up_fused").  Default 0: measured
                                  // 6 launches and 0.35 GB of HBM traffic fewer per forward but 0.7 % SLOWER (the 9-tap interpolation per pixel on the vector
                                  // pipe in front of a K = 48 .. 192 1x1 costs more than the copy it saves: lgcat_conv_d01 72 -> 110 us for a 19 us launch)

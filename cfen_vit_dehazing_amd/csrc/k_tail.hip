@@ -138,7 +138,8 @@ __global__ __launch_bounds__(768) void k_tail_fused(Grouped<TailArgs> ga, int nb
       const floatx4 scT = *reinterpret_cast<const floatx4*>(a.sT + n), shT = *reinterpret_cast<const floatx4*>(a.tT + n);
       // LDS offset of the (tap column, column tile) fragment; epilogue: t1 column of (xq, lane) = 32 xq + 2 r16 + px = X - (X0 - 4)
       int a_ld[2][3], a_pix[3];
-      bool a_keep[3], a_ximg[3];
+      bool a_keep[3];
+      floatx4 a_sc[3], a_sh[3];
 #pragma unroll
       for (int xq = 0; xq < 3; ++xq) {
 #pragma unroll
@@ -149,7 +150,9 @@ __global__ __launch_bounds__(768) void k_tail_fused(Grouped<TailArgs> ga, int nb
         const int idx = 32 * xq + 2 * r16 + px, X = X0 - 4 + idx;
         a_keep[xq] = idx < TF_T1KEEP;
         a_pix[xq] = tf_t1col(idx) * 32 + n * 2;
-        a_ximg[xq] = X >= 0 && X < Wf;                 // a column outside the image is the 3x3's zero padding
+        const bool ximg = X >= 0 && X < Wf;            // a column outside the image is the 3x3's zero padding: exact zeros through a zero scale and shift
+        a_sc[xq] = ximg ? scT : floatx4{0.f, 0.f, 0.f, 0.f};
+        a_sh[xq] = ximg ? shT : floatx4{0.f, 0.f, 0.f, 0.f};
       }
       for (int j = k0 - 2; j <= jend; ++j) {
         __syncthreads();
@@ -185,14 +188,13 @@ __global__ __launch_bounds__(768) void k_tail_fused(Grouped<TailArgs> ga, int nb
             for (int xq = 0; xq < 3; ++xq) {
               floatx4 v = floatx4{0.f, 0.f, 0.f, 0.f};
               if (yimg) {
-                v = acc[r][xq] * scT + shT;
+                v = acc[r][xq] * a_sc[xq] + a_sh[xq];
                 if (actT == 1) {
 #pragma unroll
                   for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
                 }
               }
-              half4 o = {(half_t)v[0], (half_t)v[1], (half_t)v[2], (half_t)v[3]};
-              if (!a_ximg[xq]) o = half4{(half_t)0, (half_t)0, (half_t)0, (half_t)0};   // (two selects on the packed result)
+              const half4 o = {(half_t)v[0], (half_t)v[1], (half_t)v[2], (half_t)v[3]};   // (ReLU on the packed halves -- v_pk_max_f16 -- is NOT bitwise the fp32 one: tested)
               if (a_keep[xq]) *reinterpret_cast<half4*>(row + a_pix[xq]) = o;
             }
           }
@@ -323,7 +325,7 @@ int& cfen_tune_tail_debug() {   // timing experiments (results invalid): 1 no Co
   return v;
 }
 int& cfen_tune_tail_segments() {   // vertical segments a strip is cut into ("tail.segments"): more workgroups against 5 fill / drain steps per segment.  Measured, batch 8:
-  static int v = 2;                // alone 4 segments are fastest (202 us against 235 for 2); with four forwards in flight 2 segments (2.022-2.030 ms per step against 2.043-2.048)
+  static int v = 1;                // alone 4 segments are fastest (202 us against 235 for 2); with four forwards in flight fewer are: 2.043-2.048 ms per step on 4, 2.022-2.046 on 2, 2.023-2.035 on 1
   return v;
 }
 

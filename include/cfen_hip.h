@@ -51,7 +51,7 @@ const char* cfen_last_error(void);
  *   "gemm.mid": the k_gemm_dma tile for launches of more than 512 tiles of 96 x 32 and fewer than 1024 of 96 x 64 (the grouped GViT-2 decoder GEMMs): 2 (default,
  *                  round 5) 96 x 128, 5 / 15 the 96 x 32 tiles of rounds 2-4 on 2 / 3 stages
  *   "net.tail_fused": the decoders' output tails (us_conv_d01* ConvTranspose, 3x3, reflect-pad 7x7 + tanh): 2 (default, round 5) ONE launch (k_tail_fused, both
- *                  intermediate maps in LDS), 1 ConvTranspose + 3x3 fused (k_up_conv3_fused) + the 7x7, 0 three launches -- bitwise equal;  "tail.segments" (default 2):
+ *                  intermediate maps in LDS), 1 ConvTranspose + 3x3 fused (k_up_conv3_fused) + the 7x7, 0 three launches -- bitwise equal;  "tail.segments" (default 1):
  *                  vertical segments a 64-column strip of k_tail_fused is cut into;  "tail.debug": timing experiments (results invalid)
  *   what-if probes (timing only, results invalid): "net.skip_from" / "net.skip_to" leave out the launches of that number range of a forward; "net.extra_launches" adds
  *                  that many one-workgroup launches in front of every ViT block; "net.gvit_dummy_wgs" / "_us" / "_levels" replace GViT blocks by a launch that only holds CUs

@@ -520,7 +520,7 @@ def test_fused_tail_equals_the_separate_launches_bitwise(size, batch):
     finally:
         ops.tune("net.tail_fused", TAIL_FUSED_DEFAULT)
         ops.tune("net.keep_stages", 0)
-        ops.tune("tail.segments", 2)
+        ops.tune("tail.segments", 1)
     ref = res[(0, 0, 4)]
     for key, got in res.items():
         for a, b in zip(got[0], ref[0]):
