@@ -368,6 +368,7 @@ int cfen_tune(const char* key, int value) {
     return CFEN_OK;
   }
   if (!strcmp(key, "net.tail_fused")) { CFEN_CHECK_ARG(value >= 0 && value <= 2, "tune: net.tail_fused is 0, 1 (ConvTranspose + 3x3) or 2 (+ the 7x7)"); cfen_tune_tail_fused() = value; return CFEN_OK; }
+  if (!strcmp(key, "tail.balance")) { cfen_tune_tail_balance() = value; return CFEN_OK; }
   if (!strcmp(key, "tail.debug")) { cfen_tune_tail_debug() = value; return CFEN_OK; }
   if (!strcmp(key, "tail.segments")) { CFEN_CHECK_ARG(value >= 1 && value <= 64, "tune: tail.segments is 1 .. 64"); cfen_tune_tail_segments() = value; return CFEN_OK; }
   if (!strcmp(key, "net.up_fused")) { cfen_tune_up_fused() = value != 0; return CFEN_OK; }

@@ -185,6 +185,7 @@ int cfen_up_conv3_fused_impl_g(int dtype, int ng, const CfenUpConv3* u, hipStrea
 struct ConvDesc;
 bool cfen_tail_fused_supported(int dtype, int cs_in, int Cup_pad, int cs_up, int C3_pad, int Hin, int Win, int Cout7, int out_mode);
 int cfen_tail_fused_impl_g(int dtype, int ng, const CfenUpConv3* u, const ConvDesc* d7, hipStream_t s);
+int& cfen_tune_tail_balance();   // work split between k_tail_fused's wave groups ("tail.balance")
 int& cfen_tune_tail_debug();     // timing experiments of k_tail_fused ("tail.debug", results invalid)
 int& cfen_tune_tail_segments();  // vertical segments per 64-column strip of k_tail_fused ("tail.segments", default 1)
 int& cfen_tune_up_fused();       // 1: GViT's x4 bilinear runs inside the level's fuse conv (k_conv UP), no k_upsample4 launch ("net.up_fused").  Default 0: measured

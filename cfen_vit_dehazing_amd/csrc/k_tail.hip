@@ -42,7 +42,7 @@ CFEN_DEV int tf_zpiece(int P, int q) { const int slot = 2 * P + q; return (slot 
 CFEN_DEV int tf_t1slot(int y) { return (y + 8 * TF_T1R) % TF_T1R; }       // y >= -160
 CFEN_DEV int tf_t2slot(int y) { return (y + 8 * TF_T2R) % TF_T2R; }
 
-__global__ __launch_bounds__(768) void k_tail_fused(Grouped<TailArgs> ga, int nblk, int segb, int dbg) {
+__global__ __launch_bounds__(768) void k_tail_fused(Grouped<TailArgs> ga, int nblk, int segb, int dbg, int bal, unsigned long long* stamps) {
   const TailArgs& a = ga.g[blockIdx.z];
   typedef half_t T;
   typedef half8 frag;
@@ -62,11 +62,15 @@ __global__ __launch_bounds__(768) void k_tail_fused(Grouped<TailArgs> ga, int nb
   // scalars of the argument block the band loop uses: read once (behind a barrier the compiler re-reads them from the kernel arguments, an s_load + lgkmcnt(0) per use)
   const int actT = a.actT, act3 = a.act3, act7 = a.act7, Cout = a.Cout, out_mode = a.out_mode, Hin = a.Hin, Win = a.Win;
   void* const outp = a.out;
+  // in-kernel stamps (tail.debug & 64): workgroup 0 of problem 0, lane 0 of the first wave of each group: [step][group][after the barrier, own work done]
+  const bool stamper = stamps && blk == 0 && blockIdx.z == 0 && lane == 0 && (wave == 0 || wave == 4 || wave == 8);
+  auto stamp = [&](int step, int which) { if (stamper && step < 96) stamps[(step * 3 + (wave >> 2)) * 2 + which] = __builtin_amdgcn_s_memrealtime(); };
   auto band_live = [&](int j) { return j >= k0 - 2 && j < k1 && 8 * j + 11 >= 0 && 8 * j + 4 < Hf; };   // ConvTranspose rows 8j+4 .. 8j+11 are wanted and meet the image
   const int jend = k1 + 2;                             // the last step finishes band k1 - 1
 
   if (wave < 8) {
-    // ---- staging (waves 0..7): the 6 rows x 40 columns x 4 pieces of 16 bytes of a band are dealt over 512 threads, two pieces each ----
+    // ---- staging (waves 0..7): the 6 rows x 40 columns x 4 pieces of 16 bytes of a band are dealt over 512 threads, two pieces each (all of it on the
+    //      ConvTranspose waves, four pieces each: slower, 277 against 265 us) ----
     const int src_pixb = a.cs_in * 2, src_pieces = src_pixb / 16;
     const unsigned char* src = (const unsigned char*)a.in + (size_t)b * a.Hin * a.Win * src_pixb;
     int s_row[2], s_off[2], s_dst[2];
@@ -96,9 +100,9 @@ __global__ __launch_bounds__(768) void k_tail_fused(Grouped<TailArgs> ga, int nb
     };
     const float sc7 = a.s7[h], sh7 = a.t7[h];            // (h = 3 may read a padding entry of the [16] table; its results are never stored)
     // finish band e (waves 0..7 = its rows): scale, tanh, store -- k_conv7_tz's epilogue on the accumulators the C waves parked
-    auto finish = [&](int e) {
-      const int y = 8 * e + wave;
-      floatx4 v = *reinterpret_cast<const floatx4*>(zbuf + (e & 1) * TF_ZBUF + ((wave * 4 + h) * 16 + r16) * 16) * sc7 + sh7;
+    auto finish = [&](int e, int row) {
+      const int y = 8 * e + row;
+      floatx4 v = *reinterpret_cast<const floatx4*>(zbuf + (e & 1) * TF_ZBUF + ((row * 4 + h) * 16 + r16) * 16) * sc7 + sh7;
       if (act7 == 1) {
 #pragma unroll
         for (int q = 0; q < 4; ++q) v[q] = fmaxf(v[q], 0.f);
@@ -155,7 +159,9 @@ __global__ __launch_bounds__(768) void k_tail_fused(Grouped<TailArgs> ga, int nb
         a_sh[xq] = ximg ? shT : floatx4{0.f, 0.f, 0.f, 0.f};
       }
       for (int j = k0 - 2; j <= jend; ++j) {
+        stamp(j - (k0 - 2), 1);
         __syncthreads();
+        stamp(j - (k0 - 2) + 1, 0);
         const bool a_live = band_live(j);              // wave-uniform
         if (band_live(j + 1) && !(dbg & 32)) fetch(j + 1);
         if (j < k1) {
@@ -199,7 +205,10 @@ __global__ __launch_bounds__(768) void k_tail_fused(Grouped<TailArgs> ga, int nb
             }
           }
         }
-        if (j - 3 >= k0 && j - 3 < k1 && !(dbg & 16)) finish(j - 3);
+        if (j - 3 >= k0 && j - 3 < k1 && !(dbg & 16)) {
+          if (bal & 1) { finish(j - 3, 2 * wave); finish(j - 3, 2 * wave + 1); }   // all eight rows on the ConvTranspose waves (the 3x3 waves are the long pole)
+          else finish(j - 3, wave);
+        }
         if (band_live(j + 1)) stage(j + 1);
       }
     } else {
@@ -230,7 +239,9 @@ __global__ __launch_bounds__(768) void k_tail_fused(Grouped<TailArgs> ga, int nb
         b_moff[ct] = (tf_zpiece(Pm & 127, h >> 1) << 4) + (h & 1) * 8;
       }
       for (int j = k0 - 2; j <= jend; ++j) {
+        stamp(j - (k0 - 2), 1);
         __syncthreads();
+        stamp(j - (k0 - 2) + 1, 0);
         const int bj = j - 1;
         if (band_live(j + 1) && !(dbg & 32)) fetch(j + 1);
         if (bj >= k0 - 1 && bj < k1) {
@@ -273,7 +284,7 @@ __global__ __launch_bounds__(768) void k_tail_fused(Grouped<TailArgs> ga, int nb
             }
           }
         }
-        if (j - 3 >= k0 && j - 3 < k1 && !(dbg & 16)) finish(j - 3);
+        if (j - 3 >= k0 && j - 3 < k1 && !(dbg & 16) && !(bal & 1)) finish(j - 3, wave);
         if (band_live(j + 1)) stage(j + 1);
       }
     }
@@ -289,7 +300,9 @@ __global__ __launch_bounds__(768) void k_tail_fused(Grouped<TailArgs> ga, int nb
         for (int c = 0; c < TF_ZNCH; ++c) w7[dy][c] = load_frag<T>(pz + (dy * TF_ZNCH + c) * 32);
     }
     for (int j = k0 - 2; j <= jend; ++j) {
+      stamp(j - (k0 - 2), 1);
       __syncthreads();
+      stamp(j - (k0 - 2) + 1, 0);
       const int cj = j - 2;
       if (cj < k0 || cj >= k1) continue;               // wave-uniform
       floatx4 zc[2] = {floatx4{0.f, 0.f, 0.f, 0.f}, floatx4{0.f, 0.f, 0.f, 0.f}};
@@ -320,6 +333,11 @@ __global__ __launch_bounds__(768) void k_tail_fused(Grouped<TailArgs> ga, int nb
 
 }  // namespace
 
+int& cfen_tune_tail_balance() {   // work split between the wave groups ("tail.balance"): bit 0 = the 7x7's scale / tanh / store of all eight rows on the ConvTranspose waves.
+  static int v = 0;              // In-kernel stamps (tools/dbg_tail_stamps.py): per band the ConvTranspose waves are busy 3.05 us, the 3x3 waves 4.2, the 7x7 waves 3.45 -> with bit 0
+                                 // 3.3 / 3.8 / 3.45 and the launch 8 % shorter alone (265 against 287 us), but no faster with four forwards in flight (2.090-2.109 against 2.084-2.092 ms)
+  return v;
+}
 int& cfen_tune_tail_debug() {   // timing experiments (results invalid): 1 no ConvTranspose MFMAs, 2 no 3x3 MFMAs, 4 no 7x7 MFMAs, 8 no tanh, 16 no output stores, 32 no input fetch
   static int v = 0;
   return v;
@@ -365,7 +383,22 @@ int cfen_tail_fused_impl_g(int dtype, int ng, const CfenUpConv3* u, const ConvDe
     }
     attr_set = true;
   }
-  CFEN_LAUNCH(k_tail_fused, dim3(cfen_grid8(nblk), 1, ng), dim3(768), TF_LDS, s, ga, (int)nblk, bands / nseg, cfen_tune_tail_debug());
+  static unsigned long long* stamps = nullptr;
+  const bool stamping = (cfen_tune_tail_debug() & 64) != 0;
+  if (stamping && !stamps && hipMalloc(&stamps, 96 * 3 * 2 * sizeof(unsigned long long)) != hipSuccess) stamps = nullptr;
+  if (stamping && stamps) (void)hipMemsetAsync(stamps, 0, 96 * 3 * 2 * sizeof(unsigned long long), s);
+  CFEN_LAUNCH(k_tail_fused, dim3(cfen_grid8(nblk), 1, ng), dim3(768), TF_LDS, s, ga, (int)nblk, bands / nseg, cfen_tune_tail_debug(), cfen_tune_tail_balance(), stamping ? stamps : nullptr);
+  if (stamping && stamps && !cfen_recorder()) {   // timing experiment: per-step stamps of workgroup 0 to stderr (100 MHz ticks -> us)
+    unsigned long long hst[96 * 3 * 2];
+    if (hipStreamSynchronize(s) == hipSuccess && hipMemcpy(hst, stamps, sizeof(hst), hipMemcpyDeviceToHost) == hipSuccess) {
+      const unsigned long long t0 = hst[2];
+      for (int st = 1; st < 96 && hst[(st * 3) * 2]; ++st) {
+        fprintf(stderr, "tail step %2d:", st);
+        for (int g = 0; g < 3; ++g) fprintf(stderr, "  %c start %7.2f busy %5.2f", "ABC"[g], (double)(hst[(st * 3 + g) * 2] - t0) * 0.01, hst[(st * 3 + g) * 2 + 1] ? (double)(hst[(st * 3 + g) * 2 + 1] - hst[(st * 3 + g) * 2]) * 0.01 : 0.0);
+        fprintf(stderr, "\n");
+      }
+    }
+  }
   CFEN_CHECK_LAUNCH("tail (fused)");
   return CFEN_OK;
 }
