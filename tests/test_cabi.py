@@ -61,8 +61,11 @@ def test_tuning_knobs_validate_without_a_gpu():
     assert lib.cfen_tune(b"no.such.knob", 1) == -1 and b"unknown key" in lib.cfen_last_error()
     assert lib.cfen_tune(b"gemm.kernel", 99) == -1
     assert lib.cfen_tune(b"gemm.large", 1) == -1            # tile ids are 2..5 (+10 / +20 for deeper rings)
-    for key, val in ((b"gemm.kernel", -1), (b"gemm.large", 4), (b"gemm.small", 15), (b"gemm.splitk", 1), (b"mlp.small_tiles", 10),
-                     (b"net.attn_head_major", 1), (b"net.embed_gather", 1), (b"net.fused_front_max_dim", 192), (b"net.skip_classes", 0)):
+    assert lib.cfen_tune(b"net.tail_fused", 3) == -1 and lib.cfen_tune(b"tail.segments", 0) == -1 and lib.cfen_tune(b"gemm.mid", 7) == -1
+    for key, val in ((b"gemm.kernel", -1), (b"gemm.large", 4), (b"gemm.small", 15), (b"gemm.mid", 2), (b"gemm.splitk", 0), (b"mlp.small_tiles", 10),
+                     (b"net.attn_head_major", 1), (b"net.embed_gather", 1), (b"net.fused_front_max_dim", 192), (b"net.skip_classes", 0),
+                     (b"net.tail_fused", 2), (b"tail.segments", 1), (b"tail.balance", 0), (b"tail.debug", 0), (b"net.skip_from", -1), (b"net.skip_to", -1),
+                     (b"net.extra_launches", 0), (b"net.gvit_dummy_levels", 0)):
         assert lib.cfen_tune(key, val) == 0, key       # (the shipped defaults: the knobs are process-wide)
 
 
