@@ -495,7 +495,10 @@ def test_fused_tail_equals_the_separate_launches_bitwise(size, batch):
     x = synthetic_input(batch, cfg).to("cuda:0")
     res = {}
     try:
-        for fused, keep, seg in ((0, 0, 4), (1, 1, 4), (1, 0, 4), (2, 0, 4), (2, 0, 1), (2, 0, 2), (2, 0, 8)):
+        configs = ((0, 0, 4), (1, 1, 4), (1, 0, 4), (2, 0, 4), (2, 0, 1), (2, 0, 2), (2, 0, 8))
+        if ls >= 512:       # 1024 x 1024: the separate launches, the shipped shape and one other segmentation
+            configs = ((0, 0, 4), (1, 1, 4), (2, 0, 1), (2, 0, 4))
+        for fused, keep, seg in configs:
             ops.tune("net.tail_fused", fused)
             ops.tune("net.keep_stages", keep)
             ops.tune("tail.segments", seg)
