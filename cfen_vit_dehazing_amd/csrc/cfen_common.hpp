@@ -114,6 +114,18 @@ CFEN_DEV float col_max(float v) {
   return fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
 }
 
+// Two adjacent 16-feature tiles of the same 16 tokens -> ONE 16-byte store per lane (round 5).  A lane (token r16, row h of 16 lanes) holds features 4h .. 4h+3 of each
+// tile; v_permlane16_swap exchanges the odd rows of tile A with the even rows of tile B, after which row 0 holds A's features 0..7, row 1 B's 0..7, row 2 A's 8..15,
+// row 3 B's 8..15: every lane stores 8 consecutive features (feature offset from A's first: 16 (h & 1) + 8 (h >> 1)), a store instruction covers 64 bytes per token
+// instead of 32, and there are half as many store instructions.  Pure data movement: the stored bits are those of the two 8-byte stores.
+CFEN_DEV uint4 pair_tiles16(floatx4 a, floatx4 b) {
+  const half4 ha = {(half_t)a[0], (half_t)a[1], (half_t)a[2], (half_t)a[3]}, hb = {(half_t)b[0], (half_t)b[1], (half_t)b[2], (half_t)b[3]};
+  const uint2 ua = __builtin_bit_cast(uint2, ha), ub = __builtin_bit_cast(uint2, hb);
+  auto lo = __builtin_amdgcn_permlane16_swap(ua.x, ub.x, false, false);
+  auto hi = __builtin_amdgcn_permlane16_swap(ua.y, ub.y, false, false);
+  return uint4{lo[0], hi[0], lo[1], hi[1]};
+}
+
 // Reductions inside a 16-lane row with DPP (quad_perm xor1 / xor2, row_half_mirror, row_mirror): pure VALU.
 // Every lane of the row ends with the bitwise identical total.
 template <int CTRL> CFEN_DEV float dpp_mov(float v) {

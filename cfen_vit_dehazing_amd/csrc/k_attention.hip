@@ -555,9 +555,11 @@ __global__ __launch_bounds__(NW * 64) void k_attention_hm_long(PtrG<const half_t
     for (int j = 0; j < 2; ++j) {
       const float l = col_sum(h == 2 ? o[1][j][0] : 0.f);   // row 24 of O^T = sum of the probabilities (rescaled with the rest)
       const float inv = 1.f / l;
-      half_t* op = O + ((size_t)seq * S + q0[j] + r16) * D + head * DH + 4 * h;
-      store4<half_t>(op, o[0][j] * inv);
-      if (h < 2) store4<half_t>(op + 16, o[1][j] * inv);
+      // the 24 features of the head leave as one 16-byte store from three of the four lane rows (pair_tiles16: row 0 features 0..7, row 1 16..23, row 2 8..15; row 3
+      // holds the padding rows of the second tile)
+      const uint4 v = pair_tiles16(o[0][j] * inv, o[1][j] * inv);
+      half_t* op = O + ((size_t)seq * S + q0[j] + r16) * D + head * DH + 16 * (h & 1) + 8 * (h >> 1);
+      if (h < 3) *reinterpret_cast<uint4*>(op) = v;
     }
   }
 }

@@ -380,7 +380,9 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(2, 2)))
   constexpr int NG = RT * GPT;                        // ... per chunk
   static_assert(RS % 16 == 0 && RS * PP1 % 64 == 0 && D % RS == 0 && NCH % 3 == 0, "chunk geometry");
   constexpr int NC = NEC + NQC, PF = NS - 1;          // chunks; chunks in flight beyond the one being multiplied
-  static_assert(NS >= 2 && NS * STAGE <= 80 * 1024 && PF <= NEC && (PF - 1) * NI + PF * RT * TM <= 31, "ring geometry");
+  constexpr bool PAIR = RT % 2 == 0 && ND % 2 == 0;   // adjacent feature tiles leave as one 16-byte store per lane (eq_pair_tiles)
+  constexpr int QST = PAIR ? RT / 2 * TM : RT * TM;   // QKV store instructions per chunk and wave
+  static_assert(NS >= 2 && NS * STAGE <= 80 * 1024 && PF <= NEC && (PF - 1) * NI + PF * QST <= 31, "ring geometry");
   typedef half8 frag;
   __shared__ __attribute__((aligned(1024))) unsigned char lds[NS * STAGE];
   const int tid = threadIdx.x, lane = tid & 63, r16 = lane & 15, h = lane >> 4;
@@ -474,9 +476,15 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(2, 2)))
   });
 #pragma unroll
   for (int j = 0; j < TM; ++j) {
-    T* yp = (T*)a.X1 + tk[j] * D + 4 * h;
+    if constexpr (PAIR) {
+      T* yp = (T*)a.X1 + tk[j] * D + 16 * (h & 1) + 8 * (h >> 1);
 #pragma unroll
-    for (int i = 0; i < ND; ++i) store4<T>(yp + i * 16, acc[i][j]);
+      for (int i = 0; i < ND; i += 2) *reinterpret_cast<uint4*>(yp + i * 16) = pair_tiles16(acc[i][j], acc[i + 1][j]);
+    } else {
+      T* yp = (T*)a.X1 + tk[j] * D + 4 * h;
+#pragma unroll
+      for (int i = 0; i < ND; ++i) store4<T>(yp + i * 16, acc[i][j]);
+    }
   }
   // ---- LayerNorm(y) -> B fragments ----
 #pragma unroll
@@ -522,13 +530,13 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(2, 2)))
     // stores and LayerNorm parameter loads sit behind the DMA too -- drain)
     // (with NS stages: behind the DMA of chunk c come the tile stores of PF chunks and the DMAs of the up to PF - 1 younger chunks)
     if (cq == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    else if constexpr (NS == 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(RT * TM) : "memory");
-    else eq_wait_vmcnt((PF - 1 < NC - 1 - c ? PF - 1 : NC - 1 - c) * nd + (cq < PF ? cq : PF) * RT * TM);
+    else if constexpr (NS == 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(QST) : "memory");
+    else eq_wait_vmcnt((PF - 1 < NC - 1 - c ? PF - 1 : NC - 1 - c) * nd + (cq < PF ? cq : PF) * QST);
     __builtin_amdgcn_s_barrier();
     if (c + PF < NC) issue(c + PF, (c + PF) % NS);
     const unsigned char* buf = lds + (c % NS) * STAGE;
     frag F[2][3];
-    floatx4 q[TM];
+    floatx4 q[TM], qe[TM];                            // qe: the even tile of a pair, kept until its odd neighbour is done
     load_g(buf, std::integral_constant<int, 0>{}, F[0]);
     eq_static_for<0, NG>([&](auto gc) {
       constexpr int g = decltype(gc)::value, u = g / GPT, cg = g % GPT;
@@ -543,10 +551,22 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(2, 2)))
 #pragma unroll
         for (int j = 0; j < TM; ++j) q[j] = Mma<T>::mma(F[g & 1][k], xb[cg * 3 + k][j], q[j]);
       if constexpr (cg == GPT - 1) {
-        const int f = (cq * RT + u) * 16 + 4 * h;
-        const long long fo = a.hm_heads ? hm_feature_off<D>(f, S) : f;
+        if constexpr (PAIR) {
+          if constexpr ((u & 1) == 0) {
 #pragma unroll
-        for (int j = 0; j < TM; ++j) store4<T>((T*)a.QKV + qrow[j] + fo, q[j]);
+            for (int j = 0; j < TM; ++j) qe[j] = q[j];
+          } else {
+            const int f = (cq * RT + u - 1) * 16 + 16 * (h & 1) + 8 * (h >> 1);     // 8 consecutive features, inside one head (heads are 24 = 3 x 8 wide)
+            const long long fo = a.hm_heads ? hm_feature_off<D>(f, S) : f;
+#pragma unroll
+            for (int j = 0; j < TM; ++j) *reinterpret_cast<uint4*>((T*)a.QKV + qrow[j] + fo) = pair_tiles16(qe[j], q[j]);
+          }
+        } else {
+          const int f = (cq * RT + u) * 16 + 4 * h;
+          const long long fo = a.hm_heads ? hm_feature_off<D>(f, S) : f;
+#pragma unroll
+          for (int j = 0; j < TM; ++j) store4<T>((T*)a.QKV + qrow[j] + fo, q[j]);
+        }
       }
       __builtin_amdgcn_sched_barrier(0);
     });

@@ -535,12 +535,13 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(NW / 4,
   for (int j = 0; j < TM; ++j) {
     const int t = tok[j];
     const int y0 = wy * a.ws + (t / tw) * a.p, x0 = wx * a.ws + (t % tw) * a.p;
+    // adjacent feature tiles leave as one 16-byte store per lane (cfen_common.hpp pair_tiles16): 8 consecutive features = 8 channels of one patch pixel (C = 24)
 #pragma unroll
-    for (int i = 0; i < ND; ++i) {
-      const int f = i * 16 + 4 * h;
+    for (int i = 0; i < ND; i += 2) {
+      const int f = i * 16 + 16 * (h & 1) + 8 * (h >> 1);
       const int ij = f / a.C, c = f - ij * a.C;
       T* dst = (T*)a.out + (((size_t)b * a.H + y0 + ij / a.p) * a.W + x0 + ij % a.p) * a.cs_out + c;
-      store4<T>(dst, acc[i][j]);
+      *reinterpret_cast<uint4*>(dst) = pair_tiles16(acc[i][j], acc[i + 1][j]);
     }
   }
 }
@@ -567,8 +568,8 @@ int cfen_lvit_window_impl_g(int dtype, int ng, const LvitArgs* ap, hipStream_t s
     const int D = a.p * a.p * a.C, tw = a.p ? a.ws / a.p : 0;
     CFEN_CHECK_ARG(a.p > 0 && a.ws > 0 && a.ws % a.p == 0 && cfen_lvit_window_supported(dtype, D, 4, tw * tw, a.Hm),
                    "lvit_window: fp16, C = 24, p = 2, 32-pixel windows (256 tokens of dim 96, 4 heads), hidden %% 32 == 0 only");
-    CFEN_CHECK_ARG(a.B > 0 && a.H % a.ws == 0 && a.W % a.ws == 0 && a.cs_in >= a.C && a.cs_out >= a.C && a.cs_in % 4 == 0 && a.cs_out % 4 == 0 && a.C % 4 == 0,
-                   "lvit_window: bad map geometry");
+    CFEN_CHECK_ARG(a.B > 0 && a.H % a.ws == 0 && a.W % a.ws == 0 && a.cs_in >= a.C && a.cs_out >= a.C && a.cs_in % 4 == 0 && a.cs_out % 8 == 0 && a.C % 8 == 0 &&
+                   cfen_aligned16(a.out), "lvit_window: bad map geometry (the output map takes 16-byte stores: C and its channel stride multiples of 8)");
     CFEN_CHECK_ARG(a.fmap && a.out && a.Ws && a.be && a.pos && a.ln1_g && a.ln1_b && a.ln2_g && a.ln2_b && a.b1a && a.b2a && a.b1b && a.b2b,
                    "lvit_window: null pointer");
     CFEN_CHECK_ARG(cfen_aligned16(a.fmap) && cfen_aligned16(a.out) && cfen_aligned16(a.Ws) && cfen_aligned16(a.be) && cfen_aligned16(a.pos) &&

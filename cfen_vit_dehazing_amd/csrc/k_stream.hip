@@ -319,28 +319,35 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(WPE, WP
     for (int j = 0; j < TM; ++j) acc[i][j] += bb;
   }
 #pragma unroll
+  // adjacent feature tiles leave as one 16-byte store per lane (pair_tiles16: 8 consecutive features = 8 channels of one patch pixel, C is a multiple of 8)
   for (int j = 0; j < TM; ++j) {
     const long long t = tok0 + j * 16 + r16;
-    if (t >= a.M) continue;
+    const bool live = t < a.M;                         // (every lane takes part in the exchange)
+    const long long tc = live ? t : 0;
+    const int f0 = 16 * (h & 1) + 8 * (h >> 1);
     if (!a.fmap) {
-      T* yp = (T*)a.Y + t * D + 4 * h;
+      T* yp = (T*)a.Y + tc * D + f0;
 #pragma unroll
-      for (int i = 0; i < ND; ++i) store4<T>(yp + i * 16, acc[i][j]);
+      for (int i = 0; i < ND; i += 2) {
+        const uint4 v = pair_tiles16(acc[i][j], acc[i + 1][j]);
+        if (live) *reinterpret_cast<uint4*>(yp + i * 16) = v;
+      }
     } else {
       const int tw = a.ws / a.p, S = tw * tw;
       const int nwx = a.mapW / a.ws, nwy = a.mapH / a.ws;
-      const int tt = (int)(t % S);
-      const long long wi = t / S;
+      const int tt = (int)(tc % S);
+      const long long wi = tc / S;
       const int wx = (int)(wi % nwx), wy = (int)((wi / nwx) % nwy);
       const long long b = wi / ((long long)nwx * nwy);
       const int y0 = wy * a.ws + (tt / tw) * a.p, x0 = wx * a.ws + (tt % tw) * a.p;
 #pragma unroll
-      for (int i = 0; i < ND; ++i) {
-        const int f = i * 16 + 4 * h;
+      for (int i = 0; i < ND; i += 2) {
+        const int f = i * 16 + f0;
         const int ij = f / a.C, c = f - ij * a.C;
         const int pi = ij / a.p, pj = ij - pi * a.p;
         T* dst = (T*)a.fmap + ((b * a.mapH + y0 + pi) * a.mapW + x0 + pj) * a.cs + c;
-        store4<T>(dst, acc[i][j]);
+        const uint4 v = pair_tiles16(acc[i][j], acc[i + 1][j]);
+        if (live) *reinterpret_cast<uint4*>(dst) = v;
       }
     }
   }
@@ -490,9 +497,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
   mfma_results_settle();
 #pragma unroll
   for (int j = 0; j < TM; ++j) {
-    T* yp = (T*)a.X1 + tk[j] * D + 4 * h;
+    T* yp = (T*)a.X1 + tk[j] * D + 16 * (h & 1) + 8 * (h >> 1);
 #pragma unroll
-    for (int i = 0; i < ND; ++i) store4<T>(yp + i * 16, acc[i][j]);
+    for (int i = 0; i < ND; i += 2) *reinterpret_cast<uint4*>(yp + i * 16) = pair_tiles16(acc[i][j], acc[i + 1][j]);   // one 16-byte store per lane and tile pair
   }
   // ---- LayerNorm(y) -> B fragments ----
 #pragma unroll
@@ -549,14 +556,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
       for (int j = 0; j < TM; ++j) qa[v][j] = Mma<T>::mma(fr, xb[c][j], qa[v][j]);
       if constexpr (c == NCH - 1 && v == 1) {
         mfma_results_settle();
-#pragma unroll
-        for (int w2 = 0; w2 < 2; ++w2) {
-          const int fq = (4 * t + 2 * g2 + w2) * 16 + 4 * h;
+        {   // the two tiles of the row group leave as one 16-byte store per lane: 8 consecutive features, inside one head (heads are 24 = 3 x 8 wide)
+          const int fq = (4 * t + 2 * g2) * 16 + 16 * (h & 1) + 8 * (h >> 1);
           const long long fo = a.hm_heads ? st_hm_feature_off<D>(fq, S) : fq;
 #pragma unroll
-          for (int j = 0; j < TM; ++j) store4<T>((T*)a.QKV + qrow[j] + fo, qa[w2][j]);
+          for (int j = 0; j < TM; ++j) *reinterpret_cast<uint4*>((T*)a.QKV + qrow[j] + fo) = pair_tiles16(qa[0][j], qa[1][j]);
         }
-        vm_issued += 2 * TM;
+        vm_issued += TM;
       }
     });
   }
@@ -614,7 +620,7 @@ int cfen_mlp3_impl_g(int dtype, int ng, const Mlp3Args* ap, hipStream_t s) {
                    cfen_aligned16(a.Wb) && cfen_aligned16(a.b1a) && cfen_aligned16(a.b2a) && cfen_aligned16(a.b1b) && cfen_aligned16(a.b2b) &&
                    cfen_aligned16(a.ln_g) && cfen_aligned16(a.ln_b), "mlp3: pointers must be 16-byte aligned");
     if (a.fmap) {
-      CFEN_CHECK_ARG(a.C > 0 && a.C % 4 == 0 && a.cs >= a.C && a.cs % 4 == 0 && a.p > 0 && a.ws % a.p == 0 && a.mapH % a.ws == 0 && a.mapW % a.ws == 0 &&
+      CFEN_CHECK_ARG(a.C > 0 && a.C % 8 == 0 && a.cs >= a.C && a.cs % 8 == 0 && a.p > 0 && a.ws % a.p == 0 && a.mapH % a.ws == 0 && a.mapW % a.ws == 0 &&
                      a.p * a.p * a.C == a.D, "mlp3: bad fold geometry");
       CFEN_CHECK_ARG(a.M % ((long long)(a.ws / a.p) * (a.ws / a.p)) == 0, "mlp3: token count does not tile the map");
     }
