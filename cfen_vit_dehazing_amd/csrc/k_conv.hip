@@ -305,6 +305,23 @@ __global__ __launch_bounds__(NW * 64) void k_conv(Grouped<ConvDesc> dg) {
       }
     __builtin_amdgcn_sched_barrier(0);       // keep the next group's loads out of this one: its registers are what the grouping saves
   }
+  if constexpr (sizeof(T) == 2 && TN >= 2) {
+    if (d.cs_out % 8 == 0) {   // (wave-uniform) pairs of adjacent channel tiles leave as one 16-byte store per lane (cfen_common.hpp pair_tiles16): a 24-channel pixel in ONE instruction
+#pragma unroll
+      for (int j = 0; j < TM; ++j) {
+#pragma unroll
+        for (int i = 0; i + 1 < TN; i += 2) {
+          const int f = i * 16 + 16 * (h & 1) + 8 * (h >> 1);
+          const uint4 v = pair_tiles16(acc[i][j], acc[i + 1][j]);     // every lane takes part in the exchange
+          if (pv[j] && f < d.cs_out) *reinterpret_cast<uint4*>((T*)d.out + opix[j] * d.cs_out + f) = v;
+        }
+        if constexpr (TN % 2 == 1) {
+          if (pv[j] && (TN - 1) * 16 + 4 * h < d.cs_out) store4<T>((T*)d.out + opix[j] * d.cs_out + (TN - 1) * 16 + 4 * h, acc[TN - 1][j]);
+        }
+      }
+      return;
+    }
+  }
 #pragma unroll
   for (int j = 0; j < TM; ++j) {
     if (!pv[j]) continue;
