@@ -245,7 +245,7 @@ def main():
     ap.add_argument("--no-graph", action="store_true", help="launch eagerly instead of replaying a hipGraph")
     ap.add_argument("--gather-dtype", default="auto", choices=["auto", "fp16", "fp32"],
                     help="wire type of the output all-gather (N > 1); auto = the compute dtype")
-    ap.add_argument("--in-flight", type=int, default=0, choices=[0, 1, 2, 3, 4, 5, 6],
+    ap.add_argument("--in-flight", type=int, default=0, choices=[0, 1, 2, 3, 4, 5, 6, 7, 8],
                     help="forwards in flight (0 = default: 4 on one GPU, 3 per rank when an all-gather stream runs beside them): N > 1 = consecutive steps rotate over N launch plans (own workspace and output slab each, shared "
                          "weights) on N streams, so the tail of step i overlaps the head of steps i + 1 .. i + N - 1; every step is still one whole forward of "
                          "one batch and all K steps complete inside the timed region")
