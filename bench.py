@@ -310,7 +310,9 @@ def main():
     torch.cuda.synchronize()
     graphs = None
     nfl = args.in_flight
-    lanes = [torch.cuda.Stream(dev) for _ in range(nfl)] if nfl > 1 else None
+    # CFEN_BENCH_LANE_PRIORITIES="-1,0,0,0" (what-if probe): stream priorities of the lanes (lower = more urgent); default: all equal
+    prios = [int(v) for v in os.environ.get("CFEN_BENCH_LANE_PRIORITIES", "").split(",") if v.strip()]
+    lanes = [torch.cuda.Stream(dev, priority=prios[k % len(prios)]) if prios else torch.cuda.Stream(dev) for k in range(nfl)] if nfl > 1 else None
     if not args.no_graph:
         graphs = []
         for k, s in enumerate(slabs):          # native hipGraph per output slab (and, with two forwards in flight, per launch-plan replica)
