@@ -94,58 +94,23 @@ def nearer_roof(gflop, gbytes, ms, peak_tflops):
     return "mfma", round(gflop / ms, 2), peak_tflops, "TFLOP/s", round(f_m, 5)
 
 
-def time_config(cfg, B, dtype, dev, steps, min_seconds, warmup=3, in_flight=1):
-    """one extra BASELINE configuration on this GPU: build, capture, replay `steps` forwards per timed region until `min_seconds` are
-    timed (median repetition); `in_flight` forwards overlap as in the headline run (serial launch plan per forward, one replica workspace,
-    output slab and stream each).  Returns the same quantities as the headline run, with its own self_check."""
-    from cfen_vit_dehazing_amd.hipnet import dec_ipt
-    from cfen_vit_dehazing_amd.manifest import generate_state_dict, synthetic_input
-    from cfen_vit_dehazing_amd.parallel import split_slab
-    net = dec_ipt(cfg, compute_dtype=dtype)
-    net.load_state_dict(generate_state_dict(cfg, seed=0), strict=True)
-    net.to(dev)
-    net.serial_plan = in_flight > 1
-    n = cfg.image_size
-    x = synthetic_input(B, cfg, seed0=0).to(dev)
-    slabs = [torch.empty(7 * B * n * n, dtype=torch.float32, device=dev) for _ in range(in_flight)]
-    net(x, out=slabs[0])
-    torch.cuda.synchronize()
-    gids = []
-    for k in range(in_flight):
-        net.replica = k
-        gids.append(net.capture(x, out=slabs[k])[0])
-    net.replica = 0
-    streams = [torch.cuda.Stream(dev) for _ in range(in_flight)] if in_flight > 1 else [None]
-
-    def run(count):
-        for i in range(count):
-            k = i % in_flight
-            if streams[k] is None:
-                net.replay(gids[k])
-            else:
-                with torch.cuda.stream(streams[k]):
-                    net.replay(gids[k])
-
-    run(warmup * in_flight)
-    reps = []
-    while sum(reps) < min_seconds and len(reps) < 100:
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        run(steps)
-        torch.cuda.synchronize()
-        reps.append(time.perf_counter() - t0)
-    dt = sorted(reps)[len(reps) // 2]
-    fl = net.flops_per_image()
-    ips = B * steps / dt
-    out = {"workload": "batch=%d %dx%d n_feats=24 hidden_dim_ratio=%d %s" % (B, n, n, cfg.hidden_dim_ratio, dtype),
-           "value": round(ips, 2), "unit": "images/sec", "ms_per_step": round(dt / steps * 1e3, 3), "steps": steps, "repetitions": len(reps),
-           "timing_method": "median of the repetitions", "forwards_in_flight": in_flight,
-           "timed_seconds": round(sum(reps), 3), "gflop_per_image": round(fl / 1e9, 2),
-           "whole_forward_tflops": round(ips * fl / 1e12, 2), "whole_forward_frac": round(ips * fl / 1e12 / MFMA_PEAK_TFLOPS[dtype], 5),
-           "self_check": self_check(net, x, split_slab(slabs[(steps - 1) % in_flight], B, n), cfg, dtype)}
-    del net
-    torch.cuda.empty_cache()
-    return out
+def run_child(extra_args, timeout=420):
+    """one optional leg of the default run as a FRESH PROCESS of this same file in --brief mode (round 6): the leg gets the streams, hardware queues and
+    allocator state of a stand-alone run (inside the headline process configs 4 / 5 measured 6-9 % below their stand-alone runs on the same box), and a hang or an RCCL
+    abort in it is a timeout here, not a lost headline line.  Returns the child's JSON (or {"error": ...})."""
+    import subprocess
+    cmd = [sys.executable, os.path.abspath(__file__), "--brief", "--no-cpu-baseline", "--no-extra-configs"] + [str(a) for a in extra_args]
+    try:
+        r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=timeout, cwd=ROOT)
+    except subprocess.TimeoutExpired:
+        return {"error": "timed out after %d s: %s" % (timeout, " ".join(cmd[2:]))}
+    lines = [l for l in r.stdout.decode(errors="replace").splitlines() if l.startswith("{")]
+    if r.returncode != 0 or not lines:
+        return {"error": "rc %d: %s" % (r.returncode, r.stderr.decode(errors="replace")[-400:])}
+    try:
+        return json.loads(lines[-1])
+    except ValueError as e:
+        return {"error": "unparsable result line: %s" % e}
 
 
 def self_check(net, x, outs, cfg, dtype):
@@ -257,6 +222,10 @@ def main():
     ap.add_argument("--no-extra-configs", action="store_true",
                     help="skip the short timed legs of BASELINE configs 4 (batch 4, 1024x1024) and 5 (batch 16, hidden_dim_ratio 2) in the default run")
     ap.add_argument("--cpu-seconds", type=float, default=20.0)
+    ap.add_argument("--brief", action="store_true",
+                    help="a leg of another run: the timed region and the self-check only (no per-launch profile, no one-forward leg), a compact result line")
+    ap.add_argument("--force-gather", action="store_true",
+                    help="with --gpus 1: run the sharded run's per-rank configuration on ONE GPU -- a world-1 RCCL communicator and the output gatherer behind every step")
     args = ap.parse_args()
     apply_tuning()
 
@@ -274,10 +243,16 @@ def main():
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     dist = None
+    forced_pg = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", device_id=dev)
+    elif args.force_gather:
+        import tempfile
+        import torch.distributed as forced_pg            # a file store: no port to race for
+        store_dir = tempfile.mkdtemp(prefix="cfen_bench_store_")
+        forced_pg.init_process_group("nccl", store=forced_pg.FileStore(os.path.join(store_dir, "store"), 1), rank=0, world_size=1, device_id=dev)
 
     from cfen_vit_dehazing_amd.config import NetConfig
     from cfen_vit_dehazing_amd.hipnet import dec_ipt
@@ -296,7 +271,7 @@ def main():
     nslab = max(2, args.in_flight)
     slabs = [torch.empty(7 * B * n * n, dtype=torch.float32, device=dev) for _ in range(nslab)]
     gdt = args.dtype if args.gather_dtype == "auto" else args.gather_dtype
-    gather = OutputGatherer(world, slabs[0].numel(), dev, torch.float16 if gdt == "fp16" else torch.float32, slots=nslab) if world > 1 else None
+    gather = OutputGatherer(world, slabs[0].numel(), dev, torch.float16 if gdt == "fp16" else torch.float32, slots=nslab) if (world > 1 or args.force_gather) else None
 
     net(x, out=slabs[0])                       # packs weights, builds the plan
     torch.cuda.synchronize()
@@ -395,7 +370,7 @@ def main():
     ips = world * B * args.steps / dt
 
     serial = None
-    if nfl > 1 and graphs is not None:
+    if nfl > 1 and graphs is not None and not args.brief:
         # ONE forward in flight, on the launch plan that is best for it (GViT beside LViT on a second graph branch): the same K-step region on the
         # default stream, >= 0.4 s, median -- reported beside the headline so that what the overlap of consecutive steps buys is visible in every run
         was_serial = net.serial_plan
@@ -428,7 +403,21 @@ def main():
         torch.cuda.synchronize()
 
     result = None
-    if rank == 0:
+    if rank == 0 and args.brief:
+        from cfen_vit_dehazing_amd.parallel import split_slab
+        flops_img = net.flops_per_image()
+        torch.cuda.synchronize()
+        result = {"workload": "batch=%d %dx%d n_feats=24 hidden_dim_ratio=%d %s" % (B, n, n, args.hidden_dim_ratio, args.dtype),
+                  "value": round(ips, 2), "unit": "images/sec", "ms_per_step": round(ms_step, 3), "steps": args.steps, "repetitions": len(reps),
+                  "timing_method": "median of the repetitions; a fresh process of bench.py --brief", "forwards_in_flight": nfl, "timed_seconds": round(sum(reps), 3),
+                  "gflop_per_image": round(flops_img / 1e9, 2), "whole_forward_tflops": round(ips * flops_img / 1e12, 2),
+                  "whole_forward_frac": round(ips * flops_img / 1e12 / MFMA_PEAK_TFLOPS[args.dtype], 5)}
+        if gather is not None:
+            last = (args.steps - 1) % nslab
+            result["gathered_equals_slab"] = bool(torch.equal(gather.bufs[last].reshape(-1)[:slabs[last].numel()], slabs[last].to(gather.bufs[last].dtype)))
+        result["self_check"] = self_check(net, x, split_slab(slabs[(args.steps - 1) % nslab], B, n), cfg, args.dtype)
+        os.write(result_fd, (json.dumps(result) + "\n").encode())
+    elif rank == 0:
         flops_img = net.flops_per_image()
         # per-kernel-class timing with HIP events on the launch stream (3 profiled forwards, median of sums)
         profs = [net.profile(x) for _ in range(3)]
@@ -515,58 +504,28 @@ def main():
         }
         default_run = (B, args.hidden_dim_ratio, args.load_size, args.variant, args.dtype) == (8, 4, 256, "v3", "fp16")
         if world == 1 and default_run and not args.no_extra_configs:
+            # the optional legs, each a fresh process of this file (run_child): a failing or hanging leg cannot cost the headline line, and a leg runs with the
+            # stream / hardware-queue state of a stand-alone run.  This process keeps its weights and workspaces meanwhile (20 GB of 288).
             extra = {}
-            # what the sharded run's communication queue costs a rank, measured instead of modelled: the N = 1 code path WITH the gatherer (a world-1
-            # RCCL communicator, 3 forward lanes + the communication stream, exactly the per-rank configuration of --gpus N) against the same 3 lanes
-            # without it, same graphs, same box, back to back
+            # what the sharded run's communication queue costs a rank, measured instead of modelled: the N = 1 code path WITH the gatherer (a world-1 RCCL
+            # communicator, 3 forward lanes, the wire conversion and an asynchronous all_gather_into_tensor behind every step: exactly the per-rank configuration
+            # of --gpus N) against the same 3 lanes without it, same box, back to back
             if graphs is not None and nfl >= 3:
-                try:
-                    import socket
-                    import torch.distributed as dist1
-                    with socket.socket() as sk:
-                        sk.bind(("127.0.0.1", 0))
-                        port = sk.getsockname()[1]
-                    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-                    os.environ.setdefault("MASTER_PORT", str(port))
-                    dist1.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
-                    main_state = (nslab, nfl, gather)
-                    nslab, nfl = 3, 3
-                    legs = {}
-                    for tag in ("three_lanes_no_gather", "three_lanes_with_gather"):
-                        gather = OutputGatherer(1, slabs[0].numel(), dev, torch.float16 if gdt == "fp16" else torch.float32, slots=nslab) \
-                            if tag.endswith("with_gather") else None
-                        for i in range(6):
-                            step(i)
-                        if gather is not None:
-                            gather.wait_all()
-                        lr = [timed_region()]
-                        while sum(lr) < min(0.4, args.min_seconds) and len(lr) < 50:
-                            lr.append(timed_region())
-                        ldt = sorted(lr)[len(lr) // 2]
-                        legs[tag] = {"value": round(B * args.steps / ldt, 2), "unit": "images/sec", "ms_per_step": round(ldt / args.steps * 1e3, 3), "repetitions": len(lr)}
+                common = ["--steps", args.steps, "--warmup", args.warmup, "--min-seconds", min(0.4, args.min_seconds), "--in-flight", 3]
+                legs = {"three_lanes_no_gather": run_child(common), "three_lanes_with_gather": run_child(common + ["--force-gather"])}
+                if all("error" not in v for v in legs.values()):
                     legs["ms_per_step_added_by_the_gather_queue"] = round(legs["three_lanes_with_gather"]["ms_per_step"] - legs["three_lanes_no_gather"]["ms_per_step"], 3)
-                    torch.cuda.synchronize()
-                    last = (args.steps - 1) % nslab
-                    legs["gathered_equals_slab"] = bool(torch.equal(gather.bufs[last], slabs[last].to(gather.bufs[last].dtype)))
-                    legs["what"] = ("per-rank configuration of the sharded run on ONE GPU: 3 forwards in flight, each followed on its own lane by the wire conversion and an "
-                                    "asynchronous RCCL all_gather_into_tensor of the %s output slab (world-1 communicator, torch's internal collective stream is the "
-                                    "fourth busy queue), one gather slot per slab" % gdt)
-                    nslab, nfl, gather = main_state
-                    dist1.destroy_process_group()
-                    extra["gather_overhead_1gpu"] = legs
-                except Exception as e:          # a failing extra leg must not cost the headline line
-                    extra["gather_overhead_1gpu"] = {"error": "%s: %s" % (type(e).__name__, e)}
-            # BASELINE configs 4 and 5, and the exact-fp32 path (the one that meets north_star's 1e-3 max-abs criterion) at the headline batch, as short
-            # legs of the same run, so that their numbers are observed by whoever runs bench.py
-            del net
-            torch.cuda.empty_cache()
-            for key, ecfg, eb, esteps, edt in (("config4_batch4_1024x1024", NetConfig(24, 4, patch_size=64, load_size=512), 4, 10, args.dtype),
-                                               ("config5_batch16_hdr2", NetConfig(24, 2, patch_size=32, load_size=256), 16, 20, args.dtype),
-                                               ("fp32_batch8", NetConfig(24, 4, patch_size=32, load_size=256), 8, 8, "fp32")):
-                try:
-                    extra[key] = time_config(ecfg, eb, edt, dev, esteps, 0.4, in_flight=nfl)
-                except Exception as e:          # a failing extra leg must not cost the headline line
-                    extra[key] = {"error": "%s: %s" % (type(e).__name__, e)}
+                    legs["gathered_equals_slab"] = legs["three_lanes_with_gather"].get("gathered_equals_slab")
+                legs["what"] = ("per-rank configuration of the sharded run on ONE GPU: 3 forwards in flight, each followed on its own lane by the wire conversion and an "
+                                "asynchronous RCCL all_gather_into_tensor of the %s output slab (world-1 communicator, torch's internal collective stream is the "
+                                "fourth busy queue), one gather slot per slab" % gdt)
+                extra["gather_overhead_1gpu"] = legs
+            # BASELINE configs 4 and 5, and the exact-fp32 path (the one that meets north_star's 1e-3 max-abs criterion) at the headline batch, so that their
+            # numbers are observed by whoever runs bench.py.  40 / 20-step regions: with 4 forwards in flight the fill and drain of a region is about one forward
+            for key, eargs in (("config4_batch4_1024x1024", ["--batch", 4, "--load-size", 512, "--steps", 20]),
+                               ("config5_batch16_hdr2", ["--batch", 16, "--hidden-dim-ratio", 2, "--steps", 40]),
+                               ("fp32_batch8", ["--dtype", "fp32", "--steps", 8])):
+                extra[key] = run_child(eargs + ["--warmup", 3, "--min-seconds", 0.4, "--in-flight", nfl])
             result["extra_configs"] = extra
         if world == 1 and not args.no_cpu_baseline:
             result["cpu_baseline"] = cpu_baseline(cfg, args.cpu_seconds)
@@ -575,6 +534,11 @@ def main():
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
+    if forced_pg is not None:
+        if gather is not None:
+            gather.wait_all()
+        torch.cuda.synchronize()
+        forced_pg.destroy_process_group()
 
 
 if __name__ == "__main__":

@@ -1,5 +1,8 @@
 // extern "C" surface of libcfen_hip.so (declared in include/cfen_hip.h): thin argument adapters over
 // the kernel launchers.  No allocation, no synchronisation, no exceptions.
+#include <cxxabi.h>
+#include <ctype.h>
+#include <unordered_map>
 #include <stdarg.h>
 #include <stdio.h>
 
@@ -58,6 +61,86 @@ int cfen_zero_async(void* p, size_t bytes, hipStream_t s) {
 std::string& cfen_kernel_log() {
   static thread_local std::string log;
   return log;
+}
+
+// "_ZN12_GLOBAL__N_110k_gemm_dmaIDF16_Li1ELi3ELi3EEEv7Grouped..." -> "k_gemm_dma<f16, 1, 3, 3>": the kernel's name and its template arguments where they are
+// builtin types / integer / bool literals (every kernel of this library), "..." for anything else
+static std::string cfen_demangle_lite(const char* sym) {
+  std::string m(sym);
+  size_t q = 0;
+  if (m.rfind("_ZN12_GLOBAL__N_1", 0) == 0) q = 17;
+  else if (m.rfind("_Z", 0) == 0) q = 2;
+  else return m;
+  size_t len = 0;
+  while (q < m.size() && isdigit((unsigned char)m[q])) len = len * 10 + (m[q++] - '0');
+  if (!len || q + len > m.size()) return m;
+  std::string out = m.substr(q, len);
+  q += len;
+  if (q >= m.size() || m[q] != 'I') return out;
+  ++q;
+  out += "<";
+  bool first = true;
+  while (q < m.size() && m[q] != 'E') {
+    std::string a;
+    if (m.compare(q, 5, "DF16_") == 0) { a = "f16"; q += 5; }
+    else if (m[q] == 'f') { a = "f32"; ++q; }
+    else if (m[q] == 'd') { a = "f64"; ++q; }
+    else if (m[q] == 'h') { a = "u8"; ++q; }
+    else if (m[q] == 'i') { a = "int"; ++q; }
+    else if (m[q] == 'L' && q + 2 < m.size()) {
+      const char t = m[q + 1];
+      size_t e = m.find('E', q);
+      if (e == std::string::npos) { a = "..."; q = m.size(); }
+      else {
+        std::string v = m.substr(q + 2, e - q - 2);
+        if (!v.empty() && v[0] == 'n') v[0] = '-';
+        a = t == 'b' ? (v == "1" ? "true" : "false") : v;
+        q = e + 1;
+      }
+    } else { out += first ? "..." : ", ..."; break; }
+    out += (first ? "" : ", ") + a;
+    first = false;
+  }
+  return out + ">";
+}
+
+// host stub -> "k_mlp3<24, 2, 3, 1536, 0, 1, 4, 0, 1, 0>" (see CFEN_LAUNCH)
+void cfen_log_kernel(const void* host_stub, const char* as_written) {
+  std::string& l = cfen_kernel_log();
+  if (l.size() > 600) return;
+  static thread_local std::unordered_map<const void*, std::string> names;
+  auto it = names.find(host_stub);
+  if (it == names.end()) {
+    std::string n;
+    const char* sym = hipKernelNameRefByPtr(host_stub, nullptr);
+    if (sym && *sym) {
+      int st = 0;
+      char* dm = abi::__cxa_demangle(sym, nullptr, nullptr, &st);
+      n = (st == 0 && dm) ? dm : cfen_demangle_lite(sym);       // (libstdc++'s demangler does not know DF16_ = _Float16)
+      free(dm);
+      int depth = 0;      // drop the parameter list: cut at the first '(' outside the template brackets that is not "(anonymous namespace)"
+      for (size_t q = 0; q < n.size(); ++q) {
+        if (n[q] == '<') ++depth;
+        else if (n[q] == '>') --depth;
+        else if (n[q] == '(' && depth == 0 && n.compare(q, 21, "(anonymous namespace)") != 0) { n.resize(q); break; }
+      }
+      if (n.rfind("void ", 0) == 0) n.erase(0, 5);
+      for (const char* drop : {"(anonymous namespace)::", "_Float16", "__half"}) {
+        const std::string d(drop), r = d[0] == '(' ? "" : "half_t";
+        for (size_t q; (q = n.find(d)) != std::string::npos;) n.replace(q, d.size(), r);
+      }
+    }
+    if (n.empty()) {
+      n = as_written;
+      while (!n.empty() && (n.front() == '(' || n.front() == ' ')) n.erase(n.begin());
+      while (!n.empty() && (n.back() == ')' || n.back() == ' ')) n.pop_back();
+    }
+    it = names.emplace(host_stub, n).first;
+  }
+  const std::string& n = it->second;
+  if (l.find(n) != std::string::npos) return;
+  if (!l.empty()) l += " + ";
+  l += n;
 }
 
 hipError_t& cfen_last_launch() {
@@ -258,6 +341,10 @@ int cfen_tune(const char* key, int value) {
   if (!strcmp(key, "mlp3.tm192")) {
     CFEN_CHECK_ARG((value >= 2 && value <= 4) || value == 22 || value == 24 || value == 28 || value == 29 || value == 122 || value == 222 || value == 322, "tune: mlp3.tm192 is 2, 3 or 4 token tiles a wave (one workgroup a CU), 22 / 24 = 2 tiles at 256 registers on a 3- / 4-slot ring");
     cfen_tune_mlp3_tm192() = value;
+    return CFEN_OK;
+  }
+  if (!strcmp(key, "front3.debug")) {
+    cfen_tune_front3_debug() = value;
     return CFEN_OK;
   }
   if (!strcmp(key, "mlp3.debug")) {

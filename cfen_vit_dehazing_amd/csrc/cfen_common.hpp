@@ -226,22 +226,15 @@ static inline hipError_t cfen_launch(void (*kernel)(KArgs...), dim3 grid, dim3 b
   return cfen_add_node(kernel, grid, block, smem, s, packed, std::index_sequence_for<KArgs...>{});
 }
 
-// every launch leaves the kernel's name (the template expression as written at the launch site) in a thread-local log: cfen_net_profile
-// attributes its per-launch times to DEVICE KERNELS with it (bench.py `by_symbol`), not to whatever the host code calls the step
+// every launch leaves the kernel's name in a thread-local log: cfen_net_profile attributes its per-launch times to DEVICE KERNELS with it (bench.py `by_symbol`), not to
+// whatever the host code calls the step.  The name is the INSTANTIATION (round 6: "k_mlp3<24, 2, 3, 1536, 0, 1, 4, 0, 1, 0>", what rocprofv3 prints): the runtime's own
+// record of the host stub -> device symbol registration (hipKernelNameRefByPtr), demangled, cached per stub.  Through round 5 it was the template expression as written at
+// the launch site ("k_mlp3<ND, TM, R, ...>", still the fallback), which merged the D = 192 and D = 384 kernels into one `by_symbol` row.
 #include <string>
 std::string& cfen_kernel_log();
-static inline void cfen_log_kernel(const char* name) {
-  std::string& l = cfen_kernel_log();
-  if (l.size() > 400) return;
-  std::string n(name);
-  while (!n.empty() && (n.front() == '(' || n.front() == ' ')) n.erase(n.begin());
-  while (!n.empty() && (n.back() == ')' || n.back() == ' ')) n.pop_back();
-  if (l.find(n) != std::string::npos) return;
-  if (!l.empty()) l += " + ";
-  l += n;
-}
+void cfen_log_kernel(const void* host_stub, const char* as_written);     // cfen_api.cpp
 #define CFEN_LAUNCH(kernel, grid, block, smem, stream, ...) \
-  (cfen_log_kernel(#kernel), cfen_last_launch() = cfen_launch(kernel, grid, block, smem, stream, __VA_ARGS__))
+  (cfen_log_kernel((const void*)(kernel), #kernel), cfen_last_launch() = cfen_launch(kernel, grid, block, smem, stream, __VA_ARGS__))
 
 #define CFEN_CHECK_LAUNCH(what)                                                    \
   do {                                                                             \

@@ -673,6 +673,10 @@ int cfen_net::run_vit_g(int ng, const VitCall* vc, int scr0) {
   };
   // algorithmic bytes of a token GEMM launch: weights once + tokens in + tokens out (what a weight-streaming GEMM is priced against)
   auto gemm_bytes = [&](int N, int K) { prof_bytes = (double)ng * ((double)N * K + (double)M * K + (double)M * N) * esz; };
+  // ... of a fused token-block launch (round 6: priced for the MFMA-bound kernels too, so that counter traffic / algorithmic bytes can be read from the bench line):
+  // `rows` token-row-sized tensors in and out (M x D elements each: map or token reads, X1 / QKV / ATT / map writes) + `welems` weight elements read once
+  auto block_bytes = [&](double rows, double welems) { prof_bytes = (double)ng * (rows * (double)M * v.D + welems) * esz; };
+  const double DD = (double)v.D * v.D, DH = (double)v.D * v.hidden;
   // Y = act(LN(X) W0^T + b0) with the LayerNorm folded: parameters `lname`.wl / .s / .bl (packing.ln_folded)
   auto gemm_ln = [&](const void* const* X, const std::string& lname, void* const* Y, int N, int K, int relu) -> int {
     CfenGemmPtrs gp[3];
@@ -695,8 +699,10 @@ int cfen_net::run_vit_g(int ng, const VitCall* vc, int scr0) {
       e[g] = CfenEmbedQkvArgs{PM[g], B, v.mapH, v.mapH, v.C, v.C, v.ws, v.p, P(nm[g] + ".embed.ws"), Pf(nm[g] + ".embed.b"), P(nm[g] + ".pos"),
                               Pf(nm[g] + ".ln1.g"), Pf(nm[g] + ".ln1.b"), P(nm[g] + ".qkv.ws"), X1[g], QKV[g], M, v.D, 1e-5f, 0};
     step("front_stream");
+    block_bytes(5, 4 * DD);     // pixels in, X1 + q / k / v out; W_e + W_qkv
     TRYP(K_GEMM, 8 * Md * D * D, cfen_front3_impl_g(dt, ng, e, stream));
     step("attention");
+    block_bytes(4, 0);   // q, k, v in; attention output out
     TRYP(K_ATTN, 4 * Md * v.S * D, cfen_attention_impl_g(dt, ng, cQKV, ATT, B * nwin, v.S, v.heads, v.dh, stream));
     Mlp3Args m[3];
     for (int g = 0; g < ng; ++g) {
@@ -710,6 +716,7 @@ int cfen_net::run_vit_g(int ng, const VitCall* vc, int scr0) {
       m[g].mapH = v.mapH; m[g].mapW = v.mapH; m[g].C = v.C; m[g].cs = v.C; m[g].ws = v.ws; m[g].p = v.p;
     }
     step("proj_mlp_stream");
+    block_bytes(3, DD + 4 * DH);   // X1 + attention output in, map out; W_p + the four MLP matrices
     TRYP(K_MLP, 8 * Md * D * Hd + 2 * Md * D * D, cfen_mlp3_impl_g(dt, ng, m, stream));
     if (gv_skip_up) return CFEN_OK;
     step("upsample4");
@@ -776,6 +783,7 @@ int cfen_net::run_vit_g(int ng, const VitCall* vc, int scr0) {
     };
     TRY(run_chain("chain_embed_qkv", 8 * Md * D * D));
     step("attention");
+    block_bytes(4, 0);   // q, k, v in; attention output out
     TRYP(K_ATTN, 4 * Md * v.S * D, cfen_attention_impl_g(dt, ng, cQKV, ATT, B * nwin, v.S, v.heads, v.dh, stream));
     for (int g = 0; g < ng; ++g) {
       const std::string& n = nm[g];
@@ -807,6 +815,7 @@ int cfen_net::run_vit_g(int ng, const VitCall* vc, int scr0) {
                       Pf(n + ".head1.b"), Pf(n + ".head2.b"), v.hidden, 1e-5f, 1.4426950408889634f / sqrtf((float)(v.D / v.heads))};
     }
     step("window_block_fused");
+    block_bytes(2, 5 * DD + 4 * DH);   // map in, map out; W_e, W_qkv, W_p + the four MLP matrices
     TRYP(K_MLP, 8 * Md * D * D + 4 * Md * v.S * D + 8 * Md * D * Hd + 2 * Md * D * D, cfen_lvit_window_impl_g(dt, ng, w, stream));
     return CFEN_OK;
   }
@@ -823,6 +832,7 @@ int cfen_net::run_vit_g(int ng, const VitCall* vc, int scr0) {
       e[g] = CfenEmbedQkvArgs{IN[g], B, v.mapH, v.mapH, v.C, bi.cs, v.ws, v.p, P(nm[g] + ".embed.ws"), Pf(nm[g] + ".embed.b"), P(nm[g] + ".pos"),
                               Pf(nm[g] + ".ln1.g"), Pf(nm[g] + ".ln1.b"), P(nm[g] + ".qkv.ws"), X1[g], QKV[g], M, v.D, 1e-5f, v.heads};
     step("front_stream");
+    block_bytes(5, 4 * DD);     // pixels in, X1 + q / k / v out; W_e + W_qkv
     TRYP(K_GEMM, 8 * Md * D * D, cfen_front3_impl_g(dt, ng, e, stream));
   } else if (v.fused_front && v.D <= cfen_tune_fused_front_max_dim()) {
     // LViT levels 1-2: gather + linear_encoding + residual + position + LN1 + qkv in one launch, x -> X1, QKV (k_embed.hip)
@@ -833,6 +843,7 @@ int cfen_net::run_vit_g(int ng, const VitCall* vc, int scr0) {
                               Pf(nm[g] + ".ln1.g"), Pf(nm[g] + ".ln1.b"), P(nm[g] + ".qkv.wk"), X1[g], QKV[g], M, v.D, 1e-5f,
                               head_major ? v.heads : 0};
     step("embed_ln_qkv");
+    block_bytes(5, 4 * DD);
     TRYP(K_GEMM, 8 * Md * D * D, cfen_embed_qkv_impl_g(dt, ng, e, stream));
   } else {
     if (v.global || !cfen_tune_embed_gather()) {
@@ -862,6 +873,7 @@ int cfen_net::run_vit_g(int ng, const VitCall* vc, int scr0) {
     }
   }
   step("attention");
+  block_bytes(4, 0);   // q, k, v in; attention output out
   if (head_major)
     TRYP(K_ATTN, 4 * Md * v.S * D, cfen_attention_hm_impl_g(dt, ng, cQKV, ATT, B * nwin, v.S, v.heads, v.D / v.heads, stream));
   else
@@ -885,6 +897,7 @@ int cfen_net::run_vit_g(int ng, const VitCall* vc, int scr0) {
       m[g].mapH = v.mapH; m[g].mapW = v.mapH; m[g].C = v.C; m[g].cs = bo.cs; m[g].ws = v.ws; m[g].p = v.p;
     }
     step("proj_mlp_stream");
+    block_bytes(3, DD + 4 * DH);   // X1 + attention output in, map out; W_p + the four MLP matrices
     TRYP(K_MLP, 8 * Md * D * Hd + 2 * Md * D * D, cfen_mlp3_impl_g(dt, ng, m, stream));
     return CFEN_OK;
   }
@@ -908,6 +921,7 @@ int cfen_net::run_vit_g(int ng, const VitCall* vc, int scr0) {
       m[g].mapH = v.mapH; m[g].mapW = v.mapH; m[g].C = v.C; m[g].cs = v.global ? v.C : bo.cs; m[g].ws = v.ws; m[g].p = v.p;
     }
     step("proj_mlp_fused");
+    block_bytes(3, DD + 4 * DH);
     TRYP(K_MLP, 8 * Md * D * Hd + 2 * Md * D * D, cfen_mlp_impl_g(dt, ng, m, stream));
   } else {
     // src = src + linear2(relu(linear1(LN2(src))))                             (v3:1387-1389)

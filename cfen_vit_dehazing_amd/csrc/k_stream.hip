@@ -36,6 +36,18 @@ CFEN_DEV void st_dma(const void* g, unsigned char* l) {
   __builtin_amdgcn_global_load_lds(g, (__attribute__((address_space(3))) void*)l, 16, 0, 0);
 }
 
+// the same with a wave-uniform source base in SGPRs + one per-lane byte offset (no 64-bit per-lane address registers: the spread refills of k_mlp3 issue
+// one piece at a time from inside the MFMA stream, where every live VGPR is taken) and a wave-uniform LDS byte address.  M0 is compiler-reserved and not
+// preserved around an asm statement: saved and restored here (cdna_hip_programming.md, "LDS-DMA recipe").  Invisible to hipcc's vmcnt bookkeeping, like every
+// wait of the ring.
+CFEN_DEV void st_dma_s(const void* sbase, unsigned voff, unsigned lds_dst) {
+  unsigned keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep)
+               : "v"(voff), "s"(sbase), "s"(lds_dst)
+               : "memory");
+}
+
 // wait until at most `younger` phases of DPW LDS-DMAs each are still in flight (younger <= Y)
 template <int DPW, int Y>
 CFEN_DEV void wait_phases(int younger) {
@@ -79,6 +91,13 @@ CFEN_DEV void mfma_results_settle() {
   __builtin_amdgcn_sched_barrier(0);
 }
 
+// timing experiments: a value whose store is left out stays live (its producers are not dead code)
+CFEN_DEV void keep_live(const uint4& v) {
+  typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+  const u32x4 vv = {v.x, v.y, v.z, v.w};
+  asm volatile("" ::"v"(vv));
+}
+
 CFEN_DEV half8 pack_pair(const floatx4& a, const floatx4& b) {
   half8 f = {(half_t)a[0], (half_t)a[1], (half_t)a[2], (half_t)a[3], (half_t)b[0], (half_t)b[1], (half_t)b[2], (half_t)b[3]};
   return f;
@@ -88,13 +107,22 @@ CFEN_DEV half8 pack_pair(const floatx4& a, const floatx4& b) {
 // A ring slot holds a DOUBLE phase = 2 ND fragments: the W1 slice AND the W2 slice of one 32-unit hidden sub-step (or two k-chunks of Wp).
 // Measured with single phases (one barrier per ND fragments): 0.63 us a phase whether it held 12 or 24 KiB -- barrier skew, the refill of the
 // fragment pipeline and the DMA issue cost ~0.3 us each time, as much as the 48 MFMAs of the phase; one barrier per sub-step halves that.
-// DBG (timing experiments only, results invalid): 1 = no LDS-DMA refills after the prologue, 2 = no MFMAs in the hidden loop
+// DBG (timing experiments only, results invalid), bit flags: 1 = no LDS-DMA refills after the prologue, 2 = no MFMAs in the hidden loop, 4 = no LDS fragment reads (the MFMAs
+// multiply whatever the fragment registers hold), 32 = refills as 4-byte-per-lane pieces (same instruction count, a quarter of the bytes into LDS)
 // WPE (round 5): waves per SIMD the kernel is compiled for.  1 = the whole 512-register file for one wave per SIMD (one workgroup a CU); 2 = 256 registers,
 // so that TWO workgroups of a short ring (R = 3 slots of 24 KiB at D = 192: 78 KB) share a CU -- k_mlp2's occupancy on k_mlp3's fragment-stream ring.
 // NW (round 5): waves per workgroup.  4 = one per SIMD; 8 with TM = 1 and WPE = 2 = the same 128 tokens a workgroup on two waves per SIMD (each covers the
 // other's DMA issue and waits) at twice the LDS fragment reads per token -- the D = 384 A/B of this round.
-template <int ND, int TM, int R, int HB, int DBG = 0, int WPE = 1, int NW = 4, int PDX = 0>
-__global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) void k_mlp3(Grouped<Mlp3Args> ga) {
+// SPR (round 6): how a phase's DPW LDS-DMA pieces per wave are issued.  0 = one burst in front of the phase's MFMAs (rounds 3-5); 1 = SPREAD, one piece behind every NW-th
+// fragment's MFMAs (the texture path then sees one piece per wave per 8 MFMAs instead of 48 pieces at once: the burst cost the issuing = computing wave 60-185 cycles a
+// piece, MI355X_MICROARCH.md "LDS-DMA piece issue cost"); 2 = spread and staggered by wave (wave w issues behind fragment 4k + w).
+// STAMP (timing build, results valid but ~5-10 % slower): per-wave cycle sums of [wait for the phase's DMA | barrier | phase body] of workgroup 0 -> `stamps`.
+// UMAJ (round 6): the W1 fragments of a sub-step are CONSUMED tile by tile (u slowest) instead of k-chunk by k-chunk: the first hidden tile's results are converted to
+// fp16 / ReLU'd between the MFMAs of the second tile, so that only half of the repack sits in the MFMA pipe's idle gap between the two halves of a sub-step (one wave per
+// SIMD: nothing else fills that gap; tools/repro/mfma_rate_probe.hip prices the whole repack at 3.2 cycles per MFMA of the phase).  Only the read order of the LDS image
+// changes -- the stream, the accumulation order of every chain and the results stay bit for bit.
+template <int ND, int TM, int R, int HB, int DBG = 0, int WPE = 1, int NW = 4, int PDX = 0, int SPR = 0, int STAMP = 0, int UMAJ = 0>
+__global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) void k_mlp3(Grouped<Mlp3Args> ga, unsigned long long* stamps) {
   typedef half_t T;
   typedef half8 frag;
   const Mlp3Args a = ga.g[blockIdx.z];
@@ -110,14 +138,18 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(WPE, WP
   const int npp = a.Wp ? NCH / 2 : 0;           // projection double phases
   const int NP = npp + nt * (a.Wb ? 2 : 1);
 
+  auto phase_src = [&](int q) {
+    return q < npp        ? (const unsigned char*)a.Wp + (size_t)q * SLOT
+           : q < npp + nt ? (const unsigned char*)a.Wa + (size_t)(q - npp) * SLOT
+                          : (const unsigned char*)a.Wb + (size_t)(q - npp - nt) * SLOT;
+  };
   auto issue = [&](int q, int slot) {
-    const unsigned char* src = q < npp        ? (const unsigned char*)a.Wp + (size_t)q * SLOT
-                               : q < npp + nt ? (const unsigned char*)a.Wa + (size_t)(q - npp) * SLOT
-                                              : (const unsigned char*)a.Wb + (size_t)(q - npp - nt) * SLOT;
+    const unsigned char* src = phase_src(q);
 #pragma unroll
     for (int k = 0; k < DPW; ++k) {
       const int f = k * NW + wave;
-      st_dma(src + f * 1024 + lane * 16, lds + slot * SLOT + f * 1024);
+      if constexpr (DBG & 32) __builtin_amdgcn_global_load_lds(src + f * 1024 + lane * 4, (__attribute__((address_space(3))) void*)(lds + slot * SLOT + f * 1024), 4, 0, 0);
+      else st_dma(src + f * 1024 + lane * 16, lds + slot * SLOT + f * 1024);
     }
   };
   // ---- prologue: hidden biases -> LDS, the first R - 1 phases into the ring, tokens into registers ----
@@ -157,36 +189,94 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(WPE, WP
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // one drain: biases, ring prologue and tokens have landed
 
   int p = 0, cur = 0, fill = R - 1;
+  // timing build: s_memtime stamps at points where no LDS read is in flight (the scalar load shares lgkmcnt with the hand-counted ds_reads)
+  unsigned long long tk0 = 0, tk_wait = 0, tk_bar = 0, tk_body = 0, tk_last = 0, tk_first = 0, rt0 = 0;
+  auto now = [&]() -> unsigned long long {
+    if constexpr (STAMP) {
+      unsigned long long t;
+      asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
+      return t;
+    } else {
+      return 0ull;
+    }
+  };
+  if constexpr (STAMP) {
+    tk0 = now();
+    rt0 = __builtin_amdgcn_s_memrealtime();
+  }
   // phase p has landed and is visible to every wave; every wave is done with the slot of phase p - 1
   auto begin = [&]() {
+    unsigned long long t0 = 0, t1 = 0;
+    if constexpr (STAMP) {
+      t0 = now();
+      if (tk_last) tk_body += t0 - tk_last;
+      else tk_first = t0;
+    }
     wait_phases<DPW, R - 2>(min(R - 2, NP - 1 - p));
+    if constexpr (STAMP) { t1 = now(); tk_wait += t1 - t0; }
     __builtin_amdgcn_s_barrier();
+    if constexpr (STAMP) { tk_last = now(); tk_bar += tk_last - t1; }
   };
   // ... which phase p + R - 1 may now overwrite (called after the phase's first fragment reads are issued)
+  const unsigned lbase = (unsigned)(unsigned long long)(__attribute__((address_space(3))) unsigned char*)lds;
+  const unsigned char* rbase = nullptr;   // SPR: (wave-uniform) source / LDS offset of the refill that the running phase spreads between its MFMAs
+  int rdst = 0;
+  bool rgo = false;
   auto refill = [&]() {
-    if (DBG != 1 && p + R - 1 < NP) issue(p + R - 1, fill);
+    if constexpr (SPR) {
+      rgo = !(DBG & 1) && p + R - 1 < NP;
+      rbase = phase_src(rgo ? p + R - 1 : 0) + wave * 1024;
+      rdst = fill * SLOT + wave * 1024;
+    } else {
+      if (!(DBG & 1) && p + R - 1 < NP) issue(p + R - 1, fill);
+    }
     fill = cur;
     cur = cur + 1 == R ? 0 : cur + 1;
     ++p;
   };
+  const unsigned lane16 = lane * 16;
+  auto piece = [&](int k) {   // piece k of this wave's DPW: fragment k * NW + wave of the refilled phase
+    if (rgo) st_dma_s(rbase + k * (NW * 1024), lane16, lbase + rdst + k * (NW * 1024));
+  };
   // LDS byte addresses (the low 32 bits of a generic pointer into LDS are its LDS offset)
-  const unsigned lbase = (unsigned)(unsigned long long)(__attribute__((address_space(3))) unsigned char*)lds;
   const unsigned lfrag = lbase + lane * 16;     // + slot * SLOT + fragment * 1024
   constexpr int PD = PDX ? PDX : (TM >= 4 ? 4 : 6), NB = PD + 2;   // fragment reads in flight ahead of the MFMAs (>= 256 MFMA cycles of cover) / registers of the fragment ring
   static_assert(PD < NB && PD <= NF, "fragment ring");
   // one double phase: NF fragments, each consumed by body(index, fragment); `pre` runs once the first PD reads are issued (the DMA refill)
-  auto phase = [&](unsigned sa, auto&& pre, auto&& body) {
+  // (`um`: the first ND fragments are read u-major -- consumption index g = u * NCH + c is fragment 2 c + u of the LDS image)
+  auto phase = [&](unsigned sa, auto&& pre, auto&& body, auto um) {
+    constexpr bool UM = decltype(um)::value;
     frag F[NB];
+    if constexpr (DBG & 4) {
+#pragma unroll
+      for (int i = 0; i < NB; ++i) F[i] = xb[i % NCH][0];
+    }
     sfor<0, PD>([&](auto fc) {
-      constexpr int f = decltype(fc)::value;
-      lds_rd<f * 1024>(F[f % NB], sa);
+      constexpr int f = decltype(fc)::value, lf = (UM && f < ND) ? 2 * (f % NCH) + f / NCH : f;
+      if constexpr (!(DBG & 4)) lds_rd<lf * 1024>(F[f % NB], sa);
     });
     pre();
+    if constexpr (SPR == 5) {
+#pragma unroll
+      for (int k = 0; k < DPW / 3; ++k) piece(k);
+    }
     sfor<0, NF>([&](auto fc) {
       constexpr int f = decltype(fc)::value;
-      if constexpr (f + PD < NF) lds_rd<(f + PD) * 1024>(F[(f + PD) % NB], sa);
-      lds_wait<(f + PD < NF ? PD : NF - 1 - f)>(F[f % NB]);
+      if constexpr (!(DBG & 4)) {
+        constexpr int g = f + PD, lg = (UM && g < ND) ? 2 * (g % NCH) + g / NCH : g;
+        if constexpr (g < NF) lds_rd<lg * 1024>(F[g % NB], sa);
+        lds_wait<(f + PD < NF ? PD : NF - 1 - f)>(F[f % NB]);
+      }
       body(fc, F[f % NB]);
+      if constexpr ((SPR == 1 && f % NW == 1) || (SPR == 3 && f % NW == 3) || (SPR == 4 && f % NW == 0)) piece(f / NW);
+      if constexpr (SPR == 2) {
+        if (f % NW == wave) piece(f / NW);
+      }
+      if constexpr (SPR == 5 && f == ND - 1) {
+#pragma unroll
+        for (int k = DPW / 3; k < 2 * (DPW / 3); ++k) piece(k);
+      }
+      if constexpr (SPR == 5 && f >= ND && (f - ND) % (ND / (DPW / 3)) == ND / (DPW / 3) - 2) piece(2 * (DPW / 3) + (f - ND) / (ND / (DPW / 3)));
     });
   };
 
@@ -199,7 +289,7 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(WPE, WP
         constexpr int f = decltype(fc)::value, c = 2 * q + f / ND, i = f % ND;
 #pragma unroll
         for (int j = 0; j < TM; ++j) acc[i][j] = Mma<T>::mma(fr, xb[c][j], acc[i][j]);
-      });
+      }, std::false_type{});
     });
   }
 
@@ -262,39 +352,60 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(WPE, WP
     lds_rd<64>(bv1, ba);
     floatx4 hacc[2][TM];
     frag hb[TM];
+    typedef _Float16 half4v __attribute__((ext_vector_type(4)));
+    half4v hlo[TM];
+    constexpr bool EARLY = UMAJ && NCH + 1 + 2 * TM <= ND;      // room for one early conversion step per token tile between the MFMAs of the second hidden tile
+    auto cvt_relu = [&](const floatx4& v) {
+      half4v r = {(half_t)v[0], (half_t)v[1], (half_t)v[2], (half_t)v[3]};
+      half4v z = {(half_t)0, (half_t)0, (half_t)0, (half_t)0};
+      return __builtin_elementwise_max(r, z);
+    };
     phase(lfrag + cur * SLOT, [&]() { refill(); }, [&](auto fc, frag& fr) {
       constexpr int f = decltype(fc)::value;
-      if constexpr (f == 0) lds_wait<PD>(fr, bv0, bv1);   // (the bias reads are older than every fragment read: landed with fragment 0)
+      if constexpr (f == 0) lds_wait<(DBG & 4) ? 0 : PD>(fr, bv0, bv1);   // (the bias reads are older than every fragment read: landed with fragment 0)
       if constexpr (f < ND) {
-        constexpr int u = f % 2, c = f / 2;      // (c, u) order, u fastest: four independent accumulation chains in rotation
+        constexpr int u = UMAJ ? f / NCH : f % 2, c = UMAJ ? f % NCH : f / 2;      // UMAJ: tile by tile; else (c, u) order, u fastest: four independent accumulation chains in rotation
         if constexpr (c == 0) {
 #pragma unroll
           for (int j = 0; j < TM; ++j) hacc[u][j] = u ? bv1 : bv0;
         }
 #pragma unroll
         for (int j = 0; j < TM; ++j) {
-          if constexpr (DBG == 2) hacc[u][j][0] += (float)fr[0] * (float)xb[c][j][0];
+          if constexpr (DBG & 2) hacc[u][j][0] += (float)fr[0] * (float)xb[c][j][0];
           else hacc[u][j] = Mma<T>::mma(fr, xb[c][j], hacc[u][j]);
+        }
+        if constexpr (EARLY && f >= NCH + 1 && (f - NCH - 1) % 2 == 0 && (f - NCH - 1) / 2 < TM) {
+          // tile 0 of token tile j is complete (its last MFMA is >= 4 MFMAs back): convert it now, pinned between the MFMAs of tile 1
+          constexpr int j = (f - NCH - 1) / 2;
+          __builtin_amdgcn_sched_barrier(0);
+          hlo[j] = cvt_relu(hacc[0][j]);
+          asm volatile("" : "+v"(hlo[j]));      // materialise it HERE (volatile asm keeps its place among the fragment reads / waits): hipcc sinks the conversion to its use otherwise
+          __builtin_amdgcn_sched_barrier(0);
         }
       } else {
         if constexpr (f == ND) {
           mfma_results_settle();
 #pragma unroll
           for (int j = 0; j < TM; ++j) {
-            const half8 v = pack_pair(hacc[0][j], hacc[1][j]);
-            half8 z;
+            if constexpr (EARLY) {
+              const half4v hi = cvt_relu(hacc[1][j]);
+              hb[j] = half8{hlo[j][0], hlo[j][1], hlo[j][2], hlo[j][3], hi[0], hi[1], hi[2], hi[3]};
+            } else {
+              const half8 v = pack_pair(hacc[0][j], hacc[1][j]);
+              half8 z;
 #pragma unroll
-            for (int e = 0; e < 8; ++e) z[e] = (half_t)0;
-            hb[j] = __builtin_elementwise_max(v, z);
+              for (int e = 0; e < 8; ++e) z[e] = (half_t)0;
+              hb[j] = __builtin_elementwise_max(v, z);
+            }
           }
         }
 #pragma unroll
         for (int j = 0; j < TM; ++j) {
-          if constexpr (DBG == 2) acc[f - ND][j][0] += (float)fr[0] * (float)hb[j][0];
+          if constexpr (DBG & 2) acc[f - ND][j][0] += (float)fr[0] * (float)hb[j][0];
           else acc[f - ND][j] = Mma<T>::mma(fr, hb[j], acc[f - ND][j]);
         }
       }
-    });
+    }, std::integral_constant<bool, UMAJ != 0>{});
   };
 #pragma unroll 1
   for (int t = 0; t < nt; ++t) substep(t, 0);
@@ -310,6 +421,11 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(WPE, WP
     mfma_results_settle();
   }
 
+  unsigned long long tk_loop_end = 0;
+  if constexpr (STAMP) {
+    tk_loop_end = now();
+    tk_body += tk_loop_end - tk_last;
+  }
   // ---- epilogue: (+ b2b) token-major store, or fold + window join into the NHWC map ----
 #pragma unroll
   for (int i = 0; i < ND; ++i) {
@@ -351,6 +467,14 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(WPE, WP
       }
     }
   }
+  if constexpr (STAMP) {   // workgroup 0 of problem 0: [wave][total, wait, barrier, body, phases, prologue, epilogue, 100 MHz ticks] (cycles)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    const unsigned long long t_end = now(), rt1 = __builtin_amdgcn_s_memrealtime();
+    if (stamps && blockIdx.x == 0 && blockIdx.z == 0 && lane == 0) {
+      unsigned long long* o = stamps + wave * 8;
+      o[0] = t_end - tk0; o[1] = tk_wait; o[2] = tk_bar; o[3] = tk_body; o[4] = (unsigned long long)NP; o[5] = tk_first - tk0; o[6] = t_end - tk_loop_end; o[7] = rt1 - rt0;
+    }
+  }
 }
 
 // s_waitcnt vmcnt(n) for a wave-uniform run-time n (the instruction takes an immediate): a switch over the 64 encodable values
@@ -382,8 +506,12 @@ CFEN_DEV int st_hm_feature_off(int f, int S) {
 // head-major for k_attention_hm (or row-major).  Both matrices are ROW-TILE streams (packing.pack_stream_rows): phase t = output rows
 // t*32 .. +31, fragments (c, u) = k-chunk c, row tile u (u fastest).  The qkv phases store their tiles from inside the ring loop, so the ring's waits
 // count every vector-memory operation the wave issues (`vm_issued` against the mark taken when a slot's DMA went out).
-template <int ND, int TM, int R>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void k_front3(Grouped<CfenEmbedQkvArgs> ga) {
+// DBG (timing experiments, results invalid): 1 = no LDS-DMA refills after the prologue, 8 = no qkv stores, 16 = no X1 stores.  `stamps` (timing build of the launcher, "front3.debug" & 64):
+// s_memtime at the section boundaries of workgroup 0 -> [wave][prologue + gather, embedding phases, X1 stores + LayerNorm, qkv phases, 100 MHz ticks]
+// PP (round 6): the patch edge as a compile-time constant (2: LViT level 3, C = 96; 4: GViT level 1 on the pooled map, C = 24; 0 = read it from the arguments).  The prologue's token ->
+// pixel arithmetic ran on 64-bit run-time divisions (five per token tile, two per feature tile): 11-15 us of a 60 us launch on one wave per SIMD (tools/dbg_front3.py stamps).
+template <int ND, int TM, int R, int DBG = 0, int PP = 0>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void k_front3(Grouped<CfenEmbedQkvArgs> ga, unsigned long long* stamps) {
   typedef half_t T;
   typedef half8 frag;
   const CfenEmbedQkvArgs a = ga.g[blockIdx.z];
@@ -395,6 +523,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const long long tok0 = ((long long)blockIdx.x * NW + wave) * (TM * 16);   // the launcher guarantees M % (NW * TM * 16) == 0
 
+  auto now = [&]() -> unsigned long long {      // (only where no LDS read is in flight: the scalar load shares lgkmcnt with the hand-counted ds_reads)
+    unsigned long long t = 0;
+    if (stamps) asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
+    return t;
+  };
+  const unsigned long long tk0 = now(), rt0 = stamps ? __builtin_amdgcn_s_memrealtime() : 0ull;
   int vm_issued = 0;              // vector-memory operations this wave has issued since the last full drain
   int mark[R];                    // vm_issued right after the DMAs of the phase that sits in each slot
 #pragma unroll
@@ -414,25 +548,27 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 #pragma unroll
   for (int q = 0; q < R - 1; ++q) issue(q, q);
 
-  // ---- gather x^T into accumulator layout ----
-  const int tw = a.ws / a.p, S = tw * tw, nwx = a.W / a.ws, nwy = a.H / a.ws;
+  // ---- gather x^T into accumulator layout (32-bit token arithmetic: the launcher checks M < 2^31) ----
+  const int pe = PP ? PP : a.p, Cc = PP ? D / (PP * PP) : a.C;
+  const unsigned tw = a.ws / pe, S = tw * tw, nwx = a.W / a.ws, nwy = a.H / a.ws;
   floatx4 acc[ND][TM];
   long long tk[TM];
+  unsigned tts[TM];
 #pragma unroll
   for (int j = 0; j < TM; ++j) {
-    const long long t = tok0 + j * 16 + r16;
+    const unsigned t = (unsigned)tok0 + j * 16 + r16;
     tk[j] = t;
-    const int tt = (int)(t % S);
-    const long long wi = t / S;
-    const int wx = (int)(wi % nwx), wy = (int)((wi / nwx) % nwy);
-    const long long b = wi / ((long long)nwx * nwy);
-    const int y0 = wy * a.ws + (tt / tw) * a.p, x0 = wx * a.ws + (tt % tw) * a.p;
-    const T* pix = (const T*)a.fmap + ((b * a.H + y0) * a.W + x0) * a.cs;
+    const unsigned wi = t / S, tt = t - wi * S;
+    tts[j] = tt;
+    const unsigned wr = wi / nwx, wx = wi - wr * nwx, b = wr / nwy, wy = wr - b * nwy;
+    const unsigned ty = tt / tw, tx = tt - ty * tw;
+    const int y0 = wy * a.ws + ty * pe, x0 = wx * a.ws + tx * pe;
+    const T* pix = (const T*)a.fmap + (((long long)b * a.H + y0) * a.W + x0) * a.cs;
 #pragma unroll
     for (int i = 0; i < ND; ++i) {
       const int f = i * 16 + 4 * h;
-      const int ij = f / a.C, c = f - ij * a.C;
-      acc[i][j] = load4<T>(pix + ((ij / a.p) * a.W + (ij % a.p)) * a.cs + c);
+      const int ij = f / Cc, c = f - ij * Cc;
+      acc[i][j] = load4<T>(pix + ((ij / pe) * a.W + (ij % pe)) * a.cs + c);
     }
   }
   frag xb[NCH][TM];
@@ -444,7 +580,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
   for (int i = 0; i < ND; ++i) {
     const floatx4 bb = *reinterpret_cast<const floatx4*>(a.be + i * 16 + 4 * h);
 #pragma unroll
-    for (int j = 0; j < TM; ++j) acc[i][j] += bb + load4<T>((const T*)a.pos + (size_t)(tk[j] % S) * D + i * 16 + 4 * h);
+    for (int j = 0; j < TM; ++j) acc[i][j] += bb + load4<T>((const T*)a.pos + (size_t)tts[j] * D + i * 16 + 4 * h);
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // one drain: ring prologue, pixels, position rows
   vm_issued = 0;
@@ -461,7 +597,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     __builtin_amdgcn_s_barrier();
   };
   auto refill = [&]() {
-    if (p + R - 1 < NP) issue(p + R - 1, fill);
+    if (!(DBG & 1) && p + R - 1 < NP) issue(p + R - 1, fill);
     fill = cur;
     cur = cur + 1 == R ? 0 : cur + 1;
     ++p;
@@ -484,6 +620,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     });
   };
 
+  const unsigned long long tk1 = now();
   // ---- y = W_e x + (b_e + x + pos): double phase q = output tiles 4q .. 4q + 3 (two row groups of two tiles) ----
   sfor<0, NE>([&](auto qc) {
     constexpr int q = decltype(qc)::value;
@@ -495,11 +632,16 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     });
   });
   mfma_results_settle();
+  const unsigned long long tk2 = now();
 #pragma unroll
   for (int j = 0; j < TM; ++j) {
     T* yp = (T*)a.X1 + tk[j] * D + 16 * (h & 1) + 8 * (h >> 1);
 #pragma unroll
-    for (int i = 0; i < ND; i += 2) *reinterpret_cast<uint4*>(yp + i * 16) = pair_tiles16(acc[i][j], acc[i + 1][j]);   // one 16-byte store per lane and tile pair
+    for (int i = 0; i < ND; i += 2) {
+      const uint4 v = pair_tiles16(acc[i][j], acc[i + 1][j]);   // one 16-byte store per lane and tile pair
+      if constexpr (DBG & 16) keep_live(v);      // (the value stays live: only the store goes)
+      else *reinterpret_cast<uint4*>(yp + i * 16) = v;
+    }
   }
   // ---- LayerNorm(y) -> B fragments ----
 #pragma unroll
@@ -539,8 +681,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
   long long qrow[TM];
 #pragma unroll
   for (int j = 0; j < TM; ++j)
-    qrow[j] = a.hm_heads ? (tk[j] / S) * (3LL * S * D) + (tk[j] % S) * 24 : tk[j] * (3LL * D);
+    qrow[j] = a.hm_heads ? (long long)((unsigned)tk[j] / S) * (3LL * S * D) + tts[j] * 24 : tk[j] * (3LL * D);
 
+  const unsigned long long tk3 = now();
   // ---- qkv = W_qkv LN(y): double phase t = output tiles 4t .. 4t + 3, each stored as soon as its last k-chunk is in ----
 #pragma unroll 1
   for (int t = 0; t < NQ; ++t) {
@@ -558,38 +701,86 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         mfma_results_settle();
         {   // the two tiles of the row group leave as one 16-byte store per lane: 8 consecutive features, inside one head (heads are 24 = 3 x 8 wide)
           const int fq = (4 * t + 2 * g2) * 16 + 16 * (h & 1) + 8 * (h >> 1);
-          const long long fo = a.hm_heads ? st_hm_feature_off<D>(fq, S) : fq;
+          const long long fo = a.hm_heads ? st_hm_feature_off<D>(fq, (int)S) : fq;
 #pragma unroll
-          for (int j = 0; j < TM; ++j) *reinterpret_cast<uint4*>((T*)a.QKV + qrow[j] + fo) = pair_tiles16(qa[0][j], qa[1][j]);
+          for (int j = 0; j < TM; ++j) {
+            const uint4 v = pair_tiles16(qa[0][j], qa[1][j]);
+            if constexpr (DBG & 8) keep_live(v);
+            else *reinterpret_cast<uint4*>((T*)a.QKV + qrow[j] + fo) = v;
+          }
         }
-        vm_issued += TM;
+        if (!(DBG & 8)) vm_issued += TM;
       }
     });
   }
+  if (stamps) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    const unsigned long long tk4 = now(), rt1 = __builtin_amdgcn_s_memrealtime();
+    if (blockIdx.x == 0 && blockIdx.z == 0 && lane == 0) {
+      unsigned long long* o = stamps + wave * 8;
+      o[0] = tk1 - tk0; o[1] = tk2 - tk1; o[2] = tk3 - tk2; o[3] = tk4 - tk3; o[4] = rt1 - rt0;
+    }
+  }
 }
 
-template <int ND, int TM, int R>
+template <int ND, int TM, int R, int DBG = 0, int PP = 0>
 int launch_front3(int ng, const CfenEmbedQkvArgs* ap, hipStream_t s) {
   Grouped<CfenEmbedQkvArgs> ga;
   for (int g = 0; g < CFEN_MAX_GROUPS; ++g) ga.g[g] = ap[g < ng ? g : 0];
   const long long per = 4LL * TM * 16;
   CFEN_CHECK_ARG(ap[0].M % per == 0, "front3: token count must be a multiple of %lld", per);
   const long long blocks = ap[0].M / per;
-  CFEN_CHECK_ARG(blocks > 0 && blocks < (1ll << 31), "front3: bad grid");
-  CFEN_LAUNCH((k_front3<ND, TM, R>), dim3((unsigned)blocks, 1, ng), dim3(256), 0, s, ga);
+  CFEN_CHECK_ARG(blocks > 0 && ap[0].M < (1ll << 31), "front3: bad grid");
+  unsigned long long* stamps = nullptr;
+  const bool stamping = (cfen_tune_front3_debug() & 64) != 0;
+  if (stamping) {   // timing run: the stamped workgroup's section times go to stderr after the launch (tools/dbg_front3.py)
+    static unsigned long long* buf = nullptr;
+    if (!buf && hipMalloc(&buf, 4 * 8 * sizeof(unsigned long long)) != hipSuccess) buf = nullptr;
+    stamps = buf;
+    if (stamps) (void)hipMemsetAsync(stamps, 0, 4 * 8 * sizeof(unsigned long long), s);
+  }
+  CFEN_LAUNCH((k_front3<ND, TM, R, DBG, PP>), dim3((unsigned)blocks, 1, ng), dim3(256), 0, s, ga, stamps);
   CFEN_CHECK_LAUNCH("front3");
+  if (stamping && stamps && !cfen_recorder()) {
+    unsigned long long hst[4 * 8];
+    if (hipStreamSynchronize(s) == hipSuccess && hipMemcpy(hst, stamps, sizeof(hst), hipMemcpyDeviceToHost) == hipSuccess)
+      for (int w = 0; w < 4; ++w) {
+        const unsigned long long* o = hst + w * 8;
+        fprintf(stderr, "front3 stamps wave %d: prologue + gather %llu, %d embedding phases %llu, X1 stores + LayerNorm %llu, %d qkv phases %llu cyc (%.0f / phase); %.1f us in all\n", w, o[0],
+                ND / 4, o[1], o[2], 3 * ND / 4, o[3], (double)o[3] / (3 * ND / 4), (double)o[4] / 100.0);
+      }
+  }
   return CFEN_OK;
 }
 
-template <int ND, int TM, int R, int HB, int DBG = 0, int WPE = 1, int NW = 4, int PDX = 0>
+template <int ND, int TM, int R, int HB, int DBG = 0, int WPE = 1, int NW = 4, int PDX = 0, int SPR = 0, int STAMP = 0, int UMAJ = 0>
 int launch_mlp3(int ng, const Mlp3Args* ap, hipStream_t s) {
   Grouped<Mlp3Args> ga;
   for (int g = 0; g < CFEN_MAX_GROUPS; ++g) ga.g[g] = ap[g < ng ? g : 0];
   CFEN_CHECK_ARG(ap[0].H <= HB, "mlp3: hidden width %d exceeds the %d this variant stages biases for", ap[0].H, HB);
   const long long per = (long long)NW * TM * 16, blocks = (ap[0].M + per - 1) / per;
   CFEN_CHECK_ARG(blocks > 0 && blocks < (1ll << 31), "mlp3: bad grid");
-  CFEN_LAUNCH((k_mlp3<ND, TM, R, HB, DBG, WPE, NW, PDX>), dim3((unsigned)blocks, 1, ng), dim3(NW * 64), 0, s, ga);
+  unsigned long long* stamps = nullptr;
+  if constexpr (STAMP) {   // timing build: the stamped workgroup's cycle sums go to stderr after the launch (tools/dbg_mlp3_stamps.py)
+    static unsigned long long* buf = nullptr;
+    if (!buf && hipMalloc(&buf, NW * 8 * sizeof(unsigned long long)) != hipSuccess) buf = nullptr;
+    stamps = buf;
+    if (stamps) (void)hipMemsetAsync(stamps, 0, NW * 8 * sizeof(unsigned long long), s);
+  }
+  CFEN_LAUNCH((k_mlp3<ND, TM, R, HB, DBG, WPE, NW, PDX, SPR, STAMP, UMAJ>), dim3((unsigned)blocks, 1, ng), dim3(NW * 64), 0, s, ga, stamps);
   CFEN_CHECK_LAUNCH("mlp3");
+  if constexpr (STAMP) {
+    if (stamps && !cfen_recorder()) {
+      unsigned long long hst[NW * 8];
+      if (hipStreamSynchronize(s) == hipSuccess && hipMemcpy(hst, stamps, sizeof(hst), hipMemcpyDeviceToHost) == hipSuccess)
+        for (int w = 0; w < NW; ++w) {
+          const unsigned long long* o = hst + w * 8;
+          const double np = (double)o[4], ghz = o[7] ? (double)o[0] / ((double)o[7] * 10.0) : 0.0;
+          fprintf(stderr, "mlp3 stamps wave %d: total %llu cyc (%.1f us, %.2f GHz), %d phases: wait %.0f barrier %.0f body %.0f cyc/phase; prologue %llu epilogue %llu cyc\n", w, o[0],
+                  (double)o[7] / 100.0, ghz, (int)o[4], o[1] / np, o[2] / np, o[3] / np, o[5], o[6]);
+        }
+    }
+  }
   return CFEN_OK;
 }
 
@@ -600,6 +791,10 @@ int& cfen_tune_mlp3_tm192() {   // the D = 192 variant: 22 (default, round 5) = 
   return v;
 }
 int& cfen_tune_mlp3_debug() {
+  static int v = 0;
+  return v;
+}
+int& cfen_tune_front3_debug() {
   static int v = 0;
   return v;
 }
@@ -631,7 +826,26 @@ int cfen_mlp3_impl_g(int dtype, int ng, const Mlp3Args* ap, hipStream_t s) {
   if (ap[0].D == 384 && cfen_tune_mlp3_debug() == 1) return launch_mlp3<24, 2, 3, 1536, 1>(ng, ap, s);
   if (ap[0].D == 384 && cfen_tune_mlp3_debug() == 2) return launch_mlp3<24, 2, 3, 1536, 2>(ng, ap, s);
   if (ap[0].D == 384 && cfen_tune_mlp3_debug() == 8) return launch_mlp3<24, 1, 3, 1536, 0, 2, 8>(ng, ap, s);   // round-5 A/B: 8 waves x 1 tile, two waves per SIMD
-  if (ap[0].D == 384) return launch_mlp3<24, 2, 3, 1536>(ng, ap, s);
+  if (ap[0].D == 384 && cfen_tune_mlp3_debug() == 11) return launch_mlp3<24, 2, 3, 1536, 0, 1, 4, 0, 1>(ng, ap, s);       // round-6 A/Bs: DMA pieces spread between the MFMAs
+  if (ap[0].D == 384 && cfen_tune_mlp3_debug() == 14) return launch_mlp3<24, 2, 3, 1536, 0, 1, 4, 4, 1>(ng, ap, s);       // ... 4 instead of 6 fragment reads ahead of the MFMAs
+  if (ap[0].D == 384 && cfen_tune_mlp3_debug() == 15) return launch_mlp3<24, 2, 3, 1536, 0, 1, 4, 0, 3>(ng, ap, s);       // ... behind fragment 4k + 3
+  if (ap[0].D == 384 && cfen_tune_mlp3_debug() == 16) return launch_mlp3<24, 2, 3, 1536, 0, 1, 4, 0, 4>(ng, ap, s);       // ... behind fragment 4k
+  if (ap[0].D == 384 && cfen_tune_mlp3_debug() == 17) return launch_mlp3<24, 2, 3, 1536, 0, 1, 4, 0, 5>(ng, ap, s);       // ... a third each at the phase start, in the mid-phase bubble, spread
+  if (ap[0].D == 384 && cfen_tune_mlp3_debug() == 18) return launch_mlp3<24, 2, 3, 1536, 0, 1, 4, 4, 5>(ng, ap, s);       // ... with 4 fragment reads ahead
+  if (ap[0].D == 384 && cfen_tune_mlp3_debug() == 19) return launch_mlp3<24, 2, 3, 1536, 0, 1, 4, 4, 5, 0, 1>(ng, ap, s);    // ... and the first hidden tile repacked early (UMAJ)
+  if (ap[0].D == 384 && cfen_tune_mlp3_debug() == 20) return launch_mlp3<24, 2, 3, 1536, 0, 1, 4, 0, 5, 0, 1>(ng, ap, s);
+  if (ap[0].D == 384 && cfen_tune_mlp3_debug() == 100) return launch_mlp3<24, 2, 3, 1536>(ng, ap, s);                     // the burst issue of rounds 3-5
+  if (ap[0].D == 384 && cfen_tune_mlp3_debug() == 64) return launch_mlp3<24, 2, 3, 1536, 0, 1, 4, 0, 0, 1>(ng, ap, s);    // stamped timing builds
+  if (ap[0].D == 384 && cfen_tune_mlp3_debug() == 65) return launch_mlp3<24, 2, 3, 1536, 0, 1, 4, 0, 1, 1>(ng, ap, s);
+  if (ap[0].D == 384 && cfen_tune_mlp3_debug() == 67) return launch_mlp3<24, 2, 3, 1536, 1, 1, 4, 0, 0, 1>(ng, ap, s);    // stamped, no refills
+  if (ap[0].D == 384 && cfen_tune_mlp3_debug() == 68) return launch_mlp3<24, 2, 3, 1536, 4, 1, 4, 0, 0, 1>(ng, ap, s);    // stamped, no LDS fragment reads (MFMAs + refills + barrier)
+  if (ap[0].D == 384 && cfen_tune_mlp3_debug() == 69) return launch_mlp3<24, 2, 3, 1536, 5, 1, 4, 0, 0, 1>(ng, ap, s);    // stamped, neither (MFMAs + barrier + the mid-phase repack)
+  if (ap[0].D == 384 && cfen_tune_mlp3_debug() == 70) return launch_mlp3<24, 2, 3, 1536, 32, 1, 4, 0, 0, 1>(ng, ap, s);   // stamped, 4-byte refill pieces
+  if (ap[0].D == 384 && cfen_tune_mlp3_debug() == 71) return launch_mlp3<24, 2, 3, 1536, 6, 1, 4, 0, 0, 1>(ng, ap, s);    // stamped, refills + barrier only (no MFMAs, no reads)
+  if (ap[0].D == 384 && cfen_tune_mlp3_debug() == 72) return launch_mlp3<24, 2, 3, 1536, 2, 1, 4, 0, 0, 1>(ng, ap, s);    // stamped, no MFMAs
+  // round 6 default: refills in thirds (phase start / mid-phase gap / spread over the second half), 4 fragment reads ahead, first hidden tile repacked early:
+  // 167 -> 156 us on 192 workgroups, 158 -> 152 on 16 (same box, tools/dbg_mlp3_stamps.py; profiles/r06_mlp3_d384_variants.txt), bit for bit the round-5 results
+  if (ap[0].D == 384) return launch_mlp3<24, 2, 3, 1536, 0, 1, 4, 4, 5, 0, 1>(ng, ap, s);
   if (cfen_tune_mlp3_tm192() == 22) return launch_mlp3<12, 2, 3, 768, 0, 2>(ng, ap, s);   // two 78 KB workgroups a CU, three-slot ring (round 5 A/B)
   if (cfen_tune_mlp3_tm192() == 28) return launch_mlp3<12, 2, 3, 768, 0, 2, 8>(ng, ap, s);        // ONE 8-wave workgroup a CU (two waves per SIMD) sharing one three-slot ring: 256 tokens per weight byte streamed
   if (cfen_tune_mlp3_tm192() == 29) return launch_mlp3<12, 2, 6, 768, 0, 2, 8>(ng, ap, s);        // ... on six slots
@@ -660,8 +874,14 @@ int cfen_front3_impl_g(int dtype, int ng, const CfenEmbedQkvArgs* ap, hipStream_
                    "front3: bad token geometry");
     const int tw = a.ws / a.p;
     CFEN_CHECK_ARG(a.D == a.p * a.p * a.C && a.M == (long long)a.B * (a.H / a.ws) * (a.W / a.ws) * tw * tw, "front3: D / M do not match the map");
-    CFEN_CHECK_ARG(a.D == ap[0].D && a.M == ap[0].M && a.hm_heads == ap[0].hm_heads, "front3: grouped problems must have the same shape");
+    CFEN_CHECK_ARG(a.D == ap[0].D && a.M == ap[0].M && a.hm_heads == ap[0].hm_heads && a.p == ap[0].p && a.C == ap[0].C, "front3: grouped problems must have the same shape");
     CFEN_CHECK_ARG(a.hm_heads == 0 || a.D == a.hm_heads * 24, "front3: the head-major layout needs head_dim 24");
   }
+  if ((cfen_tune_front3_debug() & 63) == 1) return launch_front3<24, 2, 3, 1>(ng, ap, s);     // timing experiments (results invalid): no refills / no qkv stores / neither store
+  if ((cfen_tune_front3_debug() & 63) == 8) return launch_front3<24, 2, 3, 8>(ng, ap, s);
+  if ((cfen_tune_front3_debug() & 63) == 24) return launch_front3<24, 2, 3, 24>(ng, ap, s);
+  if ((cfen_tune_front3_debug() & 63) == 2) return launch_front3<24, 2, 3>(ng, ap, s);        // A/B: the run-time geometry (rounds 3-5)
+  if (ap[0].p == 2 && ap[0].C == 96) return launch_front3<24, 2, 3, 0, 2>(ng, ap, s);
+  if (ap[0].p == 4 && ap[0].C == 24) return launch_front3<24, 2, 3, 0, 4>(ng, ap, s);
   return launch_front3<24, 2, 3>(ng, ap, s);
 }

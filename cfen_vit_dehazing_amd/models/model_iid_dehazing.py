@@ -57,7 +57,10 @@ class DECHLGVIT(BaseModel):
         pins[key].copy_(B)
         return pins[key]
 
-    HALF_GUARD_BAR = 3e-2     # max-abs difference of the fp16 outputs (tanh values in (-1, 1)) from the fp32 path on a checked batch
+    # max-abs difference of the fp16 outputs (tanh values in (-1, 1)) from the fp32 path on a checked batch.  Measured (round 6): 9e-4 on the seeded "trained-like" weights,
+    # 6.4e-3 .. 8.0e-3 on the reference's own init distribution (torch's CPU fp16 autocast: 8.3e-3); the bar is the test bar of that distribution
+    # (tests/test_hip_net.py REFINIT_FP16_BAR) -- it was 3e-2, four times looser than anything the path produces when it is healthy
+    HALF_GUARD_BAR = 1.5e-2
 
     def setup(self, opt):
         BaseModel.setup(self, opt)

@@ -60,7 +60,7 @@ class BaseOptions():
                        help='HIP compute type: single = fp32 MFMA, half = fp16 storage / fp32 accumulate')
         p.add_argument('--no_half_guard', action='store_true',
                        help='(extension) with --precision half the first batch also runs in fp32 once and the model falls back to single when the '
-                            'fp16 outputs differ by more than 3e-2 (range safety of a real checkpoint); this flag skips that check')
+                            'fp16 outputs differ by more than 1.5e-2 (range safety of a real checkpoint); this flag skips that check')
         p.add_argument('--half_guard_every', type=int, default=32,
                        help='(extension) with --precision half, repeat that fp32 comparison on every N-th batch of the run (0 = first batch only); all '
                             'ranks of a sharded run agree on the outcome, and the batches since the last passed check are redone in fp32 after a failure')

@@ -13,7 +13,8 @@ import cfen_oracle
 from cfen_vit_dehazing_amd.config import NetConfig
 from cfen_vit_dehazing_amd.hipnet import dec_ipt
 from cfen_vit_dehazing_amd.manifest import generate_state_dict, synthetic_input
-from helpers import load_net_fixture, check_outputs, check_stages, weight_mode
+from cfen_vit_dehazing_amd import ops
+from helpers import load_net_fixture, check_outputs, check_stages, weight_mode, sample_idx
 
 pytestmark = pytest.mark.gpu
 
@@ -402,9 +403,9 @@ def test_half_precision_guard_keeps_safe_weights_and_falls_back_on_unsafe_ones(t
         fa = model.get_current_visuals()['fake_A'].clone()
         assert torch.isfinite(fa).all()
         if tag == "safe":
-            assert model.half_guard_max_abs <= 3e-2 and model.netG.compute_dtype == torch.float16
+            assert model.half_guard_max_abs <= model.HALF_GUARD_BAR and model.netG.compute_dtype == torch.float16
         else:
-            assert not model.half_guard_max_abs <= 3e-2 and model.netG.compute_dtype == torch.float32
+            assert not model.half_guard_max_abs <= model.HALF_GUARD_BAR and model.netG.compute_dtype == torch.float32
             ref = make_net(cfg, "fp32")
             ref.load_state_dict(sd2)
             ref.to("cuda:0")
@@ -778,21 +779,42 @@ def test_reference_init_weights_and_device_actnorm_init_fp32(name):
     print("%s fp32 with device ActNorm init: outputs max-abs vs reference %.2e" % (name, worst))
 
 
+# fp16 path on the reference's own init distribution, measured in round 6 (profiles/r06_fp16_stage_errors_refinit.txt): outputs 6.4e-3 / 6.8e-3 max-abs against the reference
+# (device ActNorm init / reference ActNorm parameters) -- torch's CPU fp16 autocast measures 8.3e-3 on the same weights; every stage within 1.3e-2 of its own rms.
+# The bars sit 2x above that (the output bar was 6e-2 through round 5, ten times what the path delivers).
+REFINIT_FP16_BAR = 1.5e-2
+REFINIT_FP16_STAGE_REL_BAR = 3e-2      # sampled max-abs difference of a stage / its mean |value| (the fixture's abs-sum / numel)
+
+
 def test_reference_init_weights_fp16_psnr_ssim_full512():
     """fp16 path on the reference's own init distribution (kaiming residual branches, N(0,1) position table): both with the
-    reference's ActNorm parameters loaded and with ActNorm initialised on the device from fp16 activations"""
+    reference's ActNorm parameters loaded and with ActNorm initialised on the device from fp16 activations; with the reference's
+    parameters also EVERY stage against the reference's samples of it, relative to the stage's scale (where fp16 loses bits shows here first)"""
     name = "refinit_full512_nf24_hdr4"
     cfg, batch, z = load_net_fixture(name)
     sd = generate_state_dict(cfg, seed=0, mode="reference_init")
     x = synthetic_input(batch, cfg).to("cuda:0")
     net = make_net(cfg, "fp16", sd=sd)                                          # device init
-    w1 = _fp16_vs_fixture(z, net(x), x, 6e-2)
+    w1 = _fp16_vs_fixture(z, net(x), x, REFINIT_FP16_BAR)
     for k in [str(v) for v in z["actnorm_names"]]:
         sd[k + ".weight"], sd[k + ".bias"] = torch.from_numpy(z["actnorm_w/" + k]), torch.from_numpy(z["actnorm_b/" + k])
         sd[k + ".initialized"] = torch.tensor(1)
     net2 = make_net(cfg, "fp16", sd=sd)
-    w2 = _fp16_vs_fixture(z, net2(x), x, 6e-2)
-    print("refinit full512 fp16: max-abs vs reference %.2e (device ActNorm init) / %.2e (reference ActNorm parameters)" % (w1, w2))
+    ops.tune("net.keep_stages", 1)
+    try:
+        w2 = _fp16_vs_fixture(z, net2(x), x, REFINIT_FP16_BAR)
+        st = gpu_stages(net2, z)
+    finally:
+        ops.tune("net.keep_stages", 0)
+    rows = []
+    for n, t in st.items():
+        smp = t.float().cpu().flatten()[sample_idx(n, t.numel())].numpy()
+        scale = float(z["stage_abs/" + n]) / t.numel()
+        rows.append((float(np.abs(smp - z["stage_smp/" + n]).max()) / scale, n))
+    rows.sort(reverse=True)
+    print("refinit full512 fp16: max-abs vs reference %.2e (device ActNorm init) / %.2e (reference ActNorm parameters); worst stages (sampled max-abs / mean |value|): %s"
+          % (w1, w2, ", ".join("%s %.2e" % (n, r) for r, n in rows[:4])))
+    assert rows[0][0] <= REFINIT_FP16_STAGE_REL_BAR, "stage %s: fp16 differs from the reference by %.2e of the stage's mean |value|" % (rows[0][1], rows[0][0])
 
 
 def test_uint8_input_equals_host_normalised_input():
@@ -1010,7 +1032,7 @@ def test_half_guard_catches_an_overflow_that_starts_on_a_later_batch(tmp_path):
             assert model.netG.compute_dtype == torch.float32
         if j == 3:
             batch3_fake_A = fa.float().clone()
-    assert [b for b, _ in model.half_guard_log] == [0, 3] and model.half_guard_log[0][1] <= 3e-2 and not model.half_guard_log[1][1] <= 3e-2
+    assert [b for b, _ in model.half_guard_log] == [0, 3] and model.half_guard_log[0][1] <= model.HALF_GUARD_BAR and not model.half_guard_log[1][1] <= model.HALF_GUARD_BAR
     assert model.redo_paths == ['b1_0.png', 'b1_1.png', 'b2_0.png', 'b2_1.png']
     # batch 3 itself came out of the fp32 path: equal to a plain fp32 net on the same (scaled) weights
     sd2 = dict(sd)
