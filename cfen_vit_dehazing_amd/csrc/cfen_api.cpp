@@ -343,6 +343,18 @@ int cfen_tune(const char* key, int value) {
     cfen_tune_mlp3_tm192() = value;
     return CFEN_OK;
   }
+  if (!strcmp(key, "embed.defer_refill")) {
+    cfen_tune_embed_defer_refill() = value != 0;
+    return CFEN_OK;
+  }
+  if (!strcmp(key, "gemm.defer_refill")) {
+    cfen_tune_gemm_defer_refill() = value != 0;
+    return CFEN_OK;
+  }
+  if (!strcmp(key, "lvit.debug")) {
+    cfen_tune_lvit_debug() = value;
+    return CFEN_OK;
+  }
   if (!strcmp(key, "front3.debug")) {
     cfen_tune_front3_debug() = value;
     return CFEN_OK;

@@ -366,7 +366,7 @@ CFEN_DEV void eq_wait_vmcnt(int n) {
 // every chunk waited a whole LDS-DMA issue -> landed latency (~1.1 us), 24 chunks a workgroup.  NS - 1 chunks are in flight now; the landing wait is a COUNTED
 // vmcnt that leaves the younger chunks' DMAs (and, in the qkv loop, the tile stores issued since) outstanding.
 template <int ND, int TM, int NW, int RS, int NS = 2>
-__global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_embed_qkv2(Grouped<CfenEmbedQkvArgs> ga) {
+__global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_embed_qkv2(Grouped<CfenEmbedQkvArgs> ga, int defer) {    // defer (round 6, "embed.defer_refill"): a chunk's refill goes out behind its first fragment reads
   typedef half_t T;
   const CfenEmbedQkvArgs a = ga.g[blockIdx.z];
   constexpr int KC = 32, EPL = 8;
@@ -458,10 +458,15 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(2, 2)))
     if constexpr (c == 0 || NS == 2) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     else eq_wait_vmcnt((PF - 1 < NC - 1 - c ? PF - 1 : NC - 1 - c) * nd);
     __builtin_amdgcn_s_barrier();
-    if constexpr (c + PF < NC) issue(c + PF, (c + PF) % NS);      // into the slot of chunk c - 1, which every wave has left
+    if constexpr (c + PF < NC) {
+      if (!defer) issue(c + PF, (c + PF) % NS);      // into the slot of chunk c - 1, which every wave has left
+    }
     const unsigned char* buf = lds + (c % NS) * STAGE;
     frag F[2][3];
     load_g(buf, std::integral_constant<int, 0>{}, F[0]);
+    if constexpr (c + PF < NC) {
+      if (defer) issue(c + PF, (c + PF) % NS);
+    }
     eq_static_for<0, NG>([&](auto gc) {
       constexpr int g = decltype(gc)::value, u = g / GPT, cg = g % GPT;
       if constexpr (g + 1 < NG) load_g(buf, std::integral_constant<int, g + 1>{}, F[(g + 1) & 1]);
@@ -533,11 +538,12 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(2, 2)))
     else if constexpr (NS == 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(QST) : "memory");
     else eq_wait_vmcnt((PF - 1 < NC - 1 - c ? PF - 1 : NC - 1 - c) * nd + (cq < PF ? cq : PF) * QST);
     __builtin_amdgcn_s_barrier();
-    if (c + PF < NC) issue(c + PF, (c + PF) % NS);
+    if (c + PF < NC && !defer) issue(c + PF, (c + PF) % NS);
     const unsigned char* buf = lds + (c % NS) * STAGE;
     frag F[2][3];
     floatx4 q[TM], qe[TM];                            // qe: the even tile of a pair, kept until its odd neighbour is done
     load_g(buf, std::integral_constant<int, 0>{}, F[0]);
+    if (c + PF < NC && defer) issue(c + PF, (c + PF) % NS);
     eq_static_for<0, NG>([&](auto gc) {
       constexpr int g = decltype(gc)::value, u = g / GPT, cg = g % GPT;
       if constexpr (g + 1 < NG) load_g(buf, std::integral_constant<int, g + 1>{}, F[(g + 1) & 1]);
@@ -582,7 +588,7 @@ int launch_embed_qkv2(int ng, const CfenEmbedQkvArgs* ap, hipStream_t s) {
   CFEN_CHECK_ARG(ap[0].M % per == 0, "embed_qkv2: token count must be a multiple of %lld", per);
   const long long blocks = ap[0].M / per;
   CFEN_CHECK_ARG(blocks > 0 && blocks < (1ll << 31), "embed_qkv: bad grid");
-  CFEN_LAUNCH((k_embed_qkv2<ND, TM, NW, RS, NS>), dim3((unsigned)blocks, 1, ng), dim3(NW * 64), 0, s, ga);
+  CFEN_LAUNCH((k_embed_qkv2<ND, TM, NW, RS, NS>), dim3((unsigned)blocks, 1, ng), dim3(NW * 64), 0, s, ga, cfen_tune_embed_defer_refill());
   CFEN_CHECK_LAUNCH("embed_qkv");
   return CFEN_OK;
 }
@@ -651,6 +657,10 @@ int run_embed_qkv(int ng, const CfenEmbedQkvArgs* ap, hipStream_t s) {
 
 }  // namespace
 
+int& cfen_tune_embed_defer_refill() {   // k_embed_qkv2: 1 = refill behind the chunk's first fragment reads, 0 = right behind the barrier (rounds 2-5)
+  static int v = 1;
+  return v;
+}
 int& cfen_tune_embed_stages() {   // ring stages of k_embed_qkv2 at D = 192 ("embed.stages"): 2 (rounds 2-4), 3, 4 (default, round 5), 5
   static int v = 4;
   return v;

@@ -16,6 +16,7 @@
 #include "cfen_internal.hpp"
 
 int& cfen_tune_gemm_nt();
+int& cfen_tune_gemm_defer_refill();
 int& cfen_tune_gemm_splitk_release();
 int& cfen_tune_gemm_mid();
 
@@ -75,6 +76,7 @@ template <typename T> struct GemmArgs {
   const float* lnf_s;
   float lnf_eps;
   int wtile;   // W is tile-major (CfenGemmPtrs::wtile)
+  int defer;   // k_gemm_dma: the K-step's refill goes out behind its first fragment reads instead of right behind the barrier ("gemm.defer_refill", round 6)
 };
 
 // pointer to channel 0 of the top-left pixel of token m's patch
@@ -418,7 +420,10 @@ __global__ __launch_bounds__(256, (TN > 3 && NS == 2) ? 2 : 1) void k_gemm_dma(G
     // only cost LDS and the "deeper rings do not help" measurement of DESIGN 4.2 never had more than two K-steps in flight)
     gemm_wait_steps<LOADS, NS - 2>(min(NS - 2, nk - 1 - kt));
     __builtin_amdgcn_s_barrier();   // K-step kt visible to all waves; all waves are done with the slot consumed at kt - 1
-    if (kt + NS - 1 < nk) CFEN_GEMM_DMA_ISSUE(kt + NS - 1, fill);
+    // the refill: an LDS-DMA piece holds the issuing wave for 60-140 cycles (tools/dbg_mlp3_stamps.py).  Deferred, those pass while the wave's first fragment reads are
+    // in flight instead of in front of them (k_lvit_window: 376 -> 315 us, round 6)
+    const bool refill = kt + NS - 1 < nk;
+    if (refill && !a.defer) CFEN_GEMM_DMA_ISSUE(kt + NS - 1, fill);
     const unsigned char* st = lds + buf * STAGE;
     if (a.lnf_s) {
 #pragma unroll
@@ -437,6 +442,7 @@ __global__ __launch_bounds__(256, (TN > 3 && NS == 2) ? 2 : 1) void k_gemm_dma(G
       for (int i = 0; i < TN; ++i) af[i] = *reinterpret_cast<const frag*>(st + aoff[i] + po);
 #pragma unroll
       for (int j = 0; j < TM; ++j) bf[j] = *reinterpret_cast<const frag*>(st + boff[j] + po);
+      if (c == 0 && refill && a.defer) CFEN_GEMM_DMA_ISSUE(kt + NS - 1, fill);
 #pragma unroll
       for (int i = 0; i < TN; ++i)
 #pragma unroll
@@ -634,6 +640,7 @@ int launch_gemm(int ng, const CfenGemmPtrs* gp, int ldx, int ldw, int ldr, int p
     a.lnf_s = q.lnf_s;
     a.lnf_eps = cfen_gemm_lnf_eps();
     a.wtile = q.wtile;
+    a.defer = cfen_tune_gemm_defer_refill();
     CFEN_CHECK_ARG(q.wtile == gp[0].wtile, "gemm: grouped problems must share the weight layout");
     if (tg) {
       a.gmap = (const T*)q.gmap; a.gH = tg->H; a.gW = tg->W; a.gcs = tg->cs; a.gC = tg->C; a.gws = tg->ws; a.gp = tg->p;
@@ -748,6 +755,10 @@ int launch_gemm(int ng, const CfenGemmPtrs* gp, int ldx, int ldw, int ldr, int p
 
 float& cfen_gemm_lnf_eps() {
   static float v = 1e-5f;
+  return v;
+}
+int& cfen_tune_gemm_defer_refill() {   // k_gemm_dma: 1 = a K-step's refill behind its first fragment reads, 0 = right behind the barrier (rounds 2-5) ("gemm.defer_refill")
+  static int v = 1;
   return v;
 }
 int& cfen_tune_gemm_nt() {   // weight rows of k_gemm_dma by non-temporal LDS-DMA: 0 never, 1 few-token GEMMs (M <= 512: GViT levels 2 and 3), 2 always ("gemm.nt")

@@ -98,13 +98,25 @@ CFEN_DEV half8 lv_pack(floatx4 a, floatx4 b) {
 // 4 x 4 with one wave per SIMD and the whole 512-register file); 4 heads of 24
 // FR (round 5): 1 = the embedding and K / V matrices stream in chunks of 64 rows (12 fragments: what a stage holds for the MLP chunks anyway) instead of 32 --
 // 5 barrier-separated chunks in front of the attention instead of 9, each with 12 MFMAs per wave instead of 6; same fragment stream, same arithmetic, same bits.
-template <int ND, int NW, int TM, int SM = 0, int FR = 0>   // SM = 0: softmax denominator summed on the vector pipe; 1: on the matrix pipe (round 4; MEASURED SLOWER: 138 / 395 us against
+// MC (round 6): 2 = the MLP chunks behind the first two run as DOUBLE chunks (64 hidden units, 24 KiB + 256 B of bias per barrier) on a four-slot ring laid over the K / V tiles, which are
+// dead once the last head is done: 13 barriers instead of 24 in the MLP part.  Stamped sections (tools/dbg_lvit_sections.py): an MLP chunk took 1730-2060 cycles for 768 cycles of MFMA
+// per SIMD -- after every barrier all 16 waves read their fragments at once, multiply at once and meet again; twice the work per barrier halves that lockstep cost.
+// DR (round 6): 1 = a chunk's refill (the LDS-DMA of the chunk two ahead) is issued BEHIND the chunk's first fragment reads instead of right behind its barrier: an LDS-DMA piece costs
+// the issuing wave 60-140 cycles (tools/dbg_mlp3_stamps.py), which then pass while its own fragment reads are in flight instead of in front of them.
+template <int ND, int NW, int TM, int SM = 0, int FR = 0, int MC = 1, int DR = 0>   // SM = 0: softmax denominator summed on the vector pipe; 1: on the matrix pipe (round 4; MEASURED SLOWER: 138 / 395 us against
                                                 // 131 / 381 us for 512 / 1536 windows, tools/bench_lvit_window.py -- "lvit.shape" = 3 runs it); 2 (round 5): as 0 with the K / V
                                                 // fragment reads of the attention loops issued by hand, LV_KPD / one key block ahead of the MFMAs ("lvit.shape" = 4)
-__global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(NW / 4, NW / 4))) void k_lvit_window(Grouped<LvitArgs> ga) {
+__global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(NW / 4, NW / 4))) void k_lvit_window(Grouped<LvitArgs> ga, unsigned long long* stamps, int dbg) {
   typedef half_t T;
+  // timing runs ("lvit.debug" = 64): s_memtime at the section boundaries of workgroup 0 -> stamps[wave][prologue, embedding, LN1 + K / V, attention, LN2 + MLP stage a, stage b, fold, 100 MHz ticks]
+  auto now = [&]() -> unsigned long long {
+    unsigned long long t = 0;
+    if (stamps) asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
+    return t;
+  };
+  const unsigned long long tk0 = now(), rt0 = stamps ? __builtin_amdgcn_s_memrealtime() : 0ull;
   typedef half8 frag;
-  const LvitArgs& a = ga.g[blockIdx.z];
+  const LvitArgs a = ga.g[blockIdx.z];       // by value: a reference re-read b1a / b1b from the argument segment (s_load + wait) behind every chunk's barrier
   constexpr int KC = 32, S = 256, DH = 24, NH = 4;
   static_assert(NW * TM * 16 == S, "one workgroup = one window");
   constexpr int D = ND * 16, NCH = ND / 2;
@@ -152,7 +164,10 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(NW / 4,
   };
   // chunk t is read behind one barrier; chunks t + 1 and t + 2 are in flight behind it (three stages).  The wait leaves this wave's DMAs of
   // chunk t + 1 outstanding (a stricter wait where other vector loads were issued since: still correct)
+  const int t0 = NE + NKV + NA;                              // first MLP chunk
+  const bool dbl = MC == 2 && nhc % 2 == 0 && !(dbg & 2);
   int inflight = 0;                                          // DMA instructions of this wave for the chunk after the one being waited for
+  int pend_kind = 0, pend_a = 0, pend_b = 0;                 // the refill the current chunk owes: 1 = issue(a, b), 2 = issue_span(a, 2, slot b of the K / V area)
   auto begin_chunk = [&](int t) -> const unsigned char* {
     if (inflight >= 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
     else if (inflight == 3) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
@@ -160,8 +175,76 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(NW / 4,
     else if (inflight == 1) asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
-    inflight = t + 2 < nchunks ? issue(t + 2, (t + 2) % NS) : 0;
+    inflight = 0;
+    pend_kind = t + 2 < nchunks && !(dbl && t + 2 >= t0 + 2) ? 1 : 0;
+    pend_a = t + 2;
+    pend_b = (t + 2) % NS;
+    if constexpr (!DR) {
+      if (pend_kind) inflight = issue(pend_a, pend_b);
+      pend_kind = 0;
+    }
     return ring + (t % NS) * STAGE;
+  };
+  // MC = 2: MLP single chunks m .. m + cnt - 1 (one stage's: their b1 slices are contiguous) -> dst: cnt * 12 fragments, then cnt * 128 bytes of bias in the next KiB
+  constexpr int DSTAGE = (2 * (N1 + N2) + 1) * 1024, NDS = RING / DSTAGE, NID = (2 * (N1 + N2) + 1 + NW - 1) / NW;
+  static_assert(MC == 1 || NDS >= 3, "the double-chunk ring needs three slots in the K / V area");
+  auto issue_span = [&](int m, int cnt, unsigned char* dst) -> int {
+    const int nf = cnt * (N1 + N2);
+    const unsigned char* src = ws + (size_t)(NFRONT + (NA + m) * (N1 + N2)) * 1024 + lane * 16;
+    const unsigned char* bsrc = (const unsigned char*)(m >= nhc ? a.b1b : a.b1a) + (size_t)(m >= nhc ? m - nhc : m) * 128 + min(lane, cnt * 8 - 1) * 16;
+    int n = 0;
+#pragma unroll
+    for (int i = 0; i < NID; ++i) {
+      const int blk = i * NW + wave;
+      if (blk < nf) { lv_dma16(src + blk * 1024, dst + blk * 1024); ++n; }
+      else if (blk == nf) { lv_dma16(bsrc, dst + blk * 1024); ++n; }
+    }
+    return n;
+  };
+  const int ndbl = dbl ? nhc - 1 : 0;                        // double chunks behind the two single ones
+  auto wait_inflight = [&]() {
+    if (dbg & 1) inflight = 0;       // timing / debugging: every refill drained before the barrier
+    if (inflight >= 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    else if (inflight == 3) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+    else if (inflight == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+    else if (inflight == 1) asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  };
+  // the two single MLP chunks in front (prefetched into the old ring while the last heads run): their barriers are the first behind the attention, so the doubles they issue may
+  // overwrite K / V
+  auto begin_mlp_single = [&](int t) -> const unsigned char* {
+    wait_inflight();
+    __builtin_amdgcn_s_barrier();
+    const int k = t - t0;
+    inflight = 0;
+    pend_kind = k < ndbl ? 2 : 0;
+    pend_a = 2 + 2 * k;
+    pend_b = k;
+    if constexpr (!DR) {
+      if (pend_kind) inflight = issue_span(pend_a, 2, lds + pend_b * DSTAGE);
+      pend_kind = 0;
+    }
+    return ring + (t % NS) * STAGE;
+  };
+  auto begin_double = [&](int k) -> const unsigned char* {
+    wait_inflight();
+    __builtin_amdgcn_s_barrier();
+    inflight = 0;
+    pend_kind = k + 2 < ndbl ? 2 : 0;
+    pend_a = 2 + 2 * (k + 2);
+    pend_b = (k + 2) % NDS;
+    if constexpr (!DR) {
+      if (pend_kind) inflight = issue_span(pend_a, 2, lds + pend_b * DSTAGE);
+      pend_kind = 0;
+    }
+    return lds + (k % NDS) * DSTAGE;
+  };
+  auto refill = [&]() {                                      // DR: called once per chunk, behind its first fragment reads
+    if constexpr (DR) {
+      if (pend_kind == 1) inflight = issue(pend_a, pend_b);
+      else if (pend_kind == 2) inflight = issue_span(pend_a, 2, lds + pend_b * DSTAGE);
+      pend_kind = 0;
+    }
   };
   issue(0, 0);
   inflight = nchunks > 1 ? issue(1, 1) : 0;
@@ -226,7 +309,9 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(NW / 4,
 #pragma unroll
       for (int i = 0; i < ND; ++i) sm += acc[i][j][0] + acc[i][j][1] + acc[i][j][2] + acc[i][j][3];
       sm = col_sum(sm);
-      const float mean = sm * (1.f / D);
+      float mean = sm * (1.f / D);
+      asm volatile("" : "+v"(mean));      // the mean is rounded ONCE in every instantiation: hipcc's fp-contract fused sm * (1 / D) into the subtractions below in some template
+                                          // instantiations and not in others (1-ulp differences between workgroup shapes that the tests compare bit for bit)
       float q = 0.f;
 #pragma unroll
       for (int i = 0; i < ND; ++i)
@@ -252,6 +337,7 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(NW / 4,
     }
   };
 
+  const unsigned long long tk1 = now();
   // ---- y = W_e x + (b_e + x + pos): embedding chunks (accumulator indices are compile-time) ----
   lv_static_for<0, NE>([&](auto cc) {
     constexpr int c = decltype(cc)::value;
@@ -263,6 +349,7 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(NW / 4,
       frag F[2][3];
       load_r1(buf, 2 * pr, F[0]);
       load_r1(buf, 2 * pr + 1, F[1]);
+      if constexpr (pr == 0) refill();
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int u = 0; u < 2; ++u)
@@ -273,6 +360,7 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(NW / 4,
     });
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   });
+  const unsigned long long tk2 = now();
   layer_norm_to_xb(a.ln1_g, a.ln1_b);        // acc keeps x1 (the residual stream); xb = LN1(x1)
 
   // ---- K and V of the window -> LDS: rows [0, 96) of Wkv are the K features of the 4 heads, rows [96, 192) the V features ----
@@ -285,6 +373,7 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(NW / 4,
       frag F[2][3];
       load_r1(buf, 2 * pr, F[0]);
       load_r1(buf, 2 * pr + 1, F[1]);
+      if (pr == 0) refill();
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int u = 0; u < 2; ++u) {
@@ -307,6 +396,7 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(NW / 4,
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   }
 
+  const unsigned long long tk3 = now();
   // ---- attention, one head per chunk: Q_h = W_q[h] LN1(x) -> softmax(K_h Q_h^T) -> O_h -> x += W_p[:, h] O_h ----
   const float cs = a.scale_log2;
   const frag ones = {(half_t)1, (half_t)1, (half_t)1, (half_t)1, (half_t)1, (half_t)1, (half_t)1, (half_t)1};
@@ -319,6 +409,7 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(NW / 4,
     frag F[2][3];
     load_r1(buf, 0, F[0]);
     load_r1(buf, 1, F[1]);
+    refill();
     __builtin_amdgcn_sched_barrier(0);
     floatx4 hq[2][TM];
 #pragma unroll
@@ -468,6 +559,7 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(NW / 4,
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   }
 
+  const unsigned long long tk4 = now();
   // ---- y1 = x + W2a relu(W1a LN2(x) + b1a) + b2a;  y2 = y1 + W2b relu(W1b y1 + b1b) + b2b (as k_mlp2, 32 hidden units a chunk) ----
   layer_norm_to_xb(a.ln2_g, a.ln2_b);
 #pragma unroll
@@ -476,14 +568,15 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(NW / 4,
 #pragma unroll
     for (int j = 0; j < TM; ++j) acc[i][j] += bb;
   }
-  auto mlp_chunk = [&](int t) {
-    const unsigned char* buf = begin_chunk(t);
+  // one 32-unit chunk: fragments at wb (R1 then R2), its 128 bytes of bias at bb
+  auto mlp_body = [&](const unsigned char* wb, const unsigned char* bb, bool first) {
     frag F[2][3], G[2][3];
     floatx4 bia[2];
-    load_r1(buf, 0, F[0]);
-    bia[0] = *reinterpret_cast<const floatx4*>(buf + a3);
-    load_r1(buf, 1, F[1]);
-    bia[1] = *reinterpret_cast<const floatx4*>(buf + a3 + 64);
+    load_r1(wb, 0, F[0]);
+    bia[0] = *reinterpret_cast<const floatx4*>(bb + 16 * h);
+    load_r1(wb, 1, F[1]);
+    bia[1] = *reinterpret_cast<const floatx4*>(bb + 16 * h + 64);
+    if (first) refill();
     __builtin_amdgcn_sched_barrier(0);
     floatx4 hacc[2][TM];
 #pragma unroll
@@ -495,8 +588,8 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(NW / 4,
 #pragma unroll
         for (int j = 0; j < TM; ++j) hacc[u][j] = Mma<T>::mma(F[u][k], xb[k][j], hacc[u][j]);
       if (u == 0) {
-        load_r2(buf, 0, G[0]);
-        load_r2(buf, 1, G[1]);
+        load_r2(wb, 0, G[0]);
+        load_r2(wb, 1, G[1]);
         __builtin_amdgcn_sched_barrier(0);
       }
     }
@@ -512,23 +605,49 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(NW / 4,
       for (int k = 0; k < 3; ++k)
 #pragma unroll
         for (int j = 0; j < TM; ++j) acc[ig * 3 + k][j] = Mma<T>::mma(G[ig][k], hb[j], acc[ig * 3 + k][j]);
+  };
+  auto mlp_chunk = [&](int t) {
+    const unsigned char* buf = dbl ? begin_mlp_single(t) : begin_chunk(t);
+    mlp_body(buf, buf + R3, true);
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   };
-  const int t0 = NE + NKV + NA;
+  // stage b (mlp_head): its input is the stage-a result, which becomes the new residual
+  auto stage_switch = [&]() {
+#pragma unroll
+    for (int j = 0; j < TM; ++j)
+#pragma unroll
+      for (int c = 0; c < NCH; ++c) xb[c][j] = lv_pack(acc[c * 2][j], acc[c * 2 + 1][j]);
+#pragma unroll
+    for (int i = 0; i < ND; ++i) {
+      const floatx4 bb = *reinterpret_cast<const floatx4*>(a.b2b + i * 16 + 4 * h);
+#pragma unroll
+      for (int j = 0; j < TM; ++j) acc[i][j] += bb;
+    }
+  };
+  unsigned long long tk5 = 0;
+  if (dbl) {
+    mlp_chunk(t0);
+    mlp_chunk(t0 + 1);
 #pragma unroll 1
-  for (int t = 0; t < nhc; ++t) mlp_chunk(t0 + t);
-#pragma unroll
-  for (int j = 0; j < TM; ++j)
-#pragma unroll
-    for (int c = 0; c < NCH; ++c) xb[c][j] = lv_pack(acc[c * 2][j], acc[c * 2 + 1][j]);
-#pragma unroll
-  for (int i = 0; i < ND; ++i) {
-    const floatx4 bb = *reinterpret_cast<const floatx4*>(a.b2b + i * 16 + 4 * h);
-#pragma unroll
-    for (int j = 0; j < TM; ++j) acc[i][j] += bb;
+    for (int k = 0; k < ndbl; ++k) {
+      if (2 + 2 * k == nhc) {
+        tk5 = now();
+        stage_switch();
+      }
+      const unsigned char* buf = begin_double(k);
+      mlp_body(buf, buf + 2 * (N1 + N2) * 1024, true);
+      mlp_body(buf + (N1 + N2) * 1024, buf + 2 * (N1 + N2) * 1024 + 128, false);
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    }
+  } else {
+#pragma unroll 1
+    for (int t = 0; t < nhc; ++t) mlp_chunk(t0 + t);
+    tk5 = now();
+    stage_switch();
+#pragma unroll 1
+    for (int t = nhc; t < 2 * nhc; ++t) mlp_chunk(t0 + t);
   }
-#pragma unroll 1
-  for (int t = nhc; t < 2 * nhc; ++t) mlp_chunk(t0 + t);
+  const unsigned long long tk6 = now();
 
   // ---- fold + window join into the output map ----
 #pragma unroll
@@ -544,9 +663,22 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(NW / 4,
       *reinterpret_cast<uint4*>(dst) = pair_tiles16(acc[i][j], acc[i + 1][j]);
     }
   }
+  if (stamps) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    const unsigned long long tk7 = now(), rt1 = __builtin_amdgcn_s_memrealtime();
+    if (blockIdx.x == 0 && blockIdx.z == 0 && lane == 0 && wave < 4) {
+      unsigned long long* o = stamps + wave * 8;
+      o[0] = tk1 - tk0; o[1] = tk2 - tk1; o[2] = tk3 - tk2; o[3] = tk4 - tk3; o[4] = tk5 - tk4; o[5] = tk6 - tk5; o[6] = tk7 - tk6; o[7] = rt1 - rt0;
+    }
+  }
 }
 
 }  // namespace
+
+int& cfen_tune_lvit_debug() {
+  static int v = 0;
+  return v;
+}
 
 int& cfen_tune_lvit_shape() {   // 2 (default): 16 waves x 1 token tile (four waves per SIMD, 128 registers, no spills: 2.858 -> 2.83 ms -- a wave issues a vector
                                 // instruction every ~10 cycles and two thirds of this kernel are vector-instruction bound); 0: 8 waves x 2 token tiles;
@@ -579,24 +711,47 @@ int cfen_lvit_window_impl_g(int dtype, int ng, const LvitArgs* ap, hipStream_t s
   }
   const long long blocks = (long long)ap[0].B * (ap[0].H / ap[0].ws) * (ap[0].W / ap[0].ws);
   CFEN_CHECK_ARG(blocks > 0 && blocks < (1ll << 31), "lvit_window: bad grid");
-  if (cfen_tune_lvit_shape() == 2)
-    CFEN_LAUNCH((k_lvit_window<6, 16, 1>), dim3((unsigned)blocks, 1, ng), dim3(1024), 0, s, ga);
+  unsigned long long* stamps = nullptr;
+  const bool stamping = (cfen_tune_lvit_debug() & 64) != 0;
+  if (stamping) {   // timing run: section times of workgroup 0 to stderr after the launch (tools/dbg_lvit_sections.py)
+    static unsigned long long* buf = nullptr;
+    if (!buf && hipMalloc(&buf, 4 * 8 * sizeof(unsigned long long)) != hipSuccess) buf = nullptr;
+    stamps = buf;
+    if (stamps) (void)hipMemsetAsync(stamps, 0, 4 * 8 * sizeof(unsigned long long), s);
+  }
+  if (cfen_tune_lvit_shape() == 2)             // default (round 6): 16 waves x 1 token tile, every refill behind the chunk's first fragment reads
+    CFEN_LAUNCH((k_lvit_window<6, 16, 1, 0, 0, 1, 1>), dim3((unsigned)blocks, 1, ng), dim3(1024), 0, s, ga, stamps, cfen_tune_lvit_debug() & 63);
+  else if (cfen_tune_lvit_shape() == 12)       // the refill right behind the barrier (rounds 3-5)
+    CFEN_LAUNCH((k_lvit_window<6, 16, 1>), dim3((unsigned)blocks, 1, ng), dim3(1024), 0, s, ga, stamps, cfen_tune_lvit_debug() & 63);
+  else if (cfen_tune_lvit_shape() == 15)       // double MLP chunks on a ring over the dead K / V tiles (MEASURED: 350 against 374 us for 1536 windows alone, equal in flight; the
+    CFEN_LAUNCH((k_lvit_window<6, 16, 1, 0, 0, 2>), dim3((unsigned)blocks, 1, ng), dim3(1024), 0, s, ga, stamps, cfen_tune_lvit_debug() & 63);      // instantiation spills 112-120 bytes a lane at 128 registers)
+  else if (cfen_tune_lvit_shape() == 13)       // ... with deferred refills: 452 us (spills in the hot loops)
+    CFEN_LAUNCH((k_lvit_window<6, 16, 1, 0, 0, 2, 1>), dim3((unsigned)blocks, 1, ng), dim3(1024), 0, s, ga, stamps, cfen_tune_lvit_debug() & 63);
   else if (cfen_tune_lvit_shape() == 3)
-    CFEN_LAUNCH((k_lvit_window<6, 16, 1, 1>), dim3((unsigned)blocks, 1, ng), dim3(1024), 0, s, ga);
+    CFEN_LAUNCH((k_lvit_window<6, 16, 1, 1>), dim3((unsigned)blocks, 1, ng), dim3(1024), 0, s, ga, stamps, cfen_tune_lvit_debug() & 63);
   else if (cfen_tune_lvit_shape() == 4)
-    CFEN_LAUNCH((k_lvit_window<6, 16, 1, 2>), dim3((unsigned)blocks, 1, ng), dim3(1024), 0, s, ga);
+    CFEN_LAUNCH((k_lvit_window<6, 16, 1, 2>), dim3((unsigned)blocks, 1, ng), dim3(1024), 0, s, ga, stamps, cfen_tune_lvit_debug() & 63);
   else if (cfen_tune_lvit_shape() == 5)
-    CFEN_LAUNCH((k_lvit_window<6, 8, 2, 2>), dim3((unsigned)blocks, 1, ng), dim3(512), 0, s, ga);
+    CFEN_LAUNCH((k_lvit_window<6, 8, 2, 2>), dim3((unsigned)blocks, 1, ng), dim3(512), 0, s, ga, stamps, cfen_tune_lvit_debug() & 63);
   else if (cfen_tune_lvit_shape() == 6)
-    CFEN_LAUNCH((k_lvit_window<6, 16, 1, 0, 1>), dim3((unsigned)blocks, 1, ng), dim3(1024), 0, s, ga);
+    CFEN_LAUNCH((k_lvit_window<6, 16, 1, 0, 1>), dim3((unsigned)blocks, 1, ng), dim3(1024), 0, s, ga, stamps, cfen_tune_lvit_debug() & 63);
   else if (cfen_tune_lvit_shape() == 8)
-    CFEN_LAUNCH((k_lvit_window<6, 16, 1, 8>), dim3((unsigned)blocks, 1, ng), dim3(1024), 0, s, ga);
+    CFEN_LAUNCH((k_lvit_window<6, 16, 1, 8>), dim3((unsigned)blocks, 1, ng), dim3(1024), 0, s, ga, stamps, cfen_tune_lvit_debug() & 63);
   else if (cfen_tune_lvit_shape() == 9)
-    CFEN_LAUNCH((k_lvit_window<6, 16, 1, 9>), dim3((unsigned)blocks, 1, ng), dim3(1024), 0, s, ga);
+    CFEN_LAUNCH((k_lvit_window<6, 16, 1, 9>), dim3((unsigned)blocks, 1, ng), dim3(1024), 0, s, ga, stamps, cfen_tune_lvit_debug() & 63);
   else if (cfen_tune_lvit_shape() == 1)
-    CFEN_LAUNCH((k_lvit_window<6, 4, 4>), dim3((unsigned)blocks, 1, ng), dim3(256), 0, s, ga);
+    CFEN_LAUNCH((k_lvit_window<6, 4, 4>), dim3((unsigned)blocks, 1, ng), dim3(256), 0, s, ga, stamps, cfen_tune_lvit_debug() & 63);
   else
-    CFEN_LAUNCH((k_lvit_window<6, 8, 2>), dim3((unsigned)blocks, 1, ng), dim3(512), 0, s, ga);
+    CFEN_LAUNCH((k_lvit_window<6, 8, 2>), dim3((unsigned)blocks, 1, ng), dim3(512), 0, s, ga, stamps, cfen_tune_lvit_debug() & 63);
   CFEN_CHECK_LAUNCH("lvit_window");
+  if (stamping && stamps && !cfen_recorder()) {
+    unsigned long long hst[4 * 8];
+    if (hipStreamSynchronize(s) == hipSuccess && hipMemcpy(hst, stamps, sizeof(hst), hipMemcpyDeviceToHost) == hipSuccess)
+      for (int w = 0; w < 4; ++w) {
+        const unsigned long long* o = hst + w * 8;
+        fprintf(stderr, "lvit_window stamps wave %d: prologue %llu, embedding %llu, LN1 + K/V %llu, attention %llu, LN2 + MLP a %llu, MLP b %llu, fold %llu cyc; %.1f us in all\n", w, o[0], o[1], o[2], o[3],
+                o[4], o[5], o[6], (double)o[7] / 100.0);
+      }
+  }
   return CFEN_OK;
 }

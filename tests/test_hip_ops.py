@@ -877,7 +877,7 @@ def test_lvit_window_block_against_oracle_and_unfused_chain(B, H, W):
     close(got, want, tol(dt, 12), "fused window block vs fp64")
     # the three workgroup shapes (16 waves x 1 token tile: the default; 8 x 2; 4 x 4 on 512 registers) do the same arithmetic per token
     try:
-        for shape in (0, 1, 2, 4, 6):       # 6: the embedding / K, V matrices in 64-row chunks (5 front chunks instead of 9)          # 4: the attention loops' K / V fragment reads issued by hand ahead of the MFMAs (round 5): same arithmetic, same order
+        for shape in (0, 1, 12, 15, 4, 6):       # 12: the refill right behind the barrier; 15: double MLP chunks over the dead K / V tiles (round 6)          # 6: the embedding / K, V matrices in 64-row chunks (5 front chunks instead of 9)          # 4: the attention loops' K / V fragment reads issued by hand ahead of the MFMAs (round 5): same arithmetic, same order
             ops.tune("lvit.shape", shape)
             other = ops.from_nhwc(ops.lvit_window(fmap, 24, 32, 2, pk, g.name, g.hidden), 24)
             assert torch.equal(other, got), "lvit.shape %d differs from the default shape" % shape
