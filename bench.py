@@ -269,8 +269,11 @@ def main():
         net.serial_plan = lanes_plan == 1
     x = synthetic_input(B, cfg, seed0=rank * B).to(dev)
     nslab = max(2, args.in_flight)
-    slabs = [torch.empty(7 * B * n * n, dtype=torch.float32, device=dev) for _ in range(nslab)]
     gdt = args.dtype if args.gather_dtype == "auto" else args.gather_dtype
+    # the sharded run gathers fp16: the fused tail launch writes that type itself (round 6: no conversion pass, no fp32 slab) where the geometry allows
+    wire_f16 = (world > 1 or args.force_gather) and gdt == "fp16" and args.dtype == "fp16" and n % 64 == 0 and args.variant == "v3" and not os.environ.get("CFEN_BENCH_FP32_SLABS")
+    net.output_f16 = wire_f16
+    slabs = [torch.empty(7 * B * n * n, dtype=torch.float16 if wire_f16 else torch.float32, device=dev) for _ in range(nslab)]
     gather = OutputGatherer(world, slabs[0].numel(), dev, torch.float16 if gdt == "fp16" else torch.float32, slots=nslab) if (world > 1 or args.force_gather) else None
 
     net(x, out=slabs[0])                       # packs weights, builds the plan

@@ -79,6 +79,7 @@ SIGNATURES = {
     "cfen_net_actnorm_pending_count": (_I, [_P]),
     "cfen_net_set_input_u8": (_I, [_P, _I]),
     "cfen_net_set_output_u8": (_I, [_P, _I]),
+    "cfen_net_set_output_f16": (_I, [_P, _I]),
     "cfen_net_forward": (_I, [_P, _P, _P, _P, _P, _P, c_size_t, _P]),
     "cfen_net_graph_capture": (_I, [_P, _P, _P, _P, _P, _P, c_size_t, ctypes.POINTER(ctypes.c_int32)]),
     "cfen_net_graph_launch": (_I, [_P, ctypes.c_int32, _P]),

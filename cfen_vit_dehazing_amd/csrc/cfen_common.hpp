@@ -245,4 +245,14 @@ void cfen_log_kernel(const void* host_stub, const char* as_written);     // cfen
     }                                                                              \
   } while (0)
 
+// "has this launcher raised its kernel's dynamic-LDS limit on the CURRENT device yet?"  Per device: a process that drives several GPUs (one dec_ipt per device) must raise
+// it on each; `flags` is the launcher's own static bool[64].
+static inline bool cfen_first_use_on_device(bool (&flags)[64]) {
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
+  const bool first = !flags[dev];
+  flags[dev] = true;
+  return first;
+}
+
 static inline bool cfen_aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }

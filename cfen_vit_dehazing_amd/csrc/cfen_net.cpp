@@ -142,6 +142,7 @@ struct cfen_net {
   struct AnPending { const float* ones; const float* conv_bias; float* an_out; int win; };
   std::map<std::string, AnPending> an_pending;
   bool an_raw_pass = false;
+  int output_f16 = 0;              // 1: xr / xs / xd are fp16 NCHW (round 6: what the sharded run gathers), written by the fused tail launch (k_tail.hip) only
   int output_u8 = 0;               // 1: xr / xs / xd are uint8 HWC (B,H,W,3) = util.tensor2im of the fp32 results, written by the tails' 7x7 launch (k_conv7_tz)
   int input_u8 = 0;                // 1: x is uint8 HWC (B,H,W,3), normalised to [-1,1] by the first launch (data/base_dataset.py:44-46)
   bool cfs = false;                // sibling generators networks_iid_hlgvit_crs_gd4_cfs.py / ..._crs_gd4.py (cfg.reserved bits 8..15 == 1 / 2): the three
@@ -597,6 +598,7 @@ int cfen_net::run_conv_g(int ng, const ConvCall* cc, int act) {
     d[g].Cout = c.Cout; d[g].Cout_pad = c.Cout_pad;
     if (q.nchw_out) {
       d[g].out = q.nchw_out; d[g].out_nchw_f32 = (output_u8 && c.tz) ? 2 : 1; d[g].cs_out = c.Cout_pad;
+      CFEN_CHECK_ARG(!output_f16, "net: fp16 outputs are written by the fused tail launch only (\"net.tail_fused\" = 2, stages not kept), %s runs on its own", q.layer.c_str());
       CFEN_CHECK_ARG(!output_u8 || c.tz, "net: uint8 outputs need the Toeplitz 7x7 tail kernel, %s does not run on it", q.layer.c_str());
     } else {
       const Buf& bo = bufs.at(q.out);
@@ -1142,7 +1144,7 @@ int cfen_net::run_decoder(float* const* outs, hipStream_t sm, hipStream_t sg) {
     for (int g = 0; g < 3 && whole; ++g) {
       const ConvLayer& z = convs.at(c7[g].layer);
       const Buf& bm = bufs.at(c7[g].in0);
-      const int mode = output_u8 ? 2 : 1;
+      const int mode = output_u8 ? 2 : output_f16 ? 3 : 1;
       whole = z.tz && z.kind == 0 && z.k == 7 && z.reflect && outs[g] &&
               cfen_tail_fused_supported(dt, bufs.at(out[g]).cs, convs.at(up[g]).Cout_pad, bufs.at(up[g]).cs, convs.at(c3[g].layer).Cout_pad, bufs.at(out[g]).H,
                                         bufs.at(out[g]).W, z.Cout, mode) && bm.cs == 16;
@@ -1326,7 +1328,21 @@ int cfen_net_set_output_u8(cfen_net* net, int enabled) {
       CFEN_CHECK_ARG(it != net->convs.end() && it->second.tz && (it->second.Cout == 1 || it->second.Cout == 3),
                      "set_output_u8: %s does not run on the Toeplitz 7x7 kernel at this geometry (fp16, image edge a multiple of 64): take fp32 outputs and cfen_tensor2im_u8", t);
     }
+  CFEN_CHECK_ARG(!enabled || !net->output_f16, "set_output_u8: the net already writes fp16 outputs");
   net->output_u8 = enabled ? 1 : 0;
+  return CFEN_OK;
+}
+
+int cfen_net_set_output_f16(cfen_net* net, int enabled) {
+  CFEN_CHECK_ARG(net != nullptr, "set_output_f16: null net");
+  if (enabled) {
+    CFEN_CHECK_ARG(!net->output_u8, "set_output_f16: the net already writes uint8 outputs");
+    for (const char* t : {"tail_R.conv7", "tail_S.conv7", "tail_D.conv7"}) {
+      auto it = net->convs.find(t);
+      CFEN_CHECK_ARG(it != net->convs.end() && it->second.tz, "set_output_f16: %s does not run on the fused tail kernel at this geometry (fp16, image edge a multiple of 64)", t);
+    }
+  }
+  net->output_f16 = enabled ? 1 : 0;
   return CFEN_OK;
 }
 

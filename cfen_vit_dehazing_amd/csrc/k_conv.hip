@@ -369,13 +369,12 @@ int launch_conv_wl_t(int ng, const ConvDesc* dp, hipStream_t s) {
     smem = (smem + 15) / 16 * 16 + (size_t)3 * (Pw / 4 + 2) * (d.Cin / Mma<T>::EPL) * 16 + (size_t)P * conv_up_pitch<T>(d.Cin);
     CFEN_CHECK_ARG(smem <= 152 * 1024, "conv (x4 source): %zu bytes of LDS", smem);
   }
-  static bool attr_set = false;
-  if (!attr_set) {
+  static bool attr_set[64] = {};
+  if (cfen_first_use_on_device(attr_set)) {
     if (hipFuncSetAttribute((const void*)k_conv<T, TN, TM, true, NW, UP>, hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024) != hipSuccess) {
       cfen_set_error("conv: cannot reserve LDS for the staged weights");
       return CFEN_ERR_HIP;
     }
-    attr_set = true;
   }
   dim3 grid(cfen_grid8((total + per_block - 1) / per_block), d.nphase, ng);
   CFEN_LAUNCH((k_conv<T, TN, TM, true, NW, UP>), grid, dim3(NW * 64), smem, s, dg);

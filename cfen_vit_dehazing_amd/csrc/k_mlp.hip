@@ -609,13 +609,12 @@ int launch_mlp_t(int ng, const MlpArgs* ap, hipStream_t s) {
   const long long per = (long long)NW * TM * 16;
   const long long blocks = (a.M + per - 1) / per;
   CFEN_CHECK_ARG(blocks > 0 && blocks < (1ll << 31), "mlp: bad grid");
-  static bool attr_set = false;
-  if (!attr_set) {
+  static bool attr_set[64] = {};
+  if (cfen_first_use_on_device(attr_set)) {
     if (hipFuncSetAttribute((const void*)k_mlp<T, ND, TM, NW, HCH, WPE>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) != hipSuccess) {
       cfen_set_error("mlp: cannot reserve %zu bytes of LDS", smem);
       return CFEN_ERR_HIP;
     }
-    attr_set = true;
   }
   CFEN_LAUNCH((k_mlp<T, ND, TM, NW, HCH, WPE>), dim3((unsigned)blocks, 1, ng), dim3(NW * 64), smem, s, ga);
   CFEN_CHECK_LAUNCH("mlp");

@@ -32,7 +32,7 @@ static_assert(TF_LDS <= 160 * 1024, "one workgroup a CU");
 struct TailArgs {
   const half_t* in; const half_t* wT; const float* sT; const float* tT; int actT;
   const half_t* w3; const float* s3; const float* t3; int act3;
-  const half_t* w7; const float* s7; const float* t7; int act7; int Cout; void* out; int out_mode;   // out_mode 1: fp32 NCHW, 2: uint8 HWC x 3 (util.tensor2im)
+  const half_t* w7; const float* s7; const float* t7; int act7; int Cout; void* out; int out_mode;   // out_mode 1: fp32 NCHW, 2: uint8 HWC x 3 (util.tensor2im), 3: fp16 NCHW (round 6: the sharded run's wire type, written directly)
   int B, Hin, Win, cs_in;
 };
 
@@ -125,7 +125,13 @@ __global__ __launch_bounds__(768) void k_tail_fused(Grouped<TailArgs> ga, int nb
           op[0] = o0; op[1] = o1; op[2] = o2;
         }
       } else if (h < Cout) {
-        *reinterpret_cast<floatx4*>((float*)outp + (((size_t)b * Cout + h) * Hf + y) * Wf + X0 + 4 * r16) = v;
+        const size_t o = (((size_t)b * Cout + h) * Hf + y) * Wf + X0 + 4 * r16;
+        if (out_mode == 3) {
+          const half4 hv = {(half_t)v[0], (half_t)v[1], (half_t)v[2], (half_t)v[3]};
+          *reinterpret_cast<half4*>((half_t*)outp + o) = hv;
+        } else {
+          *reinterpret_cast<floatx4*>((float*)outp + o) = v;
+        }
       }
     };
     if (band_live(k0 - 2)) { fetch(k0 - 2); stage(k0 - 2); }
@@ -349,7 +355,7 @@ int& cfen_tune_tail_segments() {   // vertical segments a strip is cut into ("ta
 
 bool cfen_tail_fused_supported(int dtype, int cs_in, int Cup_pad, int cs_up, int C3_pad, int Hin, int Win, int Cout7, int out_mode) {
   return dtype == 1 && cs_in % 8 == 0 && cs_in * 2 <= 64 && Cup_pad == 16 && cs_up == 16 && C3_pad == 16 && Hin % 4 == 0 && Win % 32 == 0 && Hin >= 8 &&
-         Cout7 >= 1 && Cout7 <= 4 && (out_mode == 1 || (out_mode == 2 && (Cout7 == 1 || Cout7 == 3)));
+         Cout7 >= 1 && Cout7 <= 4 && (out_mode == 1 || out_mode == 3 || (out_mode == 2 && (Cout7 == 1 || Cout7 == 3)));
 }
 
 int cfen_tail_fused_impl_g(int dtype, int ng, const CfenUpConv3* u, const ConvDesc* d7, hipStream_t s) {
@@ -375,13 +381,13 @@ int cfen_tail_fused_impl_g(int dtype, int ng, const CfenUpConv3* u, const ConvDe
   while (bands % nseg) --nseg;
   const long long nblk = (long long)u[0].B * (2 * u[0].Win / 64) * nseg;
   CFEN_CHECK_ARG(nblk < (1ll << 31), "tail (fused): grid too large");
-  static bool attr_set = false;
-  if (!attr_set) {
+  // (per device: a process that drives several GPUs must raise the limit on each of them -- ADVICE r05)
+  static bool attr_set[64] = {};
+  if (cfen_first_use_on_device(attr_set)) {
     if (hipFuncSetAttribute((const void*)k_tail_fused, hipFuncAttributeMaxDynamicSharedMemorySize, TF_LDS) != hipSuccess) {
       cfen_set_error("tail (fused): cannot reserve %d bytes of LDS", TF_LDS);
       return CFEN_ERR_HIP;
     }
-    attr_set = true;
   }
   static unsigned long long* stamps = nullptr;
   const bool stamping = (cfen_tune_tail_debug() & 64) != 0;

@@ -91,6 +91,9 @@ class dec_ipt(nn.Module):
         # `output_u8`: forward() returns three uint8 (B,H,W,3) tensors = util.tensor2im of the fp32 results (test.py --out_all saves exactly those),
         # written by the tails' last launch where the geometry allows (cfen_net_set_output_u8), else by cfen_tensor2im_u8 passes on the device
         self.output_u8 = False
+        # `output_f16` (round 6): forward() writes / returns fp16 NCHW outputs (the fp32 results rounded to nearest even) straight from the fused tail launch
+        # (cfen_net_set_output_f16) -- the sharded run's wire type without a conversion pass.  fp16 nets at full-size tails only: refused loudly elsewhere
+        self.output_f16 = False
         # GViT weights tile-major (packing.pack_wtile; cfen_net_config.reserved bit 1): +1 % measured (3.34 -> 3.30 ms at B = 8); CFEN_WTILE=0 = row-major
         self.wtile = os.environ.get("CFEN_WTILE", "1") != "0"
         # CFEN_GVIT_CHAIN=1: GViT weights ALSO as MFMA fragment streams (packing.pack_stream_tiles; cfen_net_config.reserved bit 2) and the GEMMs of a
@@ -185,13 +188,25 @@ class dec_ipt(nn.Module):
         dtype = _DTYPES[dtype]
         if dtype == self.compute_dtype:
             return
-        if self._packed is not None:
+        if self._packed is not None and not self._an_pending:
+            # (a packed set whose ActNorm layers are still uninitialised is NOT kept: once they are initialised under the other type its epilogue tables and its
+            # pending list would be stale -- the next forward of this type would initialise ActNorm again, from another batch; it is repacked instead.  ADVICE r05)
             self._packed_cache[self.compute_dtype] = (self._packed, self._packed_dev, self._an_pending, getattr(self, "_ones", None))
         self.compute_dtype = dtype
         self._packed = None
         hit = self._packed_cache.pop(dtype, None)
         if hit is not None:
             self._packed, self._packed_dev, self._an_pending, self._ones = hit
+
+    def release_other_dtypes(self):
+        """free the packed weights, launch plans and workspaces of every compute type but the current one (both types stay resident after a switch: ~0.8 GB of packed
+        weights per type plus each replica's workspace -- what the harness's periodic fp32 checks want, not what a one-off fp32 leg needs afterwards)"""
+        self._packed_cache = {}
+        lib = _lib.load() if self._nets else None
+        for key in [k for k in self._nets if k[5] != self.compute_dtype]:
+            lib.cfen_net_destroy(self._nets.pop(key)[0])
+            self._native_u8.pop(key, None)
+        torch.cuda.empty_cache()
 
     def _live_state(self, device):
         sd = {}
@@ -220,7 +235,7 @@ class dec_ipt(nn.Module):
 
     def _net_for(self, batch, device, u8=False):
         packed = self._ensure_packed(device)
-        key = (batch, bool(u8), bool(self.serial_plan), int(self.replica), bool(self.output_u8), self.compute_dtype)
+        key = (batch, bool(u8), bool(self.serial_plan), int(self.replica), bool(self.output_u8), self.compute_dtype, bool(self.output_f16))
         if key in self._nets:
             return self._nets[key]
         if self.gvit_chain:
@@ -249,6 +264,10 @@ class dec_ipt(nn.Module):
         if u8:
             check(lib.cfen_net_set_input_u8(h, 1), "cfen_net_set_input_u8")
         native_u8 = bool(self.output_u8) and lib.cfen_net_set_output_u8(h, 1) == 0      # refused (fp32 net, small images): fp32 outputs + tensor2im_u8 passes
+        if self.output_f16:
+            if self.output_u8:
+                raise CfenError("output_f16 and output_u8 exclude each other")
+            check(lib.cfen_net_set_output_f16(h, 1), "cfen_net_set_output_f16")
         ws = torch.empty(lib.cfen_net_workspace_bytes(h), dtype=torch.uint8, device=device)
         self._nets[key] = (h, ws)
         self._native_u8[key] = native_u8
@@ -291,6 +310,7 @@ class dec_ipt(nn.Module):
                 m.weight.copy_(an_out[0, :c])
                 m.bias.copy_(an_out[1, :c])
                 m.initialized.fill_(1)
+        self._packed_cache = {}      # sets of the other compute types were packed before these parameters existed
         self._an_pending = {}
 
     # ---- forward ----------------------------------------------------------------------------
@@ -345,7 +365,7 @@ class dec_ipt(nn.Module):
                                 "models/actnorm.py:25-37) before capture() / profile()")
             self._arm_actnorm_init(h)
         px = B * n * n
-        key = (B, bool(u8), bool(self.serial_plan), int(self.replica), bool(self.output_u8), self.compute_dtype)
+        key = (B, bool(u8), bool(self.serial_plan), int(self.replica), bool(self.output_u8), self.compute_dtype, bool(self.output_f16))
         native_u8 = self._native_u8[key]
         if self.output_u8 and out is not None:
             raise ValueError("output_u8 allocates its own (B,H,W,3) uint8 outputs: no `out` slab")
@@ -357,10 +377,11 @@ class dec_ipt(nn.Module):
             flat = torch.empty(9 * px, dtype=torch.uint8, device=x.device)
             xr, xs, xd = (flat[k * 3 * px:(k + 1) * 3 * px].view(B, n, n, 3) for k in range(3))
         else:
+            odt = torch.float16 if self.output_f16 else torch.float32
             if out is None:
-                out = torch.empty(7 * px, dtype=torch.float32, device=x.device)
-            elif out.dtype != torch.float32 or out.numel() != 7 * px or not out.is_contiguous() or out.device != x.device:
-                raise ValueError("out must be a contiguous float32 buffer of 7*B*H*W elements on the input's device")
+                out = torch.empty(7 * px, dtype=odt, device=x.device)
+            elif out.dtype != odt or out.numel() != 7 * px or not out.is_contiguous() or out.device != x.device:
+                raise ValueError("out must be a contiguous %s buffer of 7*B*H*W elements on the input's device" % ("float16 (output_f16)" if self.output_f16 else "float32"))
             flat = out.view(-1)
             xr, xs, xd = flat[:3 * px].view(B, 3, n, n), flat[3 * px:4 * px].view(B, 1, n, n), flat[4 * px:].view(B, 3, n, n)
         lib = _lib.load()

@@ -70,6 +70,12 @@ class BaseOptions():
                             'asynchronous copies both ways, PNG decode in the DataLoader workers (--nThreads) and encode in --writers threads; the files '
                             'written are byte-identical to the sequential loop')
         p.add_argument('--writers', type=int, default=8, help='(extension) PNG encoder threads of the pipelined driver')
+        p.add_argument('--png_compress_level', type=int, default=-1,
+                       help='(extension) zlib level 0..9 of the result PNGs; -1 (default) = PIL\'s own default, the reference\'s files byte for byte. 1 encodes ~3x faster '
+                            '(same pixels, larger files)')
+        p.add_argument('--writer_procs', type=int, default=0,
+                       help='(extension) PNG encoder PROCESSES of the pipelined driver instead of --writers threads (0 = threads): forked right after option parsing, images '
+                            'handed over through shared memory; encode scales with the host cores (threads contend for the GIL around the compressor)')
         p.add_argument('--u8_input', action='store_true',
                        help='(extension) the dataset hands over uint8 HWC images and ToTensor + Normalize(0.5, 0.5) run on the device '
                             'inside the generator launch plan (12x fewer bytes over PCIe); results are identical')
@@ -108,6 +114,10 @@ class BaseOptions():
             opt.gpu_ids = [local]
         if opt.in_flight < 1:
             raise ValueError('--in_flight must be >= 1')
+        if not -1 <= opt.png_compress_level <= 9:
+            raise ValueError('--png_compress_level must be -1 (PIL default) or 0..9')
+        from ..util import util as _util
+        _util.PNG_COMPRESS_LEVEL = None if opt.png_compress_level < 0 else opt.png_compress_level      # set before any writer process is forked
         if opt.in_flight > 1:
             # the pipelined driver keeps K forwards on K streams; the HIP runtime deals a process's streams onto GPU_MAX_HW_QUEUES hardware queues
             # (default 4) and two busy streams on one queue run one behind the other (4 in flight: 2.51 ms / step on 4 queues, 2.10 on 8,

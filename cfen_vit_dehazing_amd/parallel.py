@@ -72,9 +72,10 @@ class OutputGatherer:
     per rank = the lanes + that one stream.  Measured on one MI355X with a world-1 RCCL communicator (bench.py extra_configs.gather_overhead_1gpu): a
     separate communication stream in front of torch's internal one -- five busy queues -- cost 0.72 ms per step (2.21 -> 2.93 ms with three lanes).
 
-    `dtype` is the wire type.  The kernels write fp32 slabs; with the fp16 compute path the slab is converted to fp16 before it is gathered (outputs
-    are tanh values in (-1, 1): the 2^-11 rounding is below the fp16 path's own error), which halves the xGMI traffic -- 29 MB instead of 59 MB per
-    rank at 8 images of 512x512."""
+    `dtype` is the wire type.  With the fp16 compute path the wire is fp16 (outputs are tanh values in (-1, 1): the 2^-11 rounding is below the fp16
+    path's own error), which halves the xGMI traffic -- 29 MB instead of 59 MB per rank at 8 images of 512x512.  Since round 6 the fused tail launch
+    writes that type itself (dec_ipt.output_f16): a slab that already has the wire type is gathered as it is; an fp32 slab is still converted on the
+    lane first."""
 
     def __init__(self, world, numel, device, dtype=torch.float32, slots=2):
         if slots < 1:
@@ -89,7 +90,8 @@ class OutputGatherer:
                 raise ValueError("OutputGatherer: ranks hold slabs of %d .. %d elements; shard the global batch with parallel.even_shard"
                                  % (int(-lohi[1]), int(lohi[0])))
         self.bufs = [torch.empty(world * numel, dtype=dtype, device=device) for _ in range(slots)]
-        self.stage = [torch.empty(numel, dtype=dtype, device=device) for _ in range(slots)] if dtype != torch.float32 else None
+        self.stage = [torch.empty(numel, dtype=dtype, device=device) for _ in range(slots)] if dtype != torch.float32 else None   # wire-type copies of fp32 slabs
+        self.direct = [True] * slots          # slot -> the collective last launched for it reads the caller's slab itself (no stage copy in between)
         self.work = [None] * slots            # slot -> handle of the collective that last read stage[slot] / the slab and wrote bufs[slot]
 
     def _settle(self, slot):
@@ -101,7 +103,7 @@ class OutputGatherer:
     def before_write(self, slot):
         """Call on the lane's stream before the forward overwrites the slab last handed to launch(slot).  With a converting gatherer the slab was
         released by a copy on this same lane (nothing to wait for); an fp32 wire reads the slab itself."""
-        if self.stage is None:
+        if self.direct[slot]:
             self._settle(slot)
 
     def launch(self, slab, slot):
@@ -111,10 +113,12 @@ class OutputGatherer:
                              % (slab.numel(), self.numel))
         convert = self.stage is not None and slab.dtype != self.dtype
         if not self.cuda:
+            self.direct[slot] = not convert
             src = self.stage[slot].copy_(slab) if convert else slab
             dist.all_gather_into_tensor(self.bufs[slot], src)
             return self.bufs[slot]
         self._settle(slot)                                # stage[slot] / bufs[slot] are free again
+        self.direct[slot] = not convert
         src = self.stage[slot].copy_(slab) if convert else slab
         self.work[slot] = dist.all_gather_into_tensor(self.bufs[slot], src, async_op=True)
         return self.bufs[slot]

@@ -9,7 +9,9 @@ hardware queue each.  This module is that loop for real files:
   main thread, slot k = batch % K   pinned host buffer -> cudaMemcpyAsync H2D -> graph replay of replica k -> tensor2im bytes (written by the tails' last
                                     launch where the net does that itself, by the harness's own device pass otherwise) -> cudaMemcpyAsync D2H into pinned
                                     memory -> event; all on the slot's stream, nothing waits on the host until the slot comes round again
-  writer threads (--writers)        PNG encode + file write of a finished slot (PIL releases the GIL while it compresses)
+  writers (--writers N)             PNG encode + file write of a finished slot: N threads (PIL releases the GIL while it compresses, but 32 threads measured 527 images/s =
+                                    16 each against 33 for one alone: GIL contention around the compressor), or with --writer_procs N processes forked BEFORE the model
+                                    exists (start_writer_processes) that take the images from a ring of shared-memory slots -- encode then scales with the host's cores
 
 Same files, byte for byte, as the sequential loop (tests/test_hip_net.py::test_pipelined_cli_writes_the_same_pngs): the arithmetic is the same launch plan
 on the same weights (replicas differ in workspace only), and the bytes of a visual come from the same device passes (`util.tensor2im`'s arithmetic).
@@ -33,6 +35,49 @@ def _save_png(arr, path):
     util.save_image(arr, path)
 
 
+# ---- writer PROCESSES (round 6): forked right after option parsing (test.py), like the DataLoader's decode workers -- forking a process that holds its GPU working set
+# stalls the next launch 10-16 s on MI355X / ROCm 7.2.  Images travel through an anonymous shared mapping made before the fork (a ring of image-sized slots): the parent
+# copies a finished image into a free slot (0.8 MB memcpy) and sends (slot, shape, path); a slot returns to the free list when its file is written, which also bounds the
+# backlog in bytes (the thread pool's 4096-future bound let ~3 GB of image copies queue up).
+_WRITERS = None
+
+
+def _save_png_from_ring(off, shape, path, token):
+    arr = np.frombuffer(_WRITERS["ring"], dtype=np.uint8, count=int(np.prod(shape)), offset=off).reshape(shape)
+    util.save_image(arr, path)
+    return token
+
+
+def start_writer_processes(n, image_edge, batch=8, labels=1, in_flight=4, slots=0):
+    """fork `n` PNG writer processes that read their images from one anonymous shared mapping made here, BEFORE the first HIP call:
+      * `bslots` BATCH slots of labels x batch x (edge, edge, 3) uint8: the pipelined loop registers this part as pinned host memory (hipHostRegister) and lets the
+        device-to-host copies land in it -- a writer encodes an image straight from where the DMA put it, the main thread copies nothing;
+      * `slots` single-image slots behind them for the batches that go through the model's sequential path (--precision half checks): copied in by the main thread."""
+    global _WRITERS
+    import mmap
+    import multiprocessing as mp
+    if _WRITERS is not None or n <= 0:
+        return _WRITERS
+    img = int(image_edge) * int(image_edge) * 3
+    bbytes = int(labels) * int(batch) * img
+    bslots = max(2 * int(in_flight), min(4 * int(in_flight), (3 << 29) // bbytes))
+    slots = int(slots) or 2 * int(batch) * int(labels)
+    ring = mmap.mmap(-1, bslots * bbytes + slots * img)      # anonymous + shared: inherited by the forked workers
+    _WRITERS = {"ring": ring, "img_bytes": img, "batch_bytes": bbytes, "bslots": bslots, "slots": slots, "slot0": bslots * bbytes, "n": n,
+                "batch": int(batch), "labels": int(labels)}
+    _WRITERS["pool"] = mp.get_context("fork").Pool(n)       # the workers read _WRITERS through the fork
+    return _WRITERS
+
+
+def stop_writer_processes():
+    global _WRITERS
+    if _WRITERS is not None:
+        _WRITERS["pool"].close()
+        _WRITERS["pool"].join()
+        _WRITERS["ring"].close()
+        _WRITERS = None
+
+
 class _Buffers:
     """what a slot needs for ONE batch shape: pinned + device input, the graph that reads it, the device outputs the graph writes, pinned images"""
     def __init__(self):
@@ -48,6 +93,7 @@ class _Slot:
         self.cur = None          # _Buffers of the batch in flight
         self.event = None
         self.paths = None        # image paths of the batch in flight (None = slot idle)
+        self.bslot = None        # writer processes: the batch slot of the shared ring this batch's images land in
         self.stream = None
 
 
@@ -64,6 +110,26 @@ class PipelinedRunner:
             s.stream = torch.cuda.Stream(self.dev)
         self.pool = ThreadPoolExecutor(max(1, int(getattr(opt, 'writers', 8))))
         self.pending = []
+        # writer processes, if test.py forked them (--writer_procs): free ring slots + what came back from the workers
+        self.procs = _WRITERS
+        if self.procs is not None:
+            import queue
+            import threading
+            p = self.procs
+            self.free = queue.Queue()                          # single-image slots (sequential-path batches)
+            for i in range(p["slots"]):
+                self.free.put(i)
+            self.bfree = queue.Queue()                         # batch slots (graph batches: the D2H copies land in them)
+            for i in range(p["bslots"]):
+                self.bfree.put(i)
+            self.bleft = [0] * p["bslots"]                     # images of a batch slot still with the writers
+            self.block = threading.Lock()
+            self.proc_errors = []
+            self.ring_t = torch.frombuffer(p["ring"], dtype=torch.uint8)
+            nbytes = p["bslots"] * p["batch_bytes"]
+            rc = torch.cuda.cudart().cudaHostRegister(self.ring_t.data_ptr(), nbytes, 0)
+            self.ring_pinned = int(rc) == 0 and self.ring_t[:nbytes].is_pinned()
+            self.stats_ring = {"batch_slots": p["bslots"], "registered_as_pinned": bool(self.ring_pinned)}
         self.labels = ['fake_A'] if opt.out_all else list(model.visual_names)
         self.stats = {"batches": 0, "images": 0, "graph_batches": 0, "sequential_batches": 0}
         # several forwards in flight want ONE serial chain of launches per forward (what bench.py replays): 2.26 against 2.38 ms per step with
@@ -133,18 +199,84 @@ class PipelinedRunner:
         if s.paths is None:
             return
         s.event.synchronize()
+        if self.procs is not None and s.bslot is not None:
+            # the images already sit in the slot's batch slot of the shared ring (the D2H copies landed there): the writers get (offset, shape, path), the batch slot
+            # returns to the free list when its last file is written
+            p, bs, B = self.procs, s.bslot, len(s.paths)
+            with self.block:
+                self.bleft[bs] = B * len(self.labels)
+            n = self.net.cfg.image_size
+            for li, lab in enumerate(self.labels):
+                for i, path in enumerate(s.paths):
+                    name = os.path.splitext(ntpath.basename(path))[0]
+                    off = bs * p["batch_bytes"] + (li * p["batch"] + i) * p["img_bytes"]
+                    p["pool"].apply_async(_save_png_from_ring, (off, (n, n, 3), os.path.join(self.image_dir, '%s_%s.png' % (name, lab)), bs),
+                                          callback=self._batch_image_done, error_callback=lambda e, bs=bs: self._batch_image_failed(e, bs))
+            s.paths = None
+            s.bslot = None
+            if self.proc_errors:
+                raise self.proc_errors[0]
+            return
         own = {lab: np.array(s.cur.host[lab].numpy()) for lab in self.labels}      # one copy per visual: the pinned buffers are reused as soon as this returns
         for i, path in enumerate(s.paths):
             name = os.path.splitext(ntpath.basename(path))[0]
             for lab in self.labels:
                 self.pending.append(self.pool.submit(_save_png, own[lab][i], os.path.join(self.image_dir, '%s_%s.png' % (name, lab))))
         s.paths = None
-        if len(self.pending) > 4096:
-            self._reap(keep=1024)
+        # the backlog is bounded by a few rounds of slots (it was 4096 futures = ~3 GB of image copies at 512 x 512: ADVICE r05), and finished futures are
+        # checked at every retire so that a writer's exception surfaces at once
+        bound = 8 * self.K * max(1, len(own[self.labels[0]])) * len(self.labels)
+        while self.pending and self.pending[0].done():
+            self.pending.pop(0).result()
+        if len(self.pending) > bound:
+            self._reap(keep=bound // 2)
+
+    def _batch_image_done(self, bs):
+        with self.block:
+            self.bleft[bs] -= 1
+            free = self.bleft[bs] == 0
+        if free:
+            self.bfree.put(bs)
+
+    def _batch_image_failed(self, e, bs):
+        self.proc_errors.append(e)
+        self._batch_image_done(bs)
+
+    def _host_views(self, bs, B):
+        """label -> (B, n, n, 3) uint8 tensor over batch slot `bs` of the shared ring"""
+        p, n = self.procs, self.net.cfg.image_size
+        out = {}
+        for li, lab in enumerate(self.labels):
+            o = bs * p["batch_bytes"] + li * p["batch"] * p["img_bytes"]
+            out[lab] = self.ring_t[o:o + B * p["img_bytes"]].view(B, n, n, 3)
+        return out
+
+    def _submit_proc(self, arr, path):
+        """one image of a sequential-path batch to the writer processes: copied into a free single-image slot (blocks while all are in use), then (offset, shape, path)"""
+        if self.proc_errors:
+            raise self.proc_errors[0]
+        slot = self.free.get()
+        p = self.procs
+        off = p["slot0"] + slot * p["img_bytes"]
+        np.frombuffer(p["ring"], dtype=np.uint8, count=arr.size, offset=off).reshape(arr.shape)[...] = arr
+
+        def fail(e, slot=slot):
+            self.proc_errors.append(e)
+            self.free.put(slot)
+        p["pool"].apply_async(_save_png_from_ring, (off, tuple(arr.shape), path, slot), callback=self.free.put, error_callback=fail)
 
     def _reap(self, keep=0):
         while len(self.pending) > keep:
             self.pending.pop(0).result()                      # re-raises a writer's exception here
+        if self.procs is not None and keep == 0:
+            for q, count in ((self.free, self.procs["slots"]), (self.bfree, self.procs["bslots"])):
+                held = []
+                while len(held) < count:                        # every slot back in its free list = every file written
+                    held.append(q.get())
+                for i in held:
+                    q.put(i)
+            if self.proc_errors:
+                raise self.proc_errors[0]
 
     def drain(self):
         for s in self.slots:
@@ -170,7 +302,10 @@ class PipelinedRunner:
             name = os.path.splitext(ntpath.basename(path))[0]
             for lab in self.labels:
                 arr = util.tensor2im(visuals[lab][i, :, :, :])
-                self.pending.append(self.pool.submit(_save_png, arr, os.path.join(self.image_dir, '%s_%s.png' % (name, lab))))
+                if self.procs is not None and arr.nbytes <= self.procs["img_bytes"]:
+                    self._submit_proc(np.ascontiguousarray(arr), os.path.join(self.image_dir, '%s_%s.png' % (name, lab)))
+                else:
+                    self.pending.append(self.pool.submit(_save_png, arr, os.path.join(self.image_dir, '%s_%s.png' % (name, lab))))
         self.stats["sequential_batches"] += 1
         tm["drain"] += t1 - t0; tm["set_input"] += t2 - t1; tm["test"] += t3 - t2; tm["images"] += time.perf_counter() - t3
         if self._dtype_built is not None and self.net.compute_dtype != self._dtype_built:
@@ -215,8 +350,12 @@ class PipelinedRunner:
                 with torch.cuda.stream(s.stream):
                     b.x_dev.copy_(src, non_blocking=True)
                     self.net.replay(b.gid)
+                    host = b.host
+                    if self.procs is not None and B <= self.procs["batch"]:
+                        s.bslot = self.bfree.get()              # blocks while the writers hold every batch slot: the backlog is the ring
+                        host = self._host_views(s.bslot, B)
                     for lab in self.labels:
-                        b.host[lab].copy_(self._visual_u8(s, lab, B), non_blocking=True)
+                        host[lab].copy_(self._visual_u8(s, lab, B), non_blocking=True)
                     s.event.record(s.stream)
                 s.paths = paths
                 self.model.note_unchecked(paths)
@@ -234,10 +373,16 @@ class PipelinedRunner:
         for k in tm:
             tm[k] = round(tm[k], 3)
         self.stats["seconds"] = time.perf_counter() - t0
+        if self.procs is not None:
+            self.stats["writer_ring"] = self.stats_ring
         return self.stats
 
     def close(self):
         self._reap()
         self.pool.shutdown(wait=True)
+        if self.procs is not None and self.ring_pinned:
+            torch.cuda.synchronize()
+            torch.cuda.cudart().cudaHostUnregister(self.ring_t.data_ptr())
+            self.ring_pinned = False
         self.net.replica = 0
         self.net.serial_plan = self._plan_was

@@ -25,8 +25,17 @@ def tensor2im(input_image, imtype=np.uint8):
     return ((np.transpose(a, (1, 2, 0)) + 1) / 2.0 * 255.0).astype(imtype)
 
 
+# zlib level of the PNG writer (`--png_compress_level`, an extension: the reference writes PIL's default, 6).  The default leaves every file byte for byte as the
+# reference's util.save_image (util/util.py:47-49 there) writes it; level 1 encodes ~3x faster into ~25 % larger files of the SAME pixels (file -> file inference on a
+# host whose CPU share is small is bound by this encode: profiles/r06_cli_throughput.json).  None = PIL's default.
+PNG_COMPRESS_LEVEL = None
+
+
 def save_image(image_numpy, image_path):
-    Image.fromarray(image_numpy).save(image_path)
+    if PNG_COMPRESS_LEVEL is None:
+        Image.fromarray(image_numpy).save(image_path)
+    else:
+        Image.fromarray(image_numpy).save(image_path, compress_level=int(PNG_COMPRESS_LEVEL))
 
 
 def mkdirs(paths):

@@ -111,6 +111,11 @@ int cfen_net_set_input_u8(cfen_net* net, int enabled);
  * the xr / xs / xd arguments (16-byte aligned).  CFEN_ERR_ARG when the tails do not run on the Toeplitz 7x7 kernel (fp32 nets, image edges that are
  * not multiples of 64): take fp32 outputs and cfen_tensor2im_u8 there.                                                                          */
 int cfen_net_set_output_u8(cfen_net* net, int enabled);
+/* enabled: the forward writes xr / xs / xd as fp16 NCHW (same shapes and [xr | xs | xd] order as the fp32 outputs, 2 bytes per element) from the fused tail launch --
+ * the wire type of the sharded run's output all-gather (reference analogue: nn.DataParallel's gather, networks_iid_hlgvit_crs_gd4_cfs_v3.py:77-83), without a
+ * conversion pass.  Values = the fp32 outputs rounded to nearest even.  CFEN_ERR_ARG where the tails do not run on the fused kernel (fp32 nets, image edges that
+ * are not multiples of 64); cfen_net_forward then fails if the plan falls back to the separate tail launches ("net.tail_fused" != 2, "net.keep_stages").        */
+int cfen_net_set_output_f16(cfen_net* net, int enabled);
 /* names still missing, written as a ';'-separated list into buf; returns the count                */
 int cfen_net_missing_params(const cfen_net* net, char* buf, size_t buflen);
 /* x: (B,3,H,W) fp32 NCHW in [-1,1];  xr: (B,3,H,W), xs: (B,1,H,W), xd: (B,3,H,W) fp32 NCHW        */

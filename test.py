@@ -10,7 +10,9 @@ every image of <dataroot>/hazy and writes results/<name>/<phase>_<which_epoch>/i
 import logging
 import os
 import sys
+import time
 
+_T_START = time.perf_counter()
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 
 import torch
@@ -39,6 +41,8 @@ def _rerun_in_fp32(opt, model, image_dir, paths):
 
 
 if __name__ == '__main__':
+    _startup = {"imports": round(time.perf_counter() - _T_START, 2)}      # where the seconds in front of the first batch go (printed below; tools/cli_throughput.py)
+    _t = time.perf_counter()
     opt = TestOptions().parse()   # --in_flight > 1 also exports GPU_MAX_HW_QUEUES=8 there, before the first HIP call
     opt.serial_batches = True   # no shuffle
     opt.no_flip = True          # no flip
@@ -51,9 +55,19 @@ if __name__ == '__main__':
         dist.init_process_group('gloo', rank=opt.dist_rank, world_size=opt.dist_world)
     data_loader = CreateDataLoader(opt)
     data_loader.start_workers()          # fork the --nThreads decode workers BEFORE the process holds its GPU working set (data/__init__.py)
+    if opt.in_flight > 1 and getattr(opt, 'writer_procs', 0) > 0:
+        # ... and the PNG writer processes (pipeline.start_writer_processes: a shared-memory ring of image slots made before the fork)
+        from cfen_vit_dehazing_amd.config import VARIANTS, FULL_RES_VARIANTS
+        from cfen_vit_dehazing_amd import pipeline as _pipeline
+        _edge = opt.loadSize if VARIANTS.get(opt.model_G, 'v3') in FULL_RES_VARIANTS else 2 * opt.loadSize
+        _pipeline.start_writer_processes(opt.writer_procs, _edge, batch=opt.batchSize, labels=1 if opt.out_all else 4, in_flight=opt.in_flight)
     dataset = data_loader.load_data()
+    _startup["options_loader_and_forks"] = round(time.perf_counter() - _t, 2)
+    _t = time.perf_counter()
     model = create_model(opt)
     model.setup(opt)
+    _startup["create_model_and_checkpoint_load"] = round(time.perf_counter() - _t, 2)
+    _t = time.perf_counter()
     web_dir = os.path.join(opt.results_dir, opt.name, '%s_%s' % (opt.phase, opt.which_epoch))
     webpage = html.HTML(web_dir, 'Experiment = %s, Phase = %s, Epoch = %s' % (opt.name, opt.phase, opt.which_epoch))
     n_images = min(len(data_loader), len(data_loader.dataset))
@@ -74,14 +88,19 @@ if __name__ == '__main__':
             sizes = [min(opt.batchSize, n_images)] + ([n_images % opt.batchSize] if n_images > opt.batchSize and n_images % opt.batchSize and n_batches * opt.batchSize >= n_images else [])
             u8 = getattr(opt, 'u8_input', False)
             runner.warm_up([(b, n, n, 3) if u8 else (b, 3, n, n) for b in sizes], torch.uint8 if u8 else torch.float32)
+        _startup["weight_packing_plans_graphs_and_warm_up"] = round(time.perf_counter() - _t, 2)
+        print('startup seconds %s' % _startup)
         stats = runner.run(dataset, opt.how_many)
         runner.close()
         print('pipelined driver: %d images in %.2f s = %.1f images/s file to file (%d batches replayed from graphs, %d through the sequential path)'
               % (stats['images'], stats['seconds'], stats['images'] / max(stats['seconds'], 1e-9), stats['graph_batches'], stats['sequential_batches']))
         print('pipelined driver: main-thread seconds %s' % stats['main_thread_seconds'])
+        if 'writer_ring' in stats:
+            print('pipelined driver: writer processes read from %s' % stats['writer_ring'])
         print('pipelined driver: sequential-path seconds %s' % stats.get('sequential_seconds'))
     else:
-        import time
+        _startup["weight_packing_plans_and_warm_up"] = round(time.perf_counter() - _t, 2)
+        print('startup seconds %s' % _startup)
         t_loop, n_img = time.perf_counter(), 0
         for i, data in enumerate(dataset):
             if i >= opt.how_many:
@@ -103,6 +122,8 @@ if __name__ == '__main__':
     if model.redo_paths:
         print('redoing %d images in fp32 (a --precision half check failed after they were written)' % len(model.redo_paths))
         _rerun_in_fp32(opt, model, webpage.get_image_dir(), model.redo_paths)
+    if opt.in_flight > 1 and getattr(opt, 'writer_procs', 0) > 0:
+        _pipeline.stop_writer_processes()
     if opt.dist_world > 1:
         import torch.distributed as dist
         dist.barrier()

@@ -817,6 +817,39 @@ def test_reference_init_weights_fp16_psnr_ssim_full512():
     assert rows[0][0] <= REFINIT_FP16_STAGE_REL_BAR, "stage %s: fp16 differs from the reference by %.2e of the stage's mean |value|" % (rows[0][1], rows[0][0])
 
 
+def test_fp16_outputs_written_by_the_fused_tail_equal_the_rounded_float_outputs():
+    """dec_ipt.output_f16 / cfen_net_set_output_f16 (round 6): the sharded run's wire type straight from the fused tail launch -- bit for bit the fp32 outputs rounded to
+    nearest even, eager and replayed; refused where the fused tail does not run (fp32 nets, small images)"""
+    cfg = NetConfig(24, 4, patch_size=32, load_size=256)
+    net = make_net(cfg, "fp16")
+    x = synthetic_input(2, cfg).to("cuda:0")
+    want = [o.half() for o in net(x)]
+    net.output_f16 = True
+    got = net(x)
+    assert all(g.dtype == torch.float16 and torch.equal(g, w) for g, w in zip(got, want))
+    slab = torch.zeros(7 * 2 * 512 * 512, dtype=torch.float16, device="cuda:0")
+    gid, outs = net.capture(x, out=slab)
+    slab.zero_()
+    net.replay(gid)
+    torch.cuda.synchronize()
+    assert all(torch.equal(g, w) for g, w in zip(outs, want))
+    with pytest.raises(ValueError):
+        net(x, out=torch.zeros(7 * 2 * 512 * 512, dtype=torch.float32, device="cuda:0"))
+    net32 = make_net(cfg, "fp32")
+    net32.output_f16 = True
+    with pytest.raises(Exception):
+        net32(x)
+    # ... and where the plan falls back to the separate tail launches
+    net2 = make_net(cfg, "fp16")
+    net2.output_f16 = True
+    ops.tune("net.tail_fused", 1)
+    try:
+        with pytest.raises(Exception):
+            net2(x)
+    finally:
+        ops.tune("net.tail_fused", TAIL_FUSED_DEFAULT)
+
+
 def test_uint8_input_equals_host_normalised_input():
     """--u8_input: (B,H,W,3) uint8 straight into the plan == ToTensor + Normalize(0.5, 0.5) on the host (data/base_dataset.py:44-46)"""
     cfg = NetConfig(24, 4, patch_size=8, load_size=64)
@@ -993,6 +1026,11 @@ def test_pipelined_cli_writes_the_same_pngs(tmp_path, load_size, nimg, flags):
     assert sorted(os.listdir(seq_dir)) == want and sorted(os.listdir(pipe_dir)) == want
     for f in want:
         assert open(seq_dir / f, "rb").read() == open(pipe_dir / f, "rb").read(), f
+    # round 6: the same with PNG encode in writer PROCESSES (forked before the model exists, images through a shared-memory ring of slots)
+    proc_log, proc_dir = _run_cli(tmp_path, name, load_size, "res_proc", flags + ["--in_flight", "3", "--writer_procs", "3"])
+    assert "pipelined driver" in proc_log and sorted(os.listdir(proc_dir)) == want
+    for f in want:
+        assert open(seq_dir / f, "rb").read() == open(proc_dir / f, "rb").read(), f
     if "half" in flags:
         assert "precision: half" in open(tmp_path / "res_pipe" / name / "test_32" / "precision.txt").read()
         assert "checked_batches: 0:" in open(tmp_path / "res_pipe" / name / "test_32" / "precision.txt").read()

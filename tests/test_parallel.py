@@ -146,14 +146,14 @@ def test_two_rank_shard_and_allgather_equals_single_process():
     assert q.get(timeout=5) <= 1e-5
 
 
-def _rotation_worker(rank, world, port, q):
+def _rotation_worker(rank, world, port, q, slab_dtype=torch.float32):
     """bench.py's step loop of the sharded run on CPU tensors: `nslab` = 3 output slabs rotate (three forwards in flight per rank) and the gatherer has
     one slot per slab (slot = step % nslab), so the fence in front of step i is the gather of step i - nslab, the last reader of that slab"""
     sys.path.insert(0, ROOT)
     os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     B, n, nslab, steps = 2, 8, 3, 7
-    slabs = [torch.empty(7 * B * n * n) for _ in range(nslab)]
+    slabs = [torch.empty(7 * B * n * n, dtype=slab_dtype) for _ in range(nslab)]      # fp16 slabs: what dec_ipt.output_f16 writes -- gathered as they are (round 6)
     g = OutputGatherer(world, slabs[0].numel(), "cpu", torch.float16, slots=nslab)
     assert len(g.bufs) == len(g.stage) == len(g.work) == nslab
     for i in range(steps):
@@ -161,6 +161,7 @@ def _rotation_worker(rank, world, port, q):
         g.before_write(i % nslab)
         s.copy_(torch.arange(s.numel(), dtype=torch.float32) % 31 / 64 + rank / 4 + i / 128)      # what step i of this rank "computed" (fp16-exact values)
         g.launch(s, i % nslab)
+        assert g.direct[i % nslab] == (slab_dtype == torch.float16)                                # the collective reads the slab itself only when it has the wire type
     g.wait_all()
     ok = True
     for back in range(nslab):          # the last nslab steps each still sit in their own slot
@@ -174,11 +175,12 @@ def _rotation_worker(rank, world, port, q):
     dist.destroy_process_group()
 
 
-def test_slab_rotation_of_the_sharded_bench_loop_gathers_the_last_step():
+@pytest.mark.parametrize("slab_dtype", [torch.float32, torch.float16])
+def test_slab_rotation_of_the_sharded_bench_loop_gathers_the_last_step(slab_dtype):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    port = 31500 + os.getpid() % 2000
-    procs = [ctx.Process(target=_rotation_worker, args=(r, 2, port, q)) for r in range(2)]
+    port = 31500 + os.getpid() % 2000 + (7 if slab_dtype == torch.float16 else 0)
+    procs = [ctx.Process(target=_rotation_worker, args=(r, 2, port, q, slab_dtype)) for r in range(2)]
     for p in procs:
         p.start()
     for p in procs:

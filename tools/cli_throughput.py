@@ -7,8 +7,9 @@ rates that bound it measured on the same box:
 Writes synthetic 512 x 512 hazy PNGs + a seeded checkpoint into a scratch directory, then times
   decode_only      the DataLoader alone (PNG decode in --nThreads workers), images/s
   encode_only      PNG encode + write of 512 x 512 RGB images in W writer threads, images/s
-  sequential       python test.py --batchSize 8 (one batch at a time, encode on the main thread): the reference's loop
+  sequential       python test.py --batchSize 8 (one batch at a time, encode on the main thread): the reference's loop; also with --nThreads T (decode in workers)
   pipelined        python test.py --batchSize 8 --in_flight 4 --nThreads T --writers W
+  pipelined_procs  ... --nThreads T2 --writer_procs P (round 6: PNG encode in processes forked before the model exists, images through a shared-memory ring)
 both CLI runs with --precision half --u8_input --out_all (uint8 in, tensor2im bytes out of the tails' last launch), and checks that the two
 result directories hold byte-identical files.  The GPU-only rate of the same batches is bench.py's headline; this tool says how much of it a
 file-to-file run sees and which stage is the bound.  Prints / writes ONE JSON object."""
@@ -76,7 +77,13 @@ def main():
         # ---- the two CLI runs -------------------------------------------------------------------------------------------------------------------
         env = dict(os.environ)
         env.pop("GPU_MAX_HW_QUEUES", None)
-        for tag, extra in (("sequential", ["--nThreads", "0"]), ("pipelined", ["--in_flight", "4", "--nThreads", str(threads), "--writers", str(writers)])):
+        procs = int(os.environ.get("CLI_WRITER_PROCS", min(64, max(4, ncpu // 4))))
+        threads2 = int(os.environ.get("CLI_THREADS2", min(48, max(2, ncpu // 4))))
+        res["writer_processes"], res["decode_workers_with_writer_processes"] = procs, threads2
+        for tag, extra in (("sequential", ["--nThreads", "0"]), ("sequential_decode_in_workers", ["--nThreads", str(threads)]),
+                           ("pipelined", ["--in_flight", "4", "--nThreads", str(threads), "--writers", str(writers)]),
+                           ("pipelined_procs", ["--in_flight", "4", "--nThreads", str(threads2), "--writer_procs", str(procs)]),
+                           ("pipelined_procs_png_level_1", ["--in_flight", "4", "--nThreads", str(threads2), "--writer_procs", str(procs), "--png_compress_level", "1"])):
             t0 = time.perf_counter()
             p = subprocess.run([sys.executable, os.path.join(ROOT, "test.py")] + common + ["--results_dir", os.path.join(tmp, "res_" + tag)] + extra,
                                cwd=tmp, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
@@ -86,14 +93,30 @@ def main():
                 continue
             m = re.search(r"(\d+) images in ([0-9.]+) s = ([0-9.]+) images/s file to file", p.stdout)
             mt = re.search(r"main-thread seconds (\{.*\})", p.stdout)
+            su = re.search(r"startup seconds (\{.*\})", p.stdout)
             res[tag] = {"images_per_s_file_to_file": float(m.group(3)) if m else None, "loop_seconds": float(m.group(2)) if m else None,
                         "main_thread_seconds": json.loads(mt.group(1).replace("'", '"')) if mt else None,
+                        "startup_seconds": json.loads(su.group(1).replace("'", '"')) if su else None,
                         "process_wall_seconds_incl_checkpoint_load": round(wall, 2), "flags": " ".join(extra)}
-        a, b = (os.path.join(tmp, "res_" + t, name, "test_32", "images") for t in ("sequential", "pipelined"))
-        if os.path.isdir(a) and os.path.isdir(b):
-            fa, fb = sorted(os.listdir(a)), sorted(os.listdir(b))
-            res["files_written"] = len(fb)
-            res["byte_identical"] = fa == fb and all(open(os.path.join(a, f), "rb").read() == open(os.path.join(b, f), "rb").read() for f in fa)
+        a = os.path.join(tmp, "res_sequential", name, "test_32", "images")
+        lvl1 = os.path.join(tmp, "res_pipelined_procs_png_level_1", name, "test_32", "images")
+        if os.path.isdir(a) and os.path.isdir(lvl1):      # other bytes, the same pixels
+            fa = sorted(os.listdir(a))
+            res["png_level_1_same_pixels"] = sorted(os.listdir(lvl1)) == fa and all(
+                np.array_equal(np.asarray(Image.open(os.path.join(a, f))), np.asarray(Image.open(os.path.join(lvl1, f)))) for f in fa[::16])
+            res["png_level_1_bytes_vs_default"] = round(sum(os.path.getsize(os.path.join(lvl1, f)) for f in fa) / max(1, sum(os.path.getsize(os.path.join(a, f)) for f in fa)), 3)
+        for t in ("pipelined", "pipelined_procs", "sequential_decode_in_workers"):
+            b = os.path.join(tmp, "res_" + t, name, "test_32", "images")
+            if os.path.isdir(a) and os.path.isdir(b):
+                fa, fb = sorted(os.listdir(a)), sorted(os.listdir(b))
+                res["files_written"] = len(fb)
+                res["byte_identical_" + t] = fa == fb and all(open(os.path.join(a, f), "rb").read() == open(os.path.join(b, f), "rb").read() for f in fa)
+        res["byte_identical"] = all(v for k, v in res.items() if k.startswith("byte_identical_"))
+        try:
+            res["cpu_quota"] = open("/sys/fs/cgroup/cpu.max").read().strip()
+        except OSError:
+            res["cpu_quota"] = None
+        res["usable_cpus_sched_getaffinity"] = len(os.sched_getaffinity(0))
         pipe = res.get("pipelined", {}).get("images_per_s_file_to_file")
         if pipe:
             res["bound"] = ("I/O bound, on the host: PNG encode (%.0f images/s on %d writer threads) and decode (%.0f images/s on %d workers) bound the file-to-file rate "
