@@ -31,15 +31,17 @@ struct DcnArgs {
 constexpr int D_PIX = 64, D_CO = 128;
 
 template <typename T>
-CFEN_DEV float dcn_bilinear(const T* im, int H, int W, float h, float w) {   // .cu:83-114
-  int h_low = (int)floorf(h), w_low = (int)floorf(w);
-  int h_high = h_low + 1, w_high = w_low + 1;
-  float lh = h - h_low, lw = w - w_low, hh = 1.f - lh, hw = 1.f - lw;
-  float v1 = (h_low >= 0 && w_low >= 0) ? (float)im[h_low * W + w_low] : 0.f;
-  float v2 = (h_low >= 0 && w_high <= W - 1) ? (float)im[h_low * W + w_high] : 0.f;
-  float v3 = (h_high <= H - 1 && w_low >= 0) ? (float)im[h_high * W + w_low] : 0.f;
-  float v4 = (h_high <= H - 1 && w_high <= W - 1) ? (float)im[h_high * W + w_high] : 0.f;
-  return hh * hw * v1 + hh * lw * v2 + lh * hw * v3 + lh * lw * v4;
+CFEN_DEV float dcn_bilinear(const T* im, int H, int W, float h, float w) {   // the sampling rule of .cu:83-114, per axis as in k_dcn_lean's dcn_axis
+  // a sample at (h, w) blends the four pixels around it; a neighbour outside the map contributes zero (the caller has already rejected h <= -1, h >= H, w <= -1, w >= W)
+  const int y0 = (int)floorf(h), x0 = (int)floorf(w);
+  const float fy = h - (float)y0, fx = w - (float)x0;
+  const bool top = y0 >= 0, bottom = y0 + 1 <= H - 1, left = x0 >= 0, right = x0 + 1 <= W - 1;
+  const T* row0 = im + (long long)y0 * W;
+  const T* row1 = row0 + W;
+  const float a00 = top && left ? (float)row0[x0] : 0.f, a01 = top && right ? (float)row0[x0 + 1] : 0.f;
+  const float a10 = bottom && left ? (float)row1[x0] : 0.f, a11 = bottom && right ? (float)row1[x0 + 1] : 0.f;
+  const float wy0 = 1.f - fy, wx0 = 1.f - fx;
+  return wy0 * wx0 * a00 + wy0 * fx * a01 + fy * wx0 * a10 + fy * fx * a11;       // (same products and order of additions as before: bit for bit)
 }
 
 template <typename T>
