@@ -248,11 +248,16 @@ def main():
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", device_id=dev)
-    elif args.force_gather:
+    pg_late = bool(os.environ.get("CFEN_BENCH_PG_LATE"))     # what-if probe: the communicator (and the stream torch gives it) created AFTER the lanes and their graphs
+
+    def init_forced_pg():
         import tempfile
-        import torch.distributed as forced_pg            # a file store: no port to race for
+        import torch.distributed as fpg                  # a file store: no port to race for
         store_dir = tempfile.mkdtemp(prefix="cfen_bench_store_")
-        forced_pg.init_process_group("nccl", store=forced_pg.FileStore(os.path.join(store_dir, "store"), 1), rank=0, world_size=1, device_id=dev)
+        fpg.init_process_group("nccl", store=fpg.FileStore(os.path.join(store_dir, "store"), 1), rank=0, world_size=1, device_id=dev)
+        return fpg
+    if world == 1 and args.force_gather and not pg_late:
+        forced_pg = init_forced_pg()
 
     from cfen_vit_dehazing_amd.config import NetConfig
     from cfen_vit_dehazing_amd.hipnet import dec_ipt
@@ -274,7 +279,9 @@ def main():
     wire_f16 = (world > 1 or args.force_gather) and gdt == "fp16" and args.dtype == "fp16" and n % 64 == 0 and args.variant == "v3" and not os.environ.get("CFEN_BENCH_FP32_SLABS")
     net.output_f16 = wire_f16
     slabs = [torch.empty(7 * B * n * n, dtype=torch.float16 if wire_f16 else torch.float32, device=dev) for _ in range(nslab)]
-    gather = OutputGatherer(world, slabs[0].numel(), dev, torch.float16 if gdt == "fp16" else torch.float32, slots=nslab) if (world > 1 or args.force_gather) else None
+    def make_gather():
+        return OutputGatherer(world, slabs[0].numel(), dev, torch.float16 if gdt == "fp16" else torch.float32, slots=nslab)
+    gather = make_gather() if (world > 1 or (args.force_gather and not pg_late)) else None
 
     net(x, out=slabs[0])                       # packs weights, builds the plan
     torch.cuda.synchronize()
@@ -299,6 +306,9 @@ def main():
         net.replica = 0
         torch.cuda.synchronize()
 
+    if world == 1 and args.force_gather and pg_late:
+        forced_pg = init_forced_pg()
+        gather = make_gather()
     fake_comm = [int(os.environ.get("CFEN_BENCH_FAKE_COMM_CYCLES", "0")), None]
     if fake_comm[0]:
         fake_comm[1] = torch.cuda.Stream(dev)
@@ -335,6 +345,36 @@ def main():
         if dist is not None:
             dist.barrier()
         torch.cuda.synchronize()
+
+    lane_search = None
+    if gather is not None and lanes is not None and graphs is not None and not os.environ.get("CFEN_BENCH_NO_LANE_SEARCH"):
+        # WHICH streams the lanes are matters once torch's collective stream is busy beside them: the HIP runtime deals a process's streams onto the hardware queues in an
+        # order the caller does not control, and a lane that shares a queue with the collective stream runs one behind the other (measured on one MI355X, world-1 RCCL,
+        # 3 lanes: 2.59 ms per step as created, 4.04 / 2.70 / 2.73 / 2.07 with 1 / 2 / 3 / 5 unused streams created first; 2.08 without the gather:
+        # profiles/r06_gather_lane_placement.txt).  A hipGraph replays on any stream, so the harness TRIES the placements: candidate streams c0 .. c(nfl+12), the lanes are
+        # c[s : s + nfl] for the shift s with the shortest 12-step region (each rank decides for itself; every rank runs the same number of steps and collectives).
+        cands = list(lanes) + [torch.cuda.Stream(dev) for _ in range(int(os.environ.get('CFEN_BENCH_LANE_CANDIDATES', '13')))]
+        for cs in cands:
+            with torch.cuda.stream(cs):
+                torch.zeros(16, device=dev).add_(1)
+        torch.cuda.synchronize()
+        trial = []
+        for sft in range(len(cands) - nfl + 1):
+            lanes[:] = cands[sft:sft + nfl]
+            for i in range(nslab):
+                step(i)
+            gather.wait_all()
+            barrier()
+            t0 = time.perf_counter()
+            for i in range(12):
+                step(i)
+            gather.wait_all()
+            torch.cuda.synchronize()
+            trial.append(round((time.perf_counter() - t0) / 12 * 1e3, 3))
+            barrier()
+        best = min(range(len(trial)), key=lambda k: trial[k])
+        lanes[:] = cands[best:best + nfl]
+        lane_search = {"ms_per_step_by_shift": trial, "chosen_shift": best}
 
     for i in range(args.warmup):
         step(i)
@@ -415,6 +455,8 @@ def main():
                   "timing_method": "median of the repetitions; a fresh process of bench.py --brief", "forwards_in_flight": nfl, "timed_seconds": round(sum(reps), 3),
                   "gflop_per_image": round(flops_img / 1e9, 2), "whole_forward_tflops": round(ips * flops_img / 1e12, 2),
                   "whole_forward_frac": round(ips * flops_img / 1e12 / MFMA_PEAK_TFLOPS[args.dtype], 5)}
+        if lane_search is not None:
+            result["lane_search"] = lane_search
         if gather is not None:
             last = (args.steps - 1) % nslab
             result["gathered_equals_slab"] = bool(torch.equal(gather.bufs[last].reshape(-1)[:slabs[last].numel()], slabs[last].to(gather.bufs[last].dtype)))
@@ -477,7 +519,7 @@ def main():
             "config": {"workload": "batch=%d/GPU %dx%d n_feats=24 hidden_dim_ratio=%d %s%s, weights random-init (seeded generator)"
                                    % (B, n, n, args.hidden_dim_ratio, args.dtype, "" if args.variant == "v3" else " generator variant " + args.variant),
                        "global_batch": world * B, "parallelism": "dp%d" % world, "graph": graphs is not None, "forwards_in_flight": nfl, "lanes_per_forward": 1 if net.serial_plan else 2, "hw_queues": int(os.environ.get("GPU_MAX_HW_QUEUES", "4")),
-                       "gather_dtype": (gdt if world > 1 else None),
+                       "gather_dtype": (gdt if world > 1 else None), "lane_search": lane_search,
                        "gflop_per_image": round(flops_img / 1e9, 2)},
             "roofline": {"bound": bound, "kernel": dom, "achieved": ach, "peak": rpeak, "unit": runit, "frac": rfrac,
                          "traffic": None,

@@ -847,11 +847,10 @@ int cfen_mlp3_impl_g(int dtype, int ng, const Mlp3Args* ap, hipStream_t s) {
   // 167 -> 156 us on 192 workgroups, 158 -> 152 on 16 (same box, tools/dbg_mlp3_stamps.py; profiles/r06_mlp3_d384_variants.txt), bit for bit the round-5 results
   if (ap[0].D == 384) return launch_mlp3<24, 2, 3, 1536, 0, 1, 4, 4, 5, 0, 1>(ng, ap, s);
   if (cfen_tune_mlp3_tm192() == 22) return launch_mlp3<12, 2, 3, 768, 0, 2>(ng, ap, s);   // two 78 KB workgroups a CU, three-slot ring (round 5 A/B)
+  if (cfen_tune_mlp3_tm192() == 25) return launch_mlp3<12, 2, 3, 768, 0, 2, 4, 4, 5, 0, 1>(ng, ap, s);   // round-6 A/Bs: the D = 384 kernel's refill placement (thirds) + early repack + 4 reads ahead
+  if (cfen_tune_mlp3_tm192() == 26) return launch_mlp3<12, 2, 3, 768, 0, 2, 4, 0, 5, 0, 1>(ng, ap, s);   // ... with 6 reads ahead
+  if (cfen_tune_mlp3_tm192() == 27) return launch_mlp3<12, 2, 3, 768, 0, 2, 4, 0, 0, 0, 1>(ng, ap, s);   // ... early repack only
   if (cfen_tune_mlp3_tm192() == 28) return launch_mlp3<12, 2, 3, 768, 0, 2, 8>(ng, ap, s);        // ONE 8-wave workgroup a CU (two waves per SIMD) sharing one three-slot ring: 256 tokens per weight byte streamed
-  if (cfen_tune_mlp3_tm192() == 29) return launch_mlp3<12, 2, 6, 768, 0, 2, 8>(ng, ap, s);        // ... on six slots
-  if (cfen_tune_mlp3_tm192() == 222) return launch_mlp3<12, 2, 3, 768, 0, 2, 4, 3>(ng, ap, s);    // ... with 3 / 10 / 12 fragment reads in flight instead of 6
-  if (cfen_tune_mlp3_tm192() == 122) return launch_mlp3<12, 2, 3, 768, 0, 2, 4, 10>(ng, ap, s);
-  if (cfen_tune_mlp3_tm192() == 322) return launch_mlp3<12, 2, 3, 768, 0, 2, 4, 12>(ng, ap, s);
   if (cfen_tune_mlp3_tm192() == 24) return launch_mlp3<12, 2, 4, 768, 0, 2>(ng, ap, s);   // one 102 KB workgroup a CU at 256 registers, four slots
   if (cfen_tune_mlp3_tm192() == 3) return launch_mlp3<12, 3, 6, 768>(ng, ap, s);
   if (cfen_tune_mlp3_tm192() == 2) return launch_mlp3<12, 2, 6, 768>(ng, ap, s);

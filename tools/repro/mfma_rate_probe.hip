@@ -129,7 +129,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
   }
 }
 
-int main() {
+int main(int argc, char** argv) {
+  const int grid_arg = argc > 1 ? atoi(argv[1]) : 1;      // workgroups (one per CU): 1 = the issue-rate measurement; 256 = every CU busy (PMC calibration on a full chip)
   half8* in;
   float* out;
   unsigned long long* cyc;
@@ -149,7 +150,7 @@ int main() {
   hipEvent_t a, b;
   (void)hipEventCreate(&a);
   (void)hipEventCreate(&b);
-  for (int grid : {1}) {
+  for (int grid : {grid_arg}) {
     for (int k = 0; k < 11; ++k) {
       float ms = 0;
       for (int rep = 0; rep < 3; ++rep) {
