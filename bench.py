@@ -347,7 +347,7 @@ def main():
         torch.cuda.synchronize()
 
     lane_search = None
-    if gather is not None and lanes is not None and graphs is not None and not os.environ.get("CFEN_BENCH_NO_LANE_SEARCH"):
+    if (gather is not None or os.environ.get("CFEN_BENCH_LANE_SEARCH")) and lanes is not None and graphs is not None and not os.environ.get("CFEN_BENCH_NO_LANE_SEARCH"):
         # WHICH streams the lanes are matters once torch's collective stream is busy beside them: the HIP runtime deals a process's streams onto the hardware queues in an
         # order the caller does not control, and a lane that shares a queue with the collective stream runs one behind the other (measured on one MI355X, world-1 RCCL,
         # 3 lanes: 2.59 ms per step as created, 4.04 / 2.70 / 2.73 / 2.07 with 1 / 2 / 3 / 5 unused streams created first; 2.08 without the gather:
@@ -363,12 +363,14 @@ def main():
             lanes[:] = cands[sft:sft + nfl]
             for i in range(nslab):
                 step(i)
-            gather.wait_all()
+            if gather is not None:
+                gather.wait_all()
             barrier()
             t0 = time.perf_counter()
             for i in range(12):
                 step(i)
-            gather.wait_all()
+            if gather is not None:
+                gather.wait_all()
             torch.cuda.synchronize()
             trial.append(round((time.perf_counter() - t0) / 12 * 1e3, 3))
             barrier()

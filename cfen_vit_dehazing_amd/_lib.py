@@ -118,6 +118,8 @@ SIGNATURES = {
     "cfen_deform_conv_columns_bytes": (c_size_t, [_I] * 9),
     "cfen_deform_conv_forward": (_I, [_I, _P, _P, _P, _P] + [_I] * 16 + [_P, c_size_t, _P]),
     "cfen_modulated_deform_conv_forward": (_I, [_I, _P, _P, _P, _P, _P, _P] + [_I] * 16 + [_P, c_size_t, _P]),
+    "cfen_deform_conv_forward_nhwc": (_I, [_I, _P, _P, _P, _P] + [_I] * 16 + [_P, c_size_t, _P]),
+    "cfen_modulated_deform_conv_forward_nhwc": (_I, [_I, _P, _P, _P, _P, _P, _P] + [_I] * 16 + [_P, c_size_t, _P]),
     "cfen_deform_conv_backward_bytes": (c_size_t, [_I] * 10),
     "cfen_deform_conv_backward_set_lds": (_I, [_I]),
     "cfen_deform_conv_backward_input": (_I, [_I, _P, _P, _P, _P, _P, _P] + [_I] * 16 + [_P, c_size_t, _P]),

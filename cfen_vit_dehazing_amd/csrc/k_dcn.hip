@@ -26,6 +26,7 @@ struct DcnArgs {
   int B, C, H, W, Cout, kh, kw, sh, sw, ph, pw, dh, dw, group, dg, Ho, Wo;
   const void* imT;   // fast path: NHWC copy of the input  [B][H][W][C]            (k_dcn_prep, in the caller's `columns` scratch)
   const void* wT;    //            tap-major weights        [Cout][kh*kw][C/group]
+  int im_nhwc;       // round 6: `im` already IS [B][H][W][C] (a channels_last tensor's memory): the layout pre-pass only re-orders the weights
 };
 
 constexpr int D_PIX = 64, D_CO = 128;
@@ -800,7 +801,7 @@ int launch_dcn(int dtype, const DcnArgs& a, hipStream_t s) {
   CFEN_CHECK_ARG(grid.y <= 65535 && grid.z <= 65535, "deform_conv: batch / groups too large for one launch");
   if (a.imT && (dtype == 0 || dtype == 1)) {   // fast path: NHWC + tap-major copies in the caller's scratch
     const int lean_mode = !cfen_tune_dcn_tile() ? 0 : dtype == 1 ? dcn_lean_mode<half_t>(a) : dcn_lean_mode<float>(a);
-    const long long HW = (long long)a.H * a.W, nim = (long long)a.B * (a.C / (dtype == 1 ? 8 : 4)) * HW;
+    const long long HW = (long long)a.H * a.W, nim = a.im_nhwc ? 0 : (long long)a.B * (a.C / (dtype == 1 ? 8 : 4)) * HW;
     const long long nw = (long long)a.Cout * (a.C / a.group) * a.kh * a.kw;
     const unsigned pg = (unsigned)std::min<long long>((nim + nw + 255) / 256, 8192);
     if (dtype == 1) {
@@ -836,7 +837,7 @@ void dcn_use_scratch(int dtype, DcnArgs& a, void* columns, size_t columns_bytes)
   const size_t im_bytes = ((size_t)a.B * a.H * a.W * a.C * esz + 255) / 256 * 256;
   const size_t w_bytes = (size_t)a.Cout * (a.C / a.group) * a.kh * a.kw * esz;
   if (columns_bytes < im_bytes + w_bytes) return;
-  a.imT = columns;
+  a.imT = a.im_nhwc ? a.im : columns;
   a.wT = (unsigned char*)columns + im_bytes;
 }
 
@@ -860,13 +861,14 @@ size_t cfen_deform_conv_columns_bytes(int dtype, int B, int Cin, int H, int W, i
   return ((size_t)B * H * W * Cin * esz + 255) / 256 * 256 + (size_t)Cout * (Cin / group) * kH * kW * esz;
 }
 
-int cfen_deform_conv_forward(int dtype, const void* input, const void* weight, const void* offset, void* output, int B, int Cin, int H,
-                             int W, int Cout, int kW, int kH, int dW, int dH, int padW, int padH, int dilationW, int dilationH, int group,
-                             int deformable_group, int im2col_step, void* columns, size_t columns_bytes, void* stream) {
+static int dcn_forward_v1(int nhwc, int dtype, const void* input, const void* weight, const void* offset, void* output, int B, int Cin, int H,
+                          int W, int Cout, int kW, int kH, int dW, int dH, int padW, int padH, int dilationW, int dilationH, int group,
+                          int deformable_group, int im2col_step, void* columns, size_t columns_bytes, void* stream) {
   CFEN_CHECK_ARG(im2col_step > 0 && B % (im2col_step < B ? im2col_step : B) == 0, "im2col step must divide batchsize");
   DcnArgs a{input, offset, nullptr, weight, nullptr, output, B, Cin, H, W, Cout, kH, kW, dH, dW, padH, padW, dilationH, dilationW,
-            group, deformable_group, 0, 0, nullptr, nullptr};
+            group, deformable_group, 0, 0, nullptr, nullptr, nhwc};
   dcn_use_scratch(dtype, a, columns, columns_bytes);
+  CFEN_CHECK_ARG(!nhwc || a.imT, "deform_conv (NHWC input): needs the `columns` scratch and C / group a multiple of the 16-byte channel vector");
   if (dH > 0 && dW > 0) {
     a.Ho = (H + 2 * padH - (dilationH * (kH - 1) + 1)) / dH + 1;
     a.Wo = (W + 2 * padW - (dilationW * (kW - 1) + 1)) / dW + 1;
@@ -874,20 +876,48 @@ int cfen_deform_conv_forward(int dtype, const void* input, const void* weight, c
   return launch_dcn(dtype, a, (hipStream_t)stream);
 }
 
-int cfen_modulated_deform_conv_forward(int dtype, const void* input, const void* weight, const void* bias, const void* offset,
-                                       const void* mask, void* output, int B, int Cin, int H, int W, int Cout, int kernel_h, int kernel_w,
-                                       int stride_h, int stride_w, int pad_h, int pad_w, int dilation_h, int dilation_w, int group,
-                                       int deformable_group, int with_bias, void* columns, size_t columns_bytes, void* stream) {
+int cfen_deform_conv_forward(int dtype, const void* input, const void* weight, const void* offset, void* output, int B, int Cin, int H,
+                             int W, int Cout, int kW, int kH, int dW, int dH, int padW, int padH, int dilationW, int dilationH, int group,
+                             int deformable_group, int im2col_step, void* columns, size_t columns_bytes, void* stream) {
+  return dcn_forward_v1(0, dtype, input, weight, offset, output, B, Cin, H, W, Cout, kW, kH, dW, dH, padW, padH, dilationW, dilationH, group, deformable_group, im2col_step,
+                        columns, columns_bytes, stream);
+}
+int cfen_deform_conv_forward_nhwc(int dtype, const void* input, const void* weight, const void* offset, void* output, int B, int Cin, int H,
+                                  int W, int Cout, int kW, int kH, int dW, int dH, int padW, int padH, int dilationW, int dilationH, int group,
+                                  int deformable_group, int im2col_step, void* columns, size_t columns_bytes, void* stream) {
+  return dcn_forward_v1(1, dtype, input, weight, offset, output, B, Cin, H, W, Cout, kW, kH, dW, dH, padW, padH, dilationW, dilationH, group, deformable_group, im2col_step,
+                        columns, columns_bytes, stream);
+}
+
+static int dcn_forward_v2(int nhwc, int dtype, const void* input, const void* weight, const void* bias, const void* offset,
+                          const void* mask, void* output, int B, int Cin, int H, int W, int Cout, int kernel_h, int kernel_w,
+                          int stride_h, int stride_w, int pad_h, int pad_w, int dilation_h, int dilation_w, int group,
+                          int deformable_group, int with_bias, void* columns, size_t columns_bytes, void* stream) {
   CFEN_CHECK_ARG(mask != nullptr, "modulated_deform_conv: mask is required");
   CFEN_CHECK_ARG(!with_bias || bias, "modulated_deform_conv: with_bias set but bias is null");
   DcnArgs a{input, offset, mask, weight, with_bias ? bias : nullptr, output, B, Cin, H, W, Cout, kernel_h, kernel_w, stride_h, stride_w,
-            pad_h, pad_w, dilation_h, dilation_w, group, deformable_group, 0, 0, nullptr, nullptr};
+            pad_h, pad_w, dilation_h, dilation_w, group, deformable_group, 0, 0, nullptr, nullptr, nhwc};
   dcn_use_scratch(dtype, a, columns, columns_bytes);
+  CFEN_CHECK_ARG(!nhwc || a.imT, "modulated_deform_conv (NHWC input): needs the `columns` scratch and C / group a multiple of the 16-byte channel vector");
   if (stride_h > 0 && stride_w > 0) {
     a.Ho = (H + 2 * pad_h - (dilation_h * (kernel_h - 1) + 1)) / stride_h + 1;
     a.Wo = (W + 2 * pad_w - (dilation_w * (kernel_w - 1) + 1)) / stride_w + 1;
   }
   return launch_dcn(dtype, a, (hipStream_t)stream);
+}
+int cfen_modulated_deform_conv_forward(int dtype, const void* input, const void* weight, const void* bias, const void* offset,
+                                       const void* mask, void* output, int B, int Cin, int H, int W, int Cout, int kernel_h, int kernel_w,
+                                       int stride_h, int stride_w, int pad_h, int pad_w, int dilation_h, int dilation_w, int group,
+                                       int deformable_group, int with_bias, void* columns, size_t columns_bytes, void* stream) {
+  return dcn_forward_v2(0, dtype, input, weight, bias, offset, mask, output, B, Cin, H, W, Cout, kernel_h, kernel_w, stride_h, stride_w, pad_h, pad_w, dilation_h, dilation_w, group,
+                        deformable_group, with_bias, columns, columns_bytes, stream);
+}
+int cfen_modulated_deform_conv_forward_nhwc(int dtype, const void* input, const void* weight, const void* bias, const void* offset,
+                                            const void* mask, void* output, int B, int Cin, int H, int W, int Cout, int kernel_h, int kernel_w,
+                                            int stride_h, int stride_w, int pad_h, int pad_w, int dilation_h, int dilation_w, int group,
+                                            int deformable_group, int with_bias, void* columns, size_t columns_bytes, void* stream) {
+  return dcn_forward_v2(1, dtype, input, weight, bias, offset, mask, output, B, Cin, H, W, Cout, kernel_h, kernel_w, stride_h, stride_w, pad_h, pad_w, dilation_h, dilation_w, group,
+                        deformable_group, with_bias, columns, columns_bytes, stream);
 }
 
 }  // extern "C"

@@ -24,6 +24,14 @@ def _contig(*ts):
     return [t.contiguous() if t is not None else None for t in ts]
 
 
+def _nhwc_input(ctx, input, weight, groups):
+    """(extension, round 6) a channels_last input in a forward nobody differentiates goes to the kernel as it is: the NHWC copy the kernel samples from IS its memory
+    (cfen_*_forward_nhwc).  The backward kernels read NCHW, so a differentiated call keeps the reference's contiguous() copy."""
+    ve = 16 // input.element_size()
+    return (input.dim() == 4 and not any(ctx.needs_input_grad) and not input.is_contiguous() and input.is_contiguous(memory_format=torch.channels_last)
+            and input.dtype in (torch.float16, torch.float32) and (input.size(1) // groups) % ve == 0 and input.size(1) % groups == 0)
+
+
 def _columns(input, weight, groups):
     """The reference allocates `columns` / `ones` scratch tensors per call (deform_conv.py:31, 106-107) and hands them to the extension;
     here `columns` is the scratch of the HIP kernel's NHWC / tap-major operand copies (csrc/k_dcn.hip).  (buffer, nbytes)."""
@@ -58,12 +66,16 @@ class DeformConvFunction(Function):
                                % (output.shape[2], output.shape[3], offset.shape[2], offset.shape[3]))
         if input.size(1) != weight.size(1) * groups:
             raise RuntimeError("invalid number of input planes, expected: %d, but got: %d" % (weight.size(1) * groups, input.size(1)))
-        input, offset, weight = _contig(input, offset.to(input.dtype), weight.to(input.dtype))
+        nhwc = _nhwc_input(ctx, input, weight, groups)
+        offset, weight = _contig(offset.to(input.dtype), weight.to(input.dtype))
+        if not nhwc:
+            input = input.contiguous()
         ctx.save_for_backward(input, offset, weight)
         B, C, H, W = input.shape
         columns, nbytes = _columns(input, weight, groups)
+        lib = _lib.load()
         # note the reference passes W before H here (deform_conv.py:41-46)
-        check(_lib.load().cfen_deform_conv_forward(
+        check((lib.cfen_deform_conv_forward_nhwc if nhwc else lib.cfen_deform_conv_forward)(
             dtype_code(input.dtype), ptr(input), ptr(weight), ptr(offset), ptr(output), B, C, H, W, weight.size(0),
             weight.size(3), weight.size(2), stride[1], stride[0], padding[1], padding[0], dilation[1], dilation[0],
             groups, deformable_groups, cur_im2col_step, ptr(columns), nbytes, current_stream()), "deform_conv_forward")
@@ -125,13 +137,16 @@ class ModulatedDeformConvFunction(Function):
         output = input.new_empty((n, channels_out, height_out, width_out))
         if input.size(1) != weight.size(1) * groups:
             raise RuntimeError("Input shape and kernel channels wont match: (%d vs %d)." % (input.size(1), weight.size(1) * groups))
-        input, offset, mask, weight, bias = _contig(input, offset.to(input.dtype), mask.to(input.dtype), weight.to(input.dtype),
-                                                    bias.to(input.dtype) if with_bias else None)
+        nhwc = _nhwc_input(ctx, input, weight, groups)
+        offset, mask, weight, bias = _contig(offset.to(input.dtype), mask.to(input.dtype), weight.to(input.dtype), bias.to(input.dtype) if with_bias else None)
+        if not nhwc:
+            input = input.contiguous()
         ctx.stride, ctx.padding, ctx.dilation, ctx.groups, ctx.deformable_groups, ctx.with_bias = stride, padding, dilation, groups, deformable_groups, with_bias
         ctx.save_for_backward(input, offset, mask, weight)
         columns, nbytes = _columns(input, weight, groups)
         # scalar stride / padding / dilation, h before w (deform_conv.py:117-119)
-        check(_lib.load().cfen_modulated_deform_conv_forward(
+        lib = _lib.load()
+        check((lib.cfen_modulated_deform_conv_forward_nhwc if nhwc else lib.cfen_modulated_deform_conv_forward)(
             dtype_code(input.dtype), ptr(input), ptr(weight), ptr(bias), ptr(offset), ptr(mask), ptr(output), n, input.size(1),
             height, width, channels_out, kernel_h, kernel_w, stride, stride, padding, padding, dilation, dilation, groups,
             deformable_groups, int(with_bias), ptr(columns), nbytes, current_stream()), "modulated_deform_conv_forward")

@@ -64,6 +64,29 @@ def test_lean_kernel_and_round2_kernel_agree(C, dg):
         assert float((a.float() - b.float()).abs().max()) <= 8e-3
 
 
+@pytest.mark.parametrize("dtype,C,dg", [(torch.float16, 24, 1), (torch.float16, 48, 8), (torch.float32, 24, 4)])
+def test_channels_last_input_skips_the_layout_pass_and_gives_the_same_bits(dtype, C, dg):
+    """(extension, round 6) an undifferentiated call on a channels_last input samples from the tensor's own NHWC memory (cfen_*_forward_nhwc): bit for bit the result of
+    the contiguous call, v1 and v2; a differentiated call keeps the NCHW copy (its backward kernels read NCHW)"""
+    d = "cuda:0"
+    g = torch.Generator().manual_seed(7)
+    B, H = 2, 40
+    x = torch.randn(B, C, H, H, generator=g).to(dtype).to(d)
+    w = (torch.randn(C, C, 3, 3, generator=g) * (C * 9) ** -0.5).to(dtype).to(d)
+    off = (torch.randn(B, dg * 18, H, H, generator=g) * 2.0).to(dtype).to(d)
+    mask = torch.sigmoid(torch.randn(B, dg * 9, H, H, generator=g)).to(dtype).to(d)
+    bias = torch.randn(C, generator=g).to(dtype).to(d)
+    xcl = x.contiguous(memory_format=torch.channels_last)
+    assert not xcl.is_contiguous()
+    with torch.no_grad():
+        assert torch.equal(dcn.deform_conv(xcl, off, w, 1, 1, 1, 1, dg), dcn.deform_conv(x, off, w, 1, 1, 1, 1, dg))
+        assert torch.equal(dcn.modulated_deform_conv(xcl, off, mask, w, bias, 1, 1, 1, 1, dg), dcn.modulated_deform_conv(x, off, mask, w, bias, 1, 1, 1, 1, dg))
+    xg = xcl.detach().clone(memory_format=torch.preserve_format).requires_grad_()
+    y = dcn.deform_conv(xg, off, w, 1, 1, 1, 1, dg)
+    y.float().sum().backward()
+    assert xg.grad is not None and torch.isfinite(xg.grad).all()
+
+
 def test_pack_modules_at_init_are_plain_convs():
     # DeformConvPack zero-initialises conv_offset (deform_conv.py:211-213) => plain conv
     torch.manual_seed(0)

@@ -25,6 +25,7 @@ def main():
     ap.add_argument("--burst", type=int, default=0, help="also time N back-to-back calls through the C ABI (preallocated output and scratch, no cache eviction, "
                     "no host synchronisation in between): the rate with the GPU kept busy, reported as us_burst")
     ap.add_argument("--no-flush", action="store_true", help="do not evict the caches between repetitions (hot numbers)")
+    ap.add_argument("--channels-last", action="store_true", help="hand the input over as a channels_last tensor (round 6: no NHWC pre-pass, cfen_*_forward_nhwc)")
     ap.add_argument("--channels", type=int, default=0, help="only the case with this many channels (24, 48 or 96); 0 = all three")
     args = ap.parse_args()
     dt = torch.float16 if args.dtype == "fp16" else torch.float32
@@ -41,6 +42,8 @@ def main():
         for dg in (1, 8):
             g = torch.Generator().manual_seed(C * 10 + dg)
             x = torch.randn(B, C, H, H, generator=g).to(dt).to(dev)
+            if args.channels_last and not args.backward:
+                x = x.contiguous(memory_format=torch.channels_last)
             w = (torch.randn(C, C, 3, 3, generator=g) * (C * 9) ** -0.5).to(dt).to(dev)
             off = (torch.randn(B, dg * 18, H, H, generator=g) * 2.0).to(dt).to(dev)
             mask = torch.sigmoid(torch.randn(B, dg * 9, H, H, generator=g)).to(dt).to(dev)
@@ -71,7 +74,7 @@ def main():
                     elems = 2 * (C * px + (2 if ver == 1 else 3) * dg * 9 * px + C * C * 9) + C * px
                 gbs = elems * esz / ms / 1e6
                 tf = (2.0 * C * C * 9 + 8.0 * C * 9) * px / ms / 1e9 * (2 if args.backward else 1)
-                rec = {"op": "dcn_v%d%s" % (ver, "_backward" if args.backward else ""), "shape": [B, C, H, H], "deformable_groups": dg, "dtype": args.dtype, "us": round(ms * 1e3, 1),
+                rec = {"op": "dcn_v%d%s%s" % (ver, "_backward" if args.backward else "", "_channels_last_input" if args.channels_last and not args.backward else ""), "shape": [B, C, H, H], "deformable_groups": dg, "dtype": args.dtype, "us": round(ms * 1e3, 1),
                        "algorithmic_MB": round(elems * esz / 1e6, 2), "GBps": round(gbs, 1), "hbm_frac": round(gbs / HBM_PEAK, 4), "TFLOPs": round(tf, 2)}
                 if args.burst and not args.backward:
                     from cfen_vit_dehazing_amd import _lib
