@@ -339,7 +339,7 @@ int cfen_tune(const char* key, int value) {
     return CFEN_OK;
   }
   if (!strcmp(key, "mlp3.tm192")) {
-    CFEN_CHECK_ARG((value >= 2 && value <= 4) || value == 22 || value == 24 || value == 25 || value == 26 || value == 27 || value == 28, "tune: mlp3.tm192 is 2, 3 or 4 token tiles a wave (one workgroup a CU), 22 / 24 = 2 tiles at 256 registers on a 3- / 4-slot ring");
+    CFEN_CHECK_ARG((value >= 2 && value <= 4) || value == 22 || value == 24 || value == 25 || value == 28, "tune: mlp3.tm192 is 2, 3 or 4 token tiles a wave (one workgroup a CU), 22 / 24 = 2 tiles at 256 registers on a 3- / 4-slot ring");
     cfen_tune_mlp3_tm192() = value;
     return CFEN_OK;
   }

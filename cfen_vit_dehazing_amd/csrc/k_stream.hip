@@ -826,30 +826,23 @@ int cfen_mlp3_impl_g(int dtype, int ng, const Mlp3Args* ap, hipStream_t s) {
   if (ap[0].D == 384 && cfen_tune_mlp3_debug() == 1) return launch_mlp3<24, 2, 3, 1536, 1>(ng, ap, s);
   if (ap[0].D == 384 && cfen_tune_mlp3_debug() == 2) return launch_mlp3<24, 2, 3, 1536, 2>(ng, ap, s);
   if (ap[0].D == 384 && cfen_tune_mlp3_debug() == 8) return launch_mlp3<24, 1, 3, 1536, 0, 2, 8>(ng, ap, s);   // round-5 A/B: 8 waves x 1 tile, two waves per SIMD
+  // (round-6 A/B variants 14-17, 20, 65, 72 -- other piece positions, 6 reads ahead, more stamped builds -- are recorded in profiles/r06_mlp3_d384_variants.txt / _stamps.txt and
+  //  no longer compiled: each instantiation of this kernel is 15-25 s of build time)
   if (ap[0].D == 384 && cfen_tune_mlp3_debug() == 11) return launch_mlp3<24, 2, 3, 1536, 0, 1, 4, 0, 1>(ng, ap, s);       // round-6 A/Bs: DMA pieces spread between the MFMAs
-  if (ap[0].D == 384 && cfen_tune_mlp3_debug() == 14) return launch_mlp3<24, 2, 3, 1536, 0, 1, 4, 4, 1>(ng, ap, s);       // ... 4 instead of 6 fragment reads ahead of the MFMAs
-  if (ap[0].D == 384 && cfen_tune_mlp3_debug() == 15) return launch_mlp3<24, 2, 3, 1536, 0, 1, 4, 0, 3>(ng, ap, s);       // ... behind fragment 4k + 3
-  if (ap[0].D == 384 && cfen_tune_mlp3_debug() == 16) return launch_mlp3<24, 2, 3, 1536, 0, 1, 4, 0, 4>(ng, ap, s);       // ... behind fragment 4k
-  if (ap[0].D == 384 && cfen_tune_mlp3_debug() == 17) return launch_mlp3<24, 2, 3, 1536, 0, 1, 4, 0, 5>(ng, ap, s);       // ... a third each at the phase start, in the mid-phase bubble, spread
   if (ap[0].D == 384 && cfen_tune_mlp3_debug() == 18) return launch_mlp3<24, 2, 3, 1536, 0, 1, 4, 4, 5>(ng, ap, s);       // ... with 4 fragment reads ahead
   if (ap[0].D == 384 && cfen_tune_mlp3_debug() == 19) return launch_mlp3<24, 2, 3, 1536, 0, 1, 4, 4, 5, 0, 1>(ng, ap, s);    // ... and the first hidden tile repacked early (UMAJ)
-  if (ap[0].D == 384 && cfen_tune_mlp3_debug() == 20) return launch_mlp3<24, 2, 3, 1536, 0, 1, 4, 0, 5, 0, 1>(ng, ap, s);
   if (ap[0].D == 384 && cfen_tune_mlp3_debug() == 100) return launch_mlp3<24, 2, 3, 1536>(ng, ap, s);                     // the burst issue of rounds 3-5
   if (ap[0].D == 384 && cfen_tune_mlp3_debug() == 64) return launch_mlp3<24, 2, 3, 1536, 0, 1, 4, 0, 0, 1>(ng, ap, s);    // stamped timing builds
-  if (ap[0].D == 384 && cfen_tune_mlp3_debug() == 65) return launch_mlp3<24, 2, 3, 1536, 0, 1, 4, 0, 1, 1>(ng, ap, s);
   if (ap[0].D == 384 && cfen_tune_mlp3_debug() == 67) return launch_mlp3<24, 2, 3, 1536, 1, 1, 4, 0, 0, 1>(ng, ap, s);    // stamped, no refills
   if (ap[0].D == 384 && cfen_tune_mlp3_debug() == 68) return launch_mlp3<24, 2, 3, 1536, 4, 1, 4, 0, 0, 1>(ng, ap, s);    // stamped, no LDS fragment reads (MFMAs + refills + barrier)
   if (ap[0].D == 384 && cfen_tune_mlp3_debug() == 69) return launch_mlp3<24, 2, 3, 1536, 5, 1, 4, 0, 0, 1>(ng, ap, s);    // stamped, neither (MFMAs + barrier + the mid-phase repack)
   if (ap[0].D == 384 && cfen_tune_mlp3_debug() == 70) return launch_mlp3<24, 2, 3, 1536, 32, 1, 4, 0, 0, 1>(ng, ap, s);   // stamped, 4-byte refill pieces
   if (ap[0].D == 384 && cfen_tune_mlp3_debug() == 71) return launch_mlp3<24, 2, 3, 1536, 6, 1, 4, 0, 0, 1>(ng, ap, s);    // stamped, refills + barrier only (no MFMAs, no reads)
-  if (ap[0].D == 384 && cfen_tune_mlp3_debug() == 72) return launch_mlp3<24, 2, 3, 1536, 2, 1, 4, 0, 0, 1>(ng, ap, s);    // stamped, no MFMAs
   // round 6 default: refills in thirds (phase start / mid-phase gap / spread over the second half), 4 fragment reads ahead, first hidden tile repacked early:
   // 167 -> 156 us on 192 workgroups, 158 -> 152 on 16 (same box, tools/dbg_mlp3_stamps.py; profiles/r06_mlp3_d384_variants.txt), bit for bit the round-5 results
   if (ap[0].D == 384) return launch_mlp3<24, 2, 3, 1536, 0, 1, 4, 4, 5, 0, 1>(ng, ap, s);
   if (cfen_tune_mlp3_tm192() == 22) return launch_mlp3<12, 2, 3, 768, 0, 2>(ng, ap, s);   // two 78 KB workgroups a CU, three-slot ring (round 5 A/B)
   if (cfen_tune_mlp3_tm192() == 25) return launch_mlp3<12, 2, 3, 768, 0, 2, 4, 4, 5, 0, 1>(ng, ap, s);   // round-6 A/Bs: the D = 384 kernel's refill placement (thirds) + early repack + 4 reads ahead
-  if (cfen_tune_mlp3_tm192() == 26) return launch_mlp3<12, 2, 3, 768, 0, 2, 4, 0, 5, 0, 1>(ng, ap, s);   // ... with 6 reads ahead
-  if (cfen_tune_mlp3_tm192() == 27) return launch_mlp3<12, 2, 3, 768, 0, 2, 4, 0, 0, 0, 1>(ng, ap, s);   // ... early repack only
   if (cfen_tune_mlp3_tm192() == 28) return launch_mlp3<12, 2, 3, 768, 0, 2, 8>(ng, ap, s);        // ONE 8-wave workgroup a CU (two waves per SIMD) sharing one three-slot ring: 256 tokens per weight byte streamed
   if (cfen_tune_mlp3_tm192() == 24) return launch_mlp3<12, 2, 4, 768, 0, 2>(ng, ap, s);   // one 102 KB workgroup a CU at 256 registers, four slots
   if (cfen_tune_mlp3_tm192() == 3) return launch_mlp3<12, 3, 6, 768>(ng, ap, s);

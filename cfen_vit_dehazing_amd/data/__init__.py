@@ -41,8 +41,8 @@ def to_u8_hwc(img):
 
 
 class _ResizeShortSide:
-    """--resize_or_crop resize_only / scale_width: the short side becomes --loadSize (a picklable callable: the loader's workers are started by a
-    fork server, not forked from the GPU process -- CustomDatasetDataLoader)"""
+    """--resize_or_crop resize_only / scale_width: the short side becomes --loadSize (a picklable callable: the loader's workers are forked by
+    default, early -- CustomDatasetDataLoader.start_workers -- but CFEN_LOADER_CONTEXT=forkserver|spawn must be able to pickle the transform)"""
 
     def __init__(self, load_size):
         self.load_size = load_size

@@ -43,7 +43,8 @@ def _rerun_in_fp32(opt, model, image_dir, paths):
 if __name__ == '__main__':
     _startup = {"imports": round(time.perf_counter() - _T_START, 2)}      # where the seconds in front of the first batch go (printed below; tools/cli_throughput.py)
     _t = time.perf_counter()
-    opt = TestOptions().parse()   # --in_flight > 1 also exports GPU_MAX_HW_QUEUES=8 there, before the first HIP call
+    opt = TestOptions().parse()   # --in_flight > 1 also exports GPU_MAX_HW_QUEUES=8 there, in front of its torch.cuda.set_device (the process's first HIP call: the forks
+                                  # below come after it, but before the process holds any GPU memory -- that, not the initialised runtime, is what made late forks cost 10-16 s)
     opt.serial_batches = True   # no shuffle
     opt.no_flip = True          # no flip
     opt.display_id = -1         # no visdom display

@@ -256,3 +256,40 @@ def test_plan_info_says_which_launch_plan_and_why(monkeypatch):
     monkeypatch.setenv("GPU_MAX_HW_QUEUES", "8")
     net8 = dec_ipt(NetConfig(24, 4, patch_size=8, load_size=64))
     assert net8.plan_info()["lanes_per_forward"] == 1 and "GPU_MAX_HW_QUEUES" in net8.plan_info()["why"]
+
+
+def test_writer_processes_encode_from_the_shared_ring(tmp_path):
+    """pipeline.start_writer_processes (test.py --writer_procs, round 6): workers forked here read an image from the shared mapping at the offset they are handed and write
+    the PNG util.save_image would; batch slots sit in front of the single-image slots; --png_compress_level changes the file's bytes, not its pixels"""
+    from cfen_vit_dehazing_amd import pipeline
+    n = 16
+    w = pipeline.start_writer_processes(2, n, batch=2, labels=1, in_flight=2)
+    try:
+        assert w["bslots"] >= 4 and w["slot0"] == w["bslots"] * w["batch_bytes"] and w["img_bytes"] == n * n * 3
+        rs = np.random.RandomState(3)
+        imgs = [rs.randint(0, 256, size=(n, n, 3)).astype(np.uint8) for _ in range(3)]
+        offs = [1 * w["batch_bytes"] + 1 * w["img_bytes"], w["slot0"], w["slot0"] + 3 * w["img_bytes"]]      # image 1 of batch slot 1, single slots 0 and 3
+        res = []
+        for k, (im, off) in enumerate(zip(imgs, offs)):
+            np.frombuffer(w["ring"], dtype=np.uint8, count=im.size, offset=off).reshape(im.shape)[...] = im
+            res.append(w["pool"].apply_async(pipeline._save_png_from_ring, (off, im.shape, str(tmp_path / ("w%d.png" % k)), 40 + k)))
+        assert [r.get(timeout=60) for r in res] == [40, 41, 42]                                                   # the token comes back (it frees the slot)
+        for k, im in enumerate(imgs):
+            util.save_image(im, str(tmp_path / ("d%d.png" % k)))
+            assert open(tmp_path / ("w%d.png" % k), "rb").read() == open(tmp_path / ("d%d.png" % k), "rb").read()
+    finally:
+        pipeline.stop_writer_processes()
+    assert pipeline._WRITERS is None
+    was = util.PNG_COMPRESS_LEVEL
+    try:
+        opt = TestOptions().parse(['--dataroot', str(tmp_path), '--name', 'x', '--gpu_ids', '-1', '--png_compress_level', '1'])
+        assert opt.png_compress_level == 1 and util.PNG_COMPRESS_LEVEL == 1
+        smooth = np.tile(np.arange(64, dtype=np.uint8)[None, :, None], (64, 1, 3))
+        util.save_image(smooth, str(tmp_path / "l1.png"))
+        util.PNG_COMPRESS_LEVEL = None
+        util.save_image(smooth, str(tmp_path / "l6.png"))
+        assert np.array_equal(np.asarray(Image.open(tmp_path / "l1.png")), np.asarray(Image.open(tmp_path / "l6.png")))
+        with pytest.raises(ValueError):
+            TestOptions().parse(['--dataroot', str(tmp_path), '--name', 'x', '--gpu_ids', '-1', '--png_compress_level', '12'])
+    finally:
+        util.PNG_COMPRESS_LEVEL = was

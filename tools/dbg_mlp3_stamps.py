@@ -13,9 +13,9 @@ from cfen_vit_dehazing_amd import ops, packing
 
 d = "cuda:0"
 flush = torch.empty(256 << 20, dtype=torch.uint8, device=d)
-NAMES = {0: "shipped default", 100: "burst issue (rounds 3-5)", 1: "no DMA refills (invalid)", 2: "no MFMAs in the hidden loop (invalid)", 8: "8 waves x 1 tile", 11: "spread issue", 12: "spread + staggered by wave",
-         13: "spread, 3 token tiles a wave", 14: "spread, 4 fragment reads ahead", 15: "spread at fragment 3 of 4"}
-STAMPED = {64: "burst", 65: "spread", 67: "burst, no refills", 68: "no LDS fragment reads", 69: "no reads, no refills", 70: "4-byte refill pieces", 71: "refills + barrier only", 72: "no MFMAs"}
+NAMES = {0: "shipped default", 100: "burst issue (rounds 3-5)", 1: "no DMA refills (invalid)", 2: "no MFMAs in the hidden loop (invalid)", 8: "8 waves x 1 tile", 11: "spread issue",
+         18: "refills in thirds, 4 reads ahead", 19: "... + early repack (shipped)"}
+STAMPED = {64: "burst", 67: "burst, no refills", 68: "no LDS fragment reads", 69: "no reads, no refills", 70: "4-byte refill pieces", 71: "refills + barrier only"}
 
 
 def timeit(f, n=12):
@@ -32,7 +32,7 @@ def timeit(f, n=12):
 
 
 def main():
-    want = [int(v) for v in sys.argv[1:]] or [100, 11, 14, 15, 16, 1, 2]
+    want = [int(v) for v in sys.argv[1:]] or [100, 11, 18, 1, 2]
     D, H = 384, 1536
     torch.manual_seed(0)
     for M in (2048, 8192, 24576):
