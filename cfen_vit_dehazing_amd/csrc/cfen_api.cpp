@@ -359,6 +359,10 @@ int cfen_tune(const char* key, int value) {
     cfen_tune_front3_debug() = value;
     return CFEN_OK;
   }
+  if (!strcmp(key, "mlp3.pair")) {
+    cfen_tune_mlp3_pair() = value;
+    return CFEN_OK;
+  }
   if (!strcmp(key, "mlp3.debug")) {
     cfen_tune_mlp3_debug() = value;
     return CFEN_OK;

@@ -119,6 +119,7 @@ int& cfen_tune_mlp3_tm192();         // token tiles per wave of k_mlp3 at D = 19
 int& cfen_tune_embed_defer_refill(); // k_embed_qkv2 likewise ("embed.defer_refill")
 int& cfen_tune_gemm_defer_refill();  // k_gemm_dma: refill behind the K-step's first fragment reads ("gemm.defer_refill")
 int& cfen_tune_lvit_debug();         // k_lvit_window ("lvit.debug"): 64 = section stamps of workgroup 0 to stderr
+int& cfen_tune_mlp3_pair();          // D = 384 MLP blocks on the wave-pair kernel k_mlp3p ("mlp3.pair")
 int& cfen_tune_front3_debug();       // k_front3 timing experiments ("front3.debug"): 1 no refills, 8 no qkv stores, 24 no stores (results invalid); | 64 = section stamps to stderr
 int& cfen_tune_mlp3_debug();         // k_mlp3 timing experiments (results invalid): 1 no DMA refills, 2 no MFMAs ("mlp3.debug")
 int& cfen_tune_gemm_m128();          // tile id (+10 per extra stage) for problems of <= 128 tokens, 0 = shape rule ("gemm.m128")

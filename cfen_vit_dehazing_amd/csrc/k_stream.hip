@@ -477,6 +477,449 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(WPE, WP
   }
 }
 
+// fragment offsets of k_mlp3p's runs (compile-time: a local class cannot carry a member template)
+template <int ND> struct Mlp3pOffProj { template <int k> static constexpr int at() { return (k / (ND / 2)) * ND + k % (ND / 2); } };
+struct Mlp3pOffW1 { template <int k> static constexpr int at() { return 2 * k; } };
+struct Mlp3pOffW2 { template <int k> static constexpr int at() { return k; } };
+
+// ---- k_mlp3p (round 6): the same chain at D = 384 on TWO waves per SIMD ----------------------------------------------------------------------------
+// k_mlp3<24, 2, ...> runs one wave per SIMD because 384 features x 32 tokens of fp32 residual + its fp16 copy need 288 registers; its phase is then the SUM of MFMA time, refill
+// issue, repack gap and fragment-read stalls (DESIGN 6.1 stamps).  Here a wave PAIR (waves q and q + 4: the same SIMD) owns the 32 tokens of pair q:
+//   role r = wave >> 2 holds the residual of feature tiles 12 r .. 12 r + 11 (96 accumulator registers) and the WHOLE fp16 B operand (96 registers): ~240 in all, two waves a SIMD;
+//   of a 32-unit hidden sub-step role r computes hidden tile r (the fragments (c, u = r) of the W1 slice), the two tiles are exchanged through 8 KB of LDS (own tile out, one
+//   workgroup barrier, partner's tile in) and role r adds W2[its 192 features, the 32 units] . relu(h) -- LDS fragment reads and MFMAs per SIMD are those of k_mlp3, but the refill
+//   issue, the repack and the read stalls of one wave sit under the other wave's MFMAs;
+//   LayerNorm sums cross the pair through the same 8 KB; the fp16 operand (LN(x), then y1) crosses in two rounds through the ring slot that is free at that moment.
+// Same fragment streams, same arithmetic per element except the LayerNorm sums' association (own 192 features + the partner's): not bit-equal to k_mlp3, equal to tolerance.
+// Only workgroup barriers -- no spin waits.  LDS: 3 double-phase slots (144 KB) + the current stage's hidden biases (6 KB) + the exchange area (8 KB).
+// VAR (A/B): bit 0 = both roles issue half of their refill pieces at the head of either half of a sub-step (else role 0 all six in the first half, role 1 all six in the second);
+// bit 1 / bit 2 = s_setprio 1 for the role-1 / role-0 waves (the second-dispatched half of a workgroup loses the issue arbitration otherwise: MI355X_MICROARCH.md, two waves per SIMD)
+template <int ND, int R, int HB, int STAMP = 0, int VAR = 0>
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_mlp3p(Grouped<Mlp3Args> ga, unsigned long long* stamps) {
+  typedef half_t T;
+  typedef half8 frag;
+  typedef _Float16 half4v __attribute__((ext_vector_type(4)));
+  const Mlp3Args a = ga.g[blockIdx.z];
+  constexpr int TM = 2, NW = 8, NHT = ND / 2, D = ND * 16, NCH = ND / 2, NF = 2 * ND, SLOT = NF * 1024, DPW = NF / NW, RING = R * SLOT, BIAS = HB * 4, EXCH = NW * 1024;
+  static_assert(ND % 4 == 0 && NF % NW == 0 && R >= 3 && (R - 2) * DPW < 64 && NCH % 2 == 0, "ring geometry");
+  static_assert(RING + BIAS + EXCH <= 160 * 1024, "LDS");
+  __shared__ __attribute__((aligned(1024))) unsigned char lds[RING + BIAS + EXCH];
+
+  const int tid = threadIdx.x, lane = tid & 63, r16 = lane & 15, h = lane >> 4;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int q4 = wave & 3, role = wave >> 2;                       // token pair, feature / hidden-tile half
+  const long long tok0 = ((long long)blockIdx.x * 4 + q4) * (TM * 16);
+  const int nt = a.H / 32;
+  const int npp = NCH / 2;
+  const int NP = npp + 2 * nt;
+
+  auto phase_src = [&](int q) {
+    return q < npp        ? (const unsigned char*)a.Wp + (size_t)q * SLOT
+           : q < npp + nt ? (const unsigned char*)a.Wa + (size_t)(q - npp) * SLOT
+                          : (const unsigned char*)a.Wb + (size_t)(q - npp - nt) * SLOT;
+  };
+  auto issue = [&](int q, int slot) {
+    const unsigned char* src = phase_src(q);
+#pragma unroll
+    for (int k = 0; k < DPW; ++k) {
+      const int f = k * NW + wave;
+      st_dma(src + f * 1024 + lane * 16, lds + slot * SLOT + f * 1024);
+    }
+  };
+  auto stage_bias = [&](const float* b1) {       // H * 4 bytes of hidden bias -> LDS (1 KiB pieces; the caller drains)
+    const int pieces = a.H * 4 / 16, nb = (pieces + 63) / 64;
+    for (int blk = wave; blk < nb; blk += NW) {
+      const int pc = min(blk * 64 + lane, pieces - 1);
+      st_dma((const unsigned char*)b1 + pc * 16, lds + RING + blk * 1024);
+    }
+  };
+  unsigned long long tk0 = 0, rt0 = 0;
+  if constexpr (STAMP) {
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tk0)::"memory");
+    rt0 = __builtin_amdgcn_s_memrealtime();
+  }
+  // ---- prologue: stage-a biases, the first R - 1 phases, own feature half of x, the whole attention row (projection B operand) ----
+  stage_bias(a.b1a);
+#pragma unroll
+  for (int q = 0; q < R - 1; ++q)
+    if (q < NP) issue(q, q);
+  floatx4 acc[NHT][TM];
+  // the fp16 B operand, all 12 k-chunks: xo = the chunks of this wave's OWN feature half (k-chunks 6 r .. 6 r + 5), xp = the partner's.  Two arrays with compile-time indices: a
+  // role-dependent index into one array sends it to scratch (hipcc merges the two role branches into a dynamic index).  During the projection they simply hold the attention
+  // row's chunks 0 .. 5 / 6 .. 11.
+  frag xo[NCH / 2][TM], xp[NCH / 2][TM];
+  long long tkn[TM];
+#pragma unroll
+  for (int j = 0; j < TM; ++j) {
+    long long t = tok0 + j * 16 + r16;
+    tkn[j] = t;
+    if (t >= a.M) t = a.M - 1;
+    const T* xrow = (const T*)a.X + t * D + (role * NHT) * 16 + 4 * h;
+#pragma unroll
+    for (int i = 0; i < NHT; ++i) acc[i][j] = load4<T>(xrow + i * 16);
+    const T* ap = (const T*)a.A + t * D + h * 8;
+#pragma unroll
+    for (int c = 0; c < NCH / 2; ++c) {
+      xo[c][j] = load_frag<T>(ap + c * 32);
+      xp[c][j] = load_frag<T>(ap + (NCH / 2 + c) * 32);
+    }
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+
+  int p = 0, cur = 0, fill = R - 1;
+  // VAR & 16: the role-0 waves (the first-dispatched half: they win the issue arbitration on their SIMD and finish either half of a sub-step first) issue ALL refill pieces, half of
+  // them behind their last MFMA of the first half, half behind their last MFMA of the second -- where they would wait for their partners at the barrier anyway.  Role 0 then counts
+  // 2 DPW pieces per phase, role 1 none.
+  constexpr int DPW0 = (VAR & 16) ? 2 * DPW : DPW;
+  static_assert((R - 2) * DPW0 < 64, "vmcnt range");
+  auto begin = [&]() {
+    if constexpr (VAR & 16) {
+      if (role == 0) wait_phases<DPW0, R - 2>(min(R - 2, NP - 1 - p));
+    } else {
+      wait_phases<DPW, R - 2>(min(R - 2, NP - 1 - p));
+    }
+    __builtin_amdgcn_s_barrier();
+  };
+  // role 0, VAR & 16: fragments f = kk * 4 + (wave & 3), kk = 6 part .. 6 part + 5, of the phase two ahead
+  auto refill_pair_half = [&](int part) {
+    if (p + R - 1 < NP) {
+      const unsigned char* src = phase_src(p + R - 1);
+#pragma unroll
+      for (int kk = 0; kk < DPW; ++kk) {
+        const int f = (part * DPW + kk) * 4 + q4;
+        st_dma(src + f * 1024 + lane * 16, lds + fill * SLOT + f * 1024);
+      }
+    }
+  };
+  auto refill = [&]() {
+    if (p + R - 1 < NP) issue(p + R - 1, fill);
+  };
+  // the sub-steps issue their refill in two halves, one at the head of either half of the sub-step, in BOTH roles: a wave is held 70-80 cycles per piece, and with all six in one
+  // role's half the other role waited at the next barrier (stamps: second half 540 cycles without the pieces, 970 with)
+  // VAR & 8: one piece at a time, between the MFMAs of the issuing role's half of the sub-step (the 70-80 cycles a piece holds its wave pass under the partner's MFMAs AND the
+  // wave's own MFMAs follow at once, instead of six pieces in front of its first MFMA)
+  auto refill_piece = [&](int kk) {
+    if (p + R - 1 < NP) {
+      const int f = kk * NW + wave;
+      st_dma(phase_src(p + R - 1) + f * 1024 + lane * 16, lds + fill * SLOT + f * 1024);
+    }
+  };
+  auto refill_half = [&](int part) {
+    if (p + R - 1 < NP) {
+      const unsigned char* src = phase_src(p + R - 1);
+#pragma unroll
+      for (int k = 0; k < DPW / 2; ++k) {
+        const int f = (part * (DPW / 2) + k) * NW + wave;
+        st_dma(src + f * 1024 + lane * 16, lds + fill * SLOT + f * 1024);
+      }
+    }
+  };
+  auto advance = [&]() {
+    fill = cur;
+    cur = cur + 1 == R ? 0 : cur + 1;
+    ++p;
+  };
+  const unsigned lbase = (unsigned)(unsigned long long)(__attribute__((address_space(3))) unsigned char*)lds;
+  const unsigned lfrag = lbase + lane * 16;
+  constexpr int PD = 4, NB = PD + 2;
+  // a run of N fragments at compile-time offsets OFF(k) * 1024 from `sa`: reads PD ahead, counted waits (k_mlp3's idiom)
+  auto run = [&](unsigned sa, auto offc, auto nc, auto&& pre, auto&& body) {
+    constexpr int N = decltype(nc)::value;
+    frag F[NB];
+    sfor<0, (PD < N ? PD : N)>([&](auto fc) {
+      constexpr int f = decltype(fc)::value;
+      lds_rd<decltype(offc)::template at<f>() * 1024>(F[f % NB], sa);
+    });
+    pre();
+    sfor<0, N>([&](auto fc) {
+      constexpr int f = decltype(fc)::value;
+      if constexpr (f + PD < N) lds_rd<decltype(offc)::template at<f + PD>() * 1024>(F[(f + PD) % NB], sa);
+      lds_wait<(f + PD < N ? PD : N - 1 - f)>(F[f % NB]);
+      body(fc, F[f % NB]);
+    });
+  };
+  typedef Mlp3pOffProj<ND> OffProj;     // k-chunk half k / 12, own feature tile k % 12 (base + 12 r fragments)
+  typedef Mlp3pOffW1 OffW1;             // fragment (c = k, u = role) (base + role fragments)
+  typedef Mlp3pOffW2 OffW2;             // own feature tile k (base + ND + 12 r fragments)
+
+  // ---- x += Wp att: double phase qq = k-chunks 2 qq, 2 qq + 1; this wave: its 12 feature tiles of both ----
+  if (true) {
+    sfor<0, NCH / 2>([&](auto qc) {
+      constexpr int qq = decltype(qc)::value;
+      begin();
+      run(lfrag + cur * SLOT + role * (NHT * 1024), OffProj{}, std::integral_constant<int, 2 * NHT>{},
+          [&]() {
+            if constexpr (VAR & 16) {
+              if (role == 0) { refill_pair_half(0); refill_pair_half(1); }
+            } else {
+              refill();
+            }
+            advance();
+          },
+          [&](auto fc, const frag& fr) {
+            constexpr int f = decltype(fc)::value, c = 2 * qq + f / NHT, i = f % NHT;
+#pragma unroll
+            for (int j = 0; j < TM; ++j) {
+              if constexpr (c < NCH / 2) acc[i][j] = Mma<T>::mma(fr, xo[c][j], acc[i][j]);
+              else acc[i][j] = Mma<T>::mma(fr, xp[c - NCH / 2][j], acc[i][j]);
+            }
+          });
+    });
+  }
+  mfma_results_settle();
+
+  unsigned char* exch = lds + RING + BIAS;
+  // a float per (token tile, lane) across the pair: own value out, barrier, partner's in
+  auto pair_sum = [&](float (&v)[TM], int off) {
+#pragma unroll
+    for (int j = 0; j < TM; ++j) *reinterpret_cast<float*>(exch + wave * 1024 + off + (j * 64 + lane) * 4) = v[j];
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+#pragma unroll
+    for (int j = 0; j < TM; ++j) {
+      const float o = *reinterpret_cast<const float*>(exch + (wave ^ 4) * 1024 + off + (j * 64 + lane) * 4);
+      v[j] = role ? o + v[j] : v[j] + o;              // the SAME association in both waves of the pair: role 0's half first
+    }
+  };
+  // xo holds this wave's k-chunks of the B operand; fetch the partner's into xp through the ring slot that is free right now (`fill`: the phase before the current one)
+  auto share_xb = [&]() {
+    unsigned char* area = lds + fill * SLOT;                        // 48 KiB: 8 waves x 3 chunks x 2 tiles x 1 KiB per round
+    __builtin_amdgcn_s_barrier();                                   // every wave is done with that slot's fragments (and with the exchange area)
+    sfor<0, 2>([&](auto rdc) {
+      constexpr int rd = decltype(rdc)::value;
+#pragma unroll
+      for (int cc = 0; cc < 3; ++cc)
+#pragma unroll
+        for (int j = 0; j < TM; ++j) *reinterpret_cast<frag*>(area + ((wave * 3 + cc) * TM + j) * 1024 + lane * 16) = xo[rd * 3 + cc][j];
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+#pragma unroll
+      for (int cc = 0; cc < 3; ++cc)
+#pragma unroll
+        for (int j = 0; j < TM; ++j) xp[rd * 3 + cc][j] = *reinterpret_cast<const frag*>(area + (((wave ^ 4) * 3 + cc) * TM + j) * 1024 + lane * 16);
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();                                 // (the second one also protects the slot against the next phase's refill)
+    });
+  };
+
+  if constexpr (VAR & 2) { if (role == 1) __builtin_amdgcn_s_setprio(1); }
+  if constexpr (VAR & 4) { if (role == 0) __builtin_amdgcn_s_setprio(1); }
+  // ---- LayerNorm(x) over all 384 features -> xb; the stage-a output bias joins the residual ----
+  {
+    float sm[TM], qv[TM], mean[TM], rstd[TM];
+#pragma unroll
+    for (int j = 0; j < TM; ++j) {
+      float s0 = 0.f;
+#pragma unroll
+      for (int i = 0; i < NHT; ++i) s0 += acc[i][j][0] + acc[i][j][1] + acc[i][j][2] + acc[i][j][3];
+      sm[j] = col_sum(s0);
+    }
+    pair_sum(sm, 0);
+#pragma unroll
+    for (int j = 0; j < TM; ++j) {
+      mean[j] = sm[j] * (1.f / D);
+      asm volatile("" : "+v"(mean[j]));
+      float q0 = 0.f;
+#pragma unroll
+      for (int i = 0; i < NHT; ++i)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float d = acc[i][j][r] - mean[j];
+          q0 += d * d;
+        }
+      qv[j] = col_sum(q0);
+    }
+    pair_sum(qv, 512);
+#pragma unroll
+    for (int j = 0; j < TM; ++j) {
+      rstd[j] = rsqrtf(qv[j] * (1.f / D) + a.eps);
+#pragma unroll
+      for (int c = 0; c < NCH / 2; ++c) {
+        floatx4 t[2];
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+          const int i = c * 2 + u, fi = (role * NHT + i) * 16 + 4 * h;
+          const floatx4 g = *reinterpret_cast<const floatx4*>(a.ln_g + fi);
+          const floatx4 b = *reinterpret_cast<const floatx4*>(a.ln_b + fi);
+          t[u] = (acc[i][j] - mean[j]) * rstd[j] * g + b;
+        }
+        xo[c][j] = pack_pair(t[0], t[1]);
+      }
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < NHT; ++i) {
+    const floatx4 bb = *reinterpret_cast<const floatx4*>(a.b2a + (role * NHT + i) * 16 + 4 * h);
+#pragma unroll
+    for (int j = 0; j < TM; ++j) acc[i][j] += bb;
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // LayerNorm parameters / bias loads: ordinary VMEM in front of the ring's counted waits (the ring is R - 1 phases ahead)
+  share_xb();
+
+  unsigned long long tk_b1 = 0, tk_fh = 0, tk_x = 0, tk_sh = 0;     // STAMP: cycle sums of [wait + first barrier | first half | repack + exchange (second barrier) | second half]
+  auto now = [&]() -> unsigned long long {
+    unsigned long long tt = 0;
+    if constexpr (STAMP) asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tt)::"memory");
+    return tt;
+  };
+  // ---- one 32-unit hidden sub-step ----
+  auto substep = [&](int t) {
+    const unsigned long long s0 = now();
+    begin();
+    const unsigned long long s1 = now();
+    floatx4 bv;
+    lds_rd<0>(bv, lbase + RING + (t * 32 + role * 16 + 4 * h) * 4);
+    floatx4 hacc[TM];
+    half4v own[TM];
+    // hidden tile `role`: h = W1[units 16 r .. 16 r + 15 of the slice] . xb + b1, the k-chunks in the order own half (xo), partner's half (xp): fragment (c, u = role) of the
+    // LDS image is fragment 2 c + role, own chunk k is c = 6 role + k, the partner's c = 6 (1 - role) + k.  ONE read pipeline over both halves (12 fragments, PD ahead).
+    {
+      const unsigned sa1 = lfrag + cur * SLOT + (NCH * role + role) * 1024, sa2 = lfrag + cur * SLOT + (NCH * (1 - role) + role) * 1024;
+      constexpr int N = NCH, HN = NCH / 2;
+      frag F[NB];
+      sfor<0, PD>([&](auto fc) {
+        constexpr int f = decltype(fc)::value;
+        lds_rd<2 * (f % HN) * 1024>(F[f % NB], f < HN ? sa1 : sa2);
+      });
+      if constexpr (VAR & 1) refill_half(0);
+      else if constexpr (!(VAR & 24)) { if (role == 0) refill(); }
+      sfor<0, N>([&](auto fc) {
+        constexpr int f = decltype(fc)::value, g = f + PD;
+        if constexpr (g < N) lds_rd<2 * (g % HN) * 1024>(F[g % NB], g < HN ? sa1 : sa2);
+        lds_wait<(g < N ? PD : N - 1 - f)>(F[f % NB]);
+        if constexpr (f == 0) {
+          asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(bv) : "n"(PD));   // (the bias read is older than every fragment read)
+#pragma unroll
+          for (int j = 0; j < TM; ++j) hacc[j] = bv;
+        }
+#pragma unroll
+        for (int j = 0; j < TM; ++j) {
+          if constexpr (f < HN) hacc[j] = Mma<T>::mma(F[f % NB], xo[f][j], hacc[j]);
+          else hacc[j] = Mma<T>::mma(F[f % NB], xp[f - HN][j], hacc[j]);
+        }
+        if constexpr ((VAR & 8) && f % 2 == 0 && f / 2 < DPW) {
+          if (role == 0) refill_piece(f / 2);
+        }
+      });
+    }
+    // the second half's first fragment reads go out NOW: they do not depend on the exchange, and their LDS round trip passes under the repack / barrier / partner read
+    const unsigned sa3 = lfrag + cur * SLOT + (ND + role * NHT) * 1024;
+    frag G[NB];
+    sfor<0, PD>([&](auto fc) {
+      constexpr int f = decltype(fc)::value;
+      lds_rd<f * 1024>(G[f % NB], sa3);
+    });
+    mfma_results_settle();
+    const unsigned long long s2 = now();
+#pragma unroll
+    for (int j = 0; j < TM; ++j) {
+      const half4v v = {(half_t)hacc[j][0], (half_t)hacc[j][1], (half_t)hacc[j][2], (half_t)hacc[j][3]};
+      const half4v z = {(half_t)0, (half_t)0, (half_t)0, (half_t)0};
+      own[j] = __builtin_elementwise_max(v, z);
+      *reinterpret_cast<half4v*>(exch + wave * 1024 + (j * 64 + lane) * 8) = own[j];
+    }
+    if constexpr (VAR & 16) {
+      if (role == 0) refill_pair_half(0);
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();                        // both tiles of every pair are in the exchange area (overwritten again behind the next sub-step's first barrier)
+    frag hb[TM];
+#pragma unroll
+    for (int j = 0; j < TM; ++j) {
+      const half4v o = *reinterpret_cast<const half4v*>(exch + (wave ^ 4) * 1024 + (j * 64 + lane) * 8);
+      const half4v lo = role ? o : own[j], hi = role ? own[j] : o;
+      hb[j] = frag{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    const unsigned long long s3 = now();
+    // y[own 192 features] += W2[own rows, the slice] . relu(h)
+    if constexpr (VAR & 1) refill_half(1);
+    else if constexpr (!(VAR & 24)) { if (role == 1) refill(); }
+    sfor<0, NHT>([&](auto fc) {
+      constexpr int f = decltype(fc)::value, g = f + PD;
+      if constexpr (g < NHT) lds_rd<g * 1024>(G[g % NB], sa3);
+      lds_wait<(g < NHT ? PD : NHT - 1 - f)>(G[f % NB]);
+#pragma unroll
+      for (int j = 0; j < TM; ++j) acc[f][j] = Mma<T>::mma(G[f % NB], hb[j], acc[f][j]);
+      if constexpr ((VAR & 8) && f % 2 == 0 && f / 2 < DPW) {
+        if (role == 1) refill_piece(f / 2);
+      }
+    });
+    if constexpr (VAR & 16) {
+      if (role == 0) refill_pair_half(1);
+    }
+    advance();
+    if constexpr (STAMP) {
+      const unsigned long long s4 = now();
+      tk_b1 += s1 - s0; tk_fh += s2 - s1; tk_x += s3 - s2; tk_sh += s4 - s3;
+    }
+  };
+#pragma unroll 1
+  for (int t = 0; t < nt; ++t) substep(t);
+  mfma_results_settle();
+  // ---- stage b (mlp_head): its input is the stage-a result ----
+#pragma unroll
+  for (int j = 0; j < TM; ++j)
+#pragma unroll
+    for (int c = 0; c < NCH / 2; ++c) xo[c][j] = pack_pair(acc[c * 2][j], acc[c * 2 + 1][j]);
+  share_xb();                                              // (its first barrier: every wave is done with stage a's biases too)
+  stage_bias(a.b1b);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // one drain at the switch: the new biases (and whatever the ring had in flight)
+#pragma unroll 1
+  for (int t = 0; t < nt; ++t) substep(t);
+  mfma_results_settle();
+
+  // ---- epilogue: + b2b, token-major store or fold into the NHWC map (own 12 feature tiles) ----
+#pragma unroll
+  for (int i = 0; i < NHT; ++i) {
+    const floatx4 bb = *reinterpret_cast<const floatx4*>(a.b2b + (role * NHT + i) * 16 + 4 * h);
+#pragma unroll
+    for (int j = 0; j < TM; ++j) acc[i][j] += bb;
+  }
+#pragma unroll
+  for (int j = 0; j < TM; ++j) {
+    const long long t = tkn[j];
+    const bool live = t < a.M;
+    const long long tc = live ? t : 0;
+    const int f0 = 16 * (h & 1) + 8 * (h >> 1);
+    if (!a.fmap) {
+      T* yp = (T*)a.Y + tc * D + role * NHT * 16 + f0;
+#pragma unroll
+      for (int i = 0; i < NHT; i += 2) {
+        const uint4 v = pair_tiles16(acc[i][j], acc[i + 1][j]);
+        if (live) *reinterpret_cast<uint4*>(yp + i * 16) = v;
+      }
+    } else {
+      const int tw = a.ws / a.p, S = tw * tw;
+      const int nwx = a.mapW / a.ws, nwy = a.mapH / a.ws;
+      const int tt = (int)(tc % S);
+      const long long wi = tc / S;
+      const int wx = (int)(wi % nwx), wy = (int)((wi / nwx) % nwy);
+      const long long b = wi / ((long long)nwx * nwy);
+      const int y0 = wy * a.ws + (tt / tw) * a.p, x0 = wx * a.ws + (tt % tw) * a.p;
+#pragma unroll
+      for (int i = 0; i < NHT; i += 2) {
+        const int f = (role * NHT + i) * 16 + f0;
+        const int ij = f / a.C, c = f - ij * a.C;
+        const int pi = ij / a.p, pj = ij - pi * a.p;
+        T* dst = (T*)a.fmap + ((b * a.mapH + y0 + pi) * a.mapW + x0 + pj) * a.cs + c;
+        const uint4 v = pair_tiles16(acc[i][j], acc[i + 1][j]);
+        if (live) *reinterpret_cast<uint4*>(dst) = v;
+      }
+    }
+  }
+  if constexpr (STAMP) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    unsigned long long t1;
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t1)::"memory");
+    const unsigned long long rt1 = __builtin_amdgcn_s_memrealtime();
+    if (stamps && blockIdx.x == 0 && blockIdx.z == 0 && lane == 0) {
+      unsigned long long* o = stamps + wave * 8;
+      o[0] = t1 - tk0; o[1] = rt1 - rt0; o[2] = tk_b1; o[3] = tk_fh; o[4] = tk_x; o[5] = tk_sh; o[6] = (unsigned long long)(2 * nt);
+    }
+  }
+}
+
 // s_waitcnt vmcnt(n) for a wave-uniform run-time n (the instruction takes an immediate): a switch over the 64 encodable values
 #define CFEN_VMCASE(k) case k: asm volatile("s_waitcnt vmcnt(" #k ")" ::: "memory"); break;
 CFEN_DEV void wait_vmcnt_rt(int n) {
@@ -784,8 +1227,43 @@ int launch_mlp3(int ng, const Mlp3Args* ap, hipStream_t s) {
   return CFEN_OK;
 }
 
+template <int ND, int R, int HB, int STAMP = 0, int VAR = 0>
+int launch_mlp3p(int ng, const Mlp3Args* ap, hipStream_t s) {
+  Grouped<Mlp3Args> ga;
+  for (int g = 0; g < CFEN_MAX_GROUPS; ++g) ga.g[g] = ap[g < ng ? g : 0];
+  CFEN_CHECK_ARG(ap[0].H <= HB && ap[0].H % 256 == 0, "mlp3 (pair): hidden width %d (a multiple of 256, at most %d)", ap[0].H, HB);
+  const long long per = 128, blocks = (ap[0].M + per - 1) / per;
+  CFEN_CHECK_ARG(blocks > 0 && blocks < (1ll << 31), "mlp3 (pair): bad grid");
+  unsigned long long* stamps = nullptr;
+  if constexpr (STAMP) {
+    static unsigned long long* buf = nullptr;
+    if (!buf && hipMalloc(&buf, 64 * sizeof(unsigned long long)) != hipSuccess) buf = nullptr;
+    stamps = buf;
+    if (stamps) (void)hipMemsetAsync(stamps, 0, 64 * sizeof(unsigned long long), s);
+  }
+  CFEN_LAUNCH((k_mlp3p<ND, R, HB, STAMP, VAR>), dim3((unsigned)blocks, 1, ng), dim3(512), 0, s, ga, stamps);
+  CFEN_CHECK_LAUNCH("mlp3 (pair)");
+  if constexpr (STAMP) {
+    if (stamps && !cfen_recorder()) {
+      unsigned long long hst[64];
+      if (hipStreamSynchronize(s) == hipSuccess && hipMemcpy(hst, stamps, sizeof(hst), hipMemcpyDeviceToHost) == hipSuccess)
+        for (int w = 0; w < 8; ++w) {
+          const unsigned long long* o = hst + w * 8;
+          const double n = o[6] ? (double)o[6] : 1.0;
+          fprintf(stderr, "mlp3p stamps wave %d (role %d): %llu cyc in %.1f us; per sub-step: wait + barrier %.0f, first half %.0f, repack + exchange %.0f, second half %.0f cyc\n", w, w >> 2, o[0],
+                  (double)o[1] / 100.0, o[2] / n, o[3] / n, o[4] / n, o[5] / n);
+        }
+    }
+  }
+  return CFEN_OK;
+}
+
 }  // namespace
 
+int& cfen_tune_mlp3_pair() {   // D = 384 blocks on k_mlp3p (two waves per SIMD, the hidden dimension split over a wave pair): 0 off, 1 on, 2 on with stamps ("mlp3.pair")
+  static int v = 0;
+  return v;
+}
 int& cfen_tune_mlp3_tm192() {   // the D = 192 variant: 22 (default, round 5) = 2 token tiles a wave at 256 registers on a three-slot ring, two 78 KB workgroups a CU; 24 = the same
   static int v = 22;            // on four slots (one workgroup a CU); 4 / 3 / 2 token tiles a wave on the six-slot ring of one 150 KB workgroup a CU (512 registers)
   return v;
@@ -823,6 +1301,17 @@ int cfen_mlp3_impl_g(int dtype, int ng, const Mlp3Args* ap, hipStream_t s) {
                    (a.ln_g == nullptr) == (ap[0].ln_g == nullptr) && (a.Wp == nullptr) == (ap[0].Wp == nullptr) && (a.fmap == nullptr) == (ap[0].fmap == nullptr),
                    "mlp3: grouped problems must have the same shape");
   }
+  if (ap[0].D == 384 && cfen_tune_mlp3_pair() && ap[0].Wp && ap[0].ln_g && ap[0].Wb && ap[0].H % 256 == 0)
+    switch (cfen_tune_mlp3_pair()) {
+      case 2: return launch_mlp3p<24, 3, 1536, 1>(ng, ap, s);
+      case 3: return launch_mlp3p<24, 3, 1536, 0, 1>(ng, ap, s);
+      case 4: return launch_mlp3p<24, 3, 1536, 0, 2>(ng, ap, s);
+      case 5: return launch_mlp3p<24, 3, 1536, 0, 4>(ng, ap, s);
+      case 6: return launch_mlp3p<24, 3, 1536, 1, 16>(ng, ap, s);
+      case 7: return launch_mlp3p<24, 3, 1536, 0, 16>(ng, ap, s);
+      case 8: return launch_mlp3p<24, 3, 1536, 0, 20>(ng, ap, s);
+      default: return launch_mlp3p<24, 3, 1536>(ng, ap, s);
+    }
   if (ap[0].D == 384 && cfen_tune_mlp3_debug() == 1) return launch_mlp3<24, 2, 3, 1536, 1>(ng, ap, s);
   if (ap[0].D == 384 && cfen_tune_mlp3_debug() == 2) return launch_mlp3<24, 2, 3, 1536, 2>(ng, ap, s);
   if (ap[0].D == 384 && cfen_tune_mlp3_debug() == 8) return launch_mlp3<24, 1, 3, 1536, 0, 2, 8>(ng, ap, s);   // round-5 A/B: 8 waves x 1 tile, two waves per SIMD
