@@ -1,3 +1,5 @@
+"""k_mlp3p (knob mlp3.pair) against the shipped k_mlp3<24, ...>: one launch alone, timing + error against an fp64 restatement + stamps.
+  python3 tools/dbg_mlp3_pair.py [variants, e.g. 9] [stamped variant, e.g. 10]   (profiles/r06_mlp3_pair_variants.txt)"""
 import os, sys
 sys.path.insert(0, os.getcwd())
 import torch
@@ -13,7 +15,9 @@ def timeit(f, n=12):
     ts.sort(); return ts[len(ts) // 2]
 D, H = 384, 1536
 torch.manual_seed(0)
-for M in (2048, 24576):
+VARIANTS = [int(v) for v in sys.argv[1].split(",")] if len(sys.argv) > 1 else [9]
+STAMPED = int(sys.argv[2]) if len(sys.argv) > 2 else 10
+for M in (1000, 2048, 24576):
     r = lambda *s, sc=1.0: (torch.randn(*s, device=d) * sc).half()
     x, att = r(M, D), r(M, D)
     wp, w1a, w2a, w1b, w2b = r(D, D, sc=D ** -0.5), r(H, D, sc=D ** -0.5), r(D, H, sc=H ** -0.5), r(H, D, sc=D ** -0.5), r(D, H, sc=H ** -0.5)
@@ -36,12 +40,14 @@ for M in (2048, 24576):
     torch.cuda.synchronize()
     again = call().float()
     t1 = timeit(call)
-    for v in (7, 8):
+    for v in VARIANTS:
         ops.tune("mlp3.pair", v)
         o2 = call().float()
-        print("   variant %d: %.1f us (equal to pair: %s)" % (v, timeit(call), bool(torch.equal(o2, out))), flush=True)
+        torch.cuda.synchronize()
+        o3 = call().float()
+        print("   variant %d: %.1f us (max |. - pair| %.3e, vs fp64 %.3e, deterministic %s)" % (v, timeit(call), float((o2 - out).abs().max()), float((o2.double() - Y2).abs().max()), bool(torch.equal(o2, o3))), flush=True)
     sys.stderr.write("==== M=%d\n" % M); sys.stderr.flush()
-    ops.tune("mlp3.pair", 6)
+    ops.tune("mlp3.pair", STAMPED)
     for _ in range(2):
         flush.fill_(1); call(); torch.cuda.synchronize()
     ops.tune("mlp3.pair", 0)
