@@ -492,19 +492,16 @@ struct Mlp3pOffW2 { template <int k> static constexpr int at() { return k; } };
 //   LayerNorm sums cross the pair through the same 8 KB; the fp16 operand (LN(x), then y1) crosses in two rounds through the ring slot that is free at that moment.
 // Same fragment streams, same arithmetic per element except the LayerNorm sums' association (own 192 features + the partner's): not bit-equal to k_mlp3, equal to tolerance.
 // Only workgroup barriers -- no spin waits.  LDS: 3 double-phase slots (144 KB) + the current stage's hidden biases (6 KB) + the exchange area (8 KB).
-// VAR (A/B): bit 0 = both roles issue half of their refill pieces at the head of either half of a sub-step (else role 0 all six in the first half, role 1 all six in the second);
-// bit 1 / bit 2 = s_setprio 1 for the role-1 / role-0 waves (the second-dispatched half of a workgroup loses the issue arbitration otherwise: MI355X_MICROARCH.md, two waves per SIMD)
-template <int ND, int R, int HB, int STAMP = 0, int VAR = 0>
+// Measured and dropped (profiles/r06_mlp3_pair_variants.txt; the code is in the history): other placements of the refill pieces (split over both halves, spread between the MFMAs,
+// all on role 0 behind its last MFMA of either half), s_setprio on either role, deeper fragment read-ahead, and a skewed pipeline with one barrier per sub-step.
+template <int ND, int R, int HB, int STAMP = 0>
 __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_mlp3p(Grouped<Mlp3Args> ga, unsigned long long* stamps) {
   typedef half_t T;
   typedef half8 frag;
   typedef _Float16 half4v __attribute__((ext_vector_type(4)));
   const Mlp3Args a = ga.g[blockIdx.z];
-  // VAR & 32: the skewed pipeline (one workgroup barrier per sub-step, below); its exchange area is double-buffered and the hidden biases come through scalar loads: 144 + 16 KB
-  constexpr bool SKEW = (VAR & 32) != 0;
-  constexpr int TM = 2, NW = 8, NHT = ND / 2, D = ND * 16, NCH = ND / 2, NF = 2 * ND, SLOT = NF * 1024, DPW = NF / NW, RING = R * SLOT, BIAS = SKEW ? 0 : HB * 4, EXCH = (SKEW ? 2 : 1) * NW * 1024;
-  static_assert(ND % 4 == 0 && NF % NW == 0 && ND % NW == 0 && R >= 3 && (R - 2) * DPW < 64 && NCH % 2 == 0, "ring geometry");
-  static_assert(!SKEW || R == 3, "the skewed pipeline's half-slot schedule is written for three slots");
+  constexpr int TM = 2, NW = 8, NHT = ND / 2, D = ND * 16, NCH = ND / 2, NF = 2 * ND, SLOT = NF * 1024, DPW = NF / NW, RING = R * SLOT, BIAS = HB * 4, EXCH = NW * 1024;
+  static_assert(ND % 4 == 0 && NF % NW == 0 && R >= 3 && (R - 2) * DPW < 64 && NCH % 2 == 0, "ring geometry");
   static_assert(RING + BIAS + EXCH <= 160 * 1024, "LDS");
   __shared__ __attribute__((aligned(1024))) unsigned char lds[RING + BIAS + EXCH];
 
@@ -542,7 +539,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     rt0 = __builtin_amdgcn_s_memrealtime();
   }
   // ---- prologue: stage-a biases, the first R - 1 phases, own feature half of x, the whole attention row (projection B operand) ----
-  if constexpr (!SKEW) stage_bias(a.b1a);
+  stage_bias(a.b1a);
 #pragma unroll
   for (int q = 0; q < R - 1; ++q)
     if (q < NP) issue(q, q);
@@ -568,52 +565,12 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 
   int p = 0, cur = 0, fill = R - 1;
-  // VAR & 16: the role-0 waves (the first-dispatched half: they win the issue arbitration on their SIMD and finish either half of a sub-step first) issue ALL refill pieces, half of
-  // them behind their last MFMA of the first half, half behind their last MFMA of the second -- where they would wait for their partners at the barrier anyway.  Role 0 then counts
-  // 2 DPW pieces per phase, role 1 none.
-  constexpr int DPW0 = (VAR & 16) ? 2 * DPW : DPW;
-  static_assert((R - 2) * DPW0 < 64, "vmcnt range");
   auto begin = [&]() {
-    if constexpr (VAR & 16) {
-      if (role == 0) wait_phases<DPW0, R - 2>(min(R - 2, NP - 1 - p));
-    } else {
-      wait_phases<DPW, R - 2>(min(R - 2, NP - 1 - p));
-    }
+    wait_phases<DPW, R - 2>(min(R - 2, NP - 1 - p));
     __builtin_amdgcn_s_barrier();
-  };
-  // role 0, VAR & 16: fragments f = kk * 4 + (wave & 3), kk = 6 part .. 6 part + 5, of the phase two ahead
-  auto refill_pair_half = [&](int part) {
-    if (p + R - 1 < NP) {
-      const unsigned char* src = phase_src(p + R - 1);
-#pragma unroll
-      for (int kk = 0; kk < DPW; ++kk) {
-        const int f = (part * DPW + kk) * 4 + q4;
-        st_dma(src + f * 1024 + lane * 16, lds + fill * SLOT + f * 1024);
-      }
-    }
   };
   auto refill = [&]() {
     if (p + R - 1 < NP) issue(p + R - 1, fill);
-  };
-  // the sub-steps issue their refill in two halves, one at the head of either half of the sub-step, in BOTH roles: a wave is held 70-80 cycles per piece, and with all six in one
-  // role's half the other role waited at the next barrier (stamps: second half 540 cycles without the pieces, 970 with)
-  // VAR & 8: one piece at a time, between the MFMAs of the issuing role's half of the sub-step (the 70-80 cycles a piece holds its wave pass under the partner's MFMAs AND the
-  // wave's own MFMAs follow at once, instead of six pieces in front of its first MFMA)
-  auto refill_piece = [&](int kk) {
-    if (p + R - 1 < NP) {
-      const int f = kk * NW + wave;
-      st_dma(phase_src(p + R - 1) + f * 1024 + lane * 16, lds + fill * SLOT + f * 1024);
-    }
-  };
-  auto refill_half = [&](int part) {
-    if (p + R - 1 < NP) {
-      const unsigned char* src = phase_src(p + R - 1);
-#pragma unroll
-      for (int k = 0; k < DPW / 2; ++k) {
-        const int f = (part * (DPW / 2) + k) * NW + wave;
-        st_dma(src + f * 1024 + lane * 16, lds + fill * SLOT + f * 1024);
-      }
-    }
   };
   auto advance = [&]() {
     fill = cur;
@@ -622,7 +579,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   };
   const unsigned lbase = (unsigned)(unsigned long long)(__attribute__((address_space(3))) unsigned char*)lds;
   const unsigned lfrag = lbase + lane * 16;
-  constexpr int PD = (VAR & 128) ? 3 : (VAR & 256) ? 5 : (VAR & 512) ? 6 : 4, NB = PD + 2;
+  constexpr int PD = 3, NB = PD + 2;      // fragment reads ahead of the MFMAs (3 = 4 > 5, 6 measured: the waves do not wait for these reads)
   // a run of N fragments at compile-time offsets OFF(k) * 1024 from `sa`: reads PD ahead, counted waits (k_mlp3's idiom)
   auto run = [&](unsigned sa, auto offc, auto nc, auto&& pre, auto&& body) {
     constexpr int N = decltype(nc)::value;
@@ -649,14 +606,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
       constexpr int qq = decltype(qc)::value;
       begin();
       run(lfrag + cur * SLOT + role * (NHT * 1024), OffProj{}, std::integral_constant<int, 2 * NHT>{},
-          [&]() {
-            if constexpr (VAR & 16) {
-              if (role == 0) { refill_pair_half(0); refill_pair_half(1); }
-            } else {
-              refill();
-            }
-            advance();
-          },
+          [&]() { refill(); advance(); },
           [&](auto fc, const frag& fr) {
             constexpr int f = decltype(fc)::value, c = 2 * qq + f / NHT, i = f % NHT;
 #pragma unroll
@@ -703,8 +653,6 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     });
   };
 
-  if constexpr (VAR & 2) { if (role == 1) __builtin_amdgcn_s_setprio(1); }
-  if constexpr (VAR & 4) { if (role == 0) __builtin_amdgcn_s_setprio(1); }
   // ---- LayerNorm(x) over all 384 features -> xb; the stage-a output bias joins the residual ----
   {
     float sm[TM], qv[TM], mean[TM], rstd[TM];
@@ -782,8 +730,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         constexpr int f = decltype(fc)::value;
         lds_rd<2 * (f % HN) * 1024>(F[f % NB], f < HN ? sa1 : sa2);
       });
-      if constexpr (VAR & 1) refill_half(0);
-      else if constexpr (!(VAR & 24)) { if (role == 0) refill(); }
+      if (role == 0) refill();        // role 0's six pieces here, role 1's at the head of the second half: each burst passes under the partner's MFMAs
       sfor<0, N>([&](auto fc) {
         constexpr int f = decltype(fc)::value, g = f + PD;
         if constexpr (g < N) lds_rd<2 * (g % HN) * 1024>(F[g % NB], g < HN ? sa1 : sa2);
@@ -797,9 +744,6 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         for (int j = 0; j < TM; ++j) {
           if constexpr (f < HN) hacc[j] = Mma<T>::mma(F[f % NB], xo[f][j], hacc[j]);
           else hacc[j] = Mma<T>::mma(F[f % NB], xp[f - HN][j], hacc[j]);
-        }
-        if constexpr ((VAR & 8) && f % 2 == 0 && f / 2 < DPW) {
-          if (role == 0) refill_piece(f / 2);
         }
       });
     }
@@ -819,9 +763,6 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
       own[j] = __builtin_elementwise_max(v, z);
       *reinterpret_cast<half4v*>(exch + wave * 1024 + (j * 64 + lane) * 8) = own[j];
     }
-    if constexpr (VAR & 16) {
-      if (role == 0) refill_pair_half(0);
-    }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();                        // both tiles of every pair are in the exchange area (overwritten again behind the next sub-step's first barrier)
     frag hb[TM];
@@ -834,180 +775,20 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     const unsigned long long s3 = now();
     // y[own 192 features] += W2[own rows, the slice] . relu(h)
-    if constexpr (VAR & 1) refill_half(1);
-    else if constexpr (!(VAR & 24)) { if (role == 1) refill(); }
+    if (role == 1) refill();
     sfor<0, NHT>([&](auto fc) {
       constexpr int f = decltype(fc)::value, g = f + PD;
       if constexpr (g < NHT) lds_rd<g * 1024>(G[g % NB], sa3);
       lds_wait<(g < NHT ? PD : NHT - 1 - f)>(G[f % NB]);
 #pragma unroll
       for (int j = 0; j < TM; ++j) acc[f][j] = Mma<T>::mma(G[f % NB], hb[j], acc[f][j]);
-      if constexpr ((VAR & 8) && f % 2 == 0 && f / 2 < DPW) {
-        if (role == 1) refill_piece(f / 2);
-      }
     });
-    if constexpr (VAR & 16) {
-      if (role == 0) refill_pair_half(1);
-    }
     advance();
     if constexpr (STAMP) {
       const unsigned long long s4 = now();
       tk_b1 += s1 - s0; tk_fh += s2 - s1; tk_x += s3 - s2; tk_sh += s4 - s3;
     }
   };
-  // ---- VAR & 32: the skewed pipeline.  Iteration t of a stage runs the first half of sub-step t + 1 (h = W1 xb over slot p + 1's W1 fragments) and THEN the second half of sub-step
-  // t (y += W2 relu(h) over slot p's W2 fragments): the hidden tile of sub-step t + 1 is written to the exchange area in the middle of iteration t and read behind the NEXT
-  // iteration's ring barrier, so a sub-step has ONE workgroup barrier and neither the settle / repack / ds_write / ds_read round trip of the exchange nor its barrier sits between
-  // dependent MFMAs (stamps of the two-barrier form: ~300 cycles per sub-step with both waves of a SIMD idle).  The ring is refilled in HALF slots: iteration p consumes
-  // [W2(p) | W1(p + 1)] -- the byte range one half slot further down the same stream -- and refills [W2(p + 2) -> slot p + 2 | W1(p + 3) -> slot p], both free since its barrier
-  // (three pieces per wave each); the wait in front of barrier p + 1 leaves iteration p's own pieces in flight.  The last iteration of stage a leaves W1(p + 3) to the stage
-  // switch (the operand exchange needs that slot whole).  Hidden biases: 16 floats per (sub-step, role) through s_load_dwordx16 two iterations ahead -- issued right behind the
-  // barrier, OLDER than every LDS read of the iteration (an outstanding older SMEM only makes the counted lgkmcnt waits conservative), landed by the next barrier's lgkmcnt(0).
-  typedef float floatx16 __attribute__((ext_vector_type(16)));
-  auto issue_part = [&](int q, int slot, int part) {
-    const unsigned char* src = phase_src(q) + part * (ND * 1024);
-    unsigned char* dst = lds + slot * SLOT + part * (ND * 1024);
-#pragma unroll
-    for (int kk = 0; kk < ND / NW; ++kk) {
-      const int f = kk * NW + wave;
-      st_dma(src + f * 1024 + lane * 16, dst + f * 1024);
-    }
-  };
-  // lane (r16, h) takes floats 4 h .. 4 h + 3 of the 16 in SGPRs: an exact sum of products with 0 / 1 lane masks (v_fma with one SGPR operand each).  A select chain does not
-  // work here: v_cndmask reads its mask over the constant bus, so every SGPR value first needs a VGPR copy -- hipcc's 16 copies spilled an operand fragment in the sub-step loop.
-  auto bias_of = [&](const floatx16& sb) {
-    floatx4 b = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int kq = 0; kq < 4; ++kq) {
-      float m = h == kq ? 1.f : 0.f;
-      asm volatile("" : "+v"(m));
-#pragma unroll
-      for (int r = 0; r < 4; ++r) b[r] = __builtin_fmaf(sb[4 * kq + r], m, b[r]);
-    }
-    return b;
-  };
-  auto stage_skew = [&](const float* b1, bool last_stage, int carry) {
-    const float* bp = b1 + role * 16;
-    int gprev = carry;
-    if (p + 2 < NP) { issue_part(p + 2, fill, 0); gprev += ND / NW; }       // W1(p + 2): the slot the operand exchange just left
-    floatx16 sbn;
-    asm volatile("s_load_dwordx16 %0, %1, 0x0" : "=s"(sbn) : "s"(bp) : "memory");
-    floatx4 hacc[TM];
-    half4v own[TM];
-    const half4v z = {(half_t)0, (half_t)0, (half_t)0, (half_t)0};
-    auto first_half = [&](int slot, auto&& pre) {
-      const unsigned sa1 = lfrag + slot * SLOT + (NCH * role + role) * 1024, sa2 = lfrag + slot * SLOT + (NCH * (1 - role) + role) * 1024;
-      constexpr int N = NCH, HN = NCH / 2;
-      frag F[NB];
-      sfor<0, PD>([&](auto fc) {
-        constexpr int f = decltype(fc)::value;
-        lds_rd<2 * (f % HN) * 1024>(F[f % NB], f < HN ? sa1 : sa2);
-      });
-      pre();
-#pragma unroll
-      for (int j = 0; j < TM; ++j) hacc[j] = floatx4{0.f, 0.f, 0.f, 0.f};
-      sfor<0, N>([&](auto fc) {
-        constexpr int f = decltype(fc)::value, g = f + PD;
-        if constexpr (g < N) lds_rd<2 * (g % HN) * 1024>(F[g % NB], g < HN ? sa1 : sa2);
-        lds_wait<(g < N ? PD : N - 1 - f)>(F[f % NB]);
-#pragma unroll
-        for (int j = 0; j < TM; ++j) {
-          if constexpr (f < HN) hacc[j] = Mma<T>::mma(F[f % NB], xo[f][j], hacc[j]);
-          else hacc[j] = Mma<T>::mma(F[f % NB], xp[f - HN][j], hacc[j]);
-        }
-      });
-    };
-    auto publish = [&](const floatx16& sb, int buf) {      // own hidden tile: relu(h + b1) in fp16 -> registers (the next iteration's B operand half) and the exchange area
-      const floatx4 bv = bias_of(sb);
-#pragma unroll
-      for (int j = 0; j < TM; ++j) {
-        const floatx4 hv = hacc[j] + bv;
-        const half4v v = {(half_t)hv[0], (half_t)hv[1], (half_t)hv[2], (half_t)hv[3]};
-        own[j] = __builtin_elementwise_max(v, z);
-        *reinterpret_cast<half4v*>(exch + buf * (NW * 1024) + wave * 1024 + (j * 64 + lane) * 8) = own[j];
-      }
-    };
-    // sub-step 0's first half on its own (slot p's W1 fragments: landed and fenced by the drain + barriers in front of this stage)
-    asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(sbn)::"memory");
-    first_half(cur, [] {});
-    mfma_results_settle();
-    publish(sbn, 0);
-    asm volatile("s_load_dwordx16 %0, %1, 0x80" : "=s"(sbn) : "s"(bp) : "memory");       // sub-step 1's biases
-    asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(sbn)::"memory");                           // (and the tile just published)
-#pragma unroll 1
-    for (int t = 0; t < nt; ++t) {
-      const unsigned long long s0 = now();
-      // the pieces this wave issued for THIS iteration's fragments have landed; last iteration's group (0, 1 or 2 parts of ND / NW pieces, + a stage's first W1 part) stays in flight
-      if (gprev >= 2 * (ND / NW)) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * (ND / NW)) : "memory");
-      else if (gprev >= ND / NW) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(ND / NW) : "memory");
-      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      __builtin_amdgcn_s_barrier();
-      const unsigned long long s1 = now();
-      const floatx16 sbc = sbn;
-      // (unconditional, and waited for at the bottom of THIS iteration: no compiler-made copy of the destination registers can sit between the load and its wait)
-      asm volatile("s_load_dwordx16 %0, %1, 0x0" : "=s"(sbn) : "s"(bp + min(t + 2, nt - 1) * 32) : "memory");
-      half4v o[TM];
-#pragma unroll
-      for (int j = 0; j < TM; ++j) asm volatile("ds_read_b64 %0, %1" : "=v"(o[j]) : "v"(lbase + RING + (t & 1) * (NW * 1024) + (wave ^ 4) * 1024 + (j * 64 + lane) * 8) : "memory");
-      const bool more = t + 1 < nt;
-      const int nx = cur + 1 == R ? 0 : cur + 1;
-      // this iteration's refill group: W2(p + 2) -> the slot two ahead, W1(p + 3) -> this slot's W1 half (consumed last iteration); the last iteration of stage a leaves the
-      // W1 part to the stage switch
-      const bool w2 = p + 2 < NP, w1 = p + 3 < NP && (last_stage || more);
-      const int g = (w2 ? ND / NW : 0) + (w1 ? ND / NW : 0);
-      auto group = [&]() {
-        if (w2) issue_part(p + 2, fill, 1);
-        if (w1) issue_part(p + 3, cur, 0);
-      };
-      if (more) first_half(nx, [&]() { if (role == 0) group(); });
-      else if (role == 0) group();
-      const unsigned long long s2 = now();
-      const unsigned sa3 = lfrag + cur * SLOT + (ND + role * NHT) * 1024;
-      frag G[NB];
-      sfor<0, PD>([&](auto fc) {
-        constexpr int f = decltype(fc)::value;
-        lds_rd<f * 1024>(G[f % NB], sa3);
-      });
-      if constexpr (!(VAR & 64)) { if (role == 1) group(); }       // role 1's pieces between its halves: under role 0's MFMAs, as role 0's were under role 1's first half
-      frag hb[TM];
-#pragma unroll
-      for (int j = 0; j < TM; ++j) {
-        asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(o[j]) : "n"(PD) : "memory");
-        const half4v lo = role ? o[j] : own[j], hi = role ? own[j] : o[j];
-        hb[j] = frag{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-      }
-      constexpr int WPOS = 2;          // the hidden tile of sub-step t + 1 is published behind this fragment's MFMAs: its accumulators settled under them, the write lands under the rest
-      sfor<0, NHT>([&](auto fc) {
-        constexpr int f = decltype(fc)::value, gg = f + PD;
-        if constexpr (gg < NHT) lds_rd<gg * 1024>(G[gg % NB], sa3);
-        // (the two ds_writes of publish() are younger than the reads of fragments <= WPOS + PD: count them)
-        lds_wait<(gg < NHT ? PD : NHT - 1 - f) + ((f > WPOS && f <= WPOS + PD) ? TM : 0)>(G[f % NB]);
-#pragma unroll
-        for (int j = 0; j < TM; ++j) acc[f][j] = Mma<T>::mma(G[f % NB], hb[j], acc[f][j]);
-        if constexpr (f == WPOS) publish(sbc, (t + 1) & 1);
-      });
-      if constexpr ((VAR & 64) != 0) { if (role == 1) group(); }
-      asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(sbn)::"memory");       // the published tile, every fragment read of the two slots, the next biases
-      gprev = g;
-      advance();
-      if constexpr (STAMP) {
-        const unsigned long long s3 = now();
-        tk_b1 += s1 - s0; tk_fh += s2 - s1; tk_sh += s3 - s2;
-      }
-    }
-    return gprev;
-  };
-  if constexpr (SKEW) {
-    const int left = stage_skew(a.b1a, false, 0);
-    mfma_results_settle();
-#pragma unroll
-    for (int j = 0; j < TM; ++j)
-#pragma unroll
-      for (int c = 0; c < NCH / 2; ++c) xo[c][j] = pack_pair(acc[c * 2][j], acc[c * 2 + 1][j]);
-    share_xb();
-    stage_skew(a.b1b, true, left);
-    mfma_results_settle();
-  } else {
 #pragma unroll 1
   for (int t = 0; t < nt; ++t) substep(t);
   mfma_results_settle();
@@ -1022,7 +803,6 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 #pragma unroll 1
   for (int t = 0; t < nt; ++t) substep(t);
   mfma_results_settle();
-  }
 
   // ---- epilogue: + b2b, token-major store or fold into the NHWC map (own 12 feature tiles) ----
 #pragma unroll
@@ -1382,7 +1162,7 @@ int launch_mlp3(int ng, const Mlp3Args* ap, hipStream_t s) {
   return CFEN_OK;
 }
 
-template <int ND, int R, int HB, int STAMP = 0, int VAR = 0>
+template <int ND, int R, int HB, int STAMP = 0>
 int launch_mlp3p(int ng, const Mlp3Args* ap, hipStream_t s) {
   Grouped<Mlp3Args> ga;
   for (int g = 0; g < CFEN_MAX_GROUPS; ++g) ga.g[g] = ap[g < ng ? g : 0];
@@ -1396,7 +1176,7 @@ int launch_mlp3p(int ng, const Mlp3Args* ap, hipStream_t s) {
     stamps = buf;
     if (stamps) (void)hipMemsetAsync(stamps, 0, 64 * sizeof(unsigned long long), s);
   }
-  CFEN_LAUNCH((k_mlp3p<ND, R, HB, STAMP, VAR>), dim3((unsigned)blocks, 1, ng), dim3(512), 0, s, ga, stamps);
+  CFEN_LAUNCH((k_mlp3p<ND, R, HB, STAMP>), dim3((unsigned)blocks, 1, ng), dim3(512), 0, s, ga, stamps);
   CFEN_CHECK_LAUNCH("mlp3 (pair)");
   if constexpr (STAMP) {
     if (stamps && !cfen_recorder()) {
@@ -1415,8 +1195,8 @@ int launch_mlp3p(int ng, const Mlp3Args* ap, hipStream_t s) {
 
 }  // namespace
 
-int& cfen_tune_mlp3_pair() {   // D = 384 blocks on k_mlp3p (two waves per SIMD, the hidden dimension split over a wave pair): 0 off, 1 on, 2 on with stamps ("mlp3.pair")
-  static int v = 0;
+int& cfen_tune_mlp3_pair() {   // D = 384 blocks on k_mlp3p (two waves per SIMD, the hidden dimension split over a wave pair): 0 = k_mlp3<24, ...>, 1 on (default, round 6: 134-150 us
+  static int v = 1;            // a launch against 152-172; +0.6-1.0 % on the headline step, level on the other two configurations), 2 on with stamps ("mlp3.pair")
   return v;
 }
 int& cfen_tune_mlp3_tm192() {   // the D = 192 variant: 22 (default, round 5) = 2 token tiles a wave at 256 registers on a three-slot ring, two 78 KB workgroups a CU; 24 = the same
@@ -1457,17 +1237,7 @@ int cfen_mlp3_impl_g(int dtype, int ng, const Mlp3Args* ap, hipStream_t s) {
                    "mlp3: grouped problems must have the same shape");
   }
   if (ap[0].D == 384 && cfen_tune_mlp3_pair() && ap[0].Wp && ap[0].ln_g && ap[0].Wb && ap[0].H % 256 == 0)
-    switch (cfen_tune_mlp3_pair()) {
-      case 2: return launch_mlp3p<24, 3, 1536, 1>(ng, ap, s);
-      case 3: return launch_mlp3p<24, 3, 1536, 0, 128>(ng, ap, s);
-      case 4: return launch_mlp3p<24, 3, 1536, 0, 256>(ng, ap, s);
-      case 5: return launch_mlp3p<24, 3, 1536, 0, 512>(ng, ap, s);
-      case 6: return launch_mlp3p<24, 3, 1536, 0, 32 + 256>(ng, ap, s);
-      case 7: return launch_mlp3p<24, 3, 1536, 0, 32 + 512>(ng, ap, s);
-      case 9: return launch_mlp3p<24, 3, 1536, 0, 32>(ng, ap, s);
-      case 10: return launch_mlp3p<24, 3, 1536, 1, 32>(ng, ap, s);
-      default: return launch_mlp3p<24, 3, 1536>(ng, ap, s);
-    }
+    return cfen_tune_mlp3_pair() == 2 ? launch_mlp3p<24, 3, 1536, 1>(ng, ap, s) : launch_mlp3p<24, 3, 1536>(ng, ap, s);
   if (ap[0].D == 384 && cfen_tune_mlp3_debug() == 1) return launch_mlp3<24, 2, 3, 1536, 1>(ng, ap, s);
   if (ap[0].D == 384 && cfen_tune_mlp3_debug() == 2) return launch_mlp3<24, 2, 3, 1536, 2>(ng, ap, s);
   if (ap[0].D == 384 && cfen_tune_mlp3_debug() == 8) return launch_mlp3<24, 1, 3, 1536, 0, 2, 8>(ng, ap, s);   // round-5 A/B: 8 waves x 1 tile, two waves per SIMD

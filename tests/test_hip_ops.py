@@ -847,6 +847,42 @@ def test_mlp_stream_fold_epilogue():
     assert torch.equal(fm, ops.unpatchify(tok, B, Hm, Wm, C, cs, ws, pp))
 
 
+@pytest.mark.parametrize("H,M,fold", [(1536, 24 * 128 + 77, False), (512, 256, True), (256, 130, False)])
+def test_mlp_stream_pair_kernel(H, M, fold):
+    """k_mlp3p (the D = 384 block on wave pairs, "mlp3.pair" = 1, the default): against fp64, against k_mlp3<24, ...> on the same operands (the LayerNorm sums associate over
+    the pair: 1-2 fp16 ulp, not bit-equal), run to run, ragged token counts, the fold epilogue against unpatchify of its own token-major result"""
+    dtype = torch.float16
+    d = dev()
+    D = 384
+    B, C, Hm, Wm, ws, pp, cs = 2, 96, 16, 32, 8, 2, 96
+    x, att = rnd((M, D), 1, dtype), rnd((M, D), 2, dtype)
+    wp = rnd((D, D), 3, dtype, D ** -0.5)
+    g, b = 1 + 0.1 * rnd((D,), 4, torch.float32), 0.1 * rnd((D,), 5, torch.float32)
+    w1a, w2a = rnd((H, D), 6, dtype, D ** -0.5), rnd((D, H), 7, dtype, 0.5 * H ** -0.5)
+    w1b, w2b = rnd((H, D), 8, dtype, D ** -0.5), rnd((D, H), 9, dtype, 0.5 * H ** -0.5)
+    b1a, b2a, b1b, b2b = (0.1 * rnd((n,), 10 + i, torch.float32) for i, n in enumerate((H, D, H, D)))
+    kd, kh = packing.kperm32(D), packing.kperm32(H)
+    sa = packing.pack_stream_pair(w1a[:, kd], w2a[:, kh]).to(d)
+    sb = packing.pack_stream_pair(w1b[:, kd], w2b[:, kh]).to(d)
+    sp = packing.pack_stream_sq(wp).to(d)
+    ffn = lambda v, w1, b1, w2, b2, ln: v + torch.relu((cfen_oracle.layer_norm(v, g.double(), b.double()) if ln else v) @ w1.double().t()
+                                                       + b1.double()) @ w2.double().t() + b2.double()
+    full = ffn(ffn(x.double() + att.double() @ wp.double().t(), w1a, b1a, w2a, b2a, True), w1b, b1b, w2b, b2b, False)
+    call = lambda **kw: ops.mlp_stream_block(x.to(d), sa, b1a.to(d), b2a.to(d), H, ln=(g.to(d), b.to(d)), second=(sb, b1b.to(d), b2b.to(d)), proj=(att.to(d), sp), **kw)
+    try:
+        ops.tune("mlp3.pair", 1)
+        got = call()
+        close(got, full, tol(dtype, 12), "pair kernel")
+        assert torch.equal(got, call())
+        if fold:
+            assert torch.equal(call(fold=(B, Hm, Wm, C, cs, ws, pp)), ops.unpatchify(got, B, Hm, Wm, C, cs, ws, pp))
+        ops.tune("mlp3.pair", 0)
+        single = call()
+        assert float((got.float() - single.float()).abs().max()) <= 2 ** -7 * max(1.0, float(single.float().abs().max()) / 4)
+    finally:
+        ops.tune("mlp3.pair", 1)
+
+
 # ---------------------------------------------------------------------------------------------------
 def _lvit_instance(seed):
     """one LViT level-1 instance (C = 24, D = 96, 4 heads, hidden 384) with the deterministic 'trained' weight distribution"""

@@ -15,8 +15,8 @@ def timeit(f, n=12):
     ts.sort(); return ts[len(ts) // 2]
 D, H = 384, 1536
 torch.manual_seed(0)
-VARIANTS = [int(v) for v in sys.argv[1].split(",")] if len(sys.argv) > 1 else [9]
-STAMPED = int(sys.argv[2]) if len(sys.argv) > 2 else 10
+VARIANTS = [int(v) for v in sys.argv[1].split(",") if v] if len(sys.argv) > 1 else []
+STAMPED = int(sys.argv[2]) if len(sys.argv) > 2 else 2
 for M in (1000, 2048, 24576):
     r = lambda *s, sc=1.0: (torch.randn(*s, device=d) * sc).half()
     x, att = r(M, D), r(M, D)
