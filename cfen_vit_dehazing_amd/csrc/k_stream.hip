@@ -538,6 +538,12 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tk0)::"memory");
     rt0 = __builtin_amdgcn_s_memrealtime();
   }
+  auto now = [&]() -> unsigned long long {
+    unsigned long long tt = 0;
+    if constexpr (STAMP) asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tt)::"memory");
+    return tt;
+  };
+  unsigned long long sec[7] = {0, 0, 0, 0, 0, 0, 0};      // STAMP: section ends -- prologue loads | projection | LayerNorm + operand exchange | stage a | stage switch | stage b | (epilogue = the end)
   // ---- prologue: stage-a biases, the first R - 1 phases, own feature half of x, the whole attention row (projection B operand) ----
   stage_bias(a.b1a);
 #pragma unroll
@@ -563,6 +569,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     }
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  sec[0] = now();
 
   int p = 0, cur = 0, fill = R - 1;
   auto begin = [&]() {
@@ -605,8 +612,14 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     sfor<0, NCH / 2>([&](auto qc) {
       constexpr int qq = decltype(qc)::value;
       begin();
+      // the refill by role, as in the sub-steps: role 0's six pieces at the head of the phase, role 1's behind its first k-chunk (all 48 in one burst: 4550 cycles per
+      // projection phase against the sub-steps' 2600, section stamps)
+      const int rq = p + R - 1, rslot = fill;
       run(lfrag + cur * SLOT + role * (NHT * 1024), OffProj{}, std::integral_constant<int, 2 * NHT>{},
-          [&]() { refill(); advance(); },
+          [&]() {
+            if (role == 0 && rq < NP) issue(rq, rslot);
+            advance();
+          },
           [&](auto fc, const frag& fr) {
             constexpr int f = decltype(fc)::value, c = 2 * qq + f / NHT, i = f % NHT;
 #pragma unroll
@@ -614,10 +627,14 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
               if constexpr (c < NCH / 2) acc[i][j] = Mma<T>::mma(fr, xo[c][j], acc[i][j]);
               else acc[i][j] = Mma<T>::mma(fr, xp[c - NCH / 2][j], acc[i][j]);
             }
+            if constexpr (f == NHT - 1) {
+              if (role == 1 && rq < NP) issue(rq, rslot);
+            }
           });
     });
   }
   mfma_results_settle();
+  sec[1] = now();
 
   unsigned char* exch = lds + RING + BIAS;
   // a float per (token tile, lane) across the pair: own value out, barrier, partner's in
@@ -704,13 +721,9 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // LayerNorm parameters / bias loads: ordinary VMEM in front of the ring's counted waits (the ring is R - 1 phases ahead)
   share_xb();
+  sec[2] = now();
 
   unsigned long long tk_b1 = 0, tk_fh = 0, tk_x = 0, tk_sh = 0;     // STAMP: cycle sums of [wait + first barrier | first half | repack + exchange (second barrier) | second half]
-  auto now = [&]() -> unsigned long long {
-    unsigned long long tt = 0;
-    if constexpr (STAMP) asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tt)::"memory");
-    return tt;
-  };
   // ---- one 32-unit hidden sub-step ----
   auto substep = [&](int t) {
     const unsigned long long s0 = now();
@@ -792,25 +805,30 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 #pragma unroll 1
   for (int t = 0; t < nt; ++t) substep(t);
   mfma_results_settle();
+  sec[3] = now();
   // ---- stage b (mlp_head): its input is the stage-a result ----
 #pragma unroll
   for (int j = 0; j < TM; ++j)
 #pragma unroll
     for (int c = 0; c < NCH / 2; ++c) xo[c][j] = pack_pair(acc[c * 2][j], acc[c * 2 + 1][j]);
+  // the stage-b output bias joins the residual here (its loads pass under the exchange's barriers; in the epilogue they were a memory round trip in front of the stores)
+  floatx4 bb2[NHT];
+#pragma unroll
+  for (int i = 0; i < NHT; ++i) bb2[i] = *reinterpret_cast<const floatx4*>(a.b2b + (role * NHT + i) * 16 + 4 * h);
   share_xb();                                              // (its first barrier: every wave is done with stage a's biases too)
+#pragma unroll
+  for (int i = 0; i < NHT; ++i)
+#pragma unroll
+    for (int j = 0; j < TM; ++j) acc[i][j] += bb2[i];
   stage_bias(a.b1b);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // one drain at the switch: the new biases (and whatever the ring had in flight)
+  sec[4] = now();
 #pragma unroll 1
   for (int t = 0; t < nt; ++t) substep(t);
   mfma_results_settle();
+  sec[5] = now();
 
-  // ---- epilogue: + b2b, token-major store or fold into the NHWC map (own 12 feature tiles) ----
-#pragma unroll
-  for (int i = 0; i < NHT; ++i) {
-    const floatx4 bb = *reinterpret_cast<const floatx4*>(a.b2b + (role * NHT + i) * 16 + 4 * h);
-#pragma unroll
-    for (int j = 0; j < TM; ++j) acc[i][j] += bb;
-  }
+  // ---- epilogue: token-major store or fold into the NHWC map (own 12 feature tiles) ----
 #pragma unroll
   for (int j = 0; j < TM; ++j) {
     const long long t = tok0 + j * 16 + r16;
@@ -851,6 +869,8 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     if (stamps && blockIdx.x == 0 && blockIdx.z == 0 && lane == 0) {
       unsigned long long* o = stamps + wave * 8;
       o[0] = t1 - tk0; o[1] = rt1 - rt0; o[2] = tk_b1; o[3] = tk_fh; o[4] = tk_x; o[5] = tk_sh; o[6] = (unsigned long long)(2 * nt);
+      unsigned long long* q = stamps + 64 + wave * 8;
+      q[0] = sec[0] - tk0; q[1] = sec[1] - sec[0]; q[2] = sec[2] - sec[1]; q[3] = sec[3] - sec[2]; q[4] = sec[4] - sec[3]; q[5] = sec[5] - sec[4]; q[6] = t1 - sec[5];
     }
   }
 }
@@ -1172,21 +1192,22 @@ int launch_mlp3p(int ng, const Mlp3Args* ap, hipStream_t s) {
   unsigned long long* stamps = nullptr;
   if constexpr (STAMP) {
     static unsigned long long* buf = nullptr;
-    if (!buf && hipMalloc(&buf, 64 * sizeof(unsigned long long)) != hipSuccess) buf = nullptr;
+    if (!buf && hipMalloc(&buf, 128 * sizeof(unsigned long long)) != hipSuccess) buf = nullptr;
     stamps = buf;
-    if (stamps) (void)hipMemsetAsync(stamps, 0, 64 * sizeof(unsigned long long), s);
+    if (stamps) (void)hipMemsetAsync(stamps, 0, 128 * sizeof(unsigned long long), s);
   }
   CFEN_LAUNCH((k_mlp3p<ND, R, HB, STAMP>), dim3((unsigned)blocks, 1, ng), dim3(512), 0, s, ga, stamps);
   CFEN_CHECK_LAUNCH("mlp3 (pair)");
   if constexpr (STAMP) {
     if (stamps && !cfen_recorder()) {
-      unsigned long long hst[64];
+      unsigned long long hst[128];
       if (hipStreamSynchronize(s) == hipSuccess && hipMemcpy(hst, stamps, sizeof(hst), hipMemcpyDeviceToHost) == hipSuccess)
         for (int w = 0; w < 8; ++w) {
-          const unsigned long long* o = hst + w * 8;
+          const unsigned long long *o = hst + w * 8, *q = hst + 64 + w * 8;
           const double n = o[6] ? (double)o[6] : 1.0;
-          fprintf(stderr, "mlp3p stamps wave %d (role %d): %llu cyc in %.1f us; per sub-step: wait + barrier %.0f, first half %.0f, repack + exchange %.0f, second half %.0f cyc\n", w, w >> 2, o[0],
-                  (double)o[1] / 100.0, o[2] / n, o[3] / n, o[4] / n, o[5] / n);
+          fprintf(stderr, "mlp3p stamps wave %d (role %d): %llu cyc in %.1f us; per sub-step: wait + barrier %.0f, first half %.0f, repack + exchange %.0f, second half %.0f cyc; sections: prologue loads %llu, "
+                  "projection %llu, LayerNorm + operand exchange %llu, stage a %llu, switch %llu, stage b %llu, epilogue %llu cyc\n", w, w >> 2, o[0],
+                  (double)o[1] / 100.0, o[2] / n, o[3] / n, o[4] / n, o[5] / n, q[0], q[1], q[2], q[3], q[4], q[5], q[6]);
         }
     }
   }

@@ -6,10 +6,11 @@ import torch
 from cfen_vit_dehazing_amd import ops, packing
 d = "cuda:0"
 flush = torch.empty(256 << 20, dtype=torch.uint8, device=d)
-def timeit(f, n=12):
+def timeit(f, n=12, cold=True):
     f(); f(); torch.cuda.synchronize(); ts = []
     for _ in range(n):
-        flush.fill_(1)
+        if cold:
+            flush.fill_(1)
         s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         s.record(); f(); e.record(); torch.cuda.synchronize(); ts.append(s.elapsed_time(e) * 1e3)
     ts.sort(); return ts[len(ts) // 2]
@@ -40,6 +41,7 @@ for M in (1000, 2048, 24576):
     torch.cuda.synchronize()
     again = call().float()
     t1 = timeit(call)
+    print("   warm caches (no 256 MiB fill between launches): pair %.1f us" % timeit(call, cold=False), flush=True)
     for v in VARIANTS:
         ops.tune("mlp3.pair", v)
         o2 = call().float()
