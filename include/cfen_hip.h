@@ -59,6 +59,8 @@ const char* cfen_last_error(void);
  *                  plan -- which kernels produce the outputs does not depend on the launch plan or on profiling
  *   "gvit.max_concurrent": 1 (default) .. 8: forwards of the persistent-chain plan ("net.gvit_chain") that may be in flight at once; the teams of all of them
  *                  must be resident together (grid barriers), so the host caps a team at 256 / (groups x this) CUs
+ *   "mlp3.pair" (default 1, round 6): the D = 384 block (projection + LayerNorm + both stages) on k_mlp3p -- wave pairs, two waves per SIMD; 0 = k_mlp3<24, ...> (one wave per SIMD;
+ *       results equal to 1-2 fp16 ulp: the LayerNorm sums associate over the pair); 2 = k_mlp3p's stamped timing build (prints to stderr, synchronises)
  *   "net.stream_mlp192" (default 1) / "mlp3.tm192" (default 22): LViT level 2's proj + MLP block on k_mlp3: 22 = two 4-wave 78 KB workgroups a CU on a three-slot ring
  *                  (256 registers); 24 four slots; 28 / 29 one 8-wave workgroup a CU; 2 / 3 / 4 token tiles a wave on one 150 KB workgroup a CU; net.stream_mlp192 = 0: k_mlp2
  *   "embed.stages": 2 .. 5 ring stages of k_embed_qkv2 at D = 192 (default 4)
