@@ -298,6 +298,29 @@ def main():
     # CFEN_BENCH_LANE_PRIORITIES="-1,0,0,0" (what-if probe): stream priorities of the lanes (lower = more urgent); default: all equal
     prios = [int(v) for v in os.environ.get("CFEN_BENCH_LANE_PRIORITIES", "").split(",") if v.strip()]
     lanes = [torch.cuda.Stream(dev, priority=prios[k % len(prios)]) if prios else torch.cuda.Stream(dev) for k in range(nfl)] if nfl > 1 else None
+    # CFEN_BENCH_CU_MASK="xcd" | "spread" (what-if probe, round 6): every lane gets its own share of the CUs (hipExtStreamCreateWithCUMask; a serial hipGraph replays on its
+    # stream's hardware queue) -- "xcd": whole XCDs per lane (mask bit i = CU i / 8 of XCD i % 8), "spread": 32 / nfl CUs of every XCD per lane
+    cu_mask_mode = os.environ.get("CFEN_BENCH_CU_MASK", "")
+    if cu_mask_mode and nfl > 1:
+        import ctypes
+        hip = ctypes.CDLL("libamdhip64.so")
+        ncu, nx = torch.cuda.get_device_properties(dev).multi_processor_count, 8
+        parts = int(os.environ.get("CFEN_BENCH_CU_PARTS", str(nfl)))       # lanes k and k + parts share a partition
+        lanes = []
+        for k in range(nfl):
+            bits = [0] * ((ncu + 31) // 32)
+            for i in range(ncu):
+                xcd, cu = i % nx, i // nx
+                mine = (xcd * parts // nx == k % parts) if cu_mask_mode == "xcd" else (cu * parts // (ncu // nx) == k % parts)
+                if mine:
+                    bits[i // 32] |= 1 << (i % 32)
+            arr = (ctypes.c_uint32 * len(bits))(*bits)
+            h = ctypes.c_void_p()
+            rc = hip.hipExtStreamCreateWithCUMask(ctypes.byref(h), ctypes.c_uint32(len(bits)), arr)
+            if rc != 0:
+                raise RuntimeError("hipExtStreamCreateWithCUMask failed: %d" % rc)
+            lanes.append(torch.cuda.ExternalStream(h.value, device=dev))
+        sys.stderr.write("lanes on CU masks (%s): %d partitions of %d CUs\n" % (cu_mask_mode, parts, ncu // parts))
     if not args.no_graph:
         graphs = []
         for k, s in enumerate(slabs):          # native hipGraph per output slab (and, with two forwards in flight, per launch-plan replica)
