@@ -561,11 +561,15 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     const T* xrow = (const T*)a.X + t * D + (role * NHT) * 16 + 4 * h;
 #pragma unroll
     for (int i = 0; i < NHT; ++i) acc[i][j] = load4<T>(xrow + i * 16);
-    const T* ap = (const T*)a.A + t * D + h * 8;
+    // the attention row (the projection's B operand): this wave's OWN k-chunks only; the partner's half crosses through LDS below (both roles loading the whole row was 98 KB
+    // more per workgroup in a prologue that runs at the cold-burst rate of a CU, ~14 B/cycle)
+    const T* ap = (const T*)a.A + t * D + (role * (NCH / 2)) * 32 + h * 8;
+    if (role == 0) {
 #pragma unroll
-    for (int c = 0; c < NCH / 2; ++c) {
-      xo[c][j] = load_frag<T>(ap + c * 32);
-      xp[c][j] = load_frag<T>(ap + (NCH / 2 + c) * 32);
+      for (int c = 0; c < NCH / 2; ++c) xo[c][j] = load_frag<T>(ap + c * 32);
+    } else {
+#pragma unroll
+      for (int c = 0; c < NCH / 2; ++c) xp[c][j] = load_frag<T>(ap + c * 32);
     }
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -607,35 +611,6 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   typedef Mlp3pOffW1 OffW1;             // fragment (c = k, u = role) (base + role fragments)
   typedef Mlp3pOffW2 OffW2;             // own feature tile k (base + ND + 12 r fragments)
 
-  // ---- x += Wp att: double phase qq = k-chunks 2 qq, 2 qq + 1; this wave: its 12 feature tiles of both ----
-  if (true) {
-    sfor<0, NCH / 2>([&](auto qc) {
-      constexpr int qq = decltype(qc)::value;
-      begin();
-      // the refill by role, as in the sub-steps: role 0's six pieces at the head of the phase, role 1's behind its first k-chunk (all 48 in one burst: 4550 cycles per
-      // projection phase against the sub-steps' 2600, section stamps)
-      const int rq = p + R - 1, rslot = fill;
-      run(lfrag + cur * SLOT + role * (NHT * 1024), OffProj{}, std::integral_constant<int, 2 * NHT>{},
-          [&]() {
-            if (role == 0 && rq < NP) issue(rq, rslot);
-            advance();
-          },
-          [&](auto fc, const frag& fr) {
-            constexpr int f = decltype(fc)::value, c = 2 * qq + f / NHT, i = f % NHT;
-#pragma unroll
-            for (int j = 0; j < TM; ++j) {
-              if constexpr (c < NCH / 2) acc[i][j] = Mma<T>::mma(fr, xo[c][j], acc[i][j]);
-              else acc[i][j] = Mma<T>::mma(fr, xp[c - NCH / 2][j], acc[i][j]);
-            }
-            if constexpr (f == NHT - 1) {
-              if (role == 1 && rq < NP) issue(rq, rslot);
-            }
-          });
-    });
-  }
-  mfma_results_settle();
-  sec[1] = now();
-
   unsigned char* exch = lds + RING + BIAS;
   // a float per (token tile, lane) across the pair: own value out, barrier, partner's in
   auto pair_sum = [&](float (&v)[TM], int off) {
@@ -649,8 +624,8 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
       v[j] = role ? o + v[j] : v[j] + o;              // the SAME association in both waves of the pair: role 0's half first
     }
   };
-  // xo holds this wave's k-chunks of the B operand; fetch the partner's into xp through the ring slot that is free right now (`fill`: the phase before the current one)
-  auto share_xb = [&]() {
+  // `mine` holds six k-chunks of the B operand, the partner's six go to `theirs`, through the ring slot that is free right now (`fill`: the phase before the current one)
+  auto share_half = [&](frag (&mine)[NCH / 2][TM], frag (&theirs)[NCH / 2][TM]) {
     unsigned char* area = lds + fill * SLOT;                        // 48 KiB: 8 waves x 3 chunks x 2 tiles x 1 KiB per round
     __builtin_amdgcn_s_barrier();                                   // every wave is done with that slot's fragments (and with the exchange area)
     sfor<0, 2>([&](auto rdc) {
@@ -658,17 +633,48 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 #pragma unroll
       for (int cc = 0; cc < 3; ++cc)
 #pragma unroll
-        for (int j = 0; j < TM; ++j) *reinterpret_cast<frag*>(area + ((wave * 3 + cc) * TM + j) * 1024 + lane * 16) = xo[rd * 3 + cc][j];
+        for (int j = 0; j < TM; ++j) *reinterpret_cast<frag*>(area + ((wave * 3 + cc) * TM + j) * 1024 + lane * 16) = mine[rd * 3 + cc][j];
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       __builtin_amdgcn_s_barrier();
 #pragma unroll
       for (int cc = 0; cc < 3; ++cc)
 #pragma unroll
-        for (int j = 0; j < TM; ++j) xp[rd * 3 + cc][j] = *reinterpret_cast<const frag*>(area + (((wave ^ 4) * 3 + cc) * TM + j) * 1024 + lane * 16);
+        for (int j = 0; j < TM; ++j) theirs[rd * 3 + cc][j] = *reinterpret_cast<const frag*>(area + (((wave ^ 4) * 3 + cc) * TM + j) * 1024 + lane * 16);
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       __builtin_amdgcn_s_barrier();                                 // (the second one also protects the slot against the next phase's refill)
     });
   };
+  auto share_xb = [&]() { share_half(xo, xp); };                    // the role-relative form: xo = own chunks, xp = the partner's (LayerNorm output, stage-a result)
+  // ---- x += Wp att: double phase qq = k-chunks 2 qq, 2 qq + 1; this wave: its 12 feature tiles of both ----
+  // xo = k-chunks 0 .. 5 of the attention row, xp = 6 .. 11 in BOTH roles here (role 0 loaded xo, role 1 xp: the other half crosses through LDS; slot R - 1 is free, the
+  // prologue filled slots 0 .. R - 2)
+  if (role == 0) share_half(xo, xp);
+  else share_half(xp, xo);
+  sfor<0, NCH / 2>([&](auto qc) {
+    constexpr int qq = decltype(qc)::value;
+    begin();
+    // the refill by role, as in the sub-steps: role 0's six pieces at the head of the phase, role 1's behind its first k-chunk (all 48 in one burst: 4550 cycles per
+    // projection phase against the sub-steps' 2600, section stamps)
+    const int rq = p + R - 1, rslot = fill;
+    run(lfrag + cur * SLOT + role * (NHT * 1024), OffProj{}, std::integral_constant<int, 2 * NHT>{},
+        [&]() {
+          if (role == 0 && rq < NP) issue(rq, rslot);
+          advance();
+        },
+        [&](auto fc, const frag& fr) {
+          constexpr int f = decltype(fc)::value, c = 2 * qq + f / NHT, i = f % NHT;
+#pragma unroll
+          for (int j = 0; j < TM; ++j) {
+            if constexpr (c < NCH / 2) acc[i][j] = Mma<T>::mma(fr, xo[c][j], acc[i][j]);
+            else acc[i][j] = Mma<T>::mma(fr, xp[c - NCH / 2][j], acc[i][j]);
+          }
+          if constexpr (f == NHT - 1) {
+            if (role == 1 && rq < NP) issue(rq, rslot);
+          }
+        });
+  });
+  mfma_results_settle();
+  sec[1] = now();
 
   // ---- LayerNorm(x) over all 384 features -> xb; the stage-a output bias joins the residual ----
   {
