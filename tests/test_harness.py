@@ -282,7 +282,7 @@ def test_writer_processes_encode_from_the_shared_ring(tmp_path):
     assert pipeline._WRITERS is None
     was = util.PNG_COMPRESS_LEVEL
     try:
-        opt = TestOptions().parse(['--dataroot', str(tmp_path), '--name', 'x', '--gpu_ids', '-1', '--png_compress_level', '1'])
+        opt = TestOptions().parse(['--dataroot', str(tmp_path), '--name', 'x', '--gpu_ids', '-1', '--png_compress_level', '1', '--checkpoints_dir', str(tmp_path / 'ckpt')])
         assert opt.png_compress_level == 1 and util.PNG_COMPRESS_LEVEL == 1
         smooth = np.tile(np.arange(64, dtype=np.uint8)[None, :, None], (64, 1, 3))
         util.save_image(smooth, str(tmp_path / "l1.png"))
